@@ -1,0 +1,38 @@
+# Builds everything in-tree for gfx950 (MI355X):
+#   polypolish_amd/_build/libpolypolish_hip.so   the product: HIP kernels + C ABI + host ingest
+#   bin/polypolish                               the drop-in CLI (links the library)
+#   oracle/_build/*                              the CPU oracle (test infrastructure only)
+# -ffp-contract=off: the vote's banker's rounding must see the unfused product depth*fraction.
+HIPCC    ?= hipcc
+ARCH     ?= gfx950
+CSRC     := polypolish_amd/csrc
+OUT      := polypolish_amd/_build
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+
+LIB  := $(OUT)/libpolypolish_hip.so
+OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o
+
+all: $(LIB) bin/polypolish oracle
+
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_internal.h include/polypolish_hip.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/%.o: $(CSRC)/%.cpp include/polypolish_hip.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -x c++ -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
+
+bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
+	@mkdir -p bin
+	$(HIPCC) -O2 -std=c++17 -Iinclude -x c++ $(CSRC)/pp_cli.cpp -x none -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(OUT) bin oracle/_build
+
+.PHONY: all oracle clean

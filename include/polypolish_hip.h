@@ -1,0 +1,254 @@
+/*
+ * polypolish_hip.h -- C ABI of libpolypolish_hip.so, the MI355X (gfx950) implementation of
+ * Polypolish's alignment-filter + per-base pileup/vote hot path.
+ *
+ * The reference (rrwick/Polypolish v0.6.1, Rust) has no FFI of its own; these entry points sit
+ * at the two seams where its drivers call into the hot path, and take exactly what those calls
+ * take, as structure-of-arrays in SAM file order (citations are file:line into the reference):
+ *
+ *   seam B (polish): process_one_read -> pileup.add_alignment(a, depth_contribution)
+ *                    (src/alignment.rs:297-303) and polish_one_sequence -> get_polished_seq
+ *                    (src/polish.rs:170-187)              => pp_polish_begin / _add / _finish
+ *   seam A (filter): filter_sam -> alignment_pass_qc (src/filter.rs:334) and the sampling loop of
+ *                    get_insert_size_thresholds (src/filter.rs:155-167)
+ *                                                         => pp_filter_samples / pp_filter_pairs
+ *
+ * plus the host-side ingest (FASTA/SAM text -> the SoA above; src/misc.rs:38-167,
+ * src/alignment.rs:49-128,225-322) that the `polypolish` CLI and any binding share.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns PP_OK or a
+ * PP_ERR_* code and never exits the process; pp_last_error() holds the message the reference
+ * would have printed after "Error: ".  A pp_ctx is bound to one HIP device and one stream and is
+ * not thread-safe; distinct contexts are independent.  There is no CPU fallback: without a
+ * usable gfx950 device pp_ctx_create fails with PP_ERR_HIP.
+ */
+#ifndef POLYPOLISH_HIP_H
+#define POLYPOLISH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define PP_OK 0
+#define PP_ERR_QUIT 1    /* the reference would quit_with_error (src/misc.rs:29-33): exit code 1 */
+#define PP_ERR_HIP 3     /* HIP runtime failure, or no usable device                             */
+#define PP_ERR_ARG 4     /* the caller broke this header's contract                               */
+#define PP_ERR_LIMIT 5   /* input exceeds a documented implementation limit                       */
+#define PP_ERR_PANIC 101 /* the reference would panic (unwrap / index out of bounds): exit 101    */
+
+#define PP_MEM_HOST 0   /* pointer is host memory: the library copies it to the device             */
+#define PP_MEM_DEVICE 1 /* pointer is device memory on the context's device: borrowed, not copied  */
+
+/* CIGAR runs are packed (length << 4) | op with these op codes (SAM order). */
+enum { PP_OP_M = 0, PP_OP_I = 1, PP_OP_D = 2, PP_OP_N = 3, PP_OP_S = 4, PP_OP_H = 5, PP_OP_P = 6,
+       PP_OP_EQ = 7, PP_OP_X = 8 };
+
+/* BaseStatus (src/pileup.rs:18-25) in the order of its debug strings (src/pileup.rs:156-163). */
+enum { PP_ST_KEPT = 0, PP_ST_CHANGED = 1, PP_ST_LOW_DEPTH = 2, PP_ST_NONE = 3, PP_ST_MULTIPLE = 4,
+       PP_ST_TOO_CLOSE = 5 };
+
+typedef struct pp_ctx pp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int pp_ctx_create(int device, pp_ctx **out);
+void pp_ctx_destroy(pp_ctx *ctx);
+const char *pp_last_error(const pp_ctx *ctx);
+int pp_ctx_sync(pp_ctx *ctx);          /* hipStreamSynchronize on the context's stream          */
+void *pp_ctx_stream(pp_ctx *ctx);      /* the hipStream_t every kernel of this context runs on  */
+const char *pp_version(void);          /* "polypolish-mi355x <ver> (parity target v0.6.1)"       */
+
+/* ---- seam B: pileup accumulate + per-position vote ------------------------------------------ */
+typedef struct {
+    uint32_t min_depth;      /* -d, src/main.rs:97-99   */
+    double fraction_valid;   /* -v, src/main.rs:89-91   */
+    double fraction_invalid; /* -i, src/main.rs:85-87   */
+} pp_params;
+
+/* One batch of GOOD alignments (the gates of process_one_read, src/alignment.rs:282-287, already
+ * applied; SEQ "*" already filled, src/alignment.rs:290-295), in global SAM order: array index i
+ * is the order in which the reference would call add_alignment.  Contract per record:
+ *   contig     index into the assembly's contigs (FASTA order)
+ *   ref_start  0-based leftmost reference position (POS-1; src/alignment.rs:58-61)
+ *   k          number of good alignments of the read (depth contribution is 1.0/k, :288), >= 1
+ *   seq        SEQ bytes after to_ascii_uppercase (src/alignment.rs:94), seq_len[i] of them at
+ *              seq + seq_off[i]
+ *   cigar      n_cig[i] packed runs at cigar + cig_off[i]; every run length >= 1; first and last
+ *              run M or '=' (starts_and_ends_with_match, src/alignment.rs:155-159)
+ * The device validates all of it (runs other than M,=,X,I,D; CIGAR/SEQ length mismatch; reads
+ * running past the contig end) and reports the FIRST offending record in file order, as the
+ * reference would. */
+typedef struct {
+    uint64_t n_aln;
+    const uint32_t *contig;
+    const uint32_t *ref_start;
+    const uint32_t *k;
+    const uint64_t *seq_off;
+    const uint32_t *seq_len;
+    const uint64_t *cig_off;
+    const uint32_t *n_cig;
+    const uint8_t *seq;
+    uint64_t seq_bytes;
+    const uint32_t *cigar;
+    uint64_t n_cig_total;
+} pp_aln_batch;
+
+/* Per-contig figures the reference prints to stderr (src/polish.rs:206-227). */
+typedef struct {
+    uint64_t polished_len;     /* bytes of the polished sequence                      */
+    uint64_t changed;          /* positions with status Changed                       */
+    uint64_t zero_depth;       /* positions with depth == 0.0                         */
+    double depth_sum;          /* sum of per-position depth (cosmetic: mean depth)    */
+} pp_contig_stats;
+
+/* Start a polish job.  contig_off is a HOST array of n_contigs+1 offsets into `bases` (the
+ * concatenated, ASCII-uppercased assembly, src/misc.rs:114,129; total length < 2^32-4096). */
+int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,
+                    const uint8_t *bases, int bases_mem, const pp_params *params);
+/* Provide the alignments (one batch per job in this version; `mem` applies to every pointer in
+ * the batch).  PP_MEM_DEVICE batches are borrowed until pp_polish_finish returns. */
+int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *batch, int mem);
+/* Run the kernels: CIGAR walk + homopolymer trim (src/alignment.rs:175-201,364-378), pileup
+ * accumulation (src/pileup.rs:56-65,189-200), vote (src/pileup.rs:67-134), '-' removal and
+ * concatenation (src/polish.rs:185-188).  Results stay on the device until fetched. */
+int pp_polish_finish(pp_ctx *ctx);
+/* Total polished bytes over all contigs (no headers, no newlines). */
+int pp_polish_result_size(pp_ctx *ctx, uint64_t *total_bytes);
+/* Copy the polished bytes to `out` (host or device, >= result_size bytes); contig c occupies
+ * [contig_out_off[c], contig_out_off[c+1]).  contig_out_off (HOST, n_contigs+1) and stats (HOST,
+ * n_contigs) may be NULL. */
+int pp_polish_result(pp_ctx *ctx, uint8_t *out, int out_mem, uint64_t *contig_out_off,
+                     pp_contig_stats *stats);
+/* Device pointer to the polished bytes (valid until the next pp_polish_begin). */
+const uint8_t *pp_polish_result_device(pp_ctx *ctx);
+
+/* Optional per-position record (what the --debug TSV is made of, src/pileup.rs:150-166):
+ * enable before pp_polish_finish, fetch after.  Arrays are HOST, one element per assembly
+ * position in concatenated order; any pointer may be NULL. */
+typedef struct {
+    double *depth;
+    uint32_t *count_a, *count_c, *count_g, *count_t;
+    uint32_t *count_other;  /* sum over the string-keyed table, deletions ("-") included */
+    uint32_t *valid_thr, *invalid_thr;
+    uint8_t *status;        /* PP_ST_* */
+} pp_positions;
+int pp_polish_set_debug(pp_ctx *ctx, int enable);
+int pp_polish_positions(pp_ctx *ctx, const pp_positions *out);
+
+/* Per-kernel device time of the last pp_polish_finish, measured with HIP events on the context's
+ * stream when profiling is enabled.  names[i] are static strings. */
+#define PP_MAX_KERNELS 16
+typedef struct {
+    int n;
+    const char *name[PP_MAX_KERNELS];
+    float ms[PP_MAX_KERNELS];
+    uint64_t n_entries;   /* (alignment, window) work items the tile kernel consumed */
+    uint64_t n_flagged;   /* positions resolved by the exact (string-keyed, ordered-f64) kernel */
+} pp_kernel_times;
+int pp_ctx_set_profiling(pp_ctx *ctx, int enable);
+int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
+
+/* ---- seam A: paired-read insert-size filter --------------------------------------------------
+ * Alignments of both SAM files as SoA in file order (Alignment::new_quick, src/alignment.rs:
+ * 102-128), plus the read-name grouping the reference builds in its HashMap (src/filter.rs:
+ * 91-145): reads are numbered 0..n_reads-1; for file f, the alignments of read r are
+ * grp_idx[f][grp_off[f][r] .. grp_off[f][r+1]) (indices into file f's arrays, file order). */
+typedef struct {
+    uint64_t n_aln;
+    const uint32_t *ref_id;     /* RNAME interned to an integer (equal names <=> equal ids) */
+    const uint32_t *ref_start;  /* POS-1 */
+    const uint32_t *flags;      /* FLAG */
+    const uint64_t *cig_off;
+    const uint32_t *n_cig;
+    const uint32_t *cigar;      /* packed runs; ops outside MIDNSHP=X never appear (regex) */
+    uint64_t n_cig_total;
+    const uint32_t *read;       /* read number of each alignment */
+    const uint32_t *grp_off;    /* n_reads+1 */
+    const uint32_t *grp_idx;    /* n_aln */
+} pp_filter_file;
+
+typedef struct {
+    uint32_t n_reads;
+    pp_filter_file file[2];
+} pp_filter_input;
+
+/* Upload (or adopt) the input and compute ref_end for every alignment on the device
+ * (Alignment::get_ref_end, src/alignment.rs:138-149). */
+int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem);
+/* For every read with exactly one alignment in each file on the same reference
+ * (src/filter.rs:155-167): orientation (0 fr, 1 rf, 2 ff, 3 rr; get_orientation,
+ * src/filter.rs:189-209) and insert size (src/filter.rs:212-218).  orient[r] = 255 for reads that
+ * are not sampled.  HOST arrays of n_reads. */
+int pp_filter_samples(pp_ctx *ctx, uint8_t *orient, uint32_t *insert);
+/* alignment_pass_qc (src/filter.rs:352-377) for every alignment of both files; pass1/pass2 are
+ * HOST arrays (1 = pass, 0 = append ZP:Z:fail). */
+int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t orientation,
+                    uint8_t *pass1, uint8_t *pass2);
+int pp_filter_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
+
+/* ---- host ingest (text -> SoA) -------------------------------------------------------------- */
+typedef struct pp_assembly pp_assembly;
+/* load_fasta + check_load_fasta (src/misc.rs:38-75): plain or gzip, uppercased. */
+int pp_assembly_load(const char *path, pp_assembly **out, char *err, size_t errlen);
+void pp_assembly_free(pp_assembly *a);
+uint32_t pp_assembly_n_contigs(const pp_assembly *a);
+const char *pp_assembly_name(const pp_assembly *a, uint32_t i);
+const char *pp_assembly_description(const pp_assembly *a, uint32_t i);
+const uint64_t *pp_assembly_offsets(const pp_assembly *a); /* n_contigs+1 */
+const uint8_t *pp_assembly_bases(const pp_assembly *a);
+
+typedef struct {
+    uint64_t alignments; /* aligned records seen            (src/alignment.rs:252) */
+    uint64_t used;       /* good alignments kept            (src/alignment.rs:304) */
+    uint64_t reads;      /* read groups                     (src/alignment.rs:260,266) */
+} pp_sam_counts;
+
+typedef struct pp_ingest pp_ingest;
+int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int careful, pp_ingest **out);
+/* add_to_pileup's streaming half (src/alignment.rs:225-272): parse, group adjacent QNAMEs, apply
+ * process_one_read's gates, append the good alignments to the batch.  Files in argv order. */
+int pp_ingest_sam(pp_ingest *g, const char *path, pp_sam_counts *counts, char *err, size_t errlen);
+void pp_ingest_batch(const pp_ingest *g, pp_aln_batch *out); /* borrowed view, host memory */
+/* QNAME of batch record i (for error messages). */
+const char *pp_ingest_read_name(const pp_ingest *g, uint64_t i);
+void pp_ingest_free(pp_ingest *g);
+
+/* ---- whole-command drivers (what bin/polypolish calls) --------------------------------------- */
+typedef struct {
+    double fraction_invalid; /* default 0.2  */
+    double fraction_valid;   /* default 0.5  */
+    uint32_t max_errors;     /* default 10   */
+    uint32_t min_depth;      /* default 5    */
+    int careful;
+    const char *debug_path;  /* NULL = no --debug file */
+    int quiet;               /* suppress the stderr log */
+} pp_polish_options;
+
+typedef struct {
+    uint8_t *data; /* malloc'd by the library, release with pp_bytes_free */
+    uint64_t len;
+} pp_bytes;
+void pp_bytes_free(pp_bytes *b);
+
+/* polish::polish (src/polish.rs:26-38): FASTA text exactly as the reference prints to stdout. */
+int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
+                    const pp_polish_options *opt, pp_bytes *fasta);
+
+typedef struct {
+    uint64_t before_count, after_count;
+    uint32_t low_threshold, high_threshold;
+    int orientation; /* 0 fr 1 rf 2 ff 3 rr */
+    uint64_t orientation_counts[4];
+} pp_filter_report;
+/* filter::filter (src/filter.rs:26-37). */
+int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, const char *out1,
+                    const char *out2, const char *orientation, double low, double high, int quiet,
+                    pp_filter_report *report);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,361 @@
+"""polypolish_amd -- Python face of libpolypolish_hip.so (MI355X / gfx950).
+
+The product is the C-ABI library (include/polypolish_hip.h) and the ``bin/polypolish`` CLI; this
+package is a thin ctypes binding used by the tests, bench.py and anyone who wants to call the
+hot path from Python.  It mirrors the reference's two drivers by name and argument meaning:
+
+    polish(assembly, sam, ...)            <->  polish::polish  (src/polish.rs:26-38)
+    filter(in1, in2, out1, out2, ...)     <->  filter::filter  (src/filter.rs:26-37)
+
+There is no CPU fallback: importing works anywhere the shared library loads, but every compute
+call needs a HIP device and raises ``PolypolishError`` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "_build", "libpolypolish_hip.so")
+
+OK, ERR_QUIT, ERR_HIP, ERR_ARG, ERR_LIMIT, ERR_PANIC = 0, 1, 3, 4, 5, 101
+MEM_HOST, MEM_DEVICE = 0, 1
+STATUS = ("kept", "changed", "low_depth", "none", "multiple", "too_close")
+OPS = "MIDNSHP=X"
+
+
+class PolypolishError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code, self.msg = code, msg
+
+
+class Params(C.Structure):
+    _fields_ = [("min_depth", C.c_uint32), ("fraction_valid", C.c_double), ("fraction_invalid", C.c_double)]
+
+
+class AlnBatch(C.Structure):
+    _fields_ = [("n_aln", C.c_uint64), ("contig", C.c_void_p), ("ref_start", C.c_void_p), ("k", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq_len", C.c_void_p), ("cig_off", C.c_void_p), ("n_cig", C.c_void_p),
+                ("seq", C.c_void_p), ("seq_bytes", C.c_uint64), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64)]
+
+
+class ContigStats(C.Structure):
+    _fields_ = [("polished_len", C.c_uint64), ("changed", C.c_uint64), ("zero_depth", C.c_uint64),
+                ("depth_sum", C.c_double)]
+
+
+class PositionsOut(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("count_a", C.c_void_p), ("count_c", C.c_void_p), ("count_g", C.c_void_p),
+                ("count_t", C.c_void_p), ("count_other", C.c_void_p), ("valid_thr", C.c_void_p),
+                ("invalid_thr", C.c_void_p), ("status", C.c_void_p)]
+
+
+PP_MAX_KERNELS = 16
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("n", C.c_int), ("name", C.c_char_p * PP_MAX_KERNELS), ("ms", C.c_float * PP_MAX_KERNELS),
+                ("n_entries", C.c_uint64), ("n_flagged", C.c_uint64)]
+
+    def as_dict(self):
+        d = {self.name[i].decode(): float(self.ms[i]) for i in range(self.n)}
+        return {"ms": d, "n_entries": int(self.n_entries), "n_flagged": int(self.n_flagged)}
+
+
+class SamCounts(C.Structure):
+    _fields_ = [("alignments", C.c_uint64), ("used", C.c_uint64), ("reads", C.c_uint64)]
+
+
+class PolishOptions(C.Structure):
+    _fields_ = [("fraction_invalid", C.c_double), ("fraction_valid", C.c_double), ("max_errors", C.c_uint32),
+                ("min_depth", C.c_uint32), ("careful", C.c_int), ("debug_path", C.c_char_p), ("quiet", C.c_int)]
+
+
+class Bytes(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+class FilterReport(C.Structure):
+    _fields_ = [("before_count", C.c_uint64), ("after_count", C.c_uint64), ("low_threshold", C.c_uint32),
+                ("high_threshold", C.c_uint32), ("orientation", C.c_int), ("orientation_counts", C.c_uint64 * 4)]
+
+
+class FilterFile(C.Structure):
+    _fields_ = [("n_aln", C.c_uint64), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p), ("flags", C.c_void_p),
+                ("cig_off", C.c_void_p), ("n_cig", C.c_void_p), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64),
+                ("read", C.c_void_p), ("grp_off", C.c_void_p), ("grp_idx", C.c_void_p)]
+
+
+class FilterInput(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("file", FilterFile * 2)]
+
+
+# every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
+EXPORTS = [
+    "pp_ctx_create", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
+    "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
+    "pp_polish_result_device", "pp_polish_set_debug", "pp_polish_positions", "pp_ctx_set_profiling",
+    "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
+    "pp_filter_kernel_times", "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
+    "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
+    "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
+    "pp_bytes_free", "pp_polish_files", "pp_filter_files",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fails loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+                              "polypolish_amd has no pure-Python or CPU path")
+        L = C.CDLL(LIB_PATH)
+        vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+        L.pp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.pp_ctx_destroy.argtypes = [vp]
+        L.pp_ctx_destroy.restype = None
+        L.pp_last_error.argtypes = [vp]
+        L.pp_last_error.restype = C.c_char_p
+        L.pp_ctx_sync.argtypes = [vp]
+        L.pp_ctx_stream.argtypes = [vp]
+        L.pp_ctx_stream.restype = vp
+        L.pp_version.restype = C.c_char_p
+        L.pp_polish_begin.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.POINTER(Params)]
+        L.pp_polish_add.argtypes = [vp, C.POINTER(AlnBatch), C.c_int]
+        L.pp_polish_finish.argtypes = [vp]
+        L.pp_polish_result_size.argtypes = [vp, u64p]
+        L.pp_polish_result.argtypes = [vp, vp, C.c_int, vp, vp]
+        L.pp_polish_result_device.argtypes = [vp]
+        L.pp_polish_result_device.restype = vp
+        L.pp_polish_set_debug.argtypes = [vp, C.c_int]
+        L.pp_polish_positions.argtypes = [vp, C.POINTER(PositionsOut)]
+        L.pp_ctx_set_profiling.argtypes = [vp, C.c_int]
+        L.pp_polish_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.pp_filter_begin.argtypes = [vp, C.POINTER(FilterInput), C.c_int]
+        L.pp_filter_samples.argtypes = [vp, vp, vp]
+        L.pp_filter_pairs.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint8, vp, vp]
+        L.pp_filter_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.pp_assembly_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.pp_assembly_free.argtypes = [vp]
+        L.pp_assembly_free.restype = None
+        L.pp_assembly_n_contigs.argtypes = [vp]
+        L.pp_assembly_n_contigs.restype = C.c_uint32
+        L.pp_assembly_name.argtypes = [vp, C.c_uint32]
+        L.pp_assembly_name.restype = C.c_char_p
+        L.pp_assembly_description.argtypes = [vp, C.c_uint32]
+        L.pp_assembly_description.restype = C.c_char_p
+        L.pp_assembly_offsets.argtypes = [vp]
+        L.pp_assembly_offsets.restype = u64p
+        L.pp_assembly_bases.argtypes = [vp]
+        L.pp_assembly_bases.restype = C.POINTER(C.c_uint8)
+        L.pp_ingest_create.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp)]
+        L.pp_ingest_sam.argtypes = [vp, C.c_char_p, C.POINTER(SamCounts), C.c_char_p, C.c_size_t]
+        L.pp_ingest_batch.argtypes = [vp, C.POINTER(AlnBatch)]
+        L.pp_ingest_batch.restype = None
+        L.pp_ingest_read_name.argtypes = [vp, C.c_uint64]
+        L.pp_ingest_read_name.restype = C.c_char_p
+        L.pp_ingest_free.argtypes = [vp]
+        L.pp_ingest_free.restype = None
+        L.pp_bytes_free.argtypes = [C.POINTER(Bytes)]
+        L.pp_bytes_free.restype = None
+        L.pp_polish_files.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(PolishOptions),
+                                      C.POINTER(Bytes)]
+        L.pp_filter_files.argtypes = [vp] + [C.c_char_p] * 5 + [C.c_double, C.c_double, C.c_int,
+                                                                C.POINTER(FilterReport)]
+        _lib = L
+    return _lib
+
+
+REC_FIELDS = (("contig", np.uint32), ("ref_start", np.uint32), ("k", np.uint32), ("seq_off", np.uint64),
+              ("seq_len", np.uint32), ("cig_off", np.uint64), ("n_cig", np.uint32), ("seq", np.uint8),
+              ("cigar", np.uint32))
+
+
+def ingest(assembly, sams, max_errors=10, careful=False):
+    """Host ingest only (no GPU needed): FASTA + SAM text -> (names, descs, contig_off, bases, recs, counts)."""
+    L = lib()
+    err = C.create_string_buffer(1024)
+    a = C.c_void_p()
+    rc = L.pp_assembly_load(str(assembly).encode(), C.byref(a), err, 1024)
+    if rc:
+        raise PolypolishError(rc, err.value.decode())
+    g = C.c_void_p()
+    try:
+        n = L.pp_assembly_n_contigs(a)
+        names = [L.pp_assembly_name(a, i).decode() for i in range(n)]
+        descs = [L.pp_assembly_description(a, i).decode() for i in range(n)]
+        off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,)).copy()
+        bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),)).copy()
+        L.pp_ingest_create(a, max_errors, int(careful), C.byref(g))
+        counts = []
+        for s in sams:
+            c = SamCounts()
+            rc = L.pp_ingest_sam(g, str(s).encode(), C.byref(c), err, 1024)
+            if rc:
+                raise PolypolishError(rc, err.value.decode())
+            counts.append((c.alignments, c.used, c.reads))
+        b = AlnBatch()
+        L.pp_ingest_batch(g, C.byref(b))
+        sizes = {"seq": b.seq_bytes, "cigar": b.n_cig_total}
+        recs = {}
+        for name, dt in REC_FIELDS:
+            cnt = int(sizes.get(name, b.n_aln))
+            ptr = getattr(b, name)
+            if cnt and ptr:
+                arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+            else:
+                arr = np.zeros(0, dtype=dt)
+            recs[name] = arr
+        return names, descs, off, bases, recs, counts
+    finally:
+        if g:
+            L.pp_ingest_free(g)
+        L.pp_assembly_free(a)
+
+
+class Context:
+    """One HIP device + stream (pp_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().pp_ctx_create(device, C.byref(self._h))
+        if rc:
+            raise PolypolishError(rc, f"pp_ctx_create({device}) failed: no usable HIP device (there is no CPU path)")
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib().pp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise PolypolishError(rc, lib().pp_last_error(self._h).decode())
+
+    def sync(self):
+        self._chk(lib().pp_ctx_sync(self._h))
+
+    def set_profiling(self, on=True):
+        lib().pp_ctx_set_profiling(self._h, int(on))
+
+    # ---- seam B -------------------------------------------------------------------------------
+    def polish_begin(self, contig_off, bases_ptr, bases_mem, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2):
+        off = np.ascontiguousarray(contig_off, dtype=np.uint64)
+        p = Params(min_depth, fraction_valid, fraction_invalid)
+        self._n_contigs = len(off) - 1
+        self._G = int(off[-1])
+        self._chk(lib().pp_polish_begin(self._h, self._n_contigs, off.ctypes.data, bases_ptr, bases_mem, C.byref(p)))
+
+    def polish_add_ptrs(self, n_aln, ptrs: dict, seq_bytes, n_cig_total, mem):
+        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+        self._chk(lib().pp_polish_add(self._h, C.byref(b), mem))
+
+    def polish_finish(self):
+        self._chk(lib().pp_polish_finish(self._h))
+
+    def result_size(self):
+        n = C.c_uint64()
+        self._chk(lib().pp_polish_result_size(self._h, C.byref(n)))
+        return n.value
+
+    def result_device_ptr(self):
+        return lib().pp_polish_result_device(self._h)
+
+    def result(self):
+        n = self.result_size()
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        offs = np.zeros(self._n_contigs + 1, dtype=np.uint64)
+        stats = (ContigStats * self._n_contigs)()
+        self._chk(lib().pp_polish_result(self._h, out.ctypes.data, MEM_HOST, offs.ctypes.data, stats))
+        st = [dict(polished_len=s.polished_len, changed=s.changed, zero_depth=s.zero_depth, depth_sum=s.depth_sum)
+              for s in stats]
+        return out[:n].tobytes(), offs, st
+
+    def kernel_times(self):
+        kt = KernelTimes()
+        lib().pp_polish_kernel_times(self._h, C.byref(kt))
+        return kt.as_dict()
+
+    def positions(self):
+        G = self._G
+        arrs = {"depth": np.zeros(G, np.float64), "status": np.zeros(G, np.uint8)}
+        for k in ("count_a", "count_c", "count_g", "count_t", "count_other", "valid_thr", "invalid_thr"):
+            arrs[k] = np.zeros(G, np.uint32)
+        po = PositionsOut(*[arrs[k].ctypes.data for k in ("depth", "count_a", "count_c", "count_g", "count_t",
+                                                          "count_other", "valid_thr", "invalid_thr", "status")])
+        self._chk(lib().pp_polish_positions(self._h, C.byref(po)))
+        return arrs
+
+    def polish_records(self, contig_off, bases, recs, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2,
+                       positions=False):
+        """Host numpy SoA (field names of pp_aln_batch) -> polished bytes, offsets, stats."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
+        lib().pp_polish_set_debug(self._h, int(positions))
+        self.polish_begin(contig_off, bases.ctypes.data, MEM_HOST, min_depth, fraction_valid, fraction_invalid)
+        self.polish_add_ptrs(len(keep["contig"]), {k: v.ctypes.data for k, v in keep.items()}, len(keep["seq"]),
+                             len(keep["cigar"]), MEM_HOST)
+        self.polish_finish()
+        polished, offs, stats = self.result()
+        res = {"polished": polished, "offsets": offs, "stats": stats, "positions": None}
+        if positions:
+            res["positions"] = self.positions()
+        lib().pp_polish_set_debug(self._h, 0)
+        return res
+
+    # ---- whole commands -----------------------------------------------------------------------
+    def polish_files(self, assembly, sams, fraction_invalid=0.2, fraction_valid=0.5, max_errors=10, min_depth=5,
+                     careful=False, debug=None, quiet=True):
+        opt = PolishOptions(fraction_invalid, fraction_valid, max_errors, min_depth, int(careful),
+                            str(debug).encode() if debug else None, int(quiet))
+        arr = (C.c_char_p * max(len(sams), 1))(*[str(s).encode() for s in sams])
+        out = Bytes()
+        self._chk(lib().pp_polish_files(self._h, str(assembly).encode(), arr, len(sams), C.byref(opt), C.byref(out)))
+        data = C.string_at(out.data, out.len) if out.len else b""
+        lib().pp_bytes_free(C.byref(out))
+        return data
+
+    def filter_files(self, in1, in2, out1, out2, orientation="auto", low=0.1, high=99.9, quiet=True):
+        rep = FilterReport()
+        self._chk(lib().pp_filter_files(self._h, str(in1).encode(), str(in2).encode(), str(out1).encode(),
+                                        str(out2).encode(), orientation.encode(), low, high, int(quiet),
+                                        C.byref(rep)))
+        return {"before": rep.before_count, "after": rep.after_count, "low": rep.low_threshold,
+                "high": rep.high_threshold, "orientation": ("fr", "rf", "ff", "rr")[rep.orientation],
+                "counts": list(rep.orientation_counts)}
+
+
+_default_ctx = None
+
+
+def _ctx():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("PP_DEVICE", "0")))
+    return _default_ctx
+
+
+def polish(assembly, sam, debug=None, fraction_invalid=0.2, fraction_valid=0.5, max_errors=10, min_depth=5,
+           careful=False) -> bytes:
+    """polish::polish (src/polish.rs:26-38): returns the FASTA bytes the reference prints to stdout."""
+    return _ctx().polish_files(assembly, list(sam), fraction_invalid, fraction_valid, max_errors, min_depth, careful,
+                               debug)
+
+
+def filter(in1, in2, out1, out2, orientation="auto", low=0.1, high=99.9):  # noqa: A001 (reference name)
+    """filter::filter (src/filter.rs:26-37): writes out1/out2, returns the before/after report."""
+    return _ctx().filter_files(in1, in2, out1, out2, orientation, low, high)

@@ -1,0 +1,189 @@
+// pp_cli.cpp -- `polypolish`, a drop-in for the reference binary's command line
+// (src/main.rs:23-126): same subcommands, flag names, short flags, defaults, stdout/stderr split
+// and exit codes (0 ok, 1 "Error: ...", 2 usage, 101 where the reference would panic).
+// All work happens in libpolypolish_hip.so on an MI355X; there is no CPU path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "polypolish_hip.h"
+
+static const char *HELP =
+    "Polypolish (MI355X/gfx950 implementation, parity target v0.6.1)\n"
+    "short-read polishing of long-read assemblies\n\n"
+    "Usage: polypolish <COMMAND>\n\n"
+    "Commands:\n"
+    "  filter  filter paired-end alignments based on insert size\n"
+    "  polish  polish a long-read assembly using short-read alignments\n\n"
+    "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n";
+
+static const char *HELP_FILTER =
+    "filter paired-end alignments based on insert size\n\n"
+    "Usage: polypolish filter [OPTIONS] --in1 <IN1> --in2 <IN2> --out1 <OUT1> --out2 <OUT2>\n\n"
+    "Options:\n"
+    "      --in1 <IN1>                  Input SAM file - first read in pairs\n"
+    "      --in2 <IN2>                  Input SAM file - first second in pairs\n"
+    "      --out1 <OUT1>                Output SAM file - first read in pairs\n"
+    "      --out2 <OUT2>                Output SAM file - first second in pairs\n"
+    "      --orientation <ORIENTATION>  Expected pair orientation [default: auto]\n"
+    "      --low <LOW>                  Low percentile threshold [default: 0.1]\n"
+    "      --high <HIGH>                High percentile threshold [default: 99.9]\n"
+    "  -h, --help                       Print help\n  -V, --version                    Print version\n";
+
+static const char *HELP_POLISH =
+    "polish a long-read assembly using short-read alignments\n\n"
+    "Usage: polypolish polish [OPTIONS] <ASSEMBLY> [SAM]...\n\n"
+    "Arguments:\n  <ASSEMBLY>  Assembly to polish (one file in FASTA format)\n"
+    "  [SAM]...    Short read alignments (one or more files in SAM format)\n\n"
+    "Options:\n"
+    "      --debug <DEBUG>                        Optional file to store per-base information for debugging purposes\n"
+    "  -i, --fraction_invalid <FRACTION_INVALID>  A base must make up less than this fraction of the read depth to be considered invalid [default: 0.2]\n"
+    "  -v, --fraction_valid <FRACTION_VALID>      A base must make up at least this fraction of the read depth to be considered valid [default: 0.5]\n"
+    "  -m, --max_errors <MAX_ERRORS>              Ignore alignments with more than this many mismatches and indels [default: 10]\n"
+    "  -d, --min_depth <MIN_DEPTH>                A base must occur at least this many times in the pileup to be considered valid [default: 5]\n"
+    "      --careful                              Ignore any reads with multiple alignments\n"
+    "  -h, --help                                 Print help\n  -V, --version                              Print version\n";
+
+static int usage_error(const char *msg) {
+    fprintf(stderr, "error: %s\n\nFor more information, try '--help'.\n", msg);
+    return 2;
+}
+
+static bool parse_f64(const char *s, double &v) {
+    char *e = nullptr;
+    v = strtod(s, &e);
+    return e && *e == 0 && e != s;
+}
+static bool parse_u32(const char *s, uint32_t &v) {
+    if (!*s) return false;
+    char *e = nullptr;
+    if (*s == '-') return false;
+    unsigned long long x = strtoull(s, &e, 10);
+    if (!e || *e != 0 || x > 0xFFFFFFFFull) return false;
+    v = (uint32_t)x;
+    return true;
+}
+
+// returns the value of `--name value` / `--name=value` / `-x value`; advances i
+static const char *opt_value(int argc, char **argv, int &i, const char *arg, const char *long_name, const char *short_name) {
+    size_t ln = strlen(long_name);
+    if (strncmp(arg, long_name, ln) == 0 && arg[ln] == '=') return arg + ln + 1;
+    if (strcmp(arg, long_name) == 0 || (short_name && strcmp(arg, short_name) == 0)) {
+        if (i + 1 >= argc) return nullptr;
+        return argv[++i];
+    }
+    return nullptr;
+}
+static bool is_opt(const char *arg, const char *long_name, const char *short_name) {
+    size_t ln = strlen(long_name);
+    return strcmp(arg, long_name) == 0 || (strncmp(arg, long_name, ln) == 0 && arg[ln] == '=') ||
+           (short_name && strcmp(arg, short_name) == 0);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fputs(HELP, stderr);
+        return 2;
+    }
+    std::string cmd = argv[1];
+    if (cmd == "-h" || cmd == "--help") { fputs(HELP, stdout); return 0; }
+    if (cmd == "-V" || cmd == "--version") { printf("Polypolish v0.6.1 (%s)\n", pp_version()); return 0; }
+    int device = getenv("PP_DEVICE") ? atoi(getenv("PP_DEVICE")) : 0;
+
+    if (cmd == "polish") {
+        pp_polish_options opt{0.2, 0.5, 10, 5, 0, nullptr, 0};
+        const char *assembly = nullptr;
+        std::vector<const char *> sams;
+        for (int i = 2; i < argc; i++) {
+            const char *a = argv[i];
+            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_POLISH, stdout); return 0; }
+            if (!strcmp(a, "-V") || !strcmp(a, "--version")) { printf("polypolish-polish v0.6.1\n"); return 0; }
+            if (!strcmp(a, "--careful")) { opt.careful = 1; continue; }
+            if (is_opt(a, "--debug", nullptr)) {
+                const char *v = opt_value(argc, argv, i, a, "--debug", nullptr);
+                if (!v) return usage_error("a value is required for '--debug <DEBUG>' but none was supplied");
+                opt.debug_path = v;
+                continue;
+            }
+            struct { const char *l, *s; int kind; void *dst; } table[] = {
+                {"--fraction_invalid", "-i", 0, &opt.fraction_invalid}, {"--fraction_valid", "-v", 0, &opt.fraction_valid},
+                {"--max_errors", "-m", 1, &opt.max_errors}, {"--min_depth", "-d", 1, &opt.min_depth}};
+            bool matched = false;
+            for (auto &t : table) {
+                if (!is_opt(a, t.l, t.s)) continue;
+                const char *v = opt_value(argc, argv, i, a, t.l, t.s);
+                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
+                bool ok = t.kind == 0 ? parse_f64(v, *(double *)t.dst) : parse_u32(v, *(uint32_t *)t.dst);
+                if (!ok) return usage_error((std::string("invalid value '") + v + "' for '" + t.l + "'").c_str());
+                matched = true;
+                break;
+            }
+            if (matched) continue;
+            if (a[0] == '-' && a[1] != 0) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
+            if (!assembly) assembly = a; else sams.push_back(a);
+        }
+        if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
+        pp_ctx *ctx = nullptr;
+        int rc = pp_ctx_create(device, &ctx);
+        if (rc) {
+            fprintf(stderr, "\nError: no usable MI355X (HIP) device %d -- this build has no CPU path\n", device);
+            return 1;
+        }
+        pp_bytes fasta{nullptr, 0};
+        rc = pp_polish_files(ctx, assembly, sams.data(), (int)sams.size(), &opt, &fasta);
+        if (rc) {
+            fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
+            pp_ctx_destroy(ctx);
+            return rc == PP_ERR_PANIC ? 101 : 1;
+        }
+        fwrite(fasta.data, 1, fasta.len, stdout);
+        fflush(stdout);
+        pp_bytes_free(&fasta);
+        pp_ctx_destroy(ctx);
+        return 0;
+    }
+
+    if (cmd == "filter") {
+        const char *in1 = nullptr, *in2 = nullptr, *out1 = nullptr, *out2 = nullptr, *orientation = "auto";
+        double low = 0.1, high = 99.9;
+        for (int i = 2; i < argc; i++) {
+            const char *a = argv[i];
+            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_FILTER, stdout); return 0; }
+            if (!strcmp(a, "-V") || !strcmp(a, "--version")) { printf("polypolish-filter v0.6.1\n"); return 0; }
+            struct { const char *l; const char **dst; } paths[] = {{"--in1", &in1}, {"--in2", &in2}, {"--out1", &out1},
+                                                                  {"--out2", &out2}, {"--orientation", &orientation}};
+            bool matched = false;
+            for (auto &t : paths) {
+                if (!is_opt(a, t.l, nullptr)) continue;
+                const char *v = opt_value(argc, argv, i, a, t.l, nullptr);
+                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
+                *t.dst = v;
+                matched = true;
+                break;
+            }
+            if (matched) continue;
+            if (is_opt(a, "--low", nullptr) || is_opt(a, "--high", nullptr)) {
+                bool is_low = is_opt(a, "--low", nullptr);
+                const char *v = opt_value(argc, argv, i, a, is_low ? "--low" : "--high", nullptr);
+                if (!v || !parse_f64(v, is_low ? low : high)) return usage_error("invalid value for '--low/--high'");
+                continue;
+            }
+            return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
+        }
+        if (!in1 || !in2 || !out1 || !out2)
+            return usage_error("the following required arguments were not provided:\n  --in1 <IN1> --in2 <IN2> --out1 <OUT1> --out2 <OUT2>");
+        pp_ctx *ctx = nullptr;
+        int rc = pp_ctx_create(device, &ctx);
+        if (rc) {
+            fprintf(stderr, "\nError: no usable MI355X (HIP) device %d -- this build has no CPU path\n", device);
+            return 1;
+        }
+        rc = pp_filter_files(ctx, in1, in2, out1, out2, orientation, low, high, 0, nullptr);
+        if (rc) fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
+        pp_ctx_destroy(ctx);
+        return rc == 0 ? 0 : (rc == PP_ERR_PANIC ? 101 : 1);
+    }
+    return usage_error((std::string("unrecognized subcommand '") + cmd + "'").c_str());
+}

@@ -1,0 +1,124 @@
+// pp_internal.h -- shared between the translation units of libpolypolish_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "polypolish_hip.h"
+
+namespace pp {
+
+// ---- geometry of the pileup tile kernel ----------------------------------------------------
+constexpr int TILE = 2048;           // assembly positions owned by one workgroup ("window")
+constexpr int TILE_THREADS = 1024;   // 16 waves; two workgroups per CU (57 KiB LDS each)
+constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the bucketing kernels
+constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
+constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
+
+// entry flags (entA.y bits 24..31)
+constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs
+constexpr uint32_t KCLASS_NONDYADIC = 255u;
+
+// device-side error codes, packed as (record index << 8 | code) and combined with atomicMin so
+// that the first offending record in file order wins, as in the reference's streaming loop
+enum DevErr : uint32_t {
+    DE_UNEXPECTED_OP = 1,   // alignment.rs:188-193 quit
+    DE_LEN_MISMATCH = 2,    // alignment.rs:196-198 quit
+    DE_OUT_OF_BOUNDS = 3,   // pileup.rs:194-196 panic
+    DE_BAD_CONTIG = 4,      // alignment.rs:298-300 quit
+    DE_BAD_K = 5,
+    DE_BAD_RUN = 6,         // zero-length run / op code > 8 / empty CIGAR
+    DE_BAD_ENDS = 7,        // first or last run not M/=  (gate of alignment.rs:155-159 not applied)
+    DE_NON_ASCII = 8,
+    DE_INTERNAL = 9,
+    DE_TOO_DEEP = 10,
+    DE_OVERFLOW = 11,
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct KernelTimer {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+struct ContigStatsDev {  // per contig, accumulated with atomics
+    unsigned long long changed;
+    unsigned long long zero_depth;
+    unsigned long long depth_fx;  // sum of depth in 2^-DEPTH_FX_BITS units
+};
+
+}  // namespace pp
+
+struct pp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    bool debug = false;
+    std::vector<pp::KernelTimer> timers;
+    pp_kernel_times last_times{};
+
+    // ---- polish job ----
+    bool job_open = false, job_done = false;
+    uint32_t n_contigs = 0;
+    std::vector<uint64_t> contig_off;
+    uint64_t G = 0;
+    pp_params params{};
+    const uint8_t *d_bases = nullptr;  // device pointer (owned copy or borrowed)
+    pp_aln_batch dbatch{};             // device pointers
+    bool have_batch = false;
+    uint64_t total_out = 0;
+    std::vector<uint64_t> contig_out_off;
+    std::vector<pp_contig_stats> stats;
+
+    // owned device buffers (grow-only, reused across jobs)
+    pp::DevBuf b_bases, b_contig_off, b_status;
+    pp::DevBuf b_in[9];  // uploaded batch arrays
+    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB;
+    pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
+    pp::DevBuf b_multi, b_counters, b_stats, b_out, b_ctg_out;
+    pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
+
+    // ---- filter job ----
+    pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert;
+    pp_filter_input fdev{};
+    bool filter_open = false;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace pp {
+
+#define PP_HIPCHK(ctx, expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return (ctx)->fail(PP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));    \
+    } while (0)
+
+// grow-only device allocation
+int dev_ensure(pp_ctx *ctx, DevBuf &b, size_t bytes);
+void dev_free(DevBuf &b);
+// start/stop a named kernel timer on the context's stream (no-ops unless profiling)
+void timer_begin(pp_ctx *ctx, const char *name);
+void timer_end(pp_ctx *ctx);
+int timers_collect(pp_ctx *ctx, pp_kernel_times *out);
+
+}  // namespace pp

@@ -1,0 +1,1246 @@
+// pp_kernels.hip -- gfx950 kernels of the polish hot path (seam B of include/polypolish_hip.h).
+//
+// Pipeline (one pp_polish_finish):
+//   k_prep     one thread per alignment: CIGAR walk validation, reference span and the right-end
+//              homopolymer trim (alignment.rs:175-201,364-378) -> (global start, kept entries)
+//   k_count    per-block LDS histogram of (alignment, window) items   \  atomics-free multisplit
+//   k_scan_cols / k_scan   column scan over blocks + scan over windows  > of the alignments into
+//   k_fill     scatter 16-byte work items into their window's bucket   /  2048-position windows
+//   k_tile     one workgroup per window: counters for 2048 positions live in LDS, one wave per
+//              work item streams the read bases (coalesced byte loads) and does one LDS atomic per
+//              base (pileup.rs:56-65,189-200); then one lane per position votes
+//              (pileup.rs:67-134) and writes a 1-byte emit code
+//   k_exact    the rare positions whose outcome depends on string-keyed counts (insertions, N...)
+//              or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
+//              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact
+//              key grouping
+//   k_compact / k_finalize  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes
+//
+// Integer counting, HBM/LDS bound: no MFMA anywhere by design.
+#include "pp_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace pp {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, N_ROWS = 7 };
+
+struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertion won the vote)
+    u64 off;       // absolute offset of the winning string in the seq array
+    u32 pos;       // global assembly position
+    u32 len;       // raw byte length of the string
+    u32 eff;       // bytes left after removing '-' (polish.rs:188)
+    u32 pad;
+};
+
+__device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {
+    atomicMin(status, (idx << 8) | (u64)code);
+}
+
+// misc.rs:208-215 for x >= 0
+__device__ __forceinline__ u32 d_bankers(double x) {
+    u32 r = (x >= 4294967295.0) ? 0xFFFFFFFFu : (u32)x;
+    double f = x - trunc(x);
+    if (f < 0.5) return r;
+    if (f > 0.5) return r + 1u;
+    return r + (r & 1u);
+}
+
+__device__ __forceinline__ u32 kclass_of(u32 k) {
+    if (k == 1) return 0;
+    if ((k & (k - 1)) == 0) {
+        u32 j = 31u - (u32)__clz((int)k);
+        if (j <= (u32)DEPTH_FX_BITS) return j;
+    }
+    return KCLASS_NONDYADIC;
+}
+
+// counter row of one read byte: exact "A"/"C"/"G"/"T" (pileup.rs:58-61), "-" shares the
+// deletion key, everything else goes to the string-keyed table
+__device__ __forceinline__ int row_of(u32 c) {
+    u32 t = (c >> 1) & 3u;  // A->0 C->1 T->2 G->3
+    u32 expect = (0x47544341u >> (t * 8u)) & 0xFFu;
+    return (c == expect) ? (int)t : (c == (u32)'-' ? ROW_DEL : ROW_OTH);
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// =============================================================================================
+// k_prep
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
+                                              const u32 *__restrict__ ref_start,
+                                              const u32 *__restrict__ kk,
+                                              const u64 *__restrict__ seq_off,
+                                              const u32 *__restrict__ seq_len,
+                                              const u64 *__restrict__ cig_off,
+                                              const u32 *__restrict__ n_cig,
+                                              const u32 *__restrict__ cigar,
+                                              const u8 *__restrict__ seq,
+                                              const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                              u8 *__restrict__ aflag, u64 *status) {
+    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    gstart[a] = 0;
+    nkeep[a] = 0;
+    aflag[a] = 0;
+    u32 c = contig[a];
+    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); return; }
+    if (kk[a] == 0) { report(status, a, DE_BAD_K); return; }
+    u32 nc = n_cig[a];
+    u64 co = cig_off[a], so = seq_off[a];
+    u32 sl = seq_len[a];
+    if (nc == 0) { report(status, a, DE_BAD_RUN); return; }
+    const u32 *cg = cigar + co;
+
+    // walk the runs (alignment.rs:178-194): spans and validity
+    u64 ref_span = 0, read_span = 0;
+    bool indel = false;
+    for (u32 r = 0; r < nc; r++) {
+        u32 op = cg[r], len = op >> 4, o = op & 15u;
+        if (len == 0 || o > 8u) { report(status, a, DE_BAD_RUN); return; }
+        if (o == PP_OP_M || o == PP_OP_EQ || o == PP_OP_X) { ref_span += len; read_span += len; }
+        else if (o == PP_OP_I) { read_span += len; indel = true; }
+        else if (o == PP_OP_D) { ref_span += len; indel = true; }
+        else { report(status, a, DE_UNEXPECTED_OP); return; }
+    }
+    u32 o_first = cg[0] & 15u, o_last = cg[nc - 1] & 15u;
+    if (!((o_first == PP_OP_M || o_first == PP_OP_EQ) && (o_last == PP_OP_M || o_last == PP_OP_EQ))) {
+        report(status, a, DE_BAD_ENDS);
+        return;
+    }
+    if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
+    if (ref_span >= 0x7FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
+
+    // trim_bases_for_homopolymers (alignment.rs:364-378).  The last entry is the single base
+    // seq[sl-1] (the last run is M/=).  `run` = number of trailing entries equal to it.
+    const u8 *s = seq + so;
+    u8 last = s[sl - 1];
+    u32 n_entries = (u32)ref_span, run = 0;
+    if (!indel) {
+        u32 i = sl - 1;  // walk left over the trailing homopolymer
+        while (i > 0 && s[i - 1] == last) i--;
+        run = sl - i;
+    } else {
+        u64 ro = 0;
+        for (u32 r = 0; r < nc; r++) {
+            u32 op = cg[r], len = op >> 4, o = op & 15u;
+            if (o == PP_OP_I) { ro += len; continue; }
+            u32 ins = 0;  // bases inserted right after this run (they extend its last entry)
+            for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+            if (o == PP_OP_D) {
+                // len-1 empty slots, then a slot that is empty or holds the inserted bases
+                if (len > 1) run = 0;
+                if (ins == 1 && s[ro] == last) run += 1; else run = 0;
+            } else {
+                for (u32 i = 0; i < len; i++) {
+                    bool extended = (i == len - 1) && ins > 0;
+                    if (!extended && s[ro + i] == last) run += 1; else run = 0;
+                }
+                ro += len;
+            }
+        }
+    }
+    u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
+    if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
+
+    u64 clen = contig_off[c + 1] - contig_off[c];
+    u32 rs = ref_start[a];
+    if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
+    gstart[a] = (u32)(contig_off[c] + rs);
+    nkeep[a] = nk;
+    aflag[a] = indel ? (u8)ENT_COMPLEX : (u8)0;
+}
+
+// =============================================================================================
+// bucketing: count -> scan -> fill (no global atomics; LDS histograms per block and window range)
+// =============================================================================================
+__global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__restrict__ gstart,
+                                                const u32 *__restrict__ nkeep, u32 nwin,
+                                                u32 *__restrict__ hist) {
+    __shared__ u32 h[COUNT_RANGE];
+    u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
+    u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
+    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
+        u32 nk = nkeep[a];
+        if (!nk) continue;
+        u32 g = gstart[a];
+        u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
+        u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+        for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
+        hist[(u64)blockIdx.x * nwin + range_lo + i] = h[i];
+}
+
+// per window: exclusive scan of the per-block counts down the column, total to win_cnt
+__global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
+                                                   u32 *__restrict__ win_cnt, u64 *status) {
+    u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    u64 run = 0;
+    for (u32 b = 0; b < nblocks; b++) {
+        u64 ix = (u64)b * nwin + w;
+        u32 t = hist[ix];
+        hist[ix] = (u32)run;
+        run += t;
+    }
+    if (run >= (u64)MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+    win_cnt[w] = (u32)run;
+}
+
+// single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, T *__restrict__ out,
+                                               u64 *status) {
+    __shared__ u64 part[1024];
+    u32 t = threadIdx.x;
+    u64 per = (n + 1023) / 1024;
+    u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
+    u64 s = 0;
+    for (u64 i = lo; i < hi; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        u64 v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u64 run = part[t] - s;
+    for (u64 i = lo; i < hi; i++) {
+        out[i] = (T)run;
+        run += in[i];
+    }
+    if (t == 1023) {
+        out[n] = (T)part[1023];
+        if (sizeof(T) == 4 && part[1023] > 0xFFFFFFFFull) report(status, 0, DE_OVERFLOW);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
+                                               const u32 *__restrict__ nkeep,
+                                               const u8 *__restrict__ aflag,
+                                               const u32 *__restrict__ kk,
+                                               const u64 *__restrict__ seq_off, u32 nwin,
+                                               const u32 *__restrict__ hist,
+                                               const u32 *__restrict__ win_off,
+                                               uint4 *__restrict__ entA, u32 *__restrict__ entB) {
+    __shared__ u32 cur[COUNT_RANGE];
+    u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
+    u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
+    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
+        cur[i] = win_off[range_lo + i] + hist[(u64)blockIdx.x * nwin + range_lo + i];
+    __syncthreads();
+    u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
+        u32 nk = nkeep[a];
+        if (!nk) continue;
+        u32 g = gstart[a];
+        u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
+        u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+        if (wa > wb) continue;
+        u64 so = seq_off[a];
+        u32 kc = kclass_of(kk[a]);
+        u32 fl = aflag[a];
+        for (u32 w = wa; w <= wb && w >= wa; w++) {
+            u32 slot = atomicAdd(&cur[w - range_lo], 1u);
+            uint4 e;
+            e.x = (u32)so;
+            e.y = ((u32)(so >> 32) & 0xFFFFu) | (kc << 16) | (fl << 24);
+            e.z = (u32)(int)((long long)g - (long long)w * TILE);
+            e.w = nk;
+            entA[slot] = e;
+            entB[slot] = (u32)a;
+        }
+    }
+}
+
+// =============================================================================================
+// k_tile: pileup accumulate + vote for one 2048-position window
+// =============================================================================================
+struct TileArgs {
+    const uint4 *entA;
+    const u32 *entB;
+    const u32 *win_off;
+    u32 nwin;
+    const u8 *seq;
+    const u64 *seq_off;
+    const u64 *cig_off;
+    const u32 *n_cig;
+    const u32 *cigar;
+    const u8 *bases;
+    u64 G;
+    const u64 *contig_off;
+    u32 n_contigs;
+    u32 min_depth;
+    double fv, fi;
+    u8 *code;
+    u32 *win_len;
+    u32 *counters;  // [0] n_flagged, [1] n_multi
+    u32 *flag_pos;
+    u32 *flag_cov;
+    ContigStatsDev *stats;
+    double *dbg_depth;
+    u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
+    u8 *dbg_status;
+    u64 *status;
+    int dbg;
+};
+
+__device__ __forceinline__ void tile_add(u32 *cnt, int row, int p, u32 kc) {
+    atomicAdd(&cnt[row * TILE + p], 1u);
+    if (kc) {
+        if (kc == KCLASS_NONDYADIC) atomicOr(&cnt[ROW_DEF * TILE + p], 0x80000000u);
+        else atomicAdd(&cnt[ROW_DEF * TILE + p], (1u << DEPTH_FX_BITS) - (1u << (DEPTH_FX_BITS - kc)));
+    }
+}
+
+__device__ __forceinline__ u32 find_contig(const u64 *contig_off, u32 n_contigs, u64 p) {
+    u32 lo = 0, hi = n_contigs;  // contig_off[lo] <= p < contig_off[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (contig_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct VoteOut {
+    u8 out;     // byte to emit (0 = nothing)
+    u8 status;  // PP_ST_*
+    u32 vthr, ithr;
+};
+
+// pileup.rs:67-134 restricted to the keys A,C,G,T and "-"; callers guarantee that no other key
+// can reach either threshold.
+__device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, double depth,
+                                         u8 orig, u32 min_depth, double fv, double fi) {
+    VoteOut v;
+    u32 vt = d_bankers(__dmul_rn(depth, fv));
+    v.vthr = max(min_depth, vt);
+    v.ithr = d_bankers(__dmul_rn(depth, fi));
+    v.out = orig;
+    v.status = PP_ST_KEPT;
+    if (depth < (double)min_depth) {
+        v.status = PP_ST_LOW_DEPTH;
+    } else {
+        int nv = 0, ni = 0;
+        u8 win = 0;
+        if (nA >= v.vthr) { nv++; win = 'A'; } else if (nA >= v.ithr) ni++;
+        if (nC >= v.vthr) { if (!nv) win = 'C'; nv++; } else if (nC >= v.ithr) ni++;
+        if (nG >= v.vthr) { if (!nv) win = 'G'; nv++; } else if (nG >= v.ithr) ni++;
+        if (nT >= v.vthr) { if (!nv) win = 'T'; nv++; } else if (nT >= v.ithr) ni++;
+        if (nDel > 0) {
+            if (nDel >= v.vthr) { if (!nv) win = '-'; nv++; } else if (nDel >= v.ithr) ni++;
+        }
+        if (nv == 1) {
+            if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+            else { v.out = win; if (win != orig) v.status = PP_ST_CHANGED; }
+        } else if (nv == 0) {
+            v.status = PP_ST_NONE;
+        } else {
+            v.status = PP_ST_MULTIPLE;
+        }
+    }
+    if (v.out == (u8)'-') v.out = 0;  // polish.rs:188
+    return v;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
+    __shared__ u32 cnt[N_ROWS * TILE];
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1;
+    __shared__ u64 s_depth;
+
+    // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
+    u32 per = gridDim.x >> 3;
+    u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (w >= A.nwin) return;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u64 w0 = (u64)w * TILE;
+
+    for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    if (tid == 0) {
+        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0;
+        s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
+        u64 last = min(w0 + TILE, A.G) - 1;
+        s_c1 = find_contig(A.contig_off, A.n_contigs, last);
+    }
+    __syncthreads();
+
+    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    for (u32 e = e0 + wave; e < e1; e += TILE_THREADS / 64) {
+        const uint4 ent = A.entA[e];
+        const int rel = (int)ent.z, nkeep = (int)ent.w;
+        const u32 kc = (ent.y >> 16) & 0xFFu;
+        const u64 so = (u64)ent.x | ((u64)(ent.y & 0xFFFFu) << 32);
+        if (!((ent.y >> 24) & ENT_COMPLEX)) {
+            // single run of read bases: entry i is base i
+            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+            const u8 *s = A.seq + so;
+            for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+        } else {
+            const u32 idx = A.entB[e];
+            const u32 *cg = A.cigar + A.cig_off[idx];
+            const u32 nc = A.n_cig[idx];
+            const u8 *s = A.seq + so;
+            int ent0 = 0;
+            u64 ro = 0;
+            for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+                const u32 op = cg[r], len = op >> 4, o = op & 15u;
+                if (o == PP_OP_I) { ro += len; continue; }
+                u32 ins = 0;
+                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+                const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+                for (int q = a + (int)lane; q < b; q += 64) {
+                    const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+                    int row;
+                    if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
+                    else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
+                    tile_add(cnt, row, rel + q, kc);
+                }
+                ent0 += (int)len;
+                if (o != PP_OP_D) ro += len;
+            }
+        }
+    }
+    if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
+    __syncthreads();
+
+    // ---- vote: one lane per position ----
+    u32 my_len = 0, my_changed = 0, my_zero = 0;
+    u64 my_depth = 0;
+    const bool one_contig = (s_c0 == s_c1);
+    for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
+        const u64 gp = w0 + p;
+        if (gp >= A.G) break;
+        const u32 nA = cnt[ROW_A * TILE + p], nC = cnt[ROW_C * TILE + p], nT = cnt[ROW_T * TILE + p],
+                  nG = cnt[ROW_G * TILE + p], nDel = cnt[ROW_DEL * TILE + p],
+                  nOth = cnt[ROW_OTH * TILE + p], defw = cnt[ROW_DEF * TILE + p];
+        const bool nd = (defw >> 31) != 0;
+        const u32 deficit = defw & 0x7FFFFFFFu;
+        const u32 ntot = nA + nC + nG + nT + nDel + nOth;
+        const u8 orig = A.bases[gp];
+        if (orig >= 0x80u) report(A.status, gp, DE_NON_ASCII);
+        const u64 dfx = ((u64)ntot << DEPTH_FX_BITS) - deficit;
+        const double depth = (double)dfx * (1.0 / (double)(1u << DEPTH_FX_BITS));  // exact
+        bool flag = false;
+        VoteOut v;
+        v.out = (orig == (u8)'-') ? 0 : orig;
+        v.status = PP_ST_LOW_DEPTH;
+        v.vthr = 0; v.ithr = 0;
+        if (nd) {
+            // depth is an order-dependent f64 sum: exact only in k_exact.  depth <= ntot always,
+            // so ntot < min_depth already decides DepthTooLow.
+            if (ntot >= A.min_depth || A.dbg) flag = true;
+        } else {
+            const u32 ithr = d_bankers(__dmul_rn(depth, A.fi));
+            if (!(depth < (double)A.min_depth) && nOth > 0 && nOth >= ithr) flag = true;
+            else v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+        }
+        if (flag) {
+            const u32 slot = atomicAdd(&A.counters[0], 1u);
+            A.flag_pos[slot] = (u32)gp;
+            A.flag_cov[slot] = ntot;
+            A.code[gp] = 0;
+            continue;
+        }
+        A.code[gp] = v.out;
+        const u32 l = v.out ? 1u : 0u, ch = (v.status == PP_ST_CHANGED), z = (ntot == 0);
+        if (one_contig) {
+            my_len += l; my_changed += ch; my_zero += z; my_depth += dfx;
+        } else {
+            my_len += l;
+            const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
+            if (ch) atomicAdd(&A.stats[c].changed, 1ull);
+            if (z) atomicAdd(&A.stats[c].zero_depth, 1ull);
+            if (dfx) atomicAdd(&A.stats[c].depth_fx, dfx);
+        }
+        if (A.dbg) {
+            A.dbg_depth[gp] = depth;
+            A.dbg_counts[0 * A.G + gp] = nA;
+            A.dbg_counts[1 * A.G + gp] = nC;
+            A.dbg_counts[2 * A.G + gp] = nG;
+            A.dbg_counts[3 * A.G + gp] = nT;
+            A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+            A.dbg_counts[5 * A.G + gp] = v.vthr;
+            A.dbg_counts[6 * A.G + gp] = v.ithr;
+            A.dbg_status[gp] = v.status;
+        }
+    }
+    my_len = wave_sum(my_len);
+    my_changed = wave_sum(my_changed);
+    my_zero = wave_sum(my_zero);
+    my_depth = wave_sum64(my_depth);
+    if (lane == 0) {
+        if (my_len) atomicAdd(&s_len, my_len);
+        if (my_changed) atomicAdd(&s_changed, my_changed);
+        if (my_zero) atomicAdd(&s_zero, my_zero);
+        if (my_depth) atomicAdd(&s_depth, my_depth);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        A.win_len[w] = s_len;
+        if (s_changed) atomicAdd(&A.stats[s_c0].changed, (u64)s_changed);
+        if (s_zero) atomicAdd(&A.stats[s_c0].zero_depth, (u64)s_zero);
+        if (s_depth) atomicAdd(&A.stats[s_c0].depth_fx, s_depth);
+    }
+}
+
+// =============================================================================================
+// k_exact: exact replay of flagged positions (one thread per position)
+// =============================================================================================
+// Read slice (offset relative to the read, length) of entry q of an alignment with indels:
+// get_read_bases_for_each_target_base, alignment.rs:175-201.
+__device__ void entry_slice(const u32 *cg, u32 nc, u32 q, u64 *s_rel, u32 *len) {
+    u32 ent = 0;
+    u64 ro = 0;
+    for (u32 r = 0; r < nc; r++) {
+        u32 op = cg[r], l = op >> 4, o = op & 15u;
+        if (o == PP_OP_I) { ro += l; continue; }
+        if (q < ent + l) {
+            u32 ins = 0;
+            if (q == ent + l - 1)
+                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+            if (o == PP_OP_D) { *s_rel = ro; *len = ins; }
+            else { *s_rel = ro + (q - ent); *len = 1u + ins; }
+            return;
+        }
+        ent += l;
+        if (o != PP_OP_D) ro += l;
+    }
+    *s_rel = 0;
+    *len = 0;
+}
+
+__device__ void sift_down(ulonglong2 *a, u32 start, u32 n) {
+    u32 root = start;
+    for (;;) {
+        u32 child = 2 * root + 1;
+        if (child >= n) break;
+        if (child + 1 < n && a[child].x < a[child + 1].x) child++;
+        if (a[root].x >= a[child].x) break;
+        ulonglong2 t = a[root]; a[root] = a[child]; a[child] = t;
+        root = child;
+    }
+}
+__device__ void heapsort_by_x(ulonglong2 *a, u32 n) {
+    if (n < 2) return;
+    for (u32 s = n / 2; s-- > 0;) sift_down(a, s, n);
+    for (u32 end = n - 1; end > 0; end--) {
+        ulonglong2 t = a[0]; a[0] = a[end]; a[end] = t;
+        sift_down(a, 0, end);
+    }
+}
+
+struct ExactArgs {
+    u32 n_flagged;
+    const u32 *flag_pos;
+    const u32 *flag_cov;
+    const u64 *flag_scr;
+    const uint4 *entA;
+    const u32 *entB;
+    const u32 *win_off;
+    const u8 *seq;
+    const u64 *cig_off;
+    const u32 *n_cig;
+    const u32 *cigar;
+    const u32 *kk;
+    const u8 *bases;
+    u64 G;
+    const u64 *contig_off;
+    u32 n_contigs;
+    u32 min_depth;
+    double fv, fi;
+    ulonglong2 *scratch;
+    u8 *code;
+    u32 *win_len;
+    u32 *counters;
+    MultiEnt *multi;
+    ContigStatsDev *stats;
+    double *dbg_depth;
+    u32 *dbg_counts;
+    u8 *dbg_status;
+    u64 *status;
+    int dbg;
+};
+
+constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
+constexpr u64 SL_DONE = 1ull << 63;
+
+__global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
+    u32 f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= A.n_flagged) return;
+    const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
+    const u32 w = gp / (u32)TILE;
+    const int pr = (int)(gp - w * (u32)TILE);
+    ulonglong2 *scr = A.scratch + A.flag_scr[f];
+
+    // collect the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40)
+    u32 n = 0;
+    for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
+        const uint4 ent = A.entA[e];
+        const int q = pr - (int)ent.z;
+        if (q < 0 || q >= (int)ent.w) continue;
+        const u32 idx = A.entB[e];
+        const u64 so = (u64)ent.x | ((u64)(ent.y & 0xFFFFu) << 32);
+        u64 s_rel;
+        u32 len;
+        if (!((ent.y >> 24) & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
+        if (n < cap) {
+            ulonglong2 v;
+            v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+            v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
+            scr[n] = v;
+        }
+        n++;
+    }
+    if (n != cap) { report(A.status, gp, DE_INTERNAL); return; }
+    heapsort_by_x(scr, n);
+
+    // depth: sequential f64 adds of 1.0/k in file order (pileup.rs:64, alignment.rs:288)
+    double depth = 0.0;
+    u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0;
+    for (u32 i = 0; i < n; i++) {
+        depth += 1.0 / (double)(u32)(scr[i].x & 0xFFFFFFFFull);
+        const u64 y = scr[i].y;
+        const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
+        if (len == 0) { nDel++; scr[i].y = y | SL_DONE; continue; }
+        if (len == 1) {
+            const int row = row_of(A.seq[y & SL_OFF_MASK]);
+            if (row != ROW_OTH) {
+                if (row == ROW_A) nA++; else if (row == ROW_C) nC++; else if (row == ROW_G) nG++;
+                else if (row == ROW_T) nT++; else nDel++;
+                scr[i].y = y | SL_DONE;
+                continue;
+            }
+        }
+        nOth++;
+    }
+    const u8 orig = A.bases[gp];
+    VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+    u64 win_off = 0;
+    u32 win_len = 0;  // winning string-keyed sequence, if any
+    if (v.status != PP_ST_LOW_DEPTH && nOth > 0) {
+        // redo the tally of pileup.rs:77-109 with the remaining keys added
+        int nv = 0, ni = 0;
+        u8 win = 0;
+        const u32 c5[5] = {nA, nC, nG, nT, nDel};
+        const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
+        for (int j = 0; j < 5; j++) {
+            if (j == 4 && nDel == 0) break;
+            if (c5[j] >= v.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= v.ithr) ni++;
+        }
+        for (u32 i = 0; i < n; i++) {
+            const u64 yi = scr[i].y;
+            if (yi & SL_DONE) continue;
+            const u32 li = (u32)((yi >> 40) & 0x7FFFFFu);
+            const u8 *si = A.seq + (yi & SL_OFF_MASK);
+            u32 count = 1;
+            for (u32 j = i + 1; j < n; j++) {
+                const u64 yj = scr[j].y;
+                if (yj & SL_DONE) continue;
+                if ((u32)((yj >> 40) & 0x7FFFFFu) != li) continue;
+                const u8 *sj = A.seq + (yj & SL_OFF_MASK);
+                bool same = true;
+                for (u32 b = 0; b < li; b++) if (si[b] != sj[b]) { same = false; break; }
+                if (same) { count++; scr[j].y = yj | SL_DONE; }
+            }
+            if (count >= v.vthr) { if (!nv) { win = 0; win_off = yi & SL_OFF_MASK; win_len = li; } nv++; }
+            else if (count >= v.ithr) ni++;
+        }
+        v.out = (orig == (u8)'-') ? 0 : orig;
+        v.status = PP_ST_KEPT;
+        if (nv == 1) {
+            if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+            else if (win_len == 0) {
+                v.out = (win == (u8)'-') ? 0 : win;
+                if (win != orig) v.status = PP_ST_CHANGED;
+            } else {
+                v.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+            }
+        } else {
+            win_len = 0;
+            v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+        }
+        if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
+    }
+
+    u32 emit;
+    if (win_len > 0) {
+        u32 eff = 0;
+        u8 only = 0;
+        for (u32 b = 0; b < win_len; b++) {
+            const u8 ch = A.seq[win_off + b];
+            if (ch != (u8)'-') { eff++; only = ch; }
+        }
+        if (eff == 0) { A.code[gp] = 0; }
+        else if (eff == 1 && only < 0x80u) { A.code[gp] = only; }
+        else {
+            A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
+            const u32 slot = atomicAdd(&A.counters[1], 1u);
+            MultiEnt m;
+            m.off = win_off; m.pos = gp; m.len = win_len; m.eff = eff; m.pad = 0;
+            A.multi[slot] = m;
+        }
+        emit = eff;
+    } else {
+        A.code[gp] = v.out;
+        emit = v.out ? 1u : 0u;
+    }
+    if (emit) atomicAdd(&A.win_len[w], emit);
+    const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
+    if (v.status == PP_ST_CHANGED) atomicAdd(&A.stats[c].changed, 1ull);
+    if (n == 0) atomicAdd(&A.stats[c].zero_depth, 1ull);
+    atomicAdd(&A.stats[c].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+    if (A.dbg) {
+        A.dbg_depth[gp] = depth;
+        A.dbg_counts[0 * A.G + gp] = nA;
+        A.dbg_counts[1 * A.G + gp] = nC;
+        A.dbg_counts[2 * A.G + gp] = nG;
+        A.dbg_counts[3 * A.G + gp] = nT;
+        A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+        A.dbg_counts[5 * A.G + gp] = v.vthr;
+        A.dbg_counts[6 * A.G + gp] = v.ithr;
+        A.dbg_status[gp] = v.status;
+    }
+}
+
+// =============================================================================================
+// emission: code bytes -> polished bytes
+// =============================================================================================
+__device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32 n_multi) {
+    if (c == 0) return 0;
+    if (c < 0x80u) return 1;
+    if (c != 0xFFu) return c & 0x7Fu;
+    for (u32 i = 0; i < n_multi; i++)
+        if (multi[i].pos == gp) return multi[i].eff;
+    return 0;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_compact(const u8 *__restrict__ code, u64 G,
+                                                          const u64 *__restrict__ win_out,
+                                                          const MultiEnt *__restrict__ multi,
+                                                          const u32 *__restrict__ counters,
+                                                          u8 *__restrict__ out) {
+    __shared__ u32 wsum[TILE_THREADS / 64];
+    const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const u64 p0 = (u64)w * TILE + 2ull * t;
+    const u32 n_multi = counters[1];
+    const u8 c0 = (p0 < G) ? code[p0] : 0, c1 = (p0 + 1 < G) ? code[p0 + 1] : 0;
+    const u32 l0 = code_len(c0, (u32)p0, multi, n_multi), l1 = code_len(c1, (u32)(p0 + 1), multi, n_multi);
+    const u32 s = l0 + l1;
+    u32 inc = s;  // inclusive scan within the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 v = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (u32 i = 0; i < wave; i++) base += wsum[i];
+    const u64 off = win_out[w] + base + (inc - s);
+    if (c0 && c0 < 0x80u) out[off] = c0;
+    if (c1 && c1 < 0x80u) out[off + l0] = c1;
+}
+
+// threads [0, n_multi): copy a multi-byte winner into its reserved gap;
+// threads [n_multi, n_multi + n_contigs]: output offset of each contig start (and the total)
+__global__ __launch_bounds__(64) void k_finalize(const u8 *__restrict__ code, u64 G,
+                                                 const u64 *__restrict__ win_out, u32 nwin,
+                                                 const MultiEnt *__restrict__ multi,
+                                                 const u32 *__restrict__ counters,
+                                                 const u8 *__restrict__ seq,
+                                                 const u64 *__restrict__ contig_off, u32 n_contigs,
+                                                 u8 *__restrict__ out, u64 *__restrict__ ctg_out) {
+    const u32 n_multi = counters[1];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_multi + n_contigs + 1u) return;
+    u64 gp;
+    if (t < n_multi) gp = multi[t].pos; else gp = contig_off[t - n_multi];
+    u64 off;
+    if (gp >= G) {
+        off = win_out[nwin];
+    } else {
+        const u32 w = (u32)(gp / TILE);
+        off = win_out[w];
+        for (u64 q = (u64)w * TILE; q < gp; q++) off += code_len(code[q], (u32)q, multi, n_multi);
+    }
+    if (t < n_multi) {
+        const u8 *s = seq + multi[t].off;
+        for (u32 b = 0; b < multi[t].len; b++)
+            if (s[b] != (u8)'-') out[off++] = s[b];
+    } else {
+        ctg_out[t - n_multi] = off;
+    }
+}
+
+}  // namespace pp
+
+// =============================================================================================
+// host side of the polish pipeline
+// =============================================================================================
+using namespace pp;
+
+namespace pp {
+
+int dev_ensure(pp_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return PP_OK;
+    if (b.p) {
+        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PP_HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;  // slack so steady-state jobs of similar size do not realloc
+    PP_HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return PP_OK;
+}
+
+void dev_free(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+void timer_begin(pp_ctx *ctx, const char *name) {
+    if (!ctx->profiling) return;
+    KernelTimer t;
+    t.name = name;
+    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
+    (void)hipEventRecord(t.start, ctx->stream);
+    ctx->timers.push_back(t);
+}
+void timer_end(pp_ctx *ctx) {
+    if (!ctx->profiling || ctx->timers.empty()) return;
+    (void)hipEventRecord(ctx->timers.back().stop, ctx->stream);
+}
+int timers_collect(pp_ctx *ctx, pp_kernel_times *out) {
+    out->n = 0;
+    for (auto &t : ctx->timers) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(t.stop);
+        (void)hipEventElapsedTime(&ms, t.start, t.stop);
+        int k;
+        for (k = 0; k < out->n; k++)
+            if (out->name[k] == t.name) break;
+        if (k == out->n) {
+            if (out->n == PP_MAX_KERNELS) continue;
+            out->name[k] = t.name;
+            out->ms[k] = 0.f;
+            out->n++;
+        }
+        out->ms[k] += ms;
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    ctx->timers.clear();
+    return PP_OK;
+}
+
+}  // namespace pp
+
+static int upload(pp_ctx *ctx, DevBuf &b, const void *src, size_t bytes, const void **dev) {
+    int rc = dev_ensure(ctx, b, bytes);
+    if (rc) return rc;
+    if (bytes) PP_HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = b.p;
+    return PP_OK;
+}
+
+extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,
+                               const uint8_t *bases, int bases_mem, const pp_params *params) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!contig_off || !bases || !params || n_contigs == 0)
+        return ctx->fail(PP_ERR_ARG, "pp_polish_begin: null argument or no contigs");
+    /* check_option_values, polish.rs:277-287 */
+    if (params->fraction_valid <= 0.0 || params->fraction_valid >= 1.0)
+        return ctx->fail(PP_ERR_QUIT, "--fraction_valid must be between 0 and 1 (exclusive)");
+    if (params->fraction_invalid <= 0.0 || params->fraction_invalid >= 1.0)
+        return ctx->fail(PP_ERR_QUIT, "--fraction_invalid must be between 0 and 1 (exclusive)");
+    if (params->fraction_invalid >= params->fraction_valid)
+        return ctx->fail(PP_ERR_QUIT, "--fraction_invalid must be less than --fraction_valid");
+    for (uint32_t c = 0; c < n_contigs; c++)
+        if (contig_off[c + 1] <= contig_off[c])
+            return ctx->fail(PP_ERR_ARG, "pp_polish_begin: contig %u is empty or offsets decrease", c);
+    if (contig_off[0] != 0) return ctx->fail(PP_ERR_ARG, "pp_polish_begin: contig_off[0] must be 0");
+    uint64_t G = contig_off[n_contigs];
+    if (G >= 0xFFFFFFFFull - 4096ull)
+        return ctx->fail(PP_ERR_LIMIT, "assembly of %llu bp exceeds the 2^32-4096 bp limit of this version",
+                         (unsigned long long)G);
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->n_contigs = n_contigs;
+    ctx->contig_off.assign(contig_off, contig_off + n_contigs + 1);
+    ctx->G = G;
+    ctx->params = *params;
+    const void *d;
+    int rc = upload(ctx, ctx->b_contig_off, contig_off, (n_contigs + 1) * sizeof(uint64_t), &d);
+    if (rc) return rc;
+    if (bases_mem == PP_MEM_DEVICE) {
+        ctx->d_bases = bases;
+    } else {
+        rc = upload(ctx, ctx->b_bases, bases, G, &d);
+        if (rc) return rc;
+        ctx->d_bases = (const uint8_t *)d;
+    }
+    ctx->job_open = true;
+    ctx->job_done = false;
+    ctx->have_batch = false;
+    memset(&ctx->dbatch, 0, sizeof ctx->dbatch);
+    return PP_OK;
+}
+
+extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_add without pp_polish_begin");
+    if (ctx->have_batch)
+        return ctx->fail(PP_ERR_LIMIT, "this version takes one alignment batch per polish job");
+    if (!b) return ctx->fail(PP_ERR_ARG, "pp_polish_add: null batch");
+    if (b->n_aln >= 0xFFFFFFFFull)
+        return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one batch");
+    if (b->n_aln && (!b->contig || !b->ref_start || !b->k || !b->seq_off || !b->seq_len ||
+                     !b->cig_off || !b->n_cig || !b->seq || !b->cigar))
+        return ctx->fail(PP_ERR_ARG, "pp_polish_add: null array in a non-empty batch");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (mem == PP_MEM_DEVICE) {
+        ctx->dbatch = *b;
+    } else {
+        pp_aln_batch d = *b;
+        const void *p;
+        int rc;
+        size_t n = b->n_aln;
+#define UP(i, field, T, count)                                                    \
+    rc = upload(ctx, ctx->b_in[i], b->field, (size_t)(count) * sizeof(T), &p);   \
+    if (rc) return rc;                                                            \
+    d.field = (const T *)p;
+        UP(0, contig, uint32_t, n)
+        UP(1, ref_start, uint32_t, n)
+        UP(2, k, uint32_t, n)
+        UP(3, seq_off, uint64_t, n)
+        UP(4, seq_len, uint32_t, n)
+        UP(5, cig_off, uint64_t, n)
+        UP(6, n_cig, uint32_t, n)
+        UP(7, seq, uint8_t, b->seq_bytes)
+        UP(8, cigar, uint32_t, b->n_cig_total)
+#undef UP
+        ctx->dbatch = d;
+    }
+    ctx->have_batch = true;
+    return PP_OK;
+}
+
+static int map_device_error(pp_ctx *ctx, uint64_t key) {
+    uint32_t code = (uint32_t)(key & 0xFF);
+    unsigned long long idx = (unsigned long long)(key >> 8);
+    switch (code) {
+    case DE_UNEXPECTED_OP:
+        return ctx->fail(PP_ERR_QUIT, "unexpected character (other than M, =, X, I or D) in CIGAR string "
+                                      "for alignment record %llu - did you use BWA MEM to generate your alignments?", idx);
+    case DE_LEN_MISMATCH:
+        return ctx->fail(PP_ERR_QUIT, "CIGAR string for alignment record %llu does not match read sequence", idx);
+    case DE_OUT_OF_BOUNDS:
+        return ctx->fail(PP_ERR_PANIC, "alignment record %llu runs past the end of its contig", idx);
+    case DE_BAD_CONTIG:
+        return ctx->fail(PP_ERR_QUIT, "alignment record %llu refers to a contig that is not in the assembly", idx);
+    case DE_BAD_K: return ctx->fail(PP_ERR_ARG, "alignment record %llu has k = 0", idx);
+    case DE_BAD_RUN: return ctx->fail(PP_ERR_ARG, "alignment record %llu has an empty CIGAR, a zero-length run or an unknown op code", idx);
+    case DE_BAD_ENDS: return ctx->fail(PP_ERR_ARG, "alignment record %llu does not start and end with M/= (gate of alignment.rs:155-159 not applied)", idx);
+    case DE_NON_ASCII: return ctx->fail(PP_ERR_LIMIT, "assembly position %llu holds a non-ASCII byte", idx);
+    case DE_TOO_DEEP: return ctx->fail(PP_ERR_LIMIT, "window %llu has more than 2^21 overlapping alignments", idx);
+    case DE_OVERFLOW: return ctx->fail(PP_ERR_LIMIT, "32-bit work-item count or reference span overflow (record/window %llu)", idx);
+    default: return ctx->fail(PP_ERR_HIP, "internal device inconsistency %u at %llu", code, idx);
+    }
+}
+
+static int check_status(pp_ctx *ctx) {
+    uint64_t key = 0;
+    PP_HIPCHK(ctx, hipMemcpyAsync(&key, ctx->b_status.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (key != ~0ull) return map_device_error(ctx, key);
+    return PP_OK;
+}
+
+extern "C" int pp_polish_finish(pp_ctx *ctx) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_finish without pp_polish_begin");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const pp_aln_batch &B = ctx->dbatch;
+    const uint64_t n = ctx->have_batch ? B.n_aln : 0;
+    const uint64_t G = ctx->G;
+    const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
+    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (n + 1023) / 1024));
+    const uint64_t chunk = (n + NB - 1) / NB;
+    const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
+    int rc;
+    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    ctx->timers.clear();
+
+#define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
+    ENS(b_status, 8);
+    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); ENS(b_aflag, n);
+    ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+    ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
+    ENS(b_flag_pos, G * 4); ENS(b_flag_cov, G * 4);
+    ENS(b_counters, 16); ENS(b_stats, (uint64_t)ctx->n_contigs * sizeof(ContigStatsDev));
+    ENS(b_ctg_out, ((uint64_t)ctx->n_contigs + 1) * 8);
+    if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
+
+    u64 *d_status = (u64 *)ctx->b_status.p;
+    PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
+    PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, 16, st));
+    PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_stats.p, 0, (size_t)ctx->n_contigs * sizeof(ContigStatsDev), st));
+
+    u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
+    u8 *d_aflag = (u8 *)ctx->b_aflag.p;
+    u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
+    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
+
+    if (n) {
+        timer_begin(ctx, "prep");
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
+                           B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
+                           B.n_cig, B.cigar, B.seq, d_ctg, ctx->n_contigs, d_gstart, d_nkeep, d_aflag, d_status);
+        timer_end(ctx);
+    }
+    timer_begin(ctx, "bucket");
+    hipLaunchKernelGGL(k_count, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin, d_hist);
+    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
+    hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, d_winoff, d_status);
+    timer_end(ctx);
+    PP_HIPCHK(ctx, hipGetLastError());
+
+    uint32_t n_entries = 0;
+    PP_HIPCHK(ctx, hipMemcpyAsync(&n_entries, d_winoff + nwin, 4, hipMemcpyDeviceToHost, st));
+    if ((rc = check_status(ctx))) return rc;  // synchronises
+    ENS(b_entA, (uint64_t)n_entries * 16); ENS(b_entB, (uint64_t)n_entries * 4);
+    uint4 *d_entA = (uint4 *)ctx->b_entA.p;
+    u32 *d_entB = (u32 *)ctx->b_entB.p;
+    if (n) {
+        timer_begin(ctx, "bucket");
+        hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
+                           d_aflag, B.k, (const u64 *)B.seq_off, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
+                           d_entA, d_entB);
+        timer_end(ctx);
+    }
+
+    TileArgs T;
+    T.entA = d_entA; T.entB = d_entB; T.win_off = d_winoff; T.nwin = nwin;
+    T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
+    T.n_cig = B.n_cig; T.cigar = B.cigar;
+    T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = ctx->n_contigs;
+    T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
+    T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
+    T.counters = (u32 *)ctx->b_counters.p; T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
+    T.stats = (ContigStatsDev *)ctx->b_stats.p;
+    T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
+    T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
+    const uint32_t per = (nwin + 7) / 8;
+    timer_begin(ctx, "tile");
+    hipLaunchKernelGGL(k_tile, dim3(per * 8), dim3(TILE_THREADS), 0, st, T);
+    timer_end(ctx);
+    PP_HIPCHK(ctx, hipGetLastError());
+
+    uint32_t counters[4] = {0, 0, 0, 0};
+    PP_HIPCHK(ctx, hipMemcpyAsync(counters, ctx->b_counters.p, 16, hipMemcpyDeviceToHost, st));
+    if ((rc = check_status(ctx))) return rc;
+    const uint32_t n_flagged = counters[0];
+    if (n_flagged) {
+        ENS(b_flag_scr, ((uint64_t)n_flagged + 1) * 8);
+        u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
+        timer_begin(ctx, "exact");
+        hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)ctx->b_flag_cov.p, (u64)n_flagged, d_scr, d_status);
+        uint64_t scr_total = 0;
+        PP_HIPCHK(ctx, hipMemcpyAsync(&scr_total, d_scr + n_flagged, 8, hipMemcpyDeviceToHost, st));
+        PP_HIPCHK(ctx, hipStreamSynchronize(st));
+        ENS(b_scratch, scr_total * 16);
+        ENS(b_multi, (uint64_t)n_flagged * sizeof(MultiEnt));
+        ExactArgs E;
+        E.n_flagged = n_flagged; E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
+        E.entA = d_entA; E.entB = d_entB; E.win_off = d_winoff; E.seq = B.seq;
+        E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
+        E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = ctx->n_contigs;
+        E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
+        E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
+        E.counters = T.counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = T.stats;
+        E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
+        E.status = d_status; E.dbg = T.dbg;
+        hipLaunchKernelGGL(k_exact, dim3((n_flagged + 63) / 64), dim3(64), 0, st, E);
+        timer_end(ctx);
+    } else {
+        ENS(b_multi, sizeof(MultiEnt));
+    }
+
+    u64 *d_winout = (u64 *)ctx->b_winout.p;
+    timer_begin(ctx, "emit");
+    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, d_winout, d_status);
+    timer_end(ctx);
+    uint64_t total_out = 0;
+    PP_HIPCHK(ctx, hipMemcpyAsync(&total_out, d_winout + nwin, 8, hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipMemcpyAsync(counters, ctx->b_counters.p, 16, hipMemcpyDeviceToHost, st));
+    if ((rc = check_status(ctx))) return rc;
+    ENS(b_out, total_out);
+    timer_begin(ctx, "emit");
+    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(TILE_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
+                       (const MultiEnt *)ctx->b_multi.p, (const u32 *)T.counters, (u8 *)ctx->b_out.p);
+    const uint32_t nfin = counters[1] + ctx->n_contigs + 1;
+    hipLaunchKernelGGL(k_finalize, dim3((nfin + 63) / 64), dim3(64), 0, st, (const u8 *)T.code, (u64)G,
+                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)T.counters,
+                       B.seq, d_ctg, ctx->n_contigs, (u8 *)ctx->b_out.p, (u64 *)ctx->b_ctg_out.p);
+    timer_end(ctx);
+    PP_HIPCHK(ctx, hipGetLastError());
+
+    ctx->contig_out_off.resize(ctx->n_contigs + 1);
+    std::vector<ContigStatsDev> hs(ctx->n_contigs);
+    PP_HIPCHK(ctx, hipMemcpyAsync(ctx->contig_out_off.data(), ctx->b_ctg_out.p, (ctx->n_contigs + 1) * 8ull,
+                                  hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->b_stats.p, ctx->n_contigs * sizeof(ContigStatsDev),
+                                  hipMemcpyDeviceToHost, st));
+    if ((rc = check_status(ctx))) return rc;
+    ctx->total_out = total_out;
+    ctx->stats.resize(ctx->n_contigs);
+    for (uint32_t c = 0; c < ctx->n_contigs; c++) {
+        ctx->stats[c].polished_len = ctx->contig_out_off[c + 1] - ctx->contig_out_off[c];
+        ctx->stats[c].changed = hs[c].changed;
+        ctx->stats[c].zero_depth = hs[c].zero_depth;
+        ctx->stats[c].depth_sum = (double)hs[c].depth_fx / (double)(1u << DEPTH_FX_BITS);
+    }
+    if (ctx->profiling) {
+        timers_collect(ctx, &ctx->last_times);
+        ctx->last_times.n_entries = n_entries;
+        ctx->last_times.n_flagged = n_flagged;
+    }
+    ctx->job_done = true;
+    ctx->job_open = false;
+    return PP_OK;
+#undef ENS
+}
+
+extern "C" int pp_polish_result_size(pp_ctx *ctx, uint64_t *total_bytes) {
+    if (!ctx || !total_bytes) return PP_ERR_ARG;
+    if (!ctx->job_done) return ctx->fail(PP_ERR_ARG, "no finished polish job");
+    *total_bytes = ctx->total_out;
+    return PP_OK;
+}
+
+extern "C" int pp_polish_result(pp_ctx *ctx, uint8_t *out, int out_mem, uint64_t *contig_out_off,
+                                pp_contig_stats *stats) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->job_done) return ctx->fail(PP_ERR_ARG, "no finished polish job");
+    if (out && ctx->total_out) {
+        PP_HIPCHK(ctx, hipMemcpyAsync(out, ctx->b_out.p, ctx->total_out,
+                                      out_mem == PP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                      ctx->stream));
+        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (contig_out_off) memcpy(contig_out_off, ctx->contig_out_off.data(), (ctx->n_contigs + 1) * 8ull);
+    if (stats) memcpy(stats, ctx->stats.data(), ctx->n_contigs * sizeof(pp_contig_stats));
+    return PP_OK;
+}
+
+extern "C" const uint8_t *pp_polish_result_device(pp_ctx *ctx) {
+    return (ctx && ctx->job_done) ? (const uint8_t *)ctx->b_out.p : nullptr;
+}
+
+extern "C" int pp_polish_set_debug(pp_ctx *ctx, int enable) {
+    if (!ctx) return PP_ERR_ARG;
+    ctx->debug = enable != 0;
+    return PP_OK;
+}
+
+extern "C" int pp_polish_positions(pp_ctx *ctx, const pp_positions *o) {
+    if (!ctx || !o) return PP_ERR_ARG;
+    if (!ctx->job_done || !ctx->debug || !ctx->b_dbg_depth.p)
+        return ctx->fail(PP_ERR_ARG, "per-position records need pp_polish_set_debug(1) before pp_polish_finish");
+    const uint64_t G = ctx->G;
+    hipStream_t st = ctx->stream;
+    const u32 *cnt = (const u32 *)ctx->b_dbg_counts.p;
+    uint32_t *dst[7] = {o->count_a, o->count_c, o->count_g, o->count_t, o->count_other, o->valid_thr, o->invalid_thr};
+    if (o->depth) PP_HIPCHK(ctx, hipMemcpyAsync(o->depth, ctx->b_dbg_depth.p, G * 8, hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < 7; i++)
+        if (dst[i]) PP_HIPCHK(ctx, hipMemcpyAsync(dst[i], cnt + (uint64_t)i * G, G * 4, hipMemcpyDeviceToHost, st));
+    if (o->status) PP_HIPCHK(ctx, hipMemcpyAsync(o->status, ctx->b_dbg_status.p, G, hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    return PP_OK;
+}
+
+extern "C" int pp_ctx_set_profiling(pp_ctx *ctx, int enable) {
+    if (!ctx) return PP_ERR_ARG;
+    ctx->profiling = enable != 0;
+    return PP_OK;
+}
+
+extern "C" int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out) {
+    if (!ctx || !out) return PP_ERR_ARG;
+    *out = ctx->last_times;
+    return PP_OK;
+}
+
+// ---- context -----------------------------------------------------------------------------------
+extern "C" int pp_ctx_create(int device, pp_ctx **out) {
+    if (!out) return PP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PP_ERR_HIP;
+    if (device < 0 || device >= n) return PP_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return PP_ERR_HIP;
+    pp_ctx *ctx = new pp_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PP_ERR_HIP;
+    }
+    *out = ctx;
+    return PP_OK;
+}
+
+extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
+                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB,
+                     &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_counters, &ctx->b_stats,
+                     &ctx->b_out, &ctx->b_ctg_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
+                     &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
+                     &ctx->f_insert};
+    for (DevBuf *b : all) dev_free(*b);
+    for (auto &b : ctx->b_in) dev_free(b);
+    for (auto &f : ctx->f_in) for (auto &b : f) dev_free(b);
+    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pp_ctx_set_error_(pp_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg ? msg : "";
+    return code;
+}
+extern "C" const char *pp_last_error(const pp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" int pp_ctx_sync(pp_ctx *ctx) {
+    if (!ctx) return PP_ERR_ARG;
+    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+extern "C" void *pp_ctx_stream(pp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" const char *pp_version(void) { return "polypolish-mi355x 0.1.0 (parity target v0.6.1)"; }

@@ -1,0 +1,292 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact everywhere: polished bytes, contig offsets, per-position f64 depth, counters,
+thresholds and vote status; filtered SAM bytes; CLI stdout.  Needs an MI355X: `-m gpu`."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POS_KEYS = ("depth", "count_a", "count_c", "count_g", "count_t", "count_other", "valid_thr", "invalid_thr", "status")
+
+
+@pytest.fixture(scope="module")
+def pp():
+    import polypolish_amd
+    return polypolish_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(pp):
+    c = pp.Context(0)
+    yield c
+    c.close()
+
+
+def _seqs(fasta_bytes):
+    return [l for l in fasta_bytes.decode().split("\n") if l and not l.startswith(">")]
+
+
+def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
+    want = orc.polish_records(contig_off, bases, recs, positions=True, **kw)
+    got = ctx.polish_records(contig_off, bases, recs, positions=True, **kw)
+    for k in POS_KEYS:
+        bad = np.nonzero(want["positions"][k] != got["positions"][k])[0]
+        assert len(bad) == 0, (k, len(bad), bad[:8], want["positions"][k][bad[:8]], got["positions"][k][bad[:8]])
+    assert np.array_equal(got["offsets"], want["offsets"]), (got["offsets"], want["offsets"])
+    assert got["polished"] == want["polished"]
+    st = want["positions"]["status"]
+    off = [int(x) for x in contig_off]
+    for c in range(len(off) - 1):
+        assert got["stats"][c]["changed"] == int((st[off[c]:off[c + 1]] == 1).sum())
+        assert got["stats"][c]["zero_depth"] == int((want["positions"]["depth"][off[c]:off[c + 1]] == 0.0).sum())
+    # without the per-position debug planes the same bytes must come out (different flagging rule)
+    plain = ctx.polish_records(contig_off, bases, recs, positions=False, **kw)
+    assert plain["polished"] == want["polished"]
+    return want, got
+
+
+RECORD_CASES = {
+    "plain_k1": dict(seed=1, contig_lens=(60_000,), coverage=60, indel_read_frac=0.0),
+    "indels": dict(seed=2, contig_lens=(40_000, 7_000), coverage=80, indel_read_frac=0.2, n_rate=0.003),
+    "dyadic_k": dict(seed=3, contig_lens=(30_000,), coverage=60, k_choices=(1, 2, 4, 8), indel_read_frac=0.02),
+    "nondyadic_k": dict(seed=4, contig_lens=(30_000, 2_500), coverage=50, k_choices=(1, 2, 3, 5, 6, 7),
+                        k_probs=(0.5, 0.1, 0.1, 0.1, 0.1, 0.1), indel_read_frac=0.05),
+    "all_k3": dict(seed=5, contig_lens=(9_000,), coverage=40, k_choices=(3,)),
+    "low_depth": dict(seed=6, contig_lens=(50_000,), coverage=6, indel_read_frac=0.05, n_rate=0.01),
+    "tiny_contigs": dict(seed=7, contig_lens=(300, 2048, 2049, 500, 4096, 1000), coverage=40, read_len=100,
+                         indel_read_frac=0.05),
+    "long_reads": dict(seed=8, contig_lens=(40_000,), coverage=30, read_len=5000, indel_read_frac=0.3,
+                       sub_rate=0.0005),
+    "many_N": dict(seed=9, contig_lens=(20_000,), coverage=30, n_rate=0.2),
+    "big_k": dict(seed=10, contig_lens=(20_000,), coverage=40, k_choices=(1, 1024, 2048, 4096, 1000)),
+}
+
+
+@pytest.mark.parametrize("name", list(RECORD_CASES))
+def test_polish_records_parity(ctx, orc, name):
+    contig_off, bases, recs = synth.fast_records(**RECORD_CASES[name])
+    want, _ = _compare_records(ctx, orc, contig_off, bases, recs)
+    if name in ("plain_k1", "indels"):
+        assert (want["positions"]["status"] == 1).sum() > 0
+    _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_valid=0.6, fraction_invalid=0.05)
+
+
+def test_deep_pileup_on_one_window(ctx, orc):
+    # 20,000x on a 3 kbp contig: a single window bucket of ~60k work items
+    contig_off, bases, recs = synth.fast_records(seed=21, contig_lens=(3_000,), coverage=20_000, read_len=150,
+                                                 indel_read_frac=0.01)
+    _compare_records(ctx, orc, contig_off, bases, recs)
+
+
+def test_empty_and_degenerate_jobs(ctx, orc):
+    bases = np.frombuffer(b"ACGT-NNACGTTTGCA" * 200, dtype=np.uint8)
+    off = np.array([0, 1000, 3200], dtype=np.uint64)
+    empty = {k: np.zeros(0, dtype=dt) for k, dt in (("contig", np.uint32), ("ref_start", np.uint32), ("k", np.uint32),
+             ("seq_off", np.uint64), ("seq_len", np.uint32), ("cig_off", np.uint64), ("n_cig", np.uint32),
+             ("seq", np.uint8), ("cigar", np.uint32))}
+    want, got = _compare_records(ctx, orc, off, bases, empty)  # zero alignments: '-' dropped, all low_depth
+    assert b"-" not in got["polished"] and len(got["polished"]) == 3200 - 200
+    # homopolymer reads contribute nothing (trim pops everything)
+    recs = {"contig": np.zeros(8, np.uint32), "ref_start": np.arange(8, dtype=np.uint32), "k": np.ones(8, np.uint32),
+            "seq_off": np.arange(8, dtype=np.uint64) * 20, "seq_len": np.full(8, 20, np.uint32),
+            "cig_off": np.arange(8, dtype=np.uint64), "n_cig": np.ones(8, np.uint32),
+            "seq": np.frombuffer(b"A" * 160, dtype=np.uint8), "cigar": np.full(8, (20 << 4) | 0, np.uint32)}
+    _compare_records(ctx, orc, off, bases, recs)
+
+
+def _rec(entries):
+    """entries: list of (contig, ref_start, k, seq, [(len, op), ...])."""
+    seq = b"".join(e[3].encode() for e in entries)
+    cig = [((l << 4) | "MIDNSHP=X".index(o)) for e in entries for (l, o) in e[4]]
+    n_cig = np.array([len(e[4]) for e in entries], np.uint32)
+    seq_len = np.array([len(e[3]) for e in entries], np.uint32)
+    return {"contig": np.array([e[0] for e in entries], np.uint32), "ref_start": np.array([e[1] for e in entries], np.uint32),
+            "k": np.array([e[2] for e in entries], np.uint32),
+            "seq_off": (np.cumsum(seq_len) - seq_len).astype(np.uint64), "seq_len": seq_len,
+            "cig_off": (np.cumsum(n_cig) - n_cig).astype(np.uint64), "n_cig": n_cig,
+            "seq": np.frombuffer(seq, np.uint8), "cigar": np.array(cig, np.uint32)}
+
+
+def test_insertion_deletion_and_odd_keys_win_the_vote(ctx, orc):
+    ref = "TTGACCGTAGGCTAACGTTAGCATCGGATCCATGCAAGT"
+    bases = np.frombuffer(ref.encode(), np.uint8)
+    off = np.array([0, len(ref)], np.uint64)
+    # 3-base insertion after position 9, deletion of positions 20-21, X and = runs
+    ent = [(0, 2, 1, "GACCGTAGACGGCTAACGTTATCGGATCCAT", [(8, "="), (3, "I"), (9, "M"), (2, "D"), (1, "X"), (10, "=")])
+           for _ in range(12)]
+    want, got = _compare_records(ctx, orc, off, bases, _rec(ent))
+    assert len(got["polished"]) == len(ref) + 3 - 2 and (want["positions"]["status"] == 1).sum() >= 3
+    # D immediately followed by I (slot rewritten to one base), N bases, a '-' byte in SEQ
+    ent = [(0, 5, 1, "CGTAGGNTAACGTTAG-ATCGGATCCATGCAAGT", [(6, "M"), (1, "D"), (1, "I"), (27, "M")]) for _ in range(12)]
+    want, got = _compare_records(ctx, orc, off, bases, _rec(ent))
+    assert (want["positions"]["status"] == 1).sum() >= 2 and len(got["polished"]) == len(ref) - 1
+    # a 200-base insertion (longer than the 1-byte emit code can express)
+    big = "ACGT" * 50
+    ent = [(0, 2, 1, "GACCGTAG" + big + "GCTAACGTTAGC", [(8, "M"), (200, "I"), (12, "M")]) for _ in range(9)]
+    _compare_records(ctx, orc, off, bases, _rec(ent))
+
+
+def test_f64_order_dependence_on_device(ctx, orc):
+    # D4: fifteen k=3 shares sum to 4.999999999999999 -> low_depth at min_depth 5; order of mixed shares matters
+    ref = "ACGTACGTACGTTGCA" * 4
+    bases = np.frombuffer(ref.encode(), np.uint8)
+    off = np.array([0, len(ref)], np.uint64)
+    ent = [(0, 0, 3, ref[:32], [(32, "M")]) for _ in range(15)]
+    want, got = _compare_records(ctx, orc, off, bases, _rec(ent))
+    assert want["positions"]["depth"][0] == 4.999999999999999 and want["positions"]["status"][0] == 2
+    rng = np.random.default_rng(0)
+    ks = [3, 3, 3, 1, 1, 6, 6, 5, 7, 10, 1, 3, 9, 12, 2]
+    for _ in range(4):
+        order = rng.permutation(len(ks))
+        ent = [(0, 0, ks[i], ref[:32], [(32, "M")]) for i in order]
+        _compare_records(ctx, orc, off, bases, _rec(ent))
+
+
+def test_device_reports_the_first_bad_record(ctx, pp):
+    ref = "ACGGTCATTGCAACGGTTATTGCA" * 3
+    bases = np.frombuffer(ref.encode(), np.uint8)
+    off = np.array([0, len(ref)], np.uint64)
+    good = (0, 0, 1, ref[:24], [(24, "M")])
+    cases = [
+        ((0, 0, 1, ref[:24], [(10, "M"), (4, "N"), (10, "M")]), pp.ERR_QUIT, "unexpected character"),
+        ((0, 0, 1, ref[:24], [(23, "M")]), pp.ERR_QUIT, "does not match read sequence"),
+        ((0, 60, 1, ref[:24], [(24, "M")]), pp.ERR_PANIC, "past the end"),
+        ((5, 0, 1, ref[:24], [(24, "M")]), pp.ERR_QUIT, "not in the assembly"),
+        ((0, 0, 0, ref[:24], [(24, "M")]), pp.ERR_ARG, "k = 0"),
+        ((0, 0, 1, ref[:24], [(4, "S"), (20, "M")]), pp.ERR_QUIT, "unexpected character"),
+        ((0, 0, 1, ref[:24], [(1, "I"), (23, "M")]), pp.ERR_ARG, "start and end"),
+    ]
+    for bad, code, text in cases:
+        with pytest.raises(pp.PolypolishError) as e:
+            ctx.polish_records(off, bases, _rec([good, good, bad, good, bad]))
+        assert e.value.code == code and text in e.value.msg and "record 2" in e.value.msg, e.value
+    # a read overhanging the contig end only by its trimmed tail is fine (the reference never indexes it)
+    ent = [(0, len(ref) - 22, 1, ref[-22:] + "GG", [(24, "M")])]
+    ctx.polish_records(off, bases, _rec(ent))
+
+
+FILE_CASES = [
+    dict(seed=31),
+    dict(seed=32, contig_lens=(6000, 1200, 900), coverage=30, repeat_len=400, repeat_copies=3),
+    dict(seed=33, contig_lens=(5000,), coverage=50, repeat_len=300, repeat_copies=5, inverted=False, n_rate=0.01),
+    dict(seed=34, contig_lens=(2500, 2500), coverage=8, sub_rate=0.02, zp_frac=0.1),
+]
+
+
+@pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
+def test_polish_files_parity(ctx, orc, tmp_path, case):
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    sams = [ds["sam1"], ds["sam2"]]
+    for kw in (dict(), dict(careful=True), dict(min_depth=2, fraction_invalid=0.1, max_errors=3)):
+        want = orc.polish_files(ds["fasta"], sams, **kw)["fasta"]
+        got = ctx.polish_files(ds["fasta"], sams, **kw)
+        assert got == want, kw
+
+
+@pytest.mark.parametrize("case", FILE_CASES[1:3], ids=["seed32", "seed33"])
+def test_filter_then_polish_parity(ctx, orc, tmp_path, case):
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    o1, o2, g1, g2 = (str(tmp_path / n) for n in ("o1.sam", "o2.sam", "g1.sam", "g2.sam"))
+    for kw in (dict(), dict(orientation="fr", low=5.0, high=95.0), dict(orientation="rf", low=1.0, high=60.0)):
+        try:
+            want = orc.filter_files(ds["sam1"], ds["sam2"], o1, o2, **kw)
+        except orc.OrcError as e:
+            with pytest.raises(Exception) as ge:
+                ctx.filter_files(ds["sam1"], ds["sam2"], g1, g2, **kw)
+            assert ge.value.code == e.code and ge.value.msg == e.msg
+            continue
+        got = ctx.filter_files(ds["sam1"], ds["sam2"], g1, g2, **kw)
+        assert open(g1, "rb").read() == open(o1, "rb").read()
+        assert open(g2, "rb").read() == open(o2, "rb").read()
+        assert got == want
+    orc.filter_files(ds["sam1"], ds["sam2"], o1, o2)
+    ctx.filter_files(ds["sam1"], ds["sam2"], g1, g2)
+    assert ctx.polish_files(ds["fasta"], [g1, g2]) == orc.polish_files(ds["fasta"], [o1, o2])["fasta"]
+
+
+def test_reference_orientation_vectors_on_device(ctx, pp):
+    """T4 (src/filter.rs:384-424) and T3 (src/alignment.rs:402-422) through the filter kernels."""
+    import ctypes as C
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_unit_vectors.json")))
+    cases = gold["T4_orientation"]["cases"]
+    n = len(cases)
+    names = ("fr", "rf", "ff", "rr")
+
+    def ffile(pos, flags):
+        arr = dict(ref_id=np.zeros(n, np.uint32), ref_start=np.array(pos, np.uint32) - 1, flags=np.array(flags, np.uint32),
+                   cig_off=np.arange(n, dtype=np.uint64), n_cig=np.ones(n, np.uint32),
+                   cigar=np.full(n, (150 << 4) | 0, np.uint32), read=np.arange(n, dtype=np.uint32),
+                   grp_off=np.arange(n + 1, dtype=np.uint32), grp_idx=np.arange(n, dtype=np.uint32))
+        f = pp.FilterFile(n, arr["ref_id"].ctypes.data, arr["ref_start"].ctypes.data, arr["flags"].ctypes.data,
+                          arr["cig_off"].ctypes.data, arr["n_cig"].ctypes.data, arr["cigar"].ctypes.data, n,
+                          arr["read"].ctypes.data, arr["grp_off"].ctypes.data, arr["grp_idx"].ctypes.data)
+        return f, arr
+    f1, k1 = ffile([c[0] for c in cases], [c[2] for c in cases])
+    f2, k2 = ffile([c[1] for c in cases], [c[3] for c in cases])
+    inp = pp.FilterInput(n, (pp.FilterFile * 2)(f1, f2))
+    L = pp.lib()
+    assert L.pp_filter_begin(ctx._h, C.byref(inp), pp.MEM_HOST) == 0, L.pp_last_error(ctx._h)
+    orient, insert = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
+    assert L.pp_filter_samples(ctx._h, orient.ctypes.data, insert.ctypes.data) == 0
+    assert [names[o] for o in orient] == [c[4] for c in cases]
+    assert list(insert) == [abs(c[0] - c[1]) + 150 for c in cases]
+
+
+def test_cli_is_a_drop_in(orc, tmp_path):
+    ds = synth.rich_dataset(str(tmp_path), seed=41, contig_lens=(5000, 1500), coverage=30, repeat_len=350,
+                            repeat_copies=4)
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    f1, f2, o1, o2 = (str(tmp_path / n) for n in ("f1.sam", "f2.sam", "o1.sam", "o2.sam"))
+    r = subprocess.run([exe, "filter", "--in1", ds["sam1"], "--in2", ds["sam2"], "--out1", f1, "--out2", f2],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    orc.filter_files(ds["sam1"], ds["sam2"], o1, o2)
+    assert open(f1, "rb").read() == open(o1, "rb").read() and open(f2, "rb").read() == open(o2, "rb").read()
+    r = subprocess.run([exe, "polish", "-d", "4", "--fraction_invalid=0.15", ds["fasta"], f1, f2], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == orc.polish_files(ds["fasta"], [o1, o2], min_depth=4, fraction_invalid=0.15)["fasta"]
+    assert b"positions changed" in r.stderr
+    r = subprocess.run([exe, "polish", "-i", "0.7", ds["fasta"], f1], capture_output=True)
+    assert r.returncode == 1 and r.stdout == b"" and b"Error: --fraction_invalid must be less than --fraction_valid" in r.stderr
+    r = subprocess.run([exe, "polish", str(tmp_path / "missing.fasta")], capture_output=True)
+    assert r.returncode == 1 and b"file does not exist" in r.stderr
+
+
+def test_full_size_properties(ctx, pp, orc):
+    """BASELINE.json configs[1] size (5 Mbp, 200x): size-independent properties + exact parity on a window."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    job = bench.make_job(dev, G=5_000_000, coverage=200, seed=7)
+    torch.cuda.synchronize()
+    bench.run_job(ctx, pp, job)
+    a, offs, stats = ctx.result()
+    bench.run_job(ctx, pp, job)
+    b, _, _ = ctx.result()
+    assert a == b, "two runs of the same job differ (atomics must not leak into the result)"
+    truth = bytes(job["truth"].cpu().numpy())
+    assert len(a) == job["G"] and a[1000:-1000] == truth[1000:-1000], "planted assembly errors were not all repaired"
+    n_err = sum(1 for x, y in zip(bytes(job["bases"][1000:-1000].cpu().numpy()), truth[1000:-1000]) if x != y)
+    assert stats[0]["changed"] >= n_err > 300
+    # idempotence: polishing the polished assembly with the same reads changes nothing
+    job2 = dict(job)
+    job2["bases"] = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+    bench.run_job(ctx, pp, job2)
+    c, _, st2 = ctx.result()
+    assert c == a and st2[0]["changed"] == 0
+    # partition invariance + exact oracle parity on a window of the contig
+    lo, hi = 1_000_000, 1_300_000
+    sub = bench.subset_job(job, lo, hi)
+    torch.cuda.synchronize()
+    bench.run_job(ctx, pp, sub)
+    s, _, _ = ctx.result()
+    want = orc.polish_records(np.array([0, hi - lo], np.uint64), sub["bases"].cpu().numpy(), bench.to_host_records(sub))
+    assert s == want["polished"]
+    assert s[400:-400] == a[lo + 400:hi - 400]

@@ -1,0 +1,163 @@
+"""CPU-side tests of the product's host code (no GPU): the C-ABI library loads and exports every
+symbol include/polypolish_hip.h declares, and the host ingest (FASTA/SAM text -> SoA: grouping,
+gates, 1/k share, '*' fill + reverse complement, upper-casing; alignment.rs:49-128,225-322)
+produces exactly the records the oracle's text path implies."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import polypolish_amd as pp
+import synth
+
+ROOT = pp.ROOT
+
+
+def _seqs(fasta_bytes):
+    return [l for l in fasta_bytes.decode().split("\n") if l and not l.startswith(">")]
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "polypolish_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pp.EXPORTS), declared ^ set(pp.EXPORTS)
+    L = pp.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} is declared in the header but not exported"
+    assert b"polypolish-mi355x" in L.pp_version()
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pp.PolypolishError) as e:
+        pp.Context(0)
+    assert e.value.code == pp.ERR_HIP
+    r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "polish", "x.fasta"], capture_output=True)
+    assert r.returncode == 1 and b"no CPU path" in r.stderr and r.stdout == b""
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped path must never import, link or execute anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "polypolish_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pp_oracle" not in text and "oracle." not in text and "pyref" not in text, f
+    out = subprocess.run(["ldd", pp.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+CASES = [
+    dict(seed=11),
+    dict(seed=12, contig_lens=(5000, 1500), coverage=30, repeat_len=350, repeat_copies=4, lowercase_frac=0.3),
+    dict(seed=13, contig_lens=(3000,), coverage=25, repeat_len=300, repeat_copies=3, inverted=False, zp_frac=0.2,
+         clip_frac=0.2),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"seed{c['seed']}" for c in CASES])
+@pytest.mark.parametrize("careful", [False, True])
+def test_ingest_records_reproduce_the_text_path(orc, tmp_path, case, careful):
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    sams = [ds["sam1"], ds["sam2"]]
+    names, descs, off, bases, recs, counts = pp.ingest(ds["fasta"], sams, max_errors=10, careful=careful)
+    want = orc.polish_files(ds["fasta"], sams, positions=True, careful=careful)
+    got = orc.polish_records(off, bases, recs, positions=True)
+    assert got["polished"] == "".join(_seqs(want["fasta"])).encode()
+    for k in ("depth", "count_a", "count_c", "count_g", "count_t", "count_other", "status"):
+        assert np.array_equal(want["positions"][k], got["positions"][k]), k
+    assert (sum(c[0] for c in counts), sum(c[1] for c in counts), sum(c[2] for c in counts)) == want["counts"]
+    assert len(recs["contig"]) == want["counts"][1]
+    if not careful and case.get("repeat_copies"):
+        assert recs["k"].max() > 1, "no multi-mapped read survived: the 1/k path is not exercised"
+    assert names == [c.name for c in ds["contigs"]] and descs[0] == "some description"
+
+
+def _line(name, flag, ref, pos, cigar, seq, tags="NM:i:0"):
+    return f"{name}\t{flag}\t{ref}\t{pos}\t60\t{cigar}\t*\t0\t0\t{seq}\t*\t{tags}\n"
+
+
+def test_ingest_details(tmp_path):
+    ref = "ACGGTCATTGCAACGGTTATTGCA"
+    fa = tmp_path / "a.fasta"
+    fa.write_text(f">c d1 d2\n{ref[:10]}\n{ref[10:].lower()}\n>e\nGGGG\n")
+    sam = tmp_path / "a.sam"
+    sam.write_text(
+        "@HD\tVN:1\n\n"
+        + _line("r1", 16, "c", 1, "12M", "acggtcattgca", "AS:i:3\tNM:i:2\tXX:Z:y")   # lower-case SEQ, NM not first
+        + _line("r1", 256, "c", 13, "0S12M", "*")                                     # zero-length run dropped, '*' fill (revcomp)
+        + _line("r1", 272, "c", 13, "5S7M", "*")                                      # soft clip: not good
+        + _line("r2", 4, "*", 0, "*", "ACGT", "")                                     # unaligned, no NM: skipped
+        + _line("r3", 0, "c", 1, "6=1X5=", ref[:12], "NM:i:11")                       # NM > max_errors
+        + _line("r4", 0, "c", 0, "12M", ref[:12], "NM:i:0\tzp:z:FAIL")                # ZP tag, any case; POS 0 -> 0
+        + _line("r5", 0, "e", 1, "2M1I1M", "GGAG", "NM:i:1\tNM:i:0"))                 # last NM wins
+    names, descs, off, bases, recs, counts = pp.ingest(str(fa), [str(sam)])
+    assert names == ["c", "e"] and descs == ["d1 d2", ""]
+    assert bytes(bases) == (ref + "GGGG").encode() and list(off) == [0, 24, 28]
+    assert counts == [(6, 3, 4)]
+    assert list(recs["contig"]) == [0, 0, 1] and list(recs["ref_start"]) == [0, 12, 0] and list(recs["k"]) == [2, 2, 1]
+    seqs = [bytes(recs["seq"][o:o + l]).decode() for o, l in zip(recs["seq_off"], recs["seq_len"])]
+    assert seqs == ["ACGGTCATTGCA", "TGCAATGACCGT", "GGAG"]
+    cig = [[(int(x) >> 4, pp.OPS[int(x) & 15]) for x in recs["cigar"][o:o + n]] for o, n in zip(recs["cig_off"], recs["n_cig"])]
+    assert cig == [[(12, "M")], [(12, "M")], [(2, "M"), (1, "I"), (1, "M")]]
+
+
+def test_ingest_errors_match_the_oracle(orc, tmp_path):
+    ref = "ACGGTCATTGCA"
+    fa = tmp_path / "a.fasta"
+    fa.write_text(f">c\n{ref}\n")
+
+    def both(text):
+        p = tmp_path / "e.sam"
+        p.write_text(text)
+        try:
+            pp.ingest(str(fa), [str(p)])
+            got = (0, "")
+        except pp.PolypolishError as e:
+            got = (e.code, e.msg)
+        try:
+            orc.polish_files(str(fa), [str(p)])
+            want = (0, "")
+        except orc.OrcError as e:
+            want = (e.code, e.msg)
+        return got, want
+
+    for text in [
+        "r\t0\tc\t1\t60\t12M\n",                                    # too few columns
+        "r\t0\tc\t1\t60\t12M\t*\t0\t0\t" + ref + "\t*\n",            # missing NM tag
+        _line("r", 0, "c", 1, "12Q", ref),                          # invalid CIGAR
+        _line("r", 0, "c", 1, "12M", "*"),                          # no alignment contains sequence
+        _line("r", 0, "zzz", 1, "12M", ref),                        # contig not in assembly
+    ]:
+        got, want = both(text)
+        assert got == want and got[0] == 1, (got, want)
+    for text in ["@HD\tVN:1\n", _line("r", "x", "c", 1, "12M", ref), _line("r", 0, "c", 1, "*", ref)]:
+        got, want = both(text)  # the reference panics: only the exit code is comparable
+        assert got[0] == want[0] == 101, (got, want)
+    # errors the reference raises inside the CIGAR walk are raised by the device, not by the ingest
+    got, want = both(_line("r", 0, "c", 1, "4M2N6M", ref[:10]))
+    assert got[0] == 0 and want[0] == 1
+
+
+def test_fasta_errors_match_the_oracle(orc, tmp_path):
+    import ctypes
+    for text in ["", "A", ">\nACGT\n", "ACGT\n", ">a\n>b\nAC\n", ">a\nAC\n>a\nGG\n", ">a b\n"]:
+        p = tmp_path / "f.fasta"
+        p.write_text(text)
+        try:
+            pp.ingest(str(p), [])
+            got = (0, "")
+        except pp.PolypolishError as e:
+            got = (e.code, e.msg)
+        try:
+            orc.polish_files(str(p), [])
+            want = (0, "")
+        except orc.OrcError as e:
+            want = (e.code, e.msg)
+        assert got == want and got[0] == 1, (text, got, want)
