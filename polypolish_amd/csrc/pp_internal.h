@@ -21,7 +21,9 @@ constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed 
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
 
 // entry flags (entA.y bits 24..31)
-constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs
+constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs: walked run by run, trim done by k_prep
+constexpr uint32_t ENT_PRETRIM = 2u;   // no indel, but too long / overhanging for the fast path: trim done by k_prep
+constexpr uint32_t FAST_MAX_LEN = 252; // a read of <= 252 bases is one dword-per-lane wave load
 constexpr uint32_t KCLASS_NONDYADIC = 255u;
 
 // device-side error codes, packed as (record index << 8 | code) and combined with atomicMin so

@@ -28,7 +28,13 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, N_ROWS = 7 };
+// LDS counter rows of one window.  A..OTH hold EXPLICIT tallies (every base of slow-class items, and
+// the mismatching bases of fast-class items); COV is the coverage difference array of the fast
+// class (+1 at the first kept position of a read, -1 one past the last; prefix-summed before the
+// vote) and MIS the number of fast-class bases that differ from the assembly, so that the tally of
+// the assembly's own base is  explicit + COV - MIS  without touching LDS once per matching base.
+enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, ROW_COV = 7,
+       ROW_MIS = 8, N_ROWS = 9 };
 
 struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertion won the vote)
     u64 off;       // absolute offset of the winning string in the seq array
@@ -75,6 +81,19 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// trim of a read without indels: index of the first base of the trailing homopolymer; the kept
+// entries are [0, start-1) (alignment.rs:364-378: pop the run, then one more)
+__device__ __forceinline__ u32 simple_trim_start(const u8 *s, u32 sl) {
+    const u8 last = s[sl - 1];
+    u32 i = sl - 1;
+    while (i > 0 && s[i - 1] == last) i--;
+    return i;
+}
+__device__ __forceinline__ u32 simple_nkeep(const u8 *s, u32 sl) {
+    const u32 i = simple_trim_start(s, sl);
+    return i > 0 ? i - 1u : 0u;
 }
 
 // =============================================================================================
@@ -125,15 +144,23 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
     if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
     if (ref_span >= 0x7FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
 
+    const u64 clen = contig_off[c + 1] - contig_off[c];
+    const u32 rs = ref_start[a];
+    const u8 *s = seq + so;
+    u32 n_entries = (u32)ref_span;
+    if (!indel && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
+        // fast class (the bulk): k_tile loads the whole read anyway and trims it there, so the read
+        // bytes are not touched here; bucketed by its untrimmed span
+        gstart[a] = (u32)(contig_off[c] + rs);
+        nkeep[a] = n_entries;
+        return;
+    }
     // trim_bases_for_homopolymers (alignment.rs:364-378).  The last entry is the single base
     // seq[sl-1] (the last run is M/=).  `run` = number of trailing entries equal to it.
-    const u8 *s = seq + so;
     u8 last = s[sl - 1];
-    u32 n_entries = (u32)ref_span, run = 0;
+    u32 run = 0;
     if (!indel) {
-        u32 i = sl - 1;  // walk left over the trailing homopolymer
-        while (i > 0 && s[i - 1] == last) i--;
-        run = sl - i;
+        run = sl - simple_trim_start(s, sl);
     } else {
         u64 ro = 0;
         for (u32 r = 0; r < nc; r++) {
@@ -156,13 +183,10 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
     }
     u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
     if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
-
-    u64 clen = contig_off[c + 1] - contig_off[c];
-    u32 rs = ref_start[a];
     if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
     gstart[a] = (u32)(contig_off[c] + rs);
     nkeep[a] = nk;
-    aflag[a] = indel ? (u8)ENT_COMPLEX : (u8)0;
+    aflag[a] = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
 }
 
 // =============================================================================================
@@ -363,9 +387,98 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
     return v;
 }
 
+// ---- fast class of work items: a read without indels, <= FAST_MAX_LEN bases, inside its contig ----
+struct FastItem {  // wave-uniform (built from v_readlane results)
+    u64 so;    // offset of the read in the seq array
+    int rel;   // global start of the read minus the window start
+    u32 L;     // read length == number of entries before the trim
+    u32 kc;    // depth-share class of 1/k
+    u32 mis;   // (address of the read) & 3
+    bool on;
+};
+
+__device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, const u8 *seq) {
+    const int jj = (int)min(j, nb - 1u);
+    const u32 x = (u32)__builtin_amdgcn_readlane((int)my.x, jj), y = (u32)__builtin_amdgcn_readlane((int)my.y, jj);
+    FastItem f;
+    f.so = (u64)x | ((u64)(y & 0xFFFFu) << 32);
+    f.rel = __builtin_amdgcn_readlane((int)my.z, jj);
+    f.L = (u32)__builtin_amdgcn_readlane((int)my.w, jj);
+    f.kc = (y >> 16) & 0xFFu;
+    f.mis = (u32)(((uintptr_t)(seq + f.so)) & 3u);
+    f.on = j < nb && ((y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) == 0;
+    return f;
+}
+
+// One aligned dword per lane covers the whole read (<= 252 bases + <= 3 bytes of misalignment).
+// An aligned dword that holds at least one byte of the read never leaves the read's pages.
+__device__ __forceinline__ u32 fast_load(const u8 *seq, const FastItem &f, u32 lane) {
+    u32 w = 0;
+    if (f.on && 4u * lane < f.mis + f.L) w = *((const u32 *)(seq + f.so - f.mis) + lane);
+    return w;
+}
+
+// trim (alignment.rs:364-378) by ballot; then (pileup.rs:56-65,189-200) either explicit LDS atomics
+// per kept base (reads whose depth share is not 1) or, for the bulk, two coverage-difference
+// atomics per read plus a 4-bases-at-a-time comparison against the assembly window in LDS, with
+// per-base atomics only where the read differs from the assembly.
+__device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const FastItem &f, u32 word, u32 lane) {
+    if (!f.on) return;
+    const u32 mis = f.mis;
+    const int ib = (int)(4u * lane) - (int)mis;      // read index of this lane's byte 0
+    const u32 tl = mis + f.L - 1u;                    // byte position of the last base in the wave load
+    const u32 lw = (u32)__builtin_amdgcn_readlane((int)word, (int)(tl >> 2));
+    const u32 c_last = (lw >> (8u * (tl & 3u))) & 0xFFu;
+    int hi_i = -1;  // highest read index in this lane whose base differs from the last base
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int i = ib + b;
+        const u32 c = (word >> (8 * b)) & 0xFFu;
+        if (i >= 0 && i < (int)f.L && c != c_last) hi_i = i;
+    }
+    const u64 m = __ballot(hi_i >= 0);
+    int nkeep = 0;  // index of the last base that differs: the run after it and that base are popped
+    if (m) nkeep = __builtin_amdgcn_readlane(hi_i, 63 - __clzll((long long)m));
+    const int lo = max(0, -f.rel), hi = min(nkeep, TILE - f.rel);
+    if (hi <= lo) return;
+    if (f.kc != 0) {
+        // byte order rotated by lane/8 so that the 32 lanes of an LDS group hit 32 different banks
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int b = (jj + (int)(lane >> 3)) & 3;
+            const int i = ib + b;
+            if (i >= lo && i < hi) tile_add(cnt, row_of((word >> (8 * b)) & 0xFFu), f.rel + i, f.kc);
+        }
+        return;
+    }
+    if (lane == 0) {
+        atomicAdd(&cnt[ROW_COV * TILE + f.rel + lo], 1u);
+        if (f.rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + f.rel + hi], 0xFFFFFFFFu);
+    }
+    const int lowb = max(0, lo - ib), highb = min(4, hi - ib);
+    if (lowb < highb) {
+        const u32 M = (0xFFFFFFFFu >> (8 * (4 - highb))) & (0xFFFFFFFFu << (8 * lowb));
+        const int P0 = f.rel + ib;                 // window position of byte 0 (>= -3 here)
+        const u32 ai = (u32)(P0 + 4);              // asm_w holds the window bytes at byte offset 4
+        const u32 w0 = asm_w[ai >> 2], w1 = asm_w[(ai >> 2) + 1];
+        const u32 av = __builtin_amdgcn_alignbyte(w1, w0, ai & 3u);
+        const u32 diff = (word ^ av) & M;
+        if (diff) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((diff >> (8 * b)) & 0xFFu) {
+                    atomicAdd(&cnt[row_of((word >> (8 * b)) & 0xFFu) * TILE + P0 + b], 1u);
+                    atomicAdd(&cnt[ROW_MIS * TILE + P0 + b], 1u);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1;
+    __shared__ u32 asm_w[TILE / 4 + 4];  // the window's assembly bytes at byte offset 4 (1 dword of slack each side)
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64];
     __shared__ u64 s_depth;
 
     // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
@@ -376,6 +489,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     const u64 w0 = (u64)w * TILE;
 
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    {
+        u8 *ab = (u8 *)asm_w;
+        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[4 + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        if (tid < 4) { ab[tid] = 0; ab[4 + TILE + tid] = 0; }
+        if (tid < 8) ab[8 + TILE + tid] = 0;
+    }
     if (tid == 0) {
         s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0;
         s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
@@ -385,42 +504,82 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     __syncthreads();
 
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    for (u32 e = e0 + wave; e < e1; e += TILE_THREADS / 64) {
-        const uint4 ent = A.entA[e];
-        const int rel = (int)ent.z, nkeep = (int)ent.w;
-        const u32 kc = (ent.y >> 16) & 0xFFu;
-        const u64 so = (u64)ent.x | ((u64)(ent.y & 0xFFFFu) << 32);
-        if (!((ent.y >> 24) & ENT_COMPLEX)) {
-            // single run of read bases: entry i is base i
-            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-            const u8 *s = A.seq + so;
-            for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
-        } else {
-            const u32 idx = A.entB[e];
-            const u32 *cg = A.cigar + A.cig_off[idx];
-            const u32 nc = A.n_cig[idx];
-            const u8 *s = A.seq + so;
-            int ent0 = 0;
-            u64 ro = 0;
-            for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
-                const u32 op = cg[r], len = op >> 4, o = op & 15u;
-                if (o == PP_OP_I) { ro += len; continue; }
-                u32 ins = 0;
-                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
-                const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
-                for (int q = a + (int)lane; q < b; q += 64) {
-                    const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
-                    int row;
-                    if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
-                    else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
-                    tile_add(cnt, row, rel + q, kc);
+    // Each wave takes 64 work items at a time: one coalesced 1 KiB load of their 16-byte records,
+    // fields broadcast with v_readlane (-> SGPRs), then the fast class four items at a time so
+    // that four read loads are in flight per wave.
+    for (u32 eb = e0 + wave * 64u; eb < e1; eb += (TILE_THREADS / 64) * 64u) {
+        const u32 nb = min(64u, e1 - eb);
+        const uint4 my = A.entA[eb + min(lane, nb - 1u)];
+        const bool my_slow = lane < nb && ((my.y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) != 0;
+        for (u32 j = 0; j < nb; j += 4) {
+            FastItem f[4];
+            u32 wd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                f[u] = fast_fetch(my, j + (u32)u, nb, A.seq);
+                wd[u] = fast_load(A.seq, f[u], lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) fast_apply(cnt, asm_w, f[u], wd[u], lane);
+        }
+        u64 slow = __ballot(my_slow);
+        while (slow) {
+            const int j = __ffsll((long long)slow) - 1;
+            slow &= slow - 1;
+            const u32 ex = (u32)__builtin_amdgcn_readlane((int)my.x, j), ey = (u32)__builtin_amdgcn_readlane((int)my.y, j);
+            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.w, j);
+            const u32 kc = (ey >> 16) & 0xFFu;
+            const u8 *s = A.seq + ((u64)ex | ((u64)(ey & 0xFFFFu) << 32));
+            if (!((ey >> 24) & ENT_COMPLEX)) {
+                // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
+                const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+                for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+            } else {
+                const u32 idx = A.entB[eb + (u32)j];
+                const u32 *cg = A.cigar + A.cig_off[idx];
+                const u32 nc = A.n_cig[idx];
+                int ent0 = 0;
+                u64 ro = 0;
+                for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+                    const u32 op = cg[r], len = op >> 4, o = op & 15u;
+                    if (o == PP_OP_I) { ro += len; continue; }
+                    u32 ins = 0;
+                    for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+                    const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+                    for (int q = a + (int)lane; q < b; q += 64) {
+                        const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+                        int row;
+                        if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
+                        else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
+                        tile_add(cnt, row, rel + q, kc);
+                    }
+                    ent0 += (int)len;
+                    if (o != PP_OP_D) ro += len;
                 }
-                ent0 += (int)len;
-                if (o != PP_OP_D) ro += len;
             }
         }
     }
     if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
+    __syncthreads();
+
+    // ---- coverage of the fast class: prefix sum of the difference array, in place ----
+    {
+        u32 *cov = cnt + ROW_COV * TILE;
+        const u32 d0 = cov[2 * tid], d1 = cov[2 * tid + 1];
+        const u32 sum = d0 + d1;
+        u32 inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += v;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 base = 0;
+        for (u32 i = 0; i < wave; i++) base += s_wsum[i];
+        const u32 ex = base + inc - sum;
+        cov[2 * tid] = ex + d0;
+        cov[2 * tid + 1] = ex + d0 + d1;
+    }
     __syncthreads();
 
     // ---- vote: one lane per position ----
@@ -430,13 +589,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
         const u64 gp = w0 + p;
         if (gp >= A.G) break;
-        const u32 nA = cnt[ROW_A * TILE + p], nC = cnt[ROW_C * TILE + p], nT = cnt[ROW_T * TILE + p],
-                  nG = cnt[ROW_G * TILE + p], nDel = cnt[ROW_DEL * TILE + p],
-                  nOth = cnt[ROW_OTH * TILE + p], defw = cnt[ROW_DEF * TILE + p];
+        u32 nA = cnt[ROW_A * TILE + p], nC = cnt[ROW_C * TILE + p], nT = cnt[ROW_T * TILE + p],
+            nG = cnt[ROW_G * TILE + p], nDel = cnt[ROW_DEL * TILE + p], nOth = cnt[ROW_OTH * TILE + p];
+        const u32 defw = cnt[ROW_DEF * TILE + p];
+        const u8 orig = ((const u8 *)asm_w)[4 + p];
+        {   // fast-class bases equal to the assembly base were never tallied one by one
+            const u32 same = cnt[ROW_COV * TILE + p] - cnt[ROW_MIS * TILE + p];
+            const int ro = row_of(orig);
+            nA += (ro == ROW_A) ? same : 0u; nC += (ro == ROW_C) ? same : 0u; nT += (ro == ROW_T) ? same : 0u;
+            nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
+        }
         const bool nd = (defw >> 31) != 0;
         const u32 deficit = defw & 0x7FFFFFFFu;
         const u32 ntot = nA + nC + nG + nT + nDel + nOth;
-        const u8 orig = A.bases[gp];
         if (orig >= 0x80u) report(A.status, gp, DE_NON_ASCII);
         const u64 dfx = ((u64)ntot << DEPTH_FX_BITS) - deficit;
         const double depth = (double)dfx * (1.0 / (double)(1u << DEPTH_FX_BITS));  // exact
@@ -600,6 +765,8 @@ __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
         if (q < 0 || q >= (int)ent.w) continue;
         const u32 idx = A.entB[e];
         const u64 so = (u64)ent.x | ((u64)(ent.y & 0xFFFFu) << 32);
+        // fast-class items carry their untrimmed length: apply the trim here
+        if (((ent.y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.w)) continue;
         u64 s_rel;
         u32 len;
         if (!((ent.y >> 24) & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
