@@ -99,32 +99,9 @@ __device__ __forceinline__ u32 simple_nkeep(const u8 *s, u32 sl) {
 // =============================================================================================
 // k_prep
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
-                                              const u32 *__restrict__ ref_start,
-                                              const u32 *__restrict__ kk,
-                                              const u64 *__restrict__ seq_off,
-                                              const u32 *__restrict__ seq_len,
-                                              const u64 *__restrict__ cig_off,
-                                              const u32 *__restrict__ n_cig,
-                                              const u32 *__restrict__ cigar,
-                                              const u8 *__restrict__ seq,
-                                              const u64 *__restrict__ contig_off, u32 n_contigs,
-                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
-                                              u8 *__restrict__ aflag, u64 *status) {
-    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
-    gstart[a] = 0;
-    nkeep[a] = 0;
-    aflag[a] = 0;
-    u32 c = contig[a];
-    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); return; }
-    if (kk[a] == 0) { report(status, a, DE_BAD_K); return; }
-    u32 nc = n_cig[a];
-    u64 co = cig_off[a], so = seq_off[a];
-    u32 sl = seq_len[a];
-    if (nc == 0) { report(status, a, DE_BAD_RUN); return; }
-    const u32 *cg = cigar + co;
-
+// every record that is not a single short M run inside its contig
+__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
+                                               u64 c_lo, u64 c_hi, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
     // walk the runs (alignment.rs:178-194): spans and validity
     u64 ref_span = 0, read_span = 0;
     bool indel = false;
@@ -144,15 +121,14 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
     if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
     if (ref_span >= 0x7FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
 
-    const u64 clen = contig_off[c + 1] - contig_off[c];
-    const u32 rs = ref_start[a];
+    const u64 clen = c_hi - c_lo;
     const u8 *s = seq + so;
     u32 n_entries = (u32)ref_span;
     if (!indel && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
-        // fast class (the bulk): k_tile loads the whole read anyway and trims it there, so the read
+        // fast class (=/X runs): k_tile loads the whole read anyway and trims it there, so the read
         // bytes are not touched here; bucketed by its untrimmed span
-        gstart[a] = (u32)(contig_off[c] + rs);
-        nkeep[a] = n_entries;
+        *g_out = (u32)(c_lo + rs);
+        *nk_out = n_entries;
         return;
     }
     // trim_bases_for_homopolymers (alignment.rs:364-378).  The last entry is the single base
@@ -184,9 +160,50 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
     u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
     if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
     if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
-    gstart[a] = (u32)(contig_off[c] + rs);
-    nkeep[a] = nk;
-    aflag[a] = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
+    *g_out = (u32)(c_lo + rs);
+    *nk_out = nk;
+    *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
+}
+
+__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
+                                              const u32 *__restrict__ ref_start,
+                                              const u32 *__restrict__ kk,
+                                              const u64 *__restrict__ seq_off,
+                                              const u32 *__restrict__ seq_len,
+                                              const u64 *__restrict__ cig_off,
+                                              const u32 *__restrict__ n_cig,
+                                              const u32 *__restrict__ cigar,
+                                              const u8 *__restrict__ seq,
+                                              const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                              u8 *__restrict__ aflag, u64 *status) {
+    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    // independent loads first, then the dependent ones (clamped so that they are unconditional):
+    // two memory round trips per record instead of a chain of five
+    const u32 c = contig[a], k = kk[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
+    const u64 co = cig_off[a], so = seq_off[a];
+    const u32 cc = min(c, n_contigs - 1u);
+    const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1];
+    const u32 *cg = cigar + co;
+    const u32 op0 = nc ? cg[0] : 0u;
+    u32 g_out = 0, nk_out = 0;
+    u8 fl_out = 0;
+    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); }
+    else if (so + sl > (1ull << 40)) { report(status, a, DE_OVERFLOW); }
+    else if (k == 0) { report(status, a, DE_BAD_K); }
+    else if (nc == 0) { report(status, a, DE_BAD_RUN); }
+    else if (nc == 1 && (op0 & 15u) == PP_OP_M && (op0 >> 4) == sl && sl > 0 && sl <= FAST_MAX_LEN &&
+             (u64)rs + sl <= c_hi - c_lo) {
+        // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
+        g_out = (u32)(c_lo + rs);
+        nk_out = sl;
+    } else {
+        prep_general(a, rs, sl, so, cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+    }
+    gstart[a] = g_out;
+    nkeep[a] = nk_out;
+    aflag[a] = fl_out;
 }
 
 // =============================================================================================
@@ -214,20 +231,35 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
         hist[(u64)blockIdx.x * nwin + range_lo + i] = h[i];
 }
 
-// per window: exclusive scan of the per-block counts down the column, total to win_cnt
+// per window: exclusive scan of the per-block counts down the column (one wave per window, four
+// blocks per lane: nblocks <= 256), total to win_cnt
 __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
                                                    u32 *__restrict__ win_cnt, u64 *status) {
-    u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= nwin) return;
-    u64 run = 0;
-    for (u32 b = 0; b < nblocks; b++) {
-        u64 ix = (u64)b * nwin + w;
-        u32 t = hist[ix];
-        hist[ix] = (u32)run;
-        run += t;
+    u32 v[4];
+#pragma unroll
+    for (u32 i = 0; i < 4; i++) {
+        const u32 b = 4u * lane + i;
+        v[i] = (b < nblocks) ? hist[(u64)b * nwin + w] : 0u;
     }
-    if (run >= (u64)MAX_BUCKET) report(status, w, DE_TOO_DEEP);
-    win_cnt[w] = (u32)run;
+    const u32 sum = v[0] + v[1] + v[2] + v[3];
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    u32 run = inc - sum;
+#pragma unroll
+    for (u32 i = 0; i < 4; i++) {
+        const u32 b = 4u * lane + i;
+        if (b < nblocks) hist[(u64)b * nwin + w] = run;
+        run += v[i];
+    }
+    if (lane == 63) {
+        if (inc >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+        win_cnt[w] = inc;
+    }
 }
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                                                const u64 *__restrict__ seq_off, u32 nwin,
                                                const u32 *__restrict__ hist,
                                                const u32 *__restrict__ win_off,
-                                               uint4 *__restrict__ entA, u32 *__restrict__ entB) {
+                                               uint4 *__restrict__ entA) {
     __shared__ u32 cur[COUNT_RANGE];
     u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
     u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
@@ -286,13 +318,16 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
         u32 fl = aflag[a];
         for (u32 w = wa; w <= wb && w >= wa; w++) {
             u32 slot = atomicAdd(&cur[w - range_lo], 1u);
+            // work item, 16 bytes:
+            //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
+            //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
+            //   z  global start of the read minus the window start (signed)      w  record index (file order)
             uint4 e;
-            e.x = (u32)so;
-            e.y = ((u32)(so >> 32) & 0xFFFFu) | (kc << 16) | (fl << 24);
+            e.x = fl ? nk : (u32)so;
+            e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16);
             e.z = (u32)(int)((long long)g - (long long)w * TILE);
-            e.w = nk;
+            e.w = (u32)a;
             entA[slot] = e;
-            entB[slot] = (u32)a;
         }
     }
 }
@@ -302,7 +337,6 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
 // =============================================================================================
 struct TileArgs {
     const uint4 *entA;
-    const u32 *entB;
     const u32 *win_off;
     u32 nwin;
     const u8 *seq;
@@ -387,6 +421,106 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
     return v;
 }
 
+// LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
+// lane may read the five dwords around any window position it owns a byte of.
+constexpr int ASM_PAD = 16;
+constexpr int ASM_WORDS = TILE / 4 + 12;
+constexpr u32 PLAIN_MAX_LEN = 241;  // 16 lanes x 16 bytes minus up to 15 bytes of misalignment
+
+// ---- plain class: fast class, depth share 1, <= 241 bases -- four items per wave pass ------------
+// Lanes 16q..16q+15 own item q of the pass; lane s of a row owns the 16 read bytes of one aligned
+// dwordx4 load.  Everything per item lives in vector registers (no v_readlane, no per-item
+// branches); per-byte predicates are SWAR flags in bit 7 of each byte.
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_row(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int row_max16(int v) {  // max over the 16 lanes of a DPP row, in every lane
+    v = max(v, (int)dpp_row<0x128>((u32)v));  // row_ror:8
+    v = max(v, (int)dpp_row<0x124>((u32)v));  // row_ror:4
+    v = max(v, (int)dpp_row<0x122>((u32)v));  // row_ror:2
+    v = max(v, (int)dpp_row<0x121>((u32)v));  // row_ror:1
+    return v;
+}
+// bit 7 of every non-zero byte
+__device__ __forceinline__ u32 nz_flags(u32 x) {
+    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+// bit 7 of byte b of dword k set iff (4k + b) >= n, for 0 <= n <= 16 (n16 = n * 0x01010101)
+__device__ __forceinline__ u32 ge_flags(u32 n16, int k) {
+    return ((0x83828180u + 0x04040404u * (u32)k) - n16) & 0x80808080u;
+}
+__device__ __forceinline__ u32 pick4(const uint4 &v, int k) {
+    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ void plain_pass(u32 *cnt, const u32 *asm_w, const u8 *seq, const uint4 &my, u32 nb,
+                                           u32 first, u32 lane) {
+    const u32 s = lane & 15u;
+    const u32 j = first + (lane >> 4);  // item of the 64-item batch owned by this row
+    const int src = (int)(min(j, nb - 1u) << 2);
+    const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
+    const int rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    const u32 L = ey >> 24;
+    const bool plain = j < nb && (ey & 0x00FFFF00u) == 0 && L <= PLAIN_MAX_LEN;  // flags == 0 and share class == 0
+    const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
+    const uintptr_t ad = (uintptr_t)(seq + so);
+    const u32 mis = (u32)(ad & 15u);
+    const int ib = (int)(16u * s) - (int)mis;  // read index of this lane's byte 0
+    const bool active = plain && 16u * s < mis + L;
+    uint4 W = make_uint4(0, 0, 0, 0);
+    if (active) W = *((const uint4 *)(ad - mis) + s);  // aligned: never leaves the read's pages
+
+    // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base
+    const u32 tl = mis + L - 1u;  // byte position of the last base within the row's 256 bytes
+    const u32 selw = pick4(W, (int)((tl >> 2) & 3u));
+    const u32 lastw = (u32)__builtin_amdgcn_ds_bpermute((int)((((lane & 48u) + (tl >> 4)) & 63u) << 2), (int)selw);
+    const u32 pat = ((lastw >> (8u * (tl & 3u))) & 0xFFu) * 0x01010101u;
+    const int nvalid = min(max((int)L - ib, 0), 16);  // bytes of this lane below the read's end
+    const u32 nv16 = (u32)nvalid * 0x01010101u;
+    const u32 t0 = nz_flags(W.x ^ pat) & ~ge_flags(nv16, 0), t1 = nz_flags(W.y ^ pat) & ~ge_flags(nv16, 1),
+              t2 = nz_flags(W.z ^ pat) & ~ge_flags(nv16, 2), t3 = nz_flags(W.w ^ pat) & ~ge_flags(nv16, 3);
+    const u32 tk = t3 ? t3 : (t2 ? t2 : (t1 ? t1 : t0));
+    const int tb = t3 ? 12 : (t2 ? 8 : (t1 ? 4 : 0));
+    // highest differing byte of this lane as a read index (bytes before the read's start give a
+    // negative index: they can only win when no base of the read differs, and then nkeep is 0 anyway)
+    int hi_i = (tk && active) ? ib + tb + ((31 - __clz((int)tk)) >> 3) : -(1 << 20);
+    const int nkeep = max(row_max16(hi_i), 0);
+    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+    const bool live = plain && hi > lo;
+
+    // ---- coverage difference array (two atomics per read) ----
+    if (live && s == 0) {
+        atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+        if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+    }
+    // ---- compare this lane's 16 bases with the assembly; tally only the differing ones ----
+    const int b0 = min(max(lo - ib, 0), 16), b1 = min(max(hi - ib, 0), 16);
+    if (live && active && b1 > b0) {
+        const int P0 = rel + ib;                    // window position of byte 0 (>= -15 here)
+        const u32 ai = (u32)(P0 + ASM_PAD);
+        const u32 *ap = asm_w + (ai >> 2);
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+        const u32 sh = ai & 3u;
+        const u32 lo16 = (u32)b0 * 0x01010101u, hi16 = (u32)b1 * 0x01010101u;
+        u32 z0 = nz_flags(W.x ^ __builtin_amdgcn_alignbyte(a1, a0, sh)) & ge_flags(lo16, 0) & ~ge_flags(hi16, 0);
+        u32 z1 = nz_flags(W.y ^ __builtin_amdgcn_alignbyte(a2, a1, sh)) & ge_flags(lo16, 1) & ~ge_flags(hi16, 1);
+        u32 z2 = nz_flags(W.z ^ __builtin_amdgcn_alignbyte(a3, a2, sh)) & ge_flags(lo16, 2) & ~ge_flags(hi16, 2);
+        u32 z3 = nz_flags(W.w ^ __builtin_amdgcn_alignbyte(a4, a3, sh)) & ge_flags(lo16, 3) & ~ge_flags(hi16, 3);
+        while (z0 | z1 | z2 | z3) {  // rare: one trip per differing base of this lane
+            const int k = z0 ? 0 : (z1 ? 1 : (z2 ? 2 : 3));
+            const u32 zk = z0 ? z0 : (z1 ? z1 : (z2 ? z2 : z3));
+            const int b = (__ffs((int)zk) - 1) >> 3;
+            const u32 c = (pick4(W, k) >> (8 * b)) & 0xFFu;
+            const int p = P0 + 4 * k + b;
+            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+            const u32 cleared = zk & (zk - 1u);
+            if (k == 0) z0 = cleared; else if (k == 1) z1 = cleared; else if (k == 2) z2 = cleared; else z3 = cleared;
+        }
+    }
+}
+
 // ---- fast class of work items: a read without indels, <= FAST_MAX_LEN bases, inside its contig ----
 struct FastItem {  // wave-uniform (built from v_readlane results)
     u64 so;    // offset of the read in the seq array
@@ -401,12 +535,12 @@ __device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, c
     const int jj = (int)min(j, nb - 1u);
     const u32 x = (u32)__builtin_amdgcn_readlane((int)my.x, jj), y = (u32)__builtin_amdgcn_readlane((int)my.y, jj);
     FastItem f;
-    f.so = (u64)x | ((u64)(y & 0xFFFFu) << 32);
+    f.so = (u64)x | ((u64)(y & 0xFFu) << 32);
     f.rel = __builtin_amdgcn_readlane((int)my.z, jj);
-    f.L = (u32)__builtin_amdgcn_readlane((int)my.w, jj);
-    f.kc = (y >> 16) & 0xFFu;
+    f.L = y >> 24;
+    f.kc = (y >> 8) & 0xFFu;
     f.mis = (u32)(((uintptr_t)(seq + f.so)) & 3u);
-    f.on = j < nb && ((y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) == 0;
+    f.on = j < nb && ((y >> 16) & 0xFFu) == 0;
     return f;
 }
 
@@ -459,7 +593,7 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
     if (lowb < highb) {
         const u32 M = (0xFFFFFFFFu >> (8 * (4 - highb))) & (0xFFFFFFFFu << (8 * lowb));
         const int P0 = f.rel + ib;                 // window position of byte 0 (>= -3 here)
-        const u32 ai = (u32)(P0 + 4);              // asm_w holds the window bytes at byte offset 4
+        const u32 ai = (u32)(P0 + ASM_PAD);        // asm_w holds the window bytes at byte offset ASM_PAD
         const u32 w0 = asm_w[ai >> 2], w1 = asm_w[(ai >> 2) + 1];
         const u32 av = __builtin_amdgcn_alignbyte(w1, w0, ai & 3u);
         const u32 diff = (word ^ av) & M;
@@ -477,7 +611,7 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
 
 __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
-    __shared__ u32 asm_w[TILE / 4 + 4];  // the window's assembly bytes at byte offset 4 (1 dword of slack each side)
+    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64];
     __shared__ u64 s_depth;
 
@@ -491,9 +625,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
     {
         u8 *ab = (u8 *)asm_w;
-        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[4 + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
-        if (tid < 4) { ab[tid] = 0; ab[4 + TILE + tid] = 0; }
-        if (tid < 8) ab[8 + TILE + tid] = 0;
+        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        if (tid < (u32)ASM_PAD) ab[tid] = 0;
+        if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
     if (tid == 0) {
         s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0;
@@ -510,32 +644,32 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     for (u32 eb = e0 + wave * 64u; eb < e1; eb += (TILE_THREADS / 64) * 64u) {
         const u32 nb = min(64u, e1 - eb);
         const uint4 my = A.entA[eb + min(lane, nb - 1u)];
-        const bool my_slow = lane < nb && ((my.y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) != 0;
-        for (u32 j = 0; j < nb; j += 4) {
-            FastItem f[4];
-            u32 wd[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                f[u] = fast_fetch(my, j + (u32)u, nb, A.seq);
-                wd[u] = fast_load(A.seq, f[u], lane);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) fast_apply(cnt, asm_w, f[u], wd[u], lane);
+        const u32 my_flags = (my.y >> 16) & 0xFFu, my_kc = (my.y >> 8) & 0xFFu;
+        const bool my_slow = lane < nb && my_flags != 0;
+        const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN;
+        // plain class: 16 passes of four items
+        for (u32 first = 0; first < nb; first += 4) plain_pass(cnt, asm_w, A.seq, my, nb, first, lane);
+        // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
+        u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
+        while (rest) {
+            const u32 j = (u32)__ffsll((long long)rest) - 1u;
+            rest &= rest - 1;
+            const FastItem f = fast_fetch(my, j, nb, A.seq);
+            fast_apply(cnt, asm_w, f, fast_load(A.seq, f, lane), lane);
         }
         u64 slow = __ballot(my_slow);
         while (slow) {
             const int j = __ffsll((long long)slow) - 1;
             slow &= slow - 1;
-            const u32 ex = (u32)__builtin_amdgcn_readlane((int)my.x, j), ey = (u32)__builtin_amdgcn_readlane((int)my.y, j);
-            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.w, j);
-            const u32 kc = (ey >> 16) & 0xFFu;
-            const u8 *s = A.seq + ((u64)ex | ((u64)(ey & 0xFFFFu) << 32));
-            if (!((ey >> 24) & ENT_COMPLEX)) {
+            const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j), idx = (u32)__builtin_amdgcn_readlane((int)my.w, j);
+            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
+            const u32 kc = (ey >> 8) & 0xFFu;
+            const u8 *s = A.seq + A.seq_off[idx];
+            if (!((ey >> 16) & ENT_COMPLEX)) {
                 // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
                 const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
                 for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
             } else {
-                const u32 idx = A.entB[eb + (u32)j];
                 const u32 *cg = A.cigar + A.cig_off[idx];
                 const u32 nc = A.n_cig[idx];
                 int ent0 = 0;
@@ -592,7 +726,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
         u32 nA = cnt[ROW_A * TILE + p], nC = cnt[ROW_C * TILE + p], nT = cnt[ROW_T * TILE + p],
             nG = cnt[ROW_G * TILE + p], nDel = cnt[ROW_DEL * TILE + p], nOth = cnt[ROW_OTH * TILE + p];
         const u32 defw = cnt[ROW_DEF * TILE + p];
-        const u8 orig = ((const u8 *)asm_w)[4 + p];
+        const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
         {   // fast-class bases equal to the assembly base were never tallied one by one
             const u32 same = cnt[ROW_COV * TILE + p] - cnt[ROW_MIS * TILE + p];
             const int ro = row_of(orig);
@@ -720,9 +854,9 @@ struct ExactArgs {
     const u32 *flag_cov;
     const u64 *flag_scr;
     const uint4 *entA;
-    const u32 *entB;
     const u32 *win_off;
     const u8 *seq;
+    const u64 *seq_off;
     const u64 *cig_off;
     const u32 *n_cig;
     const u32 *cigar;
@@ -762,14 +896,14 @@ __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
     for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
         const uint4 ent = A.entA[e];
         const int q = pr - (int)ent.z;
-        if (q < 0 || q >= (int)ent.w) continue;
-        const u32 idx = A.entB[e];
-        const u64 so = (u64)ent.x | ((u64)(ent.y & 0xFFFFu) << 32);
+        const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
+        if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
+        const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
         // fast-class items carry their untrimmed length: apply the trim here
-        if (((ent.y >> 24) & (ENT_COMPLEX | ENT_PRETRIM)) == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.w)) continue;
+        if (fl == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
         u64 s_rel;
         u32 len;
-        if (!((ent.y >> 24) & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
         else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
         if (n < cap) {
             ulonglong2 v;
@@ -1191,7 +1325,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     }
     timer_begin(ctx, "bucket");
     hipLaunchKernelGGL(k_count, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin, d_hist);
-    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
+    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
     hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, d_winoff, d_status);
     timer_end(ctx);
     PP_HIPCHK(ctx, hipGetLastError());
@@ -1199,19 +1333,18 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     uint32_t n_entries = 0;
     PP_HIPCHK(ctx, hipMemcpyAsync(&n_entries, d_winoff + nwin, 4, hipMemcpyDeviceToHost, st));
     if ((rc = check_status(ctx))) return rc;  // synchronises
-    ENS(b_entA, (uint64_t)n_entries * 16); ENS(b_entB, (uint64_t)n_entries * 4);
+    ENS(b_entA, (uint64_t)n_entries * 16);
     uint4 *d_entA = (uint4 *)ctx->b_entA.p;
-    u32 *d_entB = (u32 *)ctx->b_entB.p;
     if (n) {
         timer_begin(ctx, "bucket");
         hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
                            d_aflag, B.k, (const u64 *)B.seq_off, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
-                           d_entA, d_entB);
+                           d_entA);
         timer_end(ctx);
     }
 
     TileArgs T;
-    T.entA = d_entA; T.entB = d_entB; T.win_off = d_winoff; T.nwin = nwin;
+    T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
     T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
     T.n_cig = B.n_cig; T.cigar = B.cigar;
     T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = ctx->n_contigs;
@@ -1243,7 +1376,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         ENS(b_multi, (uint64_t)n_flagged * sizeof(MultiEnt));
         ExactArgs E;
         E.n_flagged = n_flagged; E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
-        E.entA = d_entA; E.entB = d_entB; E.win_off = d_winoff; E.seq = B.seq;
+        E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
         E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
         E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = ctx->n_contigs;
         E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
