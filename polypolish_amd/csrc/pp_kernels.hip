@@ -138,23 +138,27 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     if (!indel) {
         run = sl - simple_trim_start(s, sl);
     } else {
-        u64 ro = 0;
-        for (u32 r = 0; r < nc; r++) {
-            u32 op = cg[r], len = op >> 4, o = op & 15u;
-            if (o == PP_OP_I) { ro += len; continue; }
-            u32 ins = 0;  // bases inserted right after this run (they extend its last entry)
-            for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+        // walk the entries from the right end and stop at the first one that differs from the
+        // last base (typically after 2-3 steps): runs in reverse; `pend` = bases inserted right
+        // after the run being visited (they extend its last entry)
+        u64 ro = sl;
+        u32 pend = 0;
+        bool stop = false;
+        for (u32 r = nc; r-- > 0 && !stop;) {
+            const u32 op = cg[r], len = op >> 4, o = op & 15u;
+            if (o == PP_OP_I) { ro -= len; pend += len; continue; }
             if (o == PP_OP_D) {
-                // len-1 empty slots, then a slot that is empty or holds the inserted bases
-                if (len > 1) run = 0;
-                if (ins == 1 && s[ro] == last) run += 1; else run = 0;
+                // last slot of the run: empty, or rewritten to the inserted bases; the others are empty
+                if (pend == 1 && s[ro] == last) { run += 1; if (len > 1) stop = true; }
+                else stop = true;
             } else {
-                for (u32 i = 0; i < len; i++) {
-                    bool extended = (i == len - 1) && ins > 0;
-                    if (!extended && s[ro + i] == last) run += 1; else run = 0;
+                for (u32 t = 0; t < len; t++) {
+                    const bool extended = (t == 0) && pend > 0;
+                    if (!extended && s[ro - 1 - t] == last) run += 1; else { stop = true; break; }
                 }
-                ro += len;
+                ro -= len;
             }
+            pend = 0;
         }
     }
     u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
@@ -218,32 +222,41 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
     for (u32 i = threadIdx.x; i < range_n; i += blockDim.x) h[i] = 0;
     __syncthreads();
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
-        u32 nk = nkeep[a];
-        if (!nk) continue;
-        u32 g = gstart[a];
-        u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
-        u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
-        for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
+        u32 nk[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
+            const u64 a = a0 + (u64)u * blockDim.x;
+            nk[u] = a < hi ? nkeep[a] : 0u;
+            g[u] = a < hi ? gstart[a] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!nk[u]) continue;
+            u32 w0 = g[u] / (u32)TILE, w1 = (g[u] + nk[u] - 1u) / (u32)TILE;
+            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+            for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+        }
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
         hist[(u64)blockIdx.x * nwin + range_lo + i] = h[i];
 }
 
-// per window: exclusive scan of the per-block counts down the column (one wave per window, four
-// blocks per lane: nblocks <= 256), total to win_cnt
+// per window: exclusive scan of the per-block counts down the column (one wave per window, eight
+// blocks per lane: nblocks <= 512), total to win_cnt
 __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
                                                    u32 *__restrict__ win_cnt, u64 *status) {
     const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= nwin) return;
-    u32 v[4];
+    u32 v[8];
+    u32 sum = 0;
 #pragma unroll
-    for (u32 i = 0; i < 4; i++) {
-        const u32 b = 4u * lane + i;
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
         v[i] = (b < nblocks) ? hist[(u64)b * nwin + w] : 0u;
+        sum += v[i];
     }
-    const u32 sum = v[0] + v[1] + v[2] + v[3];
     u32 inc = sum;
     for (int o = 1; o < 64; o <<= 1) {
         const u32 t = __shfl_up(inc, o, 64);
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
     }
     u32 run = inc - sum;
 #pragma unroll
-    for (u32 i = 0; i < 4; i++) {
-        const u32 b = 4u * lane + i;
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
         if (b < nblocks) hist[(u64)b * nwin + w] = run;
         run += v[i];
     }
@@ -306,28 +319,44 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
         cur[i] = win_off[range_lo + i] + hist[(u64)blockIdx.x * nwin + range_lo + i];
     __syncthreads();
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
-        u32 nk = nkeep[a];
-        if (!nk) continue;
-        u32 g = gstart[a];
-        u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
-        u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
-        if (wa > wb) continue;
-        u64 so = seq_off[a];
-        u32 kc = kclass_of(kk[a]);
-        u32 fl = aflag[a];
-        for (u32 w = wa; w <= wb && w >= wa; w++) {
-            u32 slot = atomicAdd(&cur[w - range_lo], 1u);
-            // work item, 16 bytes:
-            //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
-            //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
-            //   z  global start of the read minus the window start (signed)      w  record index (file order)
-            uint4 e;
-            e.x = fl ? nk : (u32)so;
-            e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16);
-            e.z = (u32)(int)((long long)g - (long long)w * TILE);
-            e.w = (u32)a;
-            entA[slot] = e;
+    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
+        u32 nk4[4], g4[4], k4[4], fl4[4];
+        u64 so4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
+            const u64 a = a0 + (u64)u * blockDim.x;
+            const bool ok = a < hi;
+            nk4[u] = ok ? nkeep[a] : 0u;
+            g4[u] = ok ? gstart[a] : 0u;
+            k4[u] = ok ? kk[a] : 1u;
+            fl4[u] = ok ? (u32)aflag[a] : 0u;
+            so4[u] = ok ? seq_off[a] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 nk = nk4[u];
+            if (!nk) continue;
+            const u64 a = a0 + (u64)u * blockDim.x;
+            const u32 g = g4[u];
+            u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
+            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+            if (wa > wb) continue;
+            const u64 so = so4[u];
+            const u32 kc = kclass_of(k4[u]);
+            const u32 fl = fl4[u];
+            for (u32 w = wa; w <= wb && w >= wa; w++) {
+                u32 slot = atomicAdd(&cur[w - range_lo], 1u);
+                // work item, 16 bytes:
+                //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
+                //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
+                //   z  global start of the read minus the window start (signed)      w  record index (file order)
+                uint4 e;
+                e.x = fl ? nk : (u32)so;
+                e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16);
+                e.z = (u32)(int)((long long)g - (long long)w * TILE);
+                e.w = (u32)a;
+                entA[slot] = e;
+            }
         }
     }
 }
@@ -454,22 +483,40 @@ __device__ __forceinline__ u32 pick4(const uint4 &v, int k) {
     return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }
 
-__device__ __forceinline__ void plain_pass(u32 *cnt, const u32 *asm_w, const u8 *seq, const uint4 &my, u32 nb,
-                                           u32 first, u32 lane) {
+struct PlainItem {  // per lane
+    uint4 W;     // this lane's 16 read bytes
+    int rel;     // global start of the read minus the window start
+    int ib;      // read index of this lane's byte 0
+    u32 L, mis;
+    bool plain, active;
+};
+
+// fields of the row's item (ds_bpermute from the batch registers) and the read load, issued early
+__device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my, u32 nb, u32 first, u32 lane) {
+    PlainItem it;
     const u32 s = lane & 15u;
     const u32 j = first + (lane >> 4);  // item of the 64-item batch owned by this row
     const int src = (int)(min(j, nb - 1u) << 2);
     const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
-    const int rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
-    const u32 L = ey >> 24;
-    const bool plain = j < nb && (ey & 0x00FFFF00u) == 0 && L <= PLAIN_MAX_LEN;  // flags == 0 and share class == 0
+    it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    it.L = ey >> 24;
+    it.plain = j < nb && (ey & 0x00FFFF00u) == 0 && it.L <= PLAIN_MAX_LEN;  // flags == 0 and share class == 0
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
-    const uintptr_t ad = (uintptr_t)(seq + so);
-    const u32 mis = (u32)(ad & 15u);
-    const int ib = (int)(16u * s) - (int)mis;  // read index of this lane's byte 0
-    const bool active = plain && 16u * s < mis + L;
-    uint4 W = make_uint4(0, 0, 0, 0);
-    if (active) W = *((const uint4 *)(ad - mis) + s);  // aligned: never leaves the read's pages
+    const u8 *rp = seq + so;
+    it.mis = (u32)((uintptr_t)rp & 15u);
+    it.ib = (int)(16u * s) - (int)it.mis;
+    it.active = it.plain && 16u * s < it.mis + it.L;
+    it.W = make_uint4(0, 0, 0, 0);
+    if (it.active) it.W = *((const uint4 *)(rp - it.mis) + s);  // aligned: never leaves the read's pages
+    return it;
+}
+
+__device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const PlainItem &it, u32 lane) {
+    const u32 s = lane & 15u;
+    const uint4 W = it.W;
+    const int rel = it.rel, ib = it.ib;
+    const u32 L = it.L, mis = it.mis;
+    const bool plain = it.plain, active = it.active;
 
     // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base
     const u32 tl = mis + L - 1u;  // byte position of the last base within the row's 256 bytes
@@ -647,8 +694,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
         const u32 my_flags = (my.y >> 16) & 0xFFu, my_kc = (my.y >> 8) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
         const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN;
-        // plain class: 16 passes of four items
-        for (u32 first = 0; first < nb; first += 4) plain_pass(cnt, asm_w, A.seq, my, nb, first, lane);
+        // plain class: passes of four items, the next pass's read load in flight behind the current one
+        PlainItem cur = plain_fetch(A.seq, my, nb, 0, lane);
+        for (u32 first = 0; first < nb; first += 4) {
+            const PlainItem nxt = plain_fetch(A.seq, my, nb, first + 4u, lane);
+            plain_apply(cnt, asm_w, cur, lane);
+            cur = nxt;
+        }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
         u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
         while (rest) {
@@ -1289,7 +1341,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     const uint64_t n = ctx->have_batch ? B.n_aln : 0;
     const uint64_t G = ctx->G;
     const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
-    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (n + 1023) / 1024));
+    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));
     const uint64_t chunk = (n + NB - 1) / NB;
     const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
