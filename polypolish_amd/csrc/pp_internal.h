@@ -40,6 +40,7 @@ enum DevErr : uint32_t {
     DE_INTERNAL = 9,
     DE_TOO_DEEP = 10,
     DE_OVERFLOW = 11,
+    DE_CAPACITY = 12,       // an optimistic device buffer was too small: the host grows it and reruns
 };
 
 struct DevBuf {
@@ -85,9 +86,10 @@ struct pp_ctx {
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
     pp::DevBuf b_in[9];  // uploaded batch arrays
-    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB;
+    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
-    pp::DevBuf b_multi, b_counters, b_stats, b_out, b_ctg_out;
+    pp::DevBuf b_multi, b_meta, b_out;
+    size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
 
     // ---- filter job ----

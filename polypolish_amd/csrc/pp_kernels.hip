@@ -276,10 +276,15 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
 }
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
+// n_ptr (optional) overrides n with a count held on the device; the total is also stored to *total_out;
+// a total above `limit` (capacity of the buffer the offsets index into) aborts the job with DE_CAPACITY
 template <typename T>
-__global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, T *__restrict__ out,
+__global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, const u32 *__restrict__ n_ptr,
+                                               T *__restrict__ out, u64 *__restrict__ total_out, u64 limit,
                                                u64 *status) {
     __shared__ u64 part[1024];
+    if (*status != ~0ull) return;
+    if (n_ptr) n = *n_ptr;
     u32 t = threadIdx.x;
     u64 per = (n + 1023) / 1024;
     u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
@@ -299,8 +304,11 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
         run += in[i];
     }
     if (t == 1023) {
-        out[n] = (T)part[1023];
-        if (sizeof(T) == 4 && part[1023] > 0xFFFFFFFFull) report(status, 0, DE_OVERFLOW);
+        const u64 total = part[1023];
+        out[n] = (T)total;
+        if (total_out) *total_out = total;
+        if (sizeof(T) == 4 && total > 0xFFFFFFFFull) report(status, 0, DE_OVERFLOW);
+        else if (total > limit) report(status, total, DE_CAPACITY);
     }
 }
 
@@ -311,8 +319,9 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                                                const u64 *__restrict__ seq_off, u32 nwin,
                                                const u32 *__restrict__ hist,
                                                const u32 *__restrict__ win_off,
-                                               uint4 *__restrict__ entA) {
+                                               uint4 *__restrict__ entA, const u64 *__restrict__ status) {
     __shared__ u32 cur[COUNT_RANGE];
+    if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
     u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
     u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
     for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
@@ -382,6 +391,7 @@ struct TileArgs {
     u8 *code;
     u32 *win_len;
     u32 *counters;  // [0] n_flagged, [1] n_multi
+    u32 cap_flag;
     u32 *flag_pos;
     u32 *flag_cov;
     ContigStatsDev *stats;
@@ -479,8 +489,12 @@ __device__ __forceinline__ u32 nz_flags(u32 x) {
 __device__ __forceinline__ u32 ge_flags(u32 n16, int k) {
     return ((0x83828180u + 0x04040404u * (u32)k) - n16) & 0x80808080u;
 }
-__device__ __forceinline__ u32 pick4(const uint4 &v, int k) {
-    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+__device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
+    return __builtin_amdgcn_perm(n, n, 0u);
+}
+// bits 0..3 <- the bit-7 flags of bytes 0..3 (the partial products never collide)
+__device__ __forceinline__ u32 gather_flags(u32 z) {
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
 }
 
 struct PlainItem {  // per lane
@@ -488,6 +502,7 @@ struct PlainItem {  // per lane
     int rel;     // global start of the read minus the window start
     int ib;      // read index of this lane's byte 0
     u32 L, mis;
+    u32 last;    // the read's last base (row-uniform)
     bool plain, active;
 };
 
@@ -507,7 +522,11 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my,
     it.ib = (int)(16u * s) - (int)it.mis;
     it.active = it.plain && 16u * s < it.mis + it.L;
     it.W = make_uint4(0, 0, 0, 0);
-    if (it.active) it.W = *((const uint4 *)(rp - it.mis) + s);  // aligned: never leaves the read's pages
+    it.last = 0;
+    if (it.active) {
+        it.W = *((const uint4 *)(rp - it.mis) + s);  // aligned: never leaves the read's pages
+        it.last = rp[it.L - 1u];                      // same address in the whole row: one L1/L2 hit
+    }
     return it;
 }
 
@@ -515,16 +534,13 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const Pl
     const u32 s = lane & 15u;
     const uint4 W = it.W;
     const int rel = it.rel, ib = it.ib;
-    const u32 L = it.L, mis = it.mis;
+    const u32 L = it.L;
     const bool plain = it.plain, active = it.active;
 
     // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base
-    const u32 tl = mis + L - 1u;  // byte position of the last base within the row's 256 bytes
-    const u32 selw = pick4(W, (int)((tl >> 2) & 3u));
-    const u32 lastw = (u32)__builtin_amdgcn_ds_bpermute((int)((((lane & 48u) + (tl >> 4)) & 63u) << 2), (int)selw);
-    const u32 pat = ((lastw >> (8u * (tl & 3u))) & 0xFFu) * 0x01010101u;
+    const u32 pat = splat8(it.last);
     const int nvalid = min(max((int)L - ib, 0), 16);  // bytes of this lane below the read's end
-    const u32 nv16 = (u32)nvalid * 0x01010101u;
+    const u32 nv16 = splat8((u32)nvalid);
     const u32 t0 = nz_flags(W.x ^ pat) & ~ge_flags(nv16, 0), t1 = nz_flags(W.y ^ pat) & ~ge_flags(nv16, 1),
               t2 = nz_flags(W.z ^ pat) & ~ge_flags(nv16, 2), t3 = nz_flags(W.w ^ pat) & ~ge_flags(nv16, 3);
     const u32 tk = t3 ? t3 : (t2 ? t2 : (t1 ? t1 : t0));
@@ -549,21 +565,22 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const Pl
         const u32 *ap = asm_w + (ai >> 2);
         const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
         const u32 sh = ai & 3u;
-        const u32 lo16 = (u32)b0 * 0x01010101u, hi16 = (u32)b1 * 0x01010101u;
+        const u32 lo16 = splat8((u32)b0), hi16 = splat8((u32)b1);
         u32 z0 = nz_flags(W.x ^ __builtin_amdgcn_alignbyte(a1, a0, sh)) & ge_flags(lo16, 0) & ~ge_flags(hi16, 0);
         u32 z1 = nz_flags(W.y ^ __builtin_amdgcn_alignbyte(a2, a1, sh)) & ge_flags(lo16, 1) & ~ge_flags(hi16, 1);
         u32 z2 = nz_flags(W.z ^ __builtin_amdgcn_alignbyte(a3, a2, sh)) & ge_flags(lo16, 2) & ~ge_flags(hi16, 2);
         u32 z3 = nz_flags(W.w ^ __builtin_amdgcn_alignbyte(a4, a3, sh)) & ge_flags(lo16, 3) & ~ge_flags(hi16, 3);
-        while (z0 | z1 | z2 | z3) {  // rare: one trip per differing base of this lane
-            const int k = z0 ? 0 : (z1 ? 1 : (z2 ? 2 : 3));
-            const u32 zk = z0 ? z0 : (z1 ? z1 : (z2 ? z2 : z3));
-            const int b = (__ffs((int)zk) - 1) >> 3;
-            const u32 c = (pick4(W, k) >> (8 * b)) & 0xFFu;
-            const int p = P0 + 4 * k + b;
-            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
-            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-            const u32 cleared = zk & (zk - 1u);
-            if (k == 0) z0 = cleared; else if (k == 1) z1 = cleared; else if (k == 2) z2 = cleared; else z3 = cleared;
+        if (z0 | z1 | z2 | z3) {  // rare: one trip per differing base of this lane
+            u32 m16 = gather_flags(z0) | (gather_flags(z1) << 4) | (gather_flags(z2) << 8) | (gather_flags(z3) << 12);
+            const u64 wlo = (u64)W.x | ((u64)W.y << 32), whi = (u64)W.z | ((u64)W.w << 32);
+            while (m16) {
+                const int i = __ffs((int)m16) - 1;  // byte 0..15 of this lane
+                m16 &= m16 - 1u;
+                const u32 c = (u32)(((i & 8) ? whi : wlo) >> (8 * (i & 7))) & 0xFFu;
+                const int p = P0 + i;
+                atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+            }
         }
     }
 }
@@ -665,7 +682,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
     // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
     u32 per = gridDim.x >> 3;
     u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (w >= A.nwin) return;
+    if (w >= A.nwin || *A.status != ~0ull) return;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
 
@@ -807,8 +824,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
         }
         if (flag) {
             const u32 slot = atomicAdd(&A.counters[0], 1u);
-            A.flag_pos[slot] = (u32)gp;
-            A.flag_cov[slot] = ntot;
+            if (slot < A.cap_flag) {
+                A.flag_pos[slot] = (u32)gp;
+                A.flag_cov[slot] = ntot;
+            } else {
+                report(A.status, slot, DE_CAPACITY);
+            }
             A.code[gp] = 0;
             continue;
         }
@@ -901,7 +922,7 @@ __device__ void heapsort_by_x(ulonglong2 *a, u32 n) {
 }
 
 struct ExactArgs {
-    u32 n_flagged;
+    u32 cap_multi;
     const u32 *flag_pos;
     const u32 *flag_cov;
     const u64 *flag_scr;
@@ -935,9 +956,15 @@ struct ExactArgs {
 constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
 constexpr u64 SL_DONE = 1ull << 63;
 
+__device__ void exact_one(const ExactArgs &A, u32 f);
+
 __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
-    u32 f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= A.n_flagged) return;
+    if (*A.status != ~0ull) return;
+    const u32 n_flagged = A.counters[0];
+    for (u32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_flagged; f += gridDim.x * blockDim.x) exact_one(A, f);
+}
+
+__device__ void exact_one(const ExactArgs &A, u32 f) {
     const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
     const u32 w = gp / (u32)TILE;
     const int pr = (int)(gp - w * (u32)TILE);
@@ -1049,9 +1076,13 @@ __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
         else {
             A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
             const u32 slot = atomicAdd(&A.counters[1], 1u);
-            MultiEnt m;
-            m.off = win_off; m.pos = gp; m.len = win_len; m.eff = eff; m.pad = 0;
-            A.multi[slot] = m;
+            if (slot < A.cap_multi) {
+                MultiEnt m;
+                m.off = win_off; m.pos = gp; m.len = win_len; m.eff = eff; m.pad = 0;
+                A.multi[slot] = m;
+            } else {
+                report(A.status, slot, DE_CAPACITY);
+            }
         }
         emit = eff;
     } else {
@@ -1092,8 +1123,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_compact(const u8 *__restrict__
                                                           const u64 *__restrict__ win_out,
                                                           const MultiEnt *__restrict__ multi,
                                                           const u32 *__restrict__ counters,
-                                                          u8 *__restrict__ out) {
+                                                          u8 *__restrict__ out, const u64 *__restrict__ status) {
     __shared__ u32 wsum[TILE_THREADS / 64];
+    if (*status != ~0ull) return;
     const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u64 p0 = (u64)w * TILE + 2ull * t;
     const u32 n_multi = counters[1];
@@ -1122,7 +1154,9 @@ __global__ __launch_bounds__(64) void k_finalize(const u8 *__restrict__ code, u6
                                                  const u32 *__restrict__ counters,
                                                  const u8 *__restrict__ seq,
                                                  const u64 *__restrict__ contig_off, u32 n_contigs,
-                                                 u8 *__restrict__ out, u64 *__restrict__ ctg_out) {
+                                                 u8 *__restrict__ out, u64 *__restrict__ ctg_out,
+                                                 const u64 *__restrict__ status) {
+    if (*status != ~0ull) return;
     const u32 n_multi = counters[1];
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_multi + n_contigs + 1u) return;
@@ -1324,11 +1358,118 @@ static int map_device_error(pp_ctx *ctx, uint64_t key) {
     }
 }
 
-static int check_status(pp_ctx *ctx) {
-    uint64_t key = 0;
-    PP_HIPCHK(ctx, hipMemcpyAsync(&key, ctx->b_status.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (key != ~0ull) return map_device_error(ctx, key);
+// One pass over the whole pipeline with the current buffer capacities.  Everything is enqueued on
+// the context's stream without an intermediate host round trip; the sizes that are only known on
+// the device (work items, flagged positions, replay scratch, polished bytes) are bounded by
+// optimistic capacities, a kernel that would overflow one raises DE_CAPACITY and every later
+// kernel then returns at once.  A single read-back of the metadata block ends the pass.
+static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_entries_out) {
+    hipStream_t st = ctx->stream;
+    const pp_aln_batch &B = ctx->dbatch;
+    const uint64_t n = ctx->have_batch ? B.n_aln : 0;
+    const uint64_t G = ctx->G;
+    const uint32_t nc = ctx->n_contigs;
+    const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
+    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));
+    const uint64_t chunk = (n + NB - 1) / NB;
+    const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
+    int rc;
+#define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
+    // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements |
+    // 5 polished bytes | 7.. contig output offsets (nc+1) | then per-contig stats (3 words each)
+    const size_t meta_words = 8 + (size_t)nc + 1 + 3 * (size_t)nc;
+    ENS(b_meta, meta_words * 8);
+    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); ENS(b_aflag, n);
+    ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+    ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
+    ENS(b_entA, ctx->cap_ent * 16);
+    ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
+    ENS(b_scratch, ctx->cap_scr * 16); ENS(b_multi, ctx->cap_multi * sizeof(MultiEnt)); ENS(b_out, ctx->cap_out);
+    if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
+#undef ENS
+    u64 *d_meta = (u64 *)ctx->b_meta.p;
+    u64 *d_status = d_meta;
+    u32 *d_counters = (u32 *)(d_meta + 1);
+    u64 *d_ctg_out = d_meta + 7;
+    ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 8 + nc);
+    PP_HIPCHK(ctx, hipMemsetAsync(d_meta, 0, meta_words * 8, st));
+    PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
+
+    u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
+    u8 *d_aflag = (u8 *)ctx->b_aflag.p;
+    u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
+    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
+    uint4 *d_entA = (uint4 *)ctx->b_entA.p;
+
+    if (n) {
+        timer_begin(ctx, "prep");
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
+                           B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
+                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, d_aflag, d_status);
+        timer_end(ctx);
+    }
+    timer_begin(ctx, "bucket");
+    hipLaunchKernelGGL(k_count, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin, d_hist);
+    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
+    hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
+                       d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
+    if (n)
+        hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
+                           d_aflag, B.k, (const u64 *)B.seq_off, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
+                           d_entA, (const u64 *)d_status);
+    timer_end(ctx);
+
+    TileArgs T;
+    T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
+    T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
+    T.n_cig = B.n_cig; T.cigar = B.cigar;
+    T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
+    T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
+    T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
+    T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
+    T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
+    T.stats = d_stats;
+    T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
+    T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
+    const uint32_t per = (nwin + 7) / 8;
+    timer_begin(ctx, "tile");
+    hipLaunchKernelGGL(k_tile, dim3(per * 8), dim3(TILE_THREADS), 0, st, T);
+    timer_end(ctx);
+
+    u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
+    timer_begin(ctx, "exact");
+    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
+                       d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
+    ExactArgs E;
+    E.cap_multi = (u32)ctx->cap_multi; E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
+    E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
+    E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
+    E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
+    E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
+    E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
+    E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
+    E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
+    E.status = d_status; E.dbg = T.dbg;
+    hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
+    timer_end(ctx);
+
+    u64 *d_winout = (u64 *)ctx->b_winout.p;
+    timer_begin(ctx, "emit");
+    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
+                       d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
+    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(TILE_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
+                       (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, (u8 *)ctx->b_out.p, (const u64 *)d_status);
+    const uint64_t nfin = ctx->cap_multi + nc + 1;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((nfin + 63) / 64)), dim3(64), 0, st, (const u8 *)T.code, (u64)G,
+                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters,
+                       B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
+    timer_end(ctx);
+    PP_HIPCHK(ctx, hipGetLastError());
+
+    meta.resize(meta_words);
+    PP_HIPCHK(ctx, hipMemcpyAsync(meta.data(), d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    *n_entries_out = (uint32_t)meta[3];
     return PP_OK;
 }
 
@@ -1336,141 +1477,46 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (!ctx) return PP_ERR_ARG;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_finish without pp_polish_begin");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const pp_aln_batch &B = ctx->dbatch;
-    const uint64_t n = ctx->have_batch ? B.n_aln : 0;
+    const uint64_t n = ctx->have_batch ? ctx->dbatch.n_aln : 0;
     const uint64_t G = ctx->G;
-    const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
-    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));
-    const uint64_t chunk = (n + NB - 1) / NB;
-    const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
-    int rc;
-    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    ctx->timers.clear();
+    const uint32_t nc = ctx->n_contigs;
+    // optimistic capacities (grow-only across jobs)
+    ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
+    ctx->cap_flag = std::max<size_t>(ctx->cap_flag, std::min<size_t>((size_t)G, std::max<size_t>(65536, (size_t)(G / 64))));
+    ctx->cap_scr = std::max<size_t>(ctx->cap_scr, (size_t)1 << 20);
+    ctx->cap_multi = std::max<size_t>(ctx->cap_multi, 65536);
+    ctx->cap_out = std::max<size_t>(ctx->cap_out, (size_t)(G + G / 16 + 65536));
 
-#define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
-    ENS(b_status, 8);
-    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); ENS(b_aflag, n);
-    ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
-    ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
-    ENS(b_flag_pos, G * 4); ENS(b_flag_cov, G * 4);
-    ENS(b_counters, 16); ENS(b_stats, (uint64_t)ctx->n_contigs * sizeof(ContigStatsDev));
-    ENS(b_ctg_out, ((uint64_t)ctx->n_contigs + 1) * 8);
-    if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
-
-    u64 *d_status = (u64 *)ctx->b_status.p;
-    PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
-    PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_counters.p, 0, 16, st));
-    PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_stats.p, 0, (size_t)ctx->n_contigs * sizeof(ContigStatsDev), st));
-
-    u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
-    u8 *d_aflag = (u8 *)ctx->b_aflag.p;
-    u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
-    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
-
-    if (n) {
-        timer_begin(ctx, "prep");
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
-                           B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
-                           B.n_cig, B.cigar, B.seq, d_ctg, ctx->n_contigs, d_gstart, d_nkeep, d_aflag, d_status);
-        timer_end(ctx);
-    }
-    timer_begin(ctx, "bucket");
-    hipLaunchKernelGGL(k_count, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin, d_hist);
-    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
-    hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, d_winoff, d_status);
-    timer_end(ctx);
-    PP_HIPCHK(ctx, hipGetLastError());
-
+    std::vector<uint64_t> meta;
     uint32_t n_entries = 0;
-    PP_HIPCHK(ctx, hipMemcpyAsync(&n_entries, d_winoff + nwin, 4, hipMemcpyDeviceToHost, st));
-    if ((rc = check_status(ctx))) return rc;  // synchronises
-    ENS(b_entA, (uint64_t)n_entries * 16);
-    uint4 *d_entA = (uint4 *)ctx->b_entA.p;
-    if (n) {
-        timer_begin(ctx, "bucket");
-        hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
-                           d_aflag, B.k, (const u64 *)B.seq_off, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
-                           d_entA);
-        timer_end(ctx);
+    for (int attempt = 0;; attempt++) {
+        for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+        ctx->timers.clear();
+        int rc = run_pipeline(ctx, meta, &n_entries);
+        if (rc) return rc;
+        const uint64_t key = meta[0];
+        if (key == ~0ull) break;
+        if ((key & 0xFF) != DE_CAPACITY) return map_device_error(ctx, key);
+        if (attempt >= 6) return ctx->fail(PP_ERR_HIP, "device buffers kept overflowing after %d attempts", attempt);
+        // grow whatever was too small (sizes the device got to before it stopped), then rerun
+        const uint32_t *cnt = (const uint32_t *)&meta[1];
+        bool grew = false;
+        auto grow = [&](size_t &cap, uint64_t need) {
+            if (need > cap) { cap = (size_t)(need + need / 8 + 1024); grew = true; }
+        };
+        grow(ctx->cap_ent, meta[3]);
+        grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G));
+        grow(ctx->cap_scr, meta[4]);
+        grow(ctx->cap_multi, cnt[1]);
+        grow(ctx->cap_out, meta[5]);
+        if (!grew) return ctx->fail(PP_ERR_HIP, "device reported a capacity overflow that the host cannot locate");
     }
-
-    TileArgs T;
-    T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
-    T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
-    T.n_cig = B.n_cig; T.cigar = B.cigar;
-    T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = ctx->n_contigs;
-    T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
-    T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
-    T.counters = (u32 *)ctx->b_counters.p; T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
-    T.stats = (ContigStatsDev *)ctx->b_stats.p;
-    T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
-    T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
-    const uint32_t per = (nwin + 7) / 8;
-    timer_begin(ctx, "tile");
-    hipLaunchKernelGGL(k_tile, dim3(per * 8), dim3(TILE_THREADS), 0, st, T);
-    timer_end(ctx);
-    PP_HIPCHK(ctx, hipGetLastError());
-
-    uint32_t counters[4] = {0, 0, 0, 0};
-    PP_HIPCHK(ctx, hipMemcpyAsync(counters, ctx->b_counters.p, 16, hipMemcpyDeviceToHost, st));
-    if ((rc = check_status(ctx))) return rc;
-    const uint32_t n_flagged = counters[0];
-    if (n_flagged) {
-        ENS(b_flag_scr, ((uint64_t)n_flagged + 1) * 8);
-        u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
-        timer_begin(ctx, "exact");
-        hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)ctx->b_flag_cov.p, (u64)n_flagged, d_scr, d_status);
-        uint64_t scr_total = 0;
-        PP_HIPCHK(ctx, hipMemcpyAsync(&scr_total, d_scr + n_flagged, 8, hipMemcpyDeviceToHost, st));
-        PP_HIPCHK(ctx, hipStreamSynchronize(st));
-        ENS(b_scratch, scr_total * 16);
-        ENS(b_multi, (uint64_t)n_flagged * sizeof(MultiEnt));
-        ExactArgs E;
-        E.n_flagged = n_flagged; E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
-        E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
-        E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
-        E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = ctx->n_contigs;
-        E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
-        E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
-        E.counters = T.counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = T.stats;
-        E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
-        E.status = d_status; E.dbg = T.dbg;
-        hipLaunchKernelGGL(k_exact, dim3((n_flagged + 63) / 64), dim3(64), 0, st, E);
-        timer_end(ctx);
-    } else {
-        ENS(b_multi, sizeof(MultiEnt));
-    }
-
-    u64 *d_winout = (u64 *)ctx->b_winout.p;
-    timer_begin(ctx, "emit");
-    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, d_winout, d_status);
-    timer_end(ctx);
-    uint64_t total_out = 0;
-    PP_HIPCHK(ctx, hipMemcpyAsync(&total_out, d_winout + nwin, 8, hipMemcpyDeviceToHost, st));
-    PP_HIPCHK(ctx, hipMemcpyAsync(counters, ctx->b_counters.p, 16, hipMemcpyDeviceToHost, st));
-    if ((rc = check_status(ctx))) return rc;
-    ENS(b_out, total_out);
-    timer_begin(ctx, "emit");
-    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(TILE_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
-                       (const MultiEnt *)ctx->b_multi.p, (const u32 *)T.counters, (u8 *)ctx->b_out.p);
-    const uint32_t nfin = counters[1] + ctx->n_contigs + 1;
-    hipLaunchKernelGGL(k_finalize, dim3((nfin + 63) / 64), dim3(64), 0, st, (const u8 *)T.code, (u64)G,
-                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)T.counters,
-                       B.seq, d_ctg, ctx->n_contigs, (u8 *)ctx->b_out.p, (u64 *)ctx->b_ctg_out.p);
-    timer_end(ctx);
-    PP_HIPCHK(ctx, hipGetLastError());
-
-    ctx->contig_out_off.resize(ctx->n_contigs + 1);
-    std::vector<ContigStatsDev> hs(ctx->n_contigs);
-    PP_HIPCHK(ctx, hipMemcpyAsync(ctx->contig_out_off.data(), ctx->b_ctg_out.p, (ctx->n_contigs + 1) * 8ull,
-                                  hipMemcpyDeviceToHost, st));
-    PP_HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->b_stats.p, ctx->n_contigs * sizeof(ContigStatsDev),
-                                  hipMemcpyDeviceToHost, st));
-    if ((rc = check_status(ctx))) return rc;
-    ctx->total_out = total_out;
-    ctx->stats.resize(ctx->n_contigs);
-    for (uint32_t c = 0; c < ctx->n_contigs; c++) {
+    const uint32_t *cnt = (const uint32_t *)&meta[1];
+    ctx->total_out = meta[5];
+    ctx->contig_out_off.assign(meta.begin() + 7, meta.begin() + 7 + nc + 1);
+    const ContigStatsDev *hs = (const ContigStatsDev *)&meta[8 + nc];
+    ctx->stats.resize(nc);
+    for (uint32_t c = 0; c < nc; c++) {
         ctx->stats[c].polished_len = ctx->contig_out_off[c + 1] - ctx->contig_out_off[c];
         ctx->stats[c].changed = hs[c].changed;
         ctx->stats[c].zero_depth = hs[c].zero_depth;
@@ -1479,12 +1525,11 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (ctx->profiling) {
         timers_collect(ctx, &ctx->last_times);
         ctx->last_times.n_entries = n_entries;
-        ctx->last_times.n_flagged = n_flagged;
+        ctx->last_times.n_flagged = cnt[0];
     }
     ctx->job_done = true;
     ctx->job_open = false;
     return PP_OK;
-#undef ENS
 }
 
 extern "C" int pp_polish_result_size(pp_ctx *ctx, uint64_t *total_bytes) {
@@ -1570,10 +1615,10 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
-                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB,
+                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_counters, &ctx->b_stats,
-                     &ctx->b_out, &ctx->b_ctg_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta,
+                     &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};
     for (DevBuf *b : all) dev_free(*b);
