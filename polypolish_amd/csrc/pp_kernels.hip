@@ -462,125 +462,117 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
 
 // LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
 // lane may read the five dwords around any window position it owns a byte of.
-constexpr int ASM_PAD = 16;
-constexpr int ASM_WORDS = TILE / 4 + 12;
-constexpr u32 PLAIN_MAX_LEN = 241;  // 16 lanes x 16 bytes minus up to 15 bytes of misalignment
+constexpr int ASM_PAD = 32;
+constexpr int ASM_WORDS = TILE / 4 + 24;
+constexpr u32 PLAIN_MAX_LEN = 225;  // 8 lanes x 32 bytes minus up to 31 bytes of misalignment
+constexpr u32 PLAIN_MIN_LEN = 8;    // the trim looks at the two aligned dwords that end the read
 
-// ---- plain class: fast class, depth share 1, <= 241 bases -- four items per wave pass ------------
-// Lanes 16q..16q+15 own item q of the pass; lane s of a row owns the 16 read bytes of one aligned
-// dwordx4 load.  Everything per item lives in vector registers (no v_readlane, no per-item
+// ---- plain class: fast class, depth share 1, 8..225 bases -- eight items per wave pass ------------
+// Lanes 8q..8q+7 own item q of the pass; lane s of the group owns the 32 read bytes of two aligned
+// dwordx4 loads.  Everything per item lives in vector registers (no v_readlane, no per-item
 // branches); per-byte predicates are SWAR flags in bit 7 of each byte.
-template <int CTRL>
-__device__ __forceinline__ u32 dpp_row(u32 v) {
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-}
-__device__ __forceinline__ int row_max16(int v) {  // max over the 16 lanes of a DPP row, in every lane
-    v = max(v, (int)dpp_row<0x128>((u32)v));  // row_ror:8
-    v = max(v, (int)dpp_row<0x124>((u32)v));  // row_ror:4
-    v = max(v, (int)dpp_row<0x122>((u32)v));  // row_ror:2
-    v = max(v, (int)dpp_row<0x121>((u32)v));  // row_ror:1
-    return v;
-}
 // bit 7 of every non-zero byte
 __device__ __forceinline__ u32 nz_flags(u32 x) {
     return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
-// bit 7 of byte b of dword k set iff (4k + b) >= n, for 0 <= n <= 16 (n16 = n * 0x01010101)
-__device__ __forceinline__ u32 ge_flags(u32 n16, int k) {
-    return ((0x83828180u + 0x04040404u * (u32)k) - n16) & 0x80808080u;
+// bit 7 of byte b of dword k set iff (4k + b) >= n, for 0 <= n <= 32 (n8 = n * 0x01010101)
+__device__ __forceinline__ u32 ge_flags(u32 n8, int k) {
+    return ((0x83828180u + 0x04040404u * (u32)k) - n8) & 0x80808080u;
 }
 __device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
     return __builtin_amdgcn_perm(n, n, 0u);
 }
-// bits 0..3 <- the bit-7 flags of bytes 0..3 (the partial products never collide)
-__device__ __forceinline__ u32 gather_flags(u32 z) {
-    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
-}
 
 struct PlainItem {  // per lane
-    uint4 W;     // this lane's 16 read bytes
-    int rel;     // global start of the read minus the window start
-    int ib;      // read index of this lane's byte 0
-    u32 L, mis;
-    u32 last;    // the read's last base (row-uniform)
+    uint4 Wa, Wb;      // this lane's 32 read bytes
+    uint2 tail;        // the two aligned dwords that end the read (row-uniform)
+    const u8 *lane_p;  // address of this lane's byte 0
+    int rel;           // global start of the read minus the window start
+    int ib;            // read index of this lane's byte 0
+    u32 L;
+    u32 ta;            // (address of the last base) & 3
     bool plain, active;
 };
 
-// fields of the row's item (ds_bpermute from the batch registers) and the read load, issued early
+// fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
 __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my, u32 nb, u32 first, u32 lane) {
     PlainItem it;
-    const u32 s = lane & 15u;
-    const u32 j = first + (lane >> 4);  // item of the 64-item batch owned by this row
+    const u32 s = lane & 7u;
+    const u32 j = first + (lane >> 3);  // item of the 64-item batch owned by this group
     const int src = (int)(min(j, nb - 1u) << 2);
     const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
     it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
     it.L = ey >> 24;
-    it.plain = j < nb && (ey & 0x00FFFF00u) == 0 && it.L <= PLAIN_MAX_LEN;  // flags == 0 and share class == 0
+    // flags == 0 and share class == 0, length in range
+    it.plain = j < nb && (ey & 0x00FFFF00u) == 0 && it.L <= PLAIN_MAX_LEN && it.L >= PLAIN_MIN_LEN;
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
     const u8 *rp = seq + so;
-    it.mis = (u32)((uintptr_t)rp & 15u);
-    it.ib = (int)(16u * s) - (int)it.mis;
-    it.active = it.plain && 16u * s < it.mis + it.L;
-    it.W = make_uint4(0, 0, 0, 0);
-    it.last = 0;
-    if (it.active) {
-        it.W = *((const uint4 *)(rp - it.mis) + s);  // aligned: never leaves the read's pages
-        it.last = rp[it.L - 1u];                      // same address in the whole row: one L1/L2 hit
+    const u32 mis = (u32)((uintptr_t)rp & 31u);
+    it.ib = (int)(32u * s) - (int)mis;
+    it.active = it.plain && 32u * s < mis + it.L;
+    it.lane_p = rp + it.ib;
+    it.Wa = make_uint4(0, 0, 0, 0);
+    it.Wb = make_uint4(0, 0, 0, 0);
+    it.tail = make_uint2(0, 0);
+    const u8 *lastp = rp + (it.L - 1u);
+    it.ta = (u32)((uintptr_t)lastp & 3u);
+    if (it.active) {  // aligned loads that hold at least one byte of the read never leave its pages
+        it.Wa = *((const uint4 *)it.lane_p);
+        if (32u * s + 16u < mis + it.L) it.Wb = *((const uint4 *)it.lane_p + 1);
+        const u32 *tp = (const u32 *)(lastp - it.ta - 4);  // same address in the whole group
+        it.tail = make_uint2(tp[0], tp[1]);
     }
     return it;
 }
 
 __device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const PlainItem &it, u32 lane) {
-    const u32 s = lane & 15u;
-    const uint4 W = it.W;
+    const u32 s = lane & 7u;
     const int rel = it.rel, ib = it.ib;
     const u32 L = it.L;
-    const bool plain = it.plain, active = it.active;
 
-    // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base
-    const u32 pat = splat8(it.last);
-    const int nvalid = min(max((int)L - ib, 0), 16);  // bytes of this lane below the read's end
-    const u32 nv16 = splat8((u32)nvalid);
-    const u32 t0 = nz_flags(W.x ^ pat) & ~ge_flags(nv16, 0), t1 = nz_flags(W.y ^ pat) & ~ge_flags(nv16, 1),
-              t2 = nz_flags(W.z ^ pat) & ~ge_flags(nv16, 2), t3 = nz_flags(W.w ^ pat) & ~ge_flags(nv16, 3);
-    const u32 tk = t3 ? t3 : (t2 ? t2 : (t1 ? t1 : t0));
-    const int tb = t3 ? 12 : (t2 ? 8 : (t1 ? 4 : 0));
-    // highest differing byte of this lane as a read index (bytes before the read's start give a
-    // negative index: they can only win when no base of the read differs, and then nkeep is 0 anyway)
-    int hi_i = (tk && active) ? ib + tb + ((31 - __clz((int)tk)) >> 3) : -(1 << 20);
-    const int nkeep = max(row_max16(hi_i), 0);
+    // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base,
+    // read off the last four bases; a trailing homopolymer of four or more takes the byte loop
+    const u32 t4 = (it.ta == 3u) ? it.tail.y : __builtin_amdgcn_alignbyte(it.tail.y, it.tail.x, it.ta + 1u);
+    const u32 last = t4 >> 24;
+    const u32 tf = nz_flags(t4 ^ splat8(last));
+    int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
+    if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
+        const u8 *rp = it.lane_p - ib;
+        u32 i = L - 4u;
+        while (i > 0 && rp[i - 1] == (u8)last) i--;
+        nkeep = i > 0 ? (int)i - 1 : 0;
+    }
     const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-    const bool live = plain && hi > lo;
+    const bool live = it.plain && hi > lo;
 
     // ---- coverage difference array (two atomics per read) ----
     if (live && s == 0) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
     }
-    // ---- compare this lane's 16 bases with the assembly; tally only the differing ones ----
-    const int b0 = min(max(lo - ib, 0), 16), b1 = min(max(hi - ib, 0), 16);
-    if (live && active && b1 > b0) {
-        const int P0 = rel + ib;                    // window position of byte 0 (>= -15 here)
+    // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
+    const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
+    if (live && it.active && b1 > b0) {
+        const int P0 = rel + ib;  // window position of byte 0 (>= -31 here)
         const u32 ai = (u32)(P0 + ASM_PAD);
         const u32 *ap = asm_w + (ai >> 2);
-        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], a5 = ap[5], a6 = ap[6], a7 = ap[7], a8 = ap[8];
         const u32 sh = ai & 3u;
-        const u32 lo16 = splat8((u32)b0), hi16 = splat8((u32)b1);
-        u32 z0 = nz_flags(W.x ^ __builtin_amdgcn_alignbyte(a1, a0, sh)) & ge_flags(lo16, 0) & ~ge_flags(hi16, 0);
-        u32 z1 = nz_flags(W.y ^ __builtin_amdgcn_alignbyte(a2, a1, sh)) & ge_flags(lo16, 1) & ~ge_flags(hi16, 1);
-        u32 z2 = nz_flags(W.z ^ __builtin_amdgcn_alignbyte(a3, a2, sh)) & ge_flags(lo16, 2) & ~ge_flags(hi16, 2);
-        u32 z3 = nz_flags(W.w ^ __builtin_amdgcn_alignbyte(a4, a3, sh)) & ge_flags(lo16, 3) & ~ge_flags(hi16, 3);
-        if (z0 | z1 | z2 | z3) {  // rare: one trip per differing base of this lane
-            u32 m16 = gather_flags(z0) | (gather_flags(z1) << 4) | (gather_flags(z2) << 8) | (gather_flags(z3) << 12);
-            const u64 wlo = (u64)W.x | ((u64)W.y << 32), whi = (u64)W.z | ((u64)W.w << 32);
-            while (m16) {
-                const int i = __ffs((int)m16) - 1;  // byte 0..15 of this lane
-                m16 &= m16 - 1u;
-                const u32 c = (u32)(((i & 8) ? whi : wlo) >> (8 * (i & 7))) & 0xFFu;
-                const int p = P0 + i;
-                atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
-                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-            }
+        const u32 lo8 = splat8((u32)b0), hi8 = splat8((u32)b1);
+#define PP_Z(k, w, ah, al) (nz_flags((w) ^ __builtin_amdgcn_alignbyte(ah, al, sh)) & ge_flags(lo8, k) & ~ge_flags(hi8, k))
+        // bit k of byte b of Z <=> byte b of dword k differs from the assembly
+        u32 Z = (PP_Z(0, it.Wa.x, a1, a0) >> 7) | (PP_Z(1, it.Wa.y, a2, a1) >> 6) | (PP_Z(2, it.Wa.z, a3, a2) >> 5) |
+                (PP_Z(3, it.Wa.w, a4, a3) >> 4) | (PP_Z(4, it.Wb.x, a5, a4) >> 3) | (PP_Z(5, it.Wb.y, a6, a5) >> 2) |
+                (PP_Z(6, it.Wb.z, a7, a6) >> 1) | PP_Z(7, it.Wb.w, a8, a7);
+#undef PP_Z
+        while (Z) {  // rare: one trip per differing base of this lane
+            const int pos = __ffs((int)Z) - 1;
+            Z &= Z - 1u;
+            const int i = 4 * (pos & 7) + (pos >> 3);  // byte 0..31 of this lane
+            const u32 c = it.lane_p[i];
+            const int p = P0 + i;
+            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
         }
     }
 }
@@ -673,7 +665,8 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
     }
 }
 
-__global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
+// two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64];
@@ -710,11 +703,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile(TileArgs A) {
         const uint4 my = A.entA[eb + min(lane, nb - 1u)];
         const u32 my_flags = (my.y >> 16) & 0xFFu, my_kc = (my.y >> 8) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
-        const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN;
-        // plain class: passes of four items, the next pass's read load in flight behind the current one
+        const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN &&
+                              (my.y >> 24) >= PLAIN_MIN_LEN;
+        // plain class: passes of eight items, the next pass's read loads in flight behind the current one
         PlainItem cur = plain_fetch(A.seq, my, nb, 0, lane);
-        for (u32 first = 0; first < nb; first += 4) {
-            const PlainItem nxt = plain_fetch(A.seq, my, nb, first + 4u, lane);
+        for (u32 first = 0; first < nb; first += 8) {
+            const PlainItem nxt = plain_fetch(A.seq, my, nb, first + 8u, lane);
             plain_apply(cnt, asm_w, cur, lane);
             cur = nxt;
         }
