@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000,
                     help="bp of the contig given to the CPU oracle (default: the whole 5 Mbp job, ~15-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--indel-frac", type=float, default=0.01, help="experiments only: fraction of reads with a 1-bp indel")
+    ap.add_argument("--sub-rate", type=float, default=0.002, help="experiments only: per-base substitution rate")
+    ap.add_argument("--n-rate", type=float, default=1e-4, help="experiments only: per-base N rate")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,7 +189,8 @@ def main():
     ctx = pp.Context(local_rank)
 
     # contig shard of this rank: its own 5 Mbp contig (seed differs per rank)
-    job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank)
+    job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank,
+                   indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate)
     torch.cuda.synchronize()
     gather_buf = torch.zeros(args.genome + (1 << 16), dtype=torch.uint8, device=device)
     gathered = [torch.empty_like(gather_buf) for _ in range(world)] if (world > 1 and rank == 0) else None

@@ -511,17 +511,18 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my,
     it.ib = (int)(32u * s) - (int)mis;
     it.active = it.plain && 32u * s < mis + it.L;
     it.lane_p = rp + it.ib;
-    it.Wa = make_uint4(0, 0, 0, 0);
-    it.Wb = make_uint4(0, 0, 0, 0);
-    it.tail = make_uint2(0, 0);
     const u8 *lastp = rp + (it.L - 1u);
     it.ta = (u32)((uintptr_t)lastp & 3u);
-    if (it.active) {  // aligned loads that hold at least one byte of the read never leave its pages
-        it.Wa = *((const uint4 *)it.lane_p);
-        if (32u * s + 16u < mis + it.L) it.Wb = *((const uint4 *)it.lane_p + 1);
-        const u32 *tp = (const u32 *)(lastp - it.ta - 4);  // same address in the whole group
-        it.tail = make_uint2(tp[0], tp[1]);
-    }
+    // Unconditional loads (no exec-mask regions): a lane without bytes of the read re-reads a safe
+    // address -- the group's first 16 bytes for a plain item, the (16-byte floored) start of the
+    // seq array otherwise.  Aligned loads that hold at least one byte of the read never leave its pages.
+    const u8 *safe = it.plain ? (rp - mis) : (const u8 *)((uintptr_t)seq & ~(uintptr_t)15);
+    const u8 *pa = it.active ? it.lane_p : safe;
+    const u8 *pb = (it.active && 32u * s + 16u < mis + it.L) ? it.lane_p + 16 : pa;
+    const u8 *pt = it.plain ? lastp - it.ta - 4 : safe;  // same address in the whole group
+    it.Wa = *((const uint4 *)pa);
+    it.Wb = *((const uint4 *)pb);
+    it.tail = make_uint2(((const u32 *)pt)[0], ((const u32 *)pt)[1]);
     return it;
 }
 
@@ -558,21 +559,37 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const Pl
         const u32 *ap = asm_w + (ai >> 2);
         const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], a5 = ap[5], a6 = ap[6], a7 = ap[7], a8 = ap[8];
         const u32 sh = ai & 3u;
-        const u32 lo8 = splat8((u32)b0), hi8 = splat8((u32)b1);
-#define PP_Z(k, w, ah, al) (nz_flags((w) ^ __builtin_amdgcn_alignbyte(ah, al, sh)) & ge_flags(lo8, k) & ~ge_flags(hi8, k))
-        // bit k of byte b of Z <=> byte b of dword k differs from the assembly
-        u32 Z = (PP_Z(0, it.Wa.x, a1, a0) >> 7) | (PP_Z(1, it.Wa.y, a2, a1) >> 6) | (PP_Z(2, it.Wa.z, a3, a2) >> 5) |
-                (PP_Z(3, it.Wa.w, a4, a3) >> 4) | (PP_Z(4, it.Wb.x, a5, a4) >> 3) | (PP_Z(5, it.Wb.y, a6, a5) >> 2) |
-                (PP_Z(6, it.Wb.z, a7, a6) >> 1) | PP_Z(7, it.Wb.w, a8, a7);
-#undef PP_Z
-        while (Z) {  // rare: one trip per differing base of this lane
-            const int pos = __ffs((int)Z) - 1;
-            Z &= Z - 1u;
-            const int i = 4 * (pos & 7) + (pos >> 3);  // byte 0..31 of this lane
-            const u32 c = it.lane_p[i];
-            const int p = P0 + i;
-            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
-            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+        // 8 bytes per compare: which of this lane's four qwords differ from the assembly at all
+#define PP_Q(q, wl, wh, x0, x1, x2)                                                                     \
+    (((((u64)(wh) << 32) | (wl)) != (((u64)__builtin_amdgcn_alignbyte(x2, x1, sh) << 32) |             \
+                                     __builtin_amdgcn_alignbyte(x1, x0, sh))) ? (1u << (q)) : 0u)
+        const u32 mq = PP_Q(0, it.Wa.x, it.Wa.y, a0, a1, a2) | PP_Q(1, it.Wa.z, it.Wa.w, a2, a3, a4) |
+                       PP_Q(2, it.Wb.x, it.Wb.y, a4, a5, a6) | PP_Q(3, it.Wb.z, it.Wb.w, a6, a7, a8);
+#undef PP_Q
+        // qwords entirely inside [b0, b1) need a closer look only when they differ; the (at most two)
+        // qwords cut by b0 or b1 always do, because the bytes outside belong to other reads
+        const int q0 = (b0 + 7) >> 3, q1 = b1 >> 3;
+        const u32 full = q1 > q0 ? (((1u << q1) - 1u) & ~((1u << q0) - 1u)) : 0u;
+        u32 todo = (mq & full) | ((b0 & 7) ? (1u << (b0 >> 3)) : 0u) | ((b1 & 7) ? (1u << (b1 >> 3)) : 0u);
+        while (todo) {
+            const int q = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            const u32 wl = q == 0 ? it.Wa.x : (q == 1 ? it.Wa.z : (q == 2 ? it.Wb.x : it.Wb.z));
+            const u32 wh = q == 0 ? it.Wa.y : (q == 1 ? it.Wa.w : (q == 2 ? it.Wb.y : it.Wb.w));
+            const u32 *aq = ap + 2 * q;
+            const u32 x0 = aq[0], x1 = aq[1], x2 = aq[2];
+            const u32 lo8 = splat8((u32)min(max(b0 - 8 * q, 0), 8)), hi8 = splat8((u32)min(max(b1 - 8 * q, 0), 8));
+            const u32 zl = nz_flags(wl ^ __builtin_amdgcn_alignbyte(x1, x0, sh)) & ge_flags(lo8, 0) & ~ge_flags(hi8, 0);
+            const u32 zh = nz_flags(wh ^ __builtin_amdgcn_alignbyte(x2, x1, sh)) & ge_flags(lo8, 1) & ~ge_flags(hi8, 1);
+            u32 Z = (zl >> 7) | (zh >> 6);  // bit k of byte b <=> byte b of dword k of the qword differs
+            while (Z) {  // one trip per differing base
+                const int pos = __ffs((int)Z) - 1;
+                Z &= Z - 1u;
+                const u32 c = (((pos & 1) ? wh : wl) >> (pos & 24)) & 0xFFu;
+                const int p = P0 + 8 * q + 4 * (pos & 1) + (pos >> 3);
+                atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+            }
         }
     }
 }
@@ -705,12 +722,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         const bool my_slow = lane < nb && my_flags != 0;
         const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN &&
                               (my.y >> 24) >= PLAIN_MIN_LEN;
-        // plain class: passes of eight items, the next pass's read loads in flight behind the current one
-        PlainItem cur = plain_fetch(A.seq, my, nb, 0, lane);
-        for (u32 first = 0; first < nb; first += 8) {
-            const PlainItem nxt = plain_fetch(A.seq, my, nb, first + 8u, lane);
-            plain_apply(cnt, asm_w, cur, lane);
-            cur = nxt;
+        // plain class: passes of eight items, the next pass's read loads in flight behind the current
+        // one; two passes per trip so that the two register sets alternate without copies
+        PlainItem pa = plain_fetch(A.seq, my, nb, 0, lane);
+        for (u32 first = 0; first < nb; first += 16) {
+            const PlainItem pb = plain_fetch(A.seq, my, nb, first + 8u, lane);
+            plain_apply(cnt, asm_w, pa, lane);
+            pa = plain_fetch(A.seq, my, nb, first + 16u, lane);
+            if (first + 8u < nb) plain_apply(cnt, asm_w, pb, lane);
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
         u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
