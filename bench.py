@@ -178,29 +178,38 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PP_BENCH_SHARE_GPU=1 (testing on a one-GPU box only): every rank uses GPU 0 and the gather goes
+    # through gloo on host copies, so that the N>1 control flow can be exercised without N GPUs
+    share = os.environ.get("PP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import polypolish_amd as pp
-    ctx = pp.Context(local_rank)
+    ctx = pp.Context(dev_index)
 
     # contig shard of this rank: its own 5 Mbp contig (seed differs per rank)
     job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank,
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate)
     torch.cuda.synchronize()
     gather_buf = torch.zeros(args.genome + (1 << 16), dtype=torch.uint8, device=device)
-    gathered = [torch.empty_like(gather_buf) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gdev = "cpu" if share else device
+    gathered = [torch.empty(gather_buf.shape, dtype=torch.uint8, device=gdev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
 
     def step():
         run_job(ctx, pp, job)
         if world > 1:
             # the only exchange of the path: polished contig bytes -> rank 0 (RCCL over xGMI)
             pp.lib().pp_polish_result(ctx._h, gather_buf.data_ptr(), pp.MEM_DEVICE, None, None)
-            dist.gather(gather_buf, gathered, dst=0)
+            dist.gather(gather_buf.cpu() if share else gather_buf, gathered, dst=0)
 
     ctx.set_profiling(False)
     for _ in range(args.warmup):
@@ -230,6 +239,17 @@ def main():
         elapsed = float(t.item())
     ctx.set_profiling(False)
 
+    gather_ok = None
+    if world > 1:
+        # every rank's polished bytes must have arrived on rank 0 unchanged: compare byte sums
+        mine, _, _ = ctx.result()
+        sums = torch.zeros(world, dtype=torch.int64, device=gdev)
+        sums[rank] = int(np.frombuffer(mine, dtype=np.uint8).sum(dtype=np.int64))
+        dist.all_reduce(sums)
+        if rank == 0:
+            n_out = len(mine)
+            gather_ok = all(int(gathered[r][:n_out].sum(dtype=torch.int64).item()) == int(sums[r].item())
+                            for r in range(world)) and bytes(gathered[0][:n_out].cpu().numpy()) == mine
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -270,6 +290,7 @@ def main():
                      "kernel_ms": round(tile_avg_ms, 4), "algorithmic_bytes": b_alg},
         "kernel_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(all_ms.items())},
         "planted_errors_recovered": bool(recovered),
+        "gather_verified": gather_ok,
         "changed_positions": stats[0]["changed"],
     }
 

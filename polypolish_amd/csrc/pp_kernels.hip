@@ -119,7 +119,7 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
         return;
     }
     if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
-    if (ref_span >= 0x7FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
+    if (ref_span >= 0x3FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
 
     const u64 clen = c_hi - c_lo;
     const u8 *s = seq + so;
@@ -180,13 +180,14 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
                                               const u8 *__restrict__ seq,
                                               const u64 *__restrict__ contig_off, u32 n_contigs,
                                               u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
-                                              u8 *__restrict__ aflag, u64 *status) {
+                                              u64 *status) {
     u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     // independent loads first, then the dependent ones (clamped so that they are unconditional):
-    // two memory round trips per record instead of a chain of five
-    const u32 c = contig[a], k = kk[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
-    const u64 co = cig_off[a], so = seq_off[a];
+    // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
+    // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
+    const u32 c = contig[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
+    const u64 co = cig_off[a];
     const u32 cc = min(c, n_contigs - 1u);
     const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1];
     const u32 *cg = cigar + co;
@@ -194,8 +195,6 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
     u32 g_out = 0, nk_out = 0;
     u8 fl_out = 0;
     if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); }
-    else if (so + sl > (1ull << 40)) { report(status, a, DE_OVERFLOW); }
-    else if (k == 0) { report(status, a, DE_BAD_K); }
     else if (nc == 0) { report(status, a, DE_BAD_RUN); }
     else if (nc == 1 && (op0 & 15u) == PP_OP_M && (op0 >> 4) == sl && sl > 0 && sl <= FAST_MAX_LEN &&
              (u64)rs + sl <= c_hi - c_lo) {
@@ -203,11 +202,10 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
         g_out = (u32)(c_lo + rs);
         nk_out = sl;
     } else {
-        prep_general(a, rs, sl, so, cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+        prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
     }
     gstart[a] = g_out;
-    nkeep[a] = nk_out;
-    aflag[a] = fl_out;
+    nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
 }
 
 // =============================================================================================
@@ -227,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
             const u64 a = a0 + (u64)u * blockDim.x;
-            nk[u] = a < hi ? nkeep[a] : 0u;
+            nk[u] = a < hi ? (nkeep[a] & 0x3FFFFFFFu) : 0u;
             g[u] = a < hi ? gstart[a] : 0u;
         }
 #pragma unroll
@@ -314,12 +312,12 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
 
 __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
                                                const u32 *__restrict__ nkeep,
-                                               const u8 *__restrict__ aflag,
                                                const u32 *__restrict__ kk,
-                                               const u64 *__restrict__ seq_off, u32 nwin,
+                                               const u64 *__restrict__ seq_off,
+                                               const u32 *__restrict__ seq_len, u32 nwin,
                                                const u32 *__restrict__ hist,
                                                const u32 *__restrict__ win_off,
-                                               uint4 *__restrict__ entA, const u64 *__restrict__ status) {
+                                               uint4 *__restrict__ entA, u64 *__restrict__ status) {
     __shared__ u32 cur[COUNT_RANGE];
     if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
     u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
@@ -335,11 +333,16 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
         for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
             const u64 a = a0 + (u64)u * blockDim.x;
             const bool ok = a < hi;
-            nk4[u] = ok ? nkeep[a] : 0u;
+            const u32 nkw = ok ? nkeep[a] : 0u;
+            nk4[u] = nkw & 0x3FFFFFFFu;
+            fl4[u] = nkw >> 30;
             g4[u] = ok ? gstart[a] : 0u;
             k4[u] = ok ? kk[a] : 1u;
-            fl4[u] = ok ? (u32)aflag[a] : 0u;
             so4[u] = ok ? seq_off[a] : 0ull;
+            if (ok && blockIdx.y == 0) {  // checks that need k / seq_off (not read by k_prep's fast path)
+                if (k4[u] == 0) report(status, a, DE_BAD_K);
+                else if (so4[u] + seq_len[a] > (1ull << 40)) report(status, a, DE_OVERFLOW);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1392,7 +1395,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // 5 polished bytes | 7.. contig output offsets (nc+1) | then per-contig stats (3 words each)
     const size_t meta_words = 8 + (size_t)nc + 1 + 3 * (size_t)nc;
     ENS(b_meta, meta_words * 8);
-    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); ENS(b_aflag, n);
+    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
     ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
     ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
     ENS(b_entA, ctx->cap_ent * 16);
@@ -1409,7 +1412,6 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
 
     u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
-    u8 *d_aflag = (u8 *)ctx->b_aflag.p;
     u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
     const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
     uint4 *d_entA = (uint4 *)ctx->b_entA.p;
@@ -1418,7 +1420,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         timer_begin(ctx, "prep");
         hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
                            B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
-                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, d_aflag, d_status);
+                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, d_status);
         timer_end(ctx);
     }
     timer_begin(ctx, "bucket");
@@ -1428,8 +1430,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                        d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
     if (n)
         hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
-                           d_aflag, B.k, (const u64 *)B.seq_off, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
-                           d_entA, (const u64 *)d_status);
+                           B.k, (const u64 *)B.seq_off, B.seq_len, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
+                           d_entA, d_status);
     timer_end(ctx);
 
     TileArgs T;
