@@ -34,7 +34,7 @@ OP_M, OP_I, OP_D = 0, 1, 2
 
 
 def make_job(device, G=5_000_000, coverage=200, read_len=150, seed=42, sub_rate=0.002, n_rate=1e-4,
-             asm_sub_rate=1e-4, indel_read_frac=0.01):
+             asm_sub_rate=1e-4, indel_read_frac=0.01, repeat_bp=0, repeat_k=5):
     """Synthetic polish job resident on `device` (SURVEY.md section 8d recipe, vectorised): uniform
     random truth, assembly = truth with substitutions at `asm_sub_rate`, reads = truth substrings
     with 0.2 % substitutions and 1e-4 N; `indel_read_frac` of the reads carry one 1-bp insertion
@@ -92,7 +92,7 @@ def make_job(device, G=5_000_000, coverage=200, read_len=150, seed=42, sub_rate=
     recs = {
         "contig": torch.zeros(n, dtype=torch.int32, device=device),
         "ref_start": start.int(),
-        "k": torch.ones(n, dtype=torch.int32, device=device),
+        "k": torch.where((start >= G // 5) & (start < G // 5 + repeat_bp), repeat_k, 1).int(),
         "seq_off": torch.arange(n, device=device, dtype=torch.int64) * L,
         "seq_len": torch.full((n,), L, dtype=torch.int32, device=device),
         "cig_off": cig_off,
@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--indel-frac", type=float, default=0.01, help="experiments only: fraction of reads with a 1-bp indel")
     ap.add_argument("--sub-rate", type=float, default=0.002, help="experiments only: per-base substitution rate")
     ap.add_argument("--n-rate", type=float, default=1e-4, help="experiments only: per-base N rate")
+    ap.add_argument("--repeat-bp", type=int, default=0,
+                    help="experiments only: reads starting in a region of this many bp get depth share 1/5 "
+                         "(order-dependent f64 depth -> exact replay kernel), as in configs[2]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,7 +200,8 @@ def main():
 
     # contig shard of this rank: its own 5 Mbp contig (seed differs per rank)
     job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank,
-                   indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate)
+                   indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate,
+                   repeat_bp=args.repeat_bp)
     torch.cuda.synchronize()
     gather_buf = torch.zeros(args.genome + (1 << 16), dtype=torch.uint8, device=device)
     gdev = "cpu" if share else device

@@ -393,8 +393,10 @@ struct TileArgs {
     double fv, fi;
     u8 *code;
     u32 *win_len;
-    u32 *counters;  // [0] n_flagged, [1] n_multi
+    u32 *counters;  // [0] positions on the global replay list, [1] n_multi, [2] all flagged positions
     u32 cap_flag;
+    u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
+    u32 *win_nflag;   // per window: number of flagged positions
     u32 *flag_pos;
     u32 *flag_cov;
     ContigStatsDev *stats;
@@ -689,7 +691,7 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64];
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag;
     __shared__ u64 s_depth;
 
     // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     const u64 w0 = (u64)w * TILE;
 
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    if (tid < (u32)(TILE / 32)) s_fbits[tid] = 0;
     {
         u8 *ab = (u8 *)asm_w;
         for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
     if (tid == 0) {
-        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0;
+        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0;
         s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
         u64 last = min(w0 + TILE, A.G) - 1;
         s_c1 = find_contig(A.contig_off, A.n_contigs, last);
@@ -839,12 +842,17 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             else v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
         }
         if (flag) {
-            const u32 slot = atomicAdd(&A.counters[0], 1u);
-            if (slot < A.cap_flag) {
-                A.flag_pos[slot] = (u32)gp;
-                A.flag_cov[slot] = ntot;
-            } else {
-                report(A.status, slot, DE_CAPACITY);
+            atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
+            atomicAdd(&s_nflag, 1u);
+            if (e1 - e0 > SORT_MAX) {
+                // bucket too large for the wave-per-position replay: global list for k_exact
+                const u32 slot = atomicAdd(&A.counters[0], 1u);
+                if (slot < A.cap_flag) {
+                    A.flag_pos[slot] = (u32)gp;
+                    A.flag_cov[slot] = ntot;
+                } else {
+                    report(A.status, slot, DE_CAPACITY);
+                }
             }
             A.code[gp] = 0;
             continue;
@@ -883,7 +891,10 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         if (my_depth) atomicAdd(&s_depth, my_depth);
     }
     __syncthreads();
+    if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
     if (tid == 0) {
+        A.win_nflag[w] = s_nflag;
+        if (s_nflag) atomicAdd(&A.counters[2], s_nflag);
         A.win_len[w] = s_len;
         if (s_changed) atomicAdd(&A.stats[s_c0].changed, (u64)s_changed);
         if (s_zero) atomicAdd(&A.stats[s_c0].zero_depth, (u64)s_zero);
@@ -939,6 +950,11 @@ __device__ void heapsort_by_x(ulonglong2 *a, u32 n) {
 
 struct ExactArgs {
     u32 cap_multi;
+    u32 cap_flag;
+    u32 *flag_pos_w;         // global replay list (k_exact2 appends key-table overflows)
+    u32 *flag_cov_w;
+    const u32 *flag_bits;
+    const u32 *win_nflag;
     const u32 *flag_pos;
     const u32 *flag_cov;
     const u64 *flag_scr;
@@ -1120,6 +1136,225 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
         A.dbg_counts[5 * A.G + gp] = v.vthr;
         A.dbg_counts[6 * A.G + gp] = v.ithr;
         A.dbg_status[gp] = v.status;
+    }
+}
+
+// =============================================================================================
+// k_exact2: wave-per-position exact replay for windows of up to SORT_MAX work items
+// =============================================================================================
+// One workgroup per window that has flagged positions: (1) bitonic sort of the window's work items
+// by record index (= SAM file order) in LDS, (2) per item its window-relative start and trimmed
+// extent, (3) every wave replays one flagged position at a time, 64 items per step: ballot tallies,
+// f64 depth accumulated in file order with v_readlane, a 64-entry string-keyed table (one key per
+// lane) for everything that is not A/C/G/T/-.  Same arithmetic as k_exact, ~40x faster.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return (u64)lo | ((u64)hi << 32);
+}
+
+__global__ __launch_bounds__(256) void k_exact2(ExactArgs A, u32 nwin) {
+    __shared__ u64 pk[SORT_MAX];  // sort keys (record index << 16 | slot), then (start | extent << 32)
+    __shared__ unsigned short sl[SORT_MAX];
+    const u32 w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (w >= nwin || *A.status != ~0ull) return;
+    if (A.win_nflag[w] == 0) return;
+    const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
+    if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
+
+    // ---- (1) sort by record index ----
+    u32 np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (u32 i = tid; i < np2; i += 256) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+    __syncthreads();
+    for (u32 k = 2; k <= np2; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 t = tid; t < (np2 >> 1); t += 256) {
+                const u32 i = (t / j) * 2u * j + (t % j), o = i + j;
+                const bool asc = (i & k) == 0;
+                const u64 a = pk[i], b = pk[o];
+                if ((a > b) == asc) { pk[i] = b; pk[o] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- (2) start and trimmed extent of every item, in file order ----
+    for (u32 i = tid; i < n; i += 256) {
+        const u32 slot = (u32)(pk[i] & 0xFFFFu);
+        const uint4 ent = A.entA[e0 + slot];
+        const u32 fl = (ent.y >> 16) & 0xFFu;
+        u32 lim;
+        if (fl) lim = ent.x;
+        else lim = simple_nkeep(A.seq + ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32)), ent.y >> 24);
+        sl[i] = (unsigned short)slot;
+        pk[i] = (u64)ent.z | ((u64)lim << 32);  // safe: each thread rewrites only the keys it read
+    }
+    __syncthreads();
+
+    // ---- (3) replay: one position per wave at a time ----
+    u32 seen = 0;
+    for (u32 word = 0; word < (u32)(TILE / 32); word++) {
+        u32 bits = A.flag_bits[(u64)w * (TILE / 32) + word];
+        while (bits) {
+            const u32 bit = (u32)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            if ((seen++ & 3u) != wave) continue;
+            const int pr = (int)(word * 32u + bit);
+            const u32 gp = w * (u32)TILE + (u32)pr;
+
+            double depth = 0.0;
+            u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0, ncov = 0;
+            u64 t_off = 0;  // string-keyed table: lane j holds key j
+            u32 t_len = 0, t_cnt = 0, ntab = 0;
+            bool overflow = false;
+            for (u32 c = 0; c < n; c += 64) {
+                const u32 i = c + lane;
+                const u64 v = i < n ? pk[i] : 0ull;
+                const u32 q = (u32)(pr - (int)(u32)v);
+                const bool cov = i < n && q < (u32)(v >> 32);
+                const u64 m = __ballot(cov);
+                if (!m) continue;
+                int row = -1;
+                double dc = 0.0;
+                u64 s_abs = 0;
+                u32 len = 0;
+                if (cov) {
+                    const uint4 ent = A.entA[e0 + sl[i]];
+                    const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu, idx = ent.w;
+                    const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+                    if (!(fl & ENT_COMPLEX)) { s_abs = so + q; len = 1; }
+                    else {
+                        u64 s_rel;
+                        entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], q, &s_rel, &len);
+                        s_abs = so + s_rel;
+                    }
+                    const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[idx]);
+                    dc = 1.0 / (double)k;
+                    row = len == 0 ? ROW_DEL : (len == 1 ? row_of(A.seq[s_abs]) : ROW_OTH);
+                }
+                ncov += (u32)__popcll(m);
+                nA += (u32)__popcll(__ballot(row == ROW_A));
+                nC += (u32)__popcll(__ballot(row == ROW_C));
+                nG += (u32)__popcll(__ballot(row == ROW_G));
+                nT += (u32)__popcll(__ballot(row == ROW_T));
+                nDel += (u32)__popcll(__ballot(row == ROW_DEL));
+                // depth: sequential f64 adds of 1.0/k in file order (pileup.rs:64, alignment.rs:288)
+                for (u64 mm = m; mm; mm &= mm - 1) depth += readlane_f64(dc, __ffsll((long long)mm) - 1);
+                // everything else is counted by string (pileup.rs:62)
+                for (u64 mo = __ballot(row == ROW_OTH); mo; mo &= mo - 1) {
+                    const int l = __ffsll((long long)mo) - 1;
+                    const u64 ko = readlane_u64(s_abs, l);
+                    const u32 kl = (u32)__builtin_amdgcn_readlane((int)len, l);
+                    bool match = lane < ntab && t_len == kl;
+                    if (match)
+                        for (u32 b = 0; b < kl; b++)
+                            if (A.seq[t_off + b] != A.seq[ko + b]) { match = false; break; }
+                    const u64 mt = __ballot(match);
+                    if (mt) {
+                        if ((int)lane == __ffsll((long long)mt) - 1) t_cnt++;
+                    } else if (ntab < 64) {
+                        if (lane == ntab) { t_off = ko; t_len = kl; t_cnt = 1; }
+                        ntab++;
+                    } else {
+                        overflow = true;
+                    }
+                    nOth++;
+                }
+            }
+            if (overflow) {
+                // more than 64 distinct keys: hand the position to the thread-serial kernel
+                if (lane == 0) {
+                    const u32 slot = atomicAdd(&A.counters[0], 1u);
+                    if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ncov; }
+                    else report(A.status, slot, DE_CAPACITY);
+                }
+                continue;
+            }
+            const u8 orig = A.bases[gp];
+            VoteOut vo = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+            u64 win_off = 0;
+            u32 win_len = 0;
+            if (vo.status != PP_ST_LOW_DEPTH && nOth > 0) {  // the tally of pileup.rs:77-109 with all keys
+                int nv = 0, ni = 0;
+                u8 win = 0;
+                const u32 c5[5] = {nA, nC, nG, nT, nDel};
+                const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
+                for (int j = 0; j < 5; j++) {
+                    if (j == 4 && nDel == 0) break;
+                    if (c5[j] >= vo.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= vo.ithr) ni++;
+                }
+                const bool tv = lane < ntab && t_cnt >= vo.vthr, ti = lane < ntab && !tv && t_cnt >= vo.ithr;
+                const u64 mv = __ballot(tv);
+                if (mv && !nv) {
+                    const int l = __ffsll((long long)mv) - 1;
+                    win_off = readlane_u64(t_off, l);
+                    win_len = (u32)__builtin_amdgcn_readlane((int)t_len, l);
+                }
+                nv += (int)__popcll(mv);
+                ni += (int)__popcll(__ballot(ti));
+                vo.out = (orig == (u8)'-') ? 0 : orig;
+                vo.status = PP_ST_KEPT;
+                if (nv == 1) {
+                    if (ni > 0) { vo.status = PP_ST_TOO_CLOSE; win_len = 0; }
+                    else if (win_len == 0) {
+                        vo.out = (win == (u8)'-') ? 0 : win;
+                        if (win != orig) vo.status = PP_ST_CHANGED;
+                    } else {
+                        vo.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+                    }
+                } else {
+                    win_len = 0;
+                    vo.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+                }
+            }
+            if (lane == 0) {
+                u32 emit;
+                if (win_len > 0) {
+                    u32 eff = 0;
+                    u8 only = 0;
+                    for (u32 b = 0; b < win_len; b++) {
+                        const u8 ch = A.seq[win_off + b];
+                        if (ch != (u8)'-') { eff++; only = ch; }
+                    }
+                    if (eff == 0) A.code[gp] = 0;
+                    else if (eff == 1 && only < 0x80u) A.code[gp] = only;
+                    else {
+                        A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
+                        const u32 slot = atomicAdd(&A.counters[1], 1u);
+                        if (slot < A.cap_multi) {
+                            MultiEnt me;
+                            me.off = win_off; me.pos = gp; me.len = win_len; me.eff = eff; me.pad = 0;
+                            A.multi[slot] = me;
+                        } else {
+                            report(A.status, slot, DE_CAPACITY);
+                        }
+                    }
+                    emit = eff;
+                } else {
+                    A.code[gp] = vo.out;
+                    emit = vo.out ? 1u : 0u;
+                }
+                if (emit) atomicAdd(&A.win_len[w], emit);
+                const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
+                if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
+                if (ncov == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
+                atomicAdd(&A.stats[cg].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+                if (A.dbg) {
+                    A.dbg_depth[gp] = depth;
+                    A.dbg_counts[0 * A.G + gp] = nA;
+                    A.dbg_counts[1 * A.G + gp] = nC;
+                    A.dbg_counts[2 * A.G + gp] = nG;
+                    A.dbg_counts[3 * A.G + gp] = nT;
+                    A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+                    A.dbg_counts[5 * A.G + gp] = vo.vthr;
+                    A.dbg_counts[6 * A.G + gp] = vo.ithr;
+                    A.dbg_status[gp] = vo.status;
+                }
+            }
+        }
     }
 }
 
@@ -1400,6 +1635,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
+    ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
     ENS(b_scratch, ctx->cap_scr * 16); ENS(b_multi, ctx->cap_multi * sizeof(MultiEnt)); ENS(b_out, ctx->cap_out);
     if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
 #undef ENS
@@ -1443,6 +1679,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
     T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
+    T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
     T.stats = d_stats;
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
@@ -1453,10 +1690,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
 
     u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
     timer_begin(ctx, "exact");
-    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
-                       d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     ExactArgs E;
-    E.cap_multi = (u32)ctx->cap_multi; E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
+    E.cap_multi = (u32)ctx->cap_multi; E.cap_flag = (u32)ctx->cap_flag;
+    E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
+    E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
     E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
@@ -1465,6 +1702,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
     E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
     E.status = d_status; E.dbg = T.dbg;
+    // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
+    // go through the global list to the thread-serial k_exact
+    hipLaunchKernelGGL(k_exact2, dim3(nwin), dim3(256), 0, st, E, nwin);
+    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
+                       d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
     timer_end(ctx);
 
@@ -1540,7 +1782,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (ctx->profiling) {
         timers_collect(ctx, &ctx->last_times);
         ctx->last_times.n_entries = n_entries;
-        ctx->last_times.n_flagged = cnt[0];
+        ctx->last_times.n_flagged = cnt[2];
     }
     ctx->job_done = true;
     ctx->job_open = false;
@@ -1632,7 +1874,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};
