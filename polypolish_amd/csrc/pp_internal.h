@@ -19,7 +19,7 @@ constexpr int TILE_THREADS = 1024;   // 16 waves; two workgroups per CU (57 KiB 
 constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the bucketing kernels
 constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
-constexpr uint32_t SORT_MAX = 8192;       // items per window the wave-per-position replay kernel sorts in LDS
+constexpr uint32_t SORT_MAX = 16384;      // items per window the ordered-depth replay kernel sorts in LDS (128 KiB)
 
 // entry flags (entA.y bits 24..31)
 constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs: walked run by run, trim done by k_prep
@@ -89,8 +89,8 @@ struct pp_ctx {
     pp::DevBuf b_in[9];  // uploaded batch arrays
     pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
-    pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag;
-    size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0;  // element capacities of the optimistic buffers
+    pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slabs, b_ents;
+    size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
 
     // ---- filter job ----

@@ -397,6 +397,9 @@ struct TileArgs {
     u32 cap_flag;
     u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
     u32 *win_nflag;   // per window: number of flagged positions
+    u32 *win_slab;    // per window: index of its tally slab (6 x 2048 u32), or ~0
+    u32 *slabs;
+    u32 cap_slabs;
     u32 *flag_pos;
     u32 *flag_cov;
     ContigStatsDev *stats;
@@ -687,6 +690,18 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
     }
 }
 
+// exact integer tallies of one window position from the LDS rows: explicit tallies plus, for the
+// assembly's own base, the fast-class bases that were never tallied one by one
+__device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p, u32 &nA, u32 &nC, u32 &nG, u32 &nT,
+                                                 u32 &nDel, u32 &nOth) {
+    nA = cnt[ROW_A * TILE + p]; nC = cnt[ROW_C * TILE + p]; nT = cnt[ROW_T * TILE + p];
+    nG = cnt[ROW_G * TILE + p]; nDel = cnt[ROW_DEL * TILE + p]; nOth = cnt[ROW_OTH * TILE + p];
+    const u32 same = cnt[ROW_COV * TILE + p] - cnt[ROW_MIS * TILE + p];
+    const int ro = row_of(orig);
+    nA += (ro == ROW_A) ? same : 0u; nC += (ro == ROW_C) ? same : 0u; nT += (ro == ROW_T) ? same : 0u;
+    nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
+}
+
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
@@ -811,16 +826,10 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
         const u64 gp = w0 + p;
         if (gp >= A.G) break;
-        u32 nA = cnt[ROW_A * TILE + p], nC = cnt[ROW_C * TILE + p], nT = cnt[ROW_T * TILE + p],
-            nG = cnt[ROW_G * TILE + p], nDel = cnt[ROW_DEL * TILE + p], nOth = cnt[ROW_OTH * TILE + p];
+        u32 nA, nC, nG, nT, nDel, nOth;
         const u32 defw = cnt[ROW_DEF * TILE + p];
         const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
-        {   // fast-class bases equal to the assembly base were never tallied one by one
-            const u32 same = cnt[ROW_COV * TILE + p] - cnt[ROW_MIS * TILE + p];
-            const int ro = row_of(orig);
-            nA += (ro == ROW_A) ? same : 0u; nC += (ro == ROW_C) ? same : 0u; nT += (ro == ROW_T) ? same : 0u;
-            nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
-        }
+        position_tallies(cnt, orig, p, nA, nC, nG, nT, nDel, nOth);
         const bool nd = (defw >> 31) != 0;
         const u32 deficit = defw & 0x7FFFFFFFu;
         const u32 ntot = nA + nC + nG + nT + nDel + nOth;
@@ -892,6 +901,26 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
     if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
+    if (s_nflag && e1 - e0 <= SORT_MAX) {
+        // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
+        if (tid == 0) {
+            const u32 slab = atomicAdd(&A.counters[3], 1u);
+            if (slab >= A.cap_slabs) report(A.status, slab, DE_CAPACITY);
+            s_c1 = slab;
+            A.win_slab[w] = slab;
+        }
+        __syncthreads();
+        const u32 slab = s_c1;
+        if (slab < A.cap_slabs) {
+            u32 *dst = A.slabs + (u64)slab * 6u * TILE;
+            for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
+                u32 nA, nC, nG, nT, nDel, nOth;
+                position_tallies(cnt, ((const u8 *)asm_w)[ASM_PAD + p], p, nA, nC, nG, nT, nDel, nOth);
+                dst[0 * TILE + p] = nA; dst[1 * TILE + p] = nC; dst[2 * TILE + p] = nG;
+                dst[3 * TILE + p] = nT; dst[4 * TILE + p] = nDel; dst[5 * TILE + p] = nOth;
+            }
+        }
+    }
     if (tid == 0) {
         A.win_nflag[w] = s_nflag;
         if (s_nflag) atomicAdd(&A.counters[2], s_nflag);
@@ -955,6 +984,11 @@ struct ExactArgs {
     u32 *flag_cov_w;
     const u32 *flag_bits;
     const u32 *win_nflag;
+    const u32 *win_slab;
+    const u32 *slabs;
+    ulonglong2 *ents;   // per replayed window: (start | extent << 32, 1/k as f64 bits) in file order
+    u64 cap_ents;
+    u64 *ents_cursor;
     const u32 *flag_pos;
     const u32 *flag_cov;
     const u64 *flag_scr;
@@ -1140,39 +1174,39 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 }
 
 // =============================================================================================
-// k_exact2: wave-per-position exact replay for windows of up to SORT_MAX work items
+// k_exact2: ordered-depth replay for windows of up to SORT_MAX work items
 // =============================================================================================
-// One workgroup per window that has flagged positions: (1) bitonic sort of the window's work items
-// by record index (= SAM file order) in LDS, (2) per item its window-relative start and trimmed
-// extent, (3) every wave replays one flagged position at a time, 64 items per step: ballot tallies,
-// f64 depth accumulated in file order with v_readlane, a 64-entry string-keyed table (one key per
-// lane) for everything that is not A/C/G/T/-.  Same arithmetic as k_exact, ~40x faster.
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
-    return (u64)lo | ((u64)hi << 32);
-}
-
-__global__ __launch_bounds__(256) void k_exact2(ExactArgs A, u32 nwin) {
-    __shared__ u64 pk[SORT_MAX];  // sort keys (record index << 16 | slot), then (start | extent << 32)
-    __shared__ unsigned short sl[SORT_MAX];
-    const u32 w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+// Only the f64 depth depends on the order of the additions (pileup.rs:64); the integer tallies do
+// not, and k_tile saved them.  One workgroup per window that has flagged positions:
+//  (1) bitonic sort of the window's work items by record index (= SAM file order) in LDS;
+//  (2) per item, in that order: window-relative start, trimmed extent and 1.0/k, to a global slab;
+//  (3) ONE sequential pass over the items with all 2048 positions in parallel lanes: scalar loads of
+//      the item, `depth += 1/k` in the lanes it covers -- every position sees its additions in file order;
+//  (4) vote per flagged position; the few whose string-keyed tallies could reach a threshold are
+//      handed to the thread-serial k_exact through the global list.
+__global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
+    __shared__ u64 pk[SORT_MAX];  // sort keys: record index << 16 | slot
+    __shared__ u64 s_base;
+    const u32 w = blockIdx.x, tid = threadIdx.x;
     if (w >= nwin || *A.status != ~0ull) return;
     if (A.win_nflag[w] == 0) return;
     const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
     if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
+    const u32 slab = A.win_slab[w];
 
     // ---- (1) sort by record index ----
     u32 np2 = 2;
     while (np2 < n) np2 <<= 1;
-    for (u32 i = tid; i < np2; i += 256) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+    for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+    if (tid == 0) {
+        const u64 base = atomicAdd(A.ents_cursor, (u64)n);
+        if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY);
+        s_base = base;
+    }
     __syncthreads();
     for (u32 k = 2; k <= np2; k <<= 1) {
         for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 t = tid; t < (np2 >> 1); t += 256) {
+            for (u32 t = tid; t < (np2 >> 1); t += 1024) {
                 const u32 i = (t / j) * 2u * j + (t % j), o = i + j;
                 const bool asc = (i & k) == 0;
                 const u64 a = pk[i], b = pk[o];
@@ -1181,179 +1215,79 @@ __global__ __launch_bounds__(256) void k_exact2(ExactArgs A, u32 nwin) {
             __syncthreads();
         }
     }
-    // ---- (2) start and trimmed extent of every item, in file order ----
-    for (u32 i = tid; i < n; i += 256) {
-        const u32 slot = (u32)(pk[i] & 0xFFFFu);
-        const uint4 ent = A.entA[e0 + slot];
-        const u32 fl = (ent.y >> 16) & 0xFFu;
+    if (s_base + n > A.cap_ents) return;  // the host grows the buffer and reruns
+    ulonglong2 *ents = A.ents + s_base;
+    // ---- (2) start, trimmed extent and depth share of every item, in file order ----
+    for (u32 i = tid; i < n; i += 1024) {
+        const uint4 ent = A.entA[e0 + (u32)(pk[i] & 0xFFFFu)];
+        const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;
         else lim = simple_nkeep(A.seq + ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32)), ent.y >> 24);
-        sl[i] = (unsigned short)slot;
-        pk[i] = (u64)ent.z | ((u64)lim << 32);  // safe: each thread rewrites only the keys it read
+        const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[ent.w]);
+        ulonglong2 r;
+        r.x = (u64)ent.z | ((u64)lim << 32);
+        r.y = (u64)__double_as_longlong(1.0 / (double)k);
+        ents[i] = r;
     }
+    __threadfence_block();
     __syncthreads();
 
-    // ---- (3) replay: one position per wave at a time ----
-    u32 seen = 0;
-    for (u32 word = 0; word < (u32)(TILE / 32); word++) {
-        u32 bits = A.flag_bits[(u64)w * (TILE / 32) + word];
-        while (bits) {
-            const u32 bit = (u32)__ffs((int)bits) - 1u;
-            bits &= bits - 1u;
-            if ((seen++ & 3u) != wave) continue;
-            const int pr = (int)(word * 32u + bit);
-            const u32 gp = w * (u32)TILE + (u32)pr;
+    // ---- (3) the sequential pass: lanes are positions ----
+    // 64 items per vector load (one per lane), then v_readlane turns each item into scalars
+    const u32 lane = tid & 63u;
+    const int p0 = (int)tid, p1 = (int)tid + 1024;
+    double d0 = 0.0, d1 = 0.0;
+    for (u32 base = 0; base < n; base += 64) {
+        ulonglong2 mine;
+        mine.x = 0; mine.y = 0;
+        if (base + lane < n) mine = ents[base + lane];
+        const u32 nb = min(64u, n - base);
+        const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
+        for (u32 j = 0; j < nb; j++) {
+            const int rel = __builtin_amdgcn_readlane(xl, (int)j);
+            const u32 lim = (u32)__builtin_amdgcn_readlane(xh, (int)j);
+            const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, (int)j), __builtin_amdgcn_readlane(yl, (int)j));
+            if ((u32)(p0 - rel) < lim) d0 += dc;
+            if ((u32)(p1 - rel) < lim) d1 += dc;
+        }
+    }
 
-            double depth = 0.0;
-            u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0, ncov = 0;
-            u64 t_off = 0;  // string-keyed table: lane j holds key j
-            u32 t_len = 0, t_cnt = 0, ntab = 0;
-            bool overflow = false;
-            for (u32 c = 0; c < n; c += 64) {
-                const u32 i = c + lane;
-                const u64 v = i < n ? pk[i] : 0ull;
-                const u32 q = (u32)(pr - (int)(u32)v);
-                const bool cov = i < n && q < (u32)(v >> 32);
-                const u64 m = __ballot(cov);
-                if (!m) continue;
-                int row = -1;
-                double dc = 0.0;
-                u64 s_abs = 0;
-                u32 len = 0;
-                if (cov) {
-                    const uint4 ent = A.entA[e0 + sl[i]];
-                    const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu, idx = ent.w;
-                    const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
-                    if (!(fl & ENT_COMPLEX)) { s_abs = so + q; len = 1; }
-                    else {
-                        u64 s_rel;
-                        entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], q, &s_rel, &len);
-                        s_abs = so + s_rel;
-                    }
-                    const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[idx]);
-                    dc = 1.0 / (double)k;
-                    row = len == 0 ? ROW_DEL : (len == 1 ? row_of(A.seq[s_abs]) : ROW_OTH);
-                }
-                ncov += (u32)__popcll(m);
-                nA += (u32)__popcll(__ballot(row == ROW_A));
-                nC += (u32)__popcll(__ballot(row == ROW_C));
-                nG += (u32)__popcll(__ballot(row == ROW_G));
-                nT += (u32)__popcll(__ballot(row == ROW_T));
-                nDel += (u32)__popcll(__ballot(row == ROW_DEL));
-                // depth: sequential f64 adds of 1.0/k in file order (pileup.rs:64, alignment.rs:288)
-                for (u64 mm = m; mm; mm &= mm - 1) depth += readlane_f64(dc, __ffsll((long long)mm) - 1);
-                // everything else is counted by string (pileup.rs:62)
-                for (u64 mo = __ballot(row == ROW_OTH); mo; mo &= mo - 1) {
-                    const int l = __ffsll((long long)mo) - 1;
-                    const u64 ko = readlane_u64(s_abs, l);
-                    const u32 kl = (u32)__builtin_amdgcn_readlane((int)len, l);
-                    bool match = lane < ntab && t_len == kl;
-                    if (match)
-                        for (u32 b = 0; b < kl; b++)
-                            if (A.seq[t_off + b] != A.seq[ko + b]) { match = false; break; }
-                    const u64 mt = __ballot(match);
-                    if (mt) {
-                        if ((int)lane == __ffsll((long long)mt) - 1) t_cnt++;
-                    } else if (ntab < 64) {
-                        if (lane == ntab) { t_off = ko; t_len = kl; t_cnt = 1; }
-                        ntab++;
-                    } else {
-                        overflow = true;
-                    }
-                    nOth++;
-                }
-            }
-            if (overflow) {
-                // more than 64 distinct keys: hand the position to the thread-serial kernel
-                if (lane == 0) {
-                    const u32 slot = atomicAdd(&A.counters[0], 1u);
-                    if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ncov; }
-                    else report(A.status, slot, DE_CAPACITY);
-                }
-                continue;
-            }
-            const u8 orig = A.bases[gp];
-            VoteOut vo = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
-            u64 win_off = 0;
-            u32 win_len = 0;
-            if (vo.status != PP_ST_LOW_DEPTH && nOth > 0) {  // the tally of pileup.rs:77-109 with all keys
-                int nv = 0, ni = 0;
-                u8 win = 0;
-                const u32 c5[5] = {nA, nC, nG, nT, nDel};
-                const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
-                for (int j = 0; j < 5; j++) {
-                    if (j == 4 && nDel == 0) break;
-                    if (c5[j] >= vo.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= vo.ithr) ni++;
-                }
-                const bool tv = lane < ntab && t_cnt >= vo.vthr, ti = lane < ntab && !tv && t_cnt >= vo.ithr;
-                const u64 mv = __ballot(tv);
-                if (mv && !nv) {
-                    const int l = __ffsll((long long)mv) - 1;
-                    win_off = readlane_u64(t_off, l);
-                    win_len = (u32)__builtin_amdgcn_readlane((int)t_len, l);
-                }
-                nv += (int)__popcll(mv);
-                ni += (int)__popcll(__ballot(ti));
-                vo.out = (orig == (u8)'-') ? 0 : orig;
-                vo.status = PP_ST_KEPT;
-                if (nv == 1) {
-                    if (ni > 0) { vo.status = PP_ST_TOO_CLOSE; win_len = 0; }
-                    else if (win_len == 0) {
-                        vo.out = (win == (u8)'-') ? 0 : win;
-                        if (win != orig) vo.status = PP_ST_CHANGED;
-                    } else {
-                        vo.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
-                    }
-                } else {
-                    win_len = 0;
-                    vo.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
-                }
-            }
-            if (lane == 0) {
-                u32 emit;
-                if (win_len > 0) {
-                    u32 eff = 0;
-                    u8 only = 0;
-                    for (u32 b = 0; b < win_len; b++) {
-                        const u8 ch = A.seq[win_off + b];
-                        if (ch != (u8)'-') { eff++; only = ch; }
-                    }
-                    if (eff == 0) A.code[gp] = 0;
-                    else if (eff == 1 && only < 0x80u) A.code[gp] = only;
-                    else {
-                        A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
-                        const u32 slot = atomicAdd(&A.counters[1], 1u);
-                        if (slot < A.cap_multi) {
-                            MultiEnt me;
-                            me.off = win_off; me.pos = gp; me.len = win_len; me.eff = eff; me.pad = 0;
-                            A.multi[slot] = me;
-                        } else {
-                            report(A.status, slot, DE_CAPACITY);
-                        }
-                    }
-                    emit = eff;
-                } else {
-                    A.code[gp] = vo.out;
-                    emit = vo.out ? 1u : 0u;
-                }
-                if (emit) atomicAdd(&A.win_len[w], emit);
-                const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
-                if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
-                if (ncov == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
-                atomicAdd(&A.stats[cg].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
-                if (A.dbg) {
-                    A.dbg_depth[gp] = depth;
-                    A.dbg_counts[0 * A.G + gp] = nA;
-                    A.dbg_counts[1 * A.G + gp] = nC;
-                    A.dbg_counts[2 * A.G + gp] = nG;
-                    A.dbg_counts[3 * A.G + gp] = nT;
-                    A.dbg_counts[4 * A.G + gp] = nDel + nOth;
-                    A.dbg_counts[5 * A.G + gp] = vo.vthr;
-                    A.dbg_counts[6 * A.G + gp] = vo.ithr;
-                    A.dbg_status[gp] = vo.status;
-                }
-            }
+    // ---- (4) vote for the flagged positions ----
+    const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
+    for (int h = 0; h < 2; h++) {
+        const u32 p = h ? (u32)p1 : (u32)p0;
+        const double depth = h ? d1 : d0;
+        if (!((A.flag_bits[(u64)w * (TILE / 32) + (p >> 5)] >> (p & 31u)) & 1u)) continue;
+        const u32 gp = w * (u32)TILE + p;
+        const u32 nA = tal[0 * TILE + p], nC = tal[1 * TILE + p], nG = tal[2 * TILE + p], nT = tal[3 * TILE + p],
+                  nDel = tal[4 * TILE + p], nOth = tal[5 * TILE + p];
+        const u32 ntot = nA + nC + nG + nT + nDel + nOth;
+        const u8 orig = A.bases[gp];
+        const VoteOut vo = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+        if (vo.status != PP_ST_LOW_DEPTH && nOth > 0 && nOth >= vo.ithr) {
+            // a string-keyed tally could reach a threshold: full replay by the thread-serial kernel
+            const u32 slot = atomicAdd(&A.counters[0], 1u);
+            if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ntot; }
+            else report(A.status, slot, DE_CAPACITY);
+            continue;
+        }
+        A.code[gp] = vo.out;
+        if (vo.out) atomicAdd(&A.win_len[w], 1u);
+        const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
+        if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
+        if (ntot == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
+        atomicAdd(&A.stats[cg].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+        if (A.dbg) {
+            A.dbg_depth[gp] = depth;
+            A.dbg_counts[0 * A.G + gp] = nA;
+            A.dbg_counts[1 * A.G + gp] = nC;
+            A.dbg_counts[2 * A.G + gp] = nG;
+            A.dbg_counts[3 * A.G + gp] = nT;
+            A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+            A.dbg_counts[5 * A.G + gp] = vo.vthr;
+            A.dbg_counts[6 * A.G + gp] = vo.ithr;
+            A.dbg_status[gp] = vo.status;
         }
     }
 }
@@ -1636,6 +1570,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
+    ENS(b_win_slab, (uint64_t)nwin * 4); ENS(b_slabs, (uint64_t)ctx->cap_slabs * 6 * TILE * 4); ENS(b_ents, (uint64_t)ctx->cap_ents * 16);
     ENS(b_scratch, ctx->cap_scr * 16); ENS(b_multi, ctx->cap_multi * sizeof(MultiEnt)); ENS(b_out, ctx->cap_out);
     if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
 #undef ENS
@@ -1680,6 +1615,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
     T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
+    T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
@@ -1693,6 +1629,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ExactArgs E;
     E.cap_multi = (u32)ctx->cap_multi; E.cap_flag = (u32)ctx->cap_flag;
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
+    E.win_slab = T.win_slab; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
+    E.ents_cursor = d_meta + 6;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
@@ -1704,7 +1642,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.status = d_status; E.dbg = T.dbg;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
-    hipLaunchKernelGGL(k_exact2, dim3(nwin), dim3(256), 0, st, E, nwin);
+    hipLaunchKernelGGL(k_exact2, dim3(nwin), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
                        d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
@@ -1742,6 +1680,8 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     ctx->cap_flag = std::max<size_t>(ctx->cap_flag, std::min<size_t>((size_t)G, std::max<size_t>(65536, (size_t)(G / 64))));
     ctx->cap_scr = std::max<size_t>(ctx->cap_scr, (size_t)1 << 20);
     ctx->cap_multi = std::max<size_t>(ctx->cap_multi, 65536);
+    ctx->cap_slabs = std::max<size_t>(ctx->cap_slabs, 64);
+    ctx->cap_ents = std::max<size_t>(ctx->cap_ents, (size_t)1 << 20);
     ctx->cap_out = std::max<size_t>(ctx->cap_out, (size_t)(G + G / 16 + 65536));
 
     std::vector<uint64_t> meta;
@@ -1765,6 +1705,8 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G));
         grow(ctx->cap_scr, meta[4]);
         grow(ctx->cap_multi, cnt[1]);
+        grow(ctx->cap_slabs, cnt[3]);
+        grow(ctx->cap_ents, meta[6]);
         grow(ctx->cap_out, meta[5]);
         if (!grew) return ctx->fail(PP_ERR_HIP, "device reported a capacity overflow that the host cannot locate");
     }
@@ -1874,7 +1816,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};
