@@ -1235,8 +1235,11 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
 
     // ---- (3) the sequential pass: lanes are positions ----
     // 64 items per vector load (one per lane), then v_readlane turns each item into scalars
+    // Wave v owns the 128 consecutive positions [128v, 128v+128): an item that does not reach them
+    // is skipped with two scalar compares (an item overlaps ~2 of the 16 waves).
     const u32 lane = tid & 63u;
-    const int p0 = (int)tid, p1 = (int)tid + 1024;
+    const int wlo = (int)(tid >> 6) * 128;
+    const int p0 = wlo + (int)lane, p1 = p0 + 64;
     double d0 = 0.0, d1 = 0.0;
     for (u32 base = 0; base < n; base += 64) {
         ulonglong2 mine;
@@ -1247,6 +1250,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
         for (u32 j = 0; j < nb; j++) {
             const int rel = __builtin_amdgcn_readlane(xl, (int)j);
             const u32 lim = (u32)__builtin_amdgcn_readlane(xh, (int)j);
+            if (rel >= wlo + 128 || (long long)rel + (long long)lim <= (long long)wlo) continue;
             const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, (int)j), __builtin_amdgcn_readlane(yl, (int)j));
             if ((u32)(p0 - rel) < lim) d0 += dc;
             if ((u32)(p1 - rel) < lim) d1 += dc;
