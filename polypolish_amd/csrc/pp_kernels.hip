@@ -1257,8 +1257,13 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
         }
     }
 
-    // ---- (4) vote for the flagged positions ----
+    // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
     const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
+    const u64 gw0 = (u64)w * TILE;
+    const u32 c_first = find_contig(A.contig_off, A.n_contigs, gw0);
+    const bool one_contig = c_first == find_contig(A.contig_off, A.n_contigs, min(gw0 + TILE, A.G) - 1);
+    u32 my_len = 0, my_changed = 0, my_zero = 0;
+    u64 my_depth = 0;
     for (int h = 0; h < 2; h++) {
         const u32 p = h ? (u32)p1 : (u32)p0;
         const double depth = h ? d1 : d0;
@@ -1277,11 +1282,19 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
             continue;
         }
         A.code[gp] = vo.out;
-        if (vo.out) atomicAdd(&A.win_len[w], 1u);
-        const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
-        if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
-        if (ntot == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
-        atomicAdd(&A.stats[cg].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+        const u64 dfx = (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS));
+        if (one_contig) {
+            my_len += vo.out ? 1u : 0u;
+            my_changed += vo.status == PP_ST_CHANGED;
+            my_zero += ntot == 0;
+            my_depth += dfx;
+        } else {
+            my_len += vo.out ? 1u : 0u;
+            const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
+            if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
+            if (ntot == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
+            atomicAdd(&A.stats[cg].depth_fx, dfx);
+        }
         if (A.dbg) {
             A.dbg_depth[gp] = depth;
             A.dbg_counts[0 * A.G + gp] = nA;
@@ -1293,6 +1306,24 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
             A.dbg_counts[6 * A.G + gp] = vo.ithr;
             A.dbg_status[gp] = vo.status;
         }
+    }
+    __syncthreads();  // pk is free again: reuse its first words for the block reduction
+    if (tid < 4) pk[tid] = 0;
+    __syncthreads();
+    my_len = wave_sum(my_len); my_changed = wave_sum(my_changed); my_zero = wave_sum(my_zero);
+    my_depth = wave_sum64(my_depth);
+    if (lane == 0) {
+        if (my_len) atomicAdd(&pk[0], (u64)my_len);
+        if (my_changed) atomicAdd(&pk[1], (u64)my_changed);
+        if (my_zero) atomicAdd(&pk[2], (u64)my_zero);
+        if (my_depth) atomicAdd(&pk[3], my_depth);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (pk[0]) atomicAdd(&A.win_len[w], (u32)pk[0]);
+        if (pk[1]) atomicAdd(&A.stats[c_first].changed, pk[1]);
+        if (pk[2]) atomicAdd(&A.stats[c_first].zero_depth, pk[2]);
+        if (pk[3]) atomicAdd(&A.stats[c_first].depth_fx, pk[3]);
     }
 }
 
