@@ -138,6 +138,25 @@ typedef struct {
 int pp_polish_set_debug(pp_ctx *ctx, int enable);
 int pp_polish_positions(pp_ctx *ctx, const pp_positions *out);
 
+/* The rest of a --debug line (src/pileup.rs:137-166): the string-keyed tallies and the winning
+ * sequence of every position.  Valid after pp_polish_finish with debug enabled; the arrays are
+ * malloc'd by the library (release with pp_debug_extra_free).
+ *   emit[p]      0 = nothing is emitted (a deletion won, or the assembly byte is '-'), 1..127 = that
+ *                byte, >= 128 = a multi-byte winner listed in multi_* (raw bytes at seq + multi_off)
+ *   key_*        one record per (position, distinct key other than A/C/G/T): the key is the len bytes
+ *                at seq + off (the batch's seq array); len 0 = the deletion key "-"            */
+typedef struct {
+    uint8_t *emit;         /* one per assembly position */
+    uint64_t n_multi;
+    uint32_t *multi_pos, *multi_len;
+    uint64_t *multi_off;
+    uint64_t n_keys;
+    uint32_t *key_pos, *key_len, *key_count;
+    uint64_t *key_off;
+} pp_debug_extra;
+int pp_polish_debug_extra(pp_ctx *ctx, pp_debug_extra *out);
+void pp_debug_extra_free(pp_debug_extra *d);
+
 /* Per-kernel device time of the last pp_polish_finish, measured with HIP events on the context's
  * stream when profiling is enabled.  names[i] are static strings. */
 #define PP_MAX_KERNELS 16

@@ -98,7 +98,8 @@ class FilterInput(C.Structure):
 EXPORTS = [
     "pp_ctx_create", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
-    "pp_polish_result_device", "pp_polish_set_debug", "pp_polish_positions", "pp_ctx_set_profiling",
+    "pp_polish_result_device", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
+    "pp_debug_extra_free", "pp_ctx_set_profiling",
     "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
     "pp_filter_kernel_times", "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",

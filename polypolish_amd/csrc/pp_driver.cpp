@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "polypolish_hip.h"
 
 namespace {
@@ -83,6 +85,77 @@ extern "C" void pp_bytes_free(pp_bytes *b) {
     b->len = 0;
 }
 
+// write_debug_line (polish.rs:257-266) + get_debug_line / get_count_str (pileup.rs:137-166) for every
+// position, from the device's per-position records
+static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_aln_batch *batch) {
+    const uint32_t nc = pp_assembly_n_contigs(a);
+    const uint64_t *off = pp_assembly_offsets(a);
+    const uint8_t *bases = pp_assembly_bases(a);
+    const uint64_t G = off[nc];
+    std::vector<double> depth(G ? G : 1);
+    std::vector<uint32_t> ca(G ? G : 1), cc(G ? G : 1), cg(G ? G : 1), ct(G ? G : 1), vt(G ? G : 1), it(G ? G : 1);
+    std::vector<uint8_t> st(G ? G : 1);
+    pp_positions pos{depth.data(), ca.data(), cc.data(), cg.data(), ct.data(), nullptr, vt.data(), it.data(), st.data()};
+    int rc = pp_polish_positions(ctx, &pos);
+    if (rc) return rc;
+    pp_debug_extra x;
+    rc = pp_polish_debug_extra(ctx, &x);
+    if (rc) return rc;
+    // key records and multi-byte winners, grouped by position
+    std::vector<uint64_t> korder(x.n_keys), morder(x.n_multi);
+    for (uint64_t i = 0; i < x.n_keys; i++) korder[i] = i;
+    for (uint64_t i = 0; i < x.n_multi; i++) morder[i] = i;
+    std::sort(korder.begin(), korder.end(), [&](uint64_t l, uint64_t r) { return x.key_pos[l] < x.key_pos[r]; });
+    std::sort(morder.begin(), morder.end(), [&](uint64_t l, uint64_t r) { return x.multi_pos[l] < x.multi_pos[r]; });
+    static const char *STATUS[6] = {"kept", "changed", "low_depth", "none", "multiple", "too_close"};
+    uint64_t ki = 0, mi = 0;
+    std::string line;
+    std::vector<std::string> items;
+    char num[64];
+    for (uint32_t c = 0; c < nc; c++) {
+        const char *name = pp_assembly_name(a, c);
+        for (uint64_t gp = off[c]; gp < off[c + 1]; gp++) {
+            items.clear();
+            if (ca[gp]) { snprintf(num, sizeof num, "Ax%u", ca[gp]); items.push_back(num); }
+            if (cc[gp]) { snprintf(num, sizeof num, "Cx%u", cc[gp]); items.push_back(num); }
+            if (cg[gp]) { snprintf(num, sizeof num, "Gx%u", cg[gp]); items.push_back(num); }
+            if (ct[gp]) { snprintf(num, sizeof num, "Tx%u", ct[gp]); items.push_back(num); }
+            for (; ki < x.n_keys && x.key_pos[korder[ki]] == gp; ki++) {
+                const uint64_t r = korder[ki];
+                std::string key = x.key_len[r] ? std::string((const char *)batch->seq + x.key_off[r], x.key_len[r]) : std::string("-");
+                snprintf(num, sizeof num, "x%u", x.key_count[r]);
+                items.push_back(key + num);
+            }
+            std::sort(items.begin(), items.end());
+            const uint8_t e = x.emit[gp];
+            std::string new_base;
+            if (e == 0) new_base = st[gp] == PP_ST_CHANGED ? std::string("-") : std::string(1, (char)bases[gp]);
+            else if (e < 0x80) new_base = std::string(1, (char)e);
+            else {
+                while (mi < x.n_multi && x.multi_pos[morder[mi]] < gp) mi++;
+                if (mi < x.n_multi && x.multi_pos[morder[mi]] == gp)
+                    new_base = std::string((const char *)batch->seq + x.multi_off[morder[mi]], x.multi_len[morder[mi]]);
+            }
+            line.assign(name);
+            snprintf(num, sizeof num, "\t%llu\t%c\t%.1f\t%u\t%u\t", (unsigned long long)(gp - off[c]), (char)bases[gp],
+                     depth[gp], it[gp], vt[gp]);
+            line += num;
+            for (size_t i = 0; i < items.size(); i++) { if (i) line += ','; line += items[i]; }
+            line += '\t';
+            line += STATUS[st[gp] < 6 ? st[gp] : 0];
+            line += '\t';
+            line += new_base;
+            line += '\n';
+            if (fwrite(line.data(), 1, line.size(), f) != line.size()) {
+                pp_debug_extra_free(&x);
+                return pp_ctx_set_error_(ctx, PP_ERR_QUIT, "unable to write to the --debug file");
+            }
+        }
+    }
+    pp_debug_extra_free(&x);
+    return PP_OK;
+}
+
 extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                                const pp_polish_options *opt, pp_bytes *fasta) {
     if (!ctx || !assembly || !opt || !fasta || (n_sams > 0 && !sams)) return PP_ERR_ARG;
@@ -109,8 +182,6 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
             snprintf(err, sizeof err, "\"%s\" file does not exist", sams[i]);
             return set_err(ctx, PP_ERR_QUIT, err);
         }
-    if (opt->debug_path)
-        return set_err(ctx, PP_ERR_LIMIT, "--debug (per-base TSV) is not implemented by the MI355X path yet");
 
     // starting_message, polish.rs:41-73
     log("\nStarting Polypolish polish\n%s\n\nInput assembly:\n  %s\n\nInput short-read alignments:\n", pp_version(), assembly);
@@ -118,7 +189,8 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     log("\nSettings:\n  --fraction_invalid %g\n  --fraction_valid %g\n  --max_errors %u\n  --min_depth %u\n",
         opt->fraction_invalid, opt->fraction_valid, opt->max_errors, opt->min_depth);
     if (opt->careful) log("  --careful\n");
-    log("  not logging debugging information\n\n");
+    if (opt->debug_path) log("  --debug %s\n\n", opt->debug_path);
+    else log("  not logging debugging information\n\n");
 
     // load_assembly, polish.rs:93-106
     log("Loading assembly\n");
@@ -157,9 +229,25 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
     pp_aln_batch batch;
     pp_ingest_batch(g, &batch);
+    // create_debug_file, polish.rs:230-245: the file is created (and the header written) before polishing
+    FILE *dbg = nullptr;
+    if (opt->debug_path) {
+        dbg = fopen(opt->debug_path, "wb");
+        if (!dbg) {
+            snprintf(err, sizeof err, "unable to create \"%s\"", opt->debug_path);
+            pp_ingest_free(g);
+            pp_assembly_free(a);
+            return set_err(ctx, PP_ERR_QUIT, err);
+        }
+        fputs("name\tpos\tbase\tdepth\tinvalid\tvalid\tpileup\tstatus\tnew_base\n", dbg);
+    }
+    pp_polish_set_debug(ctx, dbg ? 1 : 0);
     rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
     if (rc == PP_OK) rc = pp_polish_add(ctx, &batch, PP_MEM_HOST);
     if (rc == PP_OK) rc = pp_polish_finish(ctx);
+    if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
+    if (dbg) fclose(dbg);
+    pp_polish_set_debug(ctx, 0);
     uint64_t total = 0;
     if (rc == PP_OK) rc = pp_polish_result_size(ctx, &total);
     std::vector<uint8_t> polished(total ? total : 1);

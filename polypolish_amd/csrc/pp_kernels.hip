@@ -36,6 +36,11 @@ typedef uint8_t u8;
 enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, ROW_COV = 7,
        ROW_MIS = 8, N_ROWS = 9 };
 
+struct KeyRec {    // debug only: one distinct non-ACGT key of a position (len 0 = the deletion key "-")
+    u64 off;
+    u32 pos, len, count, pad;
+};
+
 struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertion won the vote)
     u64 off;       // absolute offset of the winning string in the seq array
     u32 pos;       // global assembly position
@@ -500,6 +505,7 @@ struct PlainItem {  // per lane
     u32 L;
     u32 ta;            // (address of the last base) & 3
     bool plain, active;
+    bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
 };
 
 // fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
@@ -511,8 +517,10 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my,
     const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
     it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
     it.L = ey >> 24;
-    // flags == 0 and share class == 0, length in range
-    it.plain = j < nb && (ey & 0x00FFFF00u) == 0 && it.L <= PLAIN_MAX_LEN && it.L >= PLAIN_MIN_LEN;
+    // flags == 0, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway), length in range
+    const u32 kc = (ey >> 8) & 0xFFu;
+    it.nd = kc == KCLASS_NONDYADIC;
+    it.plain = j < nb && (ey & 0x00FF0000u) == 0 && (kc == 0 || it.nd) && it.L <= PLAIN_MAX_LEN && it.L >= PLAIN_MIN_LEN;
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
     const u8 *rp = seq + so;
     const u32 mis = (u32)((uintptr_t)rp & 31u);
@@ -534,7 +542,7 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my,
     return it;
 }
 
-__device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const PlainItem &it, u32 lane) {
+__device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
     const u32 s = lane & 7u;
     const int rel = it.rel, ib = it.ib;
     const u32 L = it.L;
@@ -558,6 +566,13 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, const u32 *asm_w, const Pl
     if (live && s == 0) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+        if (it.nd) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
+            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+            }
+        }
     }
     // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
     const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
@@ -706,7 +721,7 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag;
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
     __shared__ u64 s_depth;
 
     // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     const u64 w0 = (u64)w * TILE;
 
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
-    if (tid < (u32)(TILE / 32)) s_fbits[tid] = 0;
+    if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
     {
         u8 *ab = (u8 *)asm_w;
         for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
@@ -741,16 +756,16 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         const uint4 my = A.entA[eb + min(lane, nb - 1u)];
         const u32 my_flags = (my.y >> 16) & 0xFFu, my_kc = (my.y >> 8) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
-        const bool my_plain = lane < nb && my_flags == 0 && my_kc == 0 && (my.y >> 24) <= PLAIN_MAX_LEN &&
-                              (my.y >> 24) >= PLAIN_MIN_LEN;
+        const bool my_plain = lane < nb && my_flags == 0 && (my_kc == 0 || my_kc == KCLASS_NONDYADIC) &&
+                              (my.y >> 24) <= PLAIN_MAX_LEN && (my.y >> 24) >= PLAIN_MIN_LEN;
         // plain class: passes of eight items, the next pass's read loads in flight behind the current
         // one; two passes per trip so that the two register sets alternate without copies
         PlainItem pa = plain_fetch(A.seq, my, nb, 0, lane);
         for (u32 first = 0; first < nb; first += 16) {
             const PlainItem pb = plain_fetch(A.seq, my, nb, first + 8u, lane);
-            plain_apply(cnt, asm_w, pa, lane);
+            plain_apply(cnt, s_ndbits, asm_w, pa, lane);
             pa = plain_fetch(A.seq, my, nb, first + 16u, lane);
-            if (first + 8u < nb) plain_apply(cnt, asm_w, pb, lane);
+            if (first + 8u < nb) plain_apply(cnt, s_ndbits, asm_w, pb, lane);
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
         u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
@@ -830,7 +845,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         const u32 defw = cnt[ROW_DEF * TILE + p];
         const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
         position_tallies(cnt, orig, p, nA, nC, nG, nT, nDel, nOth);
-        const bool nd = (defw >> 31) != 0;
+        const bool nd = (defw >> 31) != 0 || ((s_ndbits[p >> 5] >> (p & 31u)) & 1u) != 0;
         const u32 deficit = defw & 0x7FFFFFFFu;
         const u32 ntot = nA + nC + nG + nT + nDel + nOth;
         if (orig >= 0x80u) report(A.status, gp, DE_NON_ASCII);
@@ -850,10 +865,16 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             if (!(depth < (double)A.min_depth) && nOth > 0 && nOth >= ithr) flag = true;
             else v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
         }
+        if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
-            atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
-            atomicAdd(&s_nflag, 1u);
-            if (e1 - e0 > SORT_MAX) {
+            const bool to_list = A.dbg || e1 - e0 > SORT_MAX;
+            if (!to_list) {
+                atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
+                atomicAdd(&s_nflag, 1u);
+            } else {
+                atomicAdd(&A.counters[2], 1u);
+            }
+            if (to_list) {
                 // bucket too large for the wave-per-position replay: global list for k_exact
                 const u32 slot = atomicAdd(&A.counters[0], 1u);
                 if (slot < A.cap_flag) {
@@ -986,6 +1007,9 @@ struct ExactArgs {
     const u32 *win_nflag;
     const u32 *win_slab;
     const u32 *slabs;
+    KeyRec *keys;       // debug only
+    u64 cap_keys;
+    u64 *n_keys;
     ulonglong2 *ents;   // per replayed window: (start | extent << 32, 1/k as f64 bits) in file order
     u64 cap_ents;
     u64 *ents_cursor;
@@ -1084,7 +1108,16 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
     VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
     u64 win_off = 0;
     u32 win_len = 0;  // winning string-keyed sequence, if any
-    if (v.status != PP_ST_LOW_DEPTH && nOth > 0) {
+    const bool low = v.status == PP_ST_LOW_DEPTH;
+    if (A.dbg && nDel > 0) {  // --debug lists the deletion key like any other
+        const u64 slot = atomicAdd(A.n_keys, 1ull);
+        if (slot < A.cap_keys) {
+            KeyRec kr;
+            kr.off = 0; kr.pos = gp; kr.len = 0; kr.count = nDel; kr.pad = 0;
+            A.keys[slot] = kr;
+        } else report(A.status, slot, DE_CAPACITY);
+    }
+    if (nOth > 0 && (!low || A.dbg)) {
         // redo the tally of pileup.rs:77-109 with the remaining keys added
         int nv = 0, ni = 0;
         u8 win = 0;
@@ -1111,22 +1144,34 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
             }
             if (count >= v.vthr) { if (!nv) { win = 0; win_off = yi & SL_OFF_MASK; win_len = li; } nv++; }
             else if (count >= v.ithr) ni++;
-        }
-        v.out = (orig == (u8)'-') ? 0 : orig;
-        v.status = PP_ST_KEPT;
-        if (nv == 1) {
-            if (ni > 0) v.status = PP_ST_TOO_CLOSE;
-            else if (win_len == 0) {
-                v.out = (win == (u8)'-') ? 0 : win;
-                if (win != orig) v.status = PP_ST_CHANGED;
-            } else {
-                v.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+            if (A.dbg) {
+                const u64 slot = atomicAdd(A.n_keys, 1ull);
+                if (slot < A.cap_keys) {
+                    KeyRec kr;
+                    kr.off = yi & SL_OFF_MASK; kr.pos = gp; kr.len = li; kr.count = count; kr.pad = 0;
+                    A.keys[slot] = kr;
+                } else report(A.status, slot, DE_CAPACITY);
             }
-        } else {
-            win_len = 0;
-            v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
         }
-        if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
+        if (low) {
+            win_len = 0;  // the keys were only walked for the --debug records
+        } else {
+            v.out = (orig == (u8)'-') ? 0 : orig;
+            v.status = PP_ST_KEPT;
+            if (nv == 1) {
+                if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+                else if (win_len == 0) {
+                    v.out = (win == (u8)'-') ? 0 : win;
+                    if (win != orig) v.status = PP_ST_CHANGED;
+                } else {
+                    v.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+                }
+            } else {
+                win_len = 0;
+                v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+            }
+            if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
+        }
     }
 
     u32 emit;
@@ -1597,7 +1642,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
 #define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
     // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements |
     // 5 polished bytes | 7.. contig output offsets (nc+1) | then per-contig stats (3 words each)
-    const size_t meta_words = 8 + (size_t)nc + 1 + 3 * (size_t)nc;
+    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;  // word 8: debug key records
     ENS(b_meta, meta_words * 8);
     ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
     ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
@@ -1606,14 +1651,15 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
     ENS(b_win_slab, (uint64_t)nwin * 4); ENS(b_slabs, (uint64_t)ctx->cap_slabs * 6 * TILE * 4); ENS(b_ents, (uint64_t)ctx->cap_ents * 16);
+    if (ctx->debug) ENS(b_keys, (uint64_t)ctx->cap_keys * sizeof(KeyRec));
     ENS(b_scratch, ctx->cap_scr * 16); ENS(b_multi, ctx->cap_multi * sizeof(MultiEnt)); ENS(b_out, ctx->cap_out);
     if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
 #undef ENS
     u64 *d_meta = (u64 *)ctx->b_meta.p;
     u64 *d_status = d_meta;
     u32 *d_counters = (u32 *)(d_meta + 1);
-    u64 *d_ctg_out = d_meta + 7;
-    ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 8 + nc);
+    u64 *d_ctg_out = d_meta + 16;
+    ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
     PP_HIPCHK(ctx, hipMemsetAsync(d_meta, 0, meta_words * 8, st));
     PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
 
@@ -1666,6 +1712,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
     E.win_slab = T.win_slab; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
     E.ents_cursor = d_meta + 6;
+    E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
@@ -1717,6 +1764,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     ctx->cap_multi = std::max<size_t>(ctx->cap_multi, 65536);
     ctx->cap_slabs = std::max<size_t>(ctx->cap_slabs, 64);
     ctx->cap_ents = std::max<size_t>(ctx->cap_ents, (size_t)1 << 20);
+    if (ctx->debug) ctx->cap_keys = std::max<size_t>(ctx->cap_keys, (size_t)1 << 20);
     ctx->cap_out = std::max<size_t>(ctx->cap_out, (size_t)(G + G / 16 + 65536));
 
     std::vector<uint64_t> meta;
@@ -1742,13 +1790,16 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         grow(ctx->cap_multi, cnt[1]);
         grow(ctx->cap_slabs, cnt[3]);
         grow(ctx->cap_ents, meta[6]);
+        if (ctx->debug) grow(ctx->cap_keys, meta[8]);
         grow(ctx->cap_out, meta[5]);
         if (!grew) return ctx->fail(PP_ERR_HIP, "device reported a capacity overflow that the host cannot locate");
     }
     const uint32_t *cnt = (const uint32_t *)&meta[1];
     ctx->total_out = meta[5];
-    ctx->contig_out_off.assign(meta.begin() + 7, meta.begin() + 7 + nc + 1);
-    const ContigStatsDev *hs = (const ContigStatsDev *)&meta[8 + nc];
+    ctx->contig_out_off.assign(meta.begin() + 16, meta.begin() + 16 + nc + 1);
+    const ContigStatsDev *hs = (const ContigStatsDev *)&meta[17 + nc];
+    ctx->n_multi = cnt[1];
+    ctx->n_keys = meta[8];
     ctx->stats.resize(nc);
     for (uint32_t c = 0; c < nc; c++) {
         ctx->stats[c].polished_len = ctx->contig_out_off[c + 1] - ctx->contig_out_off[c];
@@ -1814,6 +1865,43 @@ extern "C" int pp_polish_positions(pp_ctx *ctx, const pp_positions *o) {
     return PP_OK;
 }
 
+extern "C" int pp_polish_debug_extra(pp_ctx *ctx, pp_debug_extra *o) {
+    if (!ctx || !o) return PP_ERR_ARG;
+    memset(o, 0, sizeof *o);
+    if (!ctx->job_done || !ctx->debug)
+        return ctx->fail(PP_ERR_ARG, "debug records need pp_polish_set_debug(1) before pp_polish_finish");
+    hipStream_t st = ctx->stream;
+    const uint64_t G = ctx->G, nm = ctx->n_multi, nk = ctx->n_keys;
+    std::vector<MultiEnt> hm(nm ? nm : 1);
+    std::vector<KeyRec> hk(nk ? nk : 1);
+    o->emit = (uint8_t *)malloc(G ? G : 1);
+    PP_HIPCHK(ctx, hipMemcpyAsync(o->emit, ctx->b_code.p, G, hipMemcpyDeviceToHost, st));
+    if (nm) PP_HIPCHK(ctx, hipMemcpyAsync(hm.data(), ctx->b_multi.p, nm * sizeof(MultiEnt), hipMemcpyDeviceToHost, st));
+    if (nk) PP_HIPCHK(ctx, hipMemcpyAsync(hk.data(), ctx->b_keys.p, nk * sizeof(KeyRec), hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    o->n_multi = nm;
+    o->multi_pos = (uint32_t *)malloc((nm ? nm : 1) * 4);
+    o->multi_len = (uint32_t *)malloc((nm ? nm : 1) * 4);
+    o->multi_off = (uint64_t *)malloc((nm ? nm : 1) * 8);
+    for (uint64_t i = 0; i < nm; i++) { o->multi_pos[i] = hm[i].pos; o->multi_len[i] = hm[i].len; o->multi_off[i] = hm[i].off; }
+    o->n_keys = nk;
+    o->key_pos = (uint32_t *)malloc((nk ? nk : 1) * 4);
+    o->key_len = (uint32_t *)malloc((nk ? nk : 1) * 4);
+    o->key_count = (uint32_t *)malloc((nk ? nk : 1) * 4);
+    o->key_off = (uint64_t *)malloc((nk ? nk : 1) * 8);
+    for (uint64_t i = 0; i < nk; i++) {
+        o->key_pos[i] = hk[i].pos; o->key_len[i] = hk[i].len; o->key_count[i] = hk[i].count; o->key_off[i] = hk[i].off;
+    }
+    return PP_OK;
+}
+
+extern "C" void pp_debug_extra_free(pp_debug_extra *d) {
+    if (!d) return;
+    free(d->emit); free(d->multi_pos); free(d->multi_len); free(d->multi_off);
+    free(d->key_pos); free(d->key_len); free(d->key_count); free(d->key_off);
+    memset(d, 0, sizeof *d);
+}
+
 extern "C" int pp_ctx_set_profiling(pp_ctx *ctx, int enable) {
     if (!ctx) return PP_ERR_ARG;
     ctx->profiling = enable != 0;
@@ -1851,7 +1939,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};

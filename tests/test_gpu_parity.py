@@ -189,6 +189,25 @@ def test_polish_files_parity(ctx, orc, tmp_path, case):
         assert got == want, kw
 
 
+@pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
+def test_debug_tsv_parity(ctx, orc, tmp_path, case):
+    """--debug (src/pileup.rs:137-166, src/polish.rs:230-266): the per-base TSV, byte for byte."""
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    sams = [ds["sam1"], ds["sam2"]]
+    for i, kw in enumerate((dict(), dict(min_depth=2, fraction_invalid=0.1, max_errors=3))):
+        want = orc.polish_files(ds["fasta"], sams, debug=True, **kw)
+        tsv = str(tmp_path / f"debug{i}.tsv")
+        got = ctx.polish_files(ds["fasta"], sams, debug=tsv, **kw)
+        assert got == want["fasta"]
+        got_tsv = open(tsv, "rb").read()
+        if got_tsv != want["debug"]:
+            gl, wl = got_tsv.split(b"\n"), want["debug"].split(b"\n")
+            bad = [(a, b) for a, b in zip(gl, wl) if a != b][:5]
+            raise AssertionError((len(gl), len(wl), bad))
+    # the same job without --debug afterwards (different flagging rule) still gives the same FASTA
+    assert ctx.polish_files(ds["fasta"], sams) == orc.polish_files(ds["fasta"], sams)["fasta"]
+
+
 @pytest.mark.parametrize("case", FILE_CASES[1:3], ids=["seed32", "seed33"])
 def test_filter_then_polish_parity(ctx, orc, tmp_path, case):
     ds = synth.rich_dataset(str(tmp_path), **case)
@@ -249,9 +268,13 @@ def test_cli_is_a_drop_in(orc, tmp_path):
     assert r.returncode == 0, r.stderr
     orc.filter_files(ds["sam1"], ds["sam2"], o1, o2)
     assert open(f1, "rb").read() == open(o1, "rb").read() and open(f2, "rb").read() == open(o2, "rb").read()
-    r = subprocess.run([exe, "polish", "-d", "4", "--fraction_invalid=0.15", ds["fasta"], f1, f2], capture_output=True)
+    dbg = str(tmp_path / "cli_debug.tsv")
+    r = subprocess.run([exe, "polish", "-d", "4", "--fraction_invalid=0.15", "--debug", dbg, ds["fasta"], f1, f2],
+                       capture_output=True)
     assert r.returncode == 0, r.stderr
-    assert r.stdout == orc.polish_files(ds["fasta"], [o1, o2], min_depth=4, fraction_invalid=0.15)["fasta"]
+    want = orc.polish_files(ds["fasta"], [o1, o2], min_depth=4, fraction_invalid=0.15, debug=True)
+    assert r.stdout == want["fasta"]
+    assert open(dbg, "rb").read() == want["debug"]
     assert b"positions changed" in r.stderr
     r = subprocess.run([exe, "polish", "-i", "0.7", ds["fasta"], f1], capture_output=True)
     assert r.returncode == 1 and r.stdout == b"" and b"Error: --fraction_invalid must be less than --fraction_valid" in r.stderr
