@@ -23,7 +23,7 @@ $(OUT)/%.o: $(CSRC)/%.cpp include/polypolish_hip.h
 	$(HIPCC) $(HIPFLAGS) -x c++ -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread
 
 bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
 	@mkdir -p bin

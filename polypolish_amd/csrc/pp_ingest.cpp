@@ -8,14 +8,20 @@
 //   reverse_complement                   src/misc.rs:170-191
 // The CIGAR is kept as run-length ops (never expanded); everything downstream of the gates
 // (CIGAR walk, trim, pileup, vote) happens on the device.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -223,192 +229,149 @@ struct pp_ingest {
 
 namespace {
 
-struct Parsed {  // one aligned SAM record of the current read group
-    const char *name;
-    size_t name_n;
-    const char *ref;
-    size_t ref_n;
-    uint32_t flags;
+// One aligned SAM record (Alignment::new, alignment.rs:49-98), parsed but not yet gated.
+struct Rec {
+    const char *name, *ref, *seq;
+    uint32_t name_n, ref_n, seq_n;
     uint64_t ref_start;
-    const char *seq;
-    size_t seq_n;
-    uint32_t nm;
-    bool pass_qc;
-    uint32_t run_lo, run_hi;  // into the group's run pool (zero-length runs dropped)
+    uint32_t flags, nm;
+    int32_t contig;            // index into the assembly, -1 if RNAME is not in it
+    uint32_t run_lo, run_n;    // packed CIGAR runs in the chunk's pool (zero-length runs dropped)
+    uint8_t pass_qc;
 };
 
-struct Group {
-    std::vector<Parsed> al;
+// A slice of the file, parsed by one thread.
+struct Chunk {
+    const char *beg = nullptr, *end = nullptr;
+    std::vector<Rec> recs;
     std::vector<uint32_t> runs;
-    void clear() {
-        al.clear();
-        runs.clear();
-    }
+    uint64_t n_lines = 0;        // lines seen (up to and including a failing one)
+    int err_code = 0;            // first parse error of the chunk, if any
+    std::string err_what;        // message without the "in <file> (line N)" part where that applies
+    bool err_has_line = false;
+    size_t err_recs = 0;         // records parsed before the failing line
 };
 
-// Alignment::new, alignment.rs:49-98.  Returns false for an unaligned record (skipped by the
-// caller after a successful parse, alignment.rs:250).
-bool parse_line(const char *line, size_t n, const char *path, uint64_t line_no, Group &g) {
-    const char *col[12];
-    size_t len[12];
-    size_t nc = 0;
-    const char *p = line, *end = line + n;
-    const char *tags = nullptr;
-    while (nc < 11) {
-        const char *t = (const char *)memchr(p, '\t', (size_t)(end - p));
-        col[nc] = p;
-        len[nc] = t ? (size_t)(t - p) : (size_t)(end - p);
-        nc++;
-        if (!t) { p = end + 1; break; }
-        p = t + 1;
-    }
-    if (nc < 11) fail(PP_ERR_QUIT, "too few columns in \"%s\" (line %llu)", path, (unsigned long long)line_no);
-    tags = (p <= end) ? p : nullptr;  // start of column 12, if any
-
-    uint64_t flags, pos;
-    if (!parse_unsigned(col[1], len[1], 0xFFFFFFFFull, flags))
-        fail(PP_ERR_PANIC, "could not parse the FLAG column as u32 in \"%s\" (line %llu)", path,
-             (unsigned long long)line_no);
-    if (!parse_unsigned(col[3], len[3], UINT64_MAX, pos))
-        fail(PP_ERR_PANIC, "could not parse the POS column in \"%s\" (line %llu)", path,
-             (unsigned long long)line_no);
-    if (pos > 0) pos -= 1;
-
-    uint32_t nm = 0xFFFFFFFFu;
-    bool pass_qc = true;
-    while (tags && tags <= end) {
-        const char *t = (const char *)memchr(tags, '\t', (size_t)(end - tags));
-        size_t tl = t ? (size_t)(t - tags) : (size_t)(end - tags);
-        if (tl >= 5 && memcmp(tags, "NM:i:", 5) == 0) {
-            uint64_t v;
-            if (!parse_unsigned(tags + 5, tl - 5, 0xFFFFFFFFull, v))
-                fail(PP_ERR_PANIC, "could not parse the NM tag in \"%s\" (line %llu)", path,
-                     (unsigned long long)line_no);
-            nm = (uint32_t)v;
+void parse_chunk(Chunk &c, const pp_assembly *asmb) {
+    const char *p = c.beg;
+    std::string key;
+    const std::string *last_ref = nullptr;
+    int32_t last_contig = -1;
+    while (p < c.end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(c.end - p));
+        size_t n = nl ? (size_t)(nl - p) : (size_t)(c.end - p);
+        const char *line = p;
+        p += n + (nl ? 1 : 0);
+        if (n > 0 && line[n - 1] == '\r') n--;
+        c.n_lines++;
+        if (n == 0 || line[0] == '@') continue;
+        auto fail = [&](int code, const char *what, bool with_line) {
+            c.err_code = code; c.err_what = what; c.err_has_line = with_line; c.err_recs = c.recs.size();
+        };
+        const char *col[11];
+        size_t len[11];
+        size_t nc = 0;
+        const char *q = line, *end = line + n, *tags = nullptr;
+        while (nc < 11) {
+            const char *t = (const char *)memchr(q, '\t', (size_t)(end - q));
+            col[nc] = q;
+            len[nc] = t ? (size_t)(t - q) : (size_t)(end - q);
+            nc++;
+            if (!t) { q = end + 1; break; }
+            q = t + 1;
         }
-        if (tl == 9 && strncasecmp(tags, "ZP:Z:fail", 9) == 0) pass_qc = false;
-        if (!t) break;
-        tags = t + 1;
-    }
-    if (nm == 0xFFFFFFFFu && (flags & 4) == 0)
-        fail(PP_ERR_QUIT, "missing NM tag in \"%s\" (line %llu)", path, (unsigned long long)line_no);
-
-    // get_expanded_cigar, alignment.rs:325-346: the whole string must be \d+[MIDNSHP=X] tokens
-    uint32_t run_lo = (uint32_t)g.runs.size();
-    const char *c = col[5];
-    size_t cl = len[5];
-    if (!(cl == 1 && c[0] == '*')) {
-        size_t i = 0;
-        bool ok = true;
-        while (i < cl) {
-            size_t j = i;
-            while (j < cl && c[j] >= '0' && c[j] <= '9') j++;
-            int op = (j < cl) ? op_code(c[j]) : -1;
-            if (j == i || op < 0) { ok = false; break; }
-            uint64_t num;
-            if (!parse_unsigned(c + i, j - i, 0xFFFFFFFFull, num))
-                fail(PP_ERR_PANIC, "CIGAR run length does not fit u32 in \"%s\" (line %llu)", path,
-                     (unsigned long long)line_no);
-            while (num > 0) {  // a packed run holds 28 bits of length
-                uint32_t piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)num;
-                g.runs.push_back((piece << 4) | (uint32_t)op);
-                num -= piece;
+        if (nc < 11) { fail(PP_ERR_QUIT, "too few columns", true); return; }
+        tags = (q <= end) ? q : nullptr;
+        uint64_t flags, pos;
+        if (!parse_unsigned(col[1], len[1], 0xFFFFFFFFull, flags)) { fail(PP_ERR_PANIC, "could not parse the FLAG column as u32", true); return; }
+        if (!parse_unsigned(col[3], len[3], UINT64_MAX, pos)) { fail(PP_ERR_PANIC, "could not parse the POS column", true); return; }
+        if (pos > 0) pos -= 1;
+        uint32_t nm = 0xFFFFFFFFu;
+        bool pass_qc = true, bad_nm = false;
+        while (tags && tags <= end) {
+            const char *t = (const char *)memchr(tags, '\t', (size_t)(end - tags));
+            size_t tl = t ? (size_t)(t - tags) : (size_t)(end - tags);
+            if (tl >= 5 && memcmp(tags, "NM:i:", 5) == 0) {
+                uint64_t v;
+                if (!parse_unsigned(tags + 5, tl - 5, 0xFFFFFFFFull, v)) { bad_nm = true; break; }
+                nm = (uint32_t)v;
             }
-            i = j + 1;
+            if (tl == 9 && strncasecmp(tags, "ZP:Z:fail", 9) == 0) pass_qc = false;
+            if (!t) break;
+            tags = t + 1;
         }
-        if (!ok) {
-            g.runs.resize(run_lo);
-            fail(PP_ERR_QUIT, "encountered an invalid CIGAR string for read %.*s: \"%.*s\"", (int)len[0],
-                 col[0], (int)cl, c);
+        if (bad_nm) { fail(PP_ERR_PANIC, "could not parse the NM tag", true); return; }
+        if (nm == 0xFFFFFFFFu && (flags & 4) == 0) { fail(PP_ERR_QUIT, "missing NM tag", true); return; }
+        // get_expanded_cigar, alignment.rs:325-346: the whole string must be \d+[MIDNSHP=X] tokens
+        const uint32_t run_lo = (uint32_t)c.runs.size();
+        const char *cg = col[5];
+        const size_t cl = len[5];
+        if (!(cl == 1 && cg[0] == '*')) {
+            size_t i = 0;
+            bool ok = true, overflow = false;
+            while (i < cl) {
+                size_t j = i;
+                while (j < cl && cg[j] >= '0' && cg[j] <= '9') j++;
+                int op = (j < cl) ? op_code(cg[j]) : -1;
+                if (j == i || op < 0) { ok = false; break; }
+                uint64_t num;
+                if (!parse_unsigned(cg + i, j - i, 0xFFFFFFFFull, num)) { overflow = true; break; }
+                while (num > 0) {  // a packed run holds 28 bits of length
+                    uint32_t piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)num;
+                    c.runs.push_back((piece << 4) | (uint32_t)op);
+                    num -= piece;
+                }
+                i = j + 1;
+            }
+            if (overflow) { c.runs.resize(run_lo); fail(PP_ERR_PANIC, "CIGAR run length does not fit u32", true); return; }
+            if (!ok) {
+                c.runs.resize(run_lo);
+                char m[600];
+                snprintf(m, sizeof m, "encountered an invalid CIGAR string for read %.*s: \"%.*s\"", (int)len[0], col[0], (int)cl, cg);
+                fail(PP_ERR_QUIT, m, false);
+                return;
+            }
         }
+        if (flags & 4) { c.runs.resize(run_lo); continue; }  // unaligned: parsed, then skipped (alignment.rs:250)
+        Rec r;
+        r.name = col[0]; r.name_n = (uint32_t)len[0];
+        r.ref = col[2]; r.ref_n = (uint32_t)len[2];
+        r.seq = col[9]; r.seq_n = (uint32_t)len[9];
+        r.ref_start = pos;
+        r.flags = (uint32_t)flags;
+        r.nm = nm;
+        r.pass_qc = pass_qc;
+        r.run_lo = run_lo;
+        r.run_n = (uint32_t)c.runs.size() - run_lo;
+        if (last_ref && last_ref->size() == len[2] && memcmp(last_ref->data(), col[2], len[2]) == 0) {
+            r.contig = last_contig;
+        } else {
+            key.assign(col[2], len[2]);
+            auto it = asmb->index.find(key);
+            r.contig = it == asmb->index.end() ? -1 : (int32_t)it->second;
+            if (it != asmb->index.end()) { last_ref = &it->first; last_contig = r.contig; }
+        }
+        c.recs.push_back(r);
     }
-    if (flags & 4) {
-        g.runs.resize(run_lo);
-        return false;
-    }
-    Parsed a;
-    a.name = col[0]; a.name_n = len[0];
-    a.ref = col[2]; a.ref_n = len[2];
-    a.flags = (uint32_t)flags;
-    a.ref_start = pos;
-    a.seq = col[9]; a.seq_n = len[9];
-    a.nm = nm;
-    a.pass_qc = pass_qc;
-    a.run_lo = run_lo;
-    a.run_hi = (uint32_t)g.runs.size();
-    g.al.push_back(a);
-    return true;
 }
 
-// process_one_read, alignment.rs:275-305
-uint64_t process_one_read(pp_ingest &I, Group &g) {
-    size_t n = g.al.size();
-    if (I.careful && n > 1) return 0;
-    // get_read_seq_from_alignments, alignment.rs:311-322
-    const Parsed *src = nullptr;
-    for (size_t i = 0; i < n; i++)
-        if (!(g.al[i].seq_n == 1 && g.al[i].seq[0] == '*')) { src = &g.al[i]; break; }
-    if (!src) {
-        if (n == 0) fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
-        fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)g.al[0].name_n, g.al[0].name);
-    }
-    const bool src_fwd = (src->flags & 16) == 0;
+struct OutRec {            // a good alignment, ready to be copied into the batch
+    const Rec *rec, *src;  // src: the group's record that carries the SEQ (for "*" fills)
+    const uint32_t *runs;
+    uint32_t k;
+    bool star, revcomp;
+};
 
-    size_t n_good = 0;
-    std::vector<uint8_t> good(n, 0);
-    for (size_t i = 0; i < n; i++) {
-        const Parsed &a = g.al[i];
-        if (a.run_lo == a.run_hi)  // chars().next().unwrap() on an empty expanded CIGAR
-            fail(PP_ERR_PANIC, "aligned record of read %.*s has an empty CIGAR", (int)a.name_n, a.name);
-        uint32_t f = g.runs[a.run_lo] & 15u, l = g.runs[a.run_hi - 1] & 15u;
-        bool ends_ok = (f == PP_OP_M || f == PP_OP_EQ) && (l == PP_OP_M || l == PP_OP_EQ);
-        if (ends_ok && a.nm <= I.max_errors && a.pass_qc) {
-            good[i] = 1;
-            n_good++;
-        }
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F f) {
+    if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; t++) {
+        const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+        if (lo < hi) pool.emplace_back([=] { f(lo, hi, t); });
     }
-    for (size_t i = 0; i < n; i++) {
-        if (!good[i]) continue;
-        const Parsed &a = g.al[i];
-        auto it = I.asmb->index.find(std::string(a.ref, a.ref_n));
-        if (it == I.asmb->index.end())
-            fail(PP_ERR_QUIT, "query name %.*s in SAM but not in assembly", (int)a.ref_n, a.ref);
-        if (a.ref_start > 0xFFFFFFFEull)
-            fail(PP_ERR_PANIC, "alignment of read %.*s starts past the end of %.*s", (int)a.name_n, a.name,
-                 (int)a.ref_n, a.ref);
-        I.contig.push_back(it->second);
-        I.ref_start.push_back((uint32_t)a.ref_start);
-        I.k.push_back((uint32_t)n_good);
-        I.seq_off.push_back(I.seq.size());
-        const bool star = a.seq_n == 1 && a.seq[0] == '*';
-        const char *s = star ? src->seq : a.seq;
-        const size_t sn = star ? src->seq_n : a.seq_n;
-        const size_t base = I.seq.size();
-        I.seq.resize(base + sn);
-        uint8_t *dst = I.seq.data() + base;
-        if (star && ((a.flags & 16) == 0) != src_fwd) {
-            // add_read_seq (alignment.rs:161-167): reverse complement of the (uppercased) group SEQ
-            for (size_t j = 0; j < sn; j++) {
-                unsigned char ch = (unsigned char)s[sn - 1 - j];
-                if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
-                dst[j] = COMP.t[ch];
-            }
-        } else {
-            for (size_t j = 0; j < sn; j++) {
-                unsigned char ch = (unsigned char)s[j];
-                if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);  // to_ascii_uppercase
-                dst[j] = ch;
-            }
-        }
-        I.seq_len.push_back((uint32_t)sn);
-        I.cig_off.push_back(I.cigar.size());
-        I.n_cig.push_back(a.run_hi - a.run_lo);
-        I.cigar.insert(I.cigar.end(), g.runs.begin() + a.run_lo, g.runs.begin() + a.run_hi);
-        I.name_off.push_back(I.names.size());
-        I.names.insert(I.names.end(), a.name, a.name + a.name_n);
-        I.names.push_back('\0');
-    }
-    return n_good;
+    for (auto &th : pool) th.join();
 }
 
 }  // namespace
@@ -423,53 +386,192 @@ extern "C" int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int c
     return PP_OK;
 }
 
-// add_to_pileup, alignment.rs:225-272
+// add_to_pileup (alignment.rs:225-272) + process_one_read (alignment.rs:275-322), multi-threaded:
+// the text is parsed in parallel slices, the grouping/gates run once over the parsed records in file
+// order (so errors surface in the order the reference's streaming loop would hit them), and the SoA
+// is filled in parallel.  The result does not depend on the thread count.
 extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *counts, char *err, size_t errlen) {
     if (!I || !path) return PP_ERR_ARG;
     pp_sam_counts c{0, 0, 0};
+    int fd = -1;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::vector<char> fallback;
+    auto cleanup = [&] {
+        if (map) munmap(map, map_len);
+        if (fd >= 0) close(fd);
+    };
     try {
-        std::vector<char> text;
-        if (!read_file(path, text)) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
-        LineReader lr{text.data(), text.data() + text.size()};
-        const char *line;
-        size_t n;
-        uint64_t line_no = 0;
-        Group g;
-        std::string current;  // current_read_name
-        while (lr.next(line, n)) {
-            line_no++;
-            if (n == 0) continue;
-            if (line[0] == '@') continue;
-            // a record that does not continue the current group closes it first; the decision
-            // needs the QNAME only, so peek at it before parsing into the (possibly flushed) group
-            const char *tab = (const char *)memchr(line, '\t', n);
-            size_t qn = tab ? (size_t)(tab - line) : n;
-            Group tmp;
-            bool same = current.empty() || (current.size() == qn && memcmp(current.data(), line, qn) == 0);
-            Group &dst = same ? g : tmp;
-            if (!parse_line(line, n, path, line_no, dst)) continue;  // unaligned: skipped, name not recorded
-            c.alignments++;
-            if (!same) {
-                c.used += process_one_read(*I, g);
-                c.reads++;
-                g.clear();
-                // move the freshly parsed record into the (now empty) group
-                Parsed a = tmp.al[0];
-                a.run_lo = 0;
-                a.run_hi = (uint32_t)tmp.runs.size();
-                g.runs = tmp.runs;
-                g.al.push_back(a);
-            }
-            current.assign(line, qn);
+        fd = open(path, O_RDONLY);
+        if (fd < 0) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+        const char *text = nullptr;
+        size_t size = 0;
+        if (S_ISREG(st.st_mode) && st.st_size > 0) {
+            map_len = (size_t)st.st_size;
+            map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) { map = nullptr; fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path); }
+            madvise(map, map_len, MADV_SEQUENTIAL);
+            text = (const char *)map;
+            size = map_len;
+        } else {  // pipe or empty file
+            if (!read_file(path, fallback)) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+            text = fallback.data();
+            size = fallback.size();
         }
-        c.used += process_one_read(*I, g);
+        unsigned threads;
+        if (const char *e = getenv("PP_INGEST_THREADS")) threads = std::max(1, std::min(64, atoi(e)));
+        else threads = std::max(1u, std::min({std::thread::hardware_concurrency(), 64u, (unsigned)(size / (4u << 20)) + 1u}));
+
+        // ---- parallel parse of line-aligned slices ----
+        std::vector<Chunk> chunks(threads);
+        {
+            const char *p = text, *end = text + size;
+            for (unsigned t = 0; t < threads; t++) {
+                chunks[t].beg = p;
+                const char *want = (t + 1 == threads) ? end : text + (size / threads) * (t + 1);
+                if (want < p) want = p;
+                if (want < end) {
+                    const char *nl = (const char *)memchr(want, '\n', (size_t)(end - want));
+                    want = nl ? nl + 1 : end;
+                }
+                chunks[t].end = want;
+                p = want;
+            }
+        }
+        parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t t = lo; t < hi; t++) parse_chunk(chunks[t], I->asmb);
+        });
+        // the first slice with a parse error bounds what the streaming loop would have processed
+        size_t n_chunks_ok = threads;
+        for (unsigned t = 0; t < threads; t++)
+            if (chunks[t].err_code) { n_chunks_ok = t; break; }
+
+        // ---- grouping and gates, in file order ----
+        std::vector<OutRec> outs;
+        std::vector<const Rec *> group;
+        std::vector<const uint32_t *> group_runs;
+        const char *cur_name = nullptr;
+        uint32_t cur_n = 0;
+        auto flush = [&]() {  // process_one_read
+            const size_t n = group.size();
+            if (I->careful && n > 1) return;
+            const Rec *src = nullptr;
+            for (size_t i = 0; i < n; i++)
+                if (!(group[i]->seq_n == 1 && group[i]->seq[0] == '*')) { src = group[i]; break; }
+            if (!src) {
+                if (n == 0) fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
+                fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)group[0]->name_n, group[0]->name);
+            }
+            const bool src_fwd = (src->flags & 16) == 0;
+            uint32_t n_good = 0;
+            const size_t first_out = outs.size();
+            for (size_t i = 0; i < n; i++) {
+                const Rec &a = *group[i];
+                if (a.run_n == 0)  // chars().next().unwrap() on an empty expanded CIGAR
+                    fail(PP_ERR_PANIC, "aligned record of read %.*s has an empty CIGAR", (int)a.name_n, a.name);
+                const uint32_t f = group_runs[i][0] & 15u, l = group_runs[i][a.run_n - 1] & 15u;
+                const bool ends_ok = (f == PP_OP_M || f == PP_OP_EQ) && (l == PP_OP_M || l == PP_OP_EQ);
+                if (!(ends_ok && a.nm <= I->max_errors && a.pass_qc)) continue;
+                OutRec o;
+                o.rec = &a; o.src = src; o.runs = group_runs[i]; o.k = 0;
+                o.star = a.seq_n == 1 && a.seq[0] == '*';
+                o.revcomp = o.star && ((a.flags & 16) == 0) != src_fwd;
+                outs.push_back(o);
+                n_good++;
+            }
+            for (size_t i = first_out; i < outs.size(); i++) {
+                const Rec &a = *outs[i].rec;
+                if (a.contig < 0) fail(PP_ERR_QUIT, "query name %.*s in SAM but not in assembly", (int)a.ref_n, a.ref);
+                if (a.ref_start > 0xFFFFFFFEull)
+                    fail(PP_ERR_PANIC, "alignment of read %.*s starts past the end of %.*s", (int)a.name_n, a.name, (int)a.ref_n, a.ref);
+                outs[i].k = n_good;
+            }
+            c.used += n_good;
+        };
+        for (size_t t = 0; t <= n_chunks_ok && t < threads; t++) {
+            const Chunk &ch = chunks[t];
+            const size_t nrec = ch.err_code ? ch.err_recs : ch.recs.size();
+            for (size_t i = 0; i < nrec; i++) {
+                const Rec &r = ch.recs[i];
+                c.alignments++;
+                const bool same = cur_n == 0 || (cur_n == r.name_n && memcmp(cur_name, r.name, cur_n) == 0);
+                if (!same) {
+                    flush();
+                    c.reads++;
+                    group.clear();
+                    group_runs.clear();
+                }
+                group.push_back(&r);
+                group_runs.push_back(ch.runs.data() + r.run_lo);
+                cur_name = r.name;
+                cur_n = r.name_n;
+            }
+            if (ch.err_code) {  // the streaming loop would have stopped at this line
+                uint64_t line_no = ch.n_lines;
+                for (size_t u = 0; u < t; u++) line_no += chunks[u].n_lines;
+                if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
+                fail(ch.err_code, "%s", ch.err_what.c_str());
+            }
+        }
+        flush();
         c.reads++;
         if (c.alignments == 0) fail(PP_ERR_QUIT, "no alignments in \"%s\"", path);
+
+        // ---- parallel fill of the structure of arrays ----
+        const size_t n_out = outs.size(), base = I->contig.size();
+        std::vector<uint64_t> so(n_out + 1, 0), co(n_out + 1, 0), no(n_out + 1, 0);
+        for (size_t i = 0; i < n_out; i++) {
+            so[i + 1] = so[i] + (outs[i].star ? outs[i].src->seq_n : outs[i].rec->seq_n);
+            co[i + 1] = co[i] + outs[i].rec->run_n;
+            no[i + 1] = no[i] + outs[i].rec->name_n + 1;
+        }
+        const uint64_t seq0 = I->seq.size(), cig0 = I->cigar.size(), nam0 = I->names.size();
+        I->contig.resize(base + n_out); I->ref_start.resize(base + n_out); I->k.resize(base + n_out);
+        I->seq_off.resize(base + n_out); I->seq_len.resize(base + n_out); I->cig_off.resize(base + n_out);
+        I->n_cig.resize(base + n_out); I->name_off.resize(base + n_out);
+        I->seq.resize(seq0 + so[n_out]); I->cigar.resize(cig0 + co[n_out]); I->names.resize(nam0 + no[n_out]);
+        parallel_for(n_out, threads, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t i = lo; i < hi; i++) {
+                const OutRec &o = outs[i];
+                const Rec &a = *o.rec;
+                const size_t d = base + i;
+                I->contig[d] = (uint32_t)a.contig;
+                I->ref_start[d] = (uint32_t)a.ref_start;
+                I->k[d] = o.k;
+                I->seq_off[d] = seq0 + so[i];
+                const char *s = o.star ? o.src->seq : a.seq;
+                const size_t sn = o.star ? o.src->seq_n : a.seq_n;
+                I->seq_len[d] = (uint32_t)sn;
+                uint8_t *dst = I->seq.data() + seq0 + so[i];
+                if (o.revcomp) {  // add_read_seq (alignment.rs:161-167): reverse complement of the upper-cased group SEQ
+                    for (size_t j = 0; j < sn; j++) {
+                        unsigned char ch = (unsigned char)s[sn - 1 - j];
+                        if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
+                        dst[j] = COMP.t[ch];
+                    }
+                } else {
+                    for (size_t j = 0; j < sn; j++) {
+                        unsigned char ch = (unsigned char)s[j];
+                        dst[j] = (ch >= 'a' && ch <= 'z') ? (unsigned char)(ch - 32) : ch;  // to_ascii_uppercase
+                    }
+                }
+                I->cig_off[d] = cig0 + co[i];
+                I->n_cig[d] = a.run_n;
+                memcpy(I->cigar.data() + cig0 + co[i], o.runs, (size_t)a.run_n * 4);
+                I->name_off[d] = nam0 + no[i];
+                memcpy(I->names.data() + nam0 + no[i], a.name, a.name_n);
+                I->names[nam0 + no[i] + a.name_n] = '\0';
+            }
+        });
     } catch (const IngestError &e) {
         if (err && errlen) snprintf(err, errlen, "%s", e.msg.c_str());
         if (counts) *counts = c;
+        cleanup();
         return e.code;
     }
+    cleanup();
     if (counts) *counts = c;
     return PP_OK;
 }

@@ -161,3 +161,45 @@ def test_fasta_errors_match_the_oracle(orc, tmp_path):
         except orc.OrcError as e:
             want = (e.code, e.msg)
         assert got == want and got[0] == 1, (text, got, want)
+
+
+def test_ingest_is_independent_of_the_thread_count(orc, tmp_path, monkeypatch):
+    """The SAM ingest parses line-aligned slices in parallel; records, counts and errors (with their
+    line numbers, in the order the reference's streaming loop would hit them) must not depend on it."""
+    ds = synth.rich_dataset(str(tmp_path), seed=61, contig_lens=(5000, 1500), coverage=30, repeat_len=350,
+                            repeat_copies=4, lowercase_frac=0.2, zp_frac=0.05)
+    sams = [ds["sam1"], ds["sam2"]]
+    ref = None
+    for t in ("1", "2", "7", "64"):
+        monkeypatch.setenv("PP_INGEST_THREADS", t)
+        names, descs, off, bases, recs, counts = pp.ingest(ds["fasta"], sams, max_errors=10)
+        cur = (counts, {k: v.tobytes() for k, v in recs.items()})
+        if ref is None:
+            ref = cur
+        assert cur == ref, f"thread count {t} changed the ingest"
+    # an error deep in the file: same message and line number whatever the slicing
+    lines = open(ds["sam1"]).read().split("\n")
+    n = len(lines)
+    broken = list(lines)
+    broken[int(n * 0.8)] = "bad\t0\tcontig_1\t1\t60\t10M"          # too few columns late in the file
+    p1 = tmp_path / "late_error.sam"
+    p1.write_text("\n".join(broken))
+    broken2 = list(lines)
+    first = next(i for i, l in enumerate(broken2) if l and not l.startswith("@"))
+    f = broken2[first].split("\t"); f[9] = "*"; f[10] = "*"
+    broken2[first] = "\t".join(f)                                      # first read group has no sequence ...
+    broken2[int(n * 0.8)] = "bad\t0\tcontig_1\t1\t60\t10M"          # ... and a parse error much later
+    p2 = tmp_path / "two_errors.sam"
+    p2.write_text("\n".join(broken2))
+    for path in (p1, p2):
+        try:
+            orc.polish_files(ds["fasta"], [str(path)])
+            want = (0, "")
+        except orc.OrcError as e:
+            want = (e.code, e.msg)
+        assert want[0] == 1
+        for t in ("1", "3", "16"):
+            monkeypatch.setenv("PP_INGEST_THREADS", t)
+            with pytest.raises(pp.PolypolishError) as e:
+                pp.ingest(ds["fasta"], [str(path)])
+            assert (e.value.code, e.value.msg) == want, (t, path.name)
