@@ -192,6 +192,11 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     if (opt->debug_path) log("  --debug %s\n\n", opt->debug_path);
     else log("  not logging debugging information\n\n");
 
+    const bool timing = getenv("PP_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[timing] %-28s %8.3f s\n", what,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     // load_assembly, polish.rs:93-106
     log("Loading assembly\n");
     pp_assembly *a = nullptr;
@@ -202,6 +207,7 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     for (uint32_t c = 0; c < nc; c++) log("%s (%s bp)\n", pp_assembly_name(a, c), commas(off[c + 1] - off[c]).c_str());
     log("\n");
 
+    lap("assembly loaded");
     // load_alignments, polish.rs:109-134
     log("Loading alignments\n");
     pp_ingest *g = nullptr;
@@ -224,6 +230,7 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
         opt->careful ? " from reads with only one alignment" : "", commas(used_total).c_str(),
         commas(alignment_total - used_total).c_str());
 
+    lap("alignments ingested");
     // polish_sequences, polish.rs:137-154 -- on the device
     log("Polishing assembly sequences\n");
     pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
@@ -245,6 +252,7 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
     if (rc == PP_OK) rc = pp_polish_add(ctx, &batch, PP_MEM_HOST);
     if (rc == PP_OK) rc = pp_polish_finish(ctx);
+    lap("uploaded + polished on device");
     if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
     if (dbg) fclose(dbg);
     pp_polish_set_debug(ctx, 0);
@@ -260,6 +268,7 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
         return rc;
     }
 
+    lap("result fetched");
     // print_seq_to_stdout (polish.rs:196-203), one contig after the other in FASTA order
     size_t need = total;
     for (uint32_t c = 0; c < nc; c++)

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -217,14 +218,37 @@ extern "C" const uint64_t *pp_assembly_offsets(const pp_assembly *a) { return a-
 extern "C" const uint8_t *pp_assembly_bases(const pp_assembly *a) { return a->bases.data(); }
 
 // =================================================================================================
+// growable array whose new elements are NOT zero-filled (a 1 GB std::vector::resize costs ~0.2 s)
+template <typename T>
+struct RawBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void resize(size_t m) {
+        if (m > cap) {
+            size_t want = std::max(m, cap + cap / 2);
+            T *q = (T *)realloc(p, (want ? want : 1) * sizeof(T));
+            if (!q) throw std::bad_alloc();
+            p = q;
+            cap = want;
+        }
+        n = m;
+    }
+};
+
 struct pp_ingest {
     const pp_assembly *asmb;
     uint32_t max_errors;
     bool careful;
-    std::vector<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
-    std::vector<uint64_t> seq_off, cig_off, name_off;
-    std::vector<uint8_t> seq;
-    std::vector<char> names;  // NUL-separated QNAMEs, one per record
+    RawBuf<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
+    RawBuf<uint64_t> seq_off, cig_off, name_off;
+    RawBuf<uint8_t> seq;
+    RawBuf<char> names;  // NUL-separated QNAMEs, one per record
 };
 
 namespace {
@@ -237,6 +261,7 @@ struct Rec {
     uint32_t flags, nm;
     int32_t contig;            // index into the assembly, -1 if RNAME is not in it
     uint32_t run_lo, run_n;    // packed CIGAR runs in the chunk's pool (zero-length runs dropped)
+    const uint32_t *runs;      // = pool + run_lo, set when the chunk is complete
     uint8_t pass_qc;
 };
 
@@ -351,6 +376,7 @@ void parse_chunk(Chunk &c, const pp_assembly *asmb) {
             r.contig = it == asmb->index.end() ? -1 : (int32_t)it->second;
             if (it != asmb->index.end()) { last_ref = &it->first; last_contig = r.contig; }
         }
+        r.runs = nullptr;
         c.recs.push_back(r);
     }
 }
@@ -449,33 +475,49 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
             if (chunks[t].err_code) { n_chunks_ok = t; break; }
 
         // ---- grouping and gates, in file order ----
+        size_t total_recs = 0;
+        for (size_t t = 0; t <= n_chunks_ok && t < threads; t++)
+            total_recs += chunks[t].err_code ? chunks[t].err_recs : chunks[t].recs.size();
+        std::vector<const Rec *> all(total_recs);
+        {
+            std::vector<size_t> first(threads + 1, 0);
+            for (size_t t = 0; t <= n_chunks_ok && t < threads; t++)
+                first[t + 1] = first[t] + (chunks[t].err_code ? chunks[t].err_recs : chunks[t].recs.size());
+            parallel_for(std::min<size_t>(n_chunks_ok + 1, threads), threads, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t t = lo; t < hi; t++) {
+                    Chunk &ch = chunks[t];
+                    const size_t nrec = ch.err_code ? ch.err_recs : ch.recs.size();
+                    for (size_t i = 0; i < nrec; i++) {
+                        ch.recs[i].runs = ch.runs.data() + ch.recs[i].run_lo;
+                        all[first[t] + i] = &ch.recs[i];
+                    }
+                }
+            });
+        }
         std::vector<OutRec> outs;
-        std::vector<const Rec *> group;
-        std::vector<const uint32_t *> group_runs;
-        const char *cur_name = nullptr;
-        uint32_t cur_n = 0;
-        auto flush = [&]() {  // process_one_read
-            const size_t n = group.size();
+        outs.reserve(total_recs);
+        auto flush = [&](size_t g0, size_t g1) {  // process_one_read on records [g0, g1)
+            const size_t n = g1 - g0;
             if (I->careful && n > 1) return;
             const Rec *src = nullptr;
-            for (size_t i = 0; i < n; i++)
-                if (!(group[i]->seq_n == 1 && group[i]->seq[0] == '*')) { src = group[i]; break; }
+            for (size_t i = g0; i < g1; i++)
+                if (!(all[i]->seq_n == 1 && all[i]->seq[0] == '*')) { src = all[i]; break; }
             if (!src) {
                 if (n == 0) fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
-                fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)group[0]->name_n, group[0]->name);
+                fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)all[g0]->name_n, all[g0]->name);
             }
             const bool src_fwd = (src->flags & 16) == 0;
             uint32_t n_good = 0;
             const size_t first_out = outs.size();
-            for (size_t i = 0; i < n; i++) {
-                const Rec &a = *group[i];
+            for (size_t i = g0; i < g1; i++) {
+                const Rec &a = *all[i];
                 if (a.run_n == 0)  // chars().next().unwrap() on an empty expanded CIGAR
                     fail(PP_ERR_PANIC, "aligned record of read %.*s has an empty CIGAR", (int)a.name_n, a.name);
-                const uint32_t f = group_runs[i][0] & 15u, l = group_runs[i][a.run_n - 1] & 15u;
+                const uint32_t f = a.runs[0] & 15u, l = a.runs[a.run_n - 1] & 15u;
                 const bool ends_ok = (f == PP_OP_M || f == PP_OP_EQ) && (l == PP_OP_M || l == PP_OP_EQ);
                 if (!(ends_ok && a.nm <= I->max_errors && a.pass_qc)) continue;
                 OutRec o;
-                o.rec = &a; o.src = src; o.runs = group_runs[i]; o.k = 0;
+                o.rec = &a; o.src = src; o.runs = a.runs; o.k = 0;
                 o.star = a.seq_n == 1 && a.seq[0] == '*';
                 o.revcomp = o.star && ((a.flags & 16) == 0) != src_fwd;
                 outs.push_back(o);
@@ -490,32 +532,27 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
             }
             c.used += n_good;
         };
-        for (size_t t = 0; t <= n_chunks_ok && t < threads; t++) {
-            const Chunk &ch = chunks[t];
-            const size_t nrec = ch.err_code ? ch.err_recs : ch.recs.size();
-            for (size_t i = 0; i < nrec; i++) {
-                const Rec &r = ch.recs[i];
-                c.alignments++;
-                const bool same = cur_n == 0 || (cur_n == r.name_n && memcmp(cur_name, r.name, cur_n) == 0);
+        size_t g0 = 0;
+        for (size_t i = 0; i < total_recs; i++) {
+            if (i > g0) {  // does record i continue the group of record i-1?  (alignment.rs:255)
+                const Rec &p = *all[i - 1], &r = *all[i];
+                const bool same = p.name_n == 0 || (p.name_n == r.name_n && memcmp(p.name, r.name, r.name_n) == 0);
                 if (!same) {
-                    flush();
+                    flush(g0, i);
                     c.reads++;
-                    group.clear();
-                    group_runs.clear();
+                    g0 = i;
                 }
-                group.push_back(&r);
-                group_runs.push_back(ch.runs.data() + r.run_lo);
-                cur_name = r.name;
-                cur_n = r.name_n;
-            }
-            if (ch.err_code) {  // the streaming loop would have stopped at this line
-                uint64_t line_no = ch.n_lines;
-                for (size_t u = 0; u < t; u++) line_no += chunks[u].n_lines;
-                if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
-                fail(ch.err_code, "%s", ch.err_what.c_str());
             }
         }
-        flush();
+        c.alignments = total_recs;
+        if (n_chunks_ok < threads) {  // the streaming loop would have stopped at the failing line
+            const Chunk &ch = chunks[n_chunks_ok];
+            uint64_t line_no = ch.n_lines;
+            for (size_t u = 0; u < n_chunks_ok; u++) line_no += chunks[u].n_lines;
+            if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
+            fail(ch.err_code, "%s", ch.err_what.c_str());
+        }
+        flush(g0, total_recs);
         c.reads++;
         if (c.alignments == 0) fail(PP_ERR_QUIT, "no alignments in \"%s\"", path);
 
