@@ -55,6 +55,12 @@ typedef struct pp_ctx pp_ctx;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int pp_ctx_create(int device, pp_ctx **out);
+/* Same, but the HIP runtime / device initialisation (a few 100 ms in a fresh process) runs on a helper
+ * thread so that host-side work (pp_assembly_load, pp_ingest_sam, the host half of pp_polish_files /
+ * pp_filter_files) overlaps it.  Every entry point that needs the device waits for it first;
+ * pp_ctx_wait() waits explicitly and returns PP_OK or PP_ERR_HIP / PP_ERR_ARG (no usable device). */
+int pp_ctx_create_async(int device, pp_ctx **out);
+int pp_ctx_wait(pp_ctx *ctx);
 void pp_ctx_destroy(pp_ctx *ctx);
 const char *pp_last_error(const pp_ctx *ctx);
 int pp_ctx_sync(pp_ctx *ctx);          /* hipStreamSynchronize on the context's stream          */

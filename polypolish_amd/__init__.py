@@ -96,7 +96,7 @@ class FilterInput(C.Structure):
 
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
-    "pp_ctx_create", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
+    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
@@ -120,6 +120,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
         L.pp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.pp_ctx_create_async.argtypes = [C.c_int, C.POINTER(vp)]
+        L.pp_ctx_wait.argtypes = [vp]
         L.pp_ctx_destroy.argtypes = [vp]
         L.pp_ctx_destroy.restype = None
         L.pp_last_error.argtypes = [vp]

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 #include "polypolish_hip.h"
@@ -82,6 +83,19 @@ static bool is_opt(const char *arg, const char *long_name, const char *short_nam
            (short_name && strcmp(arg, short_name) == 0);
 }
 
+static int no_device(int device) {
+    fprintf(stderr, "\nError: no usable MI355X (HIP) device %d -- this build has no CPU path\n", device);
+    return 1;
+}
+
+// A finished run has nothing left to save: flush the streams and leave without tearing down the HIP
+// runtime and unmapping gigabytes of parsed input page by page (the kernel reclaims both at exit).
+static int finish(int code) {
+    fflush(stdout);
+    fflush(stderr);
+    _exit(code);
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         fputs(HELP, stderr);
@@ -125,24 +139,20 @@ int main(int argc, char **argv) {
             if (!assembly) assembly = a; else sams.push_back(a);
         }
         if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
+        // the device initialises on a helper thread while the host loads and parses the inputs
         pp_ctx *ctx = nullptr;
-        int rc = pp_ctx_create(device, &ctx);
-        if (rc) {
-            fprintf(stderr, "\nError: no usable MI355X (HIP) device %d -- this build has no CPU path\n", device);
-            return 1;
-        }
+        int rc = pp_ctx_create_async(device, &ctx);
+        if (rc) return no_device(device);
         pp_bytes fasta{nullptr, 0};
         rc = pp_polish_files(ctx, assembly, sams.data(), (int)sams.size(), &opt, &fasta);
+        if (pp_ctx_wait(ctx) != PP_OK) return no_device(device);
         if (rc) {
             fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
             pp_ctx_destroy(ctx);
             return rc == PP_ERR_PANIC ? 101 : 1;
         }
         fwrite(fasta.data, 1, fasta.len, stdout);
-        fflush(stdout);
-        pp_bytes_free(&fasta);
-        pp_ctx_destroy(ctx);
-        return 0;
+        return finish(0);
     }
 
     if (cmd == "filter") {
@@ -175,15 +185,16 @@ int main(int argc, char **argv) {
         if (!in1 || !in2 || !out1 || !out2)
             return usage_error("the following required arguments were not provided:\n  --in1 <IN1> --in2 <IN2> --out1 <OUT1> --out2 <OUT2>");
         pp_ctx *ctx = nullptr;
-        int rc = pp_ctx_create(device, &ctx);
-        if (rc) {
-            fprintf(stderr, "\nError: no usable MI355X (HIP) device %d -- this build has no CPU path\n", device);
-            return 1;
-        }
+        int rc = pp_ctx_create_async(device, &ctx);
+        if (rc) return no_device(device);
         rc = pp_filter_files(ctx, in1, in2, out1, out2, orientation, low, high, 0, nullptr);
-        if (rc) fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
-        pp_ctx_destroy(ctx);
-        return rc == 0 ? 0 : (rc == PP_ERR_PANIC ? 101 : 1);
+        if (pp_ctx_wait(ctx) != PP_OK) return no_device(device);
+        if (rc) {
+            fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
+            pp_ctx_destroy(ctx);
+            return rc == PP_ERR_PANIC ? 101 : 1;
+        }
+        return finish(0);
     }
     return usage_error((std::string("unrecognized subcommand '") + cmd + "'").c_str());
 }

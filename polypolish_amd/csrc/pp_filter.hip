@@ -124,6 +124,7 @@ static FileDev file_dev(const pp_ctx *ctx, int f) {
 
 extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!in) return ctx->fail(PP_ERR_ARG, "pp_filter_begin: null input");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }

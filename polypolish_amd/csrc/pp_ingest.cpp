@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -218,26 +219,40 @@ extern "C" const uint64_t *pp_assembly_offsets(const pp_assembly *a) { return a-
 extern "C" const uint8_t *pp_assembly_bases(const pp_assembly *a) { return a->bases.data(); }
 
 // =================================================================================================
-// growable array whose new elements are NOT zero-filled (a 1 GB std::vector::resize costs ~0.2 s)
+// Growable array for the multi-GB buffers of a large job: anonymous mmap backed by transparent huge
+// pages where the kernel allows (512x fewer page faults while many threads first-touch it, and a much
+// cheaper teardown), grown with mremap, and never zero-filled by us.
 template <typename T>
-struct RawBuf {
+struct HugeBuf {
+    static constexpr size_t HUGE = size_t(2) << 20;
     T *p = nullptr;
-    size_t n = 0, cap = 0;
-    ~RawBuf() { free(p); }
+    size_t n = 0, cap = 0, mapped = 0;  // elements, elements, bytes
+    HugeBuf() = default;
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
+    HugeBuf(HugeBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), mapped(o.mapped) { o.p = nullptr; o.n = o.cap = o.mapped = 0; }
+    ~HugeBuf() { if (p) munmap(p, mapped); }
     T *data() { return p; }
     const T *data() const { return p; }
     size_t size() const { return n; }
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
-    void resize(size_t m) {
-        if (m > cap) {
-            size_t want = std::max(m, cap + cap / 2);
-            T *q = (T *)realloc(p, (want ? want : 1) * sizeof(T));
-            if (!q) throw std::bad_alloc();
-            p = q;
-            cap = want;
-        }
-        n = m;
+    void reserve(size_t m) {
+        if (m <= cap) return;
+        size_t bytes = std::max(m, cap * 2) * sizeof(T);
+        bytes = (bytes + HUGE - 1) / HUGE * HUGE;
+        void *q = p ? mremap(p, mapped, bytes, MREMAP_MAYMOVE)
+                    : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        madvise(q, bytes, MADV_HUGEPAGE);
+        p = (T *)q;
+        mapped = bytes;
+        cap = bytes / sizeof(T);
+    }
+    void resize(size_t m) { reserve(m); n = m; }
+    void push_back(const T &v) {
+        if (n == cap) reserve(n + 1);
+        p[n++] = v;
     }
 };
 
@@ -245,10 +260,14 @@ struct pp_ingest {
     const pp_assembly *asmb;
     uint32_t max_errors;
     bool careful;
-    RawBuf<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
-    RawBuf<uint64_t> seq_off, cig_off, name_off;
-    RawBuf<uint8_t> seq;
-    RawBuf<char> names;  // NUL-separated QNAMEs, one per record
+    HugeBuf<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
+    HugeBuf<uint64_t> seq_off, cig_off, name_off;
+    HugeBuf<uint8_t> seq;
+    HugeBuf<char> names;  // NUL-separated QNAMEs, one per record
+    std::vector<std::thread> reapers;  // parse-time memory of finished files being released in the background
+    ~pp_ingest() {
+        for (auto &t : reapers) t.join();
+    }
 };
 
 namespace {
@@ -268,8 +287,8 @@ struct Rec {
 // A slice of the file, parsed by one thread.
 struct Chunk {
     const char *beg = nullptr, *end = nullptr;
-    std::vector<Rec> recs;
-    std::vector<uint32_t> runs;
+    HugeBuf<Rec> recs;
+    HugeBuf<uint32_t> runs;
     uint64_t n_lines = 0;        // lines seen (up to and including a failing one)
     int err_code = 0;            // first parse error of the chunk, if any
     std::string err_what;        // message without the "in <file> (line N)" part where that applies
@@ -446,6 +465,14 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
             text = fallback.data();
             size = fallback.size();
         }
+        const bool timing = getenv("PP_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[timing]   ingest: %-22s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+            t_last = now;
+        };
         unsigned threads;
         if (const char *e = getenv("PP_INGEST_THREADS")) threads = std::max(1, std::min(64, atoi(e)));
         else threads = std::max(1u, std::min({std::thread::hardware_concurrency(), 64u, (unsigned)(size / (4u << 20)) + 1u}));
@@ -469,46 +496,59 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
         parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
             for (size_t t = lo; t < hi; t++) parse_chunk(chunks[t], I->asmb);
         });
+        lap("parse");
         // the first slice with a parse error bounds what the streaming loop would have processed
         size_t n_chunks_ok = threads;
         for (unsigned t = 0; t < threads; t++)
             if (chunks[t].err_code) { n_chunks_ok = t; break; }
 
-        // ---- grouping and gates, in file order ----
+        // ---- grouping and gates ----
+        // Whether record i opens a new read group depends only on records i-1 and i (alignment.rs:255:
+        // it joins when the previous QNAME is empty or equal), so the groups can be cut in parallel:
+        // each part processes the groups that START inside its range, in file order.
         size_t total_recs = 0;
-        for (size_t t = 0; t <= n_chunks_ok && t < threads; t++)
-            total_recs += chunks[t].err_code ? chunks[t].err_recs : chunks[t].recs.size();
-        std::vector<const Rec *> all(total_recs);
-        {
-            std::vector<size_t> first(threads + 1, 0);
-            for (size_t t = 0; t <= n_chunks_ok && t < threads; t++)
-                first[t + 1] = first[t] + (chunks[t].err_code ? chunks[t].err_recs : chunks[t].recs.size());
-            parallel_for(std::min<size_t>(n_chunks_ok + 1, threads), threads, [&](size_t lo, size_t hi, unsigned) {
-                for (size_t t = lo; t < hi; t++) {
-                    Chunk &ch = chunks[t];
-                    const size_t nrec = ch.err_code ? ch.err_recs : ch.recs.size();
-                    for (size_t i = 0; i < nrec; i++) {
-                        ch.recs[i].runs = ch.runs.data() + ch.recs[i].run_lo;
-                        all[first[t] + i] = &ch.recs[i];
-                    }
-                }
-            });
+        std::vector<size_t> first(threads + 1, 0);
+        for (size_t t = 0; t < threads; t++) {
+            const size_t nrec = t > n_chunks_ok ? 0 : (chunks[t].err_code ? chunks[t].err_recs : chunks[t].recs.size());
+            first[t + 1] = first[t] + nrec;
         }
-        std::vector<OutRec> outs;
-        outs.reserve(total_recs);
-        auto flush = [&](size_t g0, size_t g1) {  // process_one_read on records [g0, g1)
+        total_recs = first[threads];
+        HugeBuf<const Rec *> all;
+        all.resize(total_recs);
+        parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t t = lo; t < hi; t++) {
+                Chunk &ch = chunks[t];
+                const size_t nrec = first[t + 1] - first[t];
+                for (size_t i = 0; i < nrec; i++) {
+                    ch.recs[i].runs = ch.runs.data() + ch.recs[i].run_lo;
+                    all[first[t] + i] = &ch.recs[i];
+                }
+            }
+        });
+        lap("flatten");
+        const bool parse_failed = n_chunks_ok < threads;  // the group pending at the failing line is never processed
+        auto is_start = [&](size_t i) {
+            if (i == 0) return true;
+            const Rec &p = *all[i - 1], &r = *all[i];
+            return !(p.name_n == 0 || (p.name_n == r.name_n && memcmp(p.name, r.name, r.name_n) == 0));
+        };
+        struct Part {
+            HugeBuf<OutRec> outs;
+            uint64_t reads = 0, used = 0, seq_sum = 0, cig_sum = 0, nam_sum = 0;
+            int err_code = 0;
+            std::string err_msg;
+        };
+        std::vector<Part> parts(threads);
+        auto process_one_read = [&](Part &P, size_t g0, size_t g1) {  // alignment.rs:275-322 on records [g0, g1)
             const size_t n = g1 - g0;
             if (I->careful && n > 1) return;
             const Rec *src = nullptr;
             for (size_t i = g0; i < g1; i++)
                 if (!(all[i]->seq_n == 1 && all[i]->seq[0] == '*')) { src = all[i]; break; }
-            if (!src) {
-                if (n == 0) fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
-                fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)all[g0]->name_n, all[g0]->name);
-            }
+            if (!src) fail(PP_ERR_QUIT, "no alignments for read %.*s contain sequence", (int)all[g0]->name_n, all[g0]->name);
             const bool src_fwd = (src->flags & 16) == 0;
             uint32_t n_good = 0;
-            const size_t first_out = outs.size();
+            const size_t first_out = P.outs.size();
             for (size_t i = g0; i < g1; i++) {
                 const Rec &a = *all[i];
                 if (a.run_n == 0)  // chars().next().unwrap() on an empty expanded CIGAR
@@ -520,87 +560,129 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
                 o.rec = &a; o.src = src; o.runs = a.runs; o.k = 0;
                 o.star = a.seq_n == 1 && a.seq[0] == '*';
                 o.revcomp = o.star && ((a.flags & 16) == 0) != src_fwd;
-                outs.push_back(o);
+                P.outs.push_back(o);
                 n_good++;
             }
-            for (size_t i = first_out; i < outs.size(); i++) {
-                const Rec &a = *outs[i].rec;
+            for (size_t i = first_out; i < P.outs.size(); i++) {
+                OutRec &o = P.outs[i];
+                const Rec &a = *o.rec;
                 if (a.contig < 0) fail(PP_ERR_QUIT, "query name %.*s in SAM but not in assembly", (int)a.ref_n, a.ref);
                 if (a.ref_start > 0xFFFFFFFEull)
                     fail(PP_ERR_PANIC, "alignment of read %.*s starts past the end of %.*s", (int)a.name_n, a.name, (int)a.ref_n, a.ref);
-                outs[i].k = n_good;
+                o.k = n_good;
+                P.seq_sum += o.star ? o.src->seq_n : a.seq_n;
+                P.cig_sum += a.run_n;
+                P.nam_sum += a.name_n + 1;
             }
-            c.used += n_good;
+            P.used += n_good;
         };
-        size_t g0 = 0;
-        for (size_t i = 0; i < total_recs; i++) {
-            if (i > g0) {  // does record i continue the group of record i-1?  (alignment.rs:255)
-                const Rec &p = *all[i - 1], &r = *all[i];
-                const bool same = p.name_n == 0 || (p.name_n == r.name_n && memcmp(p.name, r.name, r.name_n) == 0);
-                if (!same) {
-                    flush(g0, i);
-                    c.reads++;
-                    g0 = i;
+        parallel_for(total_recs, threads, [&](size_t lo, size_t hi, unsigned t) {
+            Part &P = parts[t];
+            size_t i = lo;
+            while (i < hi && !is_start(i)) i++;  // the tail of a group that started in an earlier part
+            try {
+                while (i < hi) {
+                    size_t j = i + 1;
+                    while (j < total_recs && !is_start(j)) j++;
+                    if (j == total_recs && parse_failed) break;
+                    process_one_read(P, i, j);
+                    P.reads++;
+                    i = j;
                 }
+            } catch (const IngestError &e) {
+                P.err_code = e.code;
+                P.err_msg = e.msg;
             }
-        }
+        });
         c.alignments = total_recs;
-        if (n_chunks_ok < threads) {  // the streaming loop would have stopped at the failing line
+        for (const Part &P : parts) {  // parts are in file order: the first failing group is the one the reference hits
+            c.reads += P.reads;
+            c.used += P.used;
+            if (P.err_code) throw IngestError{P.err_code, P.err_msg};
+        }
+        if (parse_failed) {  // the streaming loop would have stopped at the failing line
             const Chunk &ch = chunks[n_chunks_ok];
             uint64_t line_no = ch.n_lines;
             for (size_t u = 0; u < n_chunks_ok; u++) line_no += chunks[u].n_lines;
             if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
             fail(ch.err_code, "%s", ch.err_what.c_str());
         }
-        flush(g0, total_recs);
-        c.reads++;
-        if (c.alignments == 0) fail(PP_ERR_QUIT, "no alignments in \"%s\"", path);
+        if (total_recs == 0)  // process_one_read on an empty group after the loop (alignment.rs:268)
+            fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
+        lap("group + gates");
 
-        // ---- parallel fill of the structure of arrays ----
-        const size_t n_out = outs.size(), base = I->contig.size();
-        std::vector<uint64_t> so(n_out + 1, 0), co(n_out + 1, 0), no(n_out + 1, 0);
-        for (size_t i = 0; i < n_out; i++) {
-            so[i + 1] = so[i] + (outs[i].star ? outs[i].src->seq_n : outs[i].rec->seq_n);
-            co[i + 1] = co[i] + outs[i].rec->run_n;
-            no[i + 1] = no[i] + outs[i].rec->name_n + 1;
+        // ---- parallel fill of the structure of arrays: every part copies its own good alignments ----
+        std::vector<uint64_t> p_out(threads + 1, 0), p_seq(threads + 1, 0), p_cig(threads + 1, 0), p_nam(threads + 1, 0);
+        for (size_t t = 0; t < threads; t++) {
+            p_out[t + 1] = p_out[t] + parts[t].outs.size();
+            p_seq[t + 1] = p_seq[t] + parts[t].seq_sum;
+            p_cig[t + 1] = p_cig[t] + parts[t].cig_sum;
+            p_nam[t + 1] = p_nam[t] + parts[t].nam_sum;
         }
+        const size_t n_out = p_out[threads], base = I->contig.size();
         const uint64_t seq0 = I->seq.size(), cig0 = I->cigar.size(), nam0 = I->names.size();
         I->contig.resize(base + n_out); I->ref_start.resize(base + n_out); I->k.resize(base + n_out);
         I->seq_off.resize(base + n_out); I->seq_len.resize(base + n_out); I->cig_off.resize(base + n_out);
         I->n_cig.resize(base + n_out); I->name_off.resize(base + n_out);
-        I->seq.resize(seq0 + so[n_out]); I->cigar.resize(cig0 + co[n_out]); I->names.resize(nam0 + no[n_out]);
-        parallel_for(n_out, threads, [&](size_t lo, size_t hi, unsigned) {
-            for (size_t i = lo; i < hi; i++) {
-                const OutRec &o = outs[i];
-                const Rec &a = *o.rec;
-                const size_t d = base + i;
-                I->contig[d] = (uint32_t)a.contig;
-                I->ref_start[d] = (uint32_t)a.ref_start;
-                I->k[d] = o.k;
-                I->seq_off[d] = seq0 + so[i];
-                const char *s = o.star ? o.src->seq : a.seq;
-                const size_t sn = o.star ? o.src->seq_n : a.seq_n;
-                I->seq_len[d] = (uint32_t)sn;
-                uint8_t *dst = I->seq.data() + seq0 + so[i];
-                if (o.revcomp) {  // add_read_seq (alignment.rs:161-167): reverse complement of the upper-cased group SEQ
-                    for (size_t j = 0; j < sn; j++) {
-                        unsigned char ch = (unsigned char)s[sn - 1 - j];
-                        if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
-                        dst[j] = COMP.t[ch];
+        I->seq.resize(seq0 + p_seq[threads]); I->cigar.resize(cig0 + p_cig[threads]); I->names.resize(nam0 + p_nam[threads]);
+        lap("offsets + resize");
+        parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t t = lo; t < hi; t++) {
+                const Part &P = parts[t];
+                uint64_t so = seq0 + p_seq[t], co = cig0 + p_cig[t], no = nam0 + p_nam[t];
+                for (size_t i = 0; i < P.outs.size(); i++) {
+                    const OutRec &o = P.outs[i];
+                    const Rec &a = *o.rec;
+                    const size_t d = base + p_out[t] + i;
+                    I->contig[d] = (uint32_t)a.contig;
+                    I->ref_start[d] = (uint32_t)a.ref_start;
+                    I->k[d] = o.k;
+                    I->seq_off[d] = so;
+                    const char *s = o.star ? o.src->seq : a.seq;
+                    const size_t sn = o.star ? o.src->seq_n : a.seq_n;
+                    I->seq_len[d] = (uint32_t)sn;
+                    uint8_t *dst = I->seq.data() + so;
+                    if (o.revcomp) {  // add_read_seq (alignment.rs:161-167): reverse complement of the upper-cased group SEQ
+                        for (size_t j = 0; j < sn; j++) {
+                            unsigned char ch = (unsigned char)s[sn - 1 - j];
+                            if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
+                            dst[j] = COMP.t[ch];
+                        }
+                    } else {
+                        for (size_t j = 0; j < sn; j++) {
+                            unsigned char ch = (unsigned char)s[j];
+                            dst[j] = (ch >= 'a' && ch <= 'z') ? (unsigned char)(ch - 32) : ch;  // to_ascii_uppercase
+                        }
                     }
-                } else {
-                    for (size_t j = 0; j < sn; j++) {
-                        unsigned char ch = (unsigned char)s[j];
-                        dst[j] = (ch >= 'a' && ch <= 'z') ? (unsigned char)(ch - 32) : ch;  // to_ascii_uppercase
-                    }
+                    so += sn;
+                    I->cig_off[d] = co;
+                    I->n_cig[d] = a.run_n;
+                    memcpy(I->cigar.data() + co, o.runs, (size_t)a.run_n * 4);
+                    co += a.run_n;
+                    I->name_off[d] = no;
+                    memcpy(I->names.data() + no, a.name, a.name_n);
+                    I->names[no + a.name_n] = '\0';
+                    no += a.name_n + 1;
                 }
-                I->cig_off[d] = cig0 + co[i];
-                I->n_cig[d] = a.run_n;
-                memcpy(I->cigar.data() + cig0 + co[i], o.runs, (size_t)a.run_n * 4);
-                I->name_off[d] = nam0 + no[i];
-                memcpy(I->names.data() + nam0 + no[i], a.name, a.name_n);
-                I->names[nam0 + no[i] + a.name_n] = '\0';
             }
+        });
+        lap("fill");
+        // the parsed records, the group lists and the file mapping are released in the background
+        struct Garbage {
+            std::vector<Chunk> chunks;
+            std::vector<Part> parts;
+            HugeBuf<const Rec *> all;
+            void *map;
+            size_t map_len;
+            int fd;
+        };
+        Garbage *gb = new Garbage{std::move(chunks), std::move(parts), std::move(all), map, map_len, fd};
+        map = nullptr;
+        fd = -1;
+        I->reapers.emplace_back([gb] {
+            if (gb->map) munmap(gb->map, gb->map_len);
+            if (gb->fd >= 0) close(gb->fd);
+            delete gb;
         });
     } catch (const IngestError &e) {
         if (err && errlen) snprintf(err, errlen, "%s", e.msg.c_str());

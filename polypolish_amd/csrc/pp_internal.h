@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "polypolish_hip.h"
@@ -66,6 +67,9 @@ struct pp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    std::thread init_thread;  // pp_ctx_create_async: device initialisation in flight
+    bool init_pending = false;
+    int init_rc = 0;
     bool profiling = false;
     bool debug = false;
     std::vector<pp::KernelTimer> timers;

@@ -1522,6 +1522,7 @@ static int upload(pp_ctx *ctx, DevBuf &b, const void *src, size_t bytes, const v
 extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,
                                const uint8_t *bases, int bases_mem, const pp_params *params) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!contig_off || !bases || !params || n_contigs == 0)
         return ctx->fail(PP_ERR_ARG, "pp_polish_begin: null argument or no contigs");
     /* check_option_values, polish.rs:277-287 */
@@ -1563,6 +1564,7 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
 
 extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_add without pp_polish_begin");
     if (ctx->have_batch)
         return ctx->fail(PP_ERR_LIMIT, "this version takes one alignment batch per polish job");
@@ -1752,6 +1754,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
 
 extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_finish without pp_polish_begin");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->have_batch ? ctx->dbatch.n_aln : 0;
@@ -1904,6 +1907,7 @@ extern "C" void pp_debug_extra_free(pp_debug_extra *d) {
 
 extern "C" int pp_ctx_set_profiling(pp_ctx *ctx, int enable) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     ctx->profiling = enable != 0;
     return PP_OK;
 }
@@ -1915,25 +1919,69 @@ extern "C" int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out) {
 }
 
 // ---- context -----------------------------------------------------------------------------------
+__global__ void k_warm(uint32_t *p) {
+    if (p) p[threadIdx.x] = 0;
+}
+
+static int device_init(pp_ctx *ctx) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PP_ERR_HIP;
+    if (ctx->device < 0 || ctx->device >= n) return PP_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PP_ERR_HIP;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return PP_ERR_HIP;
+    return PP_OK;
+}
+
 extern "C" int pp_ctx_create(int device, pp_ctx **out) {
     if (!out) return PP_ERR_ARG;
     *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PP_ERR_HIP;
-    if (device < 0 || device >= n) return PP_ERR_ARG;
-    if (hipSetDevice(device) != hipSuccess) return PP_ERR_HIP;
     pp_ctx *ctx = new pp_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    const int rc = device_init(ctx);
+    if (rc) {
         delete ctx;
-        return PP_ERR_HIP;
+        return rc;
     }
     *out = ctx;
     return PP_OK;
 }
 
+extern "C" int pp_ctx_create_async(int device, pp_ctx **out) {
+    if (!out) return PP_ERR_ARG;
+    pp_ctx *ctx = new pp_ctx();
+    ctx->device = device;
+    ctx->init_pending = true;
+    ctx->init_thread = std::thread([ctx] {
+        ctx->init_rc = device_init(ctx);
+        if (ctx->init_rc == PP_OK) {  // load the code object and spin up the queue while the host parses
+            hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, ctx->stream, (uint32_t *)nullptr);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+    });
+    *out = ctx;
+    return PP_OK;
+}
+
+extern "C" int pp_ctx_wait(pp_ctx *ctx) {
+    if (!ctx) return PP_ERR_ARG;
+    if (ctx->init_pending) {
+        ctx->init_thread.join();
+        ctx->init_pending = false;
+        if (ctx->init_rc == PP_OK) (void)hipSetDevice(ctx->device);  // the device is a per-thread setting
+    }
+    if (ctx->init_rc) {
+        ctx->err = "no usable MI355X (HIP) device " + std::to_string(ctx->device) + " -- this build has no CPU path";
+        return ctx->init_rc;
+    }
+    return PP_OK;
+}
+
 extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     if (!ctx) return;
+    if (pp_ctx_wait(ctx) != PP_OK) {  // never initialised: nothing on the device to release
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
@@ -1958,8 +2006,9 @@ extern "C" int pp_ctx_set_error_(pp_ctx *ctx, int code, const char *msg) {
 extern "C" const char *pp_last_error(const pp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" int pp_ctx_sync(pp_ctx *ctx) {
     if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
     PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PP_OK;
 }
-extern "C" void *pp_ctx_stream(pp_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" void *pp_ctx_stream(pp_ctx *ctx) { return ctx && pp_ctx_wait(ctx) == PP_OK ? (void *)ctx->stream : nullptr; }
 extern "C" const char *pp_version(void) { return "polypolish-mi355x 0.1.0 (parity target v0.6.1)"; }

@@ -203,3 +203,31 @@ def test_ingest_is_independent_of_the_thread_count(orc, tmp_path, monkeypatch):
             with pytest.raises(pp.PolypolishError) as e:
                 pp.ingest(ds["fasta"], [str(path)])
             assert (e.value.code, e.value.msg) == want, (t, path.name)
+
+
+def test_read_groups_across_slice_boundaries(orc, tmp_path, monkeypatch):
+    """Groups are cut in parallel from a local predicate (previous QNAME empty or equal): a group as
+    long as the file, groups straddling every slice boundary and empty QNAMEs must all behave as in the
+    reference's streaming loop."""
+    ref = "ACGGTCATTGCAACGGTTATTGCAGGATCCATTGACCAGTA"
+    fa = tmp_path / "a.fasta"
+    fa.write_text(f">c\n{ref}\n")
+    texts = {
+        "one_group": "".join(_line("same", 0 if i == 0 else 256, "c", 1 + (i % 20), "12M", ref[i % 20:i % 20 + 12] if i == 0 else "*")
+                             for i in range(400)),
+        "triples": "".join(_line(f"r{i // 3}", 0 if i % 3 == 0 else 256, "c", 1 + (i % 25), "12M",
+                                 ref[i % 25:i % 25 + 12] if i % 3 == 0 else "*") for i in range(600)),
+        "empty_names": "".join(_line("" if i % 4 == 1 else f"r{i}", 0, "c", 1 + (i % 25), "12M", ref[i % 25:i % 25 + 12])
+                               for i in range(300)),
+    }
+    for name, text in texts.items():
+        p = tmp_path / f"{name}.sam"
+        p.write_text(text)
+        want = orc.polish_files(str(fa), [str(p)], positions=True)
+        for t in ("1", "5", "64"):
+            monkeypatch.setenv("PP_INGEST_THREADS", t)
+            names, descs, off, bases, recs, counts = pp.ingest(str(fa), [str(p)])
+            assert tuple(counts[0]) == want["counts"], (name, t)
+            got = orc.polish_records(off, bases, recs, positions=True)
+            for k in ("depth", "count_a", "count_c", "count_g", "count_t", "status"):
+                assert np.array_equal(want["positions"][k], got["positions"][k]), (name, t, k)

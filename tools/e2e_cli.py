@@ -38,6 +38,7 @@ for rep in range(2):
     dt_gpu, r1 = run([os.path.join(ROOT, "bin", "polypolish"), "polish", fa, sam])
 dt_cpu, r2 = run([os.path.join(ROOT, "oracle", "_build", "pp_oracle"), "polish", fa, sam])
 same = r1.stdout == r2.stdout
+err = r1.stderr.decode()
+print("\n".join(l for l in err.split("\n") if "[timing]" in l or "Time to run" in l))
 print(f"bin/polypolish: {dt_gpu:.2f} s ({G / 1e6 / dt_gpu:.2f} Mbp/s)   oracle (1 core): {dt_cpu:.2f} s ({G / 1e6 / dt_cpu:.3f} Mbp/s)"
       f"   speed-up {dt_cpu / dt_gpu:.1f}x   identical FASTA: {same}   sha256 {hashlib.sha256(r1.stdout).hexdigest()[:16]}")
-print(r1.stderr.decode()[-600:])
