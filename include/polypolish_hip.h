@@ -110,6 +110,14 @@ typedef struct {
     double depth_sum;          /* sum of per-position depth (cosmetic: mean depth)    */
 } pp_contig_stats;
 
+/* Optional, between pp_polish_begin and pp_polish_finish: restrict what contig c EMITS to its positions
+ * [emit_lo[c], emit_hi[c]) (0-based, relative to the contig; arrays of n_contigs, host memory).  Every
+ * position is still piled up and voted with all the alignments given, but positions outside the range
+ * contribute no polished bytes and no statistics.  This is the window tiling of one large contig across
+ * GPUs: a rank receives its window plus a halo of one alignment span on either
+ * side, with the alignments overlapping the window, and emits only the window.  NULL, NULL = everything. */
+int pp_polish_set_emit(pp_ctx *ctx, const uint64_t *emit_lo, const uint64_t *emit_hi);
+
 /* Start a polish job.  contig_off is a HOST array of n_contigs+1 offsets into `bases` (the
  * concatenated, ASCII-uppercased assembly, src/misc.rs:114,129; total length < 2^32-4096). */
 int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,

@@ -47,7 +47,8 @@ class Positions(C.Structure):
                 ("count_a", C.POINTER(C.c_uint32)), ("count_c", C.POINTER(C.c_uint32)),
                 ("count_g", C.POINTER(C.c_uint32)), ("count_t", C.POINTER(C.c_uint32)),
                 ("count_other", C.POINTER(C.c_uint32)), ("valid_thr", C.POINTER(C.c_uint32)),
-                ("invalid_thr", C.POINTER(C.c_uint32)), ("status", C.POINTER(C.c_uint8))]
+                ("invalid_thr", C.POINTER(C.c_uint32)), ("status", C.POINTER(C.c_uint8)),
+                ("emit_len", C.POINTER(C.c_uint32))]
 
     def to_numpy(self):
         n = self.n_positions

@@ -1021,6 +1021,7 @@ void orc_positions_free(orc_positions *p) {
     free(p->valid_thr);
     free(p->invalid_thr);
     free(p->status);
+    free(p->emit_len);
     memset(p, 0, sizeof *p);
 }
 static void positions_alloc(orc_positions *p, size_t n) {
@@ -1036,6 +1037,7 @@ static void positions_alloc(orc_positions *p, size_t n) {
     p->valid_thr = (uint32_t *)xmalloc(m * 4);
     p->invalid_thr = (uint32_t *)xmalloc(m * 4);
     p->status = (uint8_t *)xmalloc(m);
+    p->emit_len = (uint32_t *)xmalloc(m * 4);
 }
 
 /* get_read_seq_from_alignments, alignment.rs:311-322 */
@@ -1189,8 +1191,10 @@ static size_t polish_one_sequence(const char *name, const char *desc, const Pile
             pos->status[k] = (uint8_t)v.status;
         }
         /* polished_seq.push_str(&seq) then .replace("-", ""), polish.rs:185-188 */
+        const size_t before = polished.len;
         for (size_t q = 0; q < v.new_len; q++)
             if (v.new_base[q] != '-') buf_append(&polished, v.new_base + q, 1);
+        if (pos && pos->depth) pos->emit_len[pos_base + i] = (uint32_t)(polished.len - before);
     }
     size_t out_len = polished.len;
     if (with_header) { /* polish.rs:196-203 */

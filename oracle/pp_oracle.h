@@ -123,6 +123,7 @@ typedef struct {
     uint32_t *valid_thr;
     uint32_t *invalid_thr;
     uint8_t *status;    /* ORC_ST_*                         */
+    uint32_t *emit_len; /* bytes this position put into the polished string (new_base minus '-', polish.rs:185-188) */
 } orc_positions;
 void orc_positions_free(orc_positions *p);
 

@@ -98,7 +98,7 @@ class FilterInput(C.Structure):
 EXPORTS = [
     "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
-    "pp_polish_result_device", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
+    "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
     "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
     "pp_filter_kernel_times", "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
@@ -138,6 +138,7 @@ def lib():
         L.pp_polish_result_device.argtypes = [vp]
         L.pp_polish_result_device.restype = vp
         L.pp_polish_set_debug.argtypes = [vp, C.c_int]
+        L.pp_polish_set_emit.argtypes = [vp, vp, vp]
         L.pp_polish_positions.argtypes = [vp, C.POINTER(PositionsOut)]
         L.pp_ctx_set_profiling.argtypes = [vp, C.c_int]
         L.pp_polish_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
@@ -303,13 +304,26 @@ class Context:
         self._chk(lib().pp_polish_positions(self._h, C.byref(po)))
         return arrs
 
+    def set_emit(self, emit):
+        """emit: None or an (n_contigs, 2) array of [lo, hi) positions each contig emits (pp_polish_set_emit)."""
+        if emit is None:
+            self._chk(lib().pp_polish_set_emit(self._h, None, None))
+            return
+        e = np.ascontiguousarray(emit, dtype=np.uint64).reshape(-1, 2)
+        lo, hi = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+        if len(lo) != self._n_contigs:
+            raise PolypolishError(ERR_ARG, "set_emit: one range per contig")
+        self._chk(lib().pp_polish_set_emit(self._h, lo.ctypes.data, hi.ctypes.data))
+
     def polish_records(self, contig_off, bases, recs, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2,
-                       positions=False):
+                       positions=False, emit=None):
         """Host numpy SoA (field names of pp_aln_batch) -> polished bytes, offsets, stats."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
         lib().pp_polish_set_debug(self._h, int(positions))
         self.polish_begin(contig_off, bases.ctypes.data, MEM_HOST, min_depth, fraction_valid, fraction_invalid)
+        if emit is not None:
+            self.set_emit(emit)
         self.polish_add_ptrs(len(keep["contig"]), {k: v.ctypes.data for k, v in keep.items()}, len(keep["seq"]),
                              len(keep["cigar"]), MEM_HOST)
         self.polish_finish()

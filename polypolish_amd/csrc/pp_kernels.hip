@@ -408,6 +408,7 @@ struct TileArgs {
     u32 *flag_pos;
     u32 *flag_cov;
     ContigStatsDev *stats;
+    const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
     double *dbg_depth;
     u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
     u8 *dbg_status;
@@ -841,6 +842,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
         const u64 gp = w0 + p;
         if (gp >= A.G) break;
+        if (A.own) {  // window tiling: halo positions are voted by the rank that owns them
+            const u32 c = one_contig ? s_c0 : find_contig(A.contig_off, A.n_contigs, gp);
+            const u32 rel = (u32)(gp - A.contig_off[c]);
+            if (rel < A.own[2 * c] || rel >= A.own[2 * c + 1]) {
+                A.code[gp] = 0;
+                continue;
+            }
+        }
         u32 nA, nC, nG, nT, nDel, nOth;
         const u32 defw = cnt[ROW_DEF * TILE + p];
         const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
@@ -1558,7 +1567,26 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
     ctx->job_open = true;
     ctx->job_done = false;
     ctx->have_batch = false;
+    ctx->emit.clear();
     memset(&ctx->dbatch, 0, sizeof ctx->dbatch);
+    return PP_OK;
+}
+
+extern "C" int pp_polish_set_emit(pp_ctx *ctx, const uint64_t *emit_lo, const uint64_t *emit_hi) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_set_emit without pp_polish_begin");
+    ctx->emit.clear();
+    if (!emit_lo && !emit_hi) return PP_OK;
+    if (!emit_lo || !emit_hi) return ctx->fail(PP_ERR_ARG, "pp_polish_set_emit: both arrays or neither");
+    for (uint32_t c = 0; c < ctx->n_contigs; c++) {
+        const uint64_t len = ctx->contig_off[c + 1] - ctx->contig_off[c];
+        if (emit_lo[c] > emit_hi[c] || emit_hi[c] > len) {
+            ctx->emit.clear();
+            return ctx->fail(PP_ERR_ARG, "pp_polish_set_emit: range of contig %u is not inside the contig", c);
+        }
+        ctx->emit.push_back((uint32_t)emit_lo[c]);
+        ctx->emit.push_back((uint32_t)emit_hi[c]);
+    }
     return PP_OK;
 }
 
@@ -1700,6 +1728,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
     T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
+    T.own = nullptr;
+    if (!ctx->emit.empty()) {
+        const void *d_own = nullptr;
+        if (int rc = upload(ctx, ctx->b_own, ctx->emit.data(), ctx->emit.size() * sizeof(uint32_t), &d_own)) return rc;
+        T.own = (const u32 *)d_own;
+    }
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
     const uint32_t per = (nwin + 7) / 8;
@@ -1987,7 +2021,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};

@@ -1,11 +1,18 @@
-"""Multi-GPU polish: contigs shard across ranks, one process per GPU, no data-path collective.
+"""Multi-GPU polish: contigs (and windows of large contigs) shard across ranks, one process per GPU,
+no data-path collective.
 
 Every assembly position's counters depend only on the alignments that cover it
 (src/pileup.rs:56-65) and the only cross-alignment state -- the read group's share 1/k
 (src/alignment.rs:288) -- is fixed by the host ingest BEFORE sharding, so whole contigs can be
 polished independently.  The one exchange of the path is the final collection of polished bytes
-on rank 0, in FASTA order: an all_reduce of the per-contig lengths followed by one gather of the
+on rank 0, in FASTA order: an all_reduce of the per-unit lengths followed by one gather of the
 padded byte payloads (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
+
+A contig that carries more than one rank's share of the alignments (config C5: one 250 Mbp contig)
+is cut into contiguous windows.  A rank polishes its window plus a halo of one alignment span on
+either side, receives every alignment that overlaps the window (so each owned position sees all of
+its alignments, in file order -- the f64 depth stays exact), and emits only the window
+(pp_polish_set_emit).
 """
 from __future__ import annotations
 
@@ -62,6 +69,112 @@ def shard_job(contig_off, bases, recs, owner, rank):
     return mine, loc_off, loc_bases, out
 
 
+REF_CONSUMING = (0, 2, 3, 7, 8)  # M D N = X  (get_ref_end, src/alignment.rs:138-149)
+WINDOW_ALIGN = 2048              # the device's tile width: windows start on tile boundaries
+
+
+def ref_spans(recs) -> np.ndarray:
+    """Reference span of every record from its packed CIGAR runs."""
+    cig = np.asarray(recs["cigar"], dtype=np.uint32)
+    consumes = np.isin(cig & 15, REF_CONSUMING)
+    cs = np.concatenate([[0], np.cumsum((cig >> 4).astype(np.int64) * consumes)])
+    lo = np.asarray(recs["cig_off"], dtype=np.int64)
+    return cs[lo + np.asarray(recs["n_cig"], dtype=np.int64)] - cs[lo]
+
+
+def plan_units(contig_off, recs, world: int, min_window: int = 1 << 16):
+    """Cut the assembly into units (contig, lo, hi): whole contigs, except that a contig holding more
+    than one rank's share of the alignments becomes up to `world` windows.  Deterministic; FASTA order,
+    then position order.  Returns (unit_contig, unit_lo, unit_hi, unit_weight)."""
+    contig_off = np.asarray(contig_off, dtype=np.int64)
+    n_contigs = len(contig_off) - 1
+    lens = contig_off[1:] - contig_off[:-1]
+    per_contig = np.bincount(np.asarray(recs["contig"], dtype=np.int64), minlength=n_contigs).astype(np.float64)
+    share = per_contig.sum() / max(world, 1)
+    uc, ulo, uhi, uw = [], [], [], []
+    for c in range(n_contigs):
+        pieces = 1
+        if world > 1 and per_contig[c] > share > 0:
+            pieces = int(min(world, np.ceil(per_contig[c] / share), max(1, lens[c] // min_window)))
+        cuts = [0]
+        for j in range(1, pieces):
+            x = int(lens[c] * j // pieces) // WINDOW_ALIGN * WINDOW_ALIGN
+            if x > cuts[-1]:
+                cuts.append(x)
+        cuts.append(int(lens[c]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            uc.append(c); ulo.append(lo); uhi.append(hi)
+            uw.append(per_contig[c] * (hi - lo) / lens[c] + 1e-9 * (hi - lo))
+    return (np.array(uc, np.int64), np.array(ulo, np.int64), np.array(uhi, np.int64), np.array(uw, np.float64))
+
+
+def shard_units(contig_off, bases, recs, units, owner, rank):
+    """The sub-job of `rank` over its units.  Every unit becomes one local contig = the unit's window
+    plus a halo of max-alignment-span bases on either side (clipped to the contig), with the records
+    that overlap the window, rebased; file order is kept.  Returns (my_units, contig_off, bases, recs,
+    emit) where emit[j] = [lo, hi) of local contig j that the rank owns."""
+    contig_off = np.asarray(contig_off, dtype=np.int64)
+    uc, ulo, uhi, _ = units
+    mine = np.nonzero(owner == rank)[0]
+    rc = np.asarray(recs["contig"], dtype=np.int64)
+    start = np.asarray(recs["ref_start"], dtype=np.int64)
+    span = ref_spans(recs)
+    n_contigs = len(contig_off) - 1
+    halo = np.zeros(n_contigs, dtype=np.int64)
+    if len(rc):
+        np.maximum.at(halo, rc[rc < n_contigs], span[rc < n_contigs])
+    loc_off = [0]
+    pieces, sel_idx, sel_unit, sel_start, emit = [], [], [], [], []
+    for j, u in enumerate(mine):
+        c, lo, hi = int(uc[u]), int(ulo[u]), int(uhi[u])
+        clen = int(contig_off[c + 1] - contig_off[c])
+        whole = lo == 0 and hi == clen
+        left = 0 if whole else min(lo, int(halo[c]))
+        right = 0 if whole else min(clen - hi, int(halo[c]))
+        pieces.append(bases[int(contig_off[c]) + lo - left:int(contig_off[c]) + hi + right])
+        loc_off.append(loc_off[-1] + (hi - lo) + left + right)
+        emit.append((left, left + hi - lo))
+        if whole:
+            idx = np.nonzero(rc == c)[0]
+        else:
+            idx = np.nonzero((rc == c) & (start < hi) & (start + span > lo))[0]
+        sel_idx.append(idx)
+        sel_unit.append(np.full(len(idx), j, dtype=np.int64))
+        sel_start.append(start[idx] - (lo - left))
+    if sel_idx:
+        idx = np.concatenate(sel_idx)
+        order = np.argsort(idx, kind="stable")  # back to file order
+        sel = idx[order]
+        loc_contig = np.concatenate(sel_unit)[order]
+        loc_start = np.concatenate(sel_start)[order]
+    else:
+        sel = np.zeros(0, np.int64); loc_contig = sel; loc_start = sel
+    seq_len = np.asarray(recs["seq_len"])[sel].astype(np.int64)
+    n_cig = np.asarray(recs["n_cig"])[sel].astype(np.int64)
+
+    def gather(src, starts, lengths):
+        total = int(lengths.sum())
+        if total == 0:
+            return np.asarray(src)[:0].copy()
+        row = np.repeat(np.arange(len(lengths)), lengths)
+        first = np.cumsum(lengths) - lengths
+        return np.asarray(src)[(starts[row] + (np.arange(total) - first[row])).astype(np.int64)]
+
+    out = {
+        "contig": loc_contig.astype(np.uint32),
+        "ref_start": loc_start.astype(np.uint32),  # a start past 2^32 cannot occur: contigs are < 2^32 bp
+        "k": np.asarray(recs["k"])[sel],
+        "seq_off": (np.cumsum(seq_len) - seq_len).astype(np.uint64),
+        "seq_len": np.asarray(recs["seq_len"])[sel],
+        "cig_off": (np.cumsum(n_cig) - n_cig).astype(np.uint64),
+        "n_cig": np.asarray(recs["n_cig"])[sel],
+        "seq": gather(recs["seq"], np.asarray(recs["seq_off"])[sel].astype(np.int64), seq_len),
+        "cigar": gather(recs["cigar"], np.asarray(recs["cig_off"])[sel].astype(np.int64), n_cig),
+    }
+    loc_bases = np.concatenate(pieces) if pieces else np.zeros(0, np.uint8)
+    return mine, np.array(loc_off, dtype=np.uint64), loc_bases, out, np.array(emit, dtype=np.uint64).reshape(-1, 2)
+
+
 def gather_polished(local_contigs, local_bytes, local_off, n_contigs, rank, world, device="cpu"):
     """Collect the polished contigs on rank 0 in FASTA order.  local_bytes/local_off describe this
     rank's contigs (in the order of local_contigs).  Returns a list of bytes on rank 0, None elsewhere."""
@@ -105,26 +218,29 @@ def gather_polished(local_contigs, local_bytes, local_off, n_contigs, rank, worl
     return out
 
 
-def polish_sharded(engine, names, descs, contig_off, bases, recs, rank, world, device="cpu", **params):
-    """Contig-sharded polish.  `engine(contig_off, bases, recs, **params)` polishes one shard and
+def polish_sharded(engine, names, descs, contig_off, bases, recs, rank, world, device="cpu", min_window=1 << 16,
+                   **params):
+    """Sharded polish.  `engine(contig_off, bases, recs, emit=..., **params)` polishes one shard and
     returns {"polished": bytes, "offsets": array} (Context.polish_records on a GPU).  Rank 0 returns
     the FASTA text of the whole assembly (src/polish.rs:196-203), other ranks None."""
     contig_off = np.asarray(contig_off, dtype=np.uint64)
     n_contigs = len(contig_off) - 1
-    # weight = alignments per contig (the pileup work), ties broken by length
-    w = np.bincount(recs["contig"], minlength=n_contigs).astype(np.float64) + 1e-9 * (contig_off[1:] - contig_off[:-1])
-    owner = assign_contigs(w, world)
-    mine, loc_off, loc_bases, loc_recs = shard_job(contig_off, bases, recs, owner, rank)
+    units = plan_units(contig_off, recs, world, min_window)
+    owner = assign_contigs(units[3], world)
+    mine, loc_off, loc_bases, loc_recs, emit = shard_units(contig_off, bases, recs, units, owner, rank)
     if len(mine):
-        res = engine(loc_off, loc_bases, loc_recs, **params)
+        res = engine(loc_off, loc_bases, loc_recs, emit=emit, **params)
         polished, offs = res["polished"], res["offsets"]
     else:
         polished, offs = b"", np.zeros(1, dtype=np.uint64)
-    pieces = gather_polished(mine, polished, offs, n_contigs, rank, world, device)
+    pieces = gather_polished(mine, polished, offs, len(units[0]), rank, world, device)
     if rank != 0:
         return None
+    per_contig = [[] for _ in range(n_contigs)]
+    for u, c in enumerate(units[0]):
+        per_contig[int(c)].append(pieces[u])
     out = []
     for c in range(n_contigs):
         out.append(b">" + names[c].encode() + ((b" " + descs[c].encode()) if descs[c] else b"") + b" polypolish\n"
-                   + pieces[c] + b"\n")
+                   + b"".join(per_contig[c]) + b"\n")
     return b"".join(out)

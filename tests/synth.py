@@ -351,3 +351,20 @@ def records_to_sam(contig_off, bases, recs, names=None, path_fasta=None, path_sa
                 cig = "".join(f"{int(x) >> 4}{OPS[int(x) & 15]}" for x in recs["cigar"][co:co + nc])
                 f.write(f"r{i}\t0\t{names[int(recs['contig'][i])]}\t{int(recs['ref_start'][i]) + 1}\t60\t{cig}"
                         f"\t*\t0\t0\t{bytes(seq[so:so + sl]).decode()}\t*\tNM:i:0\n")
+
+
+def oracle_engine(orc):
+    """The oracle standing in for the per-rank device engine of polypolish_amd.distributed (tests only).
+    An emit range is honoured by slicing the polished string with the per-position emit lengths."""
+    def engine(o, b, r, emit=None, **kw):
+        res = orc.polish_records(o, b, r, positions=emit is not None, **kw)
+        if emit is None:
+            return res
+        cum = np.concatenate([[0], np.cumsum(res["positions"]["emit_len"].astype(np.int64))])
+        out, offs = [], [0]
+        for j, (lo, hi) in enumerate(np.asarray(emit, dtype=np.int64)):
+            a, z = int(cum[int(o[j]) + lo]), int(cum[int(o[j]) + hi])
+            out.append(res["polished"][a:z])
+            offs.append(offs[-1] + z - a)
+        return {"polished": b"".join(out), "offsets": np.array(offs, dtype=np.uint64)}
+    return engine

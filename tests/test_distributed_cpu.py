@@ -17,7 +17,7 @@ from polypolish_amd import distributed as D
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, fasta, sams, outfile):
+def _worker(rank, world, port, fasta, sams, outfile, min_window=1 << 16):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from oracle import orc
@@ -25,9 +25,8 @@ def _worker(rank, world, port, fasta, sams, outfile):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     names, descs, off, bases, recs, _ = pp.ingest(fasta, sams)
 
-    def engine(o, b, r, **kw):
-        return orc.polish_records(o, b, r, **kw)
-    out = D.polish_sharded(engine, names, descs, off, bases, recs, rank, world, device="cpu", min_depth=5)
+    out = D.polish_sharded(synth.oracle_engine(orc), names, descs, off, bases, recs, rank, world, device="cpu",
+                           min_window=min_window, min_depth=5)
     if rank == 0:
         open(outfile, "wb").write(out)
     dist.barrier()
@@ -43,6 +42,56 @@ def test_contig_sharded_polish_matches_unsharded(orc, tmp_path, world):
     port = 29500 + (os.getpid() % 2000) + world
     mp.spawn(_worker, args=(world, port, ds["fasta"], sams, outfile), nprocs=world, join=True)
     assert open(outfile, "rb").read() == orc.polish_files(ds["fasta"], sams)["fasta"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_tiled_polish_matches_unsharded(orc, tmp_path, world):
+    """Config C5 in miniature: one contig carries (almost) all alignments, so it is cut into windows;
+    each rank polishes window + halo and emits only the window.  Indels at window edges, multi-mapped
+    reads (k = 3, non-dyadic f64 shares) and a small second contig are in the mix."""
+    ds = synth.rich_dataset(str(tmp_path), seed=52, contig_lens=(14000, 600), coverage=25, repeat_len=300,
+                            repeat_copies=3)
+    sams = [ds["sam1"], ds["sam2"]]
+    names, descs, off, bases, recs, _ = pp.ingest(ds["fasta"], sams)
+    units = D.plan_units(off, recs, world, 2048)
+    assert (units[0] == 0).sum() == world, "the large contig was not cut into one window per rank"
+    outfile = str(tmp_path / "gathered.fasta")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, ds["fasta"], sams, outfile, 2048), nprocs=world, join=True)
+    assert open(outfile, "rb").read() == orc.polish_files(ds["fasta"], sams)["fasta"]
+
+
+def test_units_tile_every_contig_exactly_once():
+    contig_off, bases, recs = synth.fast_records(seed=4, contig_lens=(60000, 400, 9000), coverage=20, read_len=100,
+                                                 k_choices=(1, 2, 3), indel_read_frac=0.2)
+    span = D.ref_spans(recs)
+    for world in (1, 2, 4, 8):
+        units = D.plan_units(contig_off, recs, world, 4096)
+        uc, ulo, uhi, uw = units
+        for c in range(3):
+            lo, hi = ulo[uc == c], uhi[uc == c]
+            assert lo[0] == 0 and hi[-1] == contig_off[c + 1] - contig_off[c] and np.array_equal(lo[1:], hi[:-1])
+            assert np.all(lo % D.WINDOW_ALIGN == 0)
+        assert (uc == 0).sum() >= max(1, world - 1) and (uc == 1).sum() == 1
+        owner = D.assign_contigs(uw, world)
+        covered = np.zeros(int(contig_off[-1]), dtype=np.int64)
+        for r in range(world):
+            mine, off, b, rr, emit = D.shard_units(contig_off, bases, recs, units, owner, r)
+            assert len(b) == off[-1] and len(emit) == len(mine)
+            for j, u in enumerate(mine):
+                g0 = int(contig_off[uc[u]])
+                own = slice(int(off[j] + emit[j, 0]), int(off[j] + emit[j, 1]))
+                assert np.array_equal(b[own], bases[g0 + ulo[u]:g0 + uhi[u]])
+                covered[g0 + ulo[u]:g0 + uhi[u]] += 1
+            # every record lies inside its local contig and overlaps the owned window
+            ln = (off[1:] - off[:-1]).astype(np.int64)[rr["contig"]]
+            sp = D.ref_spans(rr)
+            st = rr["ref_start"].astype(np.int64)
+            assert np.all(st + sp <= ln)
+            e = emit.astype(np.int64)[rr["contig"]]
+            assert np.all((st < e[:, 1]) & (st + sp > e[:, 0]))
+        assert np.all(covered == 1)
+    assert span.min() >= 1
 
 
 def test_assignment_and_shards_are_a_partition():

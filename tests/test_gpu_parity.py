@@ -229,6 +229,57 @@ def test_filter_then_polish_parity(ctx, orc, tmp_path, case):
     assert ctx.polish_files(ds["fasta"], [g1, g2]) == orc.polish_files(ds["fasta"], [o1, o2])["fasta"]
 
 
+def test_emit_ranges_match_oracle_slices(ctx, orc):
+    """pp_polish_set_emit: every position is still voted with all alignments, but only [lo, hi) of each
+    contig contributes bytes and statistics."""
+    contig_off, bases, recs = synth.fast_records(seed=71, contig_lens=(30_000, 5_000, 9_000), coverage=50,
+                                                 k_choices=(1, 2, 3), indel_read_frac=0.2, n_rate=0.002)
+    rng = np.random.default_rng(7)
+    lens = np.diff(np.asarray(contig_off, dtype=np.int64))
+    for trial in range(4):
+        lo = rng.integers(0, lens // 2)
+        hi = lo + rng.integers(0, lens - lo + 1)
+        if trial == 0:
+            lo[:], hi[:] = 0, lens          # everything
+        if trial == 1:
+            hi[1] = lo[1]                    # an empty range
+        emit = np.stack([lo, hi], axis=1)
+        want = synth.oracle_engine(orc)(contig_off, bases, recs, emit=emit)
+        got = ctx.polish_records(contig_off, bases, recs, emit=emit)
+        assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"]), trial
+        full = orc.polish_records(contig_off, bases, recs, positions=True)["positions"]
+        for c in range(3):
+            own = slice(int(contig_off[c] + lo[c]), int(contig_off[c] + hi[c]))
+            assert got["stats"][c]["changed"] == int((full["status"][own] == 1).sum())
+            assert got["stats"][c]["zero_depth"] == int((full["depth"][own] == 0.0).sum())
+    # the next job on the same context emits everything again
+    assert ctx.polish_records(contig_off, bases, recs)["polished"] == orc.polish_records(contig_off, bases, recs)["polished"]
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_window_tiled_contig_equals_unsharded(ctx, orc, world):
+    """Config C5's partitioning with the ranks run one after the other on this GPU: windows + halos
+    through the device path, pieces concatenated, must equal the unsharded oracle output."""
+    from polypolish_amd import distributed as D
+    contig_off, bases, recs = synth.fast_records(seed=72, contig_lens=(150_000, 3_000), coverage=40,
+                                                 k_choices=(1, 2, 3, 4), indel_read_frac=0.15, n_rate=0.002)
+    units = D.plan_units(contig_off, recs, world, 4096)
+    assert (units[0] == 0).sum() >= world - 1 > 0
+    owner = D.assign_contigs(units[3], world)
+    pieces = {}
+    for rank in range(world):
+        mine, off, b, rr, emit = D.shard_units(contig_off, bases, recs, units, owner, rank)
+        if not len(mine):
+            continue
+        res = ctx.polish_records(off, b, rr, emit=emit)
+        for j, u in enumerate(mine):
+            pieces[int(u)] = res["polished"][int(res["offsets"][j]):int(res["offsets"][j + 1])]
+    want = orc.polish_records(contig_off, bases, recs)
+    got = [b"".join(pieces[u] for u in range(len(units[0])) if units[0][u] == c) for c in range(2)]
+    for c in range(2):
+        assert got[c] == want["polished"][int(want["offsets"][c]):int(want["offsets"][c + 1])], c
+
+
 def test_reference_orientation_vectors_on_device(ctx, pp):
     """T4 (src/filter.rs:384-424) and T3 (src/alignment.rs:402-422) through the filter kernels."""
     import ctypes as C
