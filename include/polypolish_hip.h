@@ -222,6 +222,27 @@ int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t orientatio
                     uint8_t *pass1, uint8_t *pass2);
 int pp_filter_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
 
+/* Host half of the filter (no device needed): both SAM files -> the pp_filter_input above, and the
+ * re-emission of a file with "\tZP:Z:fail" appended where pass == 0.  Multi-threaded; the result does
+ * not depend on the thread count.
+ *   pp_filter_load    load_alignments, src/filter.rs:91-145 (Alignment::new_quick, src/alignment.rs:102-128):
+ *                     file 1 then file 2; counts[f].loaded tells which files were read completely when
+ *                     an error is returned ("unable to load", "too few columns ... (line N)", ...)
+ *   pp_filter_write   filter_sam, src/filter.rs:309-349: header and unaligned lines verbatim, every line
+ *                     ends in "\n"; pass = HOST array over the alignments of file f (0/1) */
+typedef struct pp_filter_loaded pp_filter_loaded;
+typedef struct {
+    uint64_t alignments; /* aligned records in the file        (filter.rs:105) */
+    uint64_t reads;      /* distinct QNAMEs among them                          */
+    int loaded;
+} pp_filter_file_counts;
+int pp_filter_load(const char *in1, const char *in2, pp_filter_loaded **out, pp_filter_file_counts counts[2],
+                   char *err, size_t errlen);
+void pp_filter_loaded_input(const pp_filter_loaded *loaded, pp_filter_input *in); /* borrows from `loaded` */
+int pp_filter_write(const pp_filter_loaded *loaded, int file, const uint8_t *pass, const char *out_path,
+                    uint64_t *pass_count, uint64_t *fail_count, char *err, size_t errlen);
+void pp_filter_loaded_free(pp_filter_loaded *loaded);
+
 /* ---- host ingest (text -> SoA) -------------------------------------------------------------- */
 typedef struct pp_assembly pp_assembly;
 /* load_fasta + check_load_fasta (src/misc.rs:38-75): plain or gzip, uppercased. */

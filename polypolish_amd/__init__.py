@@ -94,6 +94,10 @@ class FilterInput(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("file", FilterFile * 2)]
 
 
+class FilterFileCounts(C.Structure):
+    _fields_ = [("alignments", C.c_uint64), ("reads", C.c_uint64), ("loaded", C.c_int)]
+
+
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
     "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
@@ -101,7 +105,8 @@ EXPORTS = [
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
     "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
-    "pp_filter_kernel_times", "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
+    "pp_filter_kernel_times", "pp_filter_load", "pp_filter_loaded_input", "pp_filter_write", "pp_filter_loaded_free",
+    "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
     "pp_bytes_free", "pp_polish_files", "pp_filter_files",
@@ -146,6 +151,13 @@ def lib():
         L.pp_filter_samples.argtypes = [vp, vp, vp]
         L.pp_filter_pairs.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint8, vp, vp]
         L.pp_filter_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.pp_filter_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(FilterFileCounts), C.c_char_p, C.c_size_t]
+        L.pp_filter_loaded_input.argtypes = [vp, C.POINTER(FilterInput)]
+        L.pp_filter_loaded_input.restype = None
+        L.pp_filter_write.argtypes = [vp, C.c_int, vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                      C.c_char_p, C.c_size_t]
+        L.pp_filter_loaded_free.argtypes = [vp]
+        L.pp_filter_loaded_free.restype = None
         L.pp_assembly_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.pp_assembly_free.argtypes = [vp]
         L.pp_assembly_free.restype = None
@@ -222,6 +234,60 @@ def ingest(assembly, sams, max_errors=10, careful=False):
         if g:
             L.pp_ingest_free(g)
         L.pp_assembly_free(a)
+
+
+class FilterLoaded:
+    """Host half of the filter (pp_filter_load / pp_filter_write; no GPU needed): `files[f]` holds the SoA
+    of pp_filter_file as numpy copies, `counts[f]` = (alignments, distinct read names)."""
+
+    def __init__(self, in1, in2):
+        L = lib()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1400)
+        fc = (FilterFileCounts * 2)()
+        rc = L.pp_filter_load(str(in1).encode(), str(in2).encode(), C.byref(self._h), fc, err, 1400)
+        self.counts = [(c.alignments, c.reads) if c.loaded else None for c in fc]
+        if rc:
+            self._h = C.c_void_p()
+            raise PolypolishError(rc, err.value.decode())
+        self.input = FilterInput()
+        L.pp_filter_loaded_input(self._h, C.byref(self.input))
+        self.n_reads = int(self.input.n_reads)
+        self.files = []
+        for f in range(2):
+            d = self.input.file[f]
+            n = int(d.n_aln)
+
+            def arr(ptr, cnt, dt):
+                if not cnt or not ptr:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+            self.files.append({
+                "ref_id": arr(d.ref_id, n, np.uint32), "ref_start": arr(d.ref_start, n, np.uint32),
+                "flags": arr(d.flags, n, np.uint32), "cig_off": arr(d.cig_off, n, np.uint64),
+                "n_cig": arr(d.n_cig, n, np.uint32), "cigar": arr(d.cigar, int(d.n_cig_total), np.uint32),
+                "read": arr(d.read, n, np.uint32), "grp_off": arr(d.grp_off, self.n_reads + 1, np.uint32),
+                "grp_idx": arr(d.grp_idx, n, np.uint32)})
+
+    def write(self, f, passed, path):
+        passed = np.ascontiguousarray(passed, dtype=np.uint8)
+        err = C.create_string_buffer(1400)
+        p_, f_ = C.c_uint64(), C.c_uint64()
+        rc = lib().pp_filter_write(self._h, f, passed.ctypes.data, str(path).encode(), C.byref(p_), C.byref(f_), err, 1400)
+        if rc:
+            raise PolypolishError(rc, err.value.decode())
+        return p_.value, f_.value
+
+    def close(self):
+        if self._h:
+            lib().pp_filter_loaded_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

@@ -310,334 +310,3 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     return PP_OK;
 }
 
-// =================================================================================================
-//   pp_filter_files = filter::filter   (src/filter.rs:26-37)
-// =================================================================================================
-#include <algorithm>
-#include <unordered_map>
-
-namespace {
-
-struct FilterFile {
-    std::vector<char> text;
-    // every line: offset + length (without the newline / CR), and the alignment index or -1
-    std::vector<uint64_t> line_off;
-    std::vector<uint32_t> line_len;
-    std::vector<int64_t> line_aln;
-    // per aligned record, file order
-    std::vector<uint32_t> ref_id, ref_start, flags, n_cig, cigar, read;
-    std::vector<uint64_t> cig_off;
-    std::vector<uint32_t> grp_off, grp_idx;
-};
-
-struct FilterErr {
-    int code;
-    std::string msg;
-};
-
-bool slurp(const char *path, std::vector<char> &out) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    char tmp[1 << 16];
-    size_t r;
-    while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) out.insert(out.end(), tmp, tmp + r);
-    bool bad = ferror(f);
-    fclose(f);
-    return !bad;
-}
-
-bool parse_u(const char *s, size_t n, uint64_t max, uint64_t &out) {
-    size_t i = 0;
-    if (n == 0) return false;
-    if (s[0] == '+') { i = 1; if (n == 1) return false; }
-    uint64_t v = 0;
-    for (; i < n; i++) {
-        if (s[i] < '0' || s[i] > '9') return false;
-        uint64_t d = (uint64_t)(s[i] - '0');
-        if (v > (max - d) / 10) return false;
-        v = v * 10 + d;
-    }
-    out = v;
-    return true;
-}
-
-int cigar_op(char c) {
-    switch (c) {
-    case 'M': return PP_OP_M; case 'I': return PP_OP_I; case 'D': return PP_OP_D; case 'N': return PP_OP_N;
-    case 'S': return PP_OP_S; case 'H': return PP_OP_H; case 'P': return PP_OP_P; case '=': return PP_OP_EQ;
-    case 'X': return PP_OP_X; default: return -1;
-    }
-}
-
-// load_alignments_one_file, filter.rs:110-145 (Alignment::new_quick, alignment.rs:102-128)
-void load_filter_file(const char *path, FilterFile &F, std::unordered_map<std::string, uint32_t> &reads,
-                      std::unordered_map<std::string, uint32_t> &refs, uint64_t &total_alignments,
-                      uint64_t &n_read_names) {
-    if (!slurp(path, F.text)) {
-        char m[1024];
-        snprintf(m, sizeof m, "unable to load alignments from \"%s\"", path);
-        throw FilterErr{PP_ERR_QUIT, m};
-    }
-    const char *p = F.text.data(), *end = p + F.text.size();
-    uint64_t line_no = 0;
-    std::unordered_map<uint32_t, char> seen;  // read_names of this file (for the stderr count)
-    while (p < end) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        size_t l = nl ? (size_t)(nl - p) : (size_t)(end - p);
-        const char *line = p;
-        p += l + (nl ? 1 : 0);
-        if (l > 0 && line[l - 1] == '\r') l--;
-        line_no++;
-        F.line_off.push_back((uint64_t)(line - F.text.data()));
-        F.line_len.push_back((uint32_t)l);
-        F.line_aln.push_back(-1);
-        if (l > 0 && line[0] == '@') continue;
-        const char *col[11];
-        size_t len[11];
-        size_t nc = 0;
-        const char *q = line, *le = line + l;
-        while (nc < 11) {
-            const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
-            col[nc] = q;
-            len[nc] = t ? (size_t)(t - q) : (size_t)(le - q);
-            nc++;
-            if (!t) break;
-            q = t + 1;
-        }
-        if (nc < 11) {
-            char m[1024];
-            snprintf(m, sizeof m, "too few columns in \"%s\" (line %llu)", path, (unsigned long long)line_no);
-            throw FilterErr{PP_ERR_QUIT, m};
-        }
-        uint64_t flags, pos;
-        if (!parse_u(col[1], len[1], 0xFFFFFFFFull, flags) || !parse_u(col[3], len[3], UINT64_MAX, pos)) {
-            char m[1024];
-            snprintf(m, sizeof m, "could not parse FLAG or POS in \"%s\" (line %llu)", path, (unsigned long long)line_no);
-            throw FilterErr{PP_ERR_PANIC, m};
-        }
-        if (flags & 4) continue;
-        if (pos > 0) pos -= 1;
-        if (pos > 0xFFFFFFFFull) {
-            char m[1024];
-            snprintf(m, sizeof m, "POS beyond 2^32 in \"%s\" (line %llu)", path, (unsigned long long)line_no);
-            throw FilterErr{PP_ERR_LIMIT, m};
-        }
-        F.line_aln.back() = (int64_t)F.flags.size();
-        uint32_t rid = reads.emplace(std::string(col[0], len[0]), (uint32_t)reads.size()).first->second;
-        uint32_t fid = refs.emplace(std::string(col[2], len[2]), (uint32_t)refs.size()).first->second;
-        seen.emplace(rid, 0);
-        F.read.push_back(rid);
-        F.ref_id.push_back(fid);
-        F.ref_start.push_back((uint32_t)pos);
-        F.flags.push_back((uint32_t)flags);
-        F.cig_off.push_back(F.cigar.size());
-        // Regex::find_iter over \d+[MIDNSHP=X] (alignment.rs:140): non-matching text is skipped
-        const char *c = col[5];
-        size_t cl = len[5], i = 0;
-        uint32_t runs = 0;
-        while (i < cl) {
-            if (c[i] >= '0' && c[i] <= '9') {
-                size_t j = i;
-                while (j < cl && c[j] >= '0' && c[j] <= '9') j++;
-                int op = j < cl ? cigar_op(c[j]) : -1;
-                if (op >= 0) {
-                    uint64_t num;
-                    if (!parse_u(c + i, j - i, UINT64_MAX, num)) throw FilterErr{PP_ERR_PANIC, "CIGAR run length overflow"};
-                    while (num > 0) {
-                        uint32_t piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)num;
-                        F.cigar.push_back((piece << 4) | (uint32_t)op);
-                        runs++;
-                        num -= piece;
-                    }
-                    i = j + 1;
-                } else {
-                    i = j;
-                }
-            } else {
-                i++;
-            }
-        }
-        F.n_cig.push_back(runs);
-        total_alignments++;
-    }
-    n_read_names = seen.size();
-}
-
-void build_groups(FilterFile &F, uint32_t n_reads) {
-    F.grp_off.assign((size_t)n_reads + 1, 0);
-    for (uint32_t r : F.read) F.grp_off[r + 1]++;
-    for (uint32_t r = 0; r < n_reads; r++) F.grp_off[r + 1] += F.grp_off[r];
-    F.grp_idx.resize(F.read.size());
-    std::vector<uint32_t> cur(F.grp_off.begin(), F.grp_off.end() - 1);
-    for (uint32_t i = 0; i < F.read.size(); i++) F.grp_idx[cur[F.read[i]]++] = i;  // file order inside a group
-}
-
-// get_percentile, filter.rs:249-259
-uint32_t percentile(const std::vector<uint32_t> &sorted, double p) {
-    if (sorted.empty()) return 0;
-    double fraction = p / 100.0;
-    double r = ceil(fraction * (double)sorted.size());
-    size_t rank = r <= 0.0 ? 0 : (r >= 1.8e19 ? SIZE_MAX : (size_t)r);
-    if (rank < 1) rank = 1;
-    return rank - 1 < sorted.size() ? sorted[rank - 1] : 0;
-}
-
-// get_percentile_name, filter.rs:262-270
-std::string percentile_name(double p) {
-    char b[64];
-    snprintf(b, sizeof b, "%g", p);
-    std::string s = b;
-    const char *suffix = "th";
-    if (s.back() == '1' && p != 11.0) suffix = "st";
-    else if (s.back() == '2' && p != 12.0) suffix = "nd";
-    else if (s.back() == '3' && p != 13.0) suffix = "rd";
-    return s + suffix + " percentile";
-}
-
-}  // namespace
-
-extern "C" int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, const char *out1,
-                               const char *out2, const char *orientation, double low, double high, int quiet,
-                               pp_filter_report *report) {
-    if (!ctx || !in1 || !in2 || !out1 || !out2 || !orientation) return PP_ERR_ARG;
-    Log log{quiet != 0};
-    auto t0 = std::chrono::steady_clock::now();
-    // check_inputs, filter.rs:40-53
-    const char *f4[4] = {in1, in2, out1, out2};
-    for (int i = 0; i < 4; i++)
-        for (int j = i + 1; j < 4; j++)
-            if (strcmp(f4[i], f4[j]) == 0)
-                return set_err(ctx, PP_ERR_QUIT, "--in1, --in2, --out1 and --out2 must all have unique values");
-    if (low <= 0.0 || low >= 50.0) return set_err(ctx, PP_ERR_QUIT, "--low must be greater than 0 and less than 50");
-    if (high <= 50.0 || high >= 100.0) return set_err(ctx, PP_ERR_QUIT, "--high must be greater than 50 and less than 100");
-    log("\nStarting Polypolish filter\n%s\n\nInput alignments:\n  %s\n  %s\n\nOutput alignments:\n  %s\n  %s\n\n"
-        "Settings:\n  --orientation %s\n  --low %g\n  --high %g\n\n", pp_version(), in1, in2, out1, out2, orientation, low, high);
-
-    FilterFile F[2];
-    std::unordered_map<std::string, uint32_t> reads, refs;
-    uint64_t before = 0;
-    log("Loading alignments\n");
-    try {
-        const char *ins[2] = {in1, in2};
-        for (int f = 0; f < 2; f++) {
-            uint64_t prev = before, names = 0;
-            load_filter_file(ins[f], F[f], reads, refs, before, names);
-            log("%s: %s alignments from %s reads\n", ins[f], commas(before - prev).c_str(), commas(names).c_str());
-            if (before == 0) {
-                char m[1024];
-                snprintf(m, sizeof m, "no alignments found in \"%s\"", ins[f]);
-                throw FilterErr{PP_ERR_QUIT, m};
-            }
-        }
-    } catch (const FilterErr &e) {
-        return set_err(ctx, e.code, e.msg.c_str());
-    }
-    log("\n");
-    const uint32_t n_reads = (uint32_t)reads.size();
-    for (int f = 0; f < 2; f++) build_groups(F[f], n_reads);
-
-    pp_filter_input in;
-    in.n_reads = n_reads;
-    for (int f = 0; f < 2; f++) {
-        pp_filter_file &d = in.file[f];
-        d.n_aln = F[f].flags.size();
-        d.ref_id = F[f].ref_id.data(); d.ref_start = F[f].ref_start.data(); d.flags = F[f].flags.data();
-        d.cig_off = F[f].cig_off.data(); d.n_cig = F[f].n_cig.data(); d.cigar = F[f].cigar.data();
-        d.n_cig_total = F[f].cigar.size(); d.read = F[f].read.data();
-        d.grp_off = F[f].grp_off.data(); d.grp_idx = F[f].grp_idx.data();
-    }
-    int rc = pp_filter_begin(ctx, &in, PP_MEM_HOST);
-    if (rc) return rc;
-
-    // get_insert_size_thresholds, filter.rs:148-186 (samples from the device, reduction on the host)
-    log("Finding insert size thresholds\n");
-    std::vector<uint8_t> orient(n_reads ? n_reads : 1);
-    std::vector<uint32_t> insert(n_reads ? n_reads : 1);
-    rc = pp_filter_samples(ctx, orient.data(), insert.data());
-    if (rc) return rc;
-    uint64_t counts[4] = {0, 0, 0, 0};
-    for (uint32_t r = 0; r < n_reads; r++)
-        if (orient[r] < 4) counts[orient[r]]++;
-    if (counts[0] + counts[1] + counts[2] + counts[3] == 0)
-        return set_err(ctx, PP_ERR_QUIT, "no one-alignment-per-read pairs available to determine orientation and "
-                                         "insert size thresholds");
-    static const char *ONAMES[4] = {"fr", "rf", "ff", "rr"};
-    for (int o = 0; o < 4; o++) log("%s: %s pairs\n", ONAMES[o], commas(counts[o]).c_str());
-    int correct = -1;
-    if (strcmp(orientation, "auto") == 0) {  // auto_determine_orientation, filter.rs:238-246
-        uint64_t mx = *std::max_element(counts, counts + 4);
-        int n_max = 0;
-        for (int o = 0; o < 4; o++)
-            if (counts[o] == mx) { n_max++; correct = o; }
-        if (n_max != 1) return set_err(ctx, PP_ERR_QUIT, "could not automatically determine read pair orientation");
-        log("\nAutomatically determined correct orientation: %s\n\n", ONAMES[correct]);
-    } else {
-        for (int o = 0; o < 4; o++)
-            if (strcmp(orientation, ONAMES[o]) == 0) correct = o;
-        log("\nUser-specified correct orientation: %s\n\n", orientation);
-    }
-    std::vector<uint32_t> sizes;
-    if (correct >= 0)
-        for (uint32_t r = 0; r < n_reads; r++)
-            if (orient[r] == correct) sizes.push_back(insert[r]);
-    if (sizes.empty()) return set_err(ctx, PP_ERR_QUIT, "no read pairs available to determine insert size thresholds");
-    std::sort(sizes.begin(), sizes.end());
-    const uint32_t lo = percentile(sizes, low), hi = percentile(sizes, high);
-    log("Low threshold:  %u (%s)\nHigh threshold: %u (%s)\n\n", lo, percentile_name(low).c_str(), hi,
-        percentile_name(high).c_str());
-
-    // filter_sams, filter.rs:273-349
-    log("Filtering SAM files\n");
-    std::vector<uint8_t> pass[2];
-    for (int f = 0; f < 2; f++) pass[f].resize(F[f].flags.size() ? F[f].flags.size() : 1);
-    rc = pp_filter_pairs(ctx, lo, hi, (uint8_t)correct, pass[0].data(), pass[1].data());
-    if (rc) return rc;
-    uint64_t after = 0;
-    const char *ins[2] = {in1, in2}, *outs[2] = {out1, out2};
-    for (int f = 0; f < 2; f++) {
-        FILE *o = fopen(outs[f], "wb");
-        if (!o) {
-            char m[1024];
-            snprintf(m, sizeof m, "unable to write alignments to \"%s\"", outs[f]);
-            return set_err(ctx, PP_ERR_QUIT, m);
-        }
-        std::vector<char> buf;
-        buf.reserve(F[f].text.size() + F[f].flags.size() * 10 + 16);
-        uint64_t n_pass = 0, n_fail = 0;
-        for (size_t i = 0; i < F[f].line_off.size(); i++) {
-            const char *line = F[f].text.data() + F[f].line_off[i];
-            buf.insert(buf.end(), line, line + F[f].line_len[i]);
-            int64_t a = F[f].line_aln[i];
-            if (a >= 0) {
-                if (pass[f][(size_t)a]) n_pass++;
-                else {
-                    static const char tag[] = "\tZP:Z:fail";
-                    buf.insert(buf.end(), tag, tag + 10);
-                    n_fail++;
-                }
-            }
-            buf.push_back('\n');
-        }
-        bool ok = fwrite(buf.data(), 1, buf.size(), o) == buf.size();
-        ok = (fclose(o) == 0) && ok;
-        if (!ok) {
-            char m[1024];
-            snprintf(m, sizeof m, "unable to write alignments to \"%s\"", outs[f]);
-            return set_err(ctx, PP_ERR_QUIT, m);
-        }
-        log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(n_pass).c_str(), commas(n_fail).c_str());
-        after += n_pass;
-    }
-    if (report) {
-        report->before_count = before;
-        report->after_count = after;
-        report->low_threshold = lo;
-        report->high_threshold = hi;
-        report->orientation = correct;
-        for (int o = 0; o < 4; o++) report->orientation_counts[o] = counts[o];
-    }
-    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    log("Finished!\nAlignments before filtering: %s\nAlignments after filtering:  %s\n\nTime to run: %s\n\n",
-        commas(before).c_str(), commas(after).c_str(), format_duration(secs).c_str());
-    return PP_OK;
-}

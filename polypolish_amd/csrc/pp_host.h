@@ -1,0 +1,135 @@
+// pp_host.h -- host-side utilities shared by the SAM ingest (pp_ingest.cpp) and the filter driver
+// (pp_filter_host.cpp): huge-page growable arrays, a fork-join parallel_for, a read-only file mapping.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace pph {
+
+// Growable array for the multi-GB buffers of a large job: anonymous mmap backed by transparent huge
+// pages where the kernel allows (512x fewer page faults while many threads first-touch it, and a much
+// cheaper teardown), grown with mremap, and never zero-filled by us.
+template <typename T>
+struct HugeBuf {
+    static constexpr size_t HUGE = size_t(2) << 20;
+    T *p = nullptr;
+    size_t n = 0, cap = 0, mapped = 0;  // elements, elements, bytes
+    HugeBuf() = default;
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
+    HugeBuf(HugeBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), mapped(o.mapped) { o.p = nullptr; o.n = o.cap = o.mapped = 0; }
+    ~HugeBuf() { if (p) munmap(p, mapped); }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; }
+    void reserve(size_t m) {
+        if (m <= cap) return;
+        size_t bytes = std::max(m, cap * 2) * sizeof(T);
+        bytes = (bytes + HUGE - 1) / HUGE * HUGE;
+        void *q = p ? mremap(p, mapped, bytes, MREMAP_MAYMOVE)
+                    : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        madvise(q, bytes, MADV_HUGEPAGE);
+        p = (T *)q;
+        mapped = bytes;
+        cap = bytes / sizeof(T);
+    }
+    void resize(size_t m) { reserve(m); n = m; }
+    void push_back(const T &v) {
+        if (n == cap) reserve(n + 1);
+        p[n++] = v;
+    }
+};
+
+// f(lo, hi, t): contiguous ranges of [0, n) in order, one per thread index t
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F f) {
+    if (threads <= 1 || n < 2) { f((size_t)0, n, 0u); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; t++) {
+        const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+        if (lo < hi) pool.emplace_back([=] { f(lo, hi, t); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// PP_INGEST_THREADS, else one thread per 4 MiB of text up to min(cores, 64)
+inline unsigned host_threads(size_t text_bytes) {
+    if (const char *e = getenv("PP_INGEST_THREADS")) return (unsigned)std::max(1, std::min(64, atoi(e)));
+    return std::max(1u, std::min({std::thread::hardware_concurrency(), 64u, (unsigned)(text_bytes / (4u << 20)) + 1u}));
+}
+
+// A whole file as read-only bytes: mmap for regular files, read() for pipes.
+struct FileText {
+    const char *text = nullptr;
+    size_t size = 0;
+    void *map = nullptr;
+    int fd = -1;
+    std::vector<char> fallback;
+    FileText() = default;
+    FileText(const FileText &) = delete;
+    FileText &operator=(const FileText &) = delete;
+    ~FileText() { close_file(); }
+    void close_file() {
+        if (map) munmap(map, size);
+        if (fd >= 0) ::close(fd);
+        map = nullptr;
+        fd = -1;
+    }
+    bool open_file(const char *path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        if (S_ISREG(st.st_mode) && st.st_size > 0) {
+            size = (size_t)st.st_size;
+            map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) { map = nullptr; return false; }
+            madvise(map, size, MADV_SEQUENTIAL);
+            text = (const char *)map;
+            return true;
+        }
+        char tmp[1 << 16];
+        ssize_t r;
+        while ((r = ::read(fd, tmp, sizeof tmp)) > 0) fallback.insert(fallback.end(), tmp, tmp + r);
+        if (r < 0) return false;
+        text = fallback.data();
+        size = fallback.size();
+        return true;
+    }
+};
+
+// [beg, end) of slice t of `threads` line-aligned slices of the text
+inline void line_slices(const char *text, size_t size, unsigned threads, std::vector<const char *> &cut) {
+    cut.assign(threads + 1, text + size);
+    const char *p = text, *end = text + size;
+    for (unsigned t = 0; t < threads; t++) {
+        cut[t] = p;
+        const char *want = (t + 1 == threads) ? end : text + (size / threads) * (t + 1);
+        if (want < p) want = p;
+        if (want < end) {
+            const char *nl = (const char *)memchr(want, '\n', (size_t)(end - want));
+            want = nl ? nl + 1 : end;
+        }
+        p = want;
+    }
+    cut[threads] = end;
+}
+
+}  // namespace pph

@@ -28,6 +28,10 @@
 #include <vector>
 
 #include "polypolish_hip.h"
+#include "pp_host.h"
+
+using pph::HugeBuf;
+using pph::parallel_for;
 
 namespace {
 
@@ -219,43 +223,6 @@ extern "C" const uint64_t *pp_assembly_offsets(const pp_assembly *a) { return a-
 extern "C" const uint8_t *pp_assembly_bases(const pp_assembly *a) { return a->bases.data(); }
 
 // =================================================================================================
-// Growable array for the multi-GB buffers of a large job: anonymous mmap backed by transparent huge
-// pages where the kernel allows (512x fewer page faults while many threads first-touch it, and a much
-// cheaper teardown), grown with mremap, and never zero-filled by us.
-template <typename T>
-struct HugeBuf {
-    static constexpr size_t HUGE = size_t(2) << 20;
-    T *p = nullptr;
-    size_t n = 0, cap = 0, mapped = 0;  // elements, elements, bytes
-    HugeBuf() = default;
-    HugeBuf(const HugeBuf &) = delete;
-    HugeBuf &operator=(const HugeBuf &) = delete;
-    HugeBuf(HugeBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), mapped(o.mapped) { o.p = nullptr; o.n = o.cap = o.mapped = 0; }
-    ~HugeBuf() { if (p) munmap(p, mapped); }
-    T *data() { return p; }
-    const T *data() const { return p; }
-    size_t size() const { return n; }
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
-    void reserve(size_t m) {
-        if (m <= cap) return;
-        size_t bytes = std::max(m, cap * 2) * sizeof(T);
-        bytes = (bytes + HUGE - 1) / HUGE * HUGE;
-        void *q = p ? mremap(p, mapped, bytes, MREMAP_MAYMOVE)
-                    : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (q == MAP_FAILED) throw std::bad_alloc();
-        madvise(q, bytes, MADV_HUGEPAGE);
-        p = (T *)q;
-        mapped = bytes;
-        cap = bytes / sizeof(T);
-    }
-    void resize(size_t m) { reserve(m); n = m; }
-    void push_back(const T &v) {
-        if (n == cap) reserve(n + 1);
-        p[n++] = v;
-    }
-};
-
 struct pp_ingest {
     const pp_assembly *asmb;
     uint32_t max_errors;
@@ -406,18 +373,6 @@ struct OutRec {            // a good alignment, ready to be copied into the batc
     uint32_t k;
     bool star, revcomp;
 };
-
-template <typename F>
-void parallel_for(size_t n, unsigned threads, F f) {
-    if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
-    std::vector<std::thread> pool;
-    const size_t per = (n + threads - 1) / threads;
-    for (unsigned t = 0; t < threads; t++) {
-        const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
-        if (lo < hi) pool.emplace_back([=] { f(lo, hi, t); });
-    }
-    for (auto &th : pool) th.join();
-}
 
 }  // namespace
 

@@ -244,3 +244,61 @@ def polish_sharded(engine, names, descs, contig_off, bases, recs, rank, world, d
         out.append(b">" + names[c].encode() + ((b" " + descs[c].encode()) if descs[c] else b"") + b" polypolish\n"
                    + b"".join(per_contig[c]) + b"\n")
     return b"".join(out)
+
+
+def main(argv=None):
+    """`polypolish polish` across the GPUs of one node, one process per GPU:
+
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+            -m polypolish_amd.distributed polish [options] assembly.fasta a_1.sam a_2.sam > polished.fasta
+
+    Options as the reference's (src/main.rs:78-108) except --debug.  Every rank runs the host ingest
+    (the 1/k shares are fixed before sharding), polishes its contigs / windows on its own GPU and rank 0
+    prints the FASTA.  PP_SHARE_GPU=1 (testing on a one-GPU box): all ranks use GPU 0, gather over gloo."""
+    import argparse
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    import polypolish_amd as pp
+    ap = argparse.ArgumentParser(prog="polypolish_amd.distributed")
+    ap.add_argument("command", choices=["polish"])
+    ap.add_argument("-i", "--fraction_invalid", type=float, default=0.2)
+    ap.add_argument("-v", "--fraction_valid", type=float, default=0.5)
+    ap.add_argument("-m", "--max_errors", type=int, default=10)
+    ap.add_argument("-d", "--min_depth", type=int, default=5)
+    ap.add_argument("--careful", action="store_true")
+    ap.add_argument("assembly")
+    ap.add_argument("sam", nargs="*")
+    a = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("PP_SHARE_GPU") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("Error: no usable MI355X (HIP) device -- this build has no CPU path")
+    dev = 0 if share else local
+    torch.cuda.set_device(dev)
+    if world > 1:
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    try:
+        names, descs, off, bases, recs, _ = pp.ingest(a.assembly, a.sam, max_errors=a.max_errors, careful=a.careful)
+        ctx = pp.Context(dev)
+        out = polish_sharded(ctx.polish_records, names, descs, off, bases, recs, rank, world,
+                             device="cpu" if share or world == 1 else f"cuda:{dev}", min_depth=a.min_depth,
+                             fraction_valid=a.fraction_valid, fraction_invalid=a.fraction_invalid)
+    except pp.PolypolishError as e:
+        sys.stderr.write(f"\nError: {e.msg}\n")
+        raise SystemExit(101 if e.code == pp.ERR_PANIC else 1)
+    if rank == 0:
+        sys.stdout.buffer.write(out)
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -280,6 +280,21 @@ def test_window_tiled_contig_equals_unsharded(ctx, orc, world):
         assert got[c] == want["polished"][int(want["offsets"][c]):int(want["offsets"][c + 1])], c
 
 
+def test_multi_process_driver_on_one_gpu(orc, tmp_path):
+    """`python -m polypolish_amd.distributed polish` with two ranks sharing this GPU (gloo gather): the
+    one-process-per-GPU driver end to end, contigs and windows sharded, FASTA identical."""
+    ds = synth.rich_dataset(str(tmp_path), seed=81, contig_lens=(140_000, 900, 2_000), coverage=12, repeat_len=300,
+                            repeat_copies=3)
+    sams = [ds["sam1"], ds["sam2"]]
+    env = dict(os.environ, PP_SHARE_GPU="1", PYTHONPATH=ROOT)
+    port = 33000 + os.getpid() % 2000
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "polypolish_amd.distributed", "polish",
+                        ds["fasta"], *sams], capture_output=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"]
+
+
 def test_reference_orientation_vectors_on_device(ctx, pp):
     """T4 (src/filter.rs:384-424) and T3 (src/alignment.rs:402-422) through the filter kernels."""
     import ctypes as C
