@@ -271,6 +271,11 @@ def main(argv=None):
     ap.add_argument("assembly")
     ap.add_argument("sam", nargs="*")
     a = ap.parse_args(argv)
+    # stdout carries the FASTA and nothing else: libraries that chat on fd 1 (gloo's "[Gloo] Rank ..." lines)
+    # are pointed at stderr for the whole run
+    sys.stdout.flush()
+    fasta_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     share = os.environ.get("PP_SHARE_GPU") == "1"
@@ -293,8 +298,10 @@ def main(argv=None):
         sys.stderr.write(f"\nError: {e.msg}\n")
         raise SystemExit(101 if e.code == pp.ERR_PANIC else 1)
     if rank == 0:
-        sys.stdout.buffer.write(out)
-        sys.stdout.flush()
+        view = memoryview(out)
+        while len(view):
+            view = view[os.write(fasta_fd, view):]
+    os.close(fasta_fd)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
