@@ -19,7 +19,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "_build", "libpolypolish_hip.so")
+LIB_PATH = os.environ.get("PP_LIB_PATH") or os.path.join(HERE, "_build", "libpolypolish_hip.so")  # PP_LIB_PATH: kernel experiments
 
 OK, ERR_QUIT, ERR_HIP, ERR_ARG, ERR_LIMIT, ERR_PANIC = 0, 1, 3, 4, 5, 101
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -319,6 +319,7 @@ class Context:
         self._chk(lib().pp_ctx_sync(self._h))
 
     def set_profiling(self, on=True):
+        """False/0 off, True/1 every kernel group, 2 only the dominant kernel (one event pair per job)."""
         lib().pp_ctx_set_profiling(self._h, int(on))
 
     # ---- seam B -------------------------------------------------------------------------------

@@ -70,7 +70,9 @@ struct pp_ctx {
     std::thread init_thread;  // pp_ctx_create_async: device initialisation in flight
     bool init_pending = false;
     int init_rc = 0;
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every kernel group, 2 the dominant kernel only
+    bool timer_open = false;
+    std::vector<hipEvent_t> event_pool;
     bool debug = false;
     std::vector<pp::KernelTimer> timers;
     pp_kernel_times last_times{};

@@ -174,20 +174,18 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
 }
 
-__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
-                                              const u32 *__restrict__ ref_start,
-                                              const u32 *__restrict__ kk,
-                                              const u64 *__restrict__ seq_off,
-                                              const u32 *__restrict__ seq_len,
-                                              const u64 *__restrict__ cig_off,
-                                              const u32 *__restrict__ n_cig,
-                                              const u32 *__restrict__ cigar,
-                                              const u8 *__restrict__ seq,
-                                              const u64 *__restrict__ contig_off, u32 n_contigs,
-                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
-                                              u64 *status) {
-    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
+#ifndef PP_PLAIN_ALIGNED
+#define PP_PLAIN_ALIGNED 0
+#endif
+constexpr u32 PLAIN_NARROW_MAX = PP_PLAIN_ALIGNED ? 129u : 160u;  // = PlainCfg<5>::MAXL below
+
+__device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ contig,
+                                         const u32 *__restrict__ ref_start, const u32 *__restrict__ kk,
+                                         const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
+                                         const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
+                                         const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
+                                         const u64 *__restrict__ contig_off, u32 n_contigs,
+                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *maxlen, u64 *status) {
     // independent loads first, then the dependent ones (clamped so that they are unconditional):
     // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
     // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
@@ -206,11 +204,31 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
         // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
         g_out = (u32)(c_lo + rs);
         nk_out = sl;
+        // the longest fast-class read picks the lane-group width of k_tile's plain class; reads of up to
+        // 160 bases (the narrowest group) never touch the word
+        if (sl > PLAIN_NARROW_MAX && sl > *maxlen) atomicMax(maxlen, sl);
     } else {
         prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
     }
     gstart[a] = g_out;
     nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
+}
+
+__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
+                                              const u32 *__restrict__ ref_start,
+                                              const u32 *__restrict__ kk,
+                                              const u64 *__restrict__ seq_off,
+                                              const u32 *__restrict__ seq_len,
+                                              const u64 *__restrict__ cig_off,
+                                              const u32 *__restrict__ n_cig,
+                                              const u32 *__restrict__ cigar,
+                                              const u8 *__restrict__ seq,
+                                              const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                              u32 *__restrict__ maxlen, u64 *status) {
+    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
+                        gstart, nkeep, maxlen, status);
 }
 
 // =============================================================================================
@@ -408,6 +426,8 @@ struct TileArgs {
     u32 *flag_pos;
     u32 *flag_cov;
     ContigStatsDev *stats;
+    const u32 *maxlen;  // longest fast-class read (written by k_prep)
+    u64 seq_bytes;
     const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
     double *dbg_depth;
     u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
@@ -478,84 +498,120 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
 // lane may read the five dwords around any window position it owns a byte of.
 constexpr int ASM_PAD = 32;
 constexpr int ASM_WORDS = TILE / 4 + 24;
-constexpr u32 PLAIN_MAX_LEN = 225;  // 8 lanes x 32 bytes minus up to 31 bytes of misalignment
-constexpr u32 PLAIN_MIN_LEN = 8;    // the trim looks at the two aligned dwords that end the read
+constexpr u32 PLAIN_MIN_LEN = 8;    // the trim reads the last four bases; shorter reads take the scalar path
 
-// ---- plain class: fast class, depth share 1, 8..225 bases -- eight items per wave pass ------------
-// Lanes 8q..8q+7 own item q of the pass; lane s of the group owns the 32 read bytes of two aligned
-// dwordx4 loads.  Everything per item lives in vector registers (no v_readlane, no per-item
-// branches); per-byte predicates are SWAR flags in bit 7 of each byte.
+// ---- plain class: fast class, depth share 1 (or non-dyadic), 8..32*GW bases ------------------------
+// A group of GW lanes owns one work item; lane s of the group owns read bytes [32s, 32s+32), fetched with
+// two 16-byte global loads at the read's own (arbitrary) byte offset -- gfx950 global loads need no
+// alignment -- so a lane's bytes line up with window positions rel + 32s .. and only the END of a read
+// (trimmed tail, bytes past the read) needs masking.  GW is picked per job from the longest fast-class
+// read: 5 lanes (12 items per wave pass) up to 160 bases, 6 (10 items) up to 192, 8 (8 items) up to 252.
+// Everything per item lives in vector registers (no v_readlane, no per-item branches).
 // bit 7 of every non-zero byte
 __device__ __forceinline__ u32 nz_flags(u32 x) {
     return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
-// bit 7 of byte b of dword k set iff (4k + b) >= n, for 0 <= n <= 32 (n8 = n * 0x01010101)
-__device__ __forceinline__ u32 ge_flags(u32 n8, int k) {
-    return ((0x83828180u + 0x04040404u * (u32)k) - n8) & 0x80808080u;
-}
 __device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
     return __builtin_amdgcn_perm(n, n, 0u);
 }
+// 4-bit mask of the non-zero bytes of x (v_dot4_u32_u8 of the 0/1 bytes with weights 1, 2, 4, 8)
+__device__ __forceinline__ u32 nz_mask4(u32 x) {
+    return __builtin_amdgcn_udot4(nz_flags(x) >> 7, 0x08040201u, 0u, false);
+}
+__device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+#if 0
+#define PP_PLAIN_ALIGNED 0  // experiment: 1 = lanes own 32-byte ALIGNED blocks of memory instead of read-relative chunks
+#endif
+template <int GW>
+struct PlainCfg {
+    static constexpr u32 IPP = 64 / GW;                    // items per wave pass
+    static constexpr u32 BATCH = (64 / IPP) * IPP;         // items per batch: whole passes only
+    static constexpr u32 SPAN = PP_PLAIN_ALIGNED ? 32 * GW - 31 : 32 * GW;
+    static constexpr u32 MAXL = SPAN < FAST_MAX_LEN ? SPAN : FAST_MAX_LEN;
+    static_assert(GW != 5 || MAXL == PLAIN_NARROW_MAX, "k_prep's threshold");
+    __device__ static __forceinline__ u32 group(u32 lane) {
+        return GW == 8 ? lane >> 3 : (GW == 5 ? (lane * 52u) >> 8 : (lane * 43u) >> 8);
+    }
+    // work-item words x, y: no flags, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway),
+    // length in range, and every 32-byte chunk of the read inside the seq array
+    __device__ static __forceinline__ bool ok(u32 ex, u32 ey, u64 seq_bytes) {
+        const u32 L = ey >> 24, kc = (ey >> 8) & 0xFFu;
+        const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
+        return (ey & 0x00FF0000u) == 0 && (kc == 0 || kc == KCLASS_NONDYADIC) && L >= PLAIN_MIN_LEN && L <= MAXL &&
+               so + ((L + 31u) & ~31u) <= seq_bytes;
+    }
+};
 
 struct PlainItem {  // per lane
     uint4 Wa, Wb;      // this lane's 32 read bytes
-    uint2 tail;        // the two aligned dwords that end the read (row-uniform)
+    u32 tail;          // the last four bases of the read (group-uniform)
     const u8 *lane_p;  // address of this lane's byte 0
     int rel;           // global start of the read minus the window start
     int ib;            // read index of this lane's byte 0
+    bool first;        // lane 0 of the group
     u32 L;
-    u32 ta;            // (address of the last base) & 3
     bool plain, active;
     bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
 };
 
 // fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
-__device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, const uint4 &my, u32 nb, u32 first, u32 lane) {
+template <int GW>
+__device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, const uint4 &my, u32 nb, u32 first,
+                                                 u32 lane) {
+    typedef PlainCfg<GW> C;
     PlainItem it;
-    const u32 s = lane & 7u;
-    const u32 j = first + (lane >> 3);  // item of the 64-item batch owned by this group
+    const u32 g = C::group(lane), s = lane - (u32)GW * g;
+    const u32 j = first + g;  // item of the batch owned by this group
     const int src = (int)(min(j, nb - 1u) << 2);
     const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
     it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
     it.L = ey >> 24;
-    // flags == 0, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway), length in range
-    const u32 kc = (ey >> 8) & 0xFFu;
-    it.nd = kc == KCLASS_NONDYADIC;
-    it.plain = j < nb && (ey & 0x00FF0000u) == 0 && (kc == 0 || it.nd) && it.L <= PLAIN_MAX_LEN && it.L >= PLAIN_MIN_LEN;
-    const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
-    const u8 *rp = seq + so;
-    const u32 mis = (u32)((uintptr_t)rp & 31u);
+    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.plain = g < C::IPP && j < nb && C::ok(ex, ey, seq_bytes);
+    const u8 *rp = seq + ((u64)ex | ((u64)(ey & 0xFFu) << 32));
+    const u32 mis = PP_PLAIN_ALIGNED ? (u32)((uintptr_t)rp & 31u) : 0u;
     it.ib = (int)(32u * s) - (int)mis;
+    it.first = s == 0;
     it.active = it.plain && 32u * s < mis + it.L;
     it.lane_p = rp + it.ib;
-    const u8 *lastp = rp + (it.L - 1u);
-    it.ta = (u32)((uintptr_t)lastp & 3u);
-    // Unconditional loads (no exec-mask regions): a lane without bytes of the read re-reads a safe
-    // address -- the group's first 16 bytes for a plain item, the (16-byte floored) start of the
-    // seq array otherwise.  Aligned loads that hold at least one byte of the read never leave its pages.
-    const u8 *safe = it.plain ? (rp - mis) : (const u8 *)((uintptr_t)seq & ~(uintptr_t)15);
-    const u8 *pa = it.active ? it.lane_p : safe;
-    const u8 *pb = (it.active && 32u * s + 16u < mis + it.L) ? it.lane_p + 16 : pa;
-    const u8 *pt = it.plain ? lastp - it.ta - 4 : safe;  // same address in the whole group
-    it.Wa = *((const uint4 *)pa);
-    it.Wb = *((const uint4 *)pb);
-    it.tail = make_uint2(((const u32 *)pt)[0], ((const u32 *)pt)[1]);
+    // Loads only where there is something to load (exec-masked): measured faster than unconditional loads
+    // from substitute addresses, and than prefetching the next pass across this pass's work.
+    it.Wa = make_uint4(0, 0, 0, 0);
+    it.Wb = make_uint4(0, 0, 0, 0);
+    it.tail = 0;
+    if (it.plain) it.tail = load4_unaligned(rp + (it.L - 4u));
+    if (it.active) {
+        it.Wa = load16_unaligned(it.lane_p);
+        it.Wb = load16_unaligned(it.lane_p + 16);
+    }
     return it;
 }
 
 __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
-    const u32 s = lane & 7u;
-    const int rel = it.rel, ib = it.ib;
+#ifdef PP_EXP_NO_APPLY
+    if ((it.Wa.x ^ it.Wa.y ^ it.Wa.z ^ it.Wa.w ^ it.Wb.x ^ it.Wb.y ^ it.Wb.z ^ it.Wb.w ^ it.tail) == 0x12345678u) cnt[lane] = 1;
+    return;
+#endif
+    const int rel = it.rel;
     const u32 L = it.L;
 
     // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base,
     // read off the last four bases; a trailing homopolymer of four or more takes the byte loop
-    const u32 t4 = (it.ta == 3u) ? it.tail.y : __builtin_amdgcn_alignbyte(it.tail.y, it.tail.x, it.ta + 1u);
-    const u32 last = t4 >> 24;
-    const u32 tf = nz_flags(t4 ^ splat8(last));
+    const u32 last = it.tail >> 24;
+    const u32 tf = nz_flags(it.tail ^ splat8(last));
     int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
     if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
-        const u8 *rp = it.lane_p - ib;
+        const u8 *rp = it.lane_p - it.ib;
         u32 i = L - 4u;
         while (i > 0 && rp[i - 1] == (u8)last) i--;
         nkeep = i > 0 ? (int)i - 1 : 0;
@@ -564,7 +620,7 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
     const bool live = it.plain && hi > lo;
 
     // ---- coverage difference array (two atomics per read) ----
-    if (live && s == 0) {
+    if (live && it.first) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
         if (it.nd) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
@@ -576,44 +632,40 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
         }
     }
     // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
+    const int ib = it.ib;
     const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
+#ifdef PP_EXP_NO_COMPARE
+    if (live && it.active && b1 > b0 && (it.Wa.x ^ it.Wa.y ^ it.Wa.z ^ it.Wa.w ^ it.Wb.x ^ it.Wb.y ^ it.Wb.z ^ it.Wb.w) == 0x12345678u) {
+#else
     if (live && it.active && b1 > b0) {
-        const int P0 = rel + ib;  // window position of byte 0 (>= -31 here)
+#endif
+        const int P0 = rel + ib;  // window position of byte 0 (> -32 here)
         const u32 ai = (u32)(P0 + ASM_PAD);
         const u32 *ap = asm_w + (ai >> 2);
         const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], a5 = ap[5], a6 = ap[6], a7 = ap[7], a8 = ap[8];
         const u32 sh = ai & 3u;
-        // 8 bytes per compare: which of this lane's four qwords differ from the assembly at all
-#define PP_Q(q, wl, wh, x0, x1, x2)                                                                     \
-    (((((u64)(wh) << 32) | (wl)) != (((u64)__builtin_amdgcn_alignbyte(x2, x1, sh) << 32) |             \
-                                     __builtin_amdgcn_alignbyte(x1, x0, sh))) ? (1u << (q)) : 0u)
-        const u32 mq = PP_Q(0, it.Wa.x, it.Wa.y, a0, a1, a2) | PP_Q(1, it.Wa.z, it.Wa.w, a2, a3, a4) |
-                       PP_Q(2, it.Wb.x, it.Wb.y, a4, a5, a6) | PP_Q(3, it.Wb.z, it.Wb.w, a6, a7, a8);
-#undef PP_Q
-        // qwords entirely inside [b0, b1) need a closer look only when they differ; the (at most two)
-        // qwords cut by b0 or b1 always do, because the bytes outside belong to other reads
-        const int q0 = (b0 + 7) >> 3, q1 = b1 >> 3;
-        const u32 full = q1 > q0 ? (((1u << q1) - 1u) & ~((1u << q0) - 1u)) : 0u;
-        u32 todo = (mq & full) | ((b0 & 7) ? (1u << (b0 >> 3)) : 0u) | ((b1 & 7) ? (1u << (b1 >> 3)) : 0u);
-        while (todo) {
-            const int q = __ffs((int)todo) - 1;
-            todo &= todo - 1u;
-            const u32 wl = q == 0 ? it.Wa.x : (q == 1 ? it.Wa.z : (q == 2 ? it.Wb.x : it.Wb.z));
-            const u32 wh = q == 0 ? it.Wa.y : (q == 1 ? it.Wa.w : (q == 2 ? it.Wb.y : it.Wb.w));
-            const u32 *aq = ap + 2 * q;
-            const u32 x0 = aq[0], x1 = aq[1], x2 = aq[2];
-            const u32 lo8 = splat8((u32)min(max(b0 - 8 * q, 0), 8)), hi8 = splat8((u32)min(max(b1 - 8 * q, 0), 8));
-            const u32 zl = nz_flags(wl ^ __builtin_amdgcn_alignbyte(x1, x0, sh)) & ge_flags(lo8, 0) & ~ge_flags(hi8, 0);
-            const u32 zh = nz_flags(wh ^ __builtin_amdgcn_alignbyte(x2, x1, sh)) & ge_flags(lo8, 1) & ~ge_flags(hi8, 1);
-            u32 Z = (zl >> 7) | (zh >> 6);  // bit k of byte b <=> byte b of dword k of the qword differs
-            while (Z) {  // one trip per differing base
-                const int pos = __ffs((int)Z) - 1;
-                Z &= Z - 1u;
-                const u32 c = (((pos & 1) ? wh : wl) >> (pos & 24)) & 0xFFu;
-                const int p = P0 + 8 * q + 4 * (pos & 1) + (pos >> 3);
-                atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
-                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-            }
+#define PP_D(k, w, x0, x1) (nz_mask4((w) ^ __builtin_amdgcn_alignbyte(x1, x0, sh)) << (4 * (k)))
+        u32 D = PP_D(0, it.Wa.x, a0, a1) | PP_D(1, it.Wa.y, a1, a2) | PP_D(2, it.Wa.z, a2, a3) | PP_D(3, it.Wa.w, a3, a4) |
+                PP_D(4, it.Wb.x, a4, a5) | PP_D(5, it.Wb.y, a5, a6) | PP_D(6, it.Wb.z, a6, a7) | PP_D(7, it.Wb.w, a7, a8);
+#undef PP_D
+        // bit i of D <=> byte i of this lane differs from the assembly; keep bytes [b0, b1) only
+        D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
+        while (D) {  // one trip per differing base
+            const int i = __ffs((int)D) - 1;
+            D &= D - 1u;
+            // byte i of the lane's eight dwords, by a select tree on the bits of i (no memory access: a
+            // load here would have to wait for the next pass's prefetch as well)
+            const u32 m4 = (u32)(((int)((u32)i << 29)) >> 31), m8 = (u32)(((int)((u32)i << 28)) >> 31),
+                      m16 = (u32)(((int)((u32)i << 27)) >> 31);
+#define PP_SEL(m, b, a) (((m) & (b)) | (~(m) & (a)))
+            const u32 w01 = PP_SEL(m4, it.Wa.y, it.Wa.x), w23 = PP_SEL(m4, it.Wa.w, it.Wa.z);
+            const u32 w45 = PP_SEL(m4, it.Wb.y, it.Wb.x), w67 = PP_SEL(m4, it.Wb.w, it.Wb.z);
+            const u32 wlo = PP_SEL(m8, w23, w01), whi = PP_SEL(m8, w67, w45);
+            const u32 c = (PP_SEL(m16, whi, wlo) >> (8 * (i & 3))) & 0xFFu;
+#undef PP_SEL
+            const int p = P0 + i;
+            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
         }
     }
 }
@@ -719,55 +771,31 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
 }
 
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
-    __shared__ u32 cnt[N_ROWS * TILE];
-    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
-    __shared__ u64 s_depth;
-
-    // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
-    u32 per = gridDim.x >> 3;
-    u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (w >= A.nwin || *A.status != ~0ull) return;
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u64 w0 = (u64)w * TILE;
-
-    for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
-    if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
-    {
-        u8 *ab = (u8 *)asm_w;
-        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
-        if (tid < (u32)ASM_PAD) ab[tid] = 0;
-        if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
-    }
-    if (tid == 0) {
-        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0;
-        s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
-        u64 last = min(w0 + TILE, A.G) - 1;
-        s_c1 = find_contig(A.contig_off, A.n_contigs, last);
-    }
-    __syncthreads();
-
-    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    // Each wave takes 64 work items at a time: one coalesced 1 KiB load of their 16-byte records,
-    // fields broadcast with v_readlane (-> SGPRs), then the fast class four items at a time so
-    // that four read loads are in flight per wave.
-    for (u32 eb = e0 + wave * 64u; eb < e1; eb += (TILE_THREADS / 64) * 64u) {
-        const u32 nb = min(64u, e1 - eb);
+// The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
+// records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
+// hidden by the other 7 waves of the SIMD, not by software pipelining (which measured slower).
+template <int GW>
+__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, u32 e0, u32 e1,
+                                           u32 wave, u32 lane) {
+    typedef PlainCfg<GW> C;
+    // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
+    // of the items does not matter: the counters are integers)
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + C::IPP - 1u) / C::IPP * C::IPP;
+    const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
+    if (lo_w >= hi_w) return;
+    for (u32 eb = lo_w; eb < hi_w; eb += C::BATCH) {
+        const u32 nb = min(C::BATCH, hi_w - eb);
         const uint4 my = A.entA[eb + min(lane, nb - 1u)];
-        const u32 my_flags = (my.y >> 16) & 0xFFu, my_kc = (my.y >> 8) & 0xFFu;
+        const u32 my_flags = (my.y >> 16) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
-        const bool my_plain = lane < nb && my_flags == 0 && (my_kc == 0 || my_kc == KCLASS_NONDYADIC) &&
-                              (my.y >> 24) <= PLAIN_MAX_LEN && (my.y >> 24) >= PLAIN_MIN_LEN;
-        // plain class: passes of eight items, the next pass's read loads in flight behind the current
-        // one; two passes per trip so that the two register sets alternate without copies
-        PlainItem pa = plain_fetch(A.seq, my, nb, 0, lane);
-        for (u32 first = 0; first < nb; first += 16) {
-            const PlainItem pb = plain_fetch(A.seq, my, nb, first + 8u, lane);
-            plain_apply(cnt, s_ndbits, asm_w, pa, lane);
-            pa = plain_fetch(A.seq, my, nb, first + 16u, lane);
-            if (first + 8u < nb) plain_apply(cnt, s_ndbits, asm_w, pb, lane);
-        }
+        const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
+#ifdef PP_EXP_ENTA_ONLY
+        if ((my.x ^ my.y ^ my.z ^ my.w) == 0x12345678u) cnt[lane] = 1;
+        continue;
+#endif
+        for (u32 first = 0; first < nb; first += C::IPP)
+            plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
         u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
         while (rest) {
@@ -812,6 +840,47 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
+    __shared__ u32 cnt[N_ROWS * TILE];
+    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
+    __shared__ u64 s_depth;
+
+    // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
+    u32 per = gridDim.x >> 3;
+    u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (w >= A.nwin || *A.status != ~0ull) return;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u64 w0 = (u64)w * TILE;
+
+    for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
+    {
+        u8 *ab = (u8 *)asm_w;
+        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        if (tid < (u32)ASM_PAD) ab[tid] = 0;
+        if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
+    }
+    if (tid == 0) {
+        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0;
+        s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
+        u64 last = min(w0 + TILE, A.G) - 1;
+        s_c1 = find_contig(A.contig_off, A.n_contigs, last);
+    }
+    __syncthreads();
+
+    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+#ifdef PP_EXP_NO_ITEMS
+    if (e0 == 0xFFFFFFFFu)
+#endif
+    {
+        const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
+        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else tile_items<8>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+    }
     if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
     __syncthreads();
 
@@ -839,7 +908,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     u32 my_len = 0, my_changed = 0, my_zero = 0;
     u64 my_depth = 0;
     const bool one_contig = (s_c0 == s_c1);
+#ifdef PP_EXP_NO_VOTE
+    for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) { if (w0 + p < A.G) A.code[w0 + p] = ((const u8 *)asm_w)[ASM_PAD + p] + (u8)cnt[ROW_COV * TILE + p]; }
+    for (u32 p = TILE; p < (u32)TILE; p += TILE_THREADS) {
+#else
     for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
+#endif
         const u64 gp = w0 + p;
         if (gp >= A.G) break;
         if (A.own) {  // window tiling: halo positions are voted by the rank that owns them
@@ -1483,17 +1557,35 @@ void dev_free(DevBuf &b) {
     b.cap = 0;
 }
 
+// Per-kernel-group timing with HIP events on the context's stream.  profiling == 1 times every group,
+// profiling == 2 only the dominant kernel ("tile": one event pair per job, for the bench's timed region).
+// Events come from a pool that lives as long as the context.
 void timer_begin(pp_ctx *ctx, const char *name) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || (ctx->profiling == 2 && strcmp(name, "tile") != 0)) return;
     KernelTimer t;
     t.name = name;
-    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
+    if (ctx->event_pool.size() >= 2) {
+        t.stop = ctx->event_pool.back(); ctx->event_pool.pop_back();
+        t.start = ctx->event_pool.back(); ctx->event_pool.pop_back();
+    } else if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
+        return;
+    }
     (void)hipEventRecord(t.start, ctx->stream);
     ctx->timers.push_back(t);
+    ctx->timer_open = true;
 }
 void timer_end(pp_ctx *ctx) {
-    if (!ctx->profiling || ctx->timers.empty()) return;
+    if (!ctx->timer_open) return;
     (void)hipEventRecord(ctx->timers.back().stop, ctx->stream);
+    ctx->timer_open = false;
+}
+void timers_release(pp_ctx *ctx) {
+    for (auto &t : ctx->timers) {
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->timers.clear();
+    ctx->timer_open = false;
 }
 int timers_collect(pp_ctx *ctx, pp_kernel_times *out) {
     out->n = 0;
@@ -1511,10 +1603,8 @@ int timers_collect(pp_ctx *ctx, pp_kernel_times *out) {
             out->n++;
         }
         out->ms[k] += ms;
-        (void)hipEventDestroy(t.start);
-        (void)hipEventDestroy(t.stop);
     }
-    ctx->timers.clear();
+    timers_release(ctx);
     return PP_OK;
 }
 
@@ -1702,7 +1792,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         timer_begin(ctx, "prep");
         hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
                            B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
-                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, d_status);
+                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, (u32 *)(d_meta + 9), d_status);
         timer_end(ctx);
     }
     timer_begin(ctx, "bucket");
@@ -1728,6 +1818,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
     T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
+    T.maxlen = (const u32 *)(d_meta + 9);
+    T.seq_bytes = B.seq_bytes;
     T.own = nullptr;
     if (!ctx->emit.empty()) {
         const void *d_own = nullptr;
@@ -1807,8 +1899,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     std::vector<uint64_t> meta;
     uint32_t n_entries = 0;
     for (int attempt = 0;; attempt++) {
-        for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-        ctx->timers.clear();
+        timers_release(ctx);
         int rc = run_pipeline(ctx, meta, &n_entries);
         if (rc) return rc;
         const uint64_t key = meta[0];
@@ -1942,7 +2033,7 @@ extern "C" void pp_debug_extra_free(pp_debug_extra *d) {
 extern "C" int pp_ctx_set_profiling(pp_ctx *ctx, int enable) {
     if (!ctx) return PP_ERR_ARG;
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable == 2 ? 2 : (enable != 0);
     return PP_OK;
 }
 
@@ -2028,7 +2119,8 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     for (DevBuf *b : all) dev_free(*b);
     for (auto &b : ctx->b_in) dev_free(b);
     for (auto &f : ctx->f_in) for (auto &b : f) dev_free(b);
-    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    timers_release(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
