@@ -215,16 +215,12 @@ def main():
             pp.lib().pp_polish_result(ctx._h, gather_buf.data_ptr(), pp.MEM_DEVICE, None, None)
             dist.gather(gather_buf.cpu() if share else gather_buf, gathered, dst=0)
 
-    # Untimed: the warm-up steps, the first few of them with every kernel group under HIP events for the
-    # per-group breakdown (kernel_ms_per_step).  Timed region: only the dominant kernel carries an event
-    # pair (on the library's stream), so that the timers do not perturb what `value` measures.
-    ctx.set_profiling(1)
-    all_ms, n_break = {}, 0
+    # Timed region: only the dominant kernel carries an event pair (on the library's stream), so that the
+    # timers do not perturb what `value` measures.  The per-group breakdown (kernel_ms_per_step) comes from
+    # a few extra, untimed steps afterwards with every kernel group under HIP events.
+    ctx.set_profiling(0)
     for _ in range(args.warmup):
         step()
-        for k, v in ctx.kernel_times()["ms"].items():
-            all_ms[k] = all_ms.get(k, 0.0) + v
-        n_break += 1
     ctx.set_profiling(2)
     tile_ms = []
     torch.cuda.synchronize()
@@ -245,7 +241,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ctx.set_profiling(False)
+    ctx.set_profiling(1)
+    all_ms, n_break = {}, 5
+    for _ in range(n_break):
+        step()
+        for k, v in ctx.kernel_times()["ms"].items():
+            all_ms[k] = all_ms.get(k, 0.0) + v
+    ctx.set_profiling(0)
 
     gather_ok = None
     if world > 1:

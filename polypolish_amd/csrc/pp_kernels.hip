@@ -1755,7 +1755,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const uint64_t G = ctx->G;
     const uint32_t nc = ctx->n_contigs;
     const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
-    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));
+    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));  // k_scan_cols: <= 512
     const uint64_t chunk = (n + NB - 1) / NB;
     const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
