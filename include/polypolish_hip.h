@@ -265,6 +265,12 @@ int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int careful, pp_
 /* add_to_pileup's streaming half (src/alignment.rs:225-272): parse, group adjacent QNAMEs, apply
  * process_one_read's gates, append the good alignments to the batch.  Files in argv order. */
 int pp_ingest_sam(pp_ingest *g, const char *path, pp_sam_counts *counts, char *err, size_t errlen);
+/* Same, with the filter's verdicts handed over in memory instead of as "ZP:Z:fail" tags in a rewritten
+ * file (fused filter -> polish): pass[i] == 0 fails the i-th ALIGNED record of the file (file order, the
+ * numbering of pp_filter_file), exactly as if the tag had been appended to its line (src/alignment.rs:72-74).
+ * n_pass must equal the number of aligned records. */
+int pp_ingest_sam_filtered(pp_ingest *g, const char *path, const uint8_t *pass, uint64_t n_pass,
+                           pp_sam_counts *counts, char *err, size_t errlen);
 void pp_ingest_batch(const pp_ingest *g, pp_aln_batch *out); /* borrowed view, host memory */
 /* QNAME of batch record i (for error messages). */
 const char *pp_ingest_read_name(const pp_ingest *g, uint64_t i);
@@ -301,6 +307,13 @@ typedef struct {
 int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, const char *out1,
                     const char *out2, const char *orientation, double low, double high, int quiet,
                     pp_filter_report *report);
+
+/* filter + polish in one process: the filter's verdicts go straight into the polish ingest,
+ * the tagged SAMs are written only if out1/out2 are given (both or neither).  The FASTA is byte-identical
+ * to `filter` followed by `polish` on its outputs. */
+int pp_filter_polish_files(pp_ctx *ctx, const char *assembly, const char *in1, const char *in2,
+                           const char *out1, const char *out2, const char *orientation, double low, double high,
+                           const pp_polish_options *opt, pp_filter_report *report, pp_bytes *fasta);
 
 #ifdef __cplusplus
 }

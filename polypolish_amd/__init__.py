@@ -109,7 +109,7 @@ EXPORTS = [
     "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
-    "pp_bytes_free", "pp_polish_files", "pp_filter_files",
+    "pp_bytes_free", "pp_polish_files", "pp_filter_files", "pp_filter_polish_files", "pp_ingest_sam_filtered",
 ]
 
 _lib = None
@@ -185,6 +185,9 @@ def lib():
                                       C.POINTER(Bytes)]
         L.pp_filter_files.argtypes = [vp] + [C.c_char_p] * 5 + [C.c_double, C.c_double, C.c_int,
                                                                 C.POINTER(FilterReport)]
+        L.pp_filter_polish_files.argtypes = [vp] + [C.c_char_p] * 6 + [C.c_double, C.c_double, C.POINTER(PolishOptions),
+                                                                       C.POINTER(FilterReport), C.POINTER(Bytes)]
+        L.pp_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -412,6 +415,22 @@ class Context:
         data = C.string_at(out.data, out.len) if out.len else b""
         lib().pp_bytes_free(C.byref(out))
         return data
+
+    def filter_polish_files(self, assembly, in1, in2, out1=None, out2=None, orientation="auto", low=0.1, high=99.9,
+                            fraction_invalid=0.2, fraction_valid=0.5, max_errors=10, min_depth=5, careful=False,
+                            debug=None, quiet=True):
+        """filter + polish in one process (pp_filter_polish_files): returns (FASTA bytes, filter report)."""
+        opt = PolishOptions(fraction_invalid, fraction_valid, max_errors, min_depth, int(careful),
+                            str(debug).encode() if debug else None, int(quiet))
+        rep, out = FilterReport(), Bytes()
+        enc = lambda x: str(x).encode() if x is not None else None
+        self._chk(lib().pp_filter_polish_files(self._h, enc(assembly), enc(in1), enc(in2), enc(out1), enc(out2),
+                                               orientation.encode(), low, high, C.byref(opt), C.byref(rep), C.byref(out)))
+        data = C.string_at(out.data, out.len) if out.len else b""
+        lib().pp_bytes_free(C.byref(out))
+        return data, {"before": rep.before_count, "after": rep.after_count, "low": rep.low_threshold,
+                      "high": rep.high_threshold, "orientation": ("fr", "rf", "ff", "rr")[rep.orientation],
+                      "counts": list(rep.orientation_counts)}
 
     def filter_files(self, in1, in2, out1, out2, orientation="auto", low=0.1, high=99.9, quiet=True):
         rep = FilterReport()

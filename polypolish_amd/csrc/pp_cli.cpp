@@ -17,7 +17,8 @@ static const char *HELP =
     "Usage: polypolish <COMMAND>\n\n"
     "Commands:\n"
     "  filter  filter paired-end alignments based on insert size\n"
-    "  polish  polish a long-read assembly using short-read alignments\n\n"
+    "  polish  polish a long-read assembly using short-read alignments\n"
+    "  filter-polish  both in one process, without the intermediate SAM files (not in the reference)\n\n"
     "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n";
 
 static const char *HELP_FILTER =
@@ -46,6 +47,12 @@ static const char *HELP_POLISH =
     "  -d, --min_depth <MIN_DEPTH>                A base must occur at least this many times in the pileup to be considered valid [default: 5]\n"
     "      --careful                              Ignore any reads with multiple alignments\n"
     "  -h, --help                                 Print help\n  -V, --version                              Print version\n";
+
+static const char *HELP_FUSED =
+    "filter paired-end alignments by insert size and polish with them, in one process\n\n"
+    "Usage: polypolish filter-polish [OPTIONS] --in1 <IN1> --in2 <IN2> <ASSEMBLY>\n\n"
+    "Options: those of `filter` (--out1/--out2 optional: write the tagged SAMs as well) and of `polish`.\n"
+    "The FASTA on stdout is byte-identical to `filter` followed by `polish` on its outputs.\n";
 
 static int usage_error(const char *msg) {
     fprintf(stderr, "error: %s\n\nFor more information, try '--help'.\n", msg);
@@ -145,6 +152,62 @@ int main(int argc, char **argv) {
         if (rc) return no_device(device);
         pp_bytes fasta{nullptr, 0};
         rc = pp_polish_files(ctx, assembly, sams.data(), (int)sams.size(), &opt, &fasta);
+        if (pp_ctx_wait(ctx) != PP_OK) return no_device(device);
+        if (rc) {
+            fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));
+            pp_ctx_destroy(ctx);
+            return rc == PP_ERR_PANIC ? 101 : 1;
+        }
+        fwrite(fasta.data, 1, fasta.len, stdout);
+        return finish(0);
+    }
+
+    if (cmd == "filter-polish") {
+        pp_polish_options opt{0.2, 0.5, 10, 5, 0, nullptr, 0};
+        const char *assembly = nullptr, *in1 = nullptr, *in2 = nullptr, *out1 = nullptr, *out2 = nullptr, *orientation = "auto";
+        double low = 0.1, high = 99.9;
+        for (int i = 2; i < argc; i++) {
+            const char *a = argv[i];
+            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_FUSED, stdout); return 0; }
+            if (!strcmp(a, "--careful")) { opt.careful = 1; continue; }
+            struct { const char *l; const char **dst; } paths[] = {{"--in1", &in1}, {"--in2", &in2}, {"--out1", &out1},
+                                                                  {"--out2", &out2}, {"--orientation", &orientation},
+                                                                  {"--debug", &opt.debug_path}};
+            bool matched = false;
+            for (auto &t : paths) {
+                if (!is_opt(a, t.l, nullptr)) continue;
+                const char *v = opt_value(argc, argv, i, a, t.l, nullptr);
+                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
+                *t.dst = v;
+                matched = true;
+                break;
+            }
+            if (matched) continue;
+            struct { const char *l, *s; int kind; void *dst; } table[] = {
+                {"--fraction_invalid", "-i", 0, &opt.fraction_invalid}, {"--fraction_valid", "-v", 0, &opt.fraction_valid},
+                {"--max_errors", "-m", 1, &opt.max_errors}, {"--min_depth", "-d", 1, &opt.min_depth},
+                {"--low", nullptr, 0, &low}, {"--high", nullptr, 0, &high}};
+            for (auto &t : table) {
+                if (!is_opt(a, t.l, t.s)) continue;
+                const char *v = opt_value(argc, argv, i, a, t.l, t.s);
+                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
+                bool ok = t.kind == 0 ? parse_f64(v, *(double *)t.dst) : parse_u32(v, *(uint32_t *)t.dst);
+                if (!ok) return usage_error((std::string("invalid value '") + v + "' for '" + t.l + "'").c_str());
+                matched = true;
+                break;
+            }
+            if (matched) continue;
+            if (a[0] == '-' && a[1] != 0) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
+            if (assembly) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
+            assembly = a;
+        }
+        if (!assembly || !in1 || !in2)
+            return usage_error("the following required arguments were not provided:\n  --in1 <IN1> --in2 <IN2> <ASSEMBLY>");
+        pp_ctx *ctx = nullptr;
+        int rc = pp_ctx_create_async(device, &ctx);
+        if (rc) return no_device(device);
+        pp_bytes fasta{nullptr, 0};
+        rc = pp_filter_polish_files(ctx, assembly, in1, in2, out1, out2, orientation, low, high, &opt, nullptr, &fasta);
         if (pp_ctx_wait(ctx) != PP_OK) return no_device(device);
         if (rc) {
             fprintf(stderr, "\nError: %s\n", pp_last_error(ctx));

@@ -156,8 +156,19 @@ static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_
     return PP_OK;
 }
 
+extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
+                                         const pp_polish_options *opt, pp_bytes *fasta,
+                                         const uint8_t *const *pass, const uint64_t *n_pass);
+
 extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                                const pp_polish_options *opt, pp_bytes *fasta) {
+    return pp_polish_files_filtered_(ctx, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
+}
+
+// pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
+extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
+                                         const pp_polish_options *opt, pp_bytes *fasta,
+                                         const uint8_t *const *pass, const uint64_t *n_pass) {
     if (!ctx || !assembly || !opt || !fasta || (n_sams > 0 && !sams)) return PP_ERR_ARG;
     fasta->data = nullptr;
     fasta->len = 0;
@@ -215,7 +226,8 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     uint64_t alignment_total = 0, used_total = 0;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;
-        rc = pp_ingest_sam(g, sams[i], &c, err, sizeof err);
+        rc = pass ? pp_ingest_sam_filtered(g, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
+                  : pp_ingest_sam(g, sams[i], &c, err, sizeof err);
         if (rc) { set_err(ctx, rc, err); break; }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
         alignment_total += c.alignments;

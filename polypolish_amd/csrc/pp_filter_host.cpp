@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <string>
@@ -579,31 +580,24 @@ extern "C" int pp_filter_write(const pp_filter_loaded *L, int f, const uint8_t *
     return PP_OK;
 }
 
-extern "C" int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, const char *out1,
-                               const char *out2, const char *orientation, double low, double high, int quiet,
-                               pp_filter_report *report) {
-    if (!ctx || !in1 || !in2 || !out1 || !out2 || !orientation) return PP_ERR_ARG;
-    auto set_err = [&](int code, const char *msg) { return pp_ctx_set_error_(ctx, code, msg); };
-    Log log{quiet != 0};
-    const auto t0 = std::chrono::steady_clock::now();
-    const bool timing = getenv("PP_TIMING") != nullptr;
-    auto lap = [&](const char *what) {
-        if (timing) fprintf(stderr, "[timing] %-28s %8.3f s\n", what,
-                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    };
-    // check_inputs, filter.rs:40-53
-    const char *f4[4] = {in1, in2, out1, out2};
-    for (int i = 0; i < 4; i++)
-        for (int j = i + 1; j < 4; j++)
-            if (strcmp(f4[i], f4[j]) == 0)
-                return set_err(PP_ERR_QUIT, "--in1, --in2, --out1 and --out2 must all have unique values");
-    if (low <= 0.0 || low >= 50.0) return set_err(PP_ERR_QUIT, "--low must be greater than 0 and less than 50");
-    if (high <= 50.0 || high >= 100.0) return set_err(PP_ERR_QUIT, "--high must be greater than 50 and less than 100");
-    log("\nStarting Polypolish filter\n%s\n\nInput alignments:\n  %s\n  %s\n\nOutput alignments:\n  %s\n  %s\n\n"
-        "Settings:\n  --orientation %s\n  --low %g\n  --high %g\n\n", pp_version(), in1, in2, out1, out2, orientation, low, high);
+namespace {
 
+struct FilterRun {
+    pp_filter_loaded *L = nullptr;
+    std::vector<uint8_t> pass[2];
+    uint64_t before = 0;
+    uint32_t lo = 0, hi = 0;
+    int correct = -1;
+    uint64_t counts[4] = {0, 0, 0, 0};
+    ~FilterRun() { pp_filter_loaded_free(L); }
+};
+
+// load_alignments + get_insert_size_thresholds + the pass/fail verdicts (filter.rs:26-34 without filter_sams)
+int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char *)> &lap, const char *in1, const char *in2,
+                const char *orientation, double low, double high, FilterRun &R) {
+    auto set_err = [&](int code, const char *msg) { return pp_ctx_set_error_(ctx, code, msg); };
     log("Loading alignments\n");
-    const char *ins[2] = {in1, in2}, *outs[2] = {out1, out2};
+    const char *ins[2] = {in1, in2};
     pp_filter_loaded *L = nullptr;
     pp_filter_file_counts fc[2];
     char err[1400] = "";
@@ -612,14 +606,11 @@ extern "C" int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, co
         if (fc[f].loaded)
             log("%s: %s alignments from %s reads\n", ins[f], commas(fc[f].alignments).c_str(), commas(fc[f].reads).c_str());
     if (rc) return set_err(rc, err);
-    struct Release {
-        pp_filter_loaded *L;
-        ~Release() { pp_filter_loaded_free(L); }
-    } release{L};
+    R.L = L;
     lap("alignments loaded");
     log("\n");
     const uint32_t n_reads = L->n_reads;
-    const uint64_t before = L->before;
+    R.before = L->before;
 
     pp_filter_input in;
     pp_filter_loaded_input(L, &in);
@@ -666,32 +657,126 @@ extern "C" int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, co
         percentile_name(high).c_str());
     lap("thresholds");
 
-    // filter_sams, filter.rs:273-349
-    log("Filtering SAM files\n");
-    std::vector<uint8_t> pass[2];
-    for (int f = 0; f < 2; f++) pass[f].resize(L->F[f].n_aln ? L->F[f].n_aln : 1);
-    rc = pp_filter_pairs(ctx, lo, hi, (uint8_t)correct, pass[0].data(), pass[1].data());
+    // alignment_pass_qc for every alignment of both files (filter.rs:352-377)
+    for (int f = 0; f < 2; f++) R.pass[f].resize(L->F[f].n_aln ? L->F[f].n_aln : 1);
+    rc = pp_filter_pairs(ctx, lo, hi, (uint8_t)correct, R.pass[0].data(), R.pass[1].data());
     if (rc) return rc;
     lap("pass flags from the device");
-    uint64_t after = 0;
+    R.lo = lo; R.hi = hi; R.correct = correct;
+    for (int o = 0; o < 4; o++) R.counts[o] = counts[o];
+    return PP_OK;
+}
+
+// filter_sams, filter.rs:273-349
+int filter_write(pp_ctx *ctx, const Log &log, const FilterRun &R, const char *const ins[2], const char *const outs[2],
+                 uint64_t *after) {
+    char err[1400] = "";
+    *after = 0;
+    log("Filtering SAM files\n");
     for (int f = 0; f < 2; f++) {
         uint64_t p_ = 0, f_ = 0;
-        rc = pp_filter_write(L, f, pass[f].data(), outs[f], &p_, &f_, err, sizeof err);
-        if (rc) return set_err(rc, err);
+        const int rc = pp_filter_write(R.L, f, R.pass[f].data(), outs[f], &p_, &f_, err, sizeof err);
+        if (rc) return pp_ctx_set_error_(ctx, rc, err);
         log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(p_).c_str(), commas(f_).c_str());
-        after += p_;
+        *after += p_;
     }
+    return PP_OK;
+}
+
+int check_filter_options(pp_ctx *ctx, const char *const *names, int n_names, double low, double high) {
+    // check_inputs, filter.rs:40-53
+    for (int i = 0; i < n_names; i++)
+        for (int j = i + 1; j < n_names; j++)
+            if (strcmp(names[i], names[j]) == 0)
+                return pp_ctx_set_error_(ctx, PP_ERR_QUIT, "--in1, --in2, --out1 and --out2 must all have unique values");
+    if (low <= 0.0 || low >= 50.0) return pp_ctx_set_error_(ctx, PP_ERR_QUIT, "--low must be greater than 0 and less than 50");
+    if (high <= 50.0 || high >= 100.0) return pp_ctx_set_error_(ctx, PP_ERR_QUIT, "--high must be greater than 50 and less than 100");
+    return PP_OK;
+}
+
+}  // namespace
+
+extern "C" int pp_filter_files(pp_ctx *ctx, const char *in1, const char *in2, const char *out1,
+                               const char *out2, const char *orientation, double low, double high, int quiet,
+                               pp_filter_report *report) {
+    if (!ctx || !in1 || !in2 || !out1 || !out2 || !orientation) return PP_ERR_ARG;
+    Log log{quiet != 0};
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool timing = getenv("PP_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[timing] %-28s %8.3f s\n", what,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
+    const char *f4[4] = {in1, in2, out1, out2};
+    if (int rc = check_filter_options(ctx, f4, 4, low, high)) return rc;
+    log("\nStarting Polypolish filter\n%s\n\nInput alignments:\n  %s\n  %s\n\nOutput alignments:\n  %s\n  %s\n\n"
+        "Settings:\n  --orientation %s\n  --low %g\n  --high %g\n\n", pp_version(), in1, in2, out1, out2, orientation, low, high);
+    FilterRun R;
+    if (int rc = filter_core(ctx, log, lap, in1, in2, orientation, low, high, R)) return rc;
+    const char *ins[2] = {in1, in2}, *outs[2] = {out1, out2};
+    uint64_t after = 0;
+    if (int rc = filter_write(ctx, log, R, ins, outs, &after)) return rc;
     lap("filtered SAMs written");
     if (report) {
-        report->before_count = before;
+        report->before_count = R.before;
         report->after_count = after;
-        report->low_threshold = lo;
-        report->high_threshold = hi;
-        report->orientation = correct;
-        for (int o = 0; o < 4; o++) report->orientation_counts[o] = counts[o];
+        report->low_threshold = R.lo;
+        report->high_threshold = R.hi;
+        report->orientation = R.correct;
+        for (int o = 0; o < 4; o++) report->orientation_counts[o] = R.counts[o];
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     log("Finished!\nAlignments before filtering: %s\nAlignments after filtering:  %s\n\nTime to run: %s\n\n",
-        commas(before).c_str(), commas(after).c_str(), format_duration(secs).c_str());
+        commas(R.before).c_str(), commas(after).c_str(), format_duration(secs).c_str());
     return PP_OK;
+}
+
+extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
+                                         const pp_polish_options *opt, pp_bytes *fasta,
+                                         const uint8_t *const *pass, const uint64_t *n_pass);
+
+extern "C" int pp_filter_polish_files(pp_ctx *ctx, const char *assembly, const char *in1, const char *in2,
+                                      const char *out1, const char *out2, const char *orientation, double low,
+                                      double high, const pp_polish_options *opt, pp_filter_report *report,
+                                      pp_bytes *fasta) {
+    if (!ctx || !assembly || !in1 || !in2 || !orientation || !opt || !fasta) return PP_ERR_ARG;
+    if ((out1 == nullptr) != (out2 == nullptr))
+        return pp_ctx_set_error_(ctx, PP_ERR_ARG, "pp_filter_polish_files: give both --out1 and --out2 or neither");
+    Log log{opt->quiet != 0};
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool timing = getenv("PP_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[timing] %-28s %8.3f s\n", what,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
+    const char *f4[4] = {in1, in2, out1, out2};
+    if (int rc = check_filter_options(ctx, f4, out1 ? 4 : 2, low, high)) return rc;
+    log("\nStarting Polypolish filter + polish (fused)\n%s\n\nInput alignments:\n  %s\n  %s\n\n"
+        "Filter settings:\n  --orientation %s\n  --low %g\n  --high %g\n\n", pp_version(), in1, in2, orientation, low, high);
+    FilterRun R;
+    if (int rc = filter_core(ctx, log, lap, in1, in2, orientation, low, high, R)) return rc;
+    const char *ins[2] = {in1, in2}, *outs[2] = {out1, out2};
+    uint64_t after = 0;
+    if (out1) {
+        if (int rc = filter_write(ctx, log, R, ins, outs, &after)) return rc;
+        lap("filtered SAMs written");
+    } else {
+        for (int f = 0; f < 2; f++)
+            for (uint64_t i = 0; i < R.L->F[f].n_aln; i++) after += R.pass[f][i];
+    }
+    if (report) {
+        report->before_count = R.before;
+        report->after_count = after;
+        report->low_threshold = R.lo;
+        report->high_threshold = R.hi;
+        report->orientation = R.correct;
+        for (int o = 0; o < 4; o++) report->orientation_counts[o] = R.counts[o];
+    }
+    log("Alignments before filtering: %s\nAlignments after filtering:  %s\n", commas(R.before).c_str(), commas(after).c_str());
+    // the verdicts go straight into the polish ingest; the filter's parse-time memory is released first
+    const uint8_t *pass[2] = {R.pass[0].data(), R.pass[1].data()};
+    const uint64_t n_pass[2] = {R.L->F[0].n_aln, R.L->F[1].n_aln};
+    pp_filter_loaded_free(R.L);
+    R.L = nullptr;
+    return pp_polish_files_filtered_(ctx, assembly, ins, 2, opt, fasta, pass, n_pass);
 }

@@ -391,6 +391,11 @@ extern "C" int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int c
 // order (so errors surface in the order the reference's streaming loop would hit them), and the SoA
 // is filled in parallel.  The result does not depend on the thread count.
 extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *counts, char *err, size_t errlen) {
+    return pp_ingest_sam_filtered(I, path, nullptr, 0, counts, err, errlen);
+}
+
+extern "C" int pp_ingest_sam_filtered(pp_ingest *I, const char *path, const uint8_t *pass, uint64_t n_pass,
+                                      pp_sam_counts *counts, char *err, size_t errlen) {
     if (!I || !path) return PP_ERR_ARG;
     pp_sam_counts c{0, 0, 0};
     int fd = -1;
@@ -477,10 +482,15 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
                 for (size_t i = 0; i < nrec; i++) {
                     ch.recs[i].runs = ch.runs.data() + ch.recs[i].run_lo;
                     all[first[t] + i] = &ch.recs[i];
+                    // the filter's verdict for this aligned record, as if "ZP:Z:fail" were on its line
+                    if (pass && first[t] + i < n_pass && !pass[first[t] + i]) ch.recs[i].pass_qc = 0;
                 }
             }
         });
         lap("flatten");
+        if (pass && n_chunks_ok == threads && n_pass != total_recs)
+            fail(PP_ERR_ARG, "%llu filter verdicts for the %llu aligned records of \"%s\"", (unsigned long long)n_pass,
+                 (unsigned long long)total_recs, path);
         const bool parse_failed = n_chunks_ok < threads;  // the group pending at the failing line is never processed
         auto is_start = [&](size_t i) {
             if (i == 0) return true;

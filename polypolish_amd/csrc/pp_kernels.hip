@@ -529,9 +529,8 @@ __device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
     return v;
 }
 
-#if 0
-#define PP_PLAIN_ALIGNED 0  // experiment: 1 = lanes own 32-byte ALIGNED blocks of memory instead of read-relative chunks
-#endif
+// PP_PLAIN_ALIGNED=1 (compile-time alternative, same speed on MI355X): lanes own 32-byte ALIGNED blocks of
+// memory instead of read-relative chunks; a group then spans 32*GW-31 bases.
 template <int GW>
 struct PlainCfg {
     static constexpr u32 IPP = 64 / GW;                    // items per wave pass
@@ -598,10 +597,6 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, c
 }
 
 __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
-#ifdef PP_EXP_NO_APPLY
-    if ((it.Wa.x ^ it.Wa.y ^ it.Wa.z ^ it.Wa.w ^ it.Wb.x ^ it.Wb.y ^ it.Wb.z ^ it.Wb.w ^ it.tail) == 0x12345678u) cnt[lane] = 1;
-    return;
-#endif
     const int rel = it.rel;
     const u32 L = it.L;
 
@@ -634,11 +629,7 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
     // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
     const int ib = it.ib;
     const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
-#ifdef PP_EXP_NO_COMPARE
-    if (live && it.active && b1 > b0 && (it.Wa.x ^ it.Wa.y ^ it.Wa.z ^ it.Wa.w ^ it.Wb.x ^ it.Wb.y ^ it.Wb.z ^ it.Wb.w) == 0x12345678u) {
-#else
     if (live && it.active && b1 > b0) {
-#endif
         const int P0 = rel + ib;  // window position of byte 0 (> -32 here)
         const u32 ai = (u32)(P0 + ASM_PAD);
         const u32 *ap = asm_w + (ai >> 2);
@@ -790,10 +781,6 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         const u32 my_flags = (my.y >> 16) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
         const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
-#ifdef PP_EXP_ENTA_ONLY
-        if ((my.x ^ my.y ^ my.z ^ my.w) == 0x12345678u) cnt[lane] = 1;
-        continue;
-#endif
         for (u32 first = 0; first < nb; first += C::IPP)
             plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
@@ -872,9 +859,6 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __syncthreads();
 
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-#ifdef PP_EXP_NO_ITEMS
-    if (e0 == 0xFFFFFFFFu)
-#endif
     {
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
         if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
@@ -908,12 +892,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     u32 my_len = 0, my_changed = 0, my_zero = 0;
     u64 my_depth = 0;
     const bool one_contig = (s_c0 == s_c1);
-#ifdef PP_EXP_NO_VOTE
-    for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) { if (w0 + p < A.G) A.code[w0 + p] = ((const u8 *)asm_w)[ASM_PAD + p] + (u8)cnt[ROW_COV * TILE + p]; }
-    for (u32 p = TILE; p < (u32)TILE; p += TILE_THREADS) {
-#else
     for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
-#endif
         const u64 gp = w0 + p;
         if (gp >= A.G) break;
         if (A.own) {  // window tiling: halo positions are voted by the rank that owns them

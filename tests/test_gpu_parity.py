@@ -229,6 +229,24 @@ def test_filter_then_polish_parity(ctx, orc, tmp_path, case):
     assert ctx.polish_files(ds["fasta"], [g1, g2]) == orc.polish_files(ds["fasta"], [o1, o2])["fasta"]
 
 
+@pytest.mark.parametrize("case", FILE_CASES[1:3], ids=["seed32", "seed33"])
+def test_fused_filter_polish_equals_the_two_commands(ctx, orc, tmp_path, case):
+    """pp_filter_polish_files / `polypolish filter-polish`: the verdicts reach the polish ingest in memory;
+    FASTA and (optional) tagged SAMs are byte-identical to the oracle's filter followed by its polish."""
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    o1, o2, g1, g2 = (str(tmp_path / n) for n in ("o1.sam", "o2.sam", "g1.sam", "g2.sam"))
+    want_rep = orc.filter_files(ds["sam1"], ds["sam2"], o1, o2)
+    want = orc.polish_files(ds["fasta"], [o1, o2])["fasta"]
+    got, rep = ctx.filter_polish_files(ds["fasta"], ds["sam1"], ds["sam2"])
+    assert got == want and rep == want_rep
+    got, rep = ctx.filter_polish_files(ds["fasta"], ds["sam1"], ds["sam2"], out1=g1, out2=g2, min_depth=3, careful=True)
+    assert got == orc.polish_files(ds["fasta"], [o1, o2], min_depth=3, careful=True)["fasta"]
+    assert open(g1, "rb").read() == open(o1, "rb").read() and open(g2, "rb").read() == open(o2, "rb").read()
+    r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "filter-polish", "--in1", ds["sam1"], "--in2", ds["sam2"],
+                        ds["fasta"]], capture_output=True)
+    assert r.returncode == 0 and r.stdout == want, r.stderr.decode()[-500:]
+
+
 def test_emit_ranges_match_oracle_slices(ctx, orc):
     """pp_polish_set_emit: every position is still voted with all alignments, but only [lo, hi) of each
     contig contributes bytes and statistics."""
