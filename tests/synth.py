@@ -368,3 +368,19 @@ def oracle_engine(orc):
             offs.append(offs[-1] + z - a)
         return {"polished": b"".join(out), "offsets": np.array(offs, dtype=np.uint64)}
     return engine
+
+
+def merge_records(a, b, seed=0):
+    """Two record sets over the same assembly -> one, in a shuffled (read) order."""
+    n_a, n_b = len(a["contig"]), len(b["contig"])
+    out = {}
+    for k in ("contig", "ref_start", "k", "seq_len", "n_cig"):
+        out[k] = np.concatenate([a[k], b[k]])
+    out["seq_off"] = np.concatenate([a["seq_off"], b["seq_off"] + np.uint64(len(a["seq"]))])
+    out["cig_off"] = np.concatenate([a["cig_off"], b["cig_off"] + np.uint64(len(a["cigar"]))])
+    out["seq"] = np.concatenate([a["seq"], b["seq"]])
+    out["cigar"] = np.concatenate([a["cigar"], b["cigar"]])
+    order = np.random.default_rng(seed).permutation(n_a + n_b)
+    for k in ("contig", "ref_start", "k", "seq_len", "n_cig", "seq_off", "cig_off"):
+        out[k] = out[k][order]
+    return out

@@ -77,6 +77,28 @@ def test_polish_records_parity(ctx, orc, name):
     _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_valid=0.6, fraction_invalid=0.05)
 
 
+@pytest.mark.parametrize("read_len", [12, 31, 33, 160, 161, 192, 193, 250, 252, 253])
+def test_read_lengths_across_the_lane_group_widths(ctx, orc, read_len):
+    """k_tile sizes its lane groups from the longest fast-class read of the job: 5 lanes x 32 B up to 160
+    bases, 6 up to 192, 8 up to 252; longer reads take the slow class.  Every boundary, with a few indels,
+    Ns and non-dyadic shares in the mix."""
+    contig_off, bases, recs = synth.fast_records(seed=100 + read_len, contig_lens=(12_000, 2_300), coverage=40,
+                                                 read_len=read_len, indel_read_frac=0.05, n_rate=0.003,
+                                                 k_choices=(1, 1, 1, 2, 3))
+    _compare_records(ctx, orc, contig_off, bases, recs)
+
+
+def test_mixed_read_lengths_in_one_job(ctx, orc):
+    """The longest read picks the group width for everyone: 150-base and 250-base reads together (8 lanes),
+    and 150 + 180 (6 lanes)."""
+    for other in (250, 180):
+        kw = dict(seed=77, contig_lens=(15_000, 3_000), coverage=25, indel_read_frac=0.05, k_choices=(1, 1, 3))
+        contig_off, bases, ra = synth.fast_records(read_len=150, **kw)
+        contig_off2, bases2, rb = synth.fast_records(read_len=other, **kw)
+        assert np.array_equal(bases, bases2)
+        _compare_records(ctx, orc, contig_off, bases, synth.merge_records(ra, rb, seed=other))
+
+
 def test_deep_pileup_on_one_window(ctx, orc):
     # 20,000x on a 3 kbp contig: a single window bucket of ~60k work items
     contig_off, bases, recs = synth.fast_records(seed=21, contig_lens=(3_000,), coverage=20_000, read_len=150,
