@@ -10,11 +10,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $BENCH > /dev/null 2> "$OUT/fetch.log"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- $BENCH > /dev/null 2> "$OUT/write.log"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python $ROOT/tools/pmc_calib.py > /dev/null 2>> "$OUT/fetch.log"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python $ROOT/tools/pmc_calib.py > /dev/null 2>> "$OUT/write.log"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $BENCH > /dev/null 2> "$OUT/fetch.log"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- $BENCH > /dev/null 2> "$OUT/write.log"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python $ROOT/tools/pmc_calib.py > /dev/null 2>> "$OUT/fetch.log"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python $ROOT/tools/pmc_calib.py > /dev/null 2>> "$OUT/write.log"
 cd "$ROOT"
 python tools/prof_summary.py /tmp/p_trace /tmp/p_fetch /tmp/p_write /tmp/c_fetch /tmp/c_write > "$OUT/rocprofv3_summary.txt"
 python tools/prof_summary.py --traffic-json "$OUT/traffic.json" --bench /tmp/p_fetch /tmp/p_write --calib /tmp/c_fetch /tmp/c_write
