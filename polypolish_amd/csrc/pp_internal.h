@@ -17,6 +17,7 @@ namespace pp {
 // ---- geometry of the pileup tile kernel ----------------------------------------------------
 constexpr int TILE = 2048;           // assembly positions owned by one workgroup ("window")
 constexpr int TILE_THREADS = 1024;   // 16 waves; two workgroups per CU (57 KiB LDS each)
+constexpr int COARSE_WINDOWS = 8;     // windows per coarse bucket of the two-level multisplit
 constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the bucketing kernels
 constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
@@ -93,7 +94,7 @@ struct pp_ctx {
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
     pp::DevBuf b_in[9];  // uploaded batch arrays
-    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA;
+    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slabs, b_ents, b_keys, b_own;
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything

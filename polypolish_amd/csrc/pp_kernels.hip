@@ -234,13 +234,22 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
 // =============================================================================================
 // bucketing: count -> scan -> fill (no global atomics; LDS histograms per block and window range)
 // =============================================================================================
+// Two-level multisplit of the (alignment, window) items.  Level 1 scatters the items into COARSE buckets of
+// COARSE_WINDOWS windows: a block's items for one coarse bucket form one contiguous run (full-line writes),
+// where a direct scatter into the windows would be 16-byte writes all over HBM.  Level 2 (k_regroup) sorts a
+// coarse bucket into its windows inside a region small enough to stay in L2.
+//   k_count     per-block LDS histogram over the windows -> global per-window counts (atomics) and the
+//               block's per-coarse-bucket counts
+//   k_scan_cols column scan over the blocks of the coarse counts; k_scan: offsets of coarse buckets and windows
+//   k_fill      items -> coarse buckets (LDS cursors);  k_regroup  coarse bucket -> windows
+template <int CW>  // windows per coarse bucket; 1 = single level (k_fill writes the windows directly)
 __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__restrict__ gstart,
-                                                const u32 *__restrict__ nkeep, u32 nwin,
-                                                u32 *__restrict__ hist) {
+                                                const u32 *__restrict__ nkeep, u32 nwin, u32 ncoarse,
+                                                u32 *__restrict__ hist_c, u32 *__restrict__ win_cnt) {
     __shared__ u32 h[COUNT_RANGE];
     u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
     u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
-    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x) h[i] = 0;
+    for (u32 i = threadIdx.x; i < (u32)COUNT_RANGE; i += blockDim.x) h[i] = 0;
     __syncthreads();
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
@@ -260,14 +269,21 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
         }
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
-        hist[(u64)blockIdx.x * nwin + range_lo + i] = h[i];
+    if (CW > 1) {  // the windows' own totals are needed as well (k_scan_cols only sees the coarse buckets)
+        for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
+            if (h[i]) atomicAdd(&win_cnt[range_lo + i], h[i]);
+    }
+    const u32 c_lo = range_lo / (u32)CW, c_n = (range_n + CW - 1u) / (u32)CW;
+    for (u32 c = threadIdx.x; c < c_n; c += blockDim.x) {
+        u32 sum = 0;
+#pragma unroll
+        for (int j = 0; j < CW; j++) sum += h[c * CW + j];  // rows past range_n are zero
+        hist_c[(u64)blockIdx.x * ncoarse + c_lo + c] = sum;
+    }
 }
 
-// per window: exclusive scan of the per-block counts down the column (one wave per window, eight
-// blocks per lane: nblocks <= 512), total to win_cnt
 __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
-                                                   u32 *__restrict__ win_cnt, u64 *status) {
+                                                   u32 *__restrict__ win_cnt) {
     const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= nwin) return;
     u32 v[8];
@@ -290,10 +306,7 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
         if (b < nblocks) hist[(u64)b * nwin + w] = run;
         run += v[i];
     }
-    if (lane == 63) {
-        if (inc >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
-        win_cnt[w] = inc;
-    }
+    if (lane == 63) win_cnt[w] = inc;
 }
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
@@ -333,21 +346,24 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
     }
 }
 
+template <int CW>
 __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
                                                const u32 *__restrict__ nkeep,
                                                const u32 *__restrict__ kk,
                                                const u64 *__restrict__ seq_off,
-                                               const u32 *__restrict__ seq_len, u32 nwin,
-                                               const u32 *__restrict__ hist,
-                                               const u32 *__restrict__ win_off,
-                                               uint4 *__restrict__ entA, u64 *__restrict__ status) {
-    __shared__ u32 cur[COUNT_RANGE];
+                                               const u32 *__restrict__ seq_len, u32 nwin, u32 ncoarse,
+                                               const u32 *__restrict__ hist_c,
+                                               const u32 *__restrict__ coarse_off,
+                                               uint4 *__restrict__ entB, u64 *__restrict__ status) {
+    __shared__ u32 cur[COUNT_RANGE];  // cursors of the coarse buckets of this pass
     if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
-    u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
-    u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
-    for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
-        cur[i] = win_off[range_lo + i] + hist[(u64)blockIdx.x * nwin + range_lo + i];
+    const u32 crange_lo = blockIdx.y * (u32)COUNT_RANGE;
+    const u32 crange_n = min((u32)COUNT_RANGE, ncoarse - crange_lo);
+    for (u32 i = threadIdx.x; i < crange_n; i += blockDim.x)
+        cur[i] = coarse_off[crange_lo + i] + hist_c[(u64)blockIdx.x * ncoarse + crange_lo + i];
     __syncthreads();
+    const u32 range_lo = crange_lo * (u32)CW;                       // the same range, in windows
+    const u32 range_n = min(crange_n * (u32)CW, nwin - range_lo);
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
         u32 nk4[4], g4[4], k4[4], fl4[4];
@@ -380,18 +396,58 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
             const u32 kc = kclass_of(k4[u]);
             const u32 fl = fl4[u];
             for (u32 w = wa; w <= wb && w >= wa; w++) {
-                u32 slot = atomicAdd(&cur[w - range_lo], 1u);
-                // work item, 16 bytes:
+                u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
+                // work item, 16 bytes (bits 20..22 of y carry the window's index inside its coarse bucket until
+                // k_regroup has used it):
                 //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
                 //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
                 //   z  global start of the read minus the window start (signed)      w  record index (file order)
                 uint4 e;
                 e.x = fl ? nk : (u32)so;
-                e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16);
+                e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16) |
+                      ((w % (u32)CW) << 20);
                 e.z = (u32)(int)((long long)g - (long long)w * TILE);
                 e.w = (u32)a;
-                entA[slot] = e;
+                entB[slot] = e;
             }
+        }
+    }
+}
+
+// Level 2 of the multisplit: one workgroup per coarse bucket moves its items into their windows.  The
+// destination region (COARSE_WINDOWS windows) is small, so the 16-byte writes merge into full lines in L2.
+// Cursors are advanced once per wave and window (ballot + popcount), not once per item.
+__global__ __launch_bounds__(1024) void k_regroup(u32 nwin, const u32 *__restrict__ coarse_off,
+                                                  const u32 *__restrict__ win_off, const uint4 *__restrict__ entB,
+                                                  uint4 *__restrict__ entA, u64 *__restrict__ status) {
+    __shared__ u32 cur[COARSE_WINDOWS];
+    if (*status != ~0ull) return;
+    const u32 c = blockIdx.x, lane = threadIdx.x & 63u;
+    if (threadIdx.x < (u32)COARSE_WINDOWS) {
+        const u32 w = c * (u32)COARSE_WINDOWS + threadIdx.x;
+        cur[threadIdx.x] = w < nwin ? win_off[w] : 0u;
+        if (w < nwin && win_off[w + 1] - win_off[w] >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+    }
+    __syncthreads();
+    const u32 lo = coarse_off[c], hi = coarse_off[c + 1];
+    for (u32 i0 = lo + (threadIdx.x & ~63u); i0 < hi; i0 += blockDim.x) {
+        const u32 i = i0 + lane;
+        const bool valid = i < hi;
+        uint4 e = valid ? entB[i] : make_uint4(0, 0, 0, 0);
+        const u32 sub = (e.y >> 20) & 7u;
+        u32 slot = 0;
+#pragma unroll
+        for (u32 t = 0; t < (u32)COARSE_WINDOWS; t++) {
+            const u64 m = __ballot(valid && sub == t);
+            if (!m) continue;
+            u32 base = 0;
+            if (lane == (u32)__ffsll((long long)m) - 1u) base = atomicAdd(&cur[t], (u32)__popcll(m));
+            base = (u32)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+            if (valid && sub == t) slot = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (valid) {
+            e.y &= ~(7u << 20);
+            entA[slot] = e;
         }
     }
 }
@@ -1744,7 +1800,18 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;  // word 8: debug key records
     ENS(b_meta, meta_words * 8);
     ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
-    ENS(b_hist, (uint64_t)NB * nwin * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+    // One level (items straight into their windows) while all windows fit one LDS pass of k_fill; two levels
+    // (coarse buckets of COARSE_WINDOWS windows, then k_regroup) beyond that: there the single-level k_fill
+    // would re-read its records once per range of 16384 windows.  Measured on MI355X: 5 Mbp: one level 0.19 ms
+    // vs two 0.21 ms (+ k_tile 4 % slower on the regrouped order); 250 Mbp: one level 6.8 ms vs two 4.1 ms.
+    static const int forced_levels = getenv("PP_BUCKET_LEVELS") ? atoi(getenv("PP_BUCKET_LEVELS")) : 0;  // tuning / tests
+    const bool two_level = forced_levels ? forced_levels == 2 : nranges > 1;
+    const uint32_t cw = two_level ? COARSE_WINDOWS : 1;
+    const uint32_t ncoarse = (nwin + cw - 1) / cw;
+    const uint32_t ncranges = (ncoarse + COUNT_RANGE - 1) / COUNT_RANGE;
+    ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+    ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
+    if (two_level) ENS(b_entB, ctx->cap_ent * 16);
     ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
@@ -1765,7 +1832,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
     u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
     const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
-    uint4 *d_entA = (uint4 *)ctx->b_entA.p;
+    uint4 *d_entA = (uint4 *)ctx->b_entA.p, *d_entB = (uint4 *)ctx->b_entB.p;
+    u32 *d_ccnt = (u32 *)ctx->b_ccnt.p, *d_coff = (u32 *)ctx->b_coff.p;
 
     if (n) {
         timer_begin(ctx, "prep");
@@ -1775,14 +1843,33 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         timer_end(ctx);
     }
     timer_begin(ctx, "bucket");
-    hipLaunchKernelGGL(k_count, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin, d_hist);
-    hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, d_status);
-    hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
-                       d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
-    if (n)
-        hipLaunchKernelGGL(k_fill, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
-                           B.k, (const u64 *)B.seq_off, B.seq_len, nwin, (const u32 *)d_hist, (const u32 *)d_winoff,
-                           d_entA, d_status);
+    if (two_level) {
+        PP_HIPCHK(ctx, hipMemsetAsync(d_wincnt, 0, (size_t)nwin * 4, st));
+        hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                           d_nkeep, nwin, ncoarse, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
+                           d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
+                           d_winoff, (u64 *)nullptr, ~0ull, d_status);
+        if (n) {
+            hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                               d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
+                               (const u32 *)d_coff, d_entB, d_status);
+            hipLaunchKernelGGL(k_regroup, dim3(ncoarse), dim3(1024), 0, st, nwin, (const u32 *)d_coff,
+                               (const u32 *)d_winoff, (const uint4 *)d_entB, d_entA, d_status);
+        }
+    } else {
+        hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
+                           nwin, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
+                           d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
+        if (n)
+            hipLaunchKernelGGL(k_fill<1>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
+                               B.k, (const u64 *)B.seq_off, B.seq_len, nwin, nwin, (const u32 *)d_hist,
+                               (const u32 *)d_winoff, d_entA, d_status);
+    }
     timer_end(ctx);
 
     TileArgs T;
@@ -2089,7 +2176,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
-                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA,
+                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,

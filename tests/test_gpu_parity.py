@@ -99,6 +99,30 @@ def test_mixed_read_lengths_in_one_job(ctx, orc):
         _compare_records(ctx, orc, contig_off, bases, synth.merge_records(ra, rb, seed=other))
 
 
+def test_two_level_bucketing_path(orc, tmp_path):
+    """Assemblies beyond 16384 windows (33.5 Mbp per GPU) bucket their work items in two levels (coarse
+    buckets, then k_regroup).  PP_BUCKET_LEVELS=2 forces that path on small jobs: same bytes, same stats."""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, synth, polypolish_amd as pp
+from oracle import orc
+ctx = pp.Context(0)
+for kw in (dict(seed=2, contig_lens=(40_000, 7_000), coverage=80, indel_read_frac=0.2, n_rate=0.003),
+           dict(seed=4, contig_lens=(30_000, 2_500), coverage=50, k_choices=(1, 2, 3, 5, 6, 7), indel_read_frac=0.05),
+           dict(seed=7, contig_lens=(300, 2048, 2049, 500, 4096, 1000), coverage=40, read_len=100, indel_read_frac=0.05)):
+    o, b, r = synth.fast_records(**kw)
+    want = orc.polish_records(o, b, r, positions=True)
+    got = ctx.polish_records(o, b, r, positions=True)
+    assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"])
+    for k in ("depth", "count_a", "count_c", "count_g", "count_t", "count_other", "status"):
+        assert np.array_equal(got["positions"][k], want["positions"][k]), k
+print("two-level ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ, PP_BUCKET_LEVELS="2"), timeout=600)
+    assert r.returncode == 0 and b"two-level ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
 def test_deep_pileup_on_one_window(ctx, orc):
     # 20,000x on a 3 kbp contig: a single window bucket of ~60k work items
     contig_off, bases, recs = synth.fast_records(seed=21, contig_lens=(3_000,), coverage=20_000, read_len=150,
