@@ -65,6 +65,8 @@ void pp_ctx_destroy(pp_ctx *ctx);
 const char *pp_last_error(const pp_ctx *ctx);
 int pp_ctx_sync(pp_ctx *ctx);          /* hipStreamSynchronize on the context's stream          */
 void *pp_ctx_stream(pp_ctx *ctx);      /* the hipStream_t every kernel of this context runs on  */
+/* device -> host copy on the context's stream, synchronous (for bindings that have no HIP of their own) */
+int pp_ctx_download(pp_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 const char *pp_version(void);          /* "polypolish-mi355x <ver> (parity target v0.6.1)"       */
 
 /* ---- seam B: pileup accumulate + per-position vote ------------------------------------------ */
@@ -296,6 +298,17 @@ void pp_bytes_free(pp_bytes *b);
 /* polish::polish (src/polish.rs:26-38): FASTA text exactly as the reference prints to stdout. */
 int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                     const pp_polish_options *opt, pp_bytes *fasta);
+
+/* The same ingest on the DEVICE: the raw SAM text is uploaded and tokenized by kernels
+ * (newline index, field split, number / CIGAR / tag validation, contig lookup, read groups, gates, 1/k,
+ * "*" fill, upper-casing, CIGAR packing).  The batch is bit-identical to pp_ingest_sam's and lives in HBM:
+ * hand it to pp_polish_add with PP_MEM_DEVICE and keep the object alive until pp_polish_finish.  Errors
+ * (same codes and messages as the host ingest) are reported through pp_last_error(ctx). */
+typedef struct pp_dev_ingest pp_dev_ingest;
+int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t max_errors, int careful, pp_dev_ingest **out);
+int pp_dev_ingest_sam(pp_dev_ingest *g, const char *path, pp_sam_counts *counts);
+void pp_dev_ingest_batch(const pp_dev_ingest *g, pp_aln_batch *out); /* borrowed view, DEVICE memory */
+void pp_dev_ingest_free(pp_dev_ingest *g);
 
 typedef struct {
     uint64_t before_count, after_count;

@@ -100,7 +100,7 @@ class FilterFileCounts(C.Structure):
 
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
-    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_version",
+    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
@@ -110,6 +110,7 @@ EXPORTS = [
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
     "pp_bytes_free", "pp_polish_files", "pp_filter_files", "pp_filter_polish_files", "pp_ingest_sam_filtered",
+    "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_batch", "pp_dev_ingest_free",
 ]
 
 _lib = None
@@ -132,6 +133,7 @@ def lib():
         L.pp_last_error.argtypes = [vp]
         L.pp_last_error.restype = C.c_char_p
         L.pp_ctx_sync.argtypes = [vp]
+        L.pp_ctx_download.argtypes = [vp, vp, vp, C.c_uint64]
         L.pp_ctx_stream.argtypes = [vp]
         L.pp_ctx_stream.restype = vp
         L.pp_version.restype = C.c_char_p
@@ -187,6 +189,12 @@ def lib():
                                                                 C.POINTER(FilterReport)]
         L.pp_filter_polish_files.argtypes = [vp] + [C.c_char_p] * 6 + [C.c_double, C.c_double, C.POINTER(PolishOptions),
                                                                        C.POINTER(FilterReport), C.POINTER(Bytes)]
+        L.pp_dev_ingest_create.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
+        L.pp_dev_ingest_sam.argtypes = [vp, C.c_char_p, C.POINTER(SamCounts)]
+        L.pp_dev_ingest_batch.argtypes = [vp, C.POINTER(AlnBatch)]
+        L.pp_dev_ingest_batch.restype = None
+        L.pp_dev_ingest_free.argtypes = [vp]
+        L.pp_dev_ingest_free.restype = None
         L.pp_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts), C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
@@ -236,6 +244,45 @@ def ingest(assembly, sams, max_errors=10, careful=False):
     finally:
         if g:
             L.pp_ingest_free(g)
+        L.pp_assembly_free(a)
+
+
+def ingest_device(ctx, assembly, sams, max_errors=10, careful=False):
+    """The device tokenizer (pp_dev_ingest_*): same return value as ingest(), the records copied back from HBM."""
+    L = lib()
+    err = C.create_string_buffer(1024)
+    a = C.c_void_p()
+    rc = L.pp_assembly_load(str(assembly).encode(), C.byref(a), err, 1024)
+    if rc:
+        raise PolypolishError(rc, err.value.decode())
+    g = C.c_void_p()
+    try:
+        n = L.pp_assembly_n_contigs(a)
+        names = [L.pp_assembly_name(a, i).decode() for i in range(n)]
+        descs = [L.pp_assembly_description(a, i).decode() for i in range(n)]
+        off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,)).copy()
+        bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),)).copy()
+        ctx._chk(L.pp_dev_ingest_create(ctx._h, a, max_errors, int(careful), C.byref(g)))
+        counts = []
+        for s in sams:
+            c = SamCounts()
+            ctx._chk(L.pp_dev_ingest_sam(g, str(s).encode(), C.byref(c)))
+            counts.append((c.alignments, c.used, c.reads))
+        b = AlnBatch()
+        L.pp_dev_ingest_batch(g, C.byref(b))
+        sizes = {"seq": b.seq_bytes, "cigar": b.n_cig_total}
+        recs = {}
+        for name, dt in REC_FIELDS:
+            cnt = int(sizes.get(name, b.n_aln))
+            ptr = getattr(b, name)
+            arr = np.zeros(cnt, dtype=dt)
+            if cnt and ptr:
+                ctx._chk(L.pp_ctx_download(ctx._h, arr.ctypes.data, ptr, arr.nbytes))
+            recs[name] = arr
+        return names, descs, off, bases, recs, counts
+    finally:
+        if g:
+            L.pp_dev_ingest_free(g)
         L.pp_assembly_free(a)
 
 

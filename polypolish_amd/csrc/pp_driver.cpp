@@ -219,22 +219,32 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     log("\n");
 
     lap("assembly loaded");
-    // load_alignments, polish.rs:109-134
+    // load_alignments, polish.rs:109-134 -- on the host (multi-threaded parse), or with PP_DEVICE_INGEST=1 by the
+    // device tokenizer (pp_tokenize.hip; not with --debug, whose TSV needs the read bytes on the host)
     log("Loading alignments\n");
+    const bool dev_ingest = getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) && !opt->debug_path && !pass;
     pp_ingest *g = nullptr;
-    rc = pp_ingest_create(a, opt->max_errors, opt->careful, &g);
+    pp_dev_ingest *dg = nullptr;
+    rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
+                    : pp_ingest_create(a, opt->max_errors, opt->careful, &g);
     uint64_t alignment_total = 0, used_total = 0;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;
-        rc = pass ? pp_ingest_sam_filtered(g, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
-                  : pp_ingest_sam(g, sams[i], &c, err, sizeof err);
-        if (rc) { set_err(ctx, rc, err); break; }
+        if (dev_ingest) {
+            rc = pp_dev_ingest_sam(dg, sams[i], &c);
+            if (rc) break;
+        } else {
+            rc = pass ? pp_ingest_sam_filtered(g, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
+                      : pp_ingest_sam(g, sams[i], &c, err, sizeof err);
+            if (rc) { set_err(ctx, rc, err); break; }
+        }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
         alignment_total += c.alignments;
         used_total += c.used;
     }
     if (rc) {
         pp_ingest_free(g);
+        pp_dev_ingest_free(dg);
         pp_assembly_free(a);
         return rc;
     }
@@ -247,7 +257,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     log("Polishing assembly sequences\n");
     pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
     pp_aln_batch batch;
-    pp_ingest_batch(g, &batch);
+    if (dev_ingest) pp_dev_ingest_batch(dg, &batch); else pp_ingest_batch(g, &batch);
     // create_debug_file, polish.rs:230-245: the file is created (and the header written) before polishing
     FILE *dbg = nullptr;
     if (opt->debug_path) {
@@ -255,6 +265,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
         if (!dbg) {
             snprintf(err, sizeof err, "unable to create \"%s\"", opt->debug_path);
             pp_ingest_free(g);
+            pp_dev_ingest_free(dg);
             pp_assembly_free(a);
             return set_err(ctx, PP_ERR_QUIT, err);
         }
@@ -262,7 +273,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     }
     pp_polish_set_debug(ctx, dbg ? 1 : 0);
     rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
-    if (rc == PP_OK) rc = pp_polish_add(ctx, &batch, PP_MEM_HOST);
+    if (rc == PP_OK) rc = pp_polish_add(ctx, &batch, dev_ingest ? PP_MEM_DEVICE : PP_MEM_HOST);
     if (rc == PP_OK) rc = pp_polish_finish(ctx);
     lap("uploaded + polished on device");
     if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
@@ -276,6 +287,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
     if (rc) {
         pp_ingest_free(g);
+        pp_dev_ingest_free(dg);
         pp_assembly_free(a);
         return rc;
     }
@@ -318,6 +330,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     log("\nTime to run: %s\n\n", format_duration(secs).c_str());
     pp_ingest_free(g);
+    pp_dev_ingest_free(dg);
     pp_assembly_free(a);
     return PP_OK;
 }

@@ -394,9 +394,25 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
     return pp_ingest_sam_filtered(I, path, nullptr, 0, counts, err, errlen);
 }
 
+static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, size_t ext_size, uint64_t line_base,
+                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen);
+
 extern "C" int pp_ingest_sam_filtered(pp_ingest *I, const char *path, const uint8_t *pass, uint64_t n_pass,
                                       pp_sam_counts *counts, char *err, size_t errlen) {
     if (!I || !path) return PP_ERR_ARG;
+    return ingest_impl(I, path, nullptr, 0, 0, pass, n_pass, counts, err, errlen);
+}
+
+// Internal (the device tokenizer's error path): the same ingest over a slice of text already in memory;
+// line numbers in messages start at line_base + 1.
+extern "C" int pp_ingest_text_(pp_ingest *I, const char *path, const char *text, size_t size, uint64_t line_base,
+                               pp_sam_counts *counts, char *err, size_t errlen) {
+    if (!I || !path || !text) return PP_ERR_ARG;
+    return ingest_impl(I, path, text, size, line_base, nullptr, 0, counts, err, errlen);
+}
+
+static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, size_t ext_size, uint64_t line_base,
+                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen) {
     pp_sam_counts c{0, 0, 0};
     int fd = -1;
     void *map = nullptr;
@@ -407,13 +423,14 @@ extern "C" int pp_ingest_sam_filtered(pp_ingest *I, const char *path, const uint
         if (fd >= 0) close(fd);
     };
     try {
-        fd = open(path, O_RDONLY);
-        if (fd < 0) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+        const char *text = ext_text;
+        size_t size = ext_size;
         struct stat st;
-        if (fstat(fd, &st) != 0) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
-        const char *text = nullptr;
-        size_t size = 0;
-        if (S_ISREG(st.st_mode) && st.st_size > 0) {
+        if (ext_text) {
+            // the caller's memory
+        } else if ((fd = open(path, O_RDONLY)) < 0 || fstat(fd, &st) != 0) {
+            fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+        } else if (S_ISREG(st.st_mode) && st.st_size > 0) {
             map_len = (size_t)st.st_size;
             map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
             if (map == MAP_FAILED) { map = nullptr; fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path); }
@@ -567,7 +584,7 @@ extern "C" int pp_ingest_sam_filtered(pp_ingest *I, const char *path, const uint
         }
         if (parse_failed) {  // the streaming loop would have stopped at the failing line
             const Chunk &ch = chunks[n_chunks_ok];
-            uint64_t line_no = ch.n_lines;
+            uint64_t line_no = line_base + ch.n_lines;
             for (size_t u = 0; u < n_chunks_ok; u++) line_no += chunks[u].n_lines;
             if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
             fail(ch.err_code, "%s", ch.err_what.c_str());

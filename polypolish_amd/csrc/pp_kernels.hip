@@ -2202,5 +2202,14 @@ extern "C" int pp_ctx_sync(pp_ctx *ctx) {
     PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PP_OK;
 }
+extern "C" int pp_ctx_download(pp_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    if (!bytes) return PP_OK;
+    PP_HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
 extern "C" void *pp_ctx_stream(pp_ctx *ctx) { return ctx && pp_ctx_wait(ctx) == PP_OK ? (void *)ctx->stream : nullptr; }
 extern "C" const char *pp_version(void) { return "polypolish-mi355x 0.1.0 (parity target v0.6.1)"; }

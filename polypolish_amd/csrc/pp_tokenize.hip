@@ -1,0 +1,685 @@
+// pp_tokenize.hip -- SAM text -> pp_aln_batch on the device: the polish ingest without the
+// host parse.  The raw text is uploaded once; newline index, field split, number/CIGAR/tag validation,
+// contig lookup, read grouping, the gates of process_one_read, the 1/k share, "*" fill (+ reverse
+// complement), upper-casing and CIGAR packing all run as kernels, and the batch stays in HBM for
+// pp_polish_add(PP_MEM_DEVICE).
+//
+// Semantics are those of pp_ingest.cpp (the host ingest), which mirrors
+//   Alignment::new               src/alignment.rs:49-98   (+ get_expanded_cigar :325-346)
+//   add_to_pileup (grouping)     src/alignment.rs:225-272
+//   process_one_read             src/alignment.rs:275-322
+// and the result is bit-identical to it (tests compare the two batches array by array).  The device only
+// has to DECIDE whether a line or a read group is in error and which event comes first in the reference's
+// streaming order; the message itself is produced by running the host ingest on the offending lines.
+//   event key = 2 * line          a line that fails to parse
+//               2 * line + 1      a read group that fails when it is flushed, i.e. when `line` -- the first
+//                                 record of the next group -- has been parsed (EOF: line = number of lines)
+#include "pp_internal.h"
+#include "pp_host.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" int pp_ingest_text_(pp_ingest *I, const char *path, const char *text, size_t size, uint64_t line_base,
+                               pp_sam_counts *counts, char *err, size_t errlen);
+
+namespace {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+constexpr u32 NL_BLOCK = 1024 * 64;  // bytes of text per block of the newline kernels (64 per thread)
+enum { K_SKIP = 0, K_UNALIGNED = 1, K_ALIGNED = 2 };
+
+struct LineRec {          // one parsed line (offsets relative to the start of the line)
+    u32 flag, contig, ref_start, nm;
+    u32 name_len, cig_off, cig_len, n_runs;
+    u32 seq_off, seq_len, bits, pad;  // bits: first op | last op << 4 | pass_qc << 8 | start beyond u32 << 9
+};
+
+__device__ __forceinline__ void report(u64 *status, u64 key) { atomicMin(status, key); }
+
+// ---- newline index -------------------------------------------------------------------------------
+__device__ __forceinline__ u32 count_nl16(uint4 v) {
+    u32 n = 0;
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32 x = w[i] ^ 0x0A0A0A0Au;  // zero bytes where the text has '\n'
+        n += (u32)__popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
+    }
+    return n;
+}
+
+// text is padded with zeros up to a multiple of NL_BLOCK
+__global__ __launch_bounds__(1024) void k_nl_count(const u8 *__restrict__ text, u32 *__restrict__ blk_cnt) {
+    __shared__ u32 s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const uint4 *p = (const uint4 *)(text + (u64)blockIdx.x * NL_BLOCK + (u64)threadIdx.x * 64u);
+    const u32 n = count_nl16(p[0]) + count_nl16(p[1]) + count_nl16(p[2]) + count_nl16(p[3]);
+    u32 v = n;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_sum;
+}
+
+__global__ __launch_bounds__(1024) void k_nl_write(const u8 *__restrict__ text, const u64 *__restrict__ blk_off,
+                                                   u64 *__restrict__ nl_pos) {
+    __shared__ u32 s_w[16];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * NL_BLOCK + (u64)threadIdx.x * 64u;
+    const uint4 *p = (const uint4 *)(text + base);
+    const u32 n = count_nl16(p[0]) + count_nl16(p[1]) + count_nl16(p[2]) + count_nl16(p[3]);
+    u32 inc = n;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    u32 before = inc - n;
+    for (u32 i = 0; i < wave; i++) before += s_w[i];
+    if (!n) return;
+    u64 out = blk_off[blockIdx.x] + before;
+    for (u32 i = 0; i < 64; i++)
+        if (text[base + i] == (u8)'\n') nl_pos[out++] = base + i;
+}
+
+// ---- single-block exclusive scan: u32 in -> T out (n + 1 entries), as pp_kernels.hip's ------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_tscan(const u32 *__restrict__ in, u64 n, T *__restrict__ out) {
+    __shared__ u64 part[1024];
+    const u32 t = threadIdx.x;
+    const u64 per = (n + 1023) / 1024;
+    const u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
+    u64 s = 0;
+    for (u64 i = lo; i < hi; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        const u64 v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u64 run = part[t] - s;
+    for (u64 i = lo; i < hi; i++) {
+        out[i] = (T)run;
+        run += in[i];
+    }
+    if (t == 1023) out[n] = (T)part[1023];
+}
+
+// ---- per-line parse (Alignment::new) ---------------------------------------------------------------
+__device__ __forceinline__ bool parse_u(const u8 *s, u32 n, u64 max, u64 &out) {  // str::parse::<uN>()
+    u32 i = 0;
+    if (n == 0) return false;
+    if (s[0] == (u8)'+') { i = 1; if (n == 1) return false; }
+    u64 v = 0;
+    for (; i < n; i++) {
+        if (s[i] < (u8)'0' || s[i] > (u8)'9') return false;
+        const u64 d = (u64)(s[i] - (u8)'0');
+        if (v > (max - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+
+__device__ __forceinline__ int op_code(u8 c) {
+    switch (c) {
+    case 'M': return PP_OP_M; case 'I': return PP_OP_I; case 'D': return PP_OP_D; case 'N': return PP_OP_N;
+    case 'S': return PP_OP_S; case 'H': return PP_OP_H; case 'P': return PP_OP_P; case '=': return PP_OP_EQ;
+    case 'X': return PP_OP_X; default: return -1;
+    }
+}
+
+__device__ __forceinline__ u32 fnv1a(const u8 *s, u32 n) {
+    u32 h = 2166136261u;
+    for (u32 i = 0; i < n; i++) h = (h ^ s[i]) * 16777619u;
+    return h;
+}
+
+struct ContigTable {      // RNAME -> contig index: open addressing over the assembly's names
+    const u32 *slots;     // contig index + 1, 0 = empty
+    const u32 *name_off;  // n_contigs + 1
+    const u8 *names;
+    u32 mask;
+};
+
+__device__ __forceinline__ int lookup_contig(const ContigTable &T, const u8 *s, u32 n) {
+    u32 i = fnv1a(s, n) & T.mask;
+    for (;;) {
+        const u32 v = T.slots[i];
+        if (!v) return -1;
+        const u32 o = T.name_off[v - 1], l = T.name_off[v] - o;
+        if (l == n) {
+            u32 j = 0;
+            while (j < n && T.names[o + j] == s[j]) j++;
+            if (j == n) return (int)(v - 1);
+        }
+        i = (i + 1) & T.mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tok_parse(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
+                                                   u64 n_nl, u64 n_lines, ContigTable T, LineRec *__restrict__ rec,
+                                                   u32 *__restrict__ is_aln, u64 *__restrict__ status) {
+    const u64 li = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lines) return;
+    const u64 ls = li ? nl_pos[li - 1] + 1 : 0, le = li < n_nl ? nl_pos[li] : size;
+    u32 n = (u32)(le - ls);
+    const u8 *L = text + ls;
+    if (n > 0 && L[n - 1] == (u8)'\r') n--;
+    is_aln[li] = 0;
+    if (n == 0 || L[0] == (u8)'@') return;  // alignment.rs:241
+    u32 cs[11], cl[11], nc = 0, q = 0;
+    while (nc < 11) {
+        u32 t = q;
+        while (t < n && L[t] != (u8)'\t') t++;
+        cs[nc] = q;
+        cl[nc] = t - q;
+        nc++;
+        if (t >= n) { q = n + 1; break; }
+        q = t + 1;
+    }
+    if (nc < 11) { report(status, 2 * li); return; }  // too few columns
+    u64 flags, pos;
+    if (!parse_u(L + cs[1], cl[1], 0xFFFFFFFFull, flags) || !parse_u(L + cs[3], cl[3], ~0ull, pos)) { report(status, 2 * li); return; }
+    if (pos > 0) pos -= 1;
+    u32 nm = 0xFFFFFFFFu, pass_qc = 1;
+    u32 tg = q;  // start of the tag fields; q == n means one empty field after a trailing tab; n + 1: none
+    while (tg <= n) {
+        u32 t = tg;
+        while (t < n && L[t] != (u8)'\t') t++;
+        const u32 tl = t - tg;
+        const u8 *f = L + tg;
+        if (tl >= 5 && f[0] == 'N' && f[1] == 'M' && f[2] == ':' && f[3] == 'i' && f[4] == ':') {
+            u64 v;
+            if (!parse_u(f + 5, tl - 5, 0xFFFFFFFFull, v)) { report(status, 2 * li); return; }
+            nm = (u32)v;
+        }
+        if (tl == 9 && (f[0] | 32) == 'z' && (f[1] | 32) == 'p' && f[2] == ':' && (f[3] | 32) == 'z' && f[4] == ':' &&
+            (f[5] | 32) == 'f' && (f[6] | 32) == 'a' && (f[7] | 32) == 'i' && (f[8] | 32) == 'l')
+            pass_qc = 0;
+        if (t >= n) break;
+        tg = t + 1;
+    }
+    if (nm == 0xFFFFFFFFu && (flags & 4) == 0) { report(status, 2 * li); return; }  // missing NM tag
+    // get_expanded_cigar (alignment.rs:325-346), kept as runs: zero-length runs vanish, long runs split
+    const u8 *cg = L + cs[5];
+    const u32 cgl = cl[5];
+    u32 n_runs = 0, first_op = 15, last_op = 15;
+    if (!(cgl == 1 && cg[0] == (u8)'*')) {
+        u32 i = 0;
+        while (i < cgl) {
+            u32 j = i;
+            while (j < cgl && cg[j] >= (u8)'0' && cg[j] <= (u8)'9') j++;
+            const int op = j < cgl ? op_code(cg[j]) : -1;
+            u64 num;
+            if (j == i || op < 0 || !parse_u(cg + i, j - i, 0xFFFFFFFFull, num)) { report(status, 2 * li); return; }
+            while (num > 0) {
+                const u32 piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (u32)num;
+                if (!n_runs) first_op = (u32)op;
+                last_op = (u32)op;
+                n_runs++;
+                num -= piece;
+            }
+            i = j + 1;
+        }
+    }
+    if (flags & 4) return;  // parsed, then skipped (alignment.rs:250)
+    LineRec r;
+    r.flag = (u32)flags;
+    r.contig = (u32)lookup_contig(T, L + cs[2], cl[2]);
+    r.ref_start = (u32)pos;
+    r.nm = nm;
+    r.name_len = cl[0];
+    r.cig_off = cs[5];
+    r.cig_len = cgl;
+    r.n_runs = n_runs;
+    r.seq_off = cs[9];
+    r.seq_len = cl[9];
+    r.bits = first_op | (last_op << 4) | (pass_qc << 8) | ((pos > 0xFFFFFFFEull ? 1u : 0u) << 9);
+    r.pad = 0;
+    rec[li] = r;
+    is_aln[li] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_tok_compact(u64 n_lines, const u32 *__restrict__ is_aln,
+                                                     const u32 *__restrict__ rec_of_line, u32 *__restrict__ rec_line) {
+    const u64 li = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li < n_lines && is_aln[li]) rec_line[rec_of_line[li]] = (u32)li;
+}
+
+__device__ __forceinline__ u64 line_start(const u64 *nl_pos, u32 li) { return li ? nl_pos[li - 1] + 1 : 0; }
+
+// does record r open a new read group?  (alignment.rs:255: it joins when the previous QNAME is empty or equal)
+__global__ __launch_bounds__(256) void k_tok_group_start(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                         const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                         u32 n_aln, u32 *__restrict__ is_start) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln) return;
+    u32 start = 1;
+    if (r > 0) {
+        const u32 lp = rec_line[r - 1], lc = rec_line[r];
+        const u32 np = rec[lp].name_len, ncur = rec[lc].name_len;
+        if (np == 0) start = 0;
+        else if (np == ncur) {
+            const u8 *a = text + line_start(nl_pos, lp), *b = text + line_start(nl_pos, lc);
+            u32 j = 0;
+            while (j < np && a[j] == b[j]) j++;
+            if (j == np) start = 0;
+        }
+    }
+    is_start[r] = start;
+}
+
+__global__ __launch_bounds__(256) void k_tok_group_first(u32 n_aln, const u32 *__restrict__ is_start,
+                                                         const u32 *__restrict__ grp_of_rec, u32 n_groups,
+                                                         u32 *__restrict__ group_first) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_aln && is_start[r]) group_first[grp_of_rec[r]] = r;
+    if (r == 0) group_first[n_groups] = n_aln;
+}
+
+// process_one_read (alignment.rs:275-322), one lane per read group
+__global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                   const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                   const u32 *__restrict__ group_first, u32 n_groups, u64 n_lines,
+                                                   u32 max_errors, int careful, u32 *__restrict__ good,
+                                                   u32 *__restrict__ kk, u32 *__restrict__ src_rec,
+                                                   u32 *__restrict__ g_seq_len, u32 *__restrict__ g_ncig,
+                                                   u64 *__restrict__ status) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const u32 r0 = group_first[g], r1 = group_first[g + 1];
+    const u64 key = 2ull * (g + 1 < n_groups ? (u64)rec_line[r1] : n_lines) + 1ull;
+    for (u32 r = r0; r < r1; r++) { good[r] = 0; kk[r] = 0; src_rec[r] = r; g_seq_len[r] = 0; g_ncig[r] = 0; }
+    if (careful && r1 - r0 > 1) return;
+    u32 src = 0xFFFFFFFFu;
+    for (u32 r = r0; r < r1; r++) {
+        const LineRec &a = rec[rec_line[r]];
+        const bool star = a.seq_len == 1 && text[line_start(nl_pos, rec_line[r]) + a.seq_off] == (u8)'*';
+        if (!star) { src = r; break; }
+    }
+    if (src == 0xFFFFFFFFu) { report(status, key); return; }  // no alignment of the read contains sequence
+    u32 n_good = 0;
+    for (u32 r = r0; r < r1; r++) {
+        const LineRec &a = rec[rec_line[r]];
+        if (a.n_runs == 0) { report(status, key); return; }  // empty expanded CIGAR: the reference panics
+        const u32 f = a.bits & 15u, l = (a.bits >> 4) & 15u;
+        const bool ends_ok = (f == PP_OP_M || f == PP_OP_EQ) && (l == PP_OP_M || l == PP_OP_EQ);
+        if (ends_ok && a.nm <= max_errors && ((a.bits >> 8) & 1u)) { good[r] = 1; n_good++; }
+    }
+    const LineRec &s = rec[rec_line[src]];
+    for (u32 r = r0; r < r1; r++) {
+        if (!good[r]) continue;
+        const LineRec &a = rec[rec_line[r]];
+        if ((int)a.contig < 0 || ((a.bits >> 9) & 1u)) { report(status, key); return; }  // not in assembly / start beyond u32
+        const bool star = a.seq_len == 1 && text[line_start(nl_pos, rec_line[r]) + a.seq_off] == (u8)'*';
+        kk[r] = n_good;
+        src_rec[r] = star ? src : r;
+        g_seq_len[r] = star ? s.seq_len : a.seq_len;
+        g_ncig[r] = a.n_runs;
+    }
+}
+
+// ---- output: the structure of arrays of pp_aln_batch ----------------------------------------------
+struct OutArrays {
+    u32 *contig, *ref_start, *k, *seq_len, *n_cig, *cigar;
+    u64 *seq_off, *cig_off;
+    u8 *seq;
+};
+
+__global__ __launch_bounds__(256) void k_tok_meta(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                  u32 n_aln, const u32 *__restrict__ good, const u32 *__restrict__ kk,
+                                                  const u32 *__restrict__ g_seq_len, const u32 *__restrict__ out_idx,
+                                                  const u64 *__restrict__ seq_scan, const u64 *__restrict__ cig_scan,
+                                                  OutArrays O, u64 out_base, u64 seq_base, u64 cig_base) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln || !good[r]) return;
+    const LineRec &a = rec[rec_line[r]];
+    const u64 o = out_base + out_idx[r];
+    O.contig[o] = a.contig;
+    O.ref_start[o] = a.ref_start;
+    O.k[o] = kk[r];
+    O.seq_len[o] = g_seq_len[r];
+    O.n_cig[o] = a.n_runs;
+    O.seq_off[o] = seq_base + seq_scan[r];
+    O.cig_off[o] = cig_base + cig_scan[r];
+}
+
+__device__ __forceinline__ u8 comp_upper(u8 c) {  // misc.rs:170-182 on the upper-cased base
+    switch (c) {
+    case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G';
+    case 'R': return 'Y'; case 'Y': return 'R'; case 'S': return 'S'; case 'W': return 'W';
+    case 'K': return 'M'; case 'M': return 'K'; case 'B': return 'V'; case 'V': return 'B';
+    case 'D': return 'H'; case 'H': return 'D'; case 'N': return 'N'; case '.': return '.';
+    case '-': return '-'; case '?': return '?'; default: return 'N';
+    }
+}
+
+// SEQ bytes: eight lanes per good record, 16 bytes per lane and trip; upper-cased; a "*" record takes the
+// group's sequence, reverse-complemented when the strands differ (alignment.rs:161-167, 288-296)
+__global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                 const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                 u32 n_aln, const u32 *__restrict__ good, const u32 *__restrict__ src_rec,
+                                                 const u64 *__restrict__ seq_scan, u8 *__restrict__ seq, u64 seq_base) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 3, s = t & 7u;
+    if (r >= n_aln || !good[r]) return;
+    const u32 sr = src_rec[r];
+    const LineRec &a = rec[rec_line[r]], &b = rec[rec_line[sr]];
+    const u8 *in = text + line_start(nl_pos, rec_line[sr]) + b.seq_off;
+    const u32 n = b.seq_len;
+    u8 *out = seq + seq_base + seq_scan[r];
+    const bool rc = sr != r && ((a.flag & 16u) == 0) != ((b.flag & 16u) == 0);
+    for (u32 i = s; i < n; i += 8) {  // byte-wise: the output offset has no alignment and n is small
+        u8 c = rc ? in[n - 1 - i] : in[i];
+        if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
+        out[i] = rc ? comp_upper(c) : c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tok_cigar(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                   const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                   u32 n_aln, const u32 *__restrict__ good,
+                                                   const u64 *__restrict__ cig_scan, u32 *__restrict__ cigar, u64 cig_base) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln || !good[r]) return;
+    const LineRec &a = rec[rec_line[r]];
+    const u8 *cg = text + line_start(nl_pos, rec_line[r]) + a.cig_off;
+    u32 *out = cigar + cig_base + cig_scan[r];
+    u32 i = 0, w = 0;
+    while (i < a.cig_len) {  // validated by k_tok_parse
+        u64 num = 0;
+        while (cg[i] >= (u8)'0' && cg[i] <= (u8)'9') num = num * 10 + (u64)(cg[i++] - (u8)'0');
+        const u32 op = (u32)op_code(cg[i++]);
+        while (num > 0) {
+            const u32 piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (u32)num;
+            out[w++] = (piece << 4) | op;
+            num -= piece;
+        }
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+struct pp_dev_ingest {
+    pp_ctx *ctx;
+    const pp_assembly *asmb;
+    u32 max_errors;
+    int careful;
+    // contig table
+    pp::DevBuf t_slots, t_off, t_names;
+    u32 t_mask = 0;
+    // per-file scratch
+    pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
+        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status;
+    // output (grows over the files)
+    pp::DevBuf o_contig, o_ref_start, o_k, o_seq_len, o_n_cig, o_cigar, o_seq_off, o_cig_off, o_seq;
+    u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
+};
+
+namespace {
+
+// grow a device buffer keeping its first `used` bytes
+int dev_grow(pp_ctx *ctx, pp::DevBuf &b, size_t need, size_t used) {
+    if (need == 0) need = 16;
+    if (b.cap >= need) return PP_OK;
+    const size_t want = need + need / 4 + 256;
+    void *q = nullptr;
+    PP_HIPCHK(ctx, hipMalloc(&q, want));
+    if (b.p && used) PP_HIPCHK(ctx, hipMemcpyAsync(q, b.p, used, hipMemcpyDeviceToDevice, ctx->stream));
+    if (b.p) {
+        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PP_HIPCHK(ctx, hipFree(b.p));
+    }
+    b.p = q;
+    b.cap = want;
+    return PP_OK;
+}
+
+template <typename T>
+int fetch(pp_ctx *ctx, const void *dev, T *host, size_t n = 1) {
+    PP_HIPCHK(ctx, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
+}  // namespace
+
+extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t max_errors, int careful,
+                                    pp_dev_ingest **out) {
+    if (!ctx || !a || !out) return PP_ERR_ARG;
+    *out = nullptr;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    pp_dev_ingest *D = new pp_dev_ingest();
+    D->ctx = ctx;
+    D->asmb = a;
+    D->max_errors = max_errors;
+    D->careful = careful != 0;
+    // RNAME table
+    const u32 nc = pp_assembly_n_contigs(a);
+    u32 cap = 16;
+    while (cap < 2 * nc + 2) cap <<= 1;
+    std::vector<u32> slots(cap, 0), off(nc + 1, 0);
+    std::string names;
+    for (u32 c = 0; c < nc; c++) {
+        const char *nm = pp_assembly_name(a, c);
+        const u32 n = (u32)strlen(nm);
+        u32 h = 2166136261u;
+        for (u32 i = 0; i < n; i++) h = (h ^ (u8)nm[i]) * 16777619u;
+        u32 i = h & (cap - 1);
+        while (slots[i]) i = (i + 1) & (cap - 1);
+        slots[i] = c + 1;
+        off[c] = (u32)names.size();
+        names.append(nm, n);
+    }
+    off[nc] = (u32)names.size();
+    D->t_mask = cap - 1;
+    int rc = pp::dev_ensure(ctx, D->t_slots, cap * 4);
+    if (!rc) rc = pp::dev_ensure(ctx, D->t_off, (nc + 1) * 4);
+    if (!rc) rc = pp::dev_ensure(ctx, D->t_names, names.size() + 16);
+    if (!rc && (hipMemcpy(D->t_slots.p, slots.data(), cap * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(D->t_off.p, off.data(), (nc + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                (names.size() && hipMemcpy(D->t_names.p, names.data(), names.size(), hipMemcpyHostToDevice) != hipSuccess)))
+        rc = ctx->fail(PP_ERR_HIP, "uploading the contig table failed");
+    if (rc) { delete D; return rc; }
+    *out = D;
+    return PP_OK;
+}
+
+extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
+    if (!D) return;
+    (void)hipStreamSynchronize(D->ctx->stream);
+    pp::DevBuf *all[] = {&D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
+                         &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
+                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status,
+                         &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
+                         &D->o_cig_off, &D->o_seq};
+    for (pp::DevBuf *b : all) pp::dev_free(*b);
+    delete D;
+}
+
+extern "C" void pp_dev_ingest_batch(const pp_dev_ingest *D, pp_aln_batch *out) {
+    out->n_aln = D->n_out;
+    out->contig = (const u32 *)D->o_contig.p;
+    out->ref_start = (const u32 *)D->o_ref_start.p;
+    out->k = (const u32 *)D->o_k.p;
+    out->seq_off = (const uint64_t *)D->o_seq_off.p;
+    out->seq_len = (const u32 *)D->o_seq_len.p;
+    out->cig_off = (const uint64_t *)D->o_cig_off.p;
+    out->n_cig = (const u32 *)D->o_n_cig.p;
+    out->seq = (const u8 *)D->o_seq.p;
+    out->seq_bytes = D->seq_bytes;
+    out->cigar = (const u32 *)D->o_cigar.p;
+    out->n_cig_total = D->n_cig_total;
+}
+
+// The reference's message for the first event of the file: run the host ingest over the lines involved.
+static int describe_error(pp_dev_ingest *D, const char *path, const char *text, size_t size, u64 key, u64 n_lines,
+                          u64 n_nl, const std::vector<u32> &rec_line, const std::vector<u32> &group_first) {
+    pp_ctx *ctx = D->ctx;
+    auto line_off = [&](u64 li, u64 *off) -> int {  // byte offset of the start of line li (li <= n_lines)
+        if (li == 0) { *off = 0; return PP_OK; }
+        if (li > n_nl) { *off = size; return PP_OK; }
+        u64 p;
+        if (int rc = fetch(ctx, (const u64 *)D->d_nl.p + (li - 1), &p)) return rc;
+        *off = p + 1;
+        return PP_OK;
+    };
+    u64 first_line, end_line;  // the slice [first_line, end_line) reproduces the event
+    if ((key & 1) == 0) {
+        first_line = key / 2;
+        end_line = first_line + 1;
+    } else {
+        const u64 flush_line = key / 2;  // the failing group ends just before this line
+        // its first record: the last group start whose line is < flush_line
+        size_t lo = 0, hi = group_first.size() - 1;  // group_first[n_groups] = n_aln
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (group_first[mid] < rec_line.size() && rec_line[group_first[mid]] < flush_line) lo = mid; else hi = mid;
+        }
+        first_line = rec_line[group_first[lo]];
+        end_line = flush_line;
+    }
+    u64 a = 0, b = size;
+    if (int rc = line_off(first_line, &a)) return rc;
+    if (int rc = line_off(std::min(end_line, n_lines), &b)) return rc;
+    if (end_line >= n_lines) b = size;
+    pp_ingest *H = nullptr;
+    if (int rc = pp_ingest_create(D->asmb, D->max_errors, D->careful, &H)) return rc;
+    char err[1024] = "";
+    pp_sam_counts c;
+    const int rc = pp_ingest_text_(H, path, text + a, (size_t)(b - a), first_line, &c, err, sizeof err);
+    pp_ingest_free(H);
+    if (rc == PP_OK) return ctx->fail(PP_ERR_HIP, "device tokenizer flagged \"%s\" (event %llu) but the host ingest accepts it", path,
+                                      (unsigned long long)key);
+    return ctx->fail(rc, "%s", err);
+}
+
+extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_counts *counts) {
+    if (!D || !path) return PP_ERR_ARG;
+    pp_ctx *ctx = D->ctx;
+    hipStream_t st = ctx->stream;
+    pp_sam_counts c{0, 0, 0};
+    if (counts) *counts = c;
+    pph::FileText F;
+    if (!F.open_file(path)) return ctx->fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+    const u64 size = F.size;
+    if (size >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "\"%s\" is larger than the 1 TiB this tokenizer indexes", path);
+    int rc;
+#define ENS(buf, bytes) if ((rc = pp::dev_ensure(ctx, D->buf, (size_t)(bytes)))) return rc
+    // ---- text + newline index ----
+    const u64 n_blk = (size + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
+    ENS(d_text, padded + 64);
+    ENS(d_status, 8);
+    if (size) PP_HIPCHK(ctx, hipMemcpyAsync(D->d_text.p, F.text, size, hipMemcpyHostToDevice, st));
+    PP_HIPCHK(ctx, hipMemsetAsync((u8 *)D->d_text.p + size, 0, padded + 64 - size, st));
+    PP_HIPCHK(ctx, hipMemsetAsync(D->d_status.p, 0xFF, 8, st));
+    const u8 *d_text = (const u8 *)D->d_text.p;
+    u64 *d_status = (u64 *)D->d_status.p;
+    u64 n_nl = 0;
+    if (n_blk) {
+        ENS(d_blk, n_blk * 4);
+        ENS(d_blkoff, (n_blk + 1) * 8);
+        hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)D->d_blk.p);
+        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_blk.p, n_blk, (u64 *)D->d_blkoff.p);
+        if ((rc = fetch(ctx, (const u64 *)D->d_blkoff.p + n_blk, &n_nl))) return rc;
+        ENS(d_nl, std::max<u64>(1, n_nl) * 8);
+        hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)D->d_blkoff.p, (u64 *)D->d_nl.p);
+    }
+    const u64 n_lines = n_nl + ((size > 0 && F.text[size - 1] != '\n') ? 1 : 0);
+    if (n_lines >= 0x7FFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "\"%s\" has more than 2^31-1 lines", path);
+    // ---- per-line parse ----
+    u32 n_aln = 0;
+    if (n_lines) {
+        ENS(d_rec, n_lines * sizeof(LineRec));
+        ENS(d_isaln, n_lines * 4);
+        ENS(d_recofline, (n_lines + 1) * 4);
+        ContigTable T{(const u32 *)D->t_slots.p, (const u32 *)D->t_off.p, (const u8 *)D->t_names.p, D->t_mask};
+        hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, size,
+                           (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
+        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_isaln.p, n_lines, (u32 *)D->d_recofline.p);
+        if ((rc = fetch(ctx, (const u32 *)D->d_recofline.p + n_lines, &n_aln))) return rc;
+    }
+    // ---- read groups and gates ----
+    u32 n_groups = 0;
+    if (n_aln) {
+        ENS(d_recline, (u64)n_aln * 4);
+        ENS(d_isstart, (u64)n_aln * 4);
+        ENS(d_grpofrec, ((u64)n_aln + 1) * 4);
+        hipLaunchKernelGGL(k_tok_compact, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, n_lines,
+                           (const u32 *)D->d_isaln.p, (const u32 *)D->d_recofline.p, (u32 *)D->d_recline.p);
+        hipLaunchKernelGGL(k_tok_group_start, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
+                           (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (u32 *)D->d_isstart.p);
+        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_isstart.p, (u64)n_aln, (u32 *)D->d_grpofrec.p);
+        if ((rc = fetch(ctx, (const u32 *)D->d_grpofrec.p + n_aln, &n_groups))) return rc;
+        ENS(d_gfirst, ((u64)n_groups + 1) * 4);
+        ENS(d_good, (u64)n_aln * 4); ENS(d_k, (u64)n_aln * 4); ENS(d_src, (u64)n_aln * 4);
+        ENS(d_gseq, (u64)n_aln * 4); ENS(d_gcig, (u64)n_aln * 4);
+        ENS(d_outidx, ((u64)n_aln + 1) * 4); ENS(d_seqscan, ((u64)n_aln + 1) * 8); ENS(d_cigscan, ((u64)n_aln + 1) * 8);
+        hipLaunchKernelGGL(k_tok_group_first, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_isstart.p,
+                           (const u32 *)D->d_grpofrec.p, n_groups, (u32 *)D->d_gfirst.p);
+        hipLaunchKernelGGL(k_tok_group, dim3((n_groups + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
+                           (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, (const u32 *)D->d_gfirst.p, n_groups,
+                           n_lines, D->max_errors, D->careful, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
+                           (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, d_status);
+        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p);
+        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_gseq.p, (u64)n_aln, (u64 *)D->d_seqscan.p);
+        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p);
+    }
+    u64 status = ~0ull;
+    if ((rc = fetch(ctx, d_status, &status))) return rc;
+    c.alignments = n_aln;
+    if (status != ~0ull) {
+        std::vector<u32> rec_line(n_aln), group_first((size_t)n_groups + 1);
+        if (n_aln && (rc = fetch(ctx, (const u32 *)D->d_recline.p, rec_line.data(), n_aln))) return rc;
+        if (n_aln && (rc = fetch(ctx, (const u32 *)D->d_gfirst.p, group_first.data(), (size_t)n_groups + 1))) return rc;
+        if (counts) *counts = c;
+        return describe_error(D, path, F.text, size, status, n_lines, n_nl, rec_line, group_first);
+    }
+    if (n_aln == 0)  // the EOF flush of an empty group (alignment.rs:268, :319)
+        return ctx->fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
+    u32 n_good = 0;
+    u64 seq_total = 0, cig_total = 0;
+    if ((rc = fetch(ctx, (const u32 *)D->d_outidx.p + n_aln, &n_good))) return rc;
+    if ((rc = fetch(ctx, (const u64 *)D->d_seqscan.p + n_aln, &seq_total))) return rc;
+    if ((rc = fetch(ctx, (const u64 *)D->d_cigscan.p + n_aln, &cig_total))) return rc;
+    // ---- append to the batch ----
+    const u64 no = D->n_out;
+#define GROW(buf, elem, count, used) if ((rc = dev_grow(ctx, D->buf, (size_t)(count) * (elem), (size_t)(used) * (elem)))) return rc
+    GROW(o_contig, 4, no + n_good, no); GROW(o_ref_start, 4, no + n_good, no); GROW(o_k, 4, no + n_good, no);
+    GROW(o_seq_len, 4, no + n_good, no); GROW(o_n_cig, 4, no + n_good, no);
+    GROW(o_seq_off, 8, no + n_good, no); GROW(o_cig_off, 8, no + n_good, no);
+    GROW(o_seq, 1, D->seq_bytes + seq_total + 64, D->seq_bytes); GROW(o_cigar, 4, D->n_cig_total + cig_total, D->n_cig_total);
+#undef GROW
+    OutArrays O{(u32 *)D->o_contig.p, (u32 *)D->o_ref_start.p, (u32 *)D->o_k.p, (u32 *)D->o_seq_len.p, (u32 *)D->o_n_cig.p,
+                (u32 *)D->o_cigar.p, (u64 *)D->o_seq_off.p, (u64 *)D->o_cig_off.p, (u8 *)D->o_seq.p};
+    hipLaunchKernelGGL(k_tok_meta, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
+                       (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_k.p,
+                       (const u32 *)D->d_gseq.p, (const u32 *)D->d_outidx.p, (const u64 *)D->d_seqscan.p,
+                       (const u64 *)D->d_cigscan.p, O, no, D->seq_bytes, D->n_cig_total);
+    hipLaunchKernelGGL(k_tok_seq, dim3((unsigned)(((u64)n_aln * 8 + 255) / 256)), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
+                       (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
+                       (const u32 *)D->d_src.p, (const u64 *)D->d_seqscan.p, O.seq, D->seq_bytes);
+    hipLaunchKernelGGL(k_tok_cigar, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
+                       (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
+                       (const u64 *)D->d_cigscan.p, O.cigar, D->n_cig_total);
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));  // the text mapping goes away with F
+    D->n_out += n_good;
+    D->seq_bytes += seq_total;
+    D->n_cig_total += cig_total;
+    c.used = n_good;
+    c.reads = n_groups;
+    if (counts) *counts = c;
+#undef ENS
+    return PP_OK;
+}

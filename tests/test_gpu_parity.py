@@ -359,6 +359,94 @@ def test_multi_process_driver_on_one_gpu(orc, tmp_path):
     assert r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"]
 
 
+def _same_ingest(pp, ctx, fasta, sams, **kw):
+    try:
+        want = pp.ingest(fasta, sams, **kw)
+        we = None
+    except pp.PolypolishError as e:
+        want, we = None, (e.code, e.msg)
+    try:
+        got = pp.ingest_device(ctx, fasta, sams, **kw)
+        ge = None
+    except pp.PolypolishError as e:
+        got, ge = None, (e.code, e.msg)
+    assert ge == we, (ge, we)
+    if want is not None:
+        assert got[5] == want[5], (got[5], want[5])
+        for k in want[4]:
+            assert np.array_equal(got[4][k], want[4][k]), k
+    return want, we
+
+
+@pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
+@pytest.mark.parametrize("careful", [False, True])
+def test_device_tokenizer_equals_host_ingest(pp, ctx, tmp_path, case, careful):
+    """pp_dev_ingest_*: SAM text tokenized by kernels; the batch must equal the host ingest's array by array
+    (and therefore what the reference's process_one_read would feed the pileup)."""
+    ds = synth.rich_dataset(str(tmp_path), lowercase_frac=0.2, **case)
+    want, err = _same_ingest(pp, ctx, ds["fasta"], [ds["sam1"], ds["sam2"]], max_errors=10, careful=careful)
+    assert err is None and len(want[4]["contig"]) > 0
+
+
+def test_device_tokenizer_details_and_errors(pp, ctx, orc, tmp_path):
+    ref = "ACGGTCATTGCAACGGTTATTGCA"
+    fa = tmp_path / "a.fasta"
+    fa.write_text(f">c d1 d2\n{ref[:10]}\n{ref[10:].lower()}\n>e\nGGGG\n")
+
+    def line(name, flag, rname, pos, cigar, seq, tags="NM:i:0"):
+        return f"{name}\t{flag}\t{rname}\t{pos}\t60\t{cigar}\t*\t0\t0\t{seq}\t*\t{tags}\n"
+    good = ("@HD\tVN:1\n\n"
+            + line("r1", 16, "c", 1, "12M", "acggtcattgca", "AS:i:3\tNM:i:2\tXX:Z:y")
+            + line("r1", 256, "c", 13, "0S12M", "*") + line("r1", 272, "c", 13, "5S7M", "*")
+            + line("r2", 4, "*", 0, "*", "ACGT", "") + line("r3", 0, "c", 1, "6=1X5=", ref[:12], "NM:i:11")
+            + line("r4", 0, "c", 0, "12M", ref[:12], "NM:i:0\tzp:z:FAIL") + line("", 0, "c", 2, "5M", ref[1:6])
+            + line("r6", 0, "c", 3, "5M", ref[2:7]) + line("r5", 0, "e", 1, "2M1I1M", "GGAG", "NM:i:1\tNM:i:0\t").rstrip("\n"))
+    sam = tmp_path / "a.sam"
+    sam.write_text(good)
+    want, err = _same_ingest(pp, ctx, str(fa), [str(sam)])
+    assert err is None and list(want[4]["k"]) == [2, 2, 2, 2, 1]   # the empty QNAME pulls r6 into its group
+    many = "".join(line(f"q{i}", 0, "c", 1 + i % 10, "12M", ref[i % 10:i % 10 + 12]) for i in range(3000))
+    cases = [
+        many + "r\t0\tc\t1\t60\t12M\n" + many,                               # too few columns, line 3001
+        many + "r\t0\tc\t1\t60\t12M\t*\t0\t0\t" + ref[:12] + "\t*\n",          # missing NM
+        many + line("r", 0, "c", 1, "12Q", ref[:12]) + many,                    # invalid CIGAR
+        line("r", 0, "c", 1, "12M", "*") + many,                                # first group has no sequence ...
+        line("r", 0, "c", 1, "12M", "*") + many[:5000] + "bad\t0\n" + many,       # ... and wins over a later parse error
+        "bad\t0\n" + line("r", 0, "c", 1, "12M", "*") + many,                    # an earlier parse error wins over the group
+        many + line("r", 0, "zzz", 1, "12M", ref[:12]),                         # contig not in assembly (EOF flush)
+        many + line("r", 0, "c", 1, "*", ref[:12]) + many,                      # empty CIGAR: panic
+        line("r", "x", "c", 1, "12M", ref[:12]),                                # FLAG does not parse: panic
+        many + line("r", 0, "c", 1, "4294967296M", ref[:12]),                   # run length overflow: panic
+        "@HD\tVN:1\n",                                                         # nothing aligned: panic
+        "",                                                                     # empty file
+        many + line("r", 0, "c", 5000000000, "12M", ref[:12]),                  # start beyond u32: panic
+    ]
+    seen = set()
+    for i, text in enumerate(cases):
+        p = tmp_path / f"e{i}.sam"
+        p.write_text(text)
+        _, err = _same_ingest(pp, ctx, str(fa), [str(p)])
+        assert err is not None, i
+        seen.add(err[0])
+    assert seen == {1, 101}
+    # two files: the batch grows across calls
+    want, err = _same_ingest(pp, ctx, str(fa), [str(sam), str(sam)])
+    assert err is None and len(want[4]["contig"]) == 10
+
+
+@pytest.mark.parametrize("case", FILE_CASES[:3], ids=["seed31", "seed32", "seed33"])
+def test_cli_with_the_device_tokenizer(orc, tmp_path, case):
+    """PP_DEVICE_INGEST=1: `polypolish polish` with the SAM text tokenized on the GPU; same stdout, same log numbers."""
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    sams = [ds["sam1"], ds["sam2"]]
+    want = orc.polish_files(ds["fasta"], sams)
+    r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "polish", ds["fasta"], *sams], capture_output=True,
+                       env=dict(os.environ, PP_DEVICE_INGEST="1"))
+    assert r.returncode == 0 and r.stdout == want["fasta"], r.stderr.decode()[-800:]
+    log = r.stderr.decode()
+    assert f"{want['counts'][1]:,} alignments kept" in log
+
+
 def test_reference_orientation_vectors_on_device(ctx, pp):
     """T4 (src/filter.rs:384-424) and T3 (src/alignment.rs:402-422) through the filter kernels."""
     import ctypes as C

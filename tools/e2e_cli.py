@@ -34,11 +34,17 @@ def run(cmd):
     t = time.time()
     r = subprocess.run(cmd, capture_output=True)
     return time.time() - t, r
+os.environ["PP_DEVICE_INGEST"] = "1"
+for rep in range(2):
+    dt_dev, r3 = run([os.path.join(ROOT, "bin", "polypolish"), "polish", fa, sam])
+print("device tokenizer:\n" + "\n".join(l for l in r3.stderr.decode().split("\n") if "[timing]" in l or "Time to run" in l))
+os.environ["PP_DEVICE_INGEST"] = "0"
 for rep in range(2):
     dt_gpu, r1 = run([os.path.join(ROOT, "bin", "polypolish"), "polish", fa, sam])
 dt_cpu, r2 = run([os.path.join(ROOT, "oracle", "_build", "pp_oracle"), "polish", fa, sam])
 same = r1.stdout == r2.stdout
 err = r1.stderr.decode()
 print("\n".join(l for l in err.split("\n") if "[timing]" in l or "Time to run" in l))
+print(f"bin/polypolish with PP_DEVICE_INGEST=1: {dt_dev:.2f} s   identical FASTA: {r3.stdout == r2.stdout}")
 print(f"bin/polypolish: {dt_gpu:.2f} s ({G / 1e6 / dt_gpu:.2f} Mbp/s)   oracle (1 core): {dt_cpu:.2f} s ({G / 1e6 / dt_cpu:.3f} Mbp/s)"
       f"   speed-up {dt_cpu / dt_gpu:.1f}x   identical FASTA: {same}   sha256 {hashlib.sha256(r1.stdout).hexdigest()[:16]}")
