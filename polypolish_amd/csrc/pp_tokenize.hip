@@ -18,6 +18,7 @@
 #include "pp_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -90,7 +91,25 @@ __global__ __launch_bounds__(1024) void k_nl_write(const u8 *__restrict__ text, 
         if (text[base + i] == (u8)'\n') nl_pos[out++] = base + i;
 }
 
-// ---- single-block exclusive scan: u32 in -> T out (n + 1 entries), as pp_kernels.hip's ------------
+// ---- exclusive scan: u32 in -> T out (n + 1 entries) -- block sums, a single-block scan of the sums,
+// then every block scans its own 8192 elements on top of its base ------------------------------------
+constexpr u32 SCAN_PER_BLOCK = 1024 * 8;
+
+__global__ __launch_bounds__(1024) void k_scan_sums(const u32 *__restrict__ in, u64 n, u32 *__restrict__ sums) {
+    __shared__ u32 s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * 8u;
+    u32 v = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++)
+        if (base + i < n) v += in[base + i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_sum;
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_tscan(const u32 *__restrict__ in, u64 n, T *__restrict__ out) {
     __shared__ u64 part[1024];
@@ -113,6 +132,35 @@ __global__ __launch_bounds__(1024) void k_tscan(const u32 *__restrict__ in, u64 
         run += in[i];
     }
     if (t == 1023) out[n] = (T)part[1023];
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan_apply(const u32 *__restrict__ in, u64 n, const u64 *__restrict__ sums_off,
+                                                     T *__restrict__ out) {
+    __shared__ u32 s_w[16];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * 8u;
+    u32 v[8], sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        v[i] = base + i < n ? in[base + i] : 0u;
+        sum += v[i];
+    }
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    u64 run = sums_off[blockIdx.x] + (inc - sum);
+    for (u32 i = 0; i < wave; i++) run += s_w[i];
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        if (base + i < n) out[base + i] = (T)run;
+        run += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (T)sums_off[gridDim.x];
 }
 
 // ---- per-line parse (Alignment::new) ---------------------------------------------------------------
@@ -421,7 +469,7 @@ struct pp_dev_ingest {
     u32 t_mask = 0;
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
-        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status;
+        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff;
     // output (grows over the files)
     pp::DevBuf o_contig, o_ref_start, o_k, o_seq_len, o_n_cig, o_cigar, o_seq_off, o_cig_off, o_seq;
     u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
@@ -443,6 +491,18 @@ int dev_grow(pp_ctx *ctx, pp::DevBuf &b, size_t need, size_t used) {
     }
     b.p = q;
     b.cap = want;
+    return PP_OK;
+}
+
+// out[0..n] = exclusive scan of in[0..n); scratch: two small device buffers for the block sums
+template <typename T>
+int scan_u32(pp_ctx *ctx, pp::DevBuf &b_sums, pp::DevBuf &b_sums_off, const u32 *in, u64 n, T *out) {
+    const u64 nb = std::max<u64>(1, (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    if (int rc = pp::dev_ensure(ctx, b_sums, nb * 4)) return rc;
+    if (int rc = pp::dev_ensure(ctx, b_sums_off, (nb + 1) * 8)) return rc;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, in, n, (u32 *)b_sums.p);
+    hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)b_sums.p, nb, (u64 *)b_sums_off.p);
+    hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, in, n, (const u64 *)b_sums_off.p, out);
     return PP_OK;
 }
 
@@ -501,7 +561,7 @@ extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     (void)hipStreamSynchronize(D->ctx->stream);
     pp::DevBuf *all[] = {&D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
-                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status,
+                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
                          &D->o_cig_off, &D->o_seq};
     for (pp::DevBuf *b : all) pp::dev_free(*b);
@@ -576,6 +636,15 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
     const u64 size = F.size;
     if (size >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "\"%s\" is larger than the 1 TiB this tokenizer indexes", path);
     int rc;
+    const bool timing = getenv("PP_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing]   tokenizer: %-20s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
 #define ENS(buf, bytes) if ((rc = pp::dev_ensure(ctx, D->buf, (size_t)(bytes)))) return rc
     // ---- text + newline index ----
     const u64 n_blk = (size + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
@@ -586,6 +655,7 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
     PP_HIPCHK(ctx, hipMemsetAsync(D->d_status.p, 0xFF, 8, st));
     const u8 *d_text = (const u8 *)D->d_text.p;
     u64 *d_status = (u64 *)D->d_status.p;
+    lap("text uploaded");
     u64 n_nl = 0;
     if (n_blk) {
         ENS(d_blk, n_blk * 4);
@@ -596,6 +666,7 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
         ENS(d_nl, std::max<u64>(1, n_nl) * 8);
         hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)D->d_blkoff.p, (u64 *)D->d_nl.p);
     }
+    lap("newline index");
     const u64 n_lines = n_nl + ((size > 0 && F.text[size - 1] != '\n') ? 1 : 0);
     if (n_lines >= 0x7FFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "\"%s\" has more than 2^31-1 lines", path);
     // ---- per-line parse ----
@@ -607,9 +678,10 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
         ContigTable T{(const u32 *)D->t_slots.p, (const u32 *)D->t_off.p, (const u8 *)D->t_names.p, D->t_mask};
         hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, size,
                            (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
-        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_isaln.p, n_lines, (u32 *)D->d_recofline.p);
+        if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_isaln.p, n_lines, (u32 *)D->d_recofline.p))) return rc;
         if ((rc = fetch(ctx, (const u32 *)D->d_recofline.p + n_lines, &n_aln))) return rc;
     }
+    lap("lines parsed");
     // ---- read groups and gates ----
     u32 n_groups = 0;
     if (n_aln) {
@@ -620,7 +692,7 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
                            (const u32 *)D->d_isaln.p, (const u32 *)D->d_recofline.p, (u32 *)D->d_recline.p);
         hipLaunchKernelGGL(k_tok_group_start, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                            (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (u32 *)D->d_isstart.p);
-        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_isstart.p, (u64)n_aln, (u32 *)D->d_grpofrec.p);
+        if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_isstart.p, (u64)n_aln, (u32 *)D->d_grpofrec.p))) return rc;
         if ((rc = fetch(ctx, (const u32 *)D->d_grpofrec.p + n_aln, &n_groups))) return rc;
         ENS(d_gfirst, ((u64)n_groups + 1) * 4);
         ENS(d_good, (u64)n_aln * 4); ENS(d_k, (u64)n_aln * 4); ENS(d_src, (u64)n_aln * 4);
@@ -632,12 +704,13 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
                            (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, (const u32 *)D->d_gfirst.p, n_groups,
                            n_lines, D->max_errors, D->careful, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
                            (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, d_status);
-        hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p);
-        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_gseq.p, (u64)n_aln, (u64 *)D->d_seqscan.p);
-        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p);
+        if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p))) return rc;
+        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gseq.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
+        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p))) return rc;
     }
     u64 status = ~0ull;
     if ((rc = fetch(ctx, d_status, &status))) return rc;
+    lap("groups + gates");
     c.alignments = n_aln;
     if (status != ~0ull) {
         std::vector<u32> rec_line(n_aln), group_first((size_t)n_groups + 1);
@@ -674,6 +747,7 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
                        (const u64 *)D->d_cigscan.p, O.cigar, D->n_cig_total);
     PP_HIPCHK(ctx, hipStreamSynchronize(st));  // the text mapping goes away with F
+    lap("batch filled");
     D->n_out += n_good;
     D->seq_bytes += seq_total;
     D->n_cig_total += cig_total;
