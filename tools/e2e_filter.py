@@ -18,7 +18,11 @@ start = rng.integers(0, G - 700, n_pairs)
 flip = rng.random(n_pairs) < 0.5           # which mate is forward
 odd = rng.random(n_pairs) < 0.002          # wrong orientation / huge insert
 is_multi = rng.random(n_pairs) < multi     # read 1 has 3 alignments, one of them consistent with the mate
-seq = "ACGT" * 37 + "AC"
+genome = rng.integers(0, 4, G, dtype=np.uint8)
+gstr = np.frombuffer(b"ACGT", dtype=np.uint8)[genome].tobytes().decode()
+fa = os.path.join(tmp, "flt.fasta")
+with open(fa, "w") as f:
+    f.write(">c0\n" + gstr + "\n")
 paths = [os.path.join(tmp, f"flt_{i}.sam") for i in (1, 2)]
 with open(paths[0], "w") as f1, open(paths[1], "w") as f2:
     for f in (f1, f2):
@@ -32,12 +36,12 @@ with open(paths[0], "w") as f1, open(paths[1], "w") as f2:
         if odd[i]:
             fl2 = fl1 & ~0x10 | (fl1 & 0x10)   # same strand as mate 1
             fl2 = (fl2 & ~0x40) | 0x80
-        b1.append(f"r{i}\t{fl1}\tc0\t{s1 + 1}\t60\t150M\t=\t{s2 + 1}\t0\t{seq}\t*\tNM:i:0\n")
+        b1.append(f"r{i}\t{fl1}\tc0\t{s1 + 1}\t60\t150M\t=\t{s2 + 1}\t0\t{gstr[s1:s1 + 150]}\t*\tNM:i:0\n")
         if is_multi[i]:
             for j in range(2):
                 far = int(rng.integers(0, G - 700))
                 b1.append(f"r{i}\t{fl1 | 256}\tc0\t{far + 1}\t0\t150M\t=\t{s2 + 1}\t0\t*\t*\tNM:i:1\n")
-        b2.append(f"r{i}\t{fl2}\tc0\t{s2 + 1}\t60\t150M\t=\t{s1 + 1}\t0\t{seq}\t*\tNM:i:0\n")
+        b2.append(f"r{i}\t{fl2}\tc0\t{s2 + 1}\t60\t150M\t=\t{s1 + 1}\t0\t{gstr[s2:s2 + 150]}\t*\tNM:i:0\n")
         if len(b1) >= 100000:
             f1.write("".join(b1)); f2.write("".join(b2)); b1, b2 = [], []
     f1.write("".join(b1)); f2.write("".join(b2))
@@ -67,3 +71,19 @@ err = r1.stderr.decode()
 print("\n".join(l for l in err.split("\n") if "[timing]" in l or "Time to run" in l or "threshold" in l or " fail" in l))
 print(f"rc {r1.returncode}/{r2.returncode}  bin/polypolish filter: {dt_gpu:.2f} s   oracle (1 core): {dt_cpu:.2f} s   speed-up {dt_cpu / dt_gpu:.1f}x   "
       f"identical SAMs: {same}")
+
+# the whole chain: filter then polish (two processes, tagged SAMs on disk) vs the fused command vs the oracle's chain
+exe = os.path.join(ROOT, "bin", "polypolish")
+for rep in range(2):
+    t = time.time()
+    ra = subprocess.run([exe] + args(outs_g), capture_output=True)
+    rb = subprocess.run([exe, "polish", fa] + outs_g, capture_output=True)
+    dt_two = time.time() - t
+for rep in range(2):
+    dt_fused, rf = run([exe, "filter-polish", "--in1", paths[0], "--in2", paths[1], fa])
+t = time.time()
+rc1 = subprocess.run([os.path.join(ROOT, "oracle", "_build", "pp_oracle")] + args(outs_c), capture_output=True)
+rc2 = subprocess.run([os.path.join(ROOT, "oracle", "_build", "pp_oracle"), "polish", fa] + outs_c, capture_output=True)
+dt_orc = time.time() - t
+print(f"filter + polish, two processes: {dt_two:.2f} s   fused filter-polish: {dt_fused:.2f} s   oracle chain (1 core): {dt_orc:.2f} s   "
+      f"identical FASTA: {rb.stdout == rc2.stdout and rf.stdout == rc2.stdout}   speed-up fused {dt_orc / dt_fused:.1f}x, two-step {dt_orc / dt_two:.1f}x")
