@@ -203,17 +203,23 @@ def main():
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate,
                    repeat_bp=args.repeat_bp)
     torch.cuda.synchronize()
-    gather_buf = torch.zeros(args.genome + (1 << 16), dtype=torch.uint8, device=device)
+    # two send buffers in turn: the RCCL gather of step i (enqueued, not waited for) may still be reading its
+    # buffer while step i+1 polishes and fills the other one; the final synchronize closes the timed region
+    gather_bufs = [torch.zeros(args.genome + (1 << 16), dtype=torch.uint8, device=device) for _ in range(2)]
+    gather_buf = gather_bufs[0]
     gdev = "cpu" if share else device
     gathered = [torch.empty(gather_buf.shape, dtype=torch.uint8, device=gdev) for _ in range(world)] \
         if (world > 1 and rank == 0) else None
+    n_steps_done = [0]
 
     def step():
         run_job(ctx, pp, job)
         if world > 1:
             # the only exchange of the path: polished contig bytes -> rank 0 (RCCL over xGMI)
-            pp.lib().pp_polish_result(ctx._h, gather_buf.data_ptr(), pp.MEM_DEVICE, None, None)
-            dist.gather(gather_buf.cpu() if share else gather_buf, gathered, dst=0)
+            buf = gather_bufs[n_steps_done[0] & 1]
+            n_steps_done[0] += 1
+            pp.lib().pp_polish_result(ctx._h, buf.data_ptr(), pp.MEM_DEVICE, None, None)
+            dist.gather(buf.cpu() if share else buf, gathered, dst=0)
 
     # Timed region: only the dominant kernel carries an event pair (on the library's stream), so that the
     # timers do not perturb what `value` measures.  The per-group breakdown (kernel_ms_per_step) comes from
@@ -253,13 +259,13 @@ def main():
     if world > 1:
         # every rank's polished bytes must have arrived on rank 0 unchanged: compare byte sums
         mine, _, _ = ctx.result()
-        sums = torch.zeros(world, dtype=torch.int64, device=gdev)
+        sums = torch.zeros(2 * world, dtype=torch.int64, device=gdev)
         sums[rank] = int(np.frombuffer(mine, dtype=np.uint8).sum(dtype=np.int64))
+        sums[world + rank] = len(mine)
         dist.all_reduce(sums)
         if rank == 0:
-            n_out = len(mine)
-            gather_ok = all(int(gathered[r][:n_out].sum(dtype=torch.int64).item()) == int(sums[r].item())
-                            for r in range(world)) and bytes(gathered[0][:n_out].cpu().numpy()) == mine
+            gather_ok = all(int(gathered[r][:int(sums[world + r].item())].sum(dtype=torch.int64).item()) == int(sums[r].item())
+                            for r in range(world)) and bytes(gathered[0][:len(mine)].cpu().numpy()) == mine
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
