@@ -179,6 +179,21 @@ __device__ __forceinline__ bool parse_u(const u8 *s, u32 n, u64 max, u64 &out) {
     return true;
 }
 
+// index of the first '\t' in L[from, n), or n -- eight bytes per step (the text buffer is padded, so a load
+// may run past the line; matches beyond n are cut off)
+__device__ __forceinline__ u32 find_tab(const u8 *L, u32 from, u32 n) {
+    u32 i = from;
+    while (i < n) {
+        u64 w;
+        __builtin_memcpy(&w, L + i, 8);
+        const u64 x = w ^ 0x0909090909090909ull;
+        const u64 m = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;  // bit 7 of the zero bytes (first one exact)
+        if (m) return min(n, i + ((u32)__ffsll((long long)m) - 1u) / 8u);
+        i += 8;
+    }
+    return n;
+}
+
 __device__ __forceinline__ int op_code(u8 c) {
     switch (c) {
     case 'M': return PP_OP_M; case 'I': return PP_OP_I; case 'D': return PP_OP_D; case 'N': return PP_OP_N;
@@ -228,8 +243,7 @@ __global__ __launch_bounds__(256) void k_tok_parse(const u8 *__restrict__ text, 
     if (n == 0 || L[0] == (u8)'@') return;  // alignment.rs:241
     u32 cs[11], cl[11], nc = 0, q = 0;
     while (nc < 11) {
-        u32 t = q;
-        while (t < n && L[t] != (u8)'\t') t++;
+        const u32 t = find_tab(L, q, n);
         cs[nc] = q;
         cl[nc] = t - q;
         nc++;
@@ -243,8 +257,7 @@ __global__ __launch_bounds__(256) void k_tok_parse(const u8 *__restrict__ text, 
     u32 nm = 0xFFFFFFFFu, pass_qc = 1;
     u32 tg = q;  // start of the tag fields; q == n means one empty field after a trailing tab; n + 1: none
     while (tg <= n) {
-        u32 t = tg;
-        while (t < n && L[t] != (u8)'\t') t++;
+        const u32 t = find_tab(L, tg, n);
         const u32 tl = t - tg;
         const u8 *f = L + tg;
         if (tl >= 5 && f[0] == 'N' && f[1] == 'M' && f[2] == ':' && f[3] == 'i' && f[4] == ':') {
