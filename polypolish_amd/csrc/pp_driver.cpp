@@ -219,10 +219,10 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     log("\n");
 
     lap("assembly loaded");
-    // load_alignments, polish.rs:109-134 -- on the host (multi-threaded parse), or with PP_DEVICE_INGEST=1 by the
-    // device tokenizer (pp_tokenize.hip; not with --debug, whose TSV needs the read bytes on the host)
+    // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
+    // parse) with PP_DEVICE_INGEST=0, with --debug (the TSV needs the read bytes on the host) and in the fused command
     log("Loading alignments\n");
-    const bool dev_ingest = getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) && !opt->debug_path && !pass;
+    const bool dev_ingest = !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path && !pass;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
     rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)

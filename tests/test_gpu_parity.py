@@ -435,16 +435,18 @@ def test_device_tokenizer_details_and_errors(pp, ctx, orc, tmp_path):
 
 
 @pytest.mark.parametrize("case", FILE_CASES[:3], ids=["seed31", "seed32", "seed33"])
-def test_cli_with_the_device_tokenizer(orc, tmp_path, case):
-    """PP_DEVICE_INGEST=1: `polypolish polish` with the SAM text tokenized on the GPU; same stdout, same log numbers."""
+def test_cli_with_either_ingest(orc, tmp_path, case):
+    """`polypolish polish` tokenizes the SAM text on the GPU by default and on the host with PP_DEVICE_INGEST=0;
+    same stdout, same log numbers."""
     ds = synth.rich_dataset(str(tmp_path), **case)
     sams = [ds["sam1"], ds["sam2"]]
     want = orc.polish_files(ds["fasta"], sams)
-    r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "polish", ds["fasta"], *sams], capture_output=True,
-                       env=dict(os.environ, PP_DEVICE_INGEST="1"))
-    assert r.returncode == 0 and r.stdout == want["fasta"], r.stderr.decode()[-800:]
-    log = r.stderr.decode()
-    assert f"{want['counts'][1]:,} alignments kept" in log
+    for mode in ("1", "0"):
+        r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "polish", ds["fasta"], *sams], capture_output=True,
+                           env=dict(os.environ, PP_DEVICE_INGEST=mode))
+        assert r.returncode == 0 and r.stdout == want["fasta"], r.stderr.decode()[-800:]
+        log = r.stderr.decode()
+        assert f"{want['counts'][1]:,} alignments kept" in log
 
 
 def test_reference_orientation_vectors_on_device(ctx, pp):
