@@ -307,6 +307,9 @@ int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, 
 typedef struct pp_dev_ingest pp_dev_ingest;
 int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t max_errors, int careful, pp_dev_ingest **out);
 int pp_dev_ingest_sam(pp_dev_ingest *g, const char *path, pp_sam_counts *counts);
+/* with the filter's verdicts, as pp_ingest_sam_filtered (pass: HOST array over the file's aligned records) */
+int pp_dev_ingest_sam_filtered(pp_dev_ingest *g, const char *path, const uint8_t *pass, uint64_t n_pass,
+                               pp_sam_counts *counts);
 void pp_dev_ingest_batch(const pp_dev_ingest *g, pp_aln_batch *out); /* borrowed view, DEVICE memory */
 void pp_dev_ingest_free(pp_dev_ingest *g);
 

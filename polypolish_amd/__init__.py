@@ -110,7 +110,7 @@ EXPORTS = [
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
     "pp_bytes_free", "pp_polish_files", "pp_filter_files", "pp_filter_polish_files", "pp_ingest_sam_filtered",
-    "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_batch", "pp_dev_ingest_free",
+    "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_sam_filtered", "pp_dev_ingest_batch", "pp_dev_ingest_free",
 ]
 
 _lib = None
@@ -191,6 +191,7 @@ def lib():
                                                                        C.POINTER(FilterReport), C.POINTER(Bytes)]
         L.pp_dev_ingest_create.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
         L.pp_dev_ingest_sam.argtypes = [vp, C.c_char_p, C.POINTER(SamCounts)]
+        L.pp_dev_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts)]
         L.pp_dev_ingest_batch.argtypes = [vp, C.POINTER(AlnBatch)]
         L.pp_dev_ingest_batch.restype = None
         L.pp_dev_ingest_free.argtypes = [vp]

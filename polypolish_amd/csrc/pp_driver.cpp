@@ -220,9 +220,9 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
 
     lap("assembly loaded");
     // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
-    // parse) with PP_DEVICE_INGEST=0, with --debug (the TSV needs the read bytes on the host) and in the fused command
+    // parse) with PP_DEVICE_INGEST=0 and with --debug (the TSV needs the read bytes on the host)
     log("Loading alignments\n");
-    const bool dev_ingest = !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path && !pass;
+    const bool dev_ingest = !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
     rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
@@ -231,7 +231,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;
         if (dev_ingest) {
-            rc = pp_dev_ingest_sam(dg, sams[i], &c);
+            rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
             if (rc) break;
         } else {
             rc = pass ? pp_ingest_sam_filtered(g, sams[i], pass[i], n_pass[i], &c, err, sizeof err)

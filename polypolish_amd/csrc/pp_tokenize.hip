@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void k_tok_group_first(u32 n_aln, const u32 *_
 __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
                                                    const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
                                                    const u32 *__restrict__ group_first, u32 n_groups, u64 n_lines,
-                                                   u32 max_errors, int careful, u32 *__restrict__ good,
+                                                   u32 max_errors, int careful, const u8 *__restrict__ pass,
+                                                   u32 *__restrict__ good,
                                                    u32 *__restrict__ kk, u32 *__restrict__ src_rec,
                                                    u32 *__restrict__ g_seq_len, u32 *__restrict__ g_ncig,
                                                    u64 *__restrict__ status) {
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, 
         if (a.n_runs == 0) { report(status, key); return; }  // empty expanded CIGAR: the reference panics
         const u32 f = a.bits & 15u, l = (a.bits >> 4) & 15u;
         const bool ends_ok = (f == PP_OP_M || f == PP_OP_EQ) && (l == PP_OP_M || l == PP_OP_EQ);
-        if (ends_ok && a.nm <= max_errors && ((a.bits >> 8) & 1u)) { good[r] = 1; n_good++; }
+        // pass: the filter's verdict for this aligned record, as if "ZP:Z:fail" were on its line
+        if (ends_ok && a.nm <= max_errors && ((a.bits >> 8) & 1u) && (!pass || pass[r])) { good[r] = 1; n_good++; }
     }
     const LineRec &s = rec[rec_line[src]];
     for (u32 r = r0; r < r1; r++) {
@@ -482,7 +484,7 @@ struct pp_dev_ingest {
     u32 t_mask = 0;
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
-        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff;
+        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
     // output (grows over the files)
     pp::DevBuf o_contig, o_ref_start, o_k, o_seq_len, o_n_cig, o_cigar, o_seq_off, o_cig_off, o_seq;
     u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
@@ -574,7 +576,7 @@ extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     (void)hipStreamSynchronize(D->ctx->stream);
     pp::DevBuf *all[] = {&D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
-                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff,
+                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
                          &D->o_cig_off, &D->o_seq};
     for (pp::DevBuf *b : all) pp::dev_free(*b);
@@ -639,6 +641,11 @@ static int describe_error(pp_dev_ingest *D, const char *path, const char *text, 
 }
 
 extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_counts *counts) {
+    return pp_dev_ingest_sam_filtered(D, path, nullptr, 0, counts);
+}
+
+extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, const uint8_t *pass, uint64_t n_pass,
+                                          pp_sam_counts *counts) {
     if (!D || !path) return PP_ERR_ARG;
     pp_ctx *ctx = D->ctx;
     hipStream_t st = ctx->stream;
@@ -697,6 +704,17 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
     lap("lines parsed");
     // ---- read groups and gates ----
     u32 n_groups = 0;
+    const u8 *d_pass = nullptr;
+    if (pass && n_aln) {
+        if (n_pass != n_aln)  // cannot be a parse error's doing: those are reported first, below
+            pass = nullptr;
+        else {
+            ENS(d_pass, n_aln);
+            PP_HIPCHK(ctx, hipMemcpyAsync(D->d_pass.p, pass, n_aln, hipMemcpyHostToDevice, st));
+            d_pass = (const u8 *)D->d_pass.p;
+        }
+    }
+    const bool pass_mismatch = n_pass && !d_pass && n_aln;
     if (n_aln) {
         ENS(d_recline, (u64)n_aln * 4);
         ENS(d_isstart, (u64)n_aln * 4);
@@ -715,7 +733,7 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
                            (const u32 *)D->d_grpofrec.p, n_groups, (u32 *)D->d_gfirst.p);
         hipLaunchKernelGGL(k_tok_group, dim3((n_groups + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                            (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, (const u32 *)D->d_gfirst.p, n_groups,
-                           n_lines, D->max_errors, D->careful, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
+                           n_lines, D->max_errors, D->careful, d_pass, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
                            (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, d_status);
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p))) return rc;
         if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gseq.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
@@ -732,6 +750,8 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
         if (counts) *counts = c;
         return describe_error(D, path, F.text, size, status, n_lines, n_nl, rec_line, group_first);
     }
+    if (pass_mismatch)
+        return ctx->fail(PP_ERR_ARG, "%llu filter verdicts for the %u aligned records of \"%s\"", (unsigned long long)n_pass, n_aln, path);
     if (n_aln == 0)  // the EOF flush of an empty group (alignment.rs:268, :319)
         return ctx->fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
     u32 n_good = 0;
