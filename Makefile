@@ -10,11 +10,11 @@ OUT      := polypolish_amd/_build
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 LIB  := $(OUT)/libpolypolish_hip.so
-OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o
+OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o
 
 all: $(LIB) bin/polypolish oracle
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_internal.h $(CSRC)/pp_host.h include/polypolish_hip.h
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_internal.h $(CSRC)/pp_host.h $(CSRC)/pp_devtext.h include/polypolish_hip.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -203,6 +203,7 @@ typedef struct {
     const uint32_t *read;       /* read number of each alignment */
     const uint32_t *grp_off;    /* n_reads+1 */
     const uint32_t *grp_idx;    /* n_aln */
+    const uint64_t *ref_end;    /* optional: precomputed get_ref_end per alignment; then cig_off / n_cig / cigar are not read */
 } pp_filter_file;
 
 typedef struct {
@@ -244,6 +245,22 @@ void pp_filter_loaded_input(const pp_filter_loaded *loaded, pp_filter_input *in)
 int pp_filter_write(const pp_filter_loaded *loaded, int file, const uint8_t *pass, const char *out_path,
                     uint64_t *pass_count, uint64_t *fail_count, char *err, size_t errlen);
 void pp_filter_loaded_free(pp_filter_loaded *loaded);
+
+/* The same load on the DEVICE: both texts are uploaded; quick parse, get_ref_end, QNAME / RNAME interning
+ * (device hash tables) and the per-file group index run as kernels.  pp_filter_dev_input gives the
+ * pp_filter_input view in DEVICE memory (ref_end filled in, no CIGAR arrays) for pp_filter_begin(..., PP_MEM_DEVICE);
+ * it equals pp_filter_load's result except that RNAME ids are arbitrary.  The host mappings of the two files
+ * stay open inside the object (pp_filter_dev_text) for pp_filter_write_text. */
+typedef struct pp_filter_dev pp_filter_dev;
+int pp_filter_load_device(pp_ctx *ctx, const char *in1, const char *in2, pp_filter_dev **out,
+                          pp_filter_file_counts counts[2]);
+void pp_filter_dev_input(const pp_filter_dev *loaded, pp_filter_input *in);
+const char *pp_filter_dev_text(const pp_filter_dev *loaded, int file, uint64_t *size);
+void pp_filter_dev_free(pp_filter_dev *loaded);
+/* filter_sam (src/filter.rs:309-349) straight from a SAM text in memory: pass = HOST array over its aligned
+ * records (lines that are neither headers nor FLAG & 4), in file order. */
+int pp_filter_write_text(const char *text, uint64_t size, const uint8_t *pass, uint64_t n_pass, const char *out_path,
+                         uint64_t *pass_count, uint64_t *fail_count, char *err, size_t errlen);
 
 /* ---- host ingest (text -> SoA) -------------------------------------------------------------- */
 typedef struct pp_assembly pp_assembly;

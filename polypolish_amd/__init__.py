@@ -87,7 +87,7 @@ class FilterReport(C.Structure):
 class FilterFile(C.Structure):
     _fields_ = [("n_aln", C.c_uint64), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p), ("flags", C.c_void_p),
                 ("cig_off", C.c_void_p), ("n_cig", C.c_void_p), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64),
-                ("read", C.c_void_p), ("grp_off", C.c_void_p), ("grp_idx", C.c_void_p)]
+                ("read", C.c_void_p), ("grp_off", C.c_void_p), ("grp_idx", C.c_void_p), ("ref_end", C.c_void_p)]
 
 
 class FilterInput(C.Structure):
@@ -106,6 +106,7 @@ EXPORTS = [
     "pp_debug_extra_free", "pp_ctx_set_profiling",
     "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
     "pp_filter_kernel_times", "pp_filter_load", "pp_filter_loaded_input", "pp_filter_write", "pp_filter_loaded_free",
+    "pp_filter_load_device", "pp_filter_dev_input", "pp_filter_dev_text", "pp_filter_dev_free", "pp_filter_write_text",
     "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
     "pp_assembly_name", "pp_assembly_description", "pp_assembly_offsets", "pp_assembly_bases",
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
@@ -160,6 +161,15 @@ def lib():
                                       C.c_char_p, C.c_size_t]
         L.pp_filter_loaded_free.argtypes = [vp]
         L.pp_filter_loaded_free.restype = None
+        L.pp_filter_load_device.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(FilterFileCounts)]
+        L.pp_filter_dev_input.argtypes = [vp, C.POINTER(FilterInput)]
+        L.pp_filter_dev_input.restype = None
+        L.pp_filter_dev_text.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+        L.pp_filter_dev_text.restype = vp
+        L.pp_filter_dev_free.argtypes = [vp]
+        L.pp_filter_dev_free.restype = None
+        L.pp_filter_write_text.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                           C.c_char_p, C.c_size_t]
         L.pp_assembly_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.pp_assembly_free.argtypes = [vp]
         L.pp_assembly_free.restype = None
@@ -332,6 +342,50 @@ class FilterLoaded:
     def close(self):
         if self._h:
             lib().pp_filter_loaded_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FilterLoadedDevice:
+    """pp_filter_load_device: the same load on the GPU; `files[f]` holds copies of the device arrays
+    (ref_end instead of the CIGAR arrays), `counts[f]` = (alignments, distinct read names)."""
+
+    def __init__(self, ctx, in1, in2):
+        L = lib()
+        self._h = C.c_void_p()
+        fc = (FilterFileCounts * 2)()
+        rc = L.pp_filter_load_device(ctx._h, str(in1).encode(), str(in2).encode(), C.byref(self._h), fc)
+        self.counts = [(c.alignments, c.reads) if c.loaded else None for c in fc]
+        if rc:
+            self._h = C.c_void_p()
+            raise PolypolishError(rc, L.pp_last_error(ctx._h).decode())
+        self.input = FilterInput()
+        L.pp_filter_dev_input(self._h, C.byref(self.input))
+        self.n_reads = int(self.input.n_reads)
+        self.files = []
+        for f in range(2):
+            d = self.input.file[f]
+            n = int(d.n_aln)
+
+            def arr(ptr, cnt, dt):
+                a = np.zeros(cnt, dtype=dt)
+                if cnt and ptr:
+                    ctx._chk(L.pp_ctx_download(ctx._h, a.ctypes.data, ptr, a.nbytes))
+                return a
+            self.files.append({
+                "ref_id": arr(d.ref_id, n, np.uint32), "ref_start": arr(d.ref_start, n, np.uint32),
+                "flags": arr(d.flags, n, np.uint32), "ref_end": arr(d.ref_end, n, np.uint64),
+                "read": arr(d.read, n, np.uint32), "grp_off": arr(d.grp_off, self.n_reads + 1, np.uint32),
+                "grp_idx": arr(d.grp_idx, n, np.uint32)})
+
+    def close(self):
+        if self._h:
+            lib().pp_filter_dev_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -118,7 +118,7 @@ static FileDev file_dev(const pp_ctx *ctx, int f) {
     const pp_filter_file &d = ctx->fdev.file[f];
     FileDev r;
     r.ref_id = d.ref_id; r.ref_start = d.ref_start; r.flags = d.flags; r.grp_off = d.grp_off;
-    r.grp_idx = d.grp_idx; r.read = d.read; r.ref_end = (const u64 *)ctx->f_refend[f].p; r.n_aln = d.n_aln;
+    r.grp_idx = d.grp_idx; r.read = d.read; r.ref_end = (const u64 *)ctx->f_refend_ptr[f]; r.n_aln = d.n_aln;
     return r;
 }
 
@@ -127,8 +127,7 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!in) return ctx->fail(PP_ERR_ARG, "pp_filter_begin: null input");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (auto &t : ctx->timers) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    ctx->timers.clear();
+    timers_release(ctx);
     ctx->fdev = *in;
     for (int f = 0; f < 2; f++) {
         const pp_filter_file &s = in->file[f];
@@ -145,15 +144,24 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
         UPF(0, ref_id, uint32_t, n)
         UPF(1, ref_start, uint32_t, n)
         UPF(2, flags, uint32_t, n)
-        UPF(3, cig_off, uint64_t, n)
-        UPF(4, n_cig, uint32_t, n)
-        UPF(5, cigar, uint32_t, s.n_cig_total)
+        if (!s.ref_end) {
+            UPF(3, cig_off, uint64_t, n)
+            UPF(4, n_cig, uint32_t, n)
+            UPF(5, cigar, uint32_t, s.n_cig_total)
+        }
         UPF(6, read, uint32_t, n)
         UPF(7, grp_idx, uint32_t, n)
         UPF(8, grp_off, uint32_t, (size_t)in->n_reads + 1)
 #undef UPF
+        if (s.ref_end) {  // precomputed (the device loader): adopt or upload, no k_ref_end
+            rc = up(ctx, ctx->f_refend[f], s.ref_end, n * 8, mem, &p);
+            if (rc) return rc;
+            ctx->f_refend_ptr[f] = (const uint64_t *)p;
+            continue;
+        }
         rc = dev_ensure(ctx, ctx->f_refend[f], n * 8);
         if (rc) return rc;
+        ctx->f_refend_ptr[f] = (const uint64_t *)ctx->f_refend[f].p;
         if (n) {
             timer_begin(ctx, "ref_end");
             hipLaunchKernelGGL(k_ref_end, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64)n,

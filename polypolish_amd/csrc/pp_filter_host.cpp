@@ -580,16 +580,131 @@ extern "C" int pp_filter_write(const pp_filter_loaded *L, int f, const uint8_t *
     return PP_OK;
 }
 
+// Internal (the device loader's error path): what load_alignments says about ONE line.
+extern "C" int pp_filter_line_error_(const char *line, size_t n, const char *path, uint64_t line_no, char *err, size_t errlen) {
+    Slice S;
+    S.beg = line;
+    S.end = line + n;
+    parse_slice(S, line);
+    const unsigned long long ln = (unsigned long long)line_no;
+    switch (S.err) {
+    case E_NONE: return PP_OK;
+    case E_COLUMNS: snprintf(err, errlen, "too few columns in \"%s\" (line %llu)", path, ln); return PP_ERR_QUIT;
+    case E_NUMBER: snprintf(err, errlen, "could not parse FLAG or POS in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
+    case E_POS_LIMIT: snprintf(err, errlen, "POS beyond 2^32 in \"%s\" (line %llu)", path, ln); return PP_ERR_LIMIT;
+    default: snprintf(err, errlen, "CIGAR run length overflow in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
+    }
+}
+
+// filter_sam (filter.rs:309-349) from a text in memory: the lines are found again here (in parallel slices);
+// a line is an aligned record when it is not a header and FLAG & 4 is clear -- the text has been validated
+// by the loader that produced the verdicts.
+extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8_t *pass, uint64_t n_pass,
+                                    const char *out_path, uint64_t *pass_count, uint64_t *fail_count, char *err,
+                                    size_t errlen) {
+    if ((!text && size) || !out_path || (!pass && n_pass)) return PP_ERR_ARG;
+    auto write_failed = [&]() {
+        if (err && errlen) snprintf(err, errlen, "unable to write alignments to \"%s\"", out_path);
+        return PP_ERR_QUIT;
+    };
+    const unsigned threads = pph::host_threads((size_t)size);
+    std::vector<const char *> cut;
+    pph::line_slices(text, (size_t)size, threads, cut);
+    auto is_aligned = [](const char *line, size_t l) {
+        if (l == 0 || line[0] == '@') return false;
+        const char *t1 = (const char *)memchr(line, '\t', l);
+        if (!t1) return false;
+        const char *f = t1 + 1, *le = line + l;
+        const char *t2 = (const char *)memchr(f, '\t', (size_t)(le - f));
+        uint64_t flags = 0;
+        if (!parse_u(f, (size_t)((t2 ? t2 : le) - f), 0xFFFFFFFFull, flags)) return false;
+        return (flags & 4) == 0;
+    };
+    // aligned records per slice -> the ordinal of each slice's first one
+    std::vector<uint64_t> first(threads + 1, 0);
+    parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t t = lo; t < hi; t++) {
+            uint64_t n = 0;
+            for (const char *p = cut[t]; p < cut[t + 1];) {
+                const char *nl = (const char *)memchr(p, '\n', (size_t)(cut[t + 1] - p));
+                size_t l = nl ? (size_t)(nl - p) : (size_t)(cut[t + 1] - p);
+                const char *line = p;
+                p += l + (nl ? 1 : 0);
+                if (l > 0 && line[l - 1] == '\r') l--;
+                n += is_aligned(line, l);
+            }
+            first[t + 1] = n;
+        }
+    });
+    for (unsigned t = 0; t < threads; t++) first[t + 1] += first[t];
+    if (first[threads] != n_pass) {
+        if (err && errlen) snprintf(err, errlen, "%llu verdicts for %llu aligned records", (unsigned long long)n_pass,
+                                    (unsigned long long)first[threads]);
+        return PP_ERR_ARG;
+    }
+    std::vector<HugeBuf<char>> out(threads);
+    std::vector<uint64_t> off(threads + 1, 0), n_ok(threads, 0), n_bad(threads, 0);
+    parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t t = lo; t < hi; t++) {
+            HugeBuf<char> &B = out[t];
+            B.reserve((size_t)(cut[t + 1] - cut[t]) + 11 * (size_t)(first[t + 1] - first[t]) + 16);
+            char *w = B.data();
+            uint64_t a = first[t];
+            for (const char *p = cut[t]; p < cut[t + 1];) {
+                const char *nl = (const char *)memchr(p, '\n', (size_t)(cut[t + 1] - p));
+                size_t l = nl ? (size_t)(nl - p) : (size_t)(cut[t + 1] - p);
+                const char *line = p;
+                p += l + (nl ? 1 : 0);
+                if (l > 0 && line[l - 1] == '\r') l--;
+                memcpy(w, line, l);
+                w += l;
+                if (is_aligned(line, l)) {
+                    if (pass[a++]) n_ok[t]++;
+                    else { memcpy(w, "\tZP:Z:fail", 10); w += 10; n_bad[t]++; }
+                }
+                *w++ = '\n';
+            }
+            B.n = (size_t)(w - B.data());
+            off[t + 1] = B.n;
+        }
+    });
+    for (unsigned t = 0; t < threads; t++) off[t + 1] += off[t];
+    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return write_failed();
+    std::atomic<int> bad{0};
+    parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t t = lo; t < hi; t++) {
+            uint64_t done = 0;
+            while (done < out[t].n) {
+                const ssize_t r = pwrite(fd, out[t].data() + done, out[t].n - done, (off_t)(off[t] + done));
+                if (r <= 0) { bad = 1; break; }
+                done += (uint64_t)r;
+            }
+        }
+    });
+    if (close(fd) != 0 || bad) return write_failed();
+    uint64_t p_ = 0, f_ = 0;
+    for (unsigned t = 0; t < threads; t++) { p_ += n_ok[t]; f_ += n_bad[t]; }
+    if (pass_count) *pass_count = p_;
+    if (fail_count) *fail_count = f_;
+    return PP_OK;
+}
+
 namespace {
 
 struct FilterRun {
-    pp_filter_loaded *L = nullptr;
+    pp_filter_loaded *L = nullptr;  // host load ...
+    pp_filter_dev *DL = nullptr;    // ... or device load (the default)
+    uint64_t n_aln[2] = {0, 0};
     std::vector<uint8_t> pass[2];
     uint64_t before = 0;
     uint32_t lo = 0, hi = 0;
     int correct = -1;
     uint64_t counts[4] = {0, 0, 0, 0};
-    ~FilterRun() { pp_filter_loaded_free(L); }
+    ~FilterRun() {
+        pp_filter_loaded_free(L);
+        pp_filter_dev_free(DL);
+    }
 };
 
 // load_alignments + get_insert_size_thresholds + the pass/fail verdicts (filter.rs:26-34 without filter_sams)
@@ -598,23 +713,26 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     auto set_err = [&](int code, const char *msg) { return pp_ctx_set_error_(ctx, code, msg); };
     log("Loading alignments\n");
     const char *ins[2] = {in1, in2};
-    pp_filter_loaded *L = nullptr;
+    const bool dev_load = !(getenv("PP_DEVICE_FILTER") && atoi(getenv("PP_DEVICE_FILTER")) == 0);
     pp_filter_file_counts fc[2];
     char err[1400] = "";
-    int rc = pp_filter_load(in1, in2, &L, fc, err, sizeof err);
+    int rc;
+    if (dev_load) rc = pp_filter_load_device(ctx, in1, in2, &R.DL, fc);
+    else rc = pp_filter_load(in1, in2, &R.L, fc, err, sizeof err);
     for (int f = 0; f < 2; f++)
         if (fc[f].loaded)
             log("%s: %s alignments from %s reads\n", ins[f], commas(fc[f].alignments).c_str(), commas(fc[f].reads).c_str());
-    if (rc) return set_err(rc, err);
-    R.L = L;
+    if (rc) return dev_load ? rc : set_err(rc, err);
     lap("alignments loaded");
     log("\n");
-    const uint32_t n_reads = L->n_reads;
-    R.before = L->before;
-
     pp_filter_input in;
-    pp_filter_loaded_input(L, &in);
-    rc = pp_filter_begin(ctx, &in, PP_MEM_HOST);
+    if (dev_load) pp_filter_dev_input(R.DL, &in);
+    else pp_filter_loaded_input(R.L, &in);
+    const uint32_t n_reads = in.n_reads;
+    R.n_aln[0] = in.file[0].n_aln;
+    R.n_aln[1] = in.file[1].n_aln;
+    R.before = R.n_aln[0] + R.n_aln[1];
+    rc = pp_filter_begin(ctx, &in, dev_load ? PP_MEM_DEVICE : PP_MEM_HOST);
     if (rc) return rc;
 
     // get_insert_size_thresholds, filter.rs:148-186 (samples from the device, reduction on the host)
@@ -658,7 +776,7 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     lap("thresholds");
 
     // alignment_pass_qc for every alignment of both files (filter.rs:352-377)
-    for (int f = 0; f < 2; f++) R.pass[f].resize(L->F[f].n_aln ? L->F[f].n_aln : 1);
+    for (int f = 0; f < 2; f++) R.pass[f].resize(R.n_aln[f] ? R.n_aln[f] : 1);
     rc = pp_filter_pairs(ctx, lo, hi, (uint8_t)correct, R.pass[0].data(), R.pass[1].data());
     if (rc) return rc;
     lap("pass flags from the device");
@@ -675,7 +793,14 @@ int filter_write(pp_ctx *ctx, const Log &log, const FilterRun &R, const char *co
     log("Filtering SAM files\n");
     for (int f = 0; f < 2; f++) {
         uint64_t p_ = 0, f_ = 0;
-        const int rc = pp_filter_write(R.L, f, R.pass[f].data(), outs[f], &p_, &f_, err, sizeof err);
+        int rc;
+        if (R.DL) {
+            uint64_t size = 0;
+            const char *text = pp_filter_dev_text(R.DL, f, &size);
+            rc = pp_filter_write_text(text, size, R.pass[f].data(), R.n_aln[f], outs[f], &p_, &f_, err, sizeof err);
+        } else {
+            rc = pp_filter_write(R.L, f, R.pass[f].data(), outs[f], &p_, &f_, err, sizeof err);
+        }
         if (rc) return pp_ctx_set_error_(ctx, rc, err);
         log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(p_).c_str(), commas(f_).c_str());
         *after += p_;
@@ -762,7 +887,7 @@ extern "C" int pp_filter_polish_files(pp_ctx *ctx, const char *assembly, const c
         lap("filtered SAMs written");
     } else {
         for (int f = 0; f < 2; f++)
-            for (uint64_t i = 0; i < R.L->F[f].n_aln; i++) after += R.pass[f][i];
+            for (uint64_t i = 0; i < R.n_aln[f]; i++) after += R.pass[f][i];
     }
     if (report) {
         report->before_count = R.before;
@@ -775,8 +900,10 @@ extern "C" int pp_filter_polish_files(pp_ctx *ctx, const char *assembly, const c
     log("Alignments before filtering: %s\nAlignments after filtering:  %s\n", commas(R.before).c_str(), commas(after).c_str());
     // the verdicts go straight into the polish ingest; the filter's parse-time memory is released first
     const uint8_t *pass[2] = {R.pass[0].data(), R.pass[1].data()};
-    const uint64_t n_pass[2] = {R.L->F[0].n_aln, R.L->F[1].n_aln};
+    const uint64_t n_pass[2] = {R.n_aln[0], R.n_aln[1]};
     pp_filter_loaded_free(R.L);
     R.L = nullptr;
+    pp_filter_dev_free(R.DL);
+    R.DL = nullptr;
     return pp_polish_files_filtered_(ctx, assembly, ins, 2, opt, fasta, pass, n_pass);
 }

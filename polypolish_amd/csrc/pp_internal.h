@@ -104,6 +104,7 @@ struct pp_ctx {
     // ---- filter job ----
     pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert;
     pp_filter_input fdev{};
+    const uint64_t *f_refend_ptr[2] = {nullptr, nullptr};
     bool filter_open = false;
 
     int fail(int code, const char *fmt, ...) {
@@ -133,5 +134,6 @@ void dev_free(DevBuf &b);
 void timer_begin(pp_ctx *ctx, const char *name);
 void timer_end(pp_ctx *ctx);
 int timers_collect(pp_ctx *ctx, pp_kernel_times *out);
+void timers_release(pp_ctx *ctx);
 
 }  // namespace pp

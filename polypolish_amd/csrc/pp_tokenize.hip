@@ -14,7 +14,7 @@
 //   event key = 2 * line          a line that fails to parse
 //               2 * line + 1      a read group that fails when it is flushed, i.e. when `line` -- the first
 //                                 record of the next group -- has been parsed (EOF: line = number of lines)
-#include "pp_internal.h"
+#include "pp_devtext.h"
 #include "pp_host.h"
 
 #include <algorithm>
@@ -28,11 +28,6 @@ extern "C" int pp_ingest_text_(pp_ingest *I, const char *path, const char *text,
 
 namespace {
 
-typedef unsigned long long u64;
-typedef uint32_t u32;
-typedef uint8_t u8;
-
-constexpr u32 NL_BLOCK = 1024 * 64;  // bytes of text per block of the newline kernels (64 per thread)
 enum { K_SKIP = 0, K_UNALIGNED = 1, K_ALIGNED = 2 };
 
 struct LineRec {          // one parsed line (offsets relative to the start of the line)
@@ -41,167 +36,7 @@ struct LineRec {          // one parsed line (offsets relative to the start of t
     u32 seq_off, seq_len, bits, pad;  // bits: first op | last op << 4 | pass_qc << 8 | start beyond u32 << 9
 };
 
-__device__ __forceinline__ void report(u64 *status, u64 key) { atomicMin(status, key); }
-
-// ---- newline index -------------------------------------------------------------------------------
-__device__ __forceinline__ u32 count_nl16(uint4 v) {
-    u32 n = 0;
-    const u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const u32 x = w[i] ^ 0x0A0A0A0Au;  // zero bytes where the text has '\n'
-        n += (u32)__popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
-    }
-    return n;
-}
-
-// text is padded with zeros up to a multiple of NL_BLOCK
-__global__ __launch_bounds__(1024) void k_nl_count(const u8 *__restrict__ text, u32 *__restrict__ blk_cnt) {
-    __shared__ u32 s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    const uint4 *p = (const uint4 *)(text + (u64)blockIdx.x * NL_BLOCK + (u64)threadIdx.x * 64u);
-    const u32 n = count_nl16(p[0]) + count_nl16(p[1]) + count_nl16(p[2]) + count_nl16(p[3]);
-    u32 v = n;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&s_sum, v);
-    __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_sum;
-}
-
-__global__ __launch_bounds__(1024) void k_nl_write(const u8 *__restrict__ text, const u64 *__restrict__ blk_off,
-                                                   u64 *__restrict__ nl_pos) {
-    __shared__ u32 s_w[16];
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u64 base = (u64)blockIdx.x * NL_BLOCK + (u64)threadIdx.x * 64u;
-    const uint4 *p = (const uint4 *)(text + base);
-    const u32 n = count_nl16(p[0]) + count_nl16(p[1]) + count_nl16(p[2]) + count_nl16(p[3]);
-    u32 inc = n;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 t = __shfl_up(inc, o, 64);
-        if ((int)lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    u32 before = inc - n;
-    for (u32 i = 0; i < wave; i++) before += s_w[i];
-    if (!n) return;
-    u64 out = blk_off[blockIdx.x] + before;
-    for (u32 i = 0; i < 64; i++)
-        if (text[base + i] == (u8)'\n') nl_pos[out++] = base + i;
-}
-
-// ---- exclusive scan: u32 in -> T out (n + 1 entries) -- block sums, a single-block scan of the sums,
-// then every block scans its own 8192 elements on top of its base ------------------------------------
-constexpr u32 SCAN_PER_BLOCK = 1024 * 8;
-
-__global__ __launch_bounds__(1024) void k_scan_sums(const u32 *__restrict__ in, u64 n, u32 *__restrict__ sums) {
-    __shared__ u32 s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * 8u;
-    u32 v = 0;
-#pragma unroll
-    for (u32 i = 0; i < 8; i++)
-        if (base + i < n) v += in[base + i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&s_sum, v);
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = s_sum;
-}
-
-template <typename T>
-__global__ __launch_bounds__(1024) void k_tscan(const u32 *__restrict__ in, u64 n, T *__restrict__ out) {
-    __shared__ u64 part[1024];
-    const u32 t = threadIdx.x;
-    const u64 per = (n + 1023) / 1024;
-    const u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
-    u64 s = 0;
-    for (u64 i = lo; i < hi; i++) s += in[i];
-    part[t] = s;
-    __syncthreads();
-    for (u32 off = 1; off < 1024; off <<= 1) {
-        const u64 v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u64 run = part[t] - s;
-    for (u64 i = lo; i < hi; i++) {
-        out[i] = (T)run;
-        run += in[i];
-    }
-    if (t == 1023) out[n] = (T)part[1023];
-}
-
-template <typename T>
-__global__ __launch_bounds__(1024) void k_scan_apply(const u32 *__restrict__ in, u64 n, const u64 *__restrict__ sums_off,
-                                                     T *__restrict__ out) {
-    __shared__ u32 s_w[16];
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * 8u;
-    u32 v[8], sum = 0;
-#pragma unroll
-    for (u32 i = 0; i < 8; i++) {
-        v[i] = base + i < n ? in[base + i] : 0u;
-        sum += v[i];
-    }
-    u32 inc = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 t = __shfl_up(inc, o, 64);
-        if ((int)lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    u64 run = sums_off[blockIdx.x] + (inc - sum);
-    for (u32 i = 0; i < wave; i++) run += s_w[i];
-#pragma unroll
-    for (u32 i = 0; i < 8; i++) {
-        if (base + i < n) out[base + i] = (T)run;
-        run += v[i];
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (T)sums_off[gridDim.x];
-}
-
 // ---- per-line parse (Alignment::new) ---------------------------------------------------------------
-__device__ __forceinline__ bool parse_u(const u8 *s, u32 n, u64 max, u64 &out) {  // str::parse::<uN>()
-    u32 i = 0;
-    if (n == 0) return false;
-    if (s[0] == (u8)'+') { i = 1; if (n == 1) return false; }
-    u64 v = 0;
-    for (; i < n; i++) {
-        if (s[i] < (u8)'0' || s[i] > (u8)'9') return false;
-        const u64 d = (u64)(s[i] - (u8)'0');
-        if (v > (max - d) / 10) return false;
-        v = v * 10 + d;
-    }
-    out = v;
-    return true;
-}
-
-// index of the first '\t' in L[from, n), or n -- eight bytes per step (the text buffer is padded, so a load
-// may run past the line; matches beyond n are cut off)
-__device__ __forceinline__ u32 find_tab(const u8 *L, u32 from, u32 n) {
-    u32 i = from;
-    while (i < n) {
-        u64 w;
-        __builtin_memcpy(&w, L + i, 8);
-        const u64 x = w ^ 0x0909090909090909ull;
-        const u64 m = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;  // bit 7 of the zero bytes (first one exact)
-        if (m) return min(n, i + ((u32)__ffsll((long long)m) - 1u) / 8u);
-        i += 8;
-    }
-    return n;
-}
-
-__device__ __forceinline__ int op_code(u8 c) {
-    switch (c) {
-    case 'M': return PP_OP_M; case 'I': return PP_OP_I; case 'D': return PP_OP_D; case 'N': return PP_OP_N;
-    case 'S': return PP_OP_S; case 'H': return PP_OP_H; case 'P': return PP_OP_P; case '=': return PP_OP_EQ;
-    case 'X': return PP_OP_X; default: return -1;
-    }
-}
-
 __device__ __forceinline__ u32 fnv1a(const u8 *s, u32 n) {
     u32 h = 2166136261u;
     for (u32 i = 0; i < n; i++) h = (h ^ s[i]) * 16777619u;
@@ -491,42 +326,6 @@ struct pp_dev_ingest {
 };
 
 namespace {
-
-// grow a device buffer keeping its first `used` bytes
-int dev_grow(pp_ctx *ctx, pp::DevBuf &b, size_t need, size_t used) {
-    if (need == 0) need = 16;
-    if (b.cap >= need) return PP_OK;
-    const size_t want = need + need / 4 + 256;
-    void *q = nullptr;
-    PP_HIPCHK(ctx, hipMalloc(&q, want));
-    if (b.p && used) PP_HIPCHK(ctx, hipMemcpyAsync(q, b.p, used, hipMemcpyDeviceToDevice, ctx->stream));
-    if (b.p) {
-        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        PP_HIPCHK(ctx, hipFree(b.p));
-    }
-    b.p = q;
-    b.cap = want;
-    return PP_OK;
-}
-
-// out[0..n] = exclusive scan of in[0..n); scratch: two small device buffers for the block sums
-template <typename T>
-int scan_u32(pp_ctx *ctx, pp::DevBuf &b_sums, pp::DevBuf &b_sums_off, const u32 *in, u64 n, T *out) {
-    const u64 nb = std::max<u64>(1, (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
-    if (int rc = pp::dev_ensure(ctx, b_sums, nb * 4)) return rc;
-    if (int rc = pp::dev_ensure(ctx, b_sums_off, (nb + 1) * 8)) return rc;
-    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, in, n, (u32 *)b_sums.p);
-    hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)b_sums.p, nb, (u64 *)b_sums_off.p);
-    hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, in, n, (const u64 *)b_sums_off.p, out);
-    return PP_OK;
-}
-
-template <typename T>
-int fetch(pp_ctx *ctx, const void *dev, T *host, size_t n = 1) {
-    PP_HIPCHK(ctx, hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PP_OK;
-}
 
 }  // namespace
 

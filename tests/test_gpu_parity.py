@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
 inputs.  Bit-exact everywhere: polished bytes, contig offsets, per-position f64 depth, counters,
 thresholds and vote status; filtered SAM bytes; CLI stdout.  Needs an MI355X: `-m gpu`."""
+import ctypes
 import os
 import subprocess
 
@@ -10,6 +11,7 @@ import pytest
 import synth
 
 pytestmark = pytest.mark.gpu
+C_u64 = ctypes.c_uint64
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 POS_KEYS = ("depth", "count_a", "count_c", "count_g", "count_t", "count_other", "valid_thr", "invalid_thr", "status")
@@ -432,6 +434,22 @@ def test_device_tokenizer_details_and_errors(pp, ctx, orc, tmp_path):
     # two files: the batch grows across calls
     want, err = _same_ingest(pp, ctx, str(fa), [str(sam), str(sam)])
     assert err is None and len(want[4]["contig"]) == 10
+    # CRLF line ends, with and without a final newline; a file that is one line without newline
+    crlf = tmp_path / "crlf.sam"
+    crlf.write_bytes(good.replace("\n", "\r\n").encode())
+    want, err = _same_ingest(pp, ctx, str(fa), [str(crlf)])
+    assert err is None and len(want[4]["contig"]) == 5
+    crlf.write_bytes((good + "\n").replace("\n", "\r\n").encode())
+    assert _same_ingest(pp, ctx, str(fa), [str(crlf)])[1] is None
+    crlf.write_text(line("solo", 0, "e", 1, "4M", "GGGG").rstrip("\n"))
+    want, err = _same_ingest(pp, ctx, str(fa), [str(crlf)])
+    assert err is None and list(want[4]["seq_len"]) == [4]
+    # `polish` without any SAM file is legal (every position low_depth): the CLI through either ingest
+    want_fasta = orc.polish_files(str(fa), [])["fasta"]
+    for mode in ("1", "0"):
+        r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "polish", str(fa)], capture_output=True,
+                           env=dict(os.environ, PP_DEVICE_INGEST=mode))
+        assert r.returncode == 0 and r.stdout == want_fasta, r.stderr.decode()[-500:]
 
 
 @pytest.mark.parametrize("case", FILE_CASES[:3], ids=["seed31", "seed32", "seed33"])
@@ -447,6 +465,87 @@ def test_cli_with_either_ingest(orc, tmp_path, case):
         assert r.returncode == 0 and r.stdout == want["fasta"], r.stderr.decode()[-800:]
         log = r.stderr.decode()
         assert f"{want['counts'][1]:,} alignments kept" in log
+
+
+def _host_ref_end(F):
+    cig = F["cigar"].astype(np.int64)
+    consumes = np.isin(cig & 15, (0, 2, 3, 7, 8))
+    cs = np.concatenate([[0], np.cumsum((cig >> 4) * consumes)])
+    lo = F["cig_off"].astype(np.int64)
+    return (F["ref_start"].astype(np.int64) + cs[lo + F["n_cig"].astype(np.int64)] - cs[lo]).astype(np.uint64)
+
+
+@pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
+def test_device_filter_load_equals_host_load(pp, ctx, tmp_path, case):
+    """pp_filter_load_device: quick parse, ref_end, QNAME/RNAME interning and the group index as kernels; the
+    arrays equal the host loader's (RNAME ids up to renaming)."""
+    ds = synth.rich_dataset(str(tmp_path), **case)
+    H = pp.FilterLoaded(ds["sam1"], ds["sam2"])
+    D = pp.FilterLoadedDevice(ctx, ds["sam1"], ds["sam2"])
+    assert D.n_reads == H.n_reads and D.counts == H.counts
+    for f in range(2):
+        h, d = H.files[f], D.files[f]
+        for k in ("flags", "ref_start", "read", "grp_off", "grp_idx"):
+            assert np.array_equal(h[k], d[k]), (f, k)
+        assert np.array_equal(_host_ref_end(h), d["ref_end"])
+    # RNAME ids: the same partition of all records of both files
+    hid = np.concatenate([H.files[0]["ref_id"], H.files[1]["ref_id"]]).astype(np.int64)
+    did = np.concatenate([D.files[0]["ref_id"], D.files[1]["ref_id"]]).astype(np.int64)
+    pairs = set(zip(hid.tolist(), did.tolist()))
+    assert len(pairs) == len(set(hid.tolist())) == len(set(did.tolist()))
+    H.close(); D.close()
+
+
+def test_device_filter_load_details_and_errors(pp, ctx, orc, tmp_path):
+    def line(name, flag, ref, pos, cigar, rest="*\t0\t0\tACGT\t*"):
+        return f"{name}\t{flag}\t{ref}\t{pos}\t60\t{cigar}\t{rest}\n"
+    a, b = tmp_path / "a.sam", tmp_path / "b.sam"
+    a.write_text("@HD\tVN:1\r\n" + line("x", 0, "c", 10, "5M2D3M") + line("y", 16, "d", 0, "4Mzz3=1Q2X") +
+                 line("x", 256, "c", 100, "*") + line("u", 4, "*", 0, "*") + line("z", 0, "c", 7, "10M").rstrip("\n"))
+    b.write_text(line("y", 0, "d", 50, "10M") + line("w", 0, "c", 1, "3M") + line("x", 16, "c", 30, "10M"))
+    D = pp.FilterLoadedDevice(ctx, str(a), str(b))
+    A, B = D.files
+    assert D.counts == [(4, 3), (3, 3)] and D.n_reads == 4
+    assert list(A["ref_start"]) == [9, 0, 99, 6] and list(A["flags"]) == [0, 16, 256, 0]
+    assert list(A["ref_end"]) == [19, 9, 99, 16] and list(B["ref_end"]) == [59, 3, 39]
+    assert list(A["read"]) == [0, 1, 0, 2] and list(B["read"]) == [1, 3, 0]
+    assert [list(A["grp_idx"][A["grp_off"][r]:A["grp_off"][r + 1]]) for r in range(4)] == [[0, 2], [1], [3], []]
+    assert A["ref_id"][0] == A["ref_id"][2] == A["ref_id"][3] == B["ref_id"][1] != A["ref_id"][1] == B["ref_id"][0]
+    D.close()
+    # the tagged output straight from the text
+    out = tmp_path / "o.sam"
+    text = a.read_bytes()
+    p_, f_ = C_u64(), C_u64()
+    err = ctypes.create_string_buffer(600)
+    verdicts = np.array([1, 0, 0, 1], np.uint8)
+    rc = pp.lib().pp_filter_write_text(text, len(text), verdicts.ctypes.data, 4, str(out).encode(), ctypes.byref(p_), ctypes.byref(f_), err, 600)
+    assert rc == 0 and (p_.value, f_.value) == (2, 2)
+    lines = out.read_text().split("\n")
+    assert lines[0] == "@HD\tVN:1" and lines[-1] == "" and [l.endswith("\tZP:Z:fail") for l in lines[1:6]] == [False, True, True, False, False]
+
+    def both(t1, t2):
+        a.write_text(t1); b.write_text(t2)
+        try:
+            pp.FilterLoaded(str(a), str(b)).close()
+            want = (0, "")
+        except pp.PolypolishError as e:
+            want = (e.code, e.msg)
+        try:
+            pp.FilterLoadedDevice(ctx, str(a), str(b)).close()
+            got = (0, "")
+        except pp.PolypolishError as e:
+            got = (e.code, e.msg)
+        return got, want
+    ok = line("r", 0, "c", 1, "4M")
+    many = "".join(line(f"r{i}", 0, "c", 1 + i, "4M") for i in range(3000))
+    for t1, t2 in [(many + "\n" + ok, ok), (many, many[:9000] + "bad\t0\tc\n" + many), ("@HD\tVN:1\n", ok),
+                   (many + "r\t0\tc\t1\n", "zzz"), (ok, "r\tx\tc\t1\t60\t4M\t*\t0\t0\tA\t*\n"),
+                   (ok, line("r", 0, "c", 99999999999, "4M"))]:
+        got, want = both(t1, t2)
+        assert got == want and got[0] != 0, (got, want)
+    for t1, t2 in [(many, many), (many, ""), (many, "@HD\tVN:1\n")]:
+        got, want = both(t1, t2)
+        assert got == want == (0, ""), (got, want)
 
 
 def test_reference_orientation_vectors_on_device(ctx, pp):
