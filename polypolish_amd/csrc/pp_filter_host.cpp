@@ -585,7 +585,8 @@ extern "C" int pp_filter_line_error_(const char *line, size_t n, const char *pat
     Slice S;
     S.beg = line;
     S.end = line + n;
-    parse_slice(S, line);
+    if (n == 0) S.err = E_COLUMNS;  // an empty line (parse_slice would not even see it without its newline)
+    else parse_slice(S, line);
     const unsigned long long ln = (unsigned long long)line_no;
     switch (S.err) {
     case E_NONE: return PP_OK;

@@ -465,6 +465,15 @@ def test_cli_with_either_ingest(orc, tmp_path, case):
         assert r.returncode == 0 and r.stdout == want["fasta"], r.stderr.decode()[-800:]
         log = r.stderr.decode()
         assert f"{want['counts'][1]:,} alignments kept" in log
+    # `polypolish filter` with the load on the device (default) and on the host
+    o1, o2, g1, g2 = (str(tmp_path / n) for n in ("o1.sam", "o2.sam", "g1.sam", "g2.sam"))
+    rep = orc.filter_files(ds["sam1"], ds["sam2"], o1, o2)
+    for mode in ("1", "0"):
+        r = subprocess.run([os.path.join(ROOT, "bin", "polypolish"), "filter", "--in1", ds["sam1"], "--in2", ds["sam2"],
+                            "--out1", g1, "--out2", g2], capture_output=True, env=dict(os.environ, PP_DEVICE_FILTER=mode))
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        assert open(g1, "rb").read() == open(o1, "rb").read() and open(g2, "rb").read() == open(o2, "rb").read()
+        assert f"Alignments after filtering:  {rep['after']:,}" in r.stderr.decode()
 
 
 def _host_ref_end(F):
