@@ -124,10 +124,13 @@ __global__ __launch_bounds__(256) void k_ht_insert(u64 lo, u64 hi, const NameRef
     const NameRef a = names[me];
     u32 i = hash_name(a) & mask;
     for (;;) {
-        const u32 v = atomicCAS(&slots[i], 0u, (u32)me + 1u);
+        // look before touching the slot with an atomic: when every record carries the same RNAME (or the mate's
+        // QNAME is already there) millions of atomics on one address would serialise in L2
+        u32 v = __atomic_load_n(&slots[i], __ATOMIC_RELAXED);
+        if (v == 0) v = atomicCAS(&slots[i], 0u, (u32)me + 1u);
         if (v == 0) return;
         if (same_name(names[v - 1], a)) {  // a slot only ever moves to a smaller index of the SAME name
-            atomicMin(&slots[i], (u32)me + 1u);
+            if ((u32)me + 1u < v) atomicMin(&slots[i], (u32)me + 1u);
             return;
         }
         i = (i + 1) & mask;

@@ -514,6 +514,7 @@ extern "C" void pp_filter_loaded_input(const pp_filter_loaded *L, pp_filter_inpu
         d.cig_off = X.cig_off.data(); d.n_cig = X.n_cig.data(); d.cigar = X.cigar.data();
         d.n_cig_total = X.n_runs; d.read = X.read.data();
         d.grp_off = X.grp_off.data(); d.grp_idx = X.grp_idx.data();
+        d.ref_end = nullptr;  // computed on the device from the CIGAR runs
     }
 }
 
@@ -695,7 +696,7 @@ namespace {
 
 struct FilterRun {
     pp_filter_loaded *L = nullptr;  // host load ...
-    pp_filter_dev *DL = nullptr;    // ... or device load (the default)
+    pp_filter_dev *DL = nullptr;    // ... or device load (PP_DEVICE_FILTER=1)
     uint64_t n_aln[2] = {0, 0};
     std::vector<uint8_t> pass[2];
     uint64_t before = 0;
@@ -714,7 +715,9 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     auto set_err = [&](int code, const char *msg) { return pp_ctx_set_error_(ctx, code, msg); };
     log("Loading alignments\n");
     const char *ins[2] = {in1, in2};
-    const bool dev_load = !(getenv("PP_DEVICE_FILTER") && atoi(getenv("PP_DEVICE_FILTER")) == 0);
+    // PP_DEVICE_FILTER=1: load_alignments as kernels (pp_filter_dev.hip).  Default is the host loader: its parse
+    // overlaps the HIP runtime's start-up, which the device loader has to wait for (measured: 0.86 s vs 1.07 s).
+    const bool dev_load = getenv("PP_DEVICE_FILTER") && atoi(getenv("PP_DEVICE_FILTER")) != 0;
     pp_filter_file_counts fc[2];
     char err[1400] = "";
     int rc;
@@ -726,7 +729,7 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     if (rc) return dev_load ? rc : set_err(rc, err);
     lap("alignments loaded");
     log("\n");
-    pp_filter_input in;
+    pp_filter_input in{};
     if (dev_load) pp_filter_dev_input(R.DL, &in);
     else pp_filter_loaded_input(R.L, &in);
     const uint32_t n_reads = in.n_reads;
