@@ -11,6 +11,8 @@
 // through a lock-free open-addressing table (the reference's HashMap<String, Vec<Alignment>>, keyed by
 // name + "_1"/"_2", becomes a read number shared by both files plus a per-file group index), and the
 // output is formatted per slice and written with pwrite.  Results do not depend on the thread count.
+#include <sys/uio.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -644,30 +646,42 @@ extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8
                                     (unsigned long long)first[threads]);
         return PP_ERR_ARG;
     }
-    std::vector<HugeBuf<char>> out(threads);
+    // The output is the input with a tag spliced in here and there: every slice becomes a list of iovecs that
+    // point INTO the input mapping (stretches of untouched lines) or at the constant tag / newline, written
+    // with pwritev -- no intermediate copy of the gigabytes that do not change.
+    static const char TAG_NL[] = "\tZP:Z:fail\n";
+    std::vector<std::vector<struct iovec>> iov(threads);
     std::vector<uint64_t> off(threads + 1, 0), n_ok(threads, 0), n_bad(threads, 0);
     parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
         for (size_t t = lo; t < hi; t++) {
-            HugeBuf<char> &B = out[t];
-            B.reserve((size_t)(cut[t + 1] - cut[t]) + 11 * (size_t)(first[t + 1] - first[t]) + 16);
-            char *w = B.data();
-            uint64_t a = first[t];
+            std::vector<struct iovec> &V = iov[t];
+            uint64_t a = first[t], bytes = 0;
+            const char *s0 = cut[t];  // start of the current untouched stretch
+            auto emit = [&](const char *p, size_t n) {
+                if (!n) return;
+                V.push_back(iovec{(void *)p, n});
+                bytes += n;
+            };
             for (const char *p = cut[t]; p < cut[t + 1];) {
                 const char *nl = (const char *)memchr(p, '\n', (size_t)(cut[t + 1] - p));
                 size_t l = nl ? (size_t)(nl - p) : (size_t)(cut[t + 1] - p);
                 const char *line = p;
                 p += l + (nl ? 1 : 0);
-                if (l > 0 && line[l - 1] == '\r') l--;
-                memcpy(w, line, l);
-                w += l;
+                const bool cr = l > 0 && line[l - 1] == '\r';
+                if (cr) l--;
+                bool failed = false;
                 if (is_aligned(line, l)) {
                     if (pass[a++]) n_ok[t]++;
-                    else { memcpy(w, "\tZP:Z:fail", 10); w += 10; n_bad[t]++; }
+                    else { failed = true; n_bad[t]++; }
                 }
-                *w++ = '\n';
+                if (failed || cr || !nl) {  // the stretch ends with this line's content; its ending is rewritten
+                    emit(s0, (size_t)(line + l - s0));
+                    if (failed) emit(TAG_NL, 11); else emit(TAG_NL + 10, 1);
+                    s0 = p;
+                }
             }
-            B.n = (size_t)(w - B.data());
-            off[t + 1] = B.n;
+            emit(s0, (size_t)(cut[t + 1] - s0));
+            off[t + 1] = bytes;
         }
     });
     for (unsigned t = 0; t < threads; t++) off[t + 1] += off[t];
@@ -676,11 +690,18 @@ extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8
     std::atomic<int> bad{0};
     parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
         for (size_t t = lo; t < hi; t++) {
-            uint64_t done = 0;
-            while (done < out[t].n) {
-                const ssize_t r = pwrite(fd, out[t].data() + done, out[t].n - done, (off_t)(off[t] + done));
-                if (r <= 0) { bad = 1; break; }
-                done += (uint64_t)r;
+            std::vector<struct iovec> &V = iov[t];
+            uint64_t pos = off[t];
+            size_t i = 0;
+            while (i < V.size()) {
+                const int cnt = (int)std::min<size_t>(1024, V.size() - i);
+                ssize_t r = pwritev(fd, &V[i], cnt, (off_t)pos);
+                if (r <= 0) { bad = 1; return; }
+                pos += (uint64_t)r;
+                while (r > 0 && i < V.size()) {  // advance over what was written (a short write cuts an iovec)
+                    if ((size_t)r >= V[i].iov_len) { r -= (ssize_t)V[i].iov_len; i++; }
+                    else { V[i].iov_base = (char *)V[i].iov_base + r; V[i].iov_len -= (size_t)r; r = 0; }
+                }
             }
         }
     });
@@ -797,14 +818,11 @@ int filter_write(pp_ctx *ctx, const Log &log, const FilterRun &R, const char *co
     log("Filtering SAM files\n");
     for (int f = 0; f < 2; f++) {
         uint64_t p_ = 0, f_ = 0;
-        int rc;
-        if (R.DL) {
-            uint64_t size = 0;
-            const char *text = pp_filter_dev_text(R.DL, f, &size);
-            rc = pp_filter_write_text(text, size, R.pass[f].data(), R.n_aln[f], outs[f], &p_, &f_, err, sizeof err);
-        } else {
-            rc = pp_filter_write(R.L, f, R.pass[f].data(), outs[f], &p_, &f_, err, sizeof err);
-        }
+        // both loaders keep the input mapped: the tags are spliced in with pwritev straight from it
+        uint64_t size = 0;
+        const char *text = R.DL ? pp_filter_dev_text(R.DL, f, &size) : R.L->F[f].text.text;
+        if (!R.DL) size = R.L->F[f].text.size;
+        const int rc = pp_filter_write_text(text, size, R.pass[f].data(), R.n_aln[f], outs[f], &p_, &f_, err, sizeof err);
         if (rc) return pp_ctx_set_error_(ctx, rc, err);
         log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(p_).c_str(), commas(f_).c_str());
         *after += p_;

@@ -171,3 +171,37 @@ def test_filter_load_details_and_errors(orc, tmp_path, monkeypatch):
     with pytest.raises(pp.PolypolishError) as e:
         pp.FilterLoaded(str(tmp_path / "missing.sam"), str(b))
     assert e.value.code == 1 and "unable to load alignments" in e.value.msg
+
+
+def test_write_text_equals_the_loaded_writer(tmp_path, monkeypatch):
+    """pp_filter_write_text (tag splicing with pwritev straight from the input mapping) against pp_filter_write
+    (from the parsed lines): same bytes for LF / CRLF input, with and without a final newline."""
+    import ctypes
+    rng = np.random.default_rng(9)
+    lines = ["@HD\tVN:1", "@SQ\tSN:c\tLN:100"]
+    for i in range(5000):
+        flag = 4 if i % 50 == 7 else (16 if i % 3 == 0 else 0)
+        lines.append(f"r{i}\t{flag}\tc\t{1 + i % 90}\t60\t4M\t*\t0\t0\tACGT\t*\tNM:i:0")
+    other = tmp_path / "other.sam"
+    other.write_text(_line("zz", 0, "c", 1, "4M"))
+    for eol, final in (("\n", True), ("\r\n", True), ("\n", False), ("\r\n", False)):
+        text = eol.join(lines) + (eol if final else "")
+        p = tmp_path / "in.sam"
+        p.write_bytes(text.encode())
+        for t in ("1", "7"):
+            monkeypatch.setenv("PP_INGEST_THREADS", t)
+            L = pp.FilterLoaded(str(p), str(other))
+            n = L.counts[0][0]
+            verdicts = (rng.random(n) < 0.7).astype(np.uint8)
+            want_counts = L.write(0, verdicts, tmp_path / "want.sam")
+            raw = p.read_bytes()
+            ok, bad = ctypes.c_uint64(), ctypes.c_uint64()
+            err = ctypes.create_string_buffer(600)
+            rc = pp.lib().pp_filter_write_text(raw, len(raw), verdicts.ctypes.data, n, str(tmp_path / "got.sam").encode(),
+                                               ctypes.byref(ok), ctypes.byref(bad), err, 600)
+            assert rc == 0, err.value
+            assert (ok.value, bad.value) == want_counts
+            assert (tmp_path / "got.sam").read_bytes() == (tmp_path / "want.sam").read_bytes(), (eol, final, t)
+            L.close()
+    rc = pp.lib().pp_filter_write_text(raw, len(raw), verdicts.ctypes.data, n - 1, str(tmp_path / "got.sam").encode(), None, None, err, 600)
+    assert rc == pp.ERR_ARG
