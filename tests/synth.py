@@ -384,3 +384,59 @@ def merge_records(a, b, seed=0):
     for k in ("contig", "ref_start", "k", "seq_len", "n_cig", "seq_off", "cig_off"):
         out[k] = out[k][order]
     return out
+
+
+def mutate_sam(text: str, rng, n_mut=3) -> str:
+    """A SAM text with a few random defects / oddities (for differential fuzzing of the parsers)."""
+    lines = text.split("\n")
+    body = [i for i, l in enumerate(lines) if l and not l.startswith("@")]
+    if not body:
+        return text
+    for _ in range(n_mut):
+        i = int(rng.choice(body))
+        f = lines[i].split("\t")
+        kind = int(rng.integers(0, 16))
+        if kind == 0 and len(f) > 3:
+            del f[int(rng.integers(0, len(f)))]                       # a column goes missing
+        elif kind == 1 and len(f) > 1:
+            f[1] = str(rng.choice(["x", "-1", "+16", "4", "99999999999", "", "0x10", "272"]))   # FLAG
+        elif kind == 2 and len(f) > 3:
+            f[3] = str(rng.choice(["0", "+5", "-3", "abc", "", "18446744073709551615", "18446744073709551616", "7"]))  # POS
+        elif kind == 3 and len(f) > 5:
+            f[5] = str(rng.choice(["*", "", "5M", "0M5M", "3S5M", "5M3S", "2M1I2M", "2M1D2M", "5Q", "M", "12", "4294967296M",
+                                   "268435456M", "1=1X1=", "2M0I2M", "5M zz", "3H5M"]))      # CIGAR
+        elif kind == 4 and len(f) > 9:
+            f[9] = str(rng.choice(["*", "", "acgtn", "ACGTRYKM", "A" * int(rng.integers(1, 40))]))  # SEQ
+        elif kind == 5:
+            f = [x for x in f if not x.startswith("NM:i:")]          # NM tag removed
+        elif kind == 6:
+            f.append(str(rng.choice(["ZP:Z:fail", "zp:z:FAIL", "ZP:Z:failed", "NM:i:x", "NM:i:", "NM:i:+3", "NM:i:99", "XX:Z:", ""])))
+        elif kind == 7:
+            f[0] = str(rng.choice(["", "same", "same", "r 1", "@odd"]))  # QNAME (an empty one glues groups together)
+        elif kind == 8 and len(f) > 2:
+            f[2] = str(rng.choice(["*", "nope", "", "contig_1", "contig_2"]))  # RNAME
+        elif kind == 9:
+            lines.insert(i, "")                                      # an empty line
+            body = [j if j < i else j + 1 for j in body]
+            continue
+        elif kind == 10:
+            lines.insert(i, lines[i])                                # a duplicated record (same QNAME: one group)
+            body = [j if j < i else j + 1 for j in body]
+            continue
+        elif kind == 11:
+            f[-1] = f[-1] + "\r"                                     # CRLF on one line
+        elif kind == 12 and len(f) > 10:
+            f = f[:11]                                               # exactly eleven columns: no tags at all
+        elif kind == 13:
+            f.append("")                                             # trailing tab
+        elif kind == 14 and len(f) > 1:
+            f[1] = str(int(f[1]) ^ 16) if f[1].isdigit() else f[1]   # strand flipped
+        else:
+            j = int(rng.integers(0, max(1, len(lines[i]))))
+            lines[i] = lines[i][:j] + str(rng.choice(["\t", "A", "0", ":", "*"])) + lines[i][j + 1:]
+            continue
+        lines[i] = "\t".join(f)
+    out = "\n".join(lines)
+    if rng.random() < 0.3:
+        out = out.rstrip("\n")                                       # no final newline
+    return out

@@ -476,6 +476,44 @@ def test_cli_with_either_ingest(orc, tmp_path, case):
         assert f"Alignments after filtering:  {rep['after']:,}" in r.stderr.decode()
 
 
+def test_fuzz_device_parsers_against_the_host_parsers(pp, ctx, tmp_path):
+    """Differential fuzzing: SAM files with random defects and oddities must get the same verdict -- identical
+    arrays, or the same error code and message -- from the kernels (pp_dev_ingest_*, pp_filter_load_device)
+    as from the host parsers, which the CPU tests tie to the oracle."""
+    ds = synth.rich_dataset(str(tmp_path), seed=91, contig_lens=(1500, 800), coverage=6, repeat_len=200, repeat_copies=2,
+                            zp_frac=0.05, lowercase_frac=0.1)
+    base1, base2 = open(ds["sam1"]).read(), open(ds["sam2"]).read()
+    rng = np.random.default_rng(2024)
+    outcomes = {"ok": 0, "error": 0}
+    f1, f2 = str(tmp_path / "f1.sam"), str(tmp_path / "f2.sam")
+    for trial in range(500):
+        open(f1, "w").write(synth.mutate_sam(base1, rng, int(rng.integers(1, 5))))
+        open(f2, "w").write(synth.mutate_sam(base2, rng, int(rng.integers(0, 3))))
+        careful = bool(trial % 5 == 0)
+        want, err = _same_ingest(pp, ctx, ds["fasta"], [f1, f2], max_errors=int(rng.choice([0, 2, 10])), careful=careful)
+        outcomes["error" if err else "ok"] += 1
+        # the filter's loaders
+        try:
+            H = pp.FilterLoaded(f1, f2)
+            he = None
+        except pp.PolypolishError as e:
+            H, he = None, (e.code, e.msg)
+        try:
+            D = pp.FilterLoadedDevice(ctx, f1, f2)
+            de = None
+        except pp.PolypolishError as e:
+            D, de = None, (e.code, e.msg)
+        assert de == he, (trial, de, he)
+        if H is not None:
+            assert D.n_reads == H.n_reads and D.counts == H.counts, trial
+            for f in range(2):
+                for k in ("flags", "ref_start", "read", "grp_off", "grp_idx"):
+                    assert np.array_equal(H.files[f][k], D.files[f][k]), (trial, f, k)
+                assert np.array_equal(_host_ref_end(H.files[f]), D.files[f]["ref_end"]), (trial, f)
+            H.close(); D.close()
+    assert outcomes["ok"] >= 50 and outcomes["error"] >= 50, outcomes
+
+
 def _host_ref_end(F):
     cig = F["cigar"].astype(np.int64)
     consumes = np.isin(cig & 15, (0, 2, 3, 7, 8))
