@@ -440,3 +440,74 @@ def mutate_sam(text: str, rng, n_mut=3) -> str:
     if rng.random() < 0.3:
         out = out.rstrip("\n")                                       # no final newline
     return out
+
+
+def random_cigar_records(seed=0, contig_lens=(3000, 1200), n_reads=1500, max_ops=7, k_choices=(1, 1, 1, 2, 3), bad_frac=0.0,
+                         n_rate=0.01):
+    """Good-alignment records with RANDOM multi-operation CIGARs (M = X I D, several indels per read, indels next to
+    each other, homopolymer ends ...) for differential fuzzing of the CIGAR walk.  With bad_frac > 0 some records
+    carry a defect the walk must reject (an op it does not know, a CIGAR that disagrees with SEQ, a read running
+    off its contig).  Returns (contig_off, bases, recs)."""
+    rng = np.random.default_rng(seed)
+    lens = np.asarray(contig_lens, dtype=np.int64)
+    contig_off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    contig_off[1:] = np.cumsum(lens)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bases = lut[rng.integers(0, 4, int(contig_off[-1]))]
+    # a few homopolymer stretches so that the right-end trim has something to chew on
+    for _ in range(20):
+        p = int(rng.integers(0, len(bases) - 12))
+        bases[p:p + int(rng.integers(3, 12))] = lut[int(rng.integers(0, 4))]
+    out = {k: [] for k in ("contig", "ref_start", "k", "seq_len", "n_cig")}
+    seqs, cigs = [], []
+    for _ in range(n_reads):
+        c = int(rng.integers(0, len(lens)))
+        ops = []
+        n_ops = int(rng.integers(1, max_ops + 1))
+        for i in range(n_ops):
+            first_or_last = i == 0 or i == n_ops - 1
+            op = "M=X"[int(rng.choice([0, 0, 0, 1, 2]))] if first_or_last else "M=XID"[int(rng.choice([0, 0, 1, 2, 3, 3, 4, 4]))]
+            if first_or_last and op == "X":
+                op = "M"
+            ops.append((int(rng.integers(1, 25)) if op in "M=X" else int(rng.integers(1, 4)), op))
+        span = sum(n for n, o in ops if o in "M=XD")
+        if span >= lens[c] - 2:
+            continue
+        start = int(rng.integers(0, lens[c] - span))
+        g = int(contig_off[c]) + start
+        seq = bytearray()
+        for n, o in ops:
+            if o in "M=":
+                seq += bytes(bases[g:g + n]); g += n
+            elif o == "X":
+                seq += bytes(lut[(np.searchsorted(lut, bases[g:g + n]) + 1) % 4]); g += n
+            elif o == "I":
+                seq += bytes(lut[rng.integers(0, 4, n)])
+            else:
+                g += n
+        seq = np.frombuffer(bytes(seq), dtype=np.uint8).copy()
+        if len(seq):
+            sub = rng.random(len(seq)) < 0.02
+            seq[sub] = lut[rng.integers(0, 4, int(sub.sum()))]
+            seq[rng.random(len(seq)) < n_rate] = ord("N")
+        packed = [(n << 4) | OPCODE[o] for n, o in ops]
+        if rng.random() < bad_frac:
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                packed.insert(int(rng.integers(0, len(packed) + 1)), (int(rng.integers(1, 5)) << 4) | OPCODE[str(rng.choice(list("NSHP")))])
+            elif kind == 1 and len(seq) > 2:
+                seq = seq[:-1]
+            elif kind == 2:
+                seq = np.concatenate([seq, lut[rng.integers(0, 4, 2)]])
+            else:
+                start = int(lens[c]) - span + int(rng.integers(1, 4))   # runs off the contig
+        out["contig"].append(c); out["ref_start"].append(start); out["k"].append(int(rng.choice(k_choices)))
+        out["seq_len"].append(len(seq)); out["n_cig"].append(len(packed))
+        seqs.append(seq); cigs.append(np.array(packed, dtype=np.uint32))
+    recs = {k: np.array(v, dtype=np.uint32) for k, v in out.items()}
+    sl, nc = recs["seq_len"].astype(np.uint64), recs["n_cig"].astype(np.uint64)
+    recs["seq_off"] = (np.cumsum(sl) - sl).astype(np.uint64)
+    recs["cig_off"] = (np.cumsum(nc) - nc).astype(np.uint64)
+    recs["seq"] = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+    recs["cigar"] = np.concatenate(cigs) if cigs else np.zeros(0, np.uint32)
+    return contig_off, bases, recs

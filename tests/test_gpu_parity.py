@@ -219,6 +219,34 @@ def test_device_reports_the_first_bad_record(ctx, pp):
     ctx.polish_records(off, bases, _rec(ent))
 
 
+def test_fuzz_cigar_walk_against_the_oracle(ctx, pp, orc):
+    """Random multi-operation CIGARs (several indels per read, indels next to each other, X/=, homopolymer ends)
+    through the device's CIGAR walk + trim + vote against the oracle; with defects mixed in, the same record must
+    be blamed with the same kind of error."""
+    import re
+    kinds = ("unexpected character", "does not match read sequence", "past the end")
+    n_ok = n_err = 0
+    for seed in range(40):
+        contig_off, bases, recs = synth.random_cigar_records(seed=1000 + seed, bad_frac=0.0 if seed % 2 == 0 else 0.003,
+                                                             n_reads=1200 + 40 * seed, max_ops=3 + seed % 6)
+        try:
+            want = orc.polish_records(contig_off, bases, recs, positions=True)
+            we = None
+        except orc.OrcError as e:
+            want, we = None, e
+        if we is None:
+            _compare_records(ctx, orc, contig_off, bases, recs)
+            n_ok += 1
+            continue
+        n_err += 1
+        with pytest.raises(pp.PolypolishError) as ge:
+            ctx.polish_records(contig_off, bases, recs)
+        idx = int(re.search(r"aln(\d+)", we.msg).group(1))
+        kind = next(k for k in kinds if k in we.msg)
+        assert ge.value.code == we.code and kind in ge.value.msg and f"record {idx}" in ge.value.msg, (seed, ge.value, we.msg)
+    assert n_ok >= 15 and n_err >= 5, (n_ok, n_err)
+
+
 FILE_CASES = [
     dict(seed=31),
     dict(seed=32, contig_lens=(6000, 1200, 900), coverage=30, repeat_len=400, repeat_copies=3),
