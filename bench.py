@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--indel-frac", type=float, default=0.01, help="experiments only: fraction of reads with a 1-bp indel")
     ap.add_argument("--sub-rate", type=float, default=0.002, help="experiments only: per-base substitution rate")
     ap.add_argument("--n-rate", type=float, default=1e-4, help="experiments only: per-base N rate")
+    ap.add_argument("--seq-layout", choices=["file", "window"], default="file",
+                    help="experiments only: where the SEQ bytes of a record live in the seq array -- 'file': in record (file) "
+                         "order, as a streaming ingest delivers them (the benchmark's layout); 'window': grouped by the 2048-bp "
+                         "window of the read's start, as an ingest that buckets while it copies could deliver them")
     ap.add_argument("--repeat-bp", type=int, default=0,
                     help="experiments only: reads starting in a region of this many bp get depth share 1/5 "
                          "(order-dependent f64 depth -> exact replay kernel), as in configs[2]")
@@ -202,6 +206,14 @@ def main():
     job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank,
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate,
                    repeat_bp=args.repeat_bp)
+    if args.seq_layout == "window":  # records stay in file order; only the placement of their bytes changes
+        r = job["recs"]
+        L = job["read_len"]
+        order = torch.argsort(r["ref_start"].long() // 2048, stable=True)
+        rank_of = torch.empty_like(order)
+        rank_of[order] = torch.arange(len(order), device=device)
+        r["seq"] = r["seq"].view(-1, L)[order].reshape(-1).contiguous()
+        r["seq_off"] = (rank_of * L).contiguous()
     torch.cuda.synchronize()
     # two send buffers in turn: the RCCL gather of step i (enqueued, not waited for) may still be reading its
     # buffer while step i+1 polishes and fills the other one; the final synchronize closes the timed region
@@ -288,7 +300,7 @@ def main():
     # -> profiles/traffic.json); null when the workload differs from the profiled one.
     traffic = None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-    default_shape = (args.genome == 5_000_000 and args.coverage == 200 and args.repeat_bp == 0 and
+    default_shape = (args.genome == 5_000_000 and args.coverage == 200 and args.repeat_bp == 0 and args.seq_layout == "file" and
                      args.indel_frac == 0.01 and args.sub_rate == 0.002 and args.n_rate == 1e-4)
     if default_shape and os.path.exists(tpath):
         with open(tpath) as f:
