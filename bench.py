@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--indel-frac", type=float, default=0.01, help="experiments only: fraction of reads with a 1-bp indel")
     ap.add_argument("--sub-rate", type=float, default=0.002, help="experiments only: per-base substitution rate")
     ap.add_argument("--n-rate", type=float, default=1e-4, help="experiments only: per-base N rate")
+    ap.add_argument("--read-len", type=int, default=150, help="experiments only: read length (coverage is kept)")
     ap.add_argument("--seq-layout", choices=["file", "window"], default="file",
                     help="experiments only: where the SEQ bytes of a record live in the seq array -- 'file': in record (file) "
                          "order, as a streaming ingest delivers them (the benchmark's layout); 'window': grouped by the 2048-bp "
@@ -203,7 +204,7 @@ def main():
     ctx = pp.Context(dev_index)
 
     # contig shard of this rank: its own 5 Mbp contig (seed differs per rank)
-    job = make_job(device, G=args.genome, coverage=args.coverage, seed=42 + 2 + 1000 * rank,
+    job = make_job(device, G=args.genome, coverage=args.coverage, read_len=args.read_len, seed=42 + 2 + 1000 * rank,
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate,
                    repeat_bp=args.repeat_bp)
     if args.seq_layout == "window":  # records stay in file order; only the placement of their bytes changes
@@ -301,6 +302,7 @@ def main():
     traffic = None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     default_shape = (args.genome == 5_000_000 and args.coverage == 200 and args.repeat_bp == 0 and args.seq_layout == "file" and
+                     args.read_len == 150 and
                      args.indel_frac == 0.01 and args.sub_rate == 0.002 and args.n_rate == 1e-4)
     if default_shape and os.path.exists(tpath):
         with open(tpath) as f:
@@ -320,7 +322,7 @@ def main():
         "dtype": "u8/u32 counts + f64 depth",
         "data": "synthetic",
         "config": {"workload": f"configs[1]: {args.genome / 1e6:g} Mbp single-contig assembly per GPU, "
-                               f"{args.coverage}x 2x150 bp alignment records resident in HBM "
+                               f"{args.coverage}x 2x{args.read_len} bp alignment records resident in HBM "
                                f"({job['n_aln']} records, 1% with a 1-bp indel)",
                    "parallelism": f"contig-shard x{world}" if world > 1 else "single GPU",
                    "alignments_per_gpu": job["n_aln"]},

@@ -185,7 +185,7 @@ __device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ c
                                          const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
                                          const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
                                          const u64 *__restrict__ contig_off, u32 n_contigs,
-                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *maxlen, u64 *status) {
+                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *fast_len, u64 *status) {
     // independent loads first, then the dependent ones (clamped so that they are unconditional):
     // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
     // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
@@ -204,9 +204,7 @@ __device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ c
         // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
         g_out = (u32)(c_lo + rs);
         nk_out = sl;
-        // the longest fast-class read picks the lane-group width of k_tile's plain class; reads of up to
-        // 160 bases (the narrowest group) never touch the word
-        if (sl > PLAIN_NARROW_MAX && sl > *maxlen) atomicMax(maxlen, sl);
+        *fast_len = sl;  // the longest fast-class read picks the lane-group width of k_tile's plain class
     } else {
         prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
     }
@@ -227,8 +225,18 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
                                               u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
                                               u32 *__restrict__ maxlen, u64 *status) {
     u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 fast_len = 0;
     if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
-                        gstart, nkeep, maxlen, status);
+                        gstart, nkeep, &fast_len, status);
+    // Only every 64th block looks (a sample: the word merely picks the lane-group width that suits the bulk of the
+    // reads -- a longer read than the sample saw simply takes the non-plain path), once per wave, and only for reads
+    // beyond the narrowest group (<= 160 bases); the word is read from L2, not from a possibly stale CU-local copy.
+    // A per-record look at that one address costs a millisecond on a 250-base job.
+    if ((blockIdx.x & 63u) == 0 && __ballot(fast_len > PLAIN_NARROW_MAX)) {
+        for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
+        if ((threadIdx.x & 63u) == 0 && fast_len > __hip_atomic_load(maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(maxlen, fast_len);
+    }
 }
 
 // =============================================================================================
