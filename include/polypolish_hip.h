@@ -13,8 +13,11 @@
  *                    get_insert_size_thresholds (src/filter.rs:155-167)
  *                                                         => pp_filter_samples / pp_filter_pairs
  *
- * plus the host-side ingest (FASTA/SAM text -> the SoA above; src/misc.rs:38-167,
- * src/alignment.rs:49-128,225-322) that the `polypolish` CLI and any binding share.
+ * plus the ingest either side of them (FASTA/SAM text -> the SoA above; src/misc.rs:38-167,
+ * src/alignment.rs:49-128,225-322, src/filter.rs:91-145,309-349) that the `polypolish` CLI and any
+ * binding share: as multi-threaded host code (pp_ingest_*, pp_filter_load / pp_filter_write) and as
+ * device tokenizers over the uploaded text (pp_dev_ingest_*, pp_filter_load_device), and the whole
+ * commands (pp_polish_files, pp_filter_files, pp_filter_polish_files).
  *
  * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns PP_OK or a
  * PP_ERR_* code and never exits the process; pp_last_error() holds the message the reference
