@@ -219,6 +219,29 @@ def test_device_reports_the_first_bad_record(ctx, pp):
     ctx.polish_records(off, bases, _rec(ent))
 
 
+def test_committed_end_to_end_fixture(ctx, tmp_path):
+    """tests/golden/derived_e2e: the product alone (no oracle in the loop) against committed bytes -- `filter`
+    (both loaders), `polish` of its output, the fused command, and `polish --careful -d 3` of the raw SAMs."""
+    import hashlib
+    import json
+    g = os.path.join(ROOT, "tests", "golden", "derived_e2e")
+    exp = json.load(open(os.path.join(g, "expected.json")))
+    s1, s2, fa = (os.path.join(g, n) for n in ("case_1.sam", "case_2.sam", "case.fasta"))
+    want = open(os.path.join(g, "polished_after_filter.fasta"), "rb").read()
+    f1, f2 = str(tmp_path / "f1.sam"), str(tmp_path / "f2.sam")
+    for mode in ("0", "1"):
+        os.environ["PP_DEVICE_FILTER"] = mode
+        try:
+            assert ctx.filter_files(s1, s2, f1, f2) == exp["filter_report"]
+        finally:
+            del os.environ["PP_DEVICE_FILTER"]
+        assert hashlib.sha256(open(f1, "rb").read()).hexdigest() == exp["filtered_1_sha256"]
+        assert hashlib.sha256(open(f2, "rb").read()).hexdigest() == exp["filtered_2_sha256"]
+    assert ctx.polish_files(fa, [f1, f2]) == want
+    assert ctx.filter_polish_files(fa, s1, s2)[0] == want
+    assert ctx.polish_files(fa, [s1, s2], careful=True, min_depth=3) == open(os.path.join(g, "polished_raw_careful_d3.fasta"), "rb").read()
+
+
 def test_fuzz_cigar_walk_against_the_oracle(ctx, pp, orc):
     """Random multi-operation CIGARs (several indels per read, indels next to each other, X/=, homopolymer ends)
     through the device's CIGAR walk + trim + vote against the oracle; with defects mixed in, the same record must

@@ -290,3 +290,23 @@ def test_error_paths(orc, tmp_path):
 def test_polish_without_sams(orc, tmp_path):
     fa, _ = _write(tmp_path, ">a d\nAC-GT\n", [])
     assert orc.polish_files(fa, [])["fasta"] == b">a d polypolish\nACGT\n"
+
+
+def test_derived_end_to_end_fixture_is_reproduced_by_the_oracle(orc, tmp_path):
+    """tests/golden/derived_e2e (made by make_derived_fixtures.py): the oracle's filter + polish of a committed
+    SAM pair must keep giving the committed bytes (a drift guard; derived, not reference-supplied)."""
+    import hashlib
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derived_e2e")
+    exp = json.load(open(os.path.join(g, "expected.json")))
+    s1, s2, fa = (os.path.join(g, n) for n in ("case_1.sam", "case_2.sam", "case.fasta"))
+    f1, f2 = str(tmp_path / "f1.sam"), str(tmp_path / "f2.sam")
+    assert orc.filter_files(s1, s2, f1, f2) == exp["filter_report"]
+    assert hashlib.sha256(open(f1, "rb").read()).hexdigest() == exp["filtered_1_sha256"]
+    assert hashlib.sha256(open(f2, "rb").read()).hexdigest() == exp["filtered_2_sha256"]
+    got = orc.polish_files(fa, [f1, f2])
+    assert got["fasta"] == open(os.path.join(g, "polished_after_filter.fasta"), "rb").read()
+    assert list(got["counts"]) == exp["counts_after_filter"]
+    got = orc.polish_files(fa, [s1, s2], careful=True, min_depth=3)
+    assert got["fasta"] == open(os.path.join(g, "polished_raw_careful_d3.fasta"), "rb").read()
