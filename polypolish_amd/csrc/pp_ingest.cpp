@@ -437,8 +437,11 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             madvise(map, map_len, MADV_SEQUENTIAL);
             text = (const char *)map;
             size = map_len;
-        } else {  // pipe or empty file
-            if (!read_file(path, fallback)) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+        } else {  // pipe or empty file: read the descriptor that is already open (a FIFO cannot be opened twice)
+            char tmp[1 << 16];
+            ssize_t r;
+            while ((r = read(fd, tmp, sizeof tmp)) > 0) fallback.insert(fallback.end(), tmp, tmp + r);
+            if (r < 0) fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
             text = fallback.data();
             size = fallback.size();
         }

@@ -231,3 +231,33 @@ def test_read_groups_across_slice_boundaries(orc, tmp_path, monkeypatch):
             got = orc.polish_records(off, bases, recs, positions=True)
             for k in ("depth", "count_a", "count_c", "count_g", "count_t", "status"):
                 assert np.array_equal(want["positions"][k], got["positions"][k]), (name, t, k)
+
+
+def test_sam_from_a_pipe(orc, tmp_path):
+    """`polypolish polish asm.fasta <(samtools view ...)`: a SAM that is not a regular file cannot be mapped; the
+    ingest and the filter loader read it through instead."""
+    import threading
+    ds = synth.rich_dataset(str(tmp_path), seed=71, contig_lens=(2000,), coverage=15)
+    want = pp.ingest(ds["fasta"], [ds["sam1"], ds["sam2"]])
+
+    def feed(path, src):
+        with open(path, "wb") as f:
+            f.write(open(src, "rb").read())
+    fifos = []
+    for i, src in enumerate((ds["sam1"], ds["sam2"])):
+        p = str(tmp_path / f"pipe{i}.sam")
+        os.mkfifo(p)
+        threading.Thread(target=feed, args=(p, src), daemon=True).start()
+        fifos.append(p)
+    got = pp.ingest(ds["fasta"], fifos)
+    assert got[5] == want[5] and all(np.array_equal(got[4][k], want[4][k]) for k in want[4])
+    H = pp.FilterLoaded(ds["sam1"], ds["sam2"])
+    fifos = []
+    for i, src in enumerate((ds["sam1"], ds["sam2"])):
+        p = str(tmp_path / f"pipe_f{i}.sam")
+        os.mkfifo(p)
+        threading.Thread(target=feed, args=(p, src), daemon=True).start()
+        fifos.append(p)
+    P = pp.FilterLoaded(*fifos)
+    assert P.counts == H.counts and all(np.array_equal(P.files[f][k], H.files[f][k]) for f in range(2) for k in H.files[f])
+    H.close(); P.close()
