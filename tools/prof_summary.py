@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     for tag in ("pp::", "void "):
         name = name.replace(tag, "")
     return name[:60]
