@@ -185,6 +185,7 @@ typedef struct {
     float ms[PP_MAX_KERNELS];
     uint64_t n_entries;   /* (alignment, window) work items the tile kernel consumed */
     uint64_t n_flagged;   /* positions resolved by the exact (string-keyed, ordered-f64) kernel */
+    uint64_t n_passes;    /* passes over the pipeline: 1, or more when a device buffer had to grow (first job) */
 } pp_kernel_times;
 int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel group, 2 only the dominant kernel ("tile") */
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);

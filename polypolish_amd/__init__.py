@@ -59,11 +59,12 @@ PP_MAX_KERNELS = 16
 
 class KernelTimes(C.Structure):
     _fields_ = [("n", C.c_int), ("name", C.c_char_p * PP_MAX_KERNELS), ("ms", C.c_float * PP_MAX_KERNELS),
-                ("n_entries", C.c_uint64), ("n_flagged", C.c_uint64)]
+                ("n_entries", C.c_uint64), ("n_flagged", C.c_uint64), ("n_passes", C.c_uint64)]
 
     def as_dict(self):
         d = {self.name[i].decode(): float(self.ms[i]) for i in range(self.n)}
-        return {"ms": d, "n_entries": int(self.n_entries), "n_flagged": int(self.n_flagged)}
+        return {"ms": d, "n_entries": int(self.n_entries), "n_flagged": int(self.n_flagged),
+                "n_passes": int(self.n_passes)}
 
 
 class SamCounts(C.Structure):

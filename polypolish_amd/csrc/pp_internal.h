@@ -44,6 +44,8 @@ enum DevErr : uint32_t {
     DE_TOO_DEEP = 10,
     DE_OVERFLOW = 11,
     DE_CAPACITY = 12,       // an optimistic device buffer was too small: the host grows it and reruns
+    DE_CAPACITY_LATE = 13,  // the same, raised from k_tile on: the work items are valid, so k_tile and k_exact2 keep
+                            // COUNTING what they would need (guarded writes) and one rerun is enough
 };
 
 struct DevBuf {

@@ -52,6 +52,12 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
 __device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {
     atomicMin(status, (idx << 8) | (u64)code);
 }
+// Job state as k_tile / k_exact2 see it: 0 running, 1 only a late capacity overflow so far (keep counting the
+// needs, every write is guarded by its capacity), 2 aborted.
+__device__ __forceinline__ int job_state(const u64 *status) {
+    const u64 s = *status;
+    return s == ~0ull ? 0 : ((s & 0xFFu) == DE_CAPACITY_LATE ? 1 : 2);
+}
 
 // misc.rs:208-215 for x >= 0
 __device__ __forceinline__ u32 d_bankers(double x) {
@@ -489,6 +495,7 @@ struct TileArgs {
     u32 cap_slabs;
     u32 *flag_pos;
     u32 *flag_cov;
+    u64 *scr_need;  // replay scratch the listed positions will need (sum of their coverage), counted past cap_flag too
     ContigStatsDev *stats;
     const u32 *maxlen;  // longest fast-class read (written by k_prep)
     u64 seq_bytes;
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
     u32 per = gridDim.x >> 3;
     u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (w >= A.nwin || *A.status != ~0ull) return;
+    if (w >= A.nwin || job_state(A.status) == 2) return;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
 
@@ -1003,11 +1010,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             if (to_list) {
                 // bucket too large for the wave-per-position replay: global list for k_exact
                 const u32 slot = atomicAdd(&A.counters[0], 1u);
+                atomicAdd(A.scr_need, (u64)ntot);
                 if (slot < A.cap_flag) {
                     A.flag_pos[slot] = (u32)gp;
                     A.flag_cov[slot] = ntot;
                 } else {
-                    report(A.status, slot, DE_CAPACITY);
+                    report(A.status, slot, DE_CAPACITY_LATE);
                 }
             }
             A.code[gp] = 0;
@@ -1052,7 +1060,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
         if (tid == 0) {
             const u32 slab = atomicAdd(&A.counters[3], 1u);
-            if (slab >= A.cap_slabs) report(A.status, slab, DE_CAPACITY);
+            if (slab >= A.cap_slabs) report(A.status, slab, DE_CAPACITY_LATE);
             s_c1 = slab;
             A.win_slab[w] = slab;
         }
@@ -1129,6 +1137,7 @@ struct ExactArgs {
     u32 cap_flag;
     u32 *flag_pos_w;         // global replay list (k_exact2 appends key-table overflows)
     u32 *flag_cov_w;
+    u64 *scr_need;
     const u32 *flag_bits;
     const u32 *win_nflag;
     const u32 *win_slab;
@@ -1359,10 +1368,15 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     __shared__ u64 pk[SORT_MAX];  // sort keys: record index << 16 | slot
     __shared__ u64 s_base;
     const u32 w = blockIdx.x, tid = threadIdx.x;
-    if (w >= nwin || *A.status != ~0ull) return;
+    const int state = w < nwin ? job_state(A.status) : 2;
+    if (state == 2) return;
     if (A.win_nflag[w] == 0) return;
     const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
     if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
+    if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
+        if (tid == 0) atomicAdd(A.ents_cursor, (u64)n);
+        return;
+    }
     const u32 slab = A.win_slab[w];
 
     // ---- (1) sort by record index ----
@@ -1371,7 +1385,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
     if (tid == 0) {
         const u64 base = atomicAdd(A.ents_cursor, (u64)n);
-        if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY);
+        if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY_LATE);
         s_base = base;
     }
     __syncthreads();
@@ -1448,8 +1462,9 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
         if (vo.status != PP_ST_LOW_DEPTH && nOth > 0 && nOth >= vo.ithr) {
             // a string-keyed tally could reach a threshold: full replay by the thread-serial kernel
             const u32 slot = atomicAdd(&A.counters[0], 1u);
+            atomicAdd(A.scr_need, (u64)ntot);
             if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ntot; }
-            else report(A.status, slot, DE_CAPACITY);
+            else report(A.status, slot, DE_CAPACITY_LATE);
             continue;
         }
         A.code[gp] = vo.out;
@@ -1803,9 +1818,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
 #define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
-    // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements |
-    // 5 polished bytes | 7.. contig output offsets (nc+1) | then per-contig stats (3 words each)
-    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;  // word 8: debug key records
+    // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements (10: the same, counted
+    // as the positions are listed) |
+    // 5 polished bytes | 6 ordered replay items | 8 key records | 9 longest fast read | 16.. contig output offsets
+    // (nc+1) | then per-contig stats (3 words each)
+    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
     ENS(b_meta, meta_words * 8);
     ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
     // One level (items straight into their windows) while all windows fit one LDS pass of k_fill; two levels
@@ -1893,6 +1910,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
     T.maxlen = (const u32 *)(d_meta + 9);
+    T.scr_need = d_meta + 10;
     T.seq_bytes = B.seq_bytes;
     T.own = nullptr;
     if (!ctx->emit.empty()) {
@@ -1914,6 +1932,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
     E.win_slab = T.win_slab; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
     E.ents_cursor = d_meta + 6;
+    E.scr_need = d_meta + 10;
     E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
@@ -1972,28 +1991,33 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
 
     std::vector<uint64_t> meta;
     uint32_t n_entries = 0;
-    for (int attempt = 0;; attempt++) {
+    int attempt = 0;
+    for (;; attempt++) {
         timers_release(ctx);
         int rc = run_pipeline(ctx, meta, &n_entries);
         if (rc) return rc;
         const uint64_t key = meta[0];
         if (key == ~0ull) break;
-        if ((key & 0xFF) != DE_CAPACITY) return map_device_error(ctx, key);
+        if ((key & 0xFF) != DE_CAPACITY && (key & 0xFF) != DE_CAPACITY_LATE) return map_device_error(ctx, key);
         if (attempt >= 6) return ctx->fail(PP_ERR_HIP, "device buffers kept overflowing after %d attempts", attempt);
         // grow whatever was too small (sizes the device got to before it stopped), then rerun
         const uint32_t *cnt = (const uint32_t *)&meta[1];
         bool grew = false;
-        auto grow = [&](size_t &cap, uint64_t need) {
-            if (need > cap) { cap = (size_t)(need + need / 8 + 1024); grew = true; }
+        static const bool trace = getenv("PP_TIMING") != nullptr;
+        auto grow = [&](size_t &cap, uint64_t need, const char *what) {
+            if (need <= cap) return;
+            if (trace) fprintf(stderr, "[timing] pass %d: %s %zu -> need %llu\n", attempt + 1, what, cap, (unsigned long long)need);
+            cap = (size_t)(need + need / 8 + 1024);
+            grew = true;
         };
-        grow(ctx->cap_ent, meta[3]);
-        grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G));
-        grow(ctx->cap_scr, meta[4]);
-        grow(ctx->cap_multi, cnt[1]);
-        grow(ctx->cap_slabs, cnt[3]);
-        grow(ctx->cap_ents, meta[6]);
-        if (ctx->debug) grow(ctx->cap_keys, meta[8]);
-        grow(ctx->cap_out, meta[5]);
+        grow(ctx->cap_ent, meta[3], "work items");
+        grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G), "listed positions");
+        grow(ctx->cap_scr, std::max(meta[4], meta[10]), "replay scratch");
+        grow(ctx->cap_multi, cnt[1], "multi-byte winners");
+        grow(ctx->cap_slabs, cnt[3], "tally slabs");
+        grow(ctx->cap_ents, meta[6], "ordered replay items");
+        if (ctx->debug) grow(ctx->cap_keys, meta[8], "key records");
+        grow(ctx->cap_out, meta[5], "polished bytes");
         if (!grew) return ctx->fail(PP_ERR_HIP, "device reported a capacity overflow that the host cannot locate");
     }
     const uint32_t *cnt = (const uint32_t *)&meta[1];
@@ -2013,6 +2037,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         timers_collect(ctx, &ctx->last_times);
         ctx->last_times.n_entries = n_entries;
         ctx->last_times.n_flagged = cnt[2];
+        ctx->last_times.n_passes = (uint64_t)attempt + 1;
     }
     ctx->job_done = true;
     ctx->job_open = false;

@@ -125,6 +125,41 @@ print("two-level ok")
     assert r.returncode == 0 and b"two-level ok" in r.stdout, r.stderr.decode()[-2000:]
 
 
+def test_buffer_growth_takes_one_rerun(tmp_path):
+    """A fresh context starts with optimistic capacities (64 tally slabs, 2^20 replay items).  A job in which EVERY
+    window has order-dependent depths overflows both: the device keeps counting what it needs (DE_CAPACITY_LATE),
+    so the host grows everything at once -- two passes, not one per in-flight wave of workgroups -- and the
+    result is the oracle's."""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, synth, polypolish_amd as pp
+from oracle import orc
+o, b, r = synth.fast_records(seed=31, contig_lens=(1_500_000,), coverage=125, k_choices=(1, 3), indel_read_frac=0.01)
+want = orc.polish_records(o, b, r, positions=True)
+ctx = pp.Context(0)
+ctx.set_profiling(1)
+got = ctx.polish_records(o, b, r)
+t = ctx.kernel_times()
+assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"])
+assert t["n_passes"] == 2, t
+got = ctx.polish_records(o, b, r)
+assert got["polished"] == want["polished"] and ctx.kernel_times()["n_passes"] == 1
+# the same with per-position records (every flagged position goes through the global list): listed positions and
+# their replay scratch overflow together
+ctx2 = pp.Context(0)
+ctx2.set_profiling(1)
+got = ctx2.polish_records(o, b, r, positions=True)
+t2 = ctx2.kernel_times()
+assert got["polished"] == want["polished"]
+assert np.array_equal(got["positions"]["depth"], want["positions"]["depth"])
+assert t2["n_passes"] == 2, t2
+print("growth ok", t["n_entries"], t["n_flagged"])
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run(["python", "-c", code], capture_output=True, timeout=600, env=dict(os.environ, PP_TIMING="1"))
+    assert r.returncode == 0 and b"growth ok" in r.stdout, r.stderr.decode()[-3000:]
+
+
 def test_deep_pileup_on_one_window(ctx, orc):
     # 20,000x on a 3 kbp contig: a single window bucket of ~60k work items
     contig_off, bases, recs = synth.fast_records(seed=21, contig_lens=(3_000,), coverage=20_000, read_len=150,
