@@ -603,10 +603,9 @@ extern "C" int pp_filter_line_error_(const char *line, size_t n, const char *pat
 // filter_sam (filter.rs:309-349) from a text in memory: the lines are found again here (in parallel slices);
 // a line is an aligned record when it is not a header and FLAG & 4 is clear -- the text has been validated
 // by the loader that produced the verdicts.
-extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8_t *pass, uint64_t n_pass,
-                                    const char *out_path, uint64_t *pass_count, uint64_t *fail_count, char *err,
-                                    size_t errlen) {
-    if ((!text && size) || !out_path || (!pass && n_pass)) return PP_ERR_ARG;
+// Tagged copy of one SAM text into an already open (and truncated) file; closes fd.
+static int write_text_fd(const char *text, uint64_t size, const uint8_t *pass, uint64_t n_pass, int fd,
+                         const char *out_path, uint64_t *pass_count, uint64_t *fail_count, char *err, size_t errlen) {
     auto write_failed = [&]() {
         if (err && errlen) snprintf(err, errlen, "unable to write alignments to \"%s\"", out_path);
         return PP_ERR_QUIT;
@@ -644,6 +643,7 @@ extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8
     if (first[threads] != n_pass) {
         if (err && errlen) snprintf(err, errlen, "%llu verdicts for %llu aligned records", (unsigned long long)n_pass,
                                     (unsigned long long)first[threads]);
+        close(fd);
         return PP_ERR_ARG;
     }
     // The output is the input with a tag spliced in here and there: every slice becomes a list of iovecs that
@@ -685,8 +685,6 @@ extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8
         }
     });
     for (unsigned t = 0; t < threads; t++) off[t + 1] += off[t];
-    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (fd < 0) return write_failed();
     std::atomic<int> bad{0};
     parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
         for (size_t t = lo; t < hi; t++) {
@@ -711,6 +709,21 @@ extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8
     if (pass_count) *pass_count = p_;
     if (fail_count) *fail_count = f_;
     return PP_OK;
+}
+
+static int open_output(const char *out_path, char *err, size_t errlen) {
+    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0 && err && errlen) snprintf(err, errlen, "unable to write alignments to \"%s\"", out_path);
+    return fd;
+}
+
+extern "C" int pp_filter_write_text(const char *text, uint64_t size, const uint8_t *pass, uint64_t n_pass,
+                                    const char *out_path, uint64_t *pass_count, uint64_t *fail_count, char *err,
+                                    size_t errlen) {
+    if ((!text && size) || !out_path || (!pass && n_pass)) return PP_ERR_ARG;
+    const int fd = open_output(out_path, err, errlen);
+    if (fd < 0) return PP_ERR_QUIT;
+    return write_text_fd(text, size, pass, n_pass, fd, out_path, pass_count, fail_count, err, errlen);
 }
 
 namespace {
@@ -810,22 +823,35 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     return PP_OK;
 }
 
-// filter_sams, filter.rs:273-349
+// filter_sams, filter.rs:273-349.  The outputs are opened in the reference's order (a second file is not created
+// when the first cannot be), then both are written at the same time: buffered writes serialise on the inode, so
+// two files in flight take about as long as one.  (Copying into a shared mapping of the output instead of
+// pwritev was 3-4x slower on the 256-core box: 1.0-1.5 s of page faults for the 1.36 GB.)
 int filter_write(pp_ctx *ctx, const Log &log, const FilterRun &R, const char *const ins[2], const char *const outs[2],
                  uint64_t *after) {
-    char err[1400] = "";
+    char err[2][1400] = {"", ""};
     *after = 0;
     log("Filtering SAM files\n");
-    for (int f = 0; f < 2; f++) {
-        uint64_t p_ = 0, f_ = 0;
+    uint64_t p_[2] = {0, 0}, f_[2] = {0, 0};
+    int rc[2] = {PP_OK, PP_OK};
+    auto write_one = [&](int f, int fd) {
         // both loaders keep the input mapped: the tags are spliced in with pwritev straight from it
         uint64_t size = 0;
         const char *text = R.DL ? pp_filter_dev_text(R.DL, f, &size) : R.L->F[f].text.text;
         if (!R.DL) size = R.L->F[f].text.size;
-        const int rc = pp_filter_write_text(text, size, R.pass[f].data(), R.n_aln[f], outs[f], &p_, &f_, err, sizeof err);
-        if (rc) return pp_ctx_set_error_(ctx, rc, err);
-        log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(p_).c_str(), commas(f_).c_str());
-        *after += p_;
+        rc[f] = write_text_fd(text, size, R.pass[f].data(), R.n_aln[f], fd, outs[f], &p_[f], &f_[f], err[f], sizeof err[f]);
+    };
+    const int fd0 = open_output(outs[0], err[0], sizeof err[0]);
+    if (fd0 < 0) return pp_ctx_set_error_(ctx, PP_ERR_QUIT, err[0]);
+    std::thread first(write_one, 0, fd0);
+    const int fd1 = open_output(outs[1], err[1], sizeof err[1]);
+    if (fd1 >= 0) write_one(1, fd1);
+    else rc[1] = PP_ERR_QUIT;
+    first.join();
+    for (int f = 0; f < 2; f++) {
+        if (rc[f]) return pp_ctx_set_error_(ctx, rc[f], err[f]);
+        log("Filtering %s:\n  %s pass\n  %s fail\n\n", ins[f], commas(p_[f]).c_str(), commas(f_[f]).c_str());
+        *after += p_[f];
     }
     return PP_OK;
 }
