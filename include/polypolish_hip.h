@@ -72,6 +72,13 @@ void *pp_ctx_stream(pp_ctx *ctx);      /* the hipStream_t every kernel of this c
 int pp_ctx_download(pp_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 const char *pp_version(void);          /* "polypolish-mi355x <ver> (parity target v0.6.1)"       */
 
+/* Three strings of the run log that the reference pins with unit tests, exported so that those vectors can be
+ * checked against the product's own text: PP_TEXT_QSCORE (qscore, src/polish.rs:290-300; value = identity in %),
+ * PP_TEXT_DURATION (format_duration, src/misc.rs:195-201; value = microseconds), PP_TEXT_PERCENTILE_NAME
+ * (get_percentile_name, src/filter.rs:262-270).  PP_OK and a NUL-terminated string in out, or PP_ERR_ARG (unknown `what`, text does not fit). */
+enum { PP_TEXT_QSCORE = 0, PP_TEXT_DURATION = 1, PP_TEXT_PERCENTILE_NAME = 2 };
+int pp_log_text(int what, double value, char *out, size_t cap);
+
 /* ---- seam B: pileup accumulate + per-position vote ------------------------------------------ */
 typedef struct {
     uint32_t min_depth;      /* -d, src/main.rs:97-99   */

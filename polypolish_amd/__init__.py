@@ -101,7 +101,7 @@ class FilterFileCounts(C.Structure):
 
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
-    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version",
+    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version", "pp_log_text",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
@@ -139,6 +139,7 @@ def lib():
         L.pp_ctx_stream.argtypes = [vp]
         L.pp_ctx_stream.restype = vp
         L.pp_version.restype = C.c_char_p
+        L.pp_log_text.argtypes = [C.c_int, C.c_double, C.c_char_p, C.c_size_t]
         L.pp_polish_begin.argtypes = [vp, C.c_uint32, vp, vp, C.c_int, C.POINTER(Params)]
         L.pp_polish_add.argtypes = [vp, C.POINTER(AlnBatch), C.c_int]
         L.pp_polish_finish.argtypes = [vp]

@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "polypolish_hip.h"
+#include "pp_host.h"
 
 namespace {
 
@@ -48,25 +49,8 @@ bool exists(const char *p) {
     return stat(p, &st) == 0;
 }
 
-// polish.rs:290-300
-std::string qscore(double identity) {
-    if (identity >= 100.0) return "Q\xE2\x88\x9E";
-    if (identity <= 0.0) return "Q0";
-    double errors = 1.0 - identity / 100.0;
-    char buf[64];
-    snprintf(buf, sizeof buf, "Q%.2f", -10.0 * log10(errors));
-    return buf;
-}
-
-// misc.rs:195-201
-std::string format_duration(double seconds) {
-    uint64_t us = (uint64_t)(seconds * 1e6);
-    char buf[64];
-    snprintf(buf, sizeof buf, "%llu:%02llu:%02llu.%06llu", (unsigned long long)(us / 1000000 / 3600),
-             (unsigned long long)(us / 1000000 / 60 % 60), (unsigned long long)(us / 1000000 % 60),
-             (unsigned long long)(us % 1000000));
-    return buf;
-}
+using pph::format_duration;
+using pph::qscore;
 
 int set_err(pp_ctx *ctx, int code, const char *msg);
 
@@ -335,3 +319,17 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     return PP_OK;
 }
 
+
+extern "C" int pp_log_text(int what, double value, char *out, size_t cap) {
+    if (!out || cap == 0) return PP_ERR_ARG;
+    std::string s;
+    switch (what) {
+    case PP_TEXT_QSCORE: s = pph::qscore(value); break;
+    case PP_TEXT_DURATION: s = pph::format_duration_us((uint64_t)value); break;
+    case PP_TEXT_PERCENTILE_NAME: s = pph::percentile_name(value); break;
+    default: return PP_ERR_ARG;
+    }
+    if (s.size() + 1 > cap) return PP_ERR_ARG;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return PP_OK;
+}

@@ -54,14 +54,8 @@ std::string commas(uint64_t v) {  // num-format's Locale::en grouping
     return out;
 }
 
-std::string format_duration(double seconds) {  // misc.rs:195-201
-    const uint64_t us = (uint64_t)(seconds * 1e6);
-    char buf[64];
-    snprintf(buf, sizeof buf, "%llu:%02llu:%02llu.%06llu", (unsigned long long)(us / 1000000 / 3600),
-             (unsigned long long)(us / 1000000 / 60 % 60), (unsigned long long)(us / 1000000 % 60),
-             (unsigned long long)(us % 1000000));
-    return buf;
-}
+using pph::format_duration;
+using pph::percentile_name;
 
 struct FilterErr {
     int code;
@@ -271,18 +265,6 @@ uint32_t percentile(std::vector<uint32_t> &v, double p) {
     if (rank - 1 >= v.size()) return 0;
     std::nth_element(v.begin(), v.begin() + (rank - 1), v.end());
     return v[rank - 1];
-}
-
-// get_percentile_name, filter.rs:262-270
-std::string percentile_name(double p) {
-    char b[64];
-    snprintf(b, sizeof b, "%g", p);
-    std::string s = b;
-    const char *suffix = "th";
-    if (s.back() == '1' && p != 11.0) suffix = "st";
-    else if (s.back() == '2' && p != 12.0) suffix = "nd";
-    else if (s.back() == '3' && p != 13.0) suffix = "rd";
-    return s + suffix + " percentile";
 }
 
 }  // namespace

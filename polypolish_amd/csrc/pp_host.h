@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -130,6 +132,46 @@ inline void line_slices(const char *text, size_t size, unsigned threads, std::ve
         p = want;
     }
     cut[threads] = end;
+}
+
+// ---- text of the run log (the reference pins these three with unit tests; exported as pp_log_text) ----
+// qscore, polish.rs:290-300
+inline std::string qscore(double identity) {
+    if (identity >= 100.0) return "Q\xE2\x88\x9E";
+    if (identity <= 0.0) return "Q0";
+    char buf[64];
+    snprintf(buf, sizeof buf, "Q%.2f", -10.0 * log10(1.0 - identity / 100.0));
+    return buf;
+}
+
+// format_duration, misc.rs:195-201
+inline std::string format_duration_us(uint64_t us) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%llu:%02llu:%02llu.%06llu", (unsigned long long)(us / 1000000 / 3600),
+             (unsigned long long)(us / 1000000 / 60 % 60), (unsigned long long)(us / 1000000 % 60),
+             (unsigned long long)(us % 1000000));
+    return buf;
+}
+inline std::string format_duration(double seconds) { return format_duration_us((uint64_t)(seconds * 1e6)); }
+
+// f64::to_string: the shortest decimal string that reads back as the same double, never in exponent form
+inline std::string shortest_decimal(double v) {
+    char b[400];
+    for (int decimals = 0; decimals <= 340; decimals++) {
+        snprintf(b, sizeof b, "%.*f", decimals, v);
+        if (strtod(b, nullptr) == v) break;
+    }
+    return b;
+}
+
+// get_percentile_name, filter.rs:262-270
+inline std::string percentile_name(double p) {
+    const std::string s = shortest_decimal(p);
+    const char *suffix = "th";
+    if (s.back() == '1' && p != 11.0) suffix = "st";
+    else if (s.back() == '2' && p != 12.0) suffix = "nd";
+    else if (s.back() == '3' && p != 13.0) suffix = "rd";
+    return s + suffix + " percentile";
 }
 
 }  // namespace pph
