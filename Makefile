@@ -2,6 +2,7 @@
 #   polypolish_amd/_build/libpolypolish_hip.so   the product: HIP kernels + C ABI + host ingest
 #   bin/polypolish                               the drop-in CLI (links the library)
 #   oracle/_build/*                              the CPU oracle (test infrastructure only)
+#   bin/polish_min                               examples/polish_min.c: a plain C99 host over the C ABI
 # -ffp-contract=off: the vote's banker's rounding must see the unfused product depth*fraction.
 HIPCC    ?= hipcc
 ARCH     ?= gfx950
@@ -12,7 +13,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iincl
 LIB  := $(OUT)/libpolypolish_hip.so
 OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o
 
-all: $(LIB) bin/polypolish oracle
+all: $(LIB) bin/polypolish bin/polish_min oracle
 
 $(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_internal.h $(CSRC)/pp_host.h $(CSRC)/pp_devtext.h include/polypolish_hip.h
 	@mkdir -p $(OUT)
@@ -28,6 +29,11 @@ $(LIB): $(OBJS)
 bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
 	@mkdir -p bin
 	$(HIPCC) -O2 -std=c++17 -Iinclude -x c++ $(CSRC)/pp_cli.cpp -x none -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
+
+# strict C99: the header is a C header, and nothing but the C ABI is needed on the caller's side
+bin/polish_min: examples/polish_min.c include/polypolish_hip.h $(LIB)
+	@mkdir -p bin
+	gcc -std=c99 -O2 -Wall -Wextra -pedantic -Werror -Iinclude $< -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
 
 oracle:
 	$(MAKE) -C oracle

@@ -734,6 +734,17 @@ def test_cli_is_a_drop_in(orc, tmp_path):
     assert r.returncode == 1 and b"file does not exist" in r.stderr
 
 
+def test_plain_c_host_over_the_abi(orc, tmp_path):
+    """examples/polish_min.c: a C99 program that sees nothing but include/polypolish_hip.h (host ingest -> seam B ->
+    its own FASTA printing) produces the oracle's bytes."""
+    ds = synth.rich_dataset(str(tmp_path), seed=43, contig_lens=(6000, 1200, 300), coverage=25, repeat_len=300,
+                            repeat_copies=3, lowercase_frac=0.1)
+    want = orc.polish_files(ds["fasta"], [ds["sam1"], ds["sam2"]])
+    r = subprocess.run([os.path.join(ROOT, "bin", "polish_min"), ds["fasta"], ds["sam1"], ds["sam2"]], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    assert r.stdout == want["fasta"]
+
+
 def test_full_size_properties(ctx, pp, orc):
     """BASELINE.json configs[1] size (5 Mbp, 200x): size-independent properties + exact parity on a window."""
     import torch

@@ -42,6 +42,22 @@ def test_no_cpu_fallback_without_a_device():
     assert r.returncode == 1 and b"no CPU path" in r.stderr and r.stdout == b""
 
 
+def test_header_is_c99_and_the_c_example_fails_loudly_without_a_device(tmp_path):
+    """include/polypolish_hip.h is a C header (strict C99, no warnings); examples/polish_min.c, which sees nothing
+    else, builds against the library and refuses to run without an MI355X."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "polypolish_hip.h"\nint main(void) { return pp_version() ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-c", str(src), "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = os.path.join(ROOT, "bin", "polish_min")
+    assert os.path.exists(exe), "make builds examples/polish_min.c"
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "x.fasta", "y.sam"], capture_output=True)
+        assert r.returncode == 1 and r.stdout == b"" and b"no CPU fallback" in r.stderr
+
+
 def test_product_does_not_touch_the_oracle():
     """The shipped path must never import, link or execute anything under oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "polypolish_amd")):
