@@ -1390,9 +1390,10 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     }
     __syncthreads();
     for (u32 k = 2; k <= np2; k <<= 1) {
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
+        for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
+            const u32 j = 1u << lj;
             for (u32 t = tid; t < (np2 >> 1); t += 1024) {
-                const u32 i = (t / j) * 2u * j + (t % j), o = i + j;
+                const u32 i = ((t >> lj) << (lj + 1u)) | (t & (j - 1u)), o = i + j;
                 const bool asc = (i & k) == 0;
                 const u64 a = pk[i], b = pk[o];
                 if ((a > b) == asc) { pk[i] = b; pk[o] = a; }
@@ -1420,8 +1421,8 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
 
     // ---- (3) the sequential pass: lanes are positions ----
     // 64 items per vector load (one per lane), then v_readlane turns each item into scalars
-    // Wave v owns the 128 consecutive positions [128v, 128v+128): an item that does not reach them
-    // is skipped with two scalar compares (an item overlaps ~2 of the 16 waves).
+    // Wave v owns the 128 consecutive positions [128v, 128v+128): an item overlaps ~2 of the 16 waves, the
+    // others never enter the scalar loop (ballot of a per-lane overlap test).
     const u32 lane = tid & 63u;
     const int wlo = (int)(tid >> 6) * 128;
     const int p0 = wlo + (int)lane, p1 = p0 + 64;
@@ -1429,14 +1430,18 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     for (u32 base = 0; base < n; base += 64) {
         ulonglong2 mine;
         mine.x = 0; mine.y = 0;
-        if (base + lane < n) mine = ents[base + lane];
-        const u32 nb = min(64u, n - base);
+        const bool have = base + lane < n;
+        if (have) mine = ents[base + lane];
         const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
-        for (u32 j = 0; j < nb; j++) {
-            const int rel = __builtin_amdgcn_readlane(xl, (int)j);
-            const u32 lim = (u32)__builtin_amdgcn_readlane(xh, (int)j);
-            if (rel >= wlo + 128 || (long long)rel + (long long)lim <= (long long)wlo) continue;
-            const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, (int)j), __builtin_amdgcn_readlane(yl, (int)j));
+        // one vector compare picks the items of this batch that reach the wave's positions; only those are
+        // visited one by one, in ascending order = file order
+        u64 hits = __ballot(have && xl < wlo + 128 && (long long)xl + (long long)(u32)xh > (long long)wlo);
+        while (hits) {
+            const int j = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const int rel = __builtin_amdgcn_readlane(xl, j);
+            const u32 lim = (u32)__builtin_amdgcn_readlane(xh, j);
+            const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, j), __builtin_amdgcn_readlane(yl, j));
             if ((u32)(p0 - rel) < lim) d0 += dc;
             if ((u32)(p1 - rel) < lim) d1 += dc;
         }
