@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
-            const bool to_list = A.dbg || e1 - e0 > SORT_MAX;
+            const bool to_list = A.dbg == 1 || e1 - e0 > SORT_MAX;  // dbg 2: test hook, see run_pipeline
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);
@@ -1365,7 +1365,7 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 //  (4) vote per flagged position; the few whose string-keyed tallies could reach a threshold are
 //      handed to the thread-serial k_exact through the global list.
 __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
-    __shared__ u64 pk[SORT_MAX];  // sort keys: record index << 16 | slot
+    __shared__ u64 pk[SORT_MAX];  // bitonic sort keys (record index << 16 | slot), or the counting sort's arrays
     __shared__ u64 s_base;
     const u32 w = blockIdx.x, tid = threadIdx.x;
     const int state = w < nwin ? job_state(A.status) : 2;
@@ -1379,33 +1379,107 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     }
     const u32 slab = A.win_slab[w];
 
-    // ---- (1) sort by record index ----
-    u32 np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+    // ---- (1) order the window's items by record index (= SAM file order) ----
+    // Record indices of a window's items are spread over the file, so a counting sort on their leading bits
+    // (up to SORT_BUCKETS buckets between the window's smallest and largest index) leaves buckets of a few
+    // items, finished by one thread each with an insertion sort: ~10x fewer LDS passes than a bitonic network
+    // over 16 K keys.  Clustered indices (a bucket above SORT_BUCKET_MAX items) take the bitonic sort instead.
+    // The arrays of the counting sort live inside pk[] (112 of its 128 KiB).
+    u32 *rec = (u32 *)pk;                           // [SORT_MAX] record index of slot i
+    unsigned short *ord = (unsigned short *)(pk + SORT_MAX / 2);       // [SORT_MAX] slots in file order
+    u32 *bkt = (u32 *)(pk + SORT_MAX / 2 + SORT_MAX / 4);              // [SORT_BUCKETS + 1] counts -> cursors
+    __shared__ u32 s_lo, s_hi, s_big, s_wtot[16];
     if (tid == 0) {
         const u64 base = atomicAdd(A.ents_cursor, (u64)n);
         if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY_LATE);
         s_base = base;
+        s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0;
+    }
+    for (u32 i = tid; i <= SORT_BUCKETS; i += 1024) bkt[i] = 0;
+    __syncthreads();
+    {
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+        for (u32 i = tid; i < n; i += 1024) {
+            const u32 r = A.entA[e0 + i].w;
+            rec[i] = r;
+            lo = min(lo, r); hi = max(hi, r);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (u32)__shfl_xor((int)lo, o, 64));
+            hi = max(hi, (u32)__shfl_xor((int)hi, o, 64));
+        }
+        if ((tid & 63u) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
     }
     __syncthreads();
-    for (u32 k = 2; k <= np2; k <<= 1) {
-        for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
-            const u32 j = 1u << lj;
-            for (u32 t = tid; t < (np2 >> 1); t += 1024) {
-                const u32 i = ((t >> lj) << (lj + 1u)) | (t & (j - 1u)), o = i + j;
-                const bool asc = (i & k) == 0;
-                const u64 a = pk[i], b = pk[o];
-                if ((a > b) == asc) { pk[i] = b; pk[o] = a; }
+    const u32 r_lo = s_lo;
+    u32 sh = 0;  // bucket of r = (r - r_lo) >> sh, below SORT_BUCKETS
+    while (((s_hi - r_lo) >> sh) >= SORT_BUCKETS) sh++;
+    for (u32 i = tid; i < n; i += 1024) atomicAdd(&bkt[(rec[i] - r_lo) >> sh], 1u);
+    __syncthreads();
+    {   // exclusive scan of the SORT_BUCKETS counts: SORT_BUCKETS / 1024 per thread, wave scan, wave totals
+        constexpr u32 PER = SORT_BUCKETS / 1024;
+        u32 c[PER], sum = 0, big = 0;
+#pragma unroll
+        for (u32 q = 0; q < PER; q++) { c[q] = bkt[tid * PER + q]; sum += c[q]; big = max(big, c[q]); }
+        u32 inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = (u32)__shfl_up((int)inc, o, 64);
+            if ((int)(tid & 63u) >= o) inc += v;
+        }
+        if ((tid & 63u) == 63u) s_wtot[tid >> 6] = inc;
+        if (big > SORT_BUCKET_MAX) atomicOr(&s_big, 1u);
+        __syncthreads();
+        u32 before = inc - sum;
+        for (u32 v = 0; v < (tid >> 6); v++) before += s_wtot[v];
+#pragma unroll
+        for (u32 q = 0; q < PER; q++) { bkt[tid * PER + q] = before; before += c[q]; }
+        if (tid == 1023) bkt[SORT_BUCKETS] = before;
+    }
+    __syncthreads();
+    const bool bitonic = s_big != 0;
+    if (!bitonic) {
+        // scatter the slots into their buckets (the cursor of bucket b ends at the start of bucket b+1) ...
+        for (u32 i = tid; i < n; i += 1024) ord[atomicAdd(&bkt[(rec[i] - r_lo) >> sh], 1u)] = (unsigned short)i;
+        __syncthreads();
+        // ... and finish every bucket: buckets tid*PER .. tid*PER+PER-1 are one contiguous stretch of ord[]
+        constexpr u32 PER = SORT_BUCKETS / 1024;
+        u32 beg = tid ? bkt[tid * PER - 1] : 0u;
+        for (u32 q = 0; q < PER; q++) {
+            const u32 end = bkt[tid * PER + q];
+            for (u32 a2 = beg + 1; a2 < end; a2++) {
+                const unsigned short v = ord[a2];
+                const u32 key = rec[v];
+                u32 c2 = a2;
+                while (c2 > beg && rec[ord[c2 - 1]] > key) { ord[c2] = ord[c2 - 1]; c2--; }
+                ord[c2] = v;
             }
-            __syncthreads();
+            beg = end;
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        u32 np2 = 2;
+        while (np2 < n) np2 <<= 1;
+        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+        __syncthreads();
+        for (u32 k = 2; k <= np2; k <<= 1) {
+            for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
+                const u32 j = 1u << lj;
+                for (u32 t = tid; t < (np2 >> 1); t += 1024) {
+                    const u32 i = ((t >> lj) << (lj + 1u)) | (t & (j - 1u)), o = i + j;
+                    const bool asc = (i & k) == 0;
+                    const u64 x = pk[i], y = pk[o];
+                    if ((x > y) == asc) { pk[i] = y; pk[o] = x; }
+                }
+                __syncthreads();
+            }
         }
     }
     if (s_base + n > A.cap_ents) return;  // the host grows the buffer and reruns
     ulonglong2 *ents = A.ents + s_base;
     // ---- (2) start, trimmed extent and depth share of every item, in file order ----
     for (u32 i = tid; i < n; i += 1024) {
-        const uint4 ent = A.entA[e0 + (u32)(pk[i] & 0xFFFFu)];
+        const uint4 ent = A.entA[e0 + (bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
         const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;
@@ -1924,7 +1998,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         T.own = (const u32 *)d_own;
     }
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
-    T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status; T.dbg = ctx->debug ? 1 : 0;
+    T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status;
+    // PP_DEBUG_REPLAY2=1 (tests): per-position records while order-dependent positions still go through k_exact2,
+    // so that its f64 depths can be compared bit for bit (the key records of the TSV are then incomplete)
+    static const bool dbg_replay2 = getenv("PP_DEBUG_REPLAY2") && atoi(getenv("PP_DEBUG_REPLAY2")) != 0;
+    T.dbg = ctx->debug ? (dbg_replay2 ? 2 : 1) : 0;
     const uint32_t per = (nwin + 7) / 8;
     timer_begin(ctx, "tile");
     hipLaunchKernelGGL(k_tile, dim3(per * 8), dim3(TILE_THREADS), 0, st, T);

@@ -160,6 +160,40 @@ print("growth ok", t["n_entries"], t["n_flagged"])
     assert r.returncode == 0 and b"growth ok" in r.stdout, r.stderr.decode()[-3000:]
 
 
+def test_ordered_replay_depths_bit_exact_on_both_sort_paths(tmp_path):
+    """k_exact2 orders a window's items by file index with a counting sort on the leading index bits, or with a
+    bitonic network when the indices are clustered.  PP_DEBUG_REPLAY2=1 keeps k_exact2 in charge while the
+    per-position records are collected, so its order-dependent f64 depths are compared bit for bit: (a) indices
+    spread over the file, (b) a position-sorted file whose window items have consecutive indices plus one straggler
+    at the end of the file (> SORT_BUCKET_MAX items per bucket -> bitonic)."""
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, synth, polypolish_amd as pp
+from oracle import orc
+ctx = pp.Context(0)
+def check(o, b, r):
+    want = orc.polish_records(o, b, r, positions=True)
+    got = ctx.polish_records(o, b, r, positions=True)
+    for k in ("depth", "count_a", "count_c", "count_g", "count_t", "status"):
+        assert np.array_equal(got["positions"][k], want["positions"][k]), k
+    assert got["polished"] == want["polished"]
+    return want
+o, b, r = synth.fast_records(seed=51, contig_lens=(40_000,), coverage=300, k_choices=(1, 3, 5, 7), indel_read_frac=0.02)
+check(o, b, r)
+o, b, r = synth.fast_records(seed=52, contig_lens=(600_000,), coverage=60, k_choices=(3, 7), indel_read_frac=0.0)
+order = np.argsort(r["ref_start"], kind="stable")
+order = np.concatenate([order[:5], order[6:], order[5:6]])   # one read of window 0 becomes the file's last record
+for k in ("contig", "ref_start", "k", "seq_len", "n_cig", "seq_off", "cig_off"):
+    r[k] = np.ascontiguousarray(r[k][order])
+want = check(o, b, r)
+assert len(np.unique(want["positions"]["depth"])) > 100
+print("replay ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run(["python", "-c", code], capture_output=True, timeout=900, env=dict(os.environ, PP_DEBUG_REPLAY2="1"))
+    assert r.returncode == 0 and b"replay ok" in r.stdout, r.stderr.decode()[-3000:]
+
+
 def test_deep_pileup_on_one_window(ctx, orc):
     # 20,000x on a 3 kbp contig: a single window bucket of ~60k work items
     contig_off, bases, recs = synth.fast_records(seed=21, contig_lens=(3_000,), coverage=20_000, read_len=150,
