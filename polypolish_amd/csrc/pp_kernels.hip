@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
     if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
     if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
-        if (tid == 0) atomicAdd(A.ents_cursor, (u64)n);
+        if (tid == 0 && n > SORT_MAX / 4) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
         return;
     }
     const u32 slab = A.win_slab[w];
@@ -1389,12 +1389,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     unsigned short *ord = (unsigned short *)(pk + SORT_MAX / 2);       // [SORT_MAX] slots in file order
     u32 *bkt = (u32 *)(pk + SORT_MAX / 2 + SORT_MAX / 4);              // [SORT_BUCKETS + 1] counts -> cursors
     __shared__ u32 s_lo, s_hi, s_big, s_wtot[16];
-    if (tid == 0) {
-        const u64 base = atomicAdd(A.ents_cursor, (u64)n);
-        if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY_LATE);
-        s_base = base;
-        s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0;
-    }
+    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0; }
     for (u32 i = tid; i <= SORT_BUCKETS; i += 1024) bkt[i] = 0;
     __syncthreads();
     {
@@ -1437,6 +1432,17 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     }
     __syncthreads();
     const bool bitonic = s_big != 0;
+    // The ordered list of (start, extent, share) records of step (2) stays in LDS when it fits the part of pk[]
+    // that is free by then (rec[]: 4096 records; the bitonic keys occupy it), else it goes to a global slab.
+    const bool in_lds = !bitonic && n <= SORT_MAX / 4;
+    if (tid == 0) {
+        u64 base = 0;
+        if (!in_lds) {
+            base = atomicAdd(A.ents_cursor, (u64)n);
+            if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY_LATE);
+        }
+        s_base = base;
+    }
     if (!bitonic) {
         // scatter the slots into their buckets (the cursor of bucket b ends at the start of bucket b+1) ...
         for (u32 i = tid; i < n; i += 1024) ord[atomicAdd(&bkt[(rec[i] - r_lo) >> sh], 1u)] = (unsigned short)i;
@@ -1475,8 +1481,9 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
             }
         }
     }
-    if (s_base + n > A.cap_ents) return;  // the host grows the buffer and reruns
+    if (!in_lds && s_base + n > A.cap_ents) return;  // the host grows the buffer and reruns
     ulonglong2 *ents = A.ents + s_base;
+    ulonglong2 *ents_lds = (ulonglong2 *)pk;
     // ---- (2) start, trimmed extent and depth share of every item, in file order ----
     for (u32 i = tid; i < n; i += 1024) {
         const uint4 ent = A.entA[e0 + (bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
@@ -1488,7 +1495,8 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
         ulonglong2 r;
         r.x = (u64)ent.z | ((u64)lim << 32);
         r.y = (u64)__double_as_longlong(1.0 / (double)k);
-        ents[i] = r;
+        if (in_lds) ents_lds[i] = r;
+        else ents[i] = r;
     }
     __threadfence_block();
     __syncthreads();
@@ -1501,11 +1509,14 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     const int wlo = (int)(tid >> 6) * 128;
     const int p0 = wlo + (int)lane, p1 = p0 + 64;
     double d0 = 0.0, d1 = 0.0;
+    ulonglong2 next;  // the batch after the current one is already on its way
+    next.x = 0; next.y = 0;
+    if (lane < n) next = in_lds ? ents_lds[lane] : ents[lane];
     for (u32 base = 0; base < n; base += 64) {
-        ulonglong2 mine;
-        mine.x = 0; mine.y = 0;
+        const ulonglong2 mine = next;
         const bool have = base + lane < n;
-        if (have) mine = ents[base + lane];
+        next.x = 0; next.y = 0;
+        if (base + 64u + lane < n) next = in_lds ? ents_lds[base + 64u + lane] : ents[base + 64u + lane];
         const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
         // one vector compare picks the items of this batch that reach the wave's positions; only those are
         // visited one by one, in ascending order = file order
