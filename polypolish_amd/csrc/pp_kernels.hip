@@ -1509,14 +1509,10 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     const int wlo = (int)(tid >> 6) * 128;
     const int p0 = wlo + (int)lane, p1 = p0 + 64;
     double d0 = 0.0, d1 = 0.0;
-    ulonglong2 next;  // the batch after the current one is already on its way
-    next.x = 0; next.y = 0;
-    if (lane < n) next = in_lds ? ents_lds[lane] : ents[lane];
-    for (u32 base = 0; base < n; base += 64) {
-        const ulonglong2 mine = next;
-        const bool have = base + lane < n;
-        next.x = 0; next.y = 0;
-        if (base + 64u + lane < n) next = in_lds ? ents_lds[base + 64u + lane] : ents[base + 64u + lane];
+    // Two instances of the loop, one per address space (through a generic pointer the loads would be flat loads,
+    // whose counters force a full wait), and two batch registers in turn, so that the load of the batch after the
+    // current one is in flight while the current one is visited.
+    auto visit = [&](const ulonglong2 &mine, bool have) {
         const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
         // one vector compare picks the items of this batch that reach the wave's positions; only those are
         // visited one by one, in ascending order = file order
@@ -1530,7 +1526,20 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
             if ((u32)(p0 - rel) < lim) d0 += dc;
             if ((u32)(p1 - rel) < lim) d1 += dc;
         }
-    }
+    };
+    auto ordered_pass = [&](auto load) {
+        // unconditional loads from clamped indices (a load under a branch would make the wait for the older
+        // batch a wait for everything); `have` masks the lanes past the end
+        ulonglong2 ba = load(min(lane, n - 1u)), bb;
+        for (u32 base = 0; base < n; base += 128) {
+            bb = load(min(base + 64u + lane, n - 1u));
+            visit(ba, base + lane < n);
+            ba = load(min(base + 128u + lane, n - 1u));
+            visit(bb, base + 64u + lane < n);
+        }
+    };
+    if (in_lds) ordered_pass([&](u32 i) { return ents_lds[i]; });
+    else ordered_pass([&](u32 i) { return ents[i]; });
 
     // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
     const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
