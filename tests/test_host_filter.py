@@ -116,6 +116,42 @@ def _line(name, flag, ref, pos, cigar, rest="*\t0\t0\tACGT\t*"):
     return f"{name}\t{flag}\t{ref}\t{pos}\t60\t{cigar}\t{rest}\n"
 
 
+def test_name_interning_under_contention(tmp_path, monkeypatch):
+    """Many records per QNAME, in both files and in random order: every thread count must produce the same read
+    numbering (representative = first record of the name), groups and counts -- the lock-free table's CAS-min and
+    its claim/publish hand-over are hit thousands of times per name here."""
+    rng = np.random.default_rng(77)
+    n_names, per = 3000, 24
+    names = [f"read{rng.integers(0, 10**9)}_{i}" + "x" * int(rng.integers(0, 30)) for i in range(n_names)]
+    paths = []
+    for f in range(2):
+        order = rng.permutation(np.repeat(np.arange(n_names), per))
+        if f == 1:
+            order = order[order % 7 != 3]          # some names only in file 1 ...
+        lines = [_line(names[i], int(rng.integers(0, 2)) * 16, "c", int(rng.integers(1, 5000)), "20M") for i in order]
+        if f == 1:
+            lines += [_line(f"only2_{j}", 0, "c", 5, "20M") for j in range(500)]     # ... and some only in file 2
+        p = tmp_path / f"dup{f}.sam"
+        p.write_text("@SQ\tSN:c\tLN:6000\n" + "".join(lines))
+        paths.append(str(p))
+    ref = None
+    for t in ("1", "2", "5", "8", "64"):
+        monkeypatch.setenv("PP_INGEST_THREADS", t)
+        for rep in range(2 if t != "1" else 1):
+            L = pp.FilterLoaded(*paths)
+            cur = (L.n_reads, L.counts, [{k: v.tobytes() for k, v in F.items()} for F in L.files])
+            if ref is None:
+                ref = cur
+                assert L.n_reads == n_names + 500 and L.counts[0] == (n_names * per, n_names)
+                # read numbers follow first appearance (file 1 first)
+                first = {}
+                for r in L.files[0]["read"]:
+                    first.setdefault(int(r), len(first))
+                assert all(k == v for k, v in first.items())
+            assert cur == ref, f"{t} threads changed the result"
+            L.close()
+
+
 def test_filter_load_details_and_errors(orc, tmp_path, monkeypatch):
     a, b = tmp_path / "a.sam", tmp_path / "b.sam"
     # names out of order and repeated non-adjacently (the reference groups by HashMap key, not adjacency);
