@@ -11,8 +11,11 @@
  * no multiply-add is fused (bankers_rounding depends on the unfused product).
  *
  * Parity status: pinned against the reference's own unit-test vectors
- * (T1..T12 of SURVEY.md section 4); everything the reference does not test is
- * restated from source and cross-checked against oracle/pyref.py only.
+ * (T1..T12 of SURVEY.md section 4).  For everything the reference does not
+ * test (read grouping and gates, 1/k shares, CIGAR walk + trim, the pair rule,
+ * whole-program output bytes) the status is "parity unpinned": restated from
+ * source and cross-checked against oracle/pyref.py only -- the reference is a
+ * Rust crate and cannot be built or run in this image (no cargo / rustc).
  */
 #define _GNU_SOURCE
 #include "pp_oracle.h"
