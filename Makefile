@@ -15,7 +15,7 @@ OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_fi
 
 all: $(LIB) bin/polypolish bin/polish_min oracle
 
-$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_internal.h $(CSRC)/pp_host.h $(CSRC)/pp_devtext.h include/polypolish_hip.h
+$(OUT)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/polypolish_hip.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,90 @@
+// pp_k_common.h -- types, LDS row layout and the small device helpers every kernel of the polish path shares.
+// Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
+#pragma once
+
+namespace pp {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+// LDS counter rows of one window.  A..OTH hold EXPLICIT tallies (every base of slow-class items, and
+// the mismatching bases of fast-class items); COV is the coverage difference array of the fast
+// class (+1 at the first kept position of a read, -1 one past the last; prefix-summed before the
+// vote) and MIS the number of fast-class bases that differ from the assembly, so that the tally of
+// the assembly's own base is  explicit + COV - MIS  without touching LDS once per matching base.
+enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, ROW_COV = 7,
+       ROW_MIS = 8, N_ROWS = 9 };
+
+struct KeyRec {    // debug only: one distinct non-ACGT key of a position (len 0 = the deletion key "-")
+    u64 off;
+    u32 pos, len, count, pad;
+};
+
+struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertion won the vote)
+    u64 off;       // absolute offset of the winning string in the seq array
+    u32 pos;       // global assembly position
+    u32 len;       // raw byte length of the string
+    u32 eff;       // bytes left after removing '-' (polish.rs:188)
+    u32 pad;
+};
+
+__device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {
+    atomicMin(status, (idx << 8) | (u64)code);
+}
+// Job state as k_tile / k_exact2 see it: 0 running, 1 only a late capacity overflow so far (keep counting the
+// needs, every write is guarded by its capacity), 2 aborted.
+__device__ __forceinline__ int job_state(const u64 *status) {
+    const u64 s = *status;
+    return s == ~0ull ? 0 : ((s & 0xFFu) == DE_CAPACITY_LATE ? 1 : 2);
+}
+
+// misc.rs:208-215 for x >= 0
+__device__ __forceinline__ u32 d_bankers(double x) {
+    u32 r = (x >= 4294967295.0) ? 0xFFFFFFFFu : (u32)x;
+    double f = x - trunc(x);
+    if (f < 0.5) return r;
+    if (f > 0.5) return r + 1u;
+    return r + (r & 1u);
+}
+
+__device__ __forceinline__ u32 kclass_of(u32 k) {
+    if (k == 1) return 0;
+    if ((k & (k - 1)) == 0) {
+        u32 j = 31u - (u32)__clz((int)k);
+        if (j <= (u32)DEPTH_FX_BITS) return j;
+    }
+    return KCLASS_NONDYADIC;
+}
+
+// counter row of one read byte: exact "A"/"C"/"G"/"T" (pileup.rs:58-61), "-" shares the
+// deletion key, everything else goes to the string-keyed table
+__device__ __forceinline__ int row_of(u32 c) {
+    u32 t = (c >> 1) & 3u;  // A->0 C->1 T->2 G->3
+    u32 expect = (0x47544341u >> (t * 8u)) & 0xFFu;
+    return (c == expect) ? (int)t : (c == (u32)'-' ? ROW_DEL : ROW_OTH);
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// trim of a read without indels: index of the first base of the trailing homopolymer; the kept
+// entries are [0, start-1) (alignment.rs:364-378: pop the run, then one more)
+__device__ __forceinline__ u32 simple_trim_start(const u8 *s, u32 sl) {
+    const u8 last = s[sl - 1];
+    u32 i = sl - 1;
+    while (i > 0 && s[i - 1] == last) i--;
+    return i;
+}
+__device__ __forceinline__ u32 simple_nkeep(const u8 *s, u32 sl) {
+    const u32 i = simple_trim_start(s, sl);
+    return i > 0 ? i - 1u : 0u;
+}
+
+}  // namespace pp

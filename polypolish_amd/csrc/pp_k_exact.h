@@ -1,0 +1,533 @@
+// pp_k_exact.h -- k_exact / k_exact2: exact replay of the flagged positions (string-keyed tallies, ordered f64 depth).
+// Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
+#pragma once
+
+namespace pp {
+
+// =============================================================================================
+// k_exact: exact replay of flagged positions (one thread per position)
+// =============================================================================================
+// Read slice (offset relative to the read, length) of entry q of an alignment with indels:
+// get_read_bases_for_each_target_base, alignment.rs:175-201.
+__device__ void entry_slice(const u32 *cg, u32 nc, u32 q, u64 *s_rel, u32 *len) {
+    u32 ent = 0;
+    u64 ro = 0;
+    for (u32 r = 0; r < nc; r++) {
+        u32 op = cg[r], l = op >> 4, o = op & 15u;
+        if (o == PP_OP_I) { ro += l; continue; }
+        if (q < ent + l) {
+            u32 ins = 0;
+            if (q == ent + l - 1)
+                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+            if (o == PP_OP_D) { *s_rel = ro; *len = ins; }
+            else { *s_rel = ro + (q - ent); *len = 1u + ins; }
+            return;
+        }
+        ent += l;
+        if (o != PP_OP_D) ro += l;
+    }
+    *s_rel = 0;
+    *len = 0;
+}
+
+__device__ void sift_down(ulonglong2 *a, u32 start, u32 n) {
+    u32 root = start;
+    for (;;) {
+        u32 child = 2 * root + 1;
+        if (child >= n) break;
+        if (child + 1 < n && a[child].x < a[child + 1].x) child++;
+        if (a[root].x >= a[child].x) break;
+        ulonglong2 t = a[root]; a[root] = a[child]; a[child] = t;
+        root = child;
+    }
+}
+__device__ void heapsort_by_x(ulonglong2 *a, u32 n) {
+    if (n < 2) return;
+    for (u32 s = n / 2; s-- > 0;) sift_down(a, s, n);
+    for (u32 end = n - 1; end > 0; end--) {
+        ulonglong2 t = a[0]; a[0] = a[end]; a[end] = t;
+        sift_down(a, 0, end);
+    }
+}
+
+struct ExactArgs {
+    u32 cap_multi;
+    u32 cap_flag;
+    u32 *flag_pos_w;         // global replay list (k_exact2 appends key-table overflows)
+    u32 *flag_cov_w;
+    u64 *scr_need;
+    const u32 *flag_bits;
+    const u32 *win_nflag;
+    const u32 *win_slab;
+    const u32 *slabs;
+    KeyRec *keys;       // debug only
+    u64 cap_keys;
+    u64 *n_keys;
+    ulonglong2 *ents;   // per replayed window: (start | extent << 32, 1/k as f64 bits) in file order
+    u64 cap_ents;
+    u64 *ents_cursor;
+    const u32 *flag_pos;
+    const u32 *flag_cov;
+    const u64 *flag_scr;
+    const uint4 *entA;
+    const u32 *win_off;
+    const u8 *seq;
+    const u64 *seq_off;
+    const u64 *cig_off;
+    const u32 *n_cig;
+    const u32 *cigar;
+    const u32 *kk;
+    const u8 *bases;
+    u64 G;
+    const u64 *contig_off;
+    u32 n_contigs;
+    u32 min_depth;
+    double fv, fi;
+    ulonglong2 *scratch;
+    u8 *code;
+    u32 *win_len;
+    u32 *counters;
+    MultiEnt *multi;
+    ContigStatsDev *stats;
+    double *dbg_depth;
+    u32 *dbg_counts;
+    u8 *dbg_status;
+    u64 *status;
+    int dbg;
+};
+
+constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
+constexpr u64 SL_DONE = 1ull << 63;
+
+__device__ void exact_one(const ExactArgs &A, u32 f);
+
+__global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
+    if (*A.status != ~0ull) return;
+    const u32 n_flagged = A.counters[0];
+    for (u32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_flagged; f += gridDim.x * blockDim.x) exact_one(A, f);
+}
+
+__device__ void exact_one(const ExactArgs &A, u32 f) {
+    const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
+    const u32 w = gp / (u32)TILE;
+    const int pr = (int)(gp - w * (u32)TILE);
+    ulonglong2 *scr = A.scratch + A.flag_scr[f];
+
+    // collect the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40)
+    u32 n = 0;
+    for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
+        const uint4 ent = A.entA[e];
+        const int q = pr - (int)ent.z;
+        const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
+        if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
+        const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+        // fast-class items carry their untrimmed length: apply the trim here
+        if (fl == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
+        u64 s_rel;
+        u32 len;
+        if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
+        if (n < cap) {
+            ulonglong2 v;
+            v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+            v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
+            scr[n] = v;
+        }
+        n++;
+    }
+    if (n != cap) { report(A.status, gp, DE_INTERNAL); return; }
+    heapsort_by_x(scr, n);
+
+    // depth: sequential f64 adds of 1.0/k in file order (pileup.rs:64, alignment.rs:288)
+    double depth = 0.0;
+    u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0;
+    for (u32 i = 0; i < n; i++) {
+        depth += 1.0 / (double)(u32)(scr[i].x & 0xFFFFFFFFull);
+        const u64 y = scr[i].y;
+        const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
+        if (len == 0) { nDel++; scr[i].y = y | SL_DONE; continue; }
+        if (len == 1) {
+            const int row = row_of(A.seq[y & SL_OFF_MASK]);
+            if (row != ROW_OTH) {
+                if (row == ROW_A) nA++; else if (row == ROW_C) nC++; else if (row == ROW_G) nG++;
+                else if (row == ROW_T) nT++; else nDel++;
+                scr[i].y = y | SL_DONE;
+                continue;
+            }
+        }
+        nOth++;
+    }
+    const u8 orig = A.bases[gp];
+    VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+    u64 win_off = 0;
+    u32 win_len = 0;  // winning string-keyed sequence, if any
+    const bool low = v.status == PP_ST_LOW_DEPTH;
+    if (A.dbg && nDel > 0) {  // --debug lists the deletion key like any other
+        const u64 slot = atomicAdd(A.n_keys, 1ull);
+        if (slot < A.cap_keys) {
+            KeyRec kr;
+            kr.off = 0; kr.pos = gp; kr.len = 0; kr.count = nDel; kr.pad = 0;
+            A.keys[slot] = kr;
+        } else report(A.status, slot, DE_CAPACITY);
+    }
+    if (nOth > 0 && (!low || A.dbg)) {
+        // redo the tally of pileup.rs:77-109 with the remaining keys added
+        int nv = 0, ni = 0;
+        u8 win = 0;
+        const u32 c5[5] = {nA, nC, nG, nT, nDel};
+        const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
+        for (int j = 0; j < 5; j++) {
+            if (j == 4 && nDel == 0) break;
+            if (c5[j] >= v.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= v.ithr) ni++;
+        }
+        for (u32 i = 0; i < n; i++) {
+            const u64 yi = scr[i].y;
+            if (yi & SL_DONE) continue;
+            const u32 li = (u32)((yi >> 40) & 0x7FFFFFu);
+            const u8 *si = A.seq + (yi & SL_OFF_MASK);
+            u32 count = 1;
+            for (u32 j = i + 1; j < n; j++) {
+                const u64 yj = scr[j].y;
+                if (yj & SL_DONE) continue;
+                if ((u32)((yj >> 40) & 0x7FFFFFu) != li) continue;
+                const u8 *sj = A.seq + (yj & SL_OFF_MASK);
+                bool same = true;
+                for (u32 b = 0; b < li; b++) if (si[b] != sj[b]) { same = false; break; }
+                if (same) { count++; scr[j].y = yj | SL_DONE; }
+            }
+            if (count >= v.vthr) { if (!nv) { win = 0; win_off = yi & SL_OFF_MASK; win_len = li; } nv++; }
+            else if (count >= v.ithr) ni++;
+            if (A.dbg) {
+                const u64 slot = atomicAdd(A.n_keys, 1ull);
+                if (slot < A.cap_keys) {
+                    KeyRec kr;
+                    kr.off = yi & SL_OFF_MASK; kr.pos = gp; kr.len = li; kr.count = count; kr.pad = 0;
+                    A.keys[slot] = kr;
+                } else report(A.status, slot, DE_CAPACITY);
+            }
+        }
+        if (low) {
+            win_len = 0;  // the keys were only walked for the --debug records
+        } else {
+            v.out = (orig == (u8)'-') ? 0 : orig;
+            v.status = PP_ST_KEPT;
+            if (nv == 1) {
+                if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+                else if (win_len == 0) {
+                    v.out = (win == (u8)'-') ? 0 : win;
+                    if (win != orig) v.status = PP_ST_CHANGED;
+                } else {
+                    v.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+                }
+            } else {
+                win_len = 0;
+                v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+            }
+            if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
+        }
+    }
+
+    u32 emit;
+    if (win_len > 0) {
+        u32 eff = 0;
+        u8 only = 0;
+        for (u32 b = 0; b < win_len; b++) {
+            const u8 ch = A.seq[win_off + b];
+            if (ch != (u8)'-') { eff++; only = ch; }
+        }
+        if (eff == 0) { A.code[gp] = 0; }
+        else if (eff == 1 && only < 0x80u) { A.code[gp] = only; }
+        else {
+            A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
+            const u32 slot = atomicAdd(&A.counters[1], 1u);
+            if (slot < A.cap_multi) {
+                MultiEnt m;
+                m.off = win_off; m.pos = gp; m.len = win_len; m.eff = eff; m.pad = 0;
+                A.multi[slot] = m;
+            } else {
+                report(A.status, slot, DE_CAPACITY);
+            }
+        }
+        emit = eff;
+    } else {
+        A.code[gp] = v.out;
+        emit = v.out ? 1u : 0u;
+    }
+    if (emit) atomicAdd(&A.win_len[w], emit);
+    const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
+    if (v.status == PP_ST_CHANGED) atomicAdd(&A.stats[c].changed, 1ull);
+    if (n == 0) atomicAdd(&A.stats[c].zero_depth, 1ull);
+    atomicAdd(&A.stats[c].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+    if (A.dbg) {
+        A.dbg_depth[gp] = depth;
+        A.dbg_counts[0 * A.G + gp] = nA;
+        A.dbg_counts[1 * A.G + gp] = nC;
+        A.dbg_counts[2 * A.G + gp] = nG;
+        A.dbg_counts[3 * A.G + gp] = nT;
+        A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+        A.dbg_counts[5 * A.G + gp] = v.vthr;
+        A.dbg_counts[6 * A.G + gp] = v.ithr;
+        A.dbg_status[gp] = v.status;
+    }
+}
+
+// =============================================================================================
+// k_exact2: ordered-depth replay for windows of up to SORT_MAX work items
+// =============================================================================================
+// Only the f64 depth depends on the order of the additions (pileup.rs:64); the integer tallies do
+// not, and k_tile saved them.  One workgroup per window that has flagged positions:
+//  (1) bitonic sort of the window's work items by record index (= SAM file order) in LDS;
+//  (2) per item, in that order: window-relative start, trimmed extent and 1.0/k, to a global slab;
+//  (3) ONE sequential pass over the items with all 2048 positions in parallel lanes: scalar loads of
+//      the item, `depth += 1/k` in the lanes it covers -- every position sees its additions in file order;
+//  (4) vote per flagged position; the few whose string-keyed tallies could reach a threshold are
+//      handed to the thread-serial k_exact through the global list.
+__global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
+    __shared__ u64 pk[SORT_MAX];  // bitonic sort keys (record index << 16 | slot), or the counting sort's arrays
+    __shared__ u64 s_base;
+    const u32 w = blockIdx.x, tid = threadIdx.x;
+    const int state = w < nwin ? job_state(A.status) : 2;
+    if (state == 2) return;
+    if (A.win_nflag[w] == 0) return;
+    const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
+    if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
+    if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
+        if (tid == 0 && n > SORT_MAX / 4) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
+        return;
+    }
+    const u32 slab = A.win_slab[w];
+
+    // ---- (1) order the window's items by record index (= SAM file order) ----
+    // Record indices of a window's items are spread over the file, so a counting sort on their leading bits
+    // (up to SORT_BUCKETS buckets between the window's smallest and largest index) leaves buckets of a few
+    // items, finished by one thread each with an insertion sort: ~10x fewer LDS passes than a bitonic network
+    // over 16 K keys.  Clustered indices (a bucket above SORT_BUCKET_MAX items) take the bitonic sort instead.
+    // The arrays of the counting sort live inside pk[] (112 of its 128 KiB).
+    u32 *rec = (u32 *)pk;                           // [SORT_MAX] record index of slot i
+    unsigned short *ord = (unsigned short *)(pk + SORT_MAX / 2);       // [SORT_MAX] slots in file order
+    u32 *bkt = (u32 *)(pk + SORT_MAX / 2 + SORT_MAX / 4);              // [SORT_BUCKETS + 1] counts -> cursors
+    __shared__ u32 s_lo, s_hi, s_big, s_wtot[16];
+    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0; }
+    for (u32 i = tid; i <= SORT_BUCKETS; i += 1024) bkt[i] = 0;
+    __syncthreads();
+    {
+        u32 lo = 0xFFFFFFFFu, hi = 0;
+        for (u32 i = tid; i < n; i += 1024) {
+            const u32 r = A.entA[e0 + i].w;
+            rec[i] = r;
+            lo = min(lo, r); hi = max(hi, r);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, (u32)__shfl_xor((int)lo, o, 64));
+            hi = max(hi, (u32)__shfl_xor((int)hi, o, 64));
+        }
+        if ((tid & 63u) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    }
+    __syncthreads();
+    const u32 r_lo = s_lo;
+    u32 sh = 0;  // bucket of r = (r - r_lo) >> sh, below SORT_BUCKETS
+    while (((s_hi - r_lo) >> sh) >= SORT_BUCKETS) sh++;
+    for (u32 i = tid; i < n; i += 1024) atomicAdd(&bkt[(rec[i] - r_lo) >> sh], 1u);
+    __syncthreads();
+    {   // exclusive scan of the SORT_BUCKETS counts: SORT_BUCKETS / 1024 per thread, wave scan, wave totals
+        constexpr u32 PER = SORT_BUCKETS / 1024;
+        u32 c[PER], sum = 0, big = 0;
+#pragma unroll
+        for (u32 q = 0; q < PER; q++) { c[q] = bkt[tid * PER + q]; sum += c[q]; big = max(big, c[q]); }
+        u32 inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = (u32)__shfl_up((int)inc, o, 64);
+            if ((int)(tid & 63u) >= o) inc += v;
+        }
+        if ((tid & 63u) == 63u) s_wtot[tid >> 6] = inc;
+        if (big > SORT_BUCKET_MAX) atomicOr(&s_big, 1u);
+        __syncthreads();
+        u32 before = inc - sum;
+        for (u32 v = 0; v < (tid >> 6); v++) before += s_wtot[v];
+#pragma unroll
+        for (u32 q = 0; q < PER; q++) { bkt[tid * PER + q] = before; before += c[q]; }
+        if (tid == 1023) bkt[SORT_BUCKETS] = before;
+    }
+    __syncthreads();
+    const bool bitonic = s_big != 0;
+    // The ordered list of (start, extent, share) records of step (2) stays in LDS when it fits the part of pk[]
+    // that is free by then (rec[]: 4096 records; the bitonic keys occupy it), else it goes to a global slab.
+    const bool in_lds = !bitonic && n <= SORT_MAX / 4;
+    if (tid == 0) {
+        u64 base = 0;
+        if (!in_lds) {
+            base = atomicAdd(A.ents_cursor, (u64)n);
+            if (base + n > A.cap_ents) report(A.status, base + n, DE_CAPACITY_LATE);
+        }
+        s_base = base;
+    }
+    if (!bitonic) {
+        // scatter the slots into their buckets (the cursor of bucket b ends at the start of bucket b+1) ...
+        for (u32 i = tid; i < n; i += 1024) ord[atomicAdd(&bkt[(rec[i] - r_lo) >> sh], 1u)] = (unsigned short)i;
+        __syncthreads();
+        // ... and finish every bucket: buckets tid*PER .. tid*PER+PER-1 are one contiguous stretch of ord[]
+        constexpr u32 PER = SORT_BUCKETS / 1024;
+        u32 beg = tid ? bkt[tid * PER - 1] : 0u;
+        for (u32 q = 0; q < PER; q++) {
+            const u32 end = bkt[tid * PER + q];
+            for (u32 a2 = beg + 1; a2 < end; a2++) {
+                const unsigned short v = ord[a2];
+                const u32 key = rec[v];
+                u32 c2 = a2;
+                while (c2 > beg && rec[ord[c2 - 1]] > key) { ord[c2] = ord[c2 - 1]; c2--; }
+                ord[c2] = v;
+            }
+            beg = end;
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        u32 np2 = 2;
+        while (np2 < n) np2 <<= 1;
+        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+        __syncthreads();
+        for (u32 k = 2; k <= np2; k <<= 1) {
+            for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
+                const u32 j = 1u << lj;
+                for (u32 t = tid; t < (np2 >> 1); t += 1024) {
+                    const u32 i = ((t >> lj) << (lj + 1u)) | (t & (j - 1u)), o = i + j;
+                    const bool asc = (i & k) == 0;
+                    const u64 x = pk[i], y = pk[o];
+                    if ((x > y) == asc) { pk[i] = y; pk[o] = x; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!in_lds && s_base + n > A.cap_ents) return;  // the host grows the buffer and reruns
+    ulonglong2 *ents = A.ents + s_base;
+    ulonglong2 *ents_lds = (ulonglong2 *)pk;
+    // ---- (2) start, trimmed extent and depth share of every item, in file order ----
+    for (u32 i = tid; i < n; i += 1024) {
+        const uint4 ent = A.entA[e0 + (bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
+        const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
+        u32 lim;
+        if (fl) lim = ent.x;
+        else lim = simple_nkeep(A.seq + ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32)), ent.y >> 24);
+        const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[ent.w]);
+        ulonglong2 r;
+        r.x = (u64)ent.z | ((u64)lim << 32);
+        r.y = (u64)__double_as_longlong(1.0 / (double)k);
+        if (in_lds) ents_lds[i] = r;
+        else ents[i] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- (3) the sequential pass: lanes are positions ----
+    // 64 items per vector load (one per lane), then v_readlane turns each item into scalars
+    // Wave v owns the 128 consecutive positions [128v, 128v+128): an item overlaps ~2 of the 16 waves, the
+    // others never enter the scalar loop (ballot of a per-lane overlap test).
+    const u32 lane = tid & 63u;
+    const int wlo = (int)(tid >> 6) * 128;
+    const int p0 = wlo + (int)lane, p1 = p0 + 64;
+    double d0 = 0.0, d1 = 0.0;
+    // Two instances of the loop, one per address space (through a generic pointer the loads would be flat loads,
+    // whose counters force a full wait), and two batch registers in turn, so that the load of the batch after the
+    // current one is in flight while the current one is visited.
+    auto visit = [&](const ulonglong2 &mine, bool have) {
+        const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
+        // one vector compare picks the items of this batch that reach the wave's positions; only those are
+        // visited one by one, in ascending order = file order
+        u64 hits = __ballot(have && xl < wlo + 128 && (long long)xl + (long long)(u32)xh > (long long)wlo);
+        while (hits) {
+            const int j = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const int rel = __builtin_amdgcn_readlane(xl, j);
+            const u32 lim = (u32)__builtin_amdgcn_readlane(xh, j);
+            const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, j), __builtin_amdgcn_readlane(yl, j));
+            if ((u32)(p0 - rel) < lim) d0 += dc;
+            if ((u32)(p1 - rel) < lim) d1 += dc;
+        }
+    };
+    auto ordered_pass = [&](auto load) {
+        // unconditional loads from clamped indices (a load under a branch would make the wait for the older
+        // batch a wait for everything); `have` masks the lanes past the end
+        ulonglong2 ba = load(min(lane, n - 1u)), bb;
+        for (u32 base = 0; base < n; base += 128) {
+            bb = load(min(base + 64u + lane, n - 1u));
+            visit(ba, base + lane < n);
+            ba = load(min(base + 128u + lane, n - 1u));
+            visit(bb, base + 64u + lane < n);
+        }
+    };
+    if (in_lds) ordered_pass([&](u32 i) { return ents_lds[i]; });
+    else ordered_pass([&](u32 i) { return ents[i]; });
+
+    // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
+    const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
+    const u64 gw0 = (u64)w * TILE;
+    const u32 c_first = find_contig(A.contig_off, A.n_contigs, gw0);
+    const bool one_contig = c_first == find_contig(A.contig_off, A.n_contigs, min(gw0 + TILE, A.G) - 1);
+    u32 my_len = 0, my_changed = 0, my_zero = 0;
+    u64 my_depth = 0;
+    for (int h = 0; h < 2; h++) {
+        const u32 p = h ? (u32)p1 : (u32)p0;
+        const double depth = h ? d1 : d0;
+        if (!((A.flag_bits[(u64)w * (TILE / 32) + (p >> 5)] >> (p & 31u)) & 1u)) continue;
+        const u32 gp = w * (u32)TILE + p;
+        const u32 nA = tal[0 * TILE + p], nC = tal[1 * TILE + p], nG = tal[2 * TILE + p], nT = tal[3 * TILE + p],
+                  nDel = tal[4 * TILE + p], nOth = tal[5 * TILE + p];
+        const u32 ntot = nA + nC + nG + nT + nDel + nOth;
+        const u8 orig = A.bases[gp];
+        const VoteOut vo = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+        if (vo.status != PP_ST_LOW_DEPTH && nOth > 0 && nOth >= vo.ithr) {
+            // a string-keyed tally could reach a threshold: full replay by the thread-serial kernel
+            const u32 slot = atomicAdd(&A.counters[0], 1u);
+            atomicAdd(A.scr_need, (u64)ntot);
+            if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ntot; }
+            else report(A.status, slot, DE_CAPACITY_LATE);
+            continue;
+        }
+        A.code[gp] = vo.out;
+        const u64 dfx = (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS));
+        if (one_contig) {
+            my_len += vo.out ? 1u : 0u;
+            my_changed += vo.status == PP_ST_CHANGED;
+            my_zero += ntot == 0;
+            my_depth += dfx;
+        } else {
+            my_len += vo.out ? 1u : 0u;
+            const u32 cg = find_contig(A.contig_off, A.n_contigs, gp);
+            if (vo.status == PP_ST_CHANGED) atomicAdd(&A.stats[cg].changed, 1ull);
+            if (ntot == 0) atomicAdd(&A.stats[cg].zero_depth, 1ull);
+            atomicAdd(&A.stats[cg].depth_fx, dfx);
+        }
+        if (A.dbg) {
+            A.dbg_depth[gp] = depth;
+            A.dbg_counts[0 * A.G + gp] = nA;
+            A.dbg_counts[1 * A.G + gp] = nC;
+            A.dbg_counts[2 * A.G + gp] = nG;
+            A.dbg_counts[3 * A.G + gp] = nT;
+            A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+            A.dbg_counts[5 * A.G + gp] = vo.vthr;
+            A.dbg_counts[6 * A.G + gp] = vo.ithr;
+            A.dbg_status[gp] = vo.status;
+        }
+    }
+    __syncthreads();  // pk is free again: reuse its first words for the block reduction
+    if (tid < 4) pk[tid] = 0;
+    __syncthreads();
+    my_len = wave_sum(my_len); my_changed = wave_sum(my_changed); my_zero = wave_sum(my_zero);
+    my_depth = wave_sum64(my_depth);
+    if (lane == 0) {
+        if (my_len) atomicAdd(&pk[0], (u64)my_len);
+        if (my_changed) atomicAdd(&pk[1], (u64)my_changed);
+        if (my_zero) atomicAdd(&pk[2], (u64)my_zero);
+        if (my_depth) atomicAdd(&pk[3], my_depth);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (pk[0]) atomicAdd(&A.win_len[w], (u32)pk[0]);
+        if (pk[1]) atomicAdd(&A.stats[c_first].changed, pk[1]);
+        if (pk[2]) atomicAdd(&A.stats[c_first].zero_depth, pk[2]);
+        if (pk[3]) atomicAdd(&A.stats[c_first].depth_fx, pk[3]);
+    }
+}
+
+}  // namespace pp

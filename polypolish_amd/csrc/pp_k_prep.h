@@ -1,0 +1,145 @@
+// pp_k_prep.h -- k_prep: one lane per alignment record -- run validation, spans, trim of the slow classes.
+// Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
+#pragma once
+
+namespace pp {
+
+// =============================================================================================
+// k_prep
+// =============================================================================================
+// every record that is not a single short M run inside its contig
+__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
+                                               u64 c_lo, u64 c_hi, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
+    // walk the runs (alignment.rs:178-194): spans and validity
+    u64 ref_span = 0, read_span = 0;
+    bool indel = false;
+    for (u32 r = 0; r < nc; r++) {
+        u32 op = cg[r], len = op >> 4, o = op & 15u;
+        if (len == 0 || o > 8u) { report(status, a, DE_BAD_RUN); return; }
+        if (o == PP_OP_M || o == PP_OP_EQ || o == PP_OP_X) { ref_span += len; read_span += len; }
+        else if (o == PP_OP_I) { read_span += len; indel = true; }
+        else if (o == PP_OP_D) { ref_span += len; indel = true; }
+        else { report(status, a, DE_UNEXPECTED_OP); return; }
+    }
+    u32 o_first = cg[0] & 15u, o_last = cg[nc - 1] & 15u;
+    if (!((o_first == PP_OP_M || o_first == PP_OP_EQ) && (o_last == PP_OP_M || o_last == PP_OP_EQ))) {
+        report(status, a, DE_BAD_ENDS);
+        return;
+    }
+    if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
+    if (ref_span >= 0x3FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
+
+    const u64 clen = c_hi - c_lo;
+    const u8 *s = seq + so;
+    u32 n_entries = (u32)ref_span;
+    if (!indel && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
+        // fast class (=/X runs): k_tile loads the whole read anyway and trims it there, so the read
+        // bytes are not touched here; bucketed by its untrimmed span
+        *g_out = (u32)(c_lo + rs);
+        *nk_out = n_entries;
+        return;
+    }
+    // trim_bases_for_homopolymers (alignment.rs:364-378).  The last entry is the single base
+    // seq[sl-1] (the last run is M/=).  `run` = number of trailing entries equal to it.
+    u8 last = s[sl - 1];
+    u32 run = 0;
+    if (!indel) {
+        run = sl - simple_trim_start(s, sl);
+    } else {
+        // walk the entries from the right end and stop at the first one that differs from the
+        // last base (typically after 2-3 steps): runs in reverse; `pend` = bases inserted right
+        // after the run being visited (they extend its last entry)
+        u64 ro = sl;
+        u32 pend = 0;
+        bool stop = false;
+        for (u32 r = nc; r-- > 0 && !stop;) {
+            const u32 op = cg[r], len = op >> 4, o = op & 15u;
+            if (o == PP_OP_I) { ro -= len; pend += len; continue; }
+            if (o == PP_OP_D) {
+                // last slot of the run: empty, or rewritten to the inserted bases; the others are empty
+                if (pend == 1 && s[ro] == last) { run += 1; if (len > 1) stop = true; }
+                else stop = true;
+            } else {
+                for (u32 t = 0; t < len; t++) {
+                    const bool extended = (t == 0) && pend > 0;
+                    if (!extended && s[ro - 1 - t] == last) run += 1; else { stop = true; break; }
+                }
+                ro -= len;
+            }
+            pend = 0;
+        }
+    }
+    u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
+    if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
+    if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
+    *g_out = (u32)(c_lo + rs);
+    *nk_out = nk;
+    *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
+}
+
+#ifndef PP_PLAIN_ALIGNED
+#define PP_PLAIN_ALIGNED 0
+#endif
+constexpr u32 PLAIN_NARROW_MAX = PP_PLAIN_ALIGNED ? 129u : 160u;  // = PlainCfg<5>::MAXL below
+
+__device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ contig,
+                                         const u32 *__restrict__ ref_start, const u32 *__restrict__ kk,
+                                         const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
+                                         const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
+                                         const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
+                                         const u64 *__restrict__ contig_off, u32 n_contigs,
+                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *fast_len, u64 *status) {
+    // independent loads first, then the dependent ones (clamped so that they are unconditional):
+    // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
+    // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
+    const u32 c = contig[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
+    const u64 co = cig_off[a];
+    const u32 cc = min(c, n_contigs - 1u);
+    const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1];
+    const u32 *cg = cigar + co;
+    const u32 op0 = nc ? cg[0] : 0u;
+    u32 g_out = 0, nk_out = 0;
+    u8 fl_out = 0;
+    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); }
+    else if (nc == 0) { report(status, a, DE_BAD_RUN); }
+    else if (nc == 1 && (op0 & 15u) == PP_OP_M && (op0 >> 4) == sl && sl > 0 && sl <= FAST_MAX_LEN &&
+             (u64)rs + sl <= c_hi - c_lo) {
+        // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
+        g_out = (u32)(c_lo + rs);
+        nk_out = sl;
+        *fast_len = sl;  // the longest fast-class read picks the lane-group width of k_tile's plain class
+    } else {
+        prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+    }
+    gstart[a] = g_out;
+    nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
+}
+
+__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
+                                              const u32 *__restrict__ ref_start,
+                                              const u32 *__restrict__ kk,
+                                              const u64 *__restrict__ seq_off,
+                                              const u32 *__restrict__ seq_len,
+                                              const u64 *__restrict__ cig_off,
+                                              const u32 *__restrict__ n_cig,
+                                              const u32 *__restrict__ cigar,
+                                              const u8 *__restrict__ seq,
+                                              const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                              u32 *__restrict__ maxlen, u64 *status) {
+    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 fast_len = 0;
+    if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
+                        gstart, nkeep, &fast_len, status);
+    // Only every 64th block looks (a sample: the word merely picks the lane-group width that suits the bulk of the
+    // reads -- a longer read than the sample saw simply takes the non-plain path), once per wave, and only for reads
+    // beyond the narrowest group (<= 160 bases); the word is read from L2, not from a possibly stale CU-local copy.
+    // A per-record look at that one address costs a millisecond on a 250-base job.
+    if ((blockIdx.x & 63u) == 0 && __ballot(fast_len > PLAIN_NARROW_MAX)) {
+        for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
+        if ((threadIdx.x & 63u) == 0 && fast_len > __hip_atomic_load(maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(maxlen, fast_len);
+    }
+}
+
+}  // namespace pp

@@ -1,0 +1,627 @@
+// pp_k_tile.h -- k_tile: pileup accumulate + vote for one window (the dominant kernel).
+// Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
+#pragma once
+
+namespace pp {
+
+// =============================================================================================
+// k_tile: pileup accumulate + vote for one 2048-position window
+// =============================================================================================
+struct TileArgs {
+    const uint4 *entA;
+    const u32 *win_off;
+    u32 nwin;
+    const u8 *seq;
+    const u64 *seq_off;
+    const u64 *cig_off;
+    const u32 *n_cig;
+    const u32 *cigar;
+    const u8 *bases;
+    u64 G;
+    const u64 *contig_off;
+    u32 n_contigs;
+    u32 min_depth;
+    double fv, fi;
+    u8 *code;
+    u32 *win_len;
+    u32 *counters;  // [0] positions on the global replay list, [1] n_multi, [2] all flagged positions
+    u32 cap_flag;
+    u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
+    u32 *win_nflag;   // per window: number of flagged positions
+    u32 *win_slab;    // per window: index of its tally slab (6 x 2048 u32), or ~0
+    u32 *slabs;
+    u32 cap_slabs;
+    u32 *flag_pos;
+    u32 *flag_cov;
+    u64 *scr_need;  // replay scratch the listed positions will need (sum of their coverage), counted past cap_flag too
+    ContigStatsDev *stats;
+    const u32 *maxlen;  // longest fast-class read (written by k_prep)
+    u64 seq_bytes;
+    const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
+    double *dbg_depth;
+    u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
+    u8 *dbg_status;
+    u64 *status;
+    int dbg;
+};
+
+__device__ __forceinline__ void tile_add(u32 *cnt, int row, int p, u32 kc) {
+    atomicAdd(&cnt[row * TILE + p], 1u);
+    if (kc) {
+        if (kc == KCLASS_NONDYADIC) atomicOr(&cnt[ROW_DEF * TILE + p], 0x80000000u);
+        else atomicAdd(&cnt[ROW_DEF * TILE + p], (1u << DEPTH_FX_BITS) - (1u << (DEPTH_FX_BITS - kc)));
+    }
+}
+
+__device__ __forceinline__ u32 find_contig(const u64 *contig_off, u32 n_contigs, u64 p) {
+    u32 lo = 0, hi = n_contigs;  // contig_off[lo] <= p < contig_off[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (contig_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct VoteOut {
+    u8 out;     // byte to emit (0 = nothing)
+    u8 status;  // PP_ST_*
+    u32 vthr, ithr;
+};
+
+// pileup.rs:67-134 restricted to the keys A,C,G,T and "-"; callers guarantee that no other key
+// can reach either threshold.
+__device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, double depth,
+                                         u8 orig, u32 min_depth, double fv, double fi) {
+    VoteOut v;
+    u32 vt = d_bankers(__dmul_rn(depth, fv));
+    v.vthr = max(min_depth, vt);
+    v.ithr = d_bankers(__dmul_rn(depth, fi));
+    v.out = orig;
+    v.status = PP_ST_KEPT;
+    if (depth < (double)min_depth) {
+        v.status = PP_ST_LOW_DEPTH;
+    } else {
+        int nv = 0, ni = 0;
+        u8 win = 0;
+        if (nA >= v.vthr) { nv++; win = 'A'; } else if (nA >= v.ithr) ni++;
+        if (nC >= v.vthr) { if (!nv) win = 'C'; nv++; } else if (nC >= v.ithr) ni++;
+        if (nG >= v.vthr) { if (!nv) win = 'G'; nv++; } else if (nG >= v.ithr) ni++;
+        if (nT >= v.vthr) { if (!nv) win = 'T'; nv++; } else if (nT >= v.ithr) ni++;
+        if (nDel > 0) {
+            if (nDel >= v.vthr) { if (!nv) win = '-'; nv++; } else if (nDel >= v.ithr) ni++;
+        }
+        if (nv == 1) {
+            if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+            else { v.out = win; if (win != orig) v.status = PP_ST_CHANGED; }
+        } else if (nv == 0) {
+            v.status = PP_ST_NONE;
+        } else {
+            v.status = PP_ST_MULTIPLE;
+        }
+    }
+    if (v.out == (u8)'-') v.out = 0;  // polish.rs:188
+    return v;
+}
+
+// LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
+// lane may read the five dwords around any window position it owns a byte of.
+constexpr int ASM_PAD = 32;
+constexpr int ASM_WORDS = TILE / 4 + 24;
+constexpr u32 PLAIN_MIN_LEN = 8;    // the trim reads the last four bases; shorter reads take the scalar path
+
+// ---- plain class: fast class, depth share 1 (or non-dyadic), 8..32*GW bases ------------------------
+// A group of GW lanes owns one work item; lane s of the group owns read bytes [32s, 32s+32), fetched with
+// two 16-byte global loads at the read's own (arbitrary) byte offset -- gfx950 global loads need no
+// alignment -- so a lane's bytes line up with window positions rel + 32s .. and only the END of a read
+// (trimmed tail, bytes past the read) needs masking.  GW is picked per job from the longest fast-class
+// read: 5 lanes (12 items per wave pass) up to 160 bases, 6 (10 items) up to 192, 8 (8 items) up to 252.
+// Everything per item lives in vector registers (no v_readlane, no per-item branches).
+// bit 7 of every non-zero byte
+__device__ __forceinline__ u32 nz_flags(u32 x) {
+    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
+    return __builtin_amdgcn_perm(n, n, 0u);
+}
+// 4-bit mask of the non-zero bytes of x (v_dot4_u32_u8 of the 0/1 bytes with weights 1, 2, 4, 8)
+__device__ __forceinline__ u32 nz_mask4(u32 x) {
+    return __builtin_amdgcn_udot4(nz_flags(x) >> 7, 0x08040201u, 0u, false);
+}
+__device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// PP_PLAIN_ALIGNED=1 (compile-time alternative, same speed on MI355X): lanes own 32-byte ALIGNED blocks of
+// memory instead of read-relative chunks; a group then spans 32*GW-31 bases.
+template <int GW>
+struct PlainCfg {
+    static constexpr u32 IPP = 64 / GW;                    // items per wave pass
+    static constexpr u32 BATCH = (64 / IPP) * IPP;         // items per batch: whole passes only
+    static constexpr u32 SPAN = PP_PLAIN_ALIGNED ? 32 * GW - 31 : 32 * GW;
+    static constexpr u32 MAXL = SPAN < FAST_MAX_LEN ? SPAN : FAST_MAX_LEN;
+    static_assert(GW != 5 || MAXL == PLAIN_NARROW_MAX, "k_prep's threshold");
+    __device__ static __forceinline__ u32 group(u32 lane) {
+        return GW == 8 ? lane >> 3 : (GW == 5 ? (lane * 52u) >> 8 : (lane * 43u) >> 8);
+    }
+    // work-item words x, y: no flags, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway),
+    // length in range, and every 32-byte chunk of the read inside the seq array
+    __device__ static __forceinline__ bool ok(u32 ex, u32 ey, u64 seq_bytes) {
+        const u32 L = ey >> 24, kc = (ey >> 8) & 0xFFu;
+        const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
+        return (ey & 0x00FF0000u) == 0 && (kc == 0 || kc == KCLASS_NONDYADIC) && L >= PLAIN_MIN_LEN && L <= MAXL &&
+               so + ((L + 31u) & ~31u) <= seq_bytes;
+    }
+};
+
+struct PlainItem {  // per lane
+    uint4 Wa, Wb;      // this lane's 32 read bytes
+    u32 tail;          // the last four bases of the read (group-uniform)
+    const u8 *lane_p;  // address of this lane's byte 0
+    int rel;           // global start of the read minus the window start
+    int ib;            // read index of this lane's byte 0
+    bool first;        // lane 0 of the group
+    u32 L;
+    bool plain, active;
+    bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
+};
+
+// fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
+template <int GW>
+__device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, const uint4 &my, u32 nb, u32 first,
+                                                 u32 lane) {
+    typedef PlainCfg<GW> C;
+    PlainItem it;
+    const u32 g = C::group(lane), s = lane - (u32)GW * g;
+    const u32 j = first + g;  // item of the batch owned by this group
+    const int src = (int)(min(j, nb - 1u) << 2);
+    const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
+    it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    it.L = ey >> 24;
+    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.plain = g < C::IPP && j < nb && C::ok(ex, ey, seq_bytes);
+    const u8 *rp = seq + ((u64)ex | ((u64)(ey & 0xFFu) << 32));
+    const u32 mis = PP_PLAIN_ALIGNED ? (u32)((uintptr_t)rp & 31u) : 0u;
+    it.ib = (int)(32u * s) - (int)mis;
+    it.first = s == 0;
+    it.active = it.plain && 32u * s < mis + it.L;
+    it.lane_p = rp + it.ib;
+    // Loads only where there is something to load (exec-masked): measured faster than unconditional loads
+    // from substitute addresses, and than prefetching the next pass across this pass's work.
+    it.Wa = make_uint4(0, 0, 0, 0);
+    it.Wb = make_uint4(0, 0, 0, 0);
+    it.tail = 0;
+    if (it.plain) it.tail = load4_unaligned(rp + (it.L - 4u));
+    if (it.active) {
+        it.Wa = load16_unaligned(it.lane_p);
+        it.Wb = load16_unaligned(it.lane_p + 16);
+    }
+    return it;
+}
+
+__device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
+    const int rel = it.rel;
+    const u32 L = it.L;
+
+    // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base,
+    // read off the last four bases; a trailing homopolymer of four or more takes the byte loop
+    const u32 last = it.tail >> 24;
+    const u32 tf = nz_flags(it.tail ^ splat8(last));
+    int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
+    if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
+        const u8 *rp = it.lane_p - it.ib;
+        u32 i = L - 4u;
+        while (i > 0 && rp[i - 1] == (u8)last) i--;
+        nkeep = i > 0 ? (int)i - 1 : 0;
+    }
+    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+    const bool live = it.plain && hi > lo;
+
+    // ---- coverage difference array (two atomics per read) ----
+    if (live && it.first) {
+        atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+        if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+        if (it.nd) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
+            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+            }
+        }
+    }
+    // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
+    const int ib = it.ib;
+    const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
+    if (live && it.active && b1 > b0) {
+        const int P0 = rel + ib;  // window position of byte 0 (> -32 here)
+        const u32 ai = (u32)(P0 + ASM_PAD);
+        const u32 *ap = asm_w + (ai >> 2);
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], a5 = ap[5], a6 = ap[6], a7 = ap[7], a8 = ap[8];
+        const u32 sh = ai & 3u;
+#define PP_D(k, w, x0, x1) (nz_mask4((w) ^ __builtin_amdgcn_alignbyte(x1, x0, sh)) << (4 * (k)))
+        u32 D = PP_D(0, it.Wa.x, a0, a1) | PP_D(1, it.Wa.y, a1, a2) | PP_D(2, it.Wa.z, a2, a3) | PP_D(3, it.Wa.w, a3, a4) |
+                PP_D(4, it.Wb.x, a4, a5) | PP_D(5, it.Wb.y, a5, a6) | PP_D(6, it.Wb.z, a6, a7) | PP_D(7, it.Wb.w, a7, a8);
+#undef PP_D
+        // bit i of D <=> byte i of this lane differs from the assembly; keep bytes [b0, b1) only
+        D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
+        while (D) {  // one trip per differing base
+            const int i = __ffs((int)D) - 1;
+            D &= D - 1u;
+            // byte i of the lane's eight dwords, by a select tree on the bits of i (no memory access: a
+            // load here would have to wait for the next pass's prefetch as well)
+            const u32 m4 = (u32)(((int)((u32)i << 29)) >> 31), m8 = (u32)(((int)((u32)i << 28)) >> 31),
+                      m16 = (u32)(((int)((u32)i << 27)) >> 31);
+#define PP_SEL(m, b, a) (((m) & (b)) | (~(m) & (a)))
+            const u32 w01 = PP_SEL(m4, it.Wa.y, it.Wa.x), w23 = PP_SEL(m4, it.Wa.w, it.Wa.z);
+            const u32 w45 = PP_SEL(m4, it.Wb.y, it.Wb.x), w67 = PP_SEL(m4, it.Wb.w, it.Wb.z);
+            const u32 wlo = PP_SEL(m8, w23, w01), whi = PP_SEL(m8, w67, w45);
+            const u32 c = (PP_SEL(m16, whi, wlo) >> (8 * (i & 3))) & 0xFFu;
+#undef PP_SEL
+            const int p = P0 + i;
+            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+        }
+    }
+}
+
+// ---- fast class of work items: a read without indels, <= FAST_MAX_LEN bases, inside its contig ----
+struct FastItem {  // wave-uniform (built from v_readlane results)
+    u64 so;    // offset of the read in the seq array
+    int rel;   // global start of the read minus the window start
+    u32 L;     // read length == number of entries before the trim
+    u32 kc;    // depth-share class of 1/k
+    u32 mis;   // (address of the read) & 3
+    bool on;
+};
+
+__device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, const u8 *seq) {
+    const int jj = (int)min(j, nb - 1u);
+    const u32 x = (u32)__builtin_amdgcn_readlane((int)my.x, jj), y = (u32)__builtin_amdgcn_readlane((int)my.y, jj);
+    FastItem f;
+    f.so = (u64)x | ((u64)(y & 0xFFu) << 32);
+    f.rel = __builtin_amdgcn_readlane((int)my.z, jj);
+    f.L = y >> 24;
+    f.kc = (y >> 8) & 0xFFu;
+    f.mis = (u32)(((uintptr_t)(seq + f.so)) & 3u);
+    f.on = j < nb && ((y >> 16) & 0xFFu) == 0;
+    return f;
+}
+
+// One aligned dword per lane covers the whole read (<= 252 bases + <= 3 bytes of misalignment).
+// An aligned dword that holds at least one byte of the read never leaves the read's pages.
+__device__ __forceinline__ u32 fast_load(const u8 *seq, const FastItem &f, u32 lane) {
+    u32 w = 0;
+    if (f.on && 4u * lane < f.mis + f.L) w = *((const u32 *)(seq + f.so - f.mis) + lane);
+    return w;
+}
+
+// trim (alignment.rs:364-378) by ballot; then (pileup.rs:56-65,189-200) either explicit LDS atomics
+// per kept base (reads whose depth share is not 1) or, for the bulk, two coverage-difference
+// atomics per read plus a 4-bases-at-a-time comparison against the assembly window in LDS, with
+// per-base atomics only where the read differs from the assembly.
+__device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const FastItem &f, u32 word, u32 lane) {
+    if (!f.on) return;
+    const u32 mis = f.mis;
+    const int ib = (int)(4u * lane) - (int)mis;      // read index of this lane's byte 0
+    const u32 tl = mis + f.L - 1u;                    // byte position of the last base in the wave load
+    const u32 lw = (u32)__builtin_amdgcn_readlane((int)word, (int)(tl >> 2));
+    const u32 c_last = (lw >> (8u * (tl & 3u))) & 0xFFu;
+    int hi_i = -1;  // highest read index in this lane whose base differs from the last base
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int i = ib + b;
+        const u32 c = (word >> (8 * b)) & 0xFFu;
+        if (i >= 0 && i < (int)f.L && c != c_last) hi_i = i;
+    }
+    const u64 m = __ballot(hi_i >= 0);
+    int nkeep = 0;  // index of the last base that differs: the run after it and that base are popped
+    if (m) nkeep = __builtin_amdgcn_readlane(hi_i, 63 - __clzll((long long)m));
+    const int lo = max(0, -f.rel), hi = min(nkeep, TILE - f.rel);
+    if (hi <= lo) return;
+    if (f.kc != 0) {
+        // byte order rotated by lane/8 so that the 32 lanes of an LDS group hit 32 different banks
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int b = (jj + (int)(lane >> 3)) & 3;
+            const int i = ib + b;
+            if (i >= lo && i < hi) tile_add(cnt, row_of((word >> (8 * b)) & 0xFFu), f.rel + i, f.kc);
+        }
+        return;
+    }
+    if (lane == 0) {
+        atomicAdd(&cnt[ROW_COV * TILE + f.rel + lo], 1u);
+        if (f.rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + f.rel + hi], 0xFFFFFFFFu);
+    }
+    const int lowb = max(0, lo - ib), highb = min(4, hi - ib);
+    if (lowb < highb) {
+        const u32 M = (0xFFFFFFFFu >> (8 * (4 - highb))) & (0xFFFFFFFFu << (8 * lowb));
+        const int P0 = f.rel + ib;                 // window position of byte 0 (>= -3 here)
+        const u32 ai = (u32)(P0 + ASM_PAD);        // asm_w holds the window bytes at byte offset ASM_PAD
+        const u32 w0 = asm_w[ai >> 2], w1 = asm_w[(ai >> 2) + 1];
+        const u32 av = __builtin_amdgcn_alignbyte(w1, w0, ai & 3u);
+        const u32 diff = (word ^ av) & M;
+        if (diff) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((diff >> (8 * b)) & 0xFFu) {
+                    atomicAdd(&cnt[row_of((word >> (8 * b)) & 0xFFu) * TILE + P0 + b], 1u);
+                    atomicAdd(&cnt[ROW_MIS * TILE + P0 + b], 1u);
+                }
+            }
+        }
+    }
+}
+
+// exact integer tallies of one window position from the LDS rows: explicit tallies plus, for the
+// assembly's own base, the fast-class bases that were never tallied one by one
+__device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p, u32 &nA, u32 &nC, u32 &nG, u32 &nT,
+                                                 u32 &nDel, u32 &nOth) {
+    nA = cnt[ROW_A * TILE + p]; nC = cnt[ROW_C * TILE + p]; nT = cnt[ROW_T * TILE + p];
+    nG = cnt[ROW_G * TILE + p]; nDel = cnt[ROW_DEL * TILE + p]; nOth = cnt[ROW_OTH * TILE + p];
+    const u32 same = cnt[ROW_COV * TILE + p] - cnt[ROW_MIS * TILE + p];
+    const int ro = row_of(orig);
+    nA += (ro == ROW_A) ? same : 0u; nC += (ro == ROW_C) ? same : 0u; nT += (ro == ROW_T) ? same : 0u;
+    nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
+}
+
+// two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
+// The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
+// records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
+// hidden by the other 7 waves of the SIMD, not by software pipelining (which measured slower).
+template <int GW>
+__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, u32 e0, u32 e1,
+                                           u32 wave, u32 lane) {
+    typedef PlainCfg<GW> C;
+    // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
+    // of the items does not matter: the counters are integers)
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + C::IPP - 1u) / C::IPP * C::IPP;
+    const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
+    if (lo_w >= hi_w) return;
+    for (u32 eb = lo_w; eb < hi_w; eb += C::BATCH) {
+        const u32 nb = min(C::BATCH, hi_w - eb);
+        const uint4 my = A.entA[eb + min(lane, nb - 1u)];
+        const u32 my_flags = (my.y >> 16) & 0xFFu;
+        const bool my_slow = lane < nb && my_flags != 0;
+        const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
+        for (u32 first = 0; first < nb; first += C::IPP)
+            plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+        // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
+        u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
+        while (rest) {
+            const u32 j = (u32)__ffsll((long long)rest) - 1u;
+            rest &= rest - 1;
+            const FastItem f = fast_fetch(my, j, nb, A.seq);
+            fast_apply(cnt, asm_w, f, fast_load(A.seq, f, lane), lane);
+        }
+        u64 slow = __ballot(my_slow);
+        while (slow) {
+            const int j = __ffsll((long long)slow) - 1;
+            slow &= slow - 1;
+            const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j), idx = (u32)__builtin_amdgcn_readlane((int)my.w, j);
+            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
+            const u32 kc = (ey >> 8) & 0xFFu;
+            const u8 *s = A.seq + A.seq_off[idx];
+            if (!((ey >> 16) & ENT_COMPLEX)) {
+                // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
+                const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+                for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+            } else {
+                const u32 *cg = A.cigar + A.cig_off[idx];
+                const u32 nc = A.n_cig[idx];
+                int ent0 = 0;
+                u64 ro = 0;
+                for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+                    const u32 op = cg[r], len = op >> 4, o = op & 15u;
+                    if (o == PP_OP_I) { ro += len; continue; }
+                    u32 ins = 0;
+                    for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+                    const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+                    for (int q = a + (int)lane; q < b; q += 64) {
+                        const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+                        int row;
+                        if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
+                        else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
+                        tile_add(cnt, row, rel + q, kc);
+                    }
+                    ent0 += (int)len;
+                    if (o != PP_OP_D) ro += len;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
+    __shared__ u32 cnt[N_ROWS * TILE];
+    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
+    __shared__ u64 s_depth;
+
+    // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
+    u32 per = gridDim.x >> 3;
+    u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (w >= A.nwin || job_state(A.status) == 2) return;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u64 w0 = (u64)w * TILE;
+
+    for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
+    {
+        u8 *ab = (u8 *)asm_w;
+        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        if (tid < (u32)ASM_PAD) ab[tid] = 0;
+        if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
+    }
+    if (tid == 0) {
+        s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0;
+        s_c0 = find_contig(A.contig_off, A.n_contigs, w0);
+        u64 last = min(w0 + TILE, A.G) - 1;
+        s_c1 = find_contig(A.contig_off, A.n_contigs, last);
+    }
+    __syncthreads();
+
+    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    {
+        const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
+        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else tile_items<8>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+    }
+    if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
+    __syncthreads();
+
+    // ---- coverage of the fast class: prefix sum of the difference array, in place ----
+    {
+        u32 *cov = cnt + ROW_COV * TILE;
+        const u32 d0 = cov[2 * tid], d1 = cov[2 * tid + 1];
+        const u32 sum = d0 + d1;
+        u32 inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += v;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        u32 base = 0;
+        for (u32 i = 0; i < wave; i++) base += s_wsum[i];
+        const u32 ex = base + inc - sum;
+        cov[2 * tid] = ex + d0;
+        cov[2 * tid + 1] = ex + d0 + d1;
+    }
+    __syncthreads();
+
+    // ---- vote: one lane per position ----
+    u32 my_len = 0, my_changed = 0, my_zero = 0;
+    u64 my_depth = 0;
+    const bool one_contig = (s_c0 == s_c1);
+    for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
+        const u64 gp = w0 + p;
+        if (gp >= A.G) break;
+        if (A.own) {  // window tiling: halo positions are voted by the rank that owns them
+            const u32 c = one_contig ? s_c0 : find_contig(A.contig_off, A.n_contigs, gp);
+            const u32 rel = (u32)(gp - A.contig_off[c]);
+            if (rel < A.own[2 * c] || rel >= A.own[2 * c + 1]) {
+                A.code[gp] = 0;
+                continue;
+            }
+        }
+        u32 nA, nC, nG, nT, nDel, nOth;
+        const u32 defw = cnt[ROW_DEF * TILE + p];
+        const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
+        position_tallies(cnt, orig, p, nA, nC, nG, nT, nDel, nOth);
+        const bool nd = (defw >> 31) != 0 || ((s_ndbits[p >> 5] >> (p & 31u)) & 1u) != 0;
+        const u32 deficit = defw & 0x7FFFFFFFu;
+        const u32 ntot = nA + nC + nG + nT + nDel + nOth;
+        if (orig >= 0x80u) report(A.status, gp, DE_NON_ASCII);
+        const u64 dfx = ((u64)ntot << DEPTH_FX_BITS) - deficit;
+        const double depth = (double)dfx * (1.0 / (double)(1u << DEPTH_FX_BITS));  // exact
+        bool flag = false;
+        VoteOut v;
+        v.out = (orig == (u8)'-') ? 0 : orig;
+        v.status = PP_ST_LOW_DEPTH;
+        v.vthr = 0; v.ithr = 0;
+        if (nd) {
+            // depth is an order-dependent f64 sum: exact only in k_exact.  depth <= ntot always,
+            // so ntot < min_depth already decides DepthTooLow.
+            if (ntot >= A.min_depth || A.dbg) flag = true;
+        } else {
+            const u32 ithr = d_bankers(__dmul_rn(depth, A.fi));
+            if (!(depth < (double)A.min_depth) && nOth > 0 && nOth >= ithr) flag = true;
+            else v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+        }
+        if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
+        if (flag) {
+            const bool to_list = A.dbg == 1 || e1 - e0 > SORT_MAX;  // dbg 2: test hook, see run_pipeline
+            if (!to_list) {
+                atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
+                atomicAdd(&s_nflag, 1u);
+            } else {
+                atomicAdd(&A.counters[2], 1u);
+            }
+            if (to_list) {
+                // bucket too large for the wave-per-position replay: global list for k_exact
+                const u32 slot = atomicAdd(&A.counters[0], 1u);
+                atomicAdd(A.scr_need, (u64)ntot);
+                if (slot < A.cap_flag) {
+                    A.flag_pos[slot] = (u32)gp;
+                    A.flag_cov[slot] = ntot;
+                } else {
+                    report(A.status, slot, DE_CAPACITY_LATE);
+                }
+            }
+            A.code[gp] = 0;
+            continue;
+        }
+        A.code[gp] = v.out;
+        const u32 l = v.out ? 1u : 0u, ch = (v.status == PP_ST_CHANGED), z = (ntot == 0);
+        if (one_contig) {
+            my_len += l; my_changed += ch; my_zero += z; my_depth += dfx;
+        } else {
+            my_len += l;
+            const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
+            if (ch) atomicAdd(&A.stats[c].changed, 1ull);
+            if (z) atomicAdd(&A.stats[c].zero_depth, 1ull);
+            if (dfx) atomicAdd(&A.stats[c].depth_fx, dfx);
+        }
+        if (A.dbg) {
+            A.dbg_depth[gp] = depth;
+            A.dbg_counts[0 * A.G + gp] = nA;
+            A.dbg_counts[1 * A.G + gp] = nC;
+            A.dbg_counts[2 * A.G + gp] = nG;
+            A.dbg_counts[3 * A.G + gp] = nT;
+            A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+            A.dbg_counts[5 * A.G + gp] = v.vthr;
+            A.dbg_counts[6 * A.G + gp] = v.ithr;
+            A.dbg_status[gp] = v.status;
+        }
+    }
+    my_len = wave_sum(my_len);
+    my_changed = wave_sum(my_changed);
+    my_zero = wave_sum(my_zero);
+    my_depth = wave_sum64(my_depth);
+    if (lane == 0) {
+        if (my_len) atomicAdd(&s_len, my_len);
+        if (my_changed) atomicAdd(&s_changed, my_changed);
+        if (my_zero) atomicAdd(&s_zero, my_zero);
+        if (my_depth) atomicAdd(&s_depth, my_depth);
+    }
+    __syncthreads();
+    if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
+    if (s_nflag && e1 - e0 <= SORT_MAX) {
+        // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
+        if (tid == 0) {
+            const u32 slab = atomicAdd(&A.counters[3], 1u);
+            if (slab >= A.cap_slabs) report(A.status, slab, DE_CAPACITY_LATE);
+            s_c1 = slab;
+            A.win_slab[w] = slab;
+        }
+        __syncthreads();
+        const u32 slab = s_c1;
+        if (slab < A.cap_slabs) {
+            u32 *dst = A.slabs + (u64)slab * 6u * TILE;
+            for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
+                u32 nA, nC, nG, nT, nDel, nOth;
+                position_tallies(cnt, ((const u8 *)asm_w)[ASM_PAD + p], p, nA, nC, nG, nT, nDel, nOth);
+                dst[0 * TILE + p] = nA; dst[1 * TILE + p] = nC; dst[2 * TILE + p] = nG;
+                dst[3 * TILE + p] = nT; dst[4 * TILE + p] = nDel; dst[5 * TILE + p] = nOth;
+            }
+        }
+    }
+    if (tid == 0) {
+        A.win_nflag[w] = s_nflag;
+        if (s_nflag) atomicAdd(&A.counters[2], s_nflag);
+        A.win_len[w] = s_len;
+        if (s_changed) atomicAdd(&A.stats[s_c0].changed, (u64)s_changed);
+        if (s_zero) atomicAdd(&A.stats[s_c0].zero_depth, (u64)s_zero);
+        if (s_depth) atomicAdd(&A.stats[s_c0].depth_fx, s_depth);
+    }
+}
+
+}  // namespace pp

@@ -2,7 +2,7 @@
 """Experiment (needs an instrumented build of the library, PP_LIB_PATH): per-phase wall-clock stamps of k_exact2 on a
 job whose every window has order-dependent depths (3 % of the reads with share 1/3, scattered).
 
-The instrumented build adds, in a scratch copy of pp_kernels.hip, `__syncthreads(); if (tid == 0) T[i] = wall_clock64();`
+The instrumented build adds, in a scratch copy of pp_k_exact.h, `__syncthreads(); if (tid == 0) T[i] = wall_clock64();`
 at the phase boundaries of k_exact2 and one device printf of the differences per 97th window.  Round-1 result
 (MI355X, n = 2.7-3.0 K items per window, all 2048 positions flagged; units of 10 ns):
     sort 9-11 us | step 2 (extent + share per item) 12-17 us | ordered pass 60-63 us | vote 2.5-3.3 us
