@@ -3,6 +3,7 @@
 #   bin/polypolish                               the drop-in CLI (links the library)
 #   oracle/_build/*                              the CPU oracle (test infrastructure only)
 #   bin/polish_min                               examples/polish_min.c: a plain C99 host over the C ABI
+#   tools/_build/libsamgen.so                    SAM text writer for bench.py's end-to-end leg (not product)
 # -ffp-contract=off: the vote's banker's rounding must see the unfused product depth*fraction.
 HIPCC    ?= hipcc
 ARCH     ?= gfx950
@@ -13,7 +14,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iincl
 LIB  := $(OUT)/libpolypolish_hip.so
 OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o
 
-all: $(LIB) bin/polypolish bin/polish_min oracle
+all: $(LIB) bin/polypolish bin/polish_min oracle tools/_build/libsamgen.so
 
 $(OUT)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/polypolish_hip.h
 	@mkdir -p $(OUT)
@@ -38,7 +39,12 @@ bin/polish_min: examples/polish_min.c include/polypolish_hip.h $(LIB)
 oracle:
 	$(MAKE) -C oracle
 
+# SAM / FASTA text writer of the synthetic workloads (bench.py's end-to-end leg; measurement infrastructure)
+tools/_build/libsamgen.so: tools/samgen.c
+	@mkdir -p tools/_build
+	gcc -O2 -std=c11 -Wall -Wextra -shared -fPIC $< -o $@
+
 clean:
-	rm -rf $(OUT) bin oracle/_build
+	rm -rf $(OUT) bin oracle/_build tools/_build
 
 .PHONY: all oracle clean
