@@ -44,7 +44,13 @@ tools/_build/libsamgen.so: tools/samgen.c
 	@mkdir -p tools/_build
 	gcc -O2 -std=c11 -Wall -Wextra -shared -fPIC $< -o $@
 
+# kernel experiments: make variant NAME=x DEFS="-DPP_..." -> $(OUT)/var_x/libpolypolish_hip.so (use with PP_LIB_PATH)
+variant: $(LIB)
+	@mkdir -p $(OUT)/var_$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pp_kernels.hip -o $(OUT)/var_$(NAME)/pp_kernels.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/var_$(NAME)/libpolypolish_hip.so $(OUT)/var_$(NAME)/pp_kernels.o $(filter-out $(OUT)/pp_kernels.o,$(OBJS)) -lz -lpthread
+
 clean:
 	rm -rf $(OUT) bin oracle/_build tools/_build
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean variant

@@ -105,6 +105,12 @@ __device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+// the same through a non-temporal load (a byte-aligned vector type keeps it one unaligned 16-byte instruction)
+typedef u32 u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ uint4 load16_stream(const u8 *p) {
+    const u32x4_unaligned v = __builtin_nontemporal_load((const u32x4_unaligned *)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
     u32 v;
     __builtin_memcpy(&v, p, 4);

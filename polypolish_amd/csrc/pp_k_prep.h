@@ -4,9 +4,12 @@
 #pragma once
 
 namespace pp {
+#ifndef PP_PREP_INLINE
+#define PP_PREP_INLINE __forceinline__
+#endif
 
 // every record that is not a single short M run inside its contig
-__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
+__device__ PP_PREP_INLINE void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
                                                u64 c_lo, u64 c_hi, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
     // walk the runs (alignment.rs:178-194): spans and validity
     u64 ref_span = 0, read_span = 0;

@@ -5,7 +5,7 @@
 
 namespace pp {
 
-constexpr u32 REGROUP_THREADS = 512;
+constexpr u32 REGROUP_THREADS = 1024;
 constexpr u32 MAX_SUB = 256;  // windows per coarse bucket (8 bits of a unit)
 
 struct RegroupArgs {
@@ -45,17 +45,35 @@ __global__ __launch_bounds__(REGROUP_THREADS) void k_regroup(RegroupArgs A) {
     const u64 nlate = min(*A.n_late, A.cap_late);
     const u32 stride = A.nbk + 1u;
     for (int pass = 0; pass < 2; pass++) {
-        for (u32 sg = tid; sg < nseg; sg += REGROUP_THREADS) {
-            const unsigned short *row = A.seg_off + (u64)sg * stride;
-            const u32 o0 = row[c], o1 = row[c + 1];
-            const u64 *p = A.units_in + A.seg_base[sg];
-            for (u32 i = o0; i < o1; i++) {
-                const u64 u = p[i];
-                const u32 lo = (u32)u, tag = lo & 3u, sub = lo >> 24;
-                if (tag == UNIT_NOP) continue;
-                const u32 cls = tag == UNIT_EVENT ? 1u : 0u;
-                const u32 at = atomicAdd(&cnt[cls][sub], 1u);
-                if (pass) A.units_out[s_base + at] = u;
+        // One lane per (segment, bucket) piece; loads batched so that several are in flight per lane: the offset
+        // pairs and bases of four segments at once, then four units of a piece at a time.
+        for (u32 sg0 = tid; sg0 < nseg; sg0 += 4u * REGROUP_THREADS) {
+            u32 o0[4], o1[4];
+            const u64 *pp[4];
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                const u32 sg = sg0 + q * REGROUP_THREADS;
+                const bool ok = sg < nseg;
+                const unsigned short *row = A.seg_off + (u64)(ok ? sg : 0u) * stride;
+                o0[q] = ok ? row[c] : 0u;
+                o1[q] = ok ? row[c + 1] : 0u;
+                pp[q] = A.units_in + A.seg_base[ok ? sg : 0u];
+            }
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                const u64 *p = pp[q];
+                for (u32 i = o0[q]; i < o1[q]; i += 4) {
+                    u64 v[4];
+#pragma unroll
+                    for (u32 r = 0; r < 4; r++) v[r] = i + r < o1[q] ? p[i + r] : (u64)UNIT_NOP;
+#pragma unroll
+                    for (u32 r = 0; r < 4; r++) {
+                        const u32 lo = (u32)v[r], tag = lo & 3u, sub = lo >> 24;
+                        if (tag == UNIT_NOP) continue;
+                        const u32 at = atomicAdd(&cnt[tag == UNIT_EVENT ? 1u : 0u][sub], 1u);
+                        if (pass) A.units_out[s_base + at] = v[r];
+                    }
+                }
             }
         }
         for (u64 e = tid; e < nlate; e += REGROUP_THREADS) {

@@ -19,10 +19,25 @@
 namespace pp {
 
 constexpr u32 UNIT_PLAIN = 0, UNIT_EVENT = 1, UNIT_SLOW = 2, UNIT_NOP = 3;
-constexpr u32 STREAM_THREADS = 1024;
+// Geometry of k_stream (compile-time; the defaults are the measured best, the macros exist for experiments)
+#ifndef PP_STREAM_THREADS
+#define PP_STREAM_THREADS 1024
+#endif
+#ifndef PP_STREAM_MINW
+#define PP_STREAM_MINW 8      // waves per SIMD the register allocation must allow (8 -> 64 VGPRs, 4 -> 128)
+#endif
+#ifndef PP_STREAM_LDS_KB
+#define PP_STREAM_LDS_KB 80   // LDS per workgroup: units staged per segment ~ this / 10 bytes
+#endif
+#ifndef PP_STREAM_NT
+#define PP_STREAM_NT 0     // 1: non-temporal loads for the SEQ stream (experiment)
+#endif
+constexpr u32 STREAM_THREADS = PP_STREAM_THREADS;
 constexpr u32 STREAM_WAVES = STREAM_THREADS / 64;
+constexpr u32 STREAM_BLOCKS_PER_CU = (PP_STREAM_MINW * 256) / PP_STREAM_THREADS < 160 / PP_STREAM_LDS_KB
+                                         ? (PP_STREAM_MINW * 256) / PP_STREAM_THREADS : 160 / PP_STREAM_LDS_KB;
 constexpr u32 STREAM_BATCH = 60;          // records per wave and block iteration (a multiple of every group count)
-constexpr u32 STREAM_HEADROOM = 2304;     // staged units a block iteration may add before the segment is flushed
+constexpr u32 STREAM_HEADROOM = STREAM_WAVES * STREAM_BATCH * 2;  // units the waves may add before they all notice that a segment is due
 constexpr u32 STREAM_DIRECT_WINDOWS = 8;  // a SLOW record spanning more windows goes to the late list as ONE entry
 constexpr int UNIT_REL_BIAS = 256;
 
@@ -75,6 +90,7 @@ struct StreamArgs {
     u64 cap_late;
     u32 *nkeep_arr;        // kept entries of SLOW records (written here, read by k_tile / the replay kernels)
     u64 *status;
+    u64 *prof;             // PP_STREAM_PROFILE builds: cycles per phase, summed over the waves
 };
 
 struct Stage {
@@ -107,61 +123,78 @@ __device__ __forceinline__ void stage_at(const StreamArgs &A, const Stage &S, u3
     }
 }
 
-// Sort the staged units by bucket and write them out as one segment.  Called by every thread of the block
-// (after a __syncthreads()); leaves the staging empty.
-__device__ void stream_flush(const StreamArgs &A, const Stage &S, u32 *s_wtot, u64 *s_base, u32 *s_seg) {
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 n = min(*S.n, S.cap);
-    if (n == 0) {
-        __syncthreads();
-        if (tid == 0) *S.n = 0;  // everything offered went to the late list
+// Sort the staged units by bucket and write them out as one segment.  Called by every thread of the block after the
+// rendezvous barrier (nobody appends).  Barriers are what a flush costs, so there are three: the first wave scans the
+// bucket counts into cursors and fetches the segment's place in HBM while the others wait; every thread then sends
+// its units to their place in the segment (LDS cursors; the segment's footprint is small and written within
+// microseconds, L2 merges the 8-byte stores).  The bucket counts for the NEXT segment live in the other half of a
+// double array that this flush clears on the way, so nothing is cleared between the last barrier and the appends.
+__device__ void stream_flush(const StreamArgs &A, const Stage &S, u32 *hist_next, u64 *s_base, u32 *s_seg) {
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u32 n = min(*(volatile u32 *)S.n, S.cap);
+    if (n == 0) {  // uniform: everything offered went to the late list, or nothing was offered
+        if (tid == 0) *S.n = 0;
         __syncthreads();
         return;
     }
-    // exclusive scan of the bucket counts: PER consecutive buckets per thread, wave scan, wave totals
-    const u32 per = (A.nbk + STREAM_THREADS - 1u) / STREAM_THREADS;
-    const u32 b0 = min(A.nbk, tid * per), b1 = min(A.nbk, b0 + per);
-    u32 sum = 0;
-    for (u32 b = b0; b < b1; b++) sum += S.hist[b];
-    u32 inc = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 v = (u32)__shfl_up((int)inc, o, 64);
-        if ((int)lane >= o) inc += v;
-    }
-    if (lane == 63u) s_wtot[wave] = inc;
-    if (tid == 0) {
-        const u64 base = atomicAdd(A.unit_cursor, (u64)n);
-        const u32 seg = atomicAdd(A.seg_cursor, 1u);
+#ifdef PP_STREAM_PROFILE
+    u64 ft0 = clock64(), ft1;
+#define PP_FSTAMP(k) do { ft1 = clock64(); if (lane == 0) atomicAdd(&A.prof[k], ft1 - ft0); ft0 = ft1; } while (0)
+#else
+#define PP_FSTAMP(k) do { } while (0)
+#endif
+    if (tid < 64u) {
+        u64 base = 0;
+        u32 seg = 0;
+        if (lane == 0) {
+            base = atomicAdd(A.unit_cursor, (u64)n);
+            seg = atomicAdd(A.seg_cursor, 1u);
+        }
+        // exclusive scan of the bucket counts: consecutive buckets per lane, wave scan; counts become cursors
+        const u32 per = (A.nbk + 63u) / 64u;
+        const u32 b0 = min(A.nbk, lane * per), b1 = min(A.nbk, b0 + per);
+        u32 sum = 0;
+        for (u32 b = b0; b < b1; b++) sum += S.hist[b];
+        u32 inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = (u32)__shfl_up((int)inc, o, 64);
+            if ((int)lane >= o) inc += v;
+        }
+        base = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(base >> 32)) << 32) |
+               (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)base);
+        seg = (u32)__builtin_amdgcn_readfirstlane((int)seg);
         const bool ok = base + n <= A.cap_units && seg < A.cap_segs;
-        if (!ok) report(A.status, base + n, DE_CAPACITY);  // the cursors keep counting what a rerun needs
-        *s_base = ok ? base : ~0ull;
-        *s_seg = seg;
+        if (!ok && lane == 0) report(A.status, base + n, DE_CAPACITY);  // the cursors keep counting what a rerun needs
+        u32 run = inc - sum;
+        unsigned short *row = A.seg_off + (u64)seg * (A.nbk + 1u);
+        for (u32 b = b0; b < b1; b++) {
+            const u32 c = S.hist[b];
+            S.hist[b] = run;
+            if (ok) row[b] = (unsigned short)run;
+            run += c;
+        }
+        if (lane == 0) {
+            if (ok) {
+                row[A.nbk] = (unsigned short)n;
+                A.seg_base[seg] = base;
+            }
+            *s_base = ok ? base : ~0ull;
+            *s_seg = seg;
+        }
+    } else {
+        for (u32 b = tid - 64u; b < A.nbk; b += STREAM_THREADS - 64u) hist_next[b] = 0;
     }
+    PP_FSTAMP(6);
     __syncthreads();
-    u32 run = inc - sum;
-    for (u32 v = 0; v < wave; v++) run += s_wtot[v];
+    PP_FSTAMP(7);
     const u64 base = *s_base;
-    const bool ok = base != ~0ull;
-    unsigned short *row = A.seg_off + (u64)(*s_seg) * (A.nbk + 1u);
-    for (u32 b = b0; b < b1; b++) {
-        const u32 c = S.hist[b];
-        S.hist[b] = run;  // cursor of the bucket
-        if (ok) row[b] = (unsigned short)run;
-        run += c;
-    }
-    if (ok && tid == 0) {
-        row[A.nbk] = (unsigned short)n;
-        A.seg_base[*s_seg] = base;
-    }
-    __syncthreads();
-    if (ok) {
+    if (base != ~0ull) {
         for (u32 i = tid; i < n; i += STREAM_THREADS) {
             const u32 p = atomicAdd(&S.hist[S.bkt[i]], 1u);
             A.units[base + p] = S.units[i];
         }
     }
-    __syncthreads();
-    for (u32 b = tid; b < A.nbk; b += STREAM_THREADS) S.hist[b] = 0;
+    PP_FSTAMP(0);
     if (tid == 0) *S.n = 0;
     __syncthreads();
 }
@@ -176,17 +209,28 @@ struct RecInfo {
     u64 so;     // PLAIN: offset of the read in the seq array
 };
 
-__device__ __forceinline__ RecInfo stream_classify(const StreamArgs &A, u64 a, bool valid) {
+// the SoA fields of one record (first round trip; prefetched one block iteration ahead)
+struct RecFields {
+    u32 c, nc, sl, rs, k;
+    u64 co, so;
+};
+__device__ __forceinline__ RecFields stream_fields(const StreamArgs &A, u64 a) {
+    const u64 ai = min(a, A.n - 1ull);  // unconditional loads, clamped
+    RecFields F;
+    F.c = A.contig[ai]; F.nc = A.n_cig[ai]; F.sl = A.seq_len[ai]; F.rs = A.ref_start[ai]; F.k = A.kk[ai];
+    F.co = A.cig_off[ai]; F.so = A.seq_off[ai];
+    return F;
+}
+
+// c_lo / c_hi: bounds of the record's contig (clamped index), op0: its first CIGAR run -- the second round trip
+__device__ __forceinline__ RecInfo stream_classify(const StreamArgs &A, u64 a, bool valid, const RecFields &F, u64 c_lo,
+                                                   u64 c_hi, u32 op0) {
     RecInfo R;
     R.g = 0; R.len = 0; R.kind = 0; R.flags = 0; R.nd = 0; R.so = 0;
-    const u64 ai = min(a, A.n - 1ull);  // unconditional loads, clamped
-    const u32 c = A.contig[ai], nc = A.n_cig[ai], sl = A.seq_len[ai], rs = A.ref_start[ai], k = A.kk[ai];
-    const u64 co = A.cig_off[ai], so = A.seq_off[ai];
-    const u32 cc = min(c, A.n_contigs - 1u);
-    const u64 c_lo = A.contig_off[cc], c_hi = A.contig_off[cc + 1];
-    const u32 *cg = A.cigar + co;
-    const u32 op0 = (valid && nc) ? cg[0] : 0u;
     if (!valid) return R;
+    const u32 c = F.c, nc = F.nc, sl = F.sl, rs = F.rs, k = F.k;
+    const u64 so = F.so;
+    const u32 *cg = A.cigar + F.co;
     bool bad = false;
     if (k == 0) { report(A.status, a, DE_BAD_K); bad = true; }
     if (so + sl > (1ull << 40)) { report(A.status, a, DE_OVERFLOW); bad = true; }
@@ -222,136 +266,164 @@ __device__ __forceinline__ RecInfo stream_classify(const StreamArgs &A, u64 a, b
     return R;
 }
 
-// ---- PLAIN passes: GW lanes per read, 32 read bytes per lane, compared with the assembly bytes at the same positions
+// ---- PLAIN passes: GW lanes per read, 32 read bytes per lane, compared with the assembly bytes at the same positions.
+// Everything that is per READ (trim, units) was done with one record per lane before the passes; a pass only loads,
+// compares and stages one EVENT per differing base.  (Measured and dropped: pipelining the loads of the next pass
+// behind this one, and a cheap any-difference test with the byte-level work handed to eight lanes through LDS --
+// both slower here: the passes are bound by the rate at which the memory pipeline takes the four 16-byte loads.)
 template <int GW>
 __device__ __forceinline__ void stream_plain_passes(const StreamArgs &A, const Stage &S, u64 base, u32 nb, u32 lane,
-                                                    const RecInfo &my) {
+                                                    u32 my_g, u64 my_so, u32 my_nkeep) {
     typedef PlainCfg<GW> C;
     const u32 g = C::group(lane), s = lane - (u32)GW * g;
-    const u32 my_w1 = my.len | (my.nd << 8) | ((my.kind == 1u ? 1u : 0u) << 9);
-    const u64 below = (1ull << lane) - 1ull;
     for (u32 first = 0; first < nb; first += C::IPP) {
         const u32 j = first + g;
         const int src = (int)(min(j, nb - 1u) << 2);
-        const u32 rg = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.g);
-        const u32 w1 = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my_w1);
-        const u32 solo = (u32)__builtin_amdgcn_ds_bpermute(src, (int)(u32)my.so);
-        const u32 sohi = (u32)__builtin_amdgcn_ds_bpermute(src, (int)(u32)(my.so >> 32));
-        const u32 L = w1 & 0xFFu;
-        const bool plain = g < C::IPP && j < nb && ((w1 >> 9) & 1u);
-        const bool active = plain && 32u * s < L;
-        const u8 *rp = A.seq + ((u64)solo | ((u64)sohi << 32));
-        uint4 Wa = make_uint4(0, 0, 0, 0), Wb = Wa, Aa = Wa, Ab = Wa;
-        u32 tail = 0;
-        if (plain) tail = load4_unaligned(rp + (L - 4u));
-        if (active) {
-            const u8 *lp = rp + 32u * s, *ap = A.bases + ((u64)rg + 32u * s);
-            Wa = load16_unaligned(lp);
-            Wb = load16_unaligned(lp + 16);
-            Aa = load16_unaligned(ap);
-            Ab = load16_unaligned(ap + 16);
-        }
-        // ---- trim (alignment.rs:364-378): kept entries = index of the last base that differs from the last base
-        const u32 last = tail >> 24;
-        const u32 tf = nz_flags(tail ^ splat8(last));
-        int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
-        if (plain && tf == 0) {  // rare: a homopolymer of four or more at the end, walk left
-            u32 i = L - 4u;
-            while (i > 0 && rp[i - 1] == (u8)last) i--;
-            nkeep = i > 0 ? (int)i - 1 : 0;
-        }
-        const bool live = plain && nkeep > 0;
-        // ---- PLAIN units: one per overlapped window (one or two), written by the group's first lane
-        const u32 wA = rg >> 11, wB = (rg + (u32)max(nkeep, 1) - 1u) >> 11;
-        const bool e1 = live && s == 0, e2 = e1 && wB != wA;
-        const u64 m1 = __ballot(e1), m2 = __ballot(e2);
-        // ---- compare: bit i <=> byte i of this lane differs from the assembly; bytes past the kept entries drop out
-        u32 D = 0;
-        if (live && active) {
-            D = nz_mask4(Wa.x ^ Aa.x) | (nz_mask4(Wa.y ^ Aa.y) << 4) | (nz_mask4(Wa.z ^ Aa.z) << 8) | (nz_mask4(Wa.w ^ Aa.w) << 12) |
+        const u32 rg = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my_g);
+        const u32 nk = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my_nkeep);  // 0 unless PLAIN with kept entries
+        const u32 solo = (u32)__builtin_amdgcn_ds_bpermute(src, (int)(u32)my_so);
+        const u32 sohi = (u32)__builtin_amdgcn_ds_bpermute(src, (int)(u32)(my_so >> 32));
+        const bool active = g < C::IPP && j < nb && 32u * s < nk;
+        if (!active) continue;
+        const u8 *lp = A.seq + ((u64)solo | ((u64)sohi << 32)) + 32u * s;
+        const u8 *ap = A.bases + ((u64)rg + 32u * s);
+        const uint4 Wa = load16_unaligned(lp), Wb = load16_unaligned(lp + 16);
+        const uint4 Aa = load16_unaligned(ap), Ab = load16_unaligned(ap + 16);
+        // bit i <=> byte i of this lane differs from the assembly; bytes past the kept entries drop out
+        u32 D = nz_mask4(Wa.x ^ Aa.x) | (nz_mask4(Wa.y ^ Aa.y) << 4) | (nz_mask4(Wa.z ^ Aa.z) << 8) | (nz_mask4(Wa.w ^ Aa.w) << 12) |
                 (nz_mask4(Wb.x ^ Ab.x) << 16) | (nz_mask4(Wb.y ^ Ab.y) << 20) | (nz_mask4(Wb.z ^ Ab.z) << 24) |
                 (nz_mask4(Wb.w ^ Ab.w) << 28);
-            const int b1 = min(max(nkeep - (int)(32u * s), 0), 32);
-            D = b1 > 0 ? (D & (0xFFFFFFFFu >> (32 - b1))) : 0u;
-        }
-        const u32 ne = (u32)__popc(D);
-        const u32 idx = (u32)(base + j);
-        if (m1) {
-            u32 slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(S.n, (u32)__popcll(m1) + (u32)__popcll(m2));
-            slot0 = (u32)__builtin_amdgcn_readfirstlane((int)slot0);
-            if (e1) stage_at(A, S, slot0 + (u32)__popcll(m1 & below), unit_plain(idx, (int)(rg - (wA << 11)), (u32)nkeep, (w1 >> 8) & 1u, 0), wA);
-            if (e2) stage_at(A, S, slot0 + (u32)__popcll(m1) + (u32)__popcll(m2 & below),
-                             unit_plain(idx, (int)rg - (int)(wB << 11), (u32)nkeep, (w1 >> 8) & 1u, 0), wB);
-        }
-        if (ne) {  // one EVENT per differing base (about one lane in sixteen has any)
-            u32 slot = atomicAdd(S.n, ne);
-            const u32 P0 = rg + 32u * s;
-            while (D) {
-                const int i = __ffs((int)D) - 1;
+        const u32 b1 = min(nk - 32u * s, 32u);  // >= 1 here
+        D &= 0xFFFFFFFFu >> (32u - b1);
+        if (D) {  // one EVENT per differing base (about one lane in sixteen has any)
+            u32 slot = atomicAdd(S.n, (u32)__popc(D));
+            const u32 P0 = rg + 32u * s, idx = (u32)(base + j);
+            do {
+                const u32 i = (u32)__ffs((int)D) - 1u;
                 D &= D - 1u;
-                // byte i of the lane's eight dwords, by a select tree on the bits of i (no memory access)
-                const u32 m4 = (u32)(((int)((u32)i << 29)) >> 31), m8 = (u32)(((int)((u32)i << 28)) >> 31),
-                          m16 = (u32)(((int)((u32)i << 27)) >> 31);
+                // byte i of the lane's eight dwords, by a select tree on the bits of i (no memory round trip)
+                const u32 m4 = (u32)(((int)(i << 29)) >> 31), m8 = (u32)(((int)(i << 28)) >> 31), m16 = (u32)(((int)(i << 27)) >> 31);
 #define PP_SEL(m, b, a) (((m) & (b)) | (~(m) & (a)))
                 const u32 w01 = PP_SEL(m4, Wa.y, Wa.x), w23 = PP_SEL(m4, Wa.w, Wa.z);
                 const u32 w45 = PP_SEL(m4, Wb.y, Wb.x), w67 = PP_SEL(m4, Wb.w, Wb.z);
                 const u32 wlo = PP_SEL(m8, w23, w01), whi = PP_SEL(m8, w67, w45);
-                const u32 c = (PP_SEL(m16, whi, wlo) >> (8 * (i & 3))) & 0xFFu;
+                const u32 c = (PP_SEL(m16, whi, wlo) >> (8u * (i & 3u))) & 0xFFu;
 #undef PP_SEL
-                const u32 p = P0 + (u32)i;
+                const u32 p = P0 + i;
                 stage_at(A, S, slot++, unit_event(idx, p & (u32)(TILE - 1), (u32)row_of(c), 0), p >> 11);
-            }
+            } while (D);
         }
     }
 }
 
-__global__ __launch_bounds__(STREAM_THREADS, 8) void k_stream(StreamArgs A) {
+__global__ __launch_bounds__(STREAM_THREADS, PP_STREAM_MINW) void k_stream(StreamArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char stream_smem[];
-    __shared__ u32 s_n, s_wtot[STREAM_WAVES], s_seg;
+    __shared__ u32 s_n, s_next, s_seg;
     __shared__ u64 s_base;
     Stage S;
     S.units = (u64 *)stream_smem;
-    S.hist = (u32 *)(S.units + A.stage_cap);
-    S.bkt = (unsigned short *)(S.hist + A.nbk);
+    u32 *const hist2 = (u32 *)(S.units + A.stage_cap);   // two arrays of bucket counts, used in turn
+    S.hist = hist2;
+    S.bkt = (unsigned short *)(hist2 + 2u * A.nbk);
     S.n = &s_n;
     S.cap = A.stage_cap;
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (u32 b = tid; b < A.nbk; b += STREAM_THREADS) S.hist[b] = 0;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    for (u32 b = tid; b < 2u * A.nbk; b += STREAM_THREADS) hist2[b] = 0;
     const u64 lo = (u64)blockIdx.x * A.chunk, hi = min(A.n, lo + A.chunk);
-    const u32 flush_at = S.cap > STREAM_HEADROOM ? S.cap - STREAM_HEADROOM : 0u;
-    for (u64 it = lo; it < hi; it += (u64)STREAM_WAVES * STREAM_BATCH) {
-        const u64 base = it + (u64)wave * STREAM_BATCH;
-        const u32 nb = base < hi ? (u32)min((u64)STREAM_BATCH, hi - base) : 0u;
-        if (nb) {
-            const RecInfo my = stream_classify(A, base + lane, lane < nb);
-            // the longest PLAIN read of the batch picks the lane-group width: 5 lanes x 32 B up to 160 bases
-            // (12 reads per pass), 6 up to 192 (10), 8 up to 252 (8)
-            u32 longest = my.kind == 1u ? my.len : 0u;
-            for (int o = 32; o > 0; o >>= 1) longest = max(longest, (u32)__shfl_xor((int)longest, o, 64));
-            if (longest) {
-                if (longest <= PlainCfg<5>::MAXL) stream_plain_passes<5>(A, S, base, nb, lane, my);
-                else if (longest <= PlainCfg<6>::MAXL) stream_plain_passes<6>(A, S, base, nb, lane, my);
-                else stream_plain_passes<8>(A, S, base, nb, lane, my);
-            }
-            if (my.kind == 2u) {  // SLOW: one unit per overlapped window, or one late entry for a long span
-                const u32 idx = (u32)(base + lane);
-                A.nkeep_arr[idx] = my.len;
-                const u32 w0 = my.g >> 11, w1 = (u32)(((u64)my.g + my.len - 1ull) >> 11);
-                const u64 unit = unit_slow(idx, my.flags, 0);
-                if (w1 - w0 < STREAM_DIRECT_WINDOWS) {
-                    u32 slot = atomicAdd(S.n, w1 - w0 + 1u);
-                    for (u32 w = w0; w <= w1; w++) stage_at(A, S, slot++, unit, w);
+    const u32 flush_at = A.stage_cap > STREAM_HEADROOM ? A.stage_cap - STREAM_HEADROOM : 0u;
+    if (tid == 0) {
+        s_n = 0;
+        s_next = 0;
+    }
+    __syncthreads();
+#ifdef PP_STREAM_PROFILE
+    u64 pacc[6] = {0, 0, 0, 0, 0, 0}, plast = 0;
+#define PP_STAMP(k) do { const u64 t_ = clock64(); if (k) pacc[k] += t_ - plast; plast = t_; } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+    // The waves of the block take batches of STREAM_BATCH records from a shared counter and only meet (barrier) when a
+    // segment is due or the chunk is used up: between two rendezvous they run freely, and at a rendezvous they are at
+    // most one batch apart.
+    const u32 nbatch = (u32)((hi > lo ? hi - lo : 0ull) + STREAM_BATCH - 1u) / STREAM_BATCH;
+    u32 cur = 0;
+    for (;;) {
+        for (;;) {
+            PP_STAMP(0);
+            if (*(volatile u32 *)S.n >= flush_at) break;  // segment due (a stale read only delays the rendezvous by a batch)
+            u32 bi = 0;
+            if (lane == 0) bi = atomicAdd(&s_next, 1u);
+            bi = (u32)__builtin_amdgcn_readfirstlane((int)bi);
+            if (bi >= nbatch) break;
+            const u64 base = lo + (u64)bi * STREAM_BATCH;
+            const u32 nb = (u32)min((u64)STREAM_BATCH, hi - base);
+            const RecFields F = stream_fields(A, base + lane);
+            // ---- one record per lane: class, trim, units ----
+            const u32 cc = min(F.c, A.n_contigs - 1u);
+            const u64 c_lo = A.contig_off[cc], c_hi = A.contig_off[cc + 1];
+            const bool valid = lane < nb;
+            const u32 op0 = (valid && F.nc) ? A.cigar[F.co] : 0u;
+            const bool tail_ok = valid && F.sl >= 4u && F.so + F.sl <= A.seq_bytes;
+#ifdef PP_EXP_NOTAIL
+            const u32 tail = tail_ok ? 0x41434754u : 0u;
+#else
+            const u32 tail = tail_ok ? load4_unaligned(A.seq + F.so + (F.sl - 4u)) : 0u;
+#endif
+            const RecInfo my = stream_classify(A, base + lane, valid, F, c_lo, c_hi, op0);
+            const u32 idx = (u32)(base + lane);
+            u32 nkeep = 0;  // PLAIN: kept entries after the trim (alignment.rs:364-378)
+            if (my.kind == 1u) {
+                // index of the last base that differs from the last base, read off the last four bases; a trailing
+                // homopolymer of four or more walks left byte by byte (rare)
+                const u8 *rp = A.seq + my.so;
+                const u32 last = tail >> 24;
+                const u32 tf = nz_flags(tail ^ splat8(last));
+                if (tf) {
+                    nkeep = my.len - 4u + (u32)((31 - __clz((int)tf)) >> 3);
                 } else {
-                    late_put(A, w0, w1, unit);
+                    u32 i = my.len - 4u;
+                    while (i > 0 && rp[i - 1] == (u8)last) i--;
+                    nkeep = i > 0 ? i - 1u : 0u;
                 }
             }
+            PP_STAMP(1);
+            const u32 span = my.kind == 1u ? nkeep : (my.kind == 2u ? my.len : 0u);  // entries that reach the pileup
+            const u32 w0 = my.g >> 11, w1 = span ? (u32)(((u64)my.g + span - 1ull) >> 11) : w0;
+            if (my.kind == 2u) A.nkeep_arr[idx] = my.len;
+            if (span) {
+                if (w1 - w0 < STREAM_DIRECT_WINDOWS) {
+                    u32 slot = atomicAdd(S.n, w1 - w0 + 1u);
+                    for (u32 w = w0; w <= w1; w++)  // a PLAIN unit carries its start relative to the window it goes to
+                        stage_at(A, S, slot++, my.kind == 1u ? unit_plain(idx, (int)(my.g - (w << 11)), nkeep, my.nd != 0, 0)
+                                                              : unit_slow(idx, my.flags, 0), w);
+                } else {
+                    late_put(A, w0, w1, unit_slow(idx, my.flags, 0));  // SLOW only: a PLAIN read spans two windows at most
+                }
+            }
+            // ---- the comparison with the assembly: the longest kept stretch of the batch picks the lane-group width:
+            // 5 lanes x 32 B up to 160 bases (12 reads per pass), 6 up to 192 (10), 8 up to 252 (8)
+            PP_STAMP(2);
+            u32 longest = nkeep;
+            for (int o = 32; o > 0; o >>= 1) longest = max(longest, (u32)__shfl_xor((int)longest, o, 64));
+            if (longest) {
+                if (longest <= PlainCfg<5>::MAXL) stream_plain_passes<5>(A, S, base, nb, lane, my.g, my.so, nkeep);
+                else if (longest <= PlainCfg<6>::MAXL) stream_plain_passes<6>(A, S, base, nb, lane, my.g, my.so, nkeep);
+                else stream_plain_passes<8>(A, S, base, nb, lane, my.g, my.so, nkeep);
+            }
+            PP_STAMP(3);
         }
-        __syncthreads();
-        if (s_n > flush_at || it + (u64)STREAM_WAVES * STREAM_BATCH >= hi) stream_flush(A, S, s_wtot, &s_base, &s_seg);
+        __syncthreads();  // rendezvous: nobody is inside a batch
+        PP_STAMP(4);
+        const bool last = *(volatile u32 *)&s_next >= nbatch;
+        cur ^= 1u;
+        stream_flush(A, S, hist2 + cur * A.nbk, &s_base, &s_seg);
+        S.hist = hist2 + cur * A.nbk;
+        PP_STAMP(5);
+        if (last) break;
     }
+#ifdef PP_STREAM_PROFILE
+    if (lane == 0) for (int q = 1; q < 6; q++) atomicAdd(&A.prof[q], pacc[q]);
+#endif
 }
 
 }  // namespace pp

@@ -122,75 +122,92 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
 
 // The units of one window.  PLAIN: two LDS atomics into the coverage difference array (+1 at the first kept
 // position, -1 one past the last; prefix-summed before the vote).  EVENT: the row of the differing base + the
-// mismatch row.  SLOW: the record is walked run by run (indels), one wave per unit, every kept base tallied
-// explicitly (pileup.rs:56-65,189-200).
-__device__ __forceinline__ void tile_units(const TileArgs &A, u32 *cnt, u32 *s_ndbits, u64 e0, u32 total, u64 w0,
-                                           u32 tid, u32 lane) {
-    for (u32 i0 = tid & ~63u; i0 < total; i0 += TILE_THREADS) {
-        const u32 i = i0 + lane;
-        const bool valid = i < total;
-        const u64 u = valid ? A.units[e0 + i] : (u64)UNIT_NOP;
-        const u32 lo32 = (u32)u, tag = lo32 & 3u;
-        if (tag == UNIT_PLAIN) {
-            const int rel = (int)((lo32 >> 2) & 0xFFFu) - UNIT_REL_BIAS;
-            const int nkeep = (int)((lo32 >> 14) & 0xFFu);
-            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-            if (hi > lo) {
-                atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
-                if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
-                if ((lo32 >> 22) & 1u) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
-                    const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
-                    for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
-                        const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
-                        atomicOr(&s_ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
-                    }
+// mismatch row.
+// one unit, one lane: PLAIN and EVENT units are two LDS atomics each
+__device__ __forceinline__ void tile_unit_fast(u32 *cnt, u32 *s_ndbits, u32 lo32) {
+    const u32 tag = lo32 & 3u;
+    if (tag == UNIT_PLAIN) {
+        const int rel = (int)((lo32 >> 2) & 0xFFFu) - UNIT_REL_BIAS;
+        const int nkeep = (int)((lo32 >> 14) & 0xFFu);
+        const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+        if (hi > lo) {
+            atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+            if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+            if ((lo32 >> 22) & 1u) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
+                const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+                for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                    const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                    atomicOr(&s_ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
                 }
             }
-        } else if (tag == UNIT_EVENT) {
-            const u32 p = (lo32 >> 2) & (u32)(TILE - 1), row = (lo32 >> 13) & 7u;
-            atomicAdd(&cnt[row * TILE + p], 1u);
-            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
         }
-        u64 slow = __ballot(tag == UNIT_SLOW);
-        while (slow) {
-            const int j = __ffsll((long long)slow) - 1;
-            slow &= slow - 1;
-            const u32 fl = ((u32)__builtin_amdgcn_readlane((int)lo32, j) >> 2) & 3u;
-            const u32 idx = (u32)__builtin_amdgcn_readlane((int)(u32)(u >> 32), j);
-            const int nkeep = (int)A.nkeep_arr[idx];
-            const u64 g = A.contig_off[A.contig[idx]] + A.ref_start[idx];
-            const int rel = (int)((long long)g - (long long)w0);
-            const u32 kc = kclass_of(A.kk[idx]);
-            const u8 *s = A.seq + A.seq_off[idx];
-            if (!(fl & ENT_COMPLEX)) {
-                // no indels, trimmed by k_stream (long read, contig overhang, dyadic share): entry i is base i
-                const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-                for (int q = lo + (int)lane; q < hi; q += 64) tile_add(cnt, row_of(s[q]), rel + q, kc);
-            } else {
-                const u32 *cg = A.cigar + A.cig_off[idx];
-                const u32 nc = A.n_cig[idx];
-                int ent0 = 0;
-                u64 ro = 0;
-                for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
-                    const u32 op = cg[r], len = op >> 4, o = op & 15u;
-                    if (o == PP_OP_I) { ro += len; continue; }
-                    u32 ins = 0;
-                    for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
-                    const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
-                    for (int q = a + (int)lane; q < b; q += 64) {
-                        const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
-                        int row;
-                        if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
-                        else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
-                        tile_add(cnt, row, rel + q, kc);
-                    }
-                    ent0 += (int)len;
-                    if (o != PP_OP_D) ro += len;
+    } else if (tag == UNIT_EVENT) {
+        const u32 p = (lo32 >> 2) & (u32)(TILE - 1), row = (lo32 >> 13) & 7u;
+        atomicAdd(&cnt[row * TILE + p], 1u);
+        atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+    }
+}
+
+// SLOW units of one wave-load: the record is walked run by run (indels), one wave per unit, every kept base tallied
+// explicitly (pileup.rs:56-65,189-200).
+__device__ __forceinline__ void tile_units_slow(const TileArgs &A, u32 *cnt, u64 u, u64 w0, u32 lane) {
+    const u32 lo32 = (u32)u;
+    const bool is_slow = (lo32 & 3u) == UNIT_SLOW;
+    u64 slow = __ballot(is_slow);
+    if (!slow) return;
+    // the record fields of all SLOW units of this wave-load are fetched side by side (one round of latency) ...
+    u32 f_nkeep = 0, f_kc = 0, f_nc = 0;
+    int f_rel = 0;
+    u64 f_so = 0, f_co = 0;
+    if (is_slow) {
+        const u32 idx = (u32)(u >> 32);
+        f_nkeep = A.nkeep_arr[idx];
+        f_rel = (int)((long long)(A.contig_off[A.contig[idx]] + A.ref_start[idx]) - (long long)w0);
+        f_kc = kclass_of(A.kk[idx]);
+        f_so = A.seq_off[idx];
+        f_co = A.cig_off[idx];
+        f_nc = A.n_cig[idx];
+    }
+    // ... then every unit is walked by the whole wave
+    while (slow) {
+        const int j = __ffsll((long long)slow) - 1;
+        slow &= slow - 1;
+        const u32 fl = ((u32)__builtin_amdgcn_readlane((int)lo32, j) >> 2) & 3u;
+        const int nkeep = __builtin_amdgcn_readlane((int)f_nkeep, j), rel = __builtin_amdgcn_readlane(f_rel, j);
+        const u32 kc = (u32)__builtin_amdgcn_readlane((int)f_kc, j);
+        const u8 *s = A.seq + (((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_so >> 32), j) << 32) |
+                               (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_so, j));
+        if (!(fl & ENT_COMPLEX)) {
+            // no indels, trimmed by k_stream (long read, contig overhang, dyadic share): entry i is base i
+            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+            for (int q = lo + (int)lane; q < hi; q += 64) tile_add(cnt, row_of(s[q]), rel + q, kc);
+        } else {
+            const u32 *cg = A.cigar + (((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_co >> 32), j) << 32) |
+                                       (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_co, j));
+            const u32 nc = (u32)__builtin_amdgcn_readlane((int)f_nc, j);
+            int ent0 = 0;
+            u64 ro = 0;
+            for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+                const u32 op = cg[r], len = op >> 4, o = op & 15u;
+                if (o == PP_OP_I) { ro += len; continue; }
+                u32 ins = 0;
+                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+                const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+                for (int q = a + (int)lane; q < b; q += 64) {
+                    const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+                    int row;
+                    if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
+                    else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
+                    tile_add(cnt, row, rel + q, kc);
                 }
+                ent0 += (int)len;
+                if (o != PP_OP_D) ro += len;
             }
         }
     }
 }
+
+constexpr u32 TILE_UNROLL = 4;  // unit loads in flight per lane
 
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
@@ -204,6 +221,15 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     if (w >= A.nwin || job_state(A.status) == 2) return;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
+    // the first units of every lane are requested before the counters are cleared
+    const u64 e0 = A.win_start[w];
+    const u32 n_items = A.win_nitem[w], n_units = n_items + A.win_nev[w];
+    u64 pre[TILE_UNROLL];
+#pragma unroll
+    for (u32 q = 0; q < TILE_UNROLL; q++) {
+        const u32 i = q * TILE_THREADS + tid;
+        pre[q] = i < n_units ? A.units[e0 + i] : (u64)UNIT_NOP;
+    }
 
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
@@ -219,9 +245,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
 
-    const u64 e0 = A.win_start[w];
-    const u32 n_items = A.win_nitem[w], n_units = n_items + A.win_nev[w];
-    tile_units(A, cnt, s_ndbits, e0, n_units, w0, tid, lane);
+    for (u32 base = 0;; base += TILE_UNROLL * TILE_THREADS) {
+        if (base) {
+#pragma unroll
+            for (u32 q = 0; q < TILE_UNROLL; q++) {
+                const u32 i = base + q * TILE_THREADS + tid;
+                pre[q] = i < n_units ? A.units[e0 + i] : (u64)UNIT_NOP;
+            }
+        }
+#pragma unroll
+        for (u32 q = 0; q < TILE_UNROLL; q++) tile_unit_fast(cnt, s_ndbits, (u32)pre[q]);
+#pragma unroll
+        for (u32 q = 0; q < TILE_UNROLL; q++) tile_units_slow(A, cnt, pre[q], w0, lane);
+        if (base + TILE_UNROLL * TILE_THREADS >= n_units) break;
+    }
     __syncthreads();
 
     // ---- coverage of the fast class: prefix sum of the difference array, in place ----

@@ -262,7 +262,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     // same, counted as the positions are listed) | 5 polished bytes | 6 ordered replay items | 7 segments | 8 key records |
     // 9 late-list entries | 11 units laid out by k_regroup | 16.. contig output offsets (nc+1) | then per-contig stats
     // (3 words each)
-    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
+    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc + 8;  // + 8 words of k_stream phase cycles (profiling builds)
     ENS(b_meta, meta_words * 8);
     // Coarse buckets of 2^shift windows: few enough buckets that a segment's piece for one bucket is a run of several
     // units (segments x buckets pieces in all), at most 256 windows each (8 bits of a unit).
@@ -270,14 +270,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     uint32_t shift = 0;
     while (shift < 8 && ((nwin + (1u << shift) - 1) >> shift) > nbk_target) shift++;
     const uint32_t nbk = (nwin + (1u << shift) - 1) >> shift;
-    // LDS staging of k_stream: two workgroups per CU (80 KiB each): units (8 B) + bucket ids (2 B) + bucket counts
-    const uint32_t lds_budget = 80 * 1024 - 512;
-    if ((uint64_t)nbk * 4 + 64 * 10 > lds_budget) return ctx->fail(PP_ERR_LIMIT, "assembly too long for the bucket table");
-    uint32_t stage_cap = ((lds_budget - nbk * 4) / 10) & ~63u;
+    // LDS staging of k_stream (two workgroups per CU, 80 KiB each): units (8 B) + bucket ids (2 B) + bucket counts
+    const uint32_t lds_budget = PP_STREAM_LDS_KB * 1024 - 512;
+    if ((uint64_t)nbk * 8 + 64 * 10 > lds_budget) return ctx->fail(PP_ERR_LIMIT, "assembly too long for the bucket table");
+    uint32_t stage_cap = ((lds_budget - nbk * 8) / 10) & ~63u;
     if (stage_cap > 65472) stage_cap = 65472;
-    const size_t stream_lds = (size_t)stage_cap * 10 + (size_t)nbk * 4;
+    const size_t stream_lds = (size_t)stage_cap * 10 + (size_t)nbk * 8;
     const uint32_t per_iter = STREAM_WAVES * STREAM_BATCH;
-    const uint32_t NBs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + per_iter - 1) / per_iter));
+    const uint32_t NBs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256 * STREAM_BLOCKS_PER_CU, (n + per_iter - 1) / per_iter));
     const uint64_t chunk = ((n + NBs - 1) / NBs + per_iter - 1) / per_iter * per_iter;
     ctx->cap_segs = std::max<size_t>(ctx->cap_segs, (size_t)(ctx->cap_units / std::max<uint32_t>(1, stage_cap / 2) + NBs + 64));
     ENS(b_units1, ctx->cap_units * 8); ENS(b_units2, ctx->cap_uout * 8);
@@ -302,7 +302,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
 
     if (!ctx->lds_attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for once per device
-        PP_HIPCHK(ctx, hipFuncSetAttribute((const void *)k_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PP_HIPCHK(ctx, hipFuncSetAttribute((const void *)k_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
         ctx->lds_attr_set = true;
     }
     timer_begin(ctx, "stream");
@@ -317,7 +317,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
         S.seg_off = (unsigned short *)ctx->b_seg_off.p; S.seg_base = (u64 *)ctx->b_seg_base.p;
         S.seg_cursor = (u32 *)(d_meta + 7); S.cap_segs = (u32)ctx->cap_segs;
         S.late = (LateEnt *)ctx->b_late.p; S.late_cursor = d_meta + 9; S.cap_late = ctx->cap_late;
-        S.nkeep_arr = (u32 *)ctx->b_nkeep.p; S.status = d_status;
+        S.nkeep_arr = (u32 *)ctx->b_nkeep.p; S.status = d_status; S.prof = d_meta + 16 + nc + 1 + 3 * (size_t)nc;
         hipLaunchKernelGGL(k_stream, dim3(NBs), dim3(STREAM_THREADS), stream_lds, st, S);
     }
     timer_end(ctx);
@@ -413,6 +413,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     PP_HIPCHK(ctx, hipMemcpyAsync(meta.data(), d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
     *n_entries_out = meta[3];
+#ifdef PP_STREAM_PROFILE
+    { const uint64_t *pf = &meta[16 + nc + 1 + 3 * (size_t)nc];
+      fprintf(stderr, "[stream profile] classify %llu units %llu passes %llu barrier %llu flush %llu (wave-cycles)\n", (unsigned long long)pf[1], (unsigned long long)pf[2], (unsigned long long)pf[3], (unsigned long long)pf[4], (unsigned long long)pf[5]);
+      fprintf(stderr, "[stream profile] inside flush: own part before barrier 1 %llu, wait at barrier 1 %llu, scatter %llu\n", (unsigned long long)pf[6], (unsigned long long)pf[7], (unsigned long long)pf[0]); }
+#endif
     return PP_OK;
 }
 

@@ -13,5 +13,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INS
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAVES_EQ_64 SQ_INSTS_VALU_MFMA_I8 --output-format csv -d /tmp/sq3 -- $BENCH > /dev/null 2> "$OUT/sq3.log"
 cd "$ROOT"
 python tools/prof_summary.py /tmp/sq1 /tmp/sq2 /tmp/sq3 > "$OUT/sq_summary.txt"
-grep -A12 "^k_tile\|^k_fill\|^k_prep" "$OUT/sq_summary.txt"
+grep -A26 "^k_stream\|^k_regroup\|^k_tile" "$OUT/sq_summary.txt"
 tail -3 "$OUT"/sq*.log
