@@ -16,7 +16,9 @@ namespace pp {
 
 // ---- geometry of the pileup tile kernel ----------------------------------------------------
 constexpr int TILE = 2048;           // assembly positions owned by one workgroup ("window")
-constexpr int TILE_THREADS = 1024;   // 16 waves; two workgroups per CU (75 KiB LDS each)
+constexpr int TILE_THREADS = 1024;   // 16 waves; two workgroups per CU (57 KiB LDS each)
+constexpr int COARSE_WINDOWS = 8;     // windows per coarse bucket of the two-level multisplit
+constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the bucketing kernels
 constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
 constexpr uint32_t SORT_MAX = 16384;      // items per window the ordered-depth replay kernel sorts in LDS (128 KiB)
@@ -77,7 +79,6 @@ struct pp_ctx {
     bool timer_open = false;
     std::vector<hipEvent_t> event_pool;
     bool debug = false;
-    bool lds_attr_set = false;
     std::vector<pp::KernelTimer> timers;
     pp_kernel_times last_times{};
 
@@ -97,11 +98,11 @@ struct pp_ctx {
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
     pp::DevBuf b_in[9];  // uploaded batch arrays
-    pp::DevBuf b_nkeep, b_units1, b_units2, b_seg_off, b_seg_base, b_late, b_win_start, b_win_nitem, b_win_nev;
+    pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slabs, b_ents, b_keys, b_own;
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
-    size_t cap_units = 0, cap_uout = 0, cap_segs = 0, cap_late = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
+    size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
 
     // ---- filter job ----

@@ -1,0 +1,228 @@
+// pp_k_bucket.h -- k_count / k_scan_cols / k_scan / k_fill / k_regroup: multisplit of the records into 2048-position windows.
+// Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
+#pragma once
+
+namespace pp {
+
+// =============================================================================================
+// bucketing: count -> scan -> fill (no global atomics; LDS histograms per block and window range)
+// =============================================================================================
+// Two-level multisplit of the (alignment, window) items.  Level 1 scatters the items into COARSE buckets of
+// COARSE_WINDOWS windows: a block's items for one coarse bucket form one contiguous run (full-line writes),
+// where a direct scatter into the windows would be 16-byte writes all over HBM.  Level 2 (k_regroup) sorts a
+// coarse bucket into its windows inside a region small enough to stay in L2.
+//   k_count     per-block LDS histogram over the windows -> global per-window counts (atomics) and the
+//               block's per-coarse-bucket counts
+//   k_scan_cols column scan over the blocks of the coarse counts; k_scan: offsets of coarse buckets and windows
+//   k_fill      items -> coarse buckets (LDS cursors);  k_regroup  coarse bucket -> windows
+template <int CW>  // windows per coarse bucket; 1 = single level (k_fill writes the windows directly)
+__global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__restrict__ gstart,
+                                                const u32 *__restrict__ nkeep, u32 nwin, u32 ncoarse,
+                                                u32 *__restrict__ hist_c, u32 *__restrict__ win_cnt) {
+    __shared__ u32 h[COUNT_RANGE];
+    u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
+    u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
+    for (u32 i = threadIdx.x; i < (u32)COUNT_RANGE; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
+        u32 nk[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
+            const u64 a = a0 + (u64)u * blockDim.x;
+            nk[u] = a < hi ? (nkeep[a] & 0x3FFFFFFFu) : 0u;
+            g[u] = a < hi ? gstart[a] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!nk[u]) continue;
+            u32 w0 = g[u] / (u32)TILE, w1 = (g[u] + nk[u] - 1u) / (u32)TILE;
+            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+            for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+        }
+    }
+    __syncthreads();
+    if (CW > 1) {  // the windows' own totals are needed as well (k_scan_cols only sees the coarse buckets)
+        for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
+            if (h[i]) atomicAdd(&win_cnt[range_lo + i], h[i]);
+    }
+    const u32 c_lo = range_lo / (u32)CW, c_n = (range_n + CW - 1u) / (u32)CW;
+    for (u32 c = threadIdx.x; c < c_n; c += blockDim.x) {
+        u32 sum = 0;
+#pragma unroll
+        for (int j = 0; j < CW; j++) sum += h[c * CW + j];  // rows past range_n are zero
+        hist_c[(u64)blockIdx.x * ncoarse + c_lo + c] = sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
+                                                   u32 *__restrict__ win_cnt) {
+    const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (w >= nwin) return;
+    u32 v[8];
+    u32 sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
+        v[i] = (b < nblocks) ? hist[(u64)b * nwin + w] : 0u;
+        sum += v[i];
+    }
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    u32 run = inc - sum;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
+        if (b < nblocks) hist[(u64)b * nwin + w] = run;
+        run += v[i];
+    }
+    if (lane == 63) win_cnt[w] = inc;
+}
+
+// single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
+// n_ptr (optional) overrides n with a count held on the device; the total is also stored to *total_out;
+// a total above `limit` (capacity of the buffer the offsets index into) aborts the job with DE_CAPACITY
+template <typename T>
+__global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, const u32 *__restrict__ n_ptr,
+                                               T *__restrict__ out, u64 *__restrict__ total_out, u64 limit,
+                                               u64 *status) {
+    __shared__ u64 part[1024];
+    if (*status != ~0ull) return;
+    if (n_ptr) n = *n_ptr;
+    u32 t = threadIdx.x;
+    u64 per = (n + 1023) / 1024;
+    u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
+    u64 s = 0;
+    for (u64 i = lo; i < hi; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        u64 v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u64 run = part[t] - s;
+    for (u64 i = lo; i < hi; i++) {
+        out[i] = (T)run;
+        run += in[i];
+    }
+    if (t == 1023) {
+        const u64 total = part[1023];
+        out[n] = (T)total;
+        if (total_out) *total_out = total;
+        if (sizeof(T) == 4 && total > 0xFFFFFFFFull) report(status, 0, DE_OVERFLOW);
+        else if (total > limit) report(status, total, DE_CAPACITY);
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
+                                               const u32 *__restrict__ nkeep,
+                                               const u32 *__restrict__ kk,
+                                               const u64 *__restrict__ seq_off,
+                                               const u32 *__restrict__ seq_len, u32 nwin, u32 ncoarse,
+                                               const u32 *__restrict__ hist_c,
+                                               const u32 *__restrict__ coarse_off,
+                                               uint4 *__restrict__ entB, u64 *__restrict__ status) {
+    __shared__ u32 cur[COUNT_RANGE];  // cursors of the coarse buckets of this pass
+    if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
+    const u32 crange_lo = blockIdx.y * (u32)COUNT_RANGE;
+    const u32 crange_n = min((u32)COUNT_RANGE, ncoarse - crange_lo);
+    for (u32 i = threadIdx.x; i < crange_n; i += blockDim.x)
+        cur[i] = coarse_off[crange_lo + i] + hist_c[(u64)blockIdx.x * ncoarse + crange_lo + i];
+    __syncthreads();
+    const u32 range_lo = crange_lo * (u32)CW;                       // the same range, in windows
+    const u32 range_n = min(crange_n * (u32)CW, nwin - range_lo);
+    u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
+        u32 nk4[4], g4[4], k4[4], fl4[4];
+        u64 so4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
+            const u64 a = a0 + (u64)u * blockDim.x;
+            const bool ok = a < hi;
+            const u32 nkw = ok ? nkeep[a] : 0u;
+            nk4[u] = nkw & 0x3FFFFFFFu;
+            fl4[u] = nkw >> 30;
+            g4[u] = ok ? gstart[a] : 0u;
+            k4[u] = ok ? kk[a] : 1u;
+            so4[u] = ok ? seq_off[a] : 0ull;
+            if (ok && blockIdx.y == 0) {  // checks that need k / seq_off (not read by k_prep's fast path)
+                if (k4[u] == 0) report(status, a, DE_BAD_K);
+                else if (so4[u] + seq_len[a] > (1ull << 40)) report(status, a, DE_OVERFLOW);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 nk = nk4[u];
+            if (!nk) continue;
+            const u64 a = a0 + (u64)u * blockDim.x;
+            const u32 g = g4[u];
+            u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
+            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+            if (wa > wb) continue;
+            const u64 so = so4[u];
+            const u32 kc = kclass_of(k4[u]);
+            const u32 fl = fl4[u];
+            for (u32 w = wa; w <= wb && w >= wa; w++) {
+                u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
+                // work item, 16 bytes (bits 20..22 of y carry the window's index inside its coarse bucket until
+                // k_regroup has used it):
+                //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
+                //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
+                //   z  global start of the read minus the window start (signed)      w  record index (file order)
+                uint4 e;
+                e.x = fl ? nk : (u32)so;
+                e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16) |
+                      ((w % (u32)CW) << 20);
+                e.z = (u32)(int)((long long)g - (long long)w * TILE);
+                e.w = (u32)a;
+                entB[slot] = e;
+            }
+        }
+    }
+}
+
+// Level 2 of the multisplit: one workgroup per coarse bucket moves its items into their windows.  The
+// destination region (COARSE_WINDOWS windows) is small, so the 16-byte writes merge into full lines in L2.
+// Cursors are advanced once per wave and window (ballot + popcount), not once per item.
+__global__ __launch_bounds__(1024) void k_regroup(u32 nwin, const u32 *__restrict__ coarse_off,
+                                                  const u32 *__restrict__ win_off, const uint4 *__restrict__ entB,
+                                                  uint4 *__restrict__ entA, u64 *__restrict__ status) {
+    __shared__ u32 cur[COARSE_WINDOWS];
+    if (*status != ~0ull) return;
+    const u32 c = blockIdx.x, lane = threadIdx.x & 63u;
+    if (threadIdx.x < (u32)COARSE_WINDOWS) {
+        const u32 w = c * (u32)COARSE_WINDOWS + threadIdx.x;
+        cur[threadIdx.x] = w < nwin ? win_off[w] : 0u;
+        if (w < nwin && win_off[w + 1] - win_off[w] >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+    }
+    __syncthreads();
+    const u32 lo = coarse_off[c], hi = coarse_off[c + 1];
+    for (u32 i0 = lo + (threadIdx.x & ~63u); i0 < hi; i0 += blockDim.x) {
+        const u32 i = i0 + lane;
+        const bool valid = i < hi;
+        uint4 e = valid ? entB[i] : make_uint4(0, 0, 0, 0);
+        const u32 sub = (e.y >> 20) & 7u;
+        u32 slot = 0;
+#pragma unroll
+        for (u32 t = 0; t < (u32)COARSE_WINDOWS; t++) {
+            const u64 m = __ballot(valid && sub == t);
+            if (!m) continue;
+            u32 base = 0;
+            if (lane == (u32)__ffsll((long long)m) - 1u) base = atomicAdd(&cur[t], (u32)__popcll(m));
+            base = (u32)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+            if (valid && sub == t) slot = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        if (valid) {
+            e.y &= ~(7u << 20);
+            entA[slot] = e;
+        }
+    }
+}
+
+}  // namespace pp

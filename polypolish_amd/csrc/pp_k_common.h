@@ -87,48 +87,4 @@ __device__ __forceinline__ u32 simple_nkeep(const u8 *s, u32 sl) {
     return i > 0 ? i - 1u : 0u;
 }
 
-// ---- byte-parallel helpers of the read / assembly comparison --------------------------------------------------
-constexpr u32 PLAIN_MIN_LEN = 8;    // the trim reads the last four bases; shorter reads take the SLOW class
-// bit 7 of every non-zero byte
-__device__ __forceinline__ u32 nz_flags(u32 x) {
-    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-}
-__device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
-    return __builtin_amdgcn_perm(n, n, 0u);
-}
-// 4-bit mask of the non-zero bytes of x (v_dot4_u32_u8 of the 0/1 bytes with weights 1, 2, 4, 8)
-__device__ __forceinline__ u32 nz_mask4(u32 x) {
-    return __builtin_amdgcn_udot4(nz_flags(x) >> 7, 0x08040201u, 0u, false);
-}
-__device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-// the same through a non-temporal load (a byte-aligned vector type keeps it one unaligned 16-byte instruction)
-typedef u32 u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
-__device__ __forceinline__ uint4 load16_stream(const u8 *p) {
-    const u32x4_unaligned v = __builtin_nontemporal_load((const u32x4_unaligned *)p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
-    u32 v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-
-// PLAIN class geometry: a group of GW lanes owns one read; lane s of the group owns read bytes [32s, 32s+32), fetched
-// with two 16-byte global loads at the read's own (arbitrary) byte offset -- gfx950 global loads need no alignment.
-// GW is picked per batch of records from its longest PLAIN read: 5 lanes (12 reads per wave pass) up to 160 bases,
-// 6 (10 reads) up to 192, 8 (8 reads) up to 252.
-template <int GW>
-struct PlainCfg {
-    static constexpr u32 IPP = 64 / GW;                    // reads per wave pass
-    static constexpr u32 SPAN = 32 * GW;
-    static constexpr u32 MAXL = SPAN < FAST_MAX_LEN ? SPAN : FAST_MAX_LEN;
-    __device__ static __forceinline__ u32 group(u32 lane) {
-        return GW == 8 ? lane >> 3 : (GW == 5 ? (lane * 52u) >> 8 : (lane * 43u) >> 8);
-    }
-};
-
 }  // namespace pp

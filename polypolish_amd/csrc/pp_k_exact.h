@@ -69,10 +69,8 @@ struct ExactArgs {
     const u32 *flag_pos;
     const u32 *flag_cov;
     const u64 *flag_scr;
-    const u64 *units;       // regrouped units (k_regroup): per window its items, then its events
-    const u64 *win_start;
-    const u32 *win_nitem;
-    const u32 *contig, *ref_start, *nkeep_arr;
+    const uint4 *entA;
+    const u32 *win_off;
     const u8 *seq;
     const u64 *seq_off;
     const u64 *cig_off;
@@ -98,28 +96,6 @@ struct ExactArgs {
     int dbg;
 };
 
-// Item i of window w in the work-item form the replay kernels were written for:
-//   x  kept entries (the trim is done)            y  [15:8] depth-share class | [23:16] ENT_* flags
-//   z  global start of the read minus the window start (signed)      w  record index (file order)
-// PLAIN units carry all of it; SLOW units only the record index and class, the rest comes from the record arrays.
-__device__ __forceinline__ uint4 replay_item(const ExactArgs &A, u32 w, u32 i) {
-    const u64 u = A.units[A.win_start[w] + i];
-    const u32 lo32 = (u32)u, idx = (u32)(u >> 32);
-    uint4 e;
-    e.w = idx;
-    if ((lo32 & 3u) == UNIT_PLAIN) {
-        e.x = (lo32 >> 14) & 0xFFu;
-        e.y = ((((lo32 >> 22) & 1u) ? KCLASS_NONDYADIC : 0u) << 8) | (ENT_PRETRIM << 16);
-        e.z = (u32)((int)((lo32 >> 2) & 0xFFFu) - UNIT_REL_BIAS);
-    } else {
-        const u64 g = A.contig_off[A.contig[idx]] + A.ref_start[idx];
-        e.x = A.nkeep_arr[idx];
-        e.y = (kclass_of(A.kk[idx]) << 8) | (((lo32 >> 2) & 3u) << 16);
-        e.z = (u32)(int)((long long)g - (long long)w * TILE);
-    }
-    return e;
-}
-
 constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
 constexpr u64 SL_DONE = 1ull << 63;
 
@@ -139,9 +115,8 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 
     // collect the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40)
     u32 n = 0;
-    const u32 n_items = A.win_nitem[w];
-    for (u32 e = 0; e < n_items; e++) {
-        const uint4 ent = replay_item(A, w, e);
+    for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
+        const uint4 ent = A.entA[e];
         const int q = pr - (int)ent.z;
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
         if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
@@ -314,8 +289,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     const int state = w < nwin ? job_state(A.status) : 2;
     if (state == 2) return;
     if (A.win_nflag[w] == 0) return;
-    const u32 n = A.win_nitem[w];
-    const u64 e0 = A.win_start[w];
+    const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
     if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
     if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
         if (tid == 0 && n > SORT_MAX / 4) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
@@ -339,7 +313,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     {
         u32 lo = 0xFFFFFFFFu, hi = 0;
         for (u32 i = tid; i < n; i += 1024) {
-            const u32 r = (u32)(A.units[e0 + i] >> 32);
+            const u32 r = A.entA[e0 + i].w;
             rec[i] = r;
             lo = min(lo, r); hi = max(hi, r);
         }
@@ -410,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
         __syncthreads();
         u32 np2 = 2;
         while (np2 < n) np2 <<= 1;
-        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((A.units[e0 + i] >> 32) << 16) | (u64)i) : ~0ull;
+        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
         __syncthreads();
         for (u32 k = 2; k <= np2; k <<= 1) {
             for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
@@ -430,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     ulonglong2 *ents_lds = (ulonglong2 *)pk;
     // ---- (2) start, trimmed extent and depth share of every item, in file order ----
     for (u32 i = tid; i < n; i += 1024) {
-        const uint4 ent = replay_item(A, w, bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i]);
+        const uint4 ent = A.entA[e0 + (bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
         const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;

@@ -1,15 +1,14 @@
-// pp_k_prep.h -- prep_general: run validation, spans and the trim of one record that is not a single short M run
-// (called by k_stream, one lane per record).
+// pp_k_prep.h -- k_prep: one lane per alignment record -- run validation, spans, trim of the slow classes.
 // Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
 #pragma once
 
 namespace pp {
-#ifndef PP_PREP_INLINE
-#define PP_PREP_INLINE __forceinline__
-#endif
 
+// =============================================================================================
+// k_prep
+// =============================================================================================
 // every record that is not a single short M run inside its contig
-__device__ PP_PREP_INLINE void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
+__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
                                                u64 c_lo, u64 c_hi, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
     // walk the runs (alignment.rs:178-194): spans and validity
     u64 ref_span = 0, read_span = 0;
@@ -76,6 +75,71 @@ __device__ PP_PREP_INLINE void prep_general(u64 a, u32 rs, u32 sl, u64 so, const
     *g_out = (u32)(c_lo + rs);
     *nk_out = nk;
     *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
+}
+
+#ifndef PP_PLAIN_ALIGNED
+#define PP_PLAIN_ALIGNED 0
+#endif
+constexpr u32 PLAIN_NARROW_MAX = PP_PLAIN_ALIGNED ? 129u : 160u;  // = PlainCfg<5>::MAXL below
+
+__device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ contig,
+                                         const u32 *__restrict__ ref_start, const u32 *__restrict__ kk,
+                                         const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
+                                         const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
+                                         const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
+                                         const u64 *__restrict__ contig_off, u32 n_contigs,
+                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *fast_len, u64 *status) {
+    // independent loads first, then the dependent ones (clamped so that they are unconditional):
+    // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
+    // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
+    const u32 c = contig[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
+    const u64 co = cig_off[a];
+    const u32 cc = min(c, n_contigs - 1u);
+    const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1];
+    const u32 *cg = cigar + co;
+    const u32 op0 = nc ? cg[0] : 0u;
+    u32 g_out = 0, nk_out = 0;
+    u8 fl_out = 0;
+    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); }
+    else if (nc == 0) { report(status, a, DE_BAD_RUN); }
+    else if (nc == 1 && (op0 & 15u) == PP_OP_M && (op0 >> 4) == sl && sl > 0 && sl <= FAST_MAX_LEN &&
+             (u64)rs + sl <= c_hi - c_lo) {
+        // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
+        g_out = (u32)(c_lo + rs);
+        nk_out = sl;
+        *fast_len = sl;  // the longest fast-class read picks the lane-group width of k_tile's plain class
+    } else {
+        prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+    }
+    gstart[a] = g_out;
+    nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
+}
+
+__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
+                                              const u32 *__restrict__ ref_start,
+                                              const u32 *__restrict__ kk,
+                                              const u64 *__restrict__ seq_off,
+                                              const u32 *__restrict__ seq_len,
+                                              const u64 *__restrict__ cig_off,
+                                              const u32 *__restrict__ n_cig,
+                                              const u32 *__restrict__ cigar,
+                                              const u8 *__restrict__ seq,
+                                              const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                              u32 *__restrict__ maxlen, u64 *status) {
+    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 fast_len = 0;
+    if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
+                        gstart, nkeep, &fast_len, status);
+    // Only every 64th block looks (a sample: the word merely picks the lane-group width that suits the bulk of the
+    // reads -- a longer read than the sample saw simply takes the non-plain path), once per wave, and only for reads
+    // beyond the narrowest group (<= 160 bases); the word is read from L2, not from a possibly stale CU-local copy.
+    // A per-record look at that one address costs a millisecond on a 250-base job.
+    if ((blockIdx.x & 63u) == 0 && __ballot(fast_len > PLAIN_NARROW_MAX)) {
+        for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
+        if ((threadIdx.x & 63u) == 0 && fast_len > __hip_atomic_load(maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(maxlen, fast_len);
+    }
 }
 
 }  // namespace pp

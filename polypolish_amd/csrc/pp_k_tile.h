@@ -1,4 +1,4 @@
-// pp_k_tile.h -- k_tile: pileup accumulate (from the units k_stream / k_regroup prepared) + vote for one window.
+// pp_k_tile.h -- k_tile: pileup accumulate + vote for one window (the dominant kernel).
 // Part of pp_kernels.hip (included there, in this order, and nowhere else: it defines __global__ kernels).
 #pragma once
 
@@ -8,12 +8,9 @@ namespace pp {
 // k_tile: pileup accumulate + vote for one 2048-position window
 // =============================================================================================
 struct TileArgs {
-    const u64 *units;      // regrouped units: per window its PLAIN / SLOW items, then its EVENTs
-    const u64 *win_start;
-    const u32 *win_nitem, *win_nev;
+    const uint4 *entA;
+    const u32 *win_off;
     u32 nwin;
-    const u32 *contig, *ref_start, *kk;   // record arrays (SLOW units only)
-    const u32 *nkeep_arr;                 // kept entries of SLOW records (k_stream)
     const u8 *seq;
     const u64 *seq_off;
     const u64 *cig_off;
@@ -38,6 +35,8 @@ struct TileArgs {
     u32 *flag_cov;
     u64 *scr_need;  // replay scratch the listed positions will need (sum of their coverage), counted past cap_flag too
     ContigStatsDev *stats;
+    const u32 *maxlen;  // longest fast-class read (written by k_prep)
+    u64 seq_bytes;
     const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
     double *dbg_depth;
     u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
@@ -104,9 +103,260 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
     return v;
 }
 
-// LDS copy of the window's assembly bytes (the vote needs the original base of every position)
-constexpr int ASM_PAD = 0;
-constexpr int ASM_WORDS = TILE / 4;
+// LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
+// lane may read the five dwords around any window position it owns a byte of.
+constexpr int ASM_PAD = 32;
+constexpr int ASM_WORDS = TILE / 4 + 24;
+constexpr u32 PLAIN_MIN_LEN = 8;    // the trim reads the last four bases; shorter reads take the scalar path
+
+// ---- plain class: fast class, depth share 1 (or non-dyadic), 8..32*GW bases ------------------------
+// A group of GW lanes owns one work item; lane s of the group owns read bytes [32s, 32s+32), fetched with
+// two 16-byte global loads at the read's own (arbitrary) byte offset -- gfx950 global loads need no
+// alignment -- so a lane's bytes line up with window positions rel + 32s .. and only the END of a read
+// (trimmed tail, bytes past the read) needs masking.  GW is picked per job from the longest fast-class
+// read: 5 lanes (12 items per wave pass) up to 160 bases, 6 (10 items) up to 192, 8 (8 items) up to 252.
+// Everything per item lives in vector registers (no v_readlane, no per-item branches).
+// bit 7 of every non-zero byte
+__device__ __forceinline__ u32 nz_flags(u32 x) {
+    return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (one v_perm_b32)
+    return __builtin_amdgcn_perm(n, n, 0u);
+}
+// 4-bit mask of the non-zero bytes of x (v_dot4_u32_u8 of the 0/1 bytes with weights 1, 2, 4, 8)
+__device__ __forceinline__ u32 nz_mask4(u32 x) {
+    return __builtin_amdgcn_udot4(nz_flags(x) >> 7, 0x08040201u, 0u, false);
+}
+__device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// PP_PLAIN_ALIGNED=1 (compile-time alternative, same speed on MI355X): lanes own 32-byte ALIGNED blocks of
+// memory instead of read-relative chunks; a group then spans 32*GW-31 bases.
+template <int GW>
+struct PlainCfg {
+    static constexpr u32 IPP = 64 / GW;                    // items per wave pass
+    static constexpr u32 BATCH = (64 / IPP) * IPP;         // items per batch: whole passes only
+    static constexpr u32 SPAN = PP_PLAIN_ALIGNED ? 32 * GW - 31 : 32 * GW;
+    static constexpr u32 MAXL = SPAN < FAST_MAX_LEN ? SPAN : FAST_MAX_LEN;
+    static_assert(GW != 5 || MAXL == PLAIN_NARROW_MAX, "k_prep's threshold");
+    __device__ static __forceinline__ u32 group(u32 lane) {
+        return GW == 8 ? lane >> 3 : (GW == 5 ? (lane * 52u) >> 8 : (lane * 43u) >> 8);
+    }
+    // work-item words x, y: no flags, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway),
+    // length in range, and every 32-byte chunk of the read inside the seq array
+    __device__ static __forceinline__ bool ok(u32 ex, u32 ey, u64 seq_bytes) {
+        const u32 L = ey >> 24, kc = (ey >> 8) & 0xFFu;
+        const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
+        return (ey & 0x00FF0000u) == 0 && (kc == 0 || kc == KCLASS_NONDYADIC) && L >= PLAIN_MIN_LEN && L <= MAXL &&
+               so + ((L + 31u) & ~31u) <= seq_bytes;
+    }
+};
+
+struct PlainItem {  // per lane
+    uint4 Wa, Wb;      // this lane's 32 read bytes
+    u32 tail;          // the last four bases of the read (group-uniform)
+    const u8 *lane_p;  // address of this lane's byte 0
+    int rel;           // global start of the read minus the window start
+    int ib;            // read index of this lane's byte 0
+    bool first;        // lane 0 of the group
+    u32 L;
+    bool plain, active;
+    bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
+};
+
+// fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
+template <int GW>
+__device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, const uint4 &my, u32 nb, u32 first,
+                                                 u32 lane) {
+    typedef PlainCfg<GW> C;
+    PlainItem it;
+    const u32 g = C::group(lane), s = lane - (u32)GW * g;
+    const u32 j = first + g;  // item of the batch owned by this group
+    const int src = (int)(min(j, nb - 1u) << 2);
+    const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
+    it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    it.L = ey >> 24;
+    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.plain = g < C::IPP && j < nb && C::ok(ex, ey, seq_bytes);
+    const u8 *rp = seq + ((u64)ex | ((u64)(ey & 0xFFu) << 32));
+    const u32 mis = PP_PLAIN_ALIGNED ? (u32)((uintptr_t)rp & 31u) : 0u;
+    it.ib = (int)(32u * s) - (int)mis;
+    it.first = s == 0;
+    it.active = it.plain && 32u * s < mis + it.L;
+    it.lane_p = rp + it.ib;
+    // Loads only where there is something to load (exec-masked): measured faster than unconditional loads
+    // from substitute addresses, and than prefetching the next pass across this pass's work.
+    it.Wa = make_uint4(0, 0, 0, 0);
+    it.Wb = make_uint4(0, 0, 0, 0);
+    it.tail = 0;
+    if (it.plain) it.tail = load4_unaligned(rp + (it.L - 4u));
+    if (it.active) {
+        it.Wa = load16_unaligned(it.lane_p);
+        it.Wb = load16_unaligned(it.lane_p + 16);
+    }
+    return it;
+}
+
+__device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
+    const int rel = it.rel;
+    const u32 L = it.L;
+
+    // ---- trim (alignment.rs:364-378): nkeep = index of the last base that differs from the last base,
+    // read off the last four bases; a trailing homopolymer of four or more takes the byte loop
+    const u32 last = it.tail >> 24;
+    const u32 tf = nz_flags(it.tail ^ splat8(last));
+    int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
+    if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
+        const u8 *rp = it.lane_p - it.ib;
+        u32 i = L - 4u;
+        while (i > 0 && rp[i - 1] == (u8)last) i--;
+        nkeep = i > 0 ? (int)i - 1 : 0;
+    }
+    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+    const bool live = it.plain && hi > lo;
+
+    // ---- coverage difference array (two atomics per read) ----
+    if (live && it.first) {
+        atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+        if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+        if (it.nd) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
+            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+            }
+        }
+    }
+    // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
+    const int ib = it.ib;
+    const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
+    if (live && it.active && b1 > b0) {
+        const int P0 = rel + ib;  // window position of byte 0 (> -32 here)
+        const u32 ai = (u32)(P0 + ASM_PAD);
+        const u32 *ap = asm_w + (ai >> 2);
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], a5 = ap[5], a6 = ap[6], a7 = ap[7], a8 = ap[8];
+        const u32 sh = ai & 3u;
+#define PP_D(k, w, x0, x1) (nz_mask4((w) ^ __builtin_amdgcn_alignbyte(x1, x0, sh)) << (4 * (k)))
+        u32 D = PP_D(0, it.Wa.x, a0, a1) | PP_D(1, it.Wa.y, a1, a2) | PP_D(2, it.Wa.z, a2, a3) | PP_D(3, it.Wa.w, a3, a4) |
+                PP_D(4, it.Wb.x, a4, a5) | PP_D(5, it.Wb.y, a5, a6) | PP_D(6, it.Wb.z, a6, a7) | PP_D(7, it.Wb.w, a7, a8);
+#undef PP_D
+        // bit i of D <=> byte i of this lane differs from the assembly; keep bytes [b0, b1) only
+        D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
+        while (D) {  // one trip per differing base
+            const int i = __ffs((int)D) - 1;
+            D &= D - 1u;
+            // byte i of the lane's eight dwords, by a select tree on the bits of i (no memory access: a
+            // load here would have to wait for the next pass's prefetch as well)
+            const u32 m4 = (u32)(((int)((u32)i << 29)) >> 31), m8 = (u32)(((int)((u32)i << 28)) >> 31),
+                      m16 = (u32)(((int)((u32)i << 27)) >> 31);
+#define PP_SEL(m, b, a) (((m) & (b)) | (~(m) & (a)))
+            const u32 w01 = PP_SEL(m4, it.Wa.y, it.Wa.x), w23 = PP_SEL(m4, it.Wa.w, it.Wa.z);
+            const u32 w45 = PP_SEL(m4, it.Wb.y, it.Wb.x), w67 = PP_SEL(m4, it.Wb.w, it.Wb.z);
+            const u32 wlo = PP_SEL(m8, w23, w01), whi = PP_SEL(m8, w67, w45);
+            const u32 c = (PP_SEL(m16, whi, wlo) >> (8 * (i & 3))) & 0xFFu;
+#undef PP_SEL
+            const int p = P0 + i;
+            atomicAdd(&cnt[row_of(c) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+        }
+    }
+}
+
+// ---- fast class of work items: a read without indels, <= FAST_MAX_LEN bases, inside its contig ----
+struct FastItem {  // wave-uniform (built from v_readlane results)
+    u64 so;    // offset of the read in the seq array
+    int rel;   // global start of the read minus the window start
+    u32 L;     // read length == number of entries before the trim
+    u32 kc;    // depth-share class of 1/k
+    u32 mis;   // (address of the read) & 3
+    bool on;
+};
+
+__device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, const u8 *seq) {
+    const int jj = (int)min(j, nb - 1u);
+    const u32 x = (u32)__builtin_amdgcn_readlane((int)my.x, jj), y = (u32)__builtin_amdgcn_readlane((int)my.y, jj);
+    FastItem f;
+    f.so = (u64)x | ((u64)(y & 0xFFu) << 32);
+    f.rel = __builtin_amdgcn_readlane((int)my.z, jj);
+    f.L = y >> 24;
+    f.kc = (y >> 8) & 0xFFu;
+    f.mis = (u32)(((uintptr_t)(seq + f.so)) & 3u);
+    f.on = j < nb && ((y >> 16) & 0xFFu) == 0;
+    return f;
+}
+
+// One aligned dword per lane covers the whole read (<= 252 bases + <= 3 bytes of misalignment).
+// An aligned dword that holds at least one byte of the read never leaves the read's pages.
+__device__ __forceinline__ u32 fast_load(const u8 *seq, const FastItem &f, u32 lane) {
+    u32 w = 0;
+    if (f.on && 4u * lane < f.mis + f.L) w = *((const u32 *)(seq + f.so - f.mis) + lane);
+    return w;
+}
+
+// trim (alignment.rs:364-378) by ballot; then (pileup.rs:56-65,189-200) either explicit LDS atomics
+// per kept base (reads whose depth share is not 1) or, for the bulk, two coverage-difference
+// atomics per read plus a 4-bases-at-a-time comparison against the assembly window in LDS, with
+// per-base atomics only where the read differs from the assembly.
+__device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const FastItem &f, u32 word, u32 lane) {
+    if (!f.on) return;
+    const u32 mis = f.mis;
+    const int ib = (int)(4u * lane) - (int)mis;      // read index of this lane's byte 0
+    const u32 tl = mis + f.L - 1u;                    // byte position of the last base in the wave load
+    const u32 lw = (u32)__builtin_amdgcn_readlane((int)word, (int)(tl >> 2));
+    const u32 c_last = (lw >> (8u * (tl & 3u))) & 0xFFu;
+    int hi_i = -1;  // highest read index in this lane whose base differs from the last base
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int i = ib + b;
+        const u32 c = (word >> (8 * b)) & 0xFFu;
+        if (i >= 0 && i < (int)f.L && c != c_last) hi_i = i;
+    }
+    const u64 m = __ballot(hi_i >= 0);
+    int nkeep = 0;  // index of the last base that differs: the run after it and that base are popped
+    if (m) nkeep = __builtin_amdgcn_readlane(hi_i, 63 - __clzll((long long)m));
+    const int lo = max(0, -f.rel), hi = min(nkeep, TILE - f.rel);
+    if (hi <= lo) return;
+    if (f.kc != 0) {
+        // byte order rotated by lane/8 so that the 32 lanes of an LDS group hit 32 different banks
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int b = (jj + (int)(lane >> 3)) & 3;
+            const int i = ib + b;
+            if (i >= lo && i < hi) tile_add(cnt, row_of((word >> (8 * b)) & 0xFFu), f.rel + i, f.kc);
+        }
+        return;
+    }
+    if (lane == 0) {
+        atomicAdd(&cnt[ROW_COV * TILE + f.rel + lo], 1u);
+        if (f.rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + f.rel + hi], 0xFFFFFFFFu);
+    }
+    const int lowb = max(0, lo - ib), highb = min(4, hi - ib);
+    if (lowb < highb) {
+        const u32 M = (0xFFFFFFFFu >> (8 * (4 - highb))) & (0xFFFFFFFFu << (8 * lowb));
+        const int P0 = f.rel + ib;                 // window position of byte 0 (>= -3 here)
+        const u32 ai = (u32)(P0 + ASM_PAD);        // asm_w holds the window bytes at byte offset ASM_PAD
+        const u32 w0 = asm_w[ai >> 2], w1 = asm_w[(ai >> 2) + 1];
+        const u32 av = __builtin_amdgcn_alignbyte(w1, w0, ai & 3u);
+        const u32 diff = (word ^ av) & M;
+        if (diff) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((diff >> (8 * b)) & 0xFFu) {
+                    atomicAdd(&cnt[row_of((word >> (8 * b)) & 0xFFu) * TILE + P0 + b], 1u);
+                    atomicAdd(&cnt[ROW_MIS * TILE + P0 + b], 1u);
+                }
+            }
+        }
+    }
+}
 
 // exact integer tallies of one window position from the LDS rows: explicit tallies plus, for the
 // assembly's own base, the fast-class bases that were never tallied one by one
@@ -120,98 +370,77 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
     nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
 }
 
-// The units of one window.  PLAIN: two LDS atomics into the coverage difference array (+1 at the first kept
-// position, -1 one past the last; prefix-summed before the vote).  EVENT: the row of the differing base + the
-// mismatch row.
-// one unit, one lane: PLAIN and EVENT units are two LDS atomics each
-__device__ __forceinline__ void tile_unit_fast(u32 *cnt, u32 *s_ndbits, u32 lo32) {
-    const u32 tag = lo32 & 3u;
-    if (tag == UNIT_PLAIN) {
-        const int rel = (int)((lo32 >> 2) & 0xFFFu) - UNIT_REL_BIAS;
-        const int nkeep = (int)((lo32 >> 14) & 0xFFu);
-        const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-        if (hi > lo) {
-            atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
-            if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
-            if ((lo32 >> 22) & 1u) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
-                const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
-                for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
-                    const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
-                    atomicOr(&s_ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
-                }
-            }
+// two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
+// The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
+// records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
+// hidden by the other 7 waves of the SIMD, not by software pipelining (which measured slower).
+template <int GW>
+__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, u32 e0, u32 e1,
+                                           u32 wave, u32 lane) {
+    typedef PlainCfg<GW> C;
+    // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
+    // of the items does not matter: the counters are integers)
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + C::IPP - 1u) / C::IPP * C::IPP;
+    const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
+    if (lo_w >= hi_w) return;
+    for (u32 eb = lo_w; eb < hi_w; eb += C::BATCH) {
+        const u32 nb = min(C::BATCH, hi_w - eb);
+        const uint4 my = A.entA[eb + min(lane, nb - 1u)];
+        const u32 my_flags = (my.y >> 16) & 0xFFu;
+        const bool my_slow = lane < nb && my_flags != 0;
+        const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
+        for (u32 first = 0; first < nb; first += C::IPP)
+            plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+        // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
+        u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
+        while (rest) {
+            const u32 j = (u32)__ffsll((long long)rest) - 1u;
+            rest &= rest - 1;
+            const FastItem f = fast_fetch(my, j, nb, A.seq);
+            fast_apply(cnt, asm_w, f, fast_load(A.seq, f, lane), lane);
         }
-    } else if (tag == UNIT_EVENT) {
-        const u32 p = (lo32 >> 2) & (u32)(TILE - 1), row = (lo32 >> 13) & 7u;
-        atomicAdd(&cnt[row * TILE + p], 1u);
-        atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-    }
-}
-
-// SLOW units of one wave-load: the record is walked run by run (indels), one wave per unit, every kept base tallied
-// explicitly (pileup.rs:56-65,189-200).
-__device__ __forceinline__ void tile_units_slow(const TileArgs &A, u32 *cnt, u64 u, u64 w0, u32 lane) {
-    const u32 lo32 = (u32)u;
-    const bool is_slow = (lo32 & 3u) == UNIT_SLOW;
-    u64 slow = __ballot(is_slow);
-    if (!slow) return;
-    // the record fields of all SLOW units of this wave-load are fetched side by side (one round of latency) ...
-    u32 f_nkeep = 0, f_kc = 0, f_nc = 0;
-    int f_rel = 0;
-    u64 f_so = 0, f_co = 0;
-    if (is_slow) {
-        const u32 idx = (u32)(u >> 32);
-        f_nkeep = A.nkeep_arr[idx];
-        f_rel = (int)((long long)(A.contig_off[A.contig[idx]] + A.ref_start[idx]) - (long long)w0);
-        f_kc = kclass_of(A.kk[idx]);
-        f_so = A.seq_off[idx];
-        f_co = A.cig_off[idx];
-        f_nc = A.n_cig[idx];
-    }
-    // ... then every unit is walked by the whole wave
-    while (slow) {
-        const int j = __ffsll((long long)slow) - 1;
-        slow &= slow - 1;
-        const u32 fl = ((u32)__builtin_amdgcn_readlane((int)lo32, j) >> 2) & 3u;
-        const int nkeep = __builtin_amdgcn_readlane((int)f_nkeep, j), rel = __builtin_amdgcn_readlane(f_rel, j);
-        const u32 kc = (u32)__builtin_amdgcn_readlane((int)f_kc, j);
-        const u8 *s = A.seq + (((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_so >> 32), j) << 32) |
-                               (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_so, j));
-        if (!(fl & ENT_COMPLEX)) {
-            // no indels, trimmed by k_stream (long read, contig overhang, dyadic share): entry i is base i
-            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-            for (int q = lo + (int)lane; q < hi; q += 64) tile_add(cnt, row_of(s[q]), rel + q, kc);
-        } else {
-            const u32 *cg = A.cigar + (((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_co >> 32), j) << 32) |
-                                       (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_co, j));
-            const u32 nc = (u32)__builtin_amdgcn_readlane((int)f_nc, j);
-            int ent0 = 0;
-            u64 ro = 0;
-            for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
-                const u32 op = cg[r], len = op >> 4, o = op & 15u;
-                if (o == PP_OP_I) { ro += len; continue; }
-                u32 ins = 0;
-                for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
-                const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
-                for (int q = a + (int)lane; q < b; q += 64) {
-                    const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
-                    int row;
-                    if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
-                    else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
-                    tile_add(cnt, row, rel + q, kc);
+        u64 slow = __ballot(my_slow);
+        while (slow) {
+            const int j = __ffsll((long long)slow) - 1;
+            slow &= slow - 1;
+            const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j), idx = (u32)__builtin_amdgcn_readlane((int)my.w, j);
+            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
+            const u32 kc = (ey >> 8) & 0xFFu;
+            const u8 *s = A.seq + A.seq_off[idx];
+            if (!((ey >> 16) & ENT_COMPLEX)) {
+                // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
+                const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+                for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+            } else {
+                const u32 *cg = A.cigar + A.cig_off[idx];
+                const u32 nc = A.n_cig[idx];
+                int ent0 = 0;
+                u64 ro = 0;
+                for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+                    const u32 op = cg[r], len = op >> 4, o = op & 15u;
+                    if (o == PP_OP_I) { ro += len; continue; }
+                    u32 ins = 0;
+                    for (u32 r2 = r + 1; r2 < nc && (cg[r2] & 15u) == PP_OP_I; r2++) ins += cg[r2] >> 4;
+                    const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+                    for (int q = a + (int)lane; q < b; q += 64) {
+                        const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+                        int row;
+                        if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
+                        else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
+                        tile_add(cnt, row, rel + q, kc);
+                    }
+                    ent0 += (int)len;
+                    if (o != PP_OP_D) ro += len;
                 }
-                ent0 += (int)len;
-                if (o != PP_OP_D) ro += len;
             }
         }
     }
 }
-
-constexpr u32 TILE_UNROLL = 4;  // unit loads in flight per lane
 
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ u32 cnt[N_ROWS * TILE];
-    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes
+    __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
     __shared__ u64 s_depth;
 
@@ -221,21 +450,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     if (w >= A.nwin || job_state(A.status) == 2) return;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
-    // the first units of every lane are requested before the counters are cleared
-    const u64 e0 = A.win_start[w];
-    const u32 n_items = A.win_nitem[w], n_units = n_items + A.win_nev[w];
-    u64 pre[TILE_UNROLL];
-#pragma unroll
-    for (u32 q = 0; q < TILE_UNROLL; q++) {
-        const u32 i = q * TILE_THREADS + tid;
-        pre[q] = i < n_units ? A.units[e0 + i] : (u64)UNIT_NOP;
-    }
 
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
     {
         u8 *ab = (u8 *)asm_w;
-        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        for (u32 i = tid; i < (u32)TILE; i += TILE_THREADS) ab[ASM_PAD + i] = (w0 + i < A.G) ? A.bases[w0 + i] : (u8)0;
+        if (tid < (u32)ASM_PAD) ab[tid] = 0;
+        if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
     if (tid == 0) {
         s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0;
@@ -245,20 +467,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
 
-    for (u32 base = 0;; base += TILE_UNROLL * TILE_THREADS) {
-        if (base) {
-#pragma unroll
-            for (u32 q = 0; q < TILE_UNROLL; q++) {
-                const u32 i = base + q * TILE_THREADS + tid;
-                pre[q] = i < n_units ? A.units[e0 + i] : (u64)UNIT_NOP;
-            }
-        }
-#pragma unroll
-        for (u32 q = 0; q < TILE_UNROLL; q++) tile_unit_fast(cnt, s_ndbits, (u32)pre[q]);
-#pragma unroll
-        for (u32 q = 0; q < TILE_UNROLL; q++) tile_units_slow(A, cnt, pre[q], w0, lane);
-        if (base + TILE_UNROLL * TILE_THREADS >= n_units) break;
+    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    {
+        const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
+        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        else tile_items<8>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
     }
+    if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
     __syncthreads();
 
     // ---- coverage of the fast class: prefix sum of the difference array, in place ----
@@ -322,7 +538,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
-            const bool to_list = A.dbg == 1 || n_items > SORT_MAX;  // dbg 2: test hook, see run_pipeline
+            const bool to_list = A.dbg == 1 || e1 - e0 > SORT_MAX;  // dbg 2: test hook, see run_pipeline
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);
@@ -378,7 +594,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
     if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
-    if (s_nflag && n_items <= SORT_MAX) {
+    if (s_nflag && e1 - e0 <= SORT_MAX) {
         // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
         if (tid == 0) {
             const u32 slab = atomicAdd(&A.counters[3], 1u);

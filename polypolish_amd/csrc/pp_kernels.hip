@@ -1,18 +1,19 @@
 // pp_kernels.hip -- gfx950 kernels of the polish hot path (seam B of include/polypolish_hip.h).
 //
 // Pipeline (one pp_polish_finish):
-//   k_stream   ONE pass over the records in file order (coalesced SEQ stream): run validation, spans, the right-end
-//              homopolymer trim (alignment.rs:175-201,364-378) and the comparison of every read with the assembly
-//              (L2-resident); per read one or two 8-byte PLAIN units (coverage interval per window) and one EVENT unit
-//              per base that differs from the assembly; indel / long reads become SLOW units.  Units are staged in
-//              LDS, sorted by coarse bucket and flushed as segments (full-line writes)
-//   k_regroup  one workgroup per bucket gathers its pieces from all segments into per-window unit lists
-//   k_tile     one workgroup per 2048-position window: counters in LDS (coverage difference array + explicit tallies of
-//              the differing bases, pileup.rs:56-65,189-200), then one lane per position votes (pileup.rs:67-134)
-//              and writes a 1-byte emit code
-//   k_exact2 / k_exact   the rare positions whose outcome depends on string-keyed counts (insertions, N...) or on the
-//              ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed exactly: covering alignments
-//              in file order, sequential f64 adds, byte-exact key grouping
+//   k_prep     one thread per alignment: CIGAR walk validation, reference span and the right-end
+//              homopolymer trim (alignment.rs:175-201,364-378) -> (global start, kept entries)
+//   k_count    per-block LDS histogram of (alignment, window) items   \  atomics-free multisplit
+//   k_scan_cols / k_scan   column scan over blocks + scan over windows  > of the alignments into
+//   k_fill     scatter 16-byte work items into their window's bucket   /  2048-position windows
+//   k_tile     one workgroup per window: counters for 2048 positions live in LDS, one wave per
+//              work item streams the read bases (coalesced byte loads) and does one LDS atomic per
+//              base (pileup.rs:56-65,189-200); then one lane per position votes
+//              (pileup.rs:67-134) and writes a 1-byte emit code
+//   k_exact    the rare positions whose outcome depends on string-keyed counts (insertions, N...)
+//              or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
+//              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact
+//              key grouping
 //   k_compact / k_finalize  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes
 //
 // Integer counting, HBM/LDS bound: no MFMA anywhere by design.
@@ -24,8 +25,7 @@
 // The kernels, in pipeline order (one translation unit: everything below is static or inlined)
 #include "pp_k_common.h"
 #include "pp_k_prep.h"
-#include "pp_k_stream.h"
-#include "pp_k_regroup.h"
+#include "pp_k_bucket.h"
 #include "pp_k_tile.h"
 #include "pp_k_exact.h"
 #include "pp_k_emit.h"
@@ -59,10 +59,10 @@ void dev_free(DevBuf &b) {
 }
 
 // Per-kernel-group timing with HIP events on the context's stream.  profiling == 1 times every group,
-// profiling == 2 only the dominant kernel ("stream": one event pair per job, for the bench's timed region).
+// profiling == 2 only the dominant kernel ("tile": one event pair per job, for the bench's timed region).
 // Events come from a pool that lives as long as the context.
 void timer_begin(pp_ctx *ctx, const char *name) {
-    if (!ctx->profiling || (ctx->profiling == 2 && strcmp(name, "stream") != 0)) return;
+    if (!ctx->profiling || (ctx->profiling == 2 && strcmp(name, "tile") != 0)) return;
     KernelTimer t;
     t.name = name;
     if (ctx->event_pool.size() >= 2) {
@@ -249,42 +249,39 @@ static int map_device_error(pp_ctx *ctx, uint64_t key) {
 // the device (work items, flagged positions, replay scratch, polished bytes) are bounded by
 // optimistic capacities, a kernel that would overflow one raises DE_CAPACITY and every later
 // kernel then returns at once.  A single read-back of the metadata block ends the pass.
-static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_entries_out) {
+static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_entries_out) {
     hipStream_t st = ctx->stream;
     const pp_aln_batch &B = ctx->dbatch;
     const uint64_t n = ctx->have_batch ? B.n_aln : 0;
     const uint64_t G = ctx->G;
     const uint32_t nc = ctx->n_contigs;
     const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
+    const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));  // k_scan_cols: <= 512
+    const uint64_t chunk = (n + NB - 1) / NB;
+    const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
 #define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
-    // metadata block (u64 words): 0 status | 1-2 counters | 3 units written by k_stream | 4 scratch elements (10: the
-    // same, counted as the positions are listed) | 5 polished bytes | 6 ordered replay items | 7 segments | 8 key records |
-    // 9 late-list entries | 11 units laid out by k_regroup | 16.. contig output offsets (nc+1) | then per-contig stats
-    // (3 words each)
-    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc + 8;  // + 8 words of k_stream phase cycles (profiling builds)
+    // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements (10: the same, counted
+    // as the positions are listed) |
+    // 5 polished bytes | 6 ordered replay items | 8 key records | 9 longest fast read | 16.. contig output offsets
+    // (nc+1) | then per-contig stats (3 words each)
+    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
     ENS(b_meta, meta_words * 8);
-    // Coarse buckets of 2^shift windows: few enough buckets that a segment's piece for one bucket is a run of several
-    // units (segments x buckets pieces in all), at most 256 windows each (8 bits of a unit).
-    static const uint32_t nbk_target = getenv("PP_NBK_TARGET") ? (uint32_t)atoi(getenv("PP_NBK_TARGET")) : 1024u;  // tuning
-    uint32_t shift = 0;
-    while (shift < 8 && ((nwin + (1u << shift) - 1) >> shift) > nbk_target) shift++;
-    const uint32_t nbk = (nwin + (1u << shift) - 1) >> shift;
-    // LDS staging of k_stream (two workgroups per CU, 80 KiB each): units (8 B) + bucket ids (2 B) + bucket counts
-    const uint32_t lds_budget = PP_STREAM_LDS_KB * 1024 - 512;
-    if ((uint64_t)nbk * 8 + 64 * 10 > lds_budget) return ctx->fail(PP_ERR_LIMIT, "assembly too long for the bucket table");
-    uint32_t stage_cap = ((lds_budget - nbk * 8) / 10) & ~63u;
-    if (stage_cap > 65472) stage_cap = 65472;
-    const size_t stream_lds = (size_t)stage_cap * 10 + (size_t)nbk * 8;
-    const uint32_t per_iter = STREAM_WAVES * STREAM_BATCH;
-    const uint32_t NBs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256 * STREAM_BLOCKS_PER_CU, (n + per_iter - 1) / per_iter));
-    const uint64_t chunk = ((n + NBs - 1) / NBs + per_iter - 1) / per_iter * per_iter;
-    ctx->cap_segs = std::max<size_t>(ctx->cap_segs, (size_t)(ctx->cap_units / std::max<uint32_t>(1, stage_cap / 2) + NBs + 64));
-    ENS(b_units1, ctx->cap_units * 8); ENS(b_units2, ctx->cap_uout * 8);
-    ENS(b_seg_off, (uint64_t)ctx->cap_segs * (nbk + 1) * 2); ENS(b_seg_base, (uint64_t)ctx->cap_segs * 8);
-    ENS(b_late, ctx->cap_late * sizeof(LateEnt)); ENS(b_nkeep, n * 4);
-    ENS(b_win_start, (uint64_t)nwin * 8); ENS(b_win_nitem, (uint64_t)nwin * 4); ENS(b_win_nev, (uint64_t)nwin * 4);
+    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
+    // One level (items straight into their windows) while all windows fit one LDS pass of k_fill; two levels
+    // (coarse buckets of COARSE_WINDOWS windows, then k_regroup) beyond that: there the single-level k_fill
+    // would re-read its records once per range of 16384 windows.  Measured on MI355X: 5 Mbp: one level 0.19 ms
+    // vs two 0.21 ms (+ k_tile 4 % slower on the regrouped order); 250 Mbp: one level 6.8 ms vs two 4.1 ms.
+    static const int forced_levels = getenv("PP_BUCKET_LEVELS") ? atoi(getenv("PP_BUCKET_LEVELS")) : 0;  // tuning / tests
+    const bool two_level = forced_levels ? forced_levels == 2 : nranges > 1;
+    const uint32_t cw = two_level ? COARSE_WINDOWS : 1;
+    const uint32_t ncoarse = (nwin + cw - 1) / cw;
+    const uint32_t ncranges = (ncoarse + COUNT_RANGE - 1) / COUNT_RANGE;
+    ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+    ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
+    if (two_level) ENS(b_entB, ctx->cap_ent * 16);
     ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
+    ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
     ENS(b_win_slab, (uint64_t)nwin * 4); ENS(b_slabs, (uint64_t)ctx->cap_slabs * 6 * TILE * 4); ENS(b_ents, (uint64_t)ctx->cap_ents * 16);
@@ -299,47 +296,52 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
     PP_HIPCHK(ctx, hipMemsetAsync(d_meta, 0, meta_words * 8, st));
     PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
-    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
 
-    if (!ctx->lds_attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for once per device
-        PP_HIPCHK(ctx, hipFuncSetAttribute((const void *)k_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_budget));
-        ctx->lds_attr_set = true;
-    }
-    timer_begin(ctx, "stream");
+    u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
+    u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
+    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
+    uint4 *d_entA = (uint4 *)ctx->b_entA.p, *d_entB = (uint4 *)ctx->b_entB.p;
+    u32 *d_ccnt = (u32 *)ctx->b_ccnt.p, *d_coff = (u32 *)ctx->b_coff.p;
+
     if (n) {
-        StreamArgs S;
-        S.n = n; S.chunk = chunk;
-        S.contig = B.contig; S.ref_start = B.ref_start; S.kk = B.k; S.seq_off = (const u64 *)B.seq_off; S.seq_len = B.seq_len;
-        S.cig_off = (const u64 *)B.cig_off; S.n_cig = B.n_cig; S.cigar = B.cigar; S.seq = B.seq; S.seq_bytes = B.seq_bytes;
-        S.bases = ctx->d_bases; S.G = G; S.contig_off = d_ctg; S.n_contigs = nc;
-        S.shift = shift; S.nbk = nbk; S.stage_cap = stage_cap;
-        S.units = (u64 *)ctx->b_units1.p; S.cap_units = ctx->cap_units; S.unit_cursor = d_meta + 3;
-        S.seg_off = (unsigned short *)ctx->b_seg_off.p; S.seg_base = (u64 *)ctx->b_seg_base.p;
-        S.seg_cursor = (u32 *)(d_meta + 7); S.cap_segs = (u32)ctx->cap_segs;
-        S.late = (LateEnt *)ctx->b_late.p; S.late_cursor = d_meta + 9; S.cap_late = ctx->cap_late;
-        S.nkeep_arr = (u32 *)ctx->b_nkeep.p; S.status = d_status; S.prof = d_meta + 16 + nc + 1 + 3 * (size_t)nc;
-        hipLaunchKernelGGL(k_stream, dim3(NBs), dim3(STREAM_THREADS), stream_lds, st, S);
+        timer_begin(ctx, "prep");
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
+                           B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
+                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, (u32 *)(d_meta + 9), d_status);
+        timer_end(ctx);
     }
-    timer_end(ctx);
-    timer_begin(ctx, "regroup");
-    {
-        RegroupArgs R;
-        R.nwin = nwin; R.shift = shift; R.nbk = nbk;
-        R.n_seg = (const u32 *)(d_meta + 7); R.cap_segs = (u32)ctx->cap_segs;
-        R.seg_off = (const unsigned short *)ctx->b_seg_off.p; R.seg_base = (const u64 *)ctx->b_seg_base.p;
-        R.units_in = (const u64 *)ctx->b_units1.p;
-        R.late = (const LateEnt *)ctx->b_late.p; R.n_late = d_meta + 9; R.cap_late = ctx->cap_late;
-        R.units_out = (u64 *)ctx->b_units2.p; R.cap_out = ctx->cap_uout; R.out_cursor = d_meta + 11;
-        R.win_start = (u64 *)ctx->b_win_start.p; R.win_nitem = (u32 *)ctx->b_win_nitem.p; R.win_nev = (u32 *)ctx->b_win_nev.p;
-        R.status = d_status;
-        hipLaunchKernelGGL(k_regroup, dim3(((nbk + 7) / 8) * 8), dim3(REGROUP_THREADS), 0, st, R);
+    timer_begin(ctx, "bucket");
+    if (two_level) {
+        PP_HIPCHK(ctx, hipMemsetAsync(d_wincnt, 0, (size_t)nwin * 4, st));
+        hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                           d_nkeep, nwin, ncoarse, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
+                           d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
+                           d_winoff, (u64 *)nullptr, ~0ull, d_status);
+        if (n) {
+            hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                               d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
+                               (const u32 *)d_coff, d_entB, d_status);
+            hipLaunchKernelGGL(k_regroup, dim3(ncoarse), dim3(1024), 0, st, nwin, (const u32 *)d_coff,
+                               (const u32 *)d_winoff, (const uint4 *)d_entB, d_entA, d_status);
+        }
+    } else {
+        hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
+                           nwin, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
+                           d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
+        if (n)
+            hipLaunchKernelGGL(k_fill<1>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
+                               B.k, (const u64 *)B.seq_off, B.seq_len, nwin, nwin, (const u32 *)d_hist,
+                               (const u32 *)d_winoff, d_entA, d_status);
     }
     timer_end(ctx);
 
     TileArgs T;
-    T.units = (const u64 *)ctx->b_units2.p; T.win_start = (const u64 *)ctx->b_win_start.p;
-    T.win_nitem = (const u32 *)ctx->b_win_nitem.p; T.win_nev = (const u32 *)ctx->b_win_nev.p; T.nwin = nwin;
-    T.contig = B.contig; T.ref_start = B.ref_start; T.kk = B.k; T.nkeep_arr = (const u32 *)ctx->b_nkeep.p;
+    T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
     T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
     T.n_cig = B.n_cig; T.cigar = B.cigar;
     T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
@@ -350,7 +352,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
     T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
+    T.maxlen = (const u32 *)(d_meta + 9);
     T.scr_need = d_meta + 10;
+    T.seq_bytes = B.seq_bytes;
     T.own = nullptr;
     if (!ctx->emit.empty()) {
         const void *d_own = nullptr;
@@ -378,9 +382,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     E.scr_need = d_meta + 10;
     E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
-    E.units = T.units; E.win_start = T.win_start; E.win_nitem = T.win_nitem;
-    E.contig = B.contig; E.ref_start = B.ref_start; E.nkeep_arr = T.nkeep_arr;
-    E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
+    E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
     E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
     E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
@@ -412,12 +414,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint64_t *n_en
     meta.resize(meta_words);
     PP_HIPCHK(ctx, hipMemcpyAsync(meta.data(), d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
-    *n_entries_out = meta[3];
-#ifdef PP_STREAM_PROFILE
-    { const uint64_t *pf = &meta[16 + nc + 1 + 3 * (size_t)nc];
-      fprintf(stderr, "[stream profile] classify %llu units %llu passes %llu barrier %llu flush %llu (wave-cycles)\n", (unsigned long long)pf[1], (unsigned long long)pf[2], (unsigned long long)pf[3], (unsigned long long)pf[4], (unsigned long long)pf[5]);
-      fprintf(stderr, "[stream profile] inside flush: own part before barrier 1 %llu, wait at barrier 1 %llu, scatter %llu\n", (unsigned long long)pf[6], (unsigned long long)pf[7], (unsigned long long)pf[0]); }
-#endif
+    *n_entries_out = (uint32_t)meta[3];
     return PP_OK;
 }
 
@@ -430,9 +427,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     const uint64_t G = ctx->G;
     const uint32_t nc = ctx->n_contigs;
     // optimistic capacities (grow-only across jobs)
-    ctx->cap_units = std::max<size_t>(ctx->cap_units, (size_t)(n + n / 2 + 65536));
-    ctx->cap_uout = std::max<size_t>(ctx->cap_uout, (size_t)(n + n / 2 + 65536));
-    ctx->cap_late = std::max<size_t>(ctx->cap_late, 65536);
+    ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
     ctx->cap_flag = std::max<size_t>(ctx->cap_flag, std::min<size_t>((size_t)G, std::max<size_t>(65536, (size_t)(G / 64))));
     ctx->cap_scr = std::max<size_t>(ctx->cap_scr, (size_t)1 << 20);
     ctx->cap_multi = std::max<size_t>(ctx->cap_multi, 65536);
@@ -442,7 +437,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     ctx->cap_out = std::max<size_t>(ctx->cap_out, (size_t)(G + G / 16 + 65536));
 
     std::vector<uint64_t> meta;
-    uint64_t n_entries = 0;
+    uint32_t n_entries = 0;
     int attempt = 0;
     for (;; attempt++) {
         timers_release(ctx);
@@ -462,10 +457,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
             cap = (size_t)(need + need / 8 + 1024);
             grew = true;
         };
-        grow(ctx->cap_units, meta[3], "units");
-        grow(ctx->cap_uout, meta[11], "regrouped units");
-        grow(ctx->cap_segs, (uint32_t)meta[7], "segments");
-        grow(ctx->cap_late, meta[9], "late-list entries");
+        grow(ctx->cap_ent, meta[3], "work items");
         grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G), "listed positions");
         grow(ctx->cap_scr, std::max(meta[4], meta[10]), "replay scratch");
         grow(ctx->cap_multi, cnt[1], "multi-byte winners");
@@ -663,8 +655,8 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_nkeep,
-                     &ctx->b_units1, &ctx->b_units2, &ctx->b_seg_off, &ctx->b_seg_base, &ctx->b_late, &ctx->b_win_start, &ctx->b_win_nitem, &ctx->b_win_nev,
+    DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
+                     &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
