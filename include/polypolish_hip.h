@@ -134,8 +134,12 @@ int pp_polish_set_emit(pp_ctx *ctx, const uint64_t *emit_lo, const uint64_t *emi
  * concatenated, ASCII-uppercased assembly, src/misc.rs:114,129; total length < 2^32-4096). */
 int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,
                     const uint8_t *bases, int bases_mem, const pp_params *params);
-/* Provide the alignments (one batch per job in this version; `mem` applies to every pointer in
- * the batch).  PP_MEM_DEVICE batches are borrowed until pp_polish_finish returns. */
+/* Provide alignments, one batch after the other as the reference streams its SAM files (src/alignment.rs:238-265):
+ * every record of a later batch follows the records of the earlier ones in file order; seq_off / cig_off are
+ * relative to the batch's own seq / cigar arrays.  `mem` applies to every pointer in the batch.  Host batches are
+ * copied before the call returns; PP_MEM_DEVICE batches must stay valid and unchanged until pp_polish_finish returns
+ * (a job's ONLY batch is used in place; with more than one batch everything is gathered into library-owned arrays
+ * with device-to-device copies on the context's stream).  Limits per job: < 2^32-1 records, < 2^40 SEQ bytes. */
 int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *batch, int mem);
 /* Run the kernels: CIGAR walk + homopolymer trim (src/alignment.rs:175-201,364-378), pileup
  * accumulation (src/pileup.rs:56-65,189-200), vote (src/pileup.rs:67-134), '-' removal and

@@ -218,6 +218,32 @@ REC_FIELDS = (("contig", np.uint32), ("ref_start", np.uint32), ("k", np.uint32),
               ("cigar", np.uint32))
 
 
+def split_records(recs, cuts):
+    """The records cut at the indices `cuts` into batches that are valid on their own: seq_off / cig_off relative to
+    each batch's seq / cigar arrays (which hold exactly the bytes / runs its records refer to, re-packed)."""
+    n = len(recs["contig"])
+    edges = [0] + sorted(int(c) for c in (cuts or []) if 0 < int(c) < n) + [n]
+    if len(edges) == 2:
+        return [recs]
+    out = []
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sl = recs["seq_len"][lo:hi].astype(np.int64)
+        so = recs["seq_off"][lo:hi].astype(np.int64)
+        nc = recs["n_cig"][lo:hi].astype(np.int64)
+        co = recs["cig_off"][lo:hi].astype(np.int64)
+        new_so = np.concatenate([[0], np.cumsum(sl)[:-1]]) if hi > lo else np.zeros(0, np.int64)
+        new_co = np.concatenate([[0], np.cumsum(nc)[:-1]]) if hi > lo else np.zeros(0, np.int64)
+        seq_idx = np.repeat(so - new_so, sl) + np.arange(int(sl.sum())) if hi > lo else np.zeros(0, np.int64)
+        cig_idx = np.repeat(co - new_co, nc) + np.arange(int(nc.sum())) if hi > lo else np.zeros(0, np.int64)
+        part = {k: np.ascontiguousarray(recs[k][lo:hi]) for k in ("contig", "ref_start", "k", "seq_len", "n_cig")}
+        part["seq_off"] = new_so.astype(np.uint64)
+        part["cig_off"] = new_co.astype(np.uint64)
+        part["seq"] = np.ascontiguousarray(recs["seq"][seq_idx]) if len(seq_idx) else np.zeros(0, np.uint8)
+        part["cigar"] = np.ascontiguousarray(recs["cigar"][cig_idx]) if len(cig_idx) else np.zeros(0, np.uint32)
+        out.append(part)
+    return out
+
+
 def ingest(assembly, sams, max_errors=10, careful=False):
     """Host ingest only (no GPU needed): FASTA + SAM text -> (names, descs, contig_off, bases, recs, counts)."""
     L = lib()
@@ -490,16 +516,18 @@ class Context:
         self._chk(lib().pp_polish_set_emit(self._h, lo.ctypes.data, hi.ctypes.data))
 
     def polish_records(self, contig_off, bases, recs, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2,
-                       positions=False, emit=None):
-        """Host numpy SoA (field names of pp_aln_batch) -> polished bytes, offsets, stats."""
+                       positions=False, emit=None, cuts=None):
+        """Host numpy SoA (field names of pp_aln_batch) -> polished bytes, offsets, stats.
+        cuts: optional record indices at which the records are cut into several pp_polish_add batches."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
         lib().pp_polish_set_debug(self._h, int(positions))
         self.polish_begin(contig_off, bases.ctypes.data, MEM_HOST, min_depth, fraction_valid, fraction_invalid)
         if emit is not None:
             self.set_emit(emit)
-        self.polish_add_ptrs(len(keep["contig"]), {k: v.ctypes.data for k, v in keep.items()}, len(keep["seq"]),
-                             len(keep["cigar"]), MEM_HOST)
+        for part in split_records(keep, cuts):
+            self.polish_add_ptrs(len(part["contig"]), {k: v.ctypes.data for k, v in part.items()}, len(part["seq"]),
+                                 len(part["cigar"]), MEM_HOST)
         self.polish_finish()
         polished, offs, stats = self.result()
         res = {"polished": polished, "offsets": offs, "stats": stats, "positions": None}

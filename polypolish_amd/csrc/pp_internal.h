@@ -91,13 +91,15 @@ struct pp_ctx {
     const uint8_t *d_bases = nullptr;  // device pointer (owned copy or borrowed)
     pp_aln_batch dbatch{};             // device pointers
     bool have_batch = false;
+    bool batch_borrowed = false;       // the one batch so far is caller-owned device memory, used in place
+    uint64_t acc_n = 0, acc_seq = 0, acc_cig = 0;  // records / SEQ bytes / CIGAR runs accumulated in b_in[]
     uint64_t total_out = 0, n_multi = 0, n_keys = 0;
     std::vector<uint64_t> contig_out_off;
     std::vector<pp_contig_stats> stats;
 
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
-    pp::DevBuf b_in[9];  // uploaded batch arrays
+    pp::DevBuf b_in[9];  // the accumulated batch arrays (uploaded or gathered)
     pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slabs, b_ents, b_keys, b_own;
@@ -133,6 +135,7 @@ namespace pp {
 
 // grow-only device allocation
 int dev_ensure(pp_ctx *ctx, DevBuf &b, size_t bytes);
+int dev_grow_keep(pp_ctx *ctx, DevBuf &b, size_t bytes, size_t used);
 void dev_free(DevBuf &b);
 // start/stop a named kernel timer on the context's stream (no-ops unless profiling)
 void timer_begin(pp_ctx *ctx, const char *name);

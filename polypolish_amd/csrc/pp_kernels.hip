@@ -6,10 +6,10 @@
 //   k_count    per-block LDS histogram of (alignment, window) items   \  atomics-free multisplit
 //   k_scan_cols / k_scan   column scan over blocks + scan over windows  > of the alignments into
 //   k_fill     scatter 16-byte work items into their window's bucket   /  2048-position windows
-//   k_tile     one workgroup per window: counters for 2048 positions live in LDS, one wave per
-//              work item streams the read bases (coalesced byte loads) and does one LDS atomic per
-//              base (pileup.rs:56-65,189-200); then one lane per position votes
-//              (pileup.rs:67-134) and writes a 1-byte emit code
+//   k_tile     one workgroup per window: counters for 2048 positions and the window's assembly bytes live in LDS;
+//              groups of 5-8 lanes own one read (32 bytes per lane), compare it with the assembly and tally only the
+//              differing bases (two LDS atomics into a coverage difference array per read, pileup.rs:56-65,189-200);
+//              then one lane per position votes (pileup.rs:67-134) and writes a 1-byte emit code
 //   k_exact    the rare positions whose outcome depends on string-keyed counts (insertions, N...)
 //              or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
 //              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact
@@ -56,6 +56,23 @@ void dev_free(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+// grow a buffer to `bytes` keeping its first `used` bytes (the accumulated alignment batches)
+int dev_grow_keep(pp_ctx *ctx, DevBuf &b, size_t bytes, size_t used) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return PP_OK;
+    void *np = nullptr;
+    const size_t want = std::max(bytes + bytes / 2, b.cap + b.cap / 2) + 256;
+    PP_HIPCHK(ctx, hipMalloc(&np, want));
+    if (b.p && used) PP_HIPCHK(ctx, hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, ctx->stream));
+    if (b.p) {
+        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PP_HIPCHK(ctx, hipFree(b.p));
+    }
+    b.p = np;
+    b.cap = want;
+    return PP_OK;
 }
 
 // Per-kernel-group timing with HIP events on the context's stream.  profiling == 1 times every group,
@@ -158,6 +175,8 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
     ctx->job_open = true;
     ctx->job_done = false;
     ctx->have_batch = false;
+    ctx->batch_borrowed = false;
+    ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
     ctx->emit.clear();
     memset(&ctx->dbatch, 0, sizeof ctx->dbatch);
     return PP_OK;
@@ -181,12 +200,54 @@ extern "C" int pp_polish_set_emit(pp_ctx *ctx, const uint64_t *emit_lo, const ui
     return PP_OK;
 }
 
+// seq_off / cig_off of an appended batch are relative to ITS seq / cigar arrays: rebase them onto the accumulated ones
+__global__ void k_rebase(u64 *seq_off, u64 *cig_off, u64 n, u64 seq_base, u64 cig_base) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        seq_off[i] += seq_base;
+        cig_off[i] += cig_base;
+    }
+}
+
+// Append one batch (host or device memory) to the library-owned accumulated arrays.
+static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
+    const uint64_t n0 = ctx->acc_n, s0 = ctx->acc_seq, c0 = ctx->acc_cig;
+    const uint64_t n = b->n_aln;
+    if (n0 + n >= 0xFFFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one polish job");
+    if (s0 + b->seq_bytes >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "more than 2^40 SEQ bytes in one polish job");
+    const hipMemcpyKind kind = mem == PP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const void *src[9] = {b->contig, b->ref_start, b->k, b->seq_off, b->seq_len, b->cig_off, b->n_cig, b->seq, b->cigar};
+    const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
+    const uint64_t old_cnt[9] = {n0, n0, n0, n0, n0, n0, n0, s0, c0};
+    const uint64_t add_cnt[9] = {n, n, n, n, n, n, n, b->seq_bytes, b->n_cig_total};
+    for (int i = 0; i < 9; i++) {
+        int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)(old_cnt[i] + add_cnt[i]) * esz[i], (size_t)old_cnt[i] * esz[i]);
+        if (rc) return rc;
+        if (add_cnt[i])
+            PP_HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_in[i].p + old_cnt[i] * esz[i], src[i], (size_t)add_cnt[i] * esz[i], kind,
+                                          ctx->stream));
+    }
+    if (n && (s0 || c0))
+        hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64 *)ctx->b_in[3].p + n0,
+                           (u64 *)ctx->b_in[5].p + n0, (u64)n, (u64)s0, (u64)c0);
+    if (mem != PP_MEM_DEVICE) PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are only borrowed for the call
+    ctx->acc_n = n0 + n; ctx->acc_seq = s0 + b->seq_bytes; ctx->acc_cig = c0 + b->n_cig_total;
+    pp_aln_batch &d = ctx->dbatch;
+    d.n_aln = ctx->acc_n; d.seq_bytes = ctx->acc_seq; d.n_cig_total = ctx->acc_cig;
+    d.contig = (const uint32_t *)ctx->b_in[0].p; d.ref_start = (const uint32_t *)ctx->b_in[1].p; d.k = (const uint32_t *)ctx->b_in[2].p;
+    d.seq_off = (const uint64_t *)ctx->b_in[3].p; d.seq_len = (const uint32_t *)ctx->b_in[4].p;
+    d.cig_off = (const uint64_t *)ctx->b_in[5].p; d.n_cig = (const uint32_t *)ctx->b_in[6].p;
+    d.seq = (const uint8_t *)ctx->b_in[7].p; d.cigar = (const uint32_t *)ctx->b_in[8].p;
+    return PP_OK;
+}
+
+// Batches may be added one after the other (the reference streams its SAM files, src/alignment.rs:238-265): record i
+// of a later batch follows every record of the earlier ones in file order.  A single PP_MEM_DEVICE batch is borrowed
+// as it is; as soon as there is a second batch everything is gathered into library-owned arrays.
 extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     if (!ctx) return PP_ERR_ARG;
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_add without pp_polish_begin");
-    if (ctx->have_batch)
-        return ctx->fail(PP_ERR_LIMIT, "this version takes one alignment batch per polish job");
     if (!b) return ctx->fail(PP_ERR_ARG, "pp_polish_add: null batch");
     if (b->n_aln >= 0xFFFFFFFFull)
         return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one batch");
@@ -194,29 +255,20 @@ extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
                      !b->cig_off || !b->n_cig || !b->seq || !b->cigar))
         return ctx->fail(PP_ERR_ARG, "pp_polish_add: null array in a non-empty batch");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (mem == PP_MEM_DEVICE) {
+    if (!ctx->have_batch && mem == PP_MEM_DEVICE) {
         ctx->dbatch = *b;
-    } else {
-        pp_aln_batch d = *b;
-        const void *p;
-        int rc;
-        size_t n = b->n_aln;
-#define UP(i, field, T, count)                                                    \
-    rc = upload(ctx, ctx->b_in[i], b->field, (size_t)(count) * sizeof(T), &p);   \
-    if (rc) return rc;                                                            \
-    d.field = (const T *)p;
-        UP(0, contig, uint32_t, n)
-        UP(1, ref_start, uint32_t, n)
-        UP(2, k, uint32_t, n)
-        UP(3, seq_off, uint64_t, n)
-        UP(4, seq_len, uint32_t, n)
-        UP(5, cig_off, uint64_t, n)
-        UP(6, n_cig, uint32_t, n)
-        UP(7, seq, uint8_t, b->seq_bytes)
-        UP(8, cigar, uint32_t, b->n_cig_total)
-#undef UP
-        ctx->dbatch = d;
+        ctx->batch_borrowed = true;
+        ctx->have_batch = true;
+        return PP_OK;
     }
+    if (ctx->have_batch && ctx->batch_borrowed) {  // a second batch: the borrowed one moves into the accumulated arrays
+        const pp_aln_batch first = ctx->dbatch;
+        ctx->batch_borrowed = false;
+        ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
+        if (int rc = append_batch(ctx, &first, PP_MEM_DEVICE)) return rc;
+    }
+    if (!ctx->have_batch) ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
+    if (int rc = append_batch(ctx, b, mem)) return rc;
     ctx->have_batch = true;
     return PP_OK;
 }

@@ -863,3 +863,51 @@ def test_full_size_configs(ctx, pp, orc, config):
         want = orc.polish_records(np.array([0, hi - lo], np.uint64), sub["bases"].cpu().numpy(), bench.to_host_records(sub))
         assert s == want["polished"], (config, c, lo, hi)
         assert len(s) == hi - lo and s[400:-400] == a[coff[c] + lo + 400:coff[c] + hi - 400], (config, c, lo, hi)
+
+
+def test_batches_added_one_after_the_other_equal_one_batch(ctx, pp, orc):
+    """pp_polish_add several times per job (the reference streams its SAM files, alignment.rs:238-265): any cut of the
+    records into batches gives the bytes, depths and statuses of the single batch -- host batches, device batches
+    (the first one borrowed in place, then gathered) and a mix; a bad record in a later batch is reported with
+    its index in the whole job, and the first one in file order wins."""
+    import torch
+    o, b, r = synth.fast_records(seed=21, contig_lens=(30_000, 5_000), coverage=40, indel_read_frac=0.1,
+                                 k_choices=(1, 1, 2, 3), n_rate=0.003)
+    want = orc.polish_records(o, b, r, positions=True)
+    n = len(r["contig"])
+    for cuts in ([n // 2], [1, 2, n - 1], [n // 3, n // 3 + 1, 2 * n // 3], [0, n]):
+        got = ctx.polish_records(o, b, r, positions=True, cuts=cuts)
+        assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"]), cuts
+        for k in POS_KEYS:
+            assert np.array_equal(got["positions"][k], want["positions"][k]), (cuts, k)
+    # device-resident batches and a host batch in between
+    dev = torch.device("cuda", 0)
+    parts = pp.split_records({k: np.ascontiguousarray(r[k], dtype=dt) for k, dt in pp.REC_FIELDS}, [n // 4, n // 2])
+    dt = {"contig": torch.int32, "ref_start": torch.int32, "k": torch.int32, "seq_off": torch.int64, "seq_len": torch.int32,
+          "cig_off": torch.int64, "n_cig": torch.int32, "seq": torch.uint8, "cigar": torch.int32}
+    tens = [{k: torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else (v.view(np.int32) if v.dtype == np.uint32 else v))
+             .to(dev).to(dt[k]) for k, v in p.items()} for p in parts]
+    bases_d = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+    torch.cuda.synchronize()
+    for kinds in ((1, 1, 1), (1, 0, 1), (0, 1, 0)):
+        ctx.polish_begin(o, bases_d.data_ptr(), pp.MEM_DEVICE)
+        for p, t, kd in zip(parts, tens, kinds):
+            if kd:
+                ctx.polish_add_ptrs(len(p["contig"]), {k: v.data_ptr() for k, v in t.items()}, t["seq"].numel(), t["cigar"].numel(),
+                                    pp.MEM_DEVICE)
+            else:
+                ctx.polish_add_ptrs(len(p["contig"]), {k: v.ctypes.data for k, v in p.items()}, len(p["seq"]), len(p["cigar"]),
+                                    pp.MEM_HOST)
+        ctx.polish_finish()
+        polished, offs, _ = ctx.result()
+        assert polished == want["polished"] and np.array_equal(offs, want["offsets"]), kinds
+    # errors: record 3 of the second batch and record 1 of the third are bad -> the job reports index n1 + 3
+    ref = "ACGGTCATTGCAACGGTTATTGCA" * 3
+    bases2 = np.frombuffer(ref.encode(), np.uint8)
+    off2 = np.array([0, len(ref)], np.uint64)
+    good = (0, 0, 1, ref[:24], [(24, "M")])
+    bad = (0, 0, 1, ref[:24], [(23, "M")])
+    recs = _rec([good] * 5 + [good, good, good, bad, good] + [good, bad])
+    with pytest.raises(pp.PolypolishError) as e:
+        ctx.polish_records(off2, bases2, recs, cuts=[5, 10])
+    assert e.value.code == pp.ERR_QUIT and "does not match read sequence" in e.value.msg and "record 8" in e.value.msg, e.value

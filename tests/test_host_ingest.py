@@ -277,3 +277,32 @@ def test_sam_from_a_pipe(orc, tmp_path):
     P = pp.FilterLoaded(*fifos)
     assert P.counts == H.counts and all(np.array_equal(P.files[f][k], H.files[f][k]) for f in range(2) for k in H.files[f])
     H.close(); P.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_reference_fasta_vector_through_the_product_loader(tmp_path, gz):
+    """T11 (src/misc.rs:245-267: three records incl. a multi-word and an empty description), plain and gzipped
+    (src/misc.rs:81-99,136-167), through the PRODUCT's pp_assembly_load -- the oracle is not involved."""
+    import ctypes as C
+    import gzip
+    import json
+    import polypolish_amd as pp
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_unit_vectors.json")))["T11_load_fasta"]
+    path = tmp_path / ("test.fasta.gz" if gz else "test.fasta")
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(gold["contents"].encode())
+    else:
+        path.write_text(gold["contents"])
+    L = pp.lib()
+    a, err = C.c_void_p(), C.create_string_buffer(512)
+    assert L.pp_assembly_load(str(path).encode(), C.byref(a), err, 512) == 0, err.value
+    try:
+        n = L.pp_assembly_n_contigs(a)
+        off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,))
+        bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),))
+        got = [[L.pp_assembly_name(a, i).decode(), L.pp_assembly_description(a, i).decode(),
+                bytes(bases[int(off[i]):int(off[i + 1])]).decode()] for i in range(n)]
+        assert got == gold["records"]
+    finally:
+        L.pp_assembly_free(a)
