@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <future>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -209,8 +210,23 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     const bool dev_ingest = !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
+    // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
+    // (pp_polish_begin + pp_polish_add on a helper thread) while file i+1 is parsed -- the reference streams its files
+    // one after the other as well (alignment.rs:238-265).  --debug keeps ONE host batch (the TSV indexes its SEQ bytes).
+    const bool stream_adds = !dev_ingest && !opt->debug_path;
+    std::vector<pp_ingest *> gs;
+    std::future<int> pending;
+    bool begun = false;
+    pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
+    auto free_all = [&]() {
+        if (pending.valid()) (void)pending.get();
+        for (pp_ingest *x : gs) pp_ingest_free(x);
+        pp_ingest_free(g);
+        pp_dev_ingest_free(dg);
+        pp_assembly_free(a);
+    };
     rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
-                    : pp_ingest_create(a, opt->max_errors, opt->careful, &g);
+                    : (stream_adds ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
     uint64_t alignment_total = 0, used_total = 0;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;
@@ -218,18 +234,35 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
             if (rc) break;
         } else {
-            rc = pass ? pp_ingest_sam_filtered(g, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
-                      : pp_ingest_sam(g, sams[i], &c, err, sizeof err);
+            pp_ingest *gi = g;
+            if (stream_adds) {
+                rc = pp_ingest_create(a, opt->max_errors, opt->careful, &gi);
+                if (rc) break;
+                gs.push_back(gi);
+            }
+            rc = pass ? pp_ingest_sam_filtered(gi, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
+                      : pp_ingest_sam(gi, sams[i], &c, err, sizeof err);
             if (rc) { set_err(ctx, rc, err); break; }
+            if (stream_adds) {
+                if (pending.valid() && (rc = pending.get())) break;  // the upload of the file before
+                const bool first = !begun;
+                begun = true;
+                pending = std::async(std::launch::async, [ctx, gi, first, nc, off, a, prm]() {
+                    int r = first ? pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
+                    pp_aln_batch bi;
+                    pp_ingest_batch(gi, &bi);
+                    if (r == PP_OK) r = pp_polish_add(ctx, &bi, PP_MEM_HOST);
+                    return r;
+                });
+            }
         }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
         alignment_total += c.alignments;
         used_total += c.used;
     }
+    if (rc == PP_OK && pending.valid()) rc = pending.get();
     if (rc) {
-        pp_ingest_free(g);
-        pp_dev_ingest_free(dg);
-        pp_assembly_free(a);
+        free_all();
         return rc;
     }
     log("\nFiltering for high-quality end-to-end alignments%s:\n  %s alignments kept\n  %s alignments discarded\n\n",
@@ -239,25 +272,25 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     lap("alignments ingested");
     // polish_sequences, polish.rs:137-154 -- on the device
     log("Polishing assembly sequences\n");
-    pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
     pp_aln_batch batch;
-    if (dev_ingest) pp_dev_ingest_batch(dg, &batch); else pp_ingest_batch(g, &batch);
+    memset(&batch, 0, sizeof batch);
+    if (dev_ingest) pp_dev_ingest_batch(dg, &batch); else if (g) pp_ingest_batch(g, &batch);
     // create_debug_file, polish.rs:230-245: the file is created (and the header written) before polishing
     FILE *dbg = nullptr;
     if (opt->debug_path) {
         dbg = fopen(opt->debug_path, "wb");
         if (!dbg) {
             snprintf(err, sizeof err, "unable to create \"%s\"", opt->debug_path);
-            pp_ingest_free(g);
-            pp_dev_ingest_free(dg);
-            pp_assembly_free(a);
+            free_all();
             return set_err(ctx, PP_ERR_QUIT, err);
         }
         fputs("name\tpos\tbase\tdepth\tinvalid\tvalid\tpileup\tstatus\tnew_base\n", dbg);
     }
     pp_polish_set_debug(ctx, dbg ? 1 : 0);
-    rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
-    if (rc == PP_OK) rc = pp_polish_add(ctx, &batch, dev_ingest ? PP_MEM_DEVICE : PP_MEM_HOST);
+    if (!begun) {  // one batch (device tokenizer, --debug), or no SAM files at all
+        rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+        if (rc == PP_OK && (dev_ingest || g)) rc = pp_polish_add(ctx, &batch, dev_ingest ? PP_MEM_DEVICE : PP_MEM_HOST);
+    }
     if (rc == PP_OK) rc = pp_polish_finish(ctx);
     lap("uploaded + polished on device");
     if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
@@ -270,9 +303,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     std::vector<pp_contig_stats> stats(nc);
     if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
     if (rc) {
-        pp_ingest_free(g);
-        pp_dev_ingest_free(dg);
-        pp_assembly_free(a);
+        free_all();
         return rc;
     }
 
@@ -313,9 +344,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
         log("  %s_polypolish (%s bp)\n", pp_assembly_name(a, c), commas(stats[c].polished_len).c_str());
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     log("\nTime to run: %s\n\n", format_duration(secs).c_str());
-    pp_ingest_free(g);
-    pp_dev_ingest_free(dg);
-    pp_assembly_free(a);
+    free_all();
     return PP_OK;
 }
 

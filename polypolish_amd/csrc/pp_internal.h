@@ -22,6 +22,7 @@ constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the
 constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
 constexpr uint32_t SORT_MAX = 16384;      // items per window the ordered-depth replay kernel sorts in LDS (128 KiB)
+constexpr uint32_t SORT_SMALL = 10112;    // ... its small instance (80 KiB of LDS: two workgroups per CU)
 constexpr uint32_t SORT_BUCKETS = 4096;   // its counting sort: buckets over the window's range of record indices ...
 constexpr uint32_t SORT_BUCKET_MAX = 48;  // ... finished by insertion sorts unless one holds more than this (-> bitonic)
 

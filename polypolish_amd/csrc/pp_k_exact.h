@@ -282,17 +282,21 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 //      the item, `depth += 1/k` in the lanes it covers -- every position sees its additions in file order;
 //  (4) vote per flagged position; the few whose string-keyed tallies could reach a threshold are
 //      handed to the thread-serial k_exact through the global list.
-__global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
-    __shared__ u64 pk[SORT_MAX];  // bitonic sort keys (record index << 16 | slot), or the counting sort's arrays
+// Two instances share the windows by their item count: (0, SORT_SMALL] with 80 KiB of LDS -- two workgroups per CU,
+// the usual case -- and (SORT_SMALL, SORT_MAX] with 128 KiB.
+template <u32 SMAX, u32 NLOW>
+__global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(ExactArgs A, u32 nwin) {
+    __shared__ u64 pk[SMAX];  // bitonic sort keys (record index << 16 | slot), or the counting sort's arrays
     __shared__ u64 s_base;
+    constexpr u32 LDS_LIST_MAX = SMAX * 3u / 8u;  // ordered (start, extent, share) records that fit below ord[]
     const u32 w = blockIdx.x, tid = threadIdx.x;
     const int state = w < nwin ? job_state(A.status) : 2;
     if (state == 2) return;
     if (A.win_nflag[w] == 0) return;
     const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
-    if (n > SORT_MAX || n == 0) return;  // large buckets are replayed by k_exact
+    if (n > SMAX || n <= NLOW) return;  // the other instance's window, or (n > SORT_MAX) replayed by k_exact
     if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
-        if (tid == 0 && n > SORT_MAX / 4) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
+        if (tid == 0 && n > LDS_LIST_MAX) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
         return;
     }
     const u32 slab = A.win_slab[w];
@@ -302,10 +306,11 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     // (up to SORT_BUCKETS buckets between the window's smallest and largest index) leaves buckets of a few
     // items, finished by one thread each with an insertion sort: ~10x fewer LDS passes than a bitonic network
     // over 16 K keys.  Clustered indices (a bucket above SORT_BUCKET_MAX items) take the bitonic sort instead.
-    // The arrays of the counting sort live inside pk[] (112 of its 128 KiB).
-    u32 *rec = (u32 *)pk;                           // [SORT_MAX] record index of slot i
-    unsigned short *ord = (unsigned short *)(pk + SORT_MAX / 2);       // [SORT_MAX] slots in file order
-    u32 *bkt = (u32 *)(pk + SORT_MAX / 2 + SORT_MAX / 4);              // [SORT_BUCKETS + 1] counts -> cursors
+    // The arrays of the counting sort live inside pk[].
+    u32 *rec = (u32 *)pk;                                              // [SMAX] record index of slot i
+    u32 *bkt = (u32 *)(pk + SMAX / 2);                                  // [SORT_BUCKETS + 1] counts -> cursors
+    unsigned short *ord = (unsigned short *)(pk + SMAX / 2 + SMAX / 4);  // [SMAX] slots in file order (last quarter)
+    static_assert((SORT_BUCKETS + 1u) * 4u <= SMAX * 2u, "bkt[] must end before ord[]");
     __shared__ u32 s_lo, s_hi, s_big, s_wtot[16];
     if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0; }
     for (u32 i = tid; i <= SORT_BUCKETS; i += 1024) bkt[i] = 0;
@@ -351,8 +356,8 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     __syncthreads();
     const bool bitonic = s_big != 0;
     // The ordered list of (start, extent, share) records of step (2) stays in LDS when it fits the part of pk[]
-    // that is free by then (rec[]: 4096 records; the bitonic keys occupy it), else it goes to a global slab.
-    const bool in_lds = !bitonic && n <= SORT_MAX / 4;
+    // that is free by then (everything below ord[]; the bitonic keys occupy it), else it goes to a global slab.
+    const bool in_lds = !bitonic && n <= LDS_LIST_MAX;
     if (tid == 0) {
         u64 base = 0;
         if (!in_lds) {
@@ -430,34 +435,49 @@ __global__ __launch_bounds__(1024) void k_exact2(ExactArgs A, u32 nwin) {
     // Two instances of the loop, one per address space (through a generic pointer the loads would be flat loads,
     // whose counters force a full wait), and two batch registers in turn, so that the load of the batch after the
     // current one is in flight while the current one is visited.
-    auto visit = [&](const ulonglong2 &mine, bool have) {
-        const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32), yl = (int)(u32)mine.y, yh = (int)(u32)(mine.y >> 32);
+    // An item that reaches a lane's position adds its share there: fma(1.0, share, depth) is the rounded sum
+    // depth + share, and fma(0.0, share, depth) leaves depth as it is -- one select + one fma per position instead
+    // of a branch.  With the list in LDS the item's three words come from ONE broadcast read at a wave-uniform
+    // address; from the global slab they are picked out of the batch registers with v_readlane.
+    auto visit = [&](const ulonglong2 &mine, bool have, u32 bbase, auto item_of) {
+        const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32);
         // one vector compare picks the items of this batch that reach the wave's positions; only those are
         // visited one by one, in ascending order = file order
         u64 hits = __ballot(have && xl < wlo + 128 && (long long)xl + (long long)(u32)xh > (long long)wlo);
         while (hits) {
             const int j = __ffsll((long long)hits) - 1;
             hits &= hits - 1;
-            const int rel = __builtin_amdgcn_readlane(xl, j);
-            const u32 lim = (u32)__builtin_amdgcn_readlane(xh, j);
-            const double dc = __hiloint2double(__builtin_amdgcn_readlane(yh, j), __builtin_amdgcn_readlane(yl, j));
-            if ((u32)(p0 - rel) < lim) d0 += dc;
-            if ((u32)(p1 - rel) < lim) d1 += dc;
+            const ulonglong2 it = item_of(mine, bbase, j);
+            const int rel = (int)(u32)it.x;
+            const u32 lim = (u32)(it.x >> 32);
+            const double dc = __longlong_as_double((long long)it.y);
+            d0 = fma(__hiloint2double((u32)(p0 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d0);
+            d1 = fma(__hiloint2double((u32)(p1 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d1);
         }
     };
-    auto ordered_pass = [&](auto load) {
+    auto ordered_pass = [&](auto load, auto item_of) {
         // unconditional loads from clamped indices (a load under a branch would make the wait for the older
         // batch a wait for everything); `have` masks the lanes past the end
         ulonglong2 ba = load(min(lane, n - 1u)), bb;
         for (u32 base = 0; base < n; base += 128) {
             bb = load(min(base + 64u + lane, n - 1u));
-            visit(ba, base + lane < n);
+            visit(ba, base + lane < n, base, item_of);
             ba = load(min(base + 128u + lane, n - 1u));
-            visit(bb, base + 64u + lane < n);
+            visit(bb, base + 64u + lane < n, base + 64u, item_of);
         }
     };
-    if (in_lds) ordered_pass([&](u32 i) { return ents_lds[i]; });
-    else ordered_pass([&](u32 i) { return ents[i]; });
+    if (in_lds)
+        ordered_pass([&](u32 i) { return ents_lds[i]; },
+                     [&](const ulonglong2 &, u32 bbase, int j) { return ents_lds[bbase + (u32)j]; });
+    else
+        ordered_pass([&](u32 i) { return ents[i]; }, [&](const ulonglong2 &mine, u32, int j) {
+            ulonglong2 r;
+            r.x = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine.x, j) |
+                  ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine.x >> 32), j) << 32);
+            r.y = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine.y, j) |
+                  ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine.y >> 32), j) << 32);
+            return r;
+        });
 
     // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
     const u32 *tal = A.slabs + (u64)slab * 6u * TILE;

@@ -444,7 +444,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.status = d_status; E.dbg = T.dbg;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
-    hipLaunchKernelGGL(k_exact2, dim3(nwin), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL>), dim3(nwin), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
                        d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
