@@ -12,7 +12,7 @@ OUT      := polypolish_amd/_build
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 LIB  := $(OUT)/libpolypolish_hip.so
-OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o
+OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_comm.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o $(OUT)/pp_shard.o
 
 all: $(LIB) bin/polypolish bin/polish_min oracle tools/_build/libsamgen.so
 
@@ -25,7 +25,7 @@ $(OUT)/%.o: $(CSRC)/%.cpp include/polypolish_hip.h $(CSRC)/pp_host.h
 	$(HIPCC) $(HIPFLAGS) -x c++ -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread -ldl
 
 bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
 	@mkdir -p bin
@@ -48,7 +48,7 @@ tools/_build/libsamgen.so: tools/samgen.c
 variant: $(LIB)
 	@mkdir -p $(OUT)/var_$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pp_kernels.hip -o $(OUT)/var_$(NAME)/pp_kernels.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/var_$(NAME)/libpolypolish_hip.so $(OUT)/var_$(NAME)/pp_kernels.o $(filter-out $(OUT)/pp_kernels.o,$(OBJS)) -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/var_$(NAME)/libpolypolish_hip.so $(OUT)/var_$(NAME)/pp_kernels.o $(filter-out $(OUT)/pp_kernels.o,$(OBJS)) -lz -lpthread -ldl
 
 clean:
 	rm -rf $(OUT) bin oracle/_build tools/_build

@@ -285,68 +285,6 @@ def to_host_records(job):
             for k, v in job["recs"].items()}
 
 
-# ---- sharding of ONE job across ranks (configs 3 and 4 with N > 1) ----------------------------------------
-def shard_job(job, rank, world, tile=2048):
-    """This rank's share of the job: whole contigs by longest-processing-time on their record counts, or -- a
-    single contig -- one of `world` windows (tile-aligned) with a halo of one read span either side and an emit
-    range.  Returns (sub_job, units) where units = [(contig, lo, hi), ...] in output order on this rank."""
-    r = job["recs"]
-    dev = r["contig"].device
-    off = job["contig_off"].astype(np.int64)
-    nc = len(off) - 1
-    L = job["read_len"]
-    if nc >= world:
-        counts = torch.bincount(r["contig"].long(), minlength=nc).cpu().numpy()
-        load = np.zeros(world, dtype=np.int64)
-        owner = np.zeros(nc, dtype=np.int64)
-        for c in np.argsort(-counts, kind="stable"):
-            w = int(np.argmin(load))
-            owner[c] = w
-            load[w] += counts[c]
-        mine = [c for c in range(nc) if owner[c] == rank]
-        remap = torch.full((nc,), -1, dtype=torch.int64, device=dev)
-        remap[torch.tensor(mine, dtype=torch.int64, device=dev)] = torch.arange(len(mine), device=dev)
-        keep = remap[r["contig"].long()] >= 0
-        idx = torch.nonzero(keep)[:, 0]
-        sub_off = np.zeros(len(mine) + 1, dtype=np.uint64)
-        sub_off[1:] = np.cumsum([off[c + 1] - off[c] for c in mine])
-        bases = torch.cat([job["bases"][off[c]:off[c + 1]] for c in mine]) if mine else job["bases"][:0]
-        sub = _take_records(job, idx, remap[r["contig"].long()[idx]].int(), r["ref_start"][idx])
-        sub.update({"G": int(sub_off[-1]), "contig_off": sub_off, "bases": bases.contiguous()})
-        return sub, [(c, 0, int(off[c + 1] - off[c])) for c in mine]
-    assert nc == 1, "fewer contigs than ranks: only the single-contig window tiling is implemented in the bench"
-    G = int(off[1])
-    ntile = (G + tile - 1) // tile
-    lo = (ntile * rank // world) * tile
-    hi = min(G, (ntile * (rank + 1) // world) * tile)
-    halo = L + 2
-    a, b = max(0, lo - halo), min(G, hi + halo)
-    rs = r["ref_start"].long()
-    keep = (rs + L + 1 > lo) & (rs < hi)
-    idx = torch.nonzero(keep)[:, 0]
-    sub = _take_records(job, idx, torch.zeros(len(idx), dtype=torch.int32, device=dev), (rs[idx] - a).int())
-    sub.update({"G": b - a, "contig_off": np.array([0, b - a], dtype=np.uint64), "bases": job["bases"][a:b].contiguous(),
-                "emit": np.array([[lo - a, hi - a]], dtype=np.uint64)})
-    return sub, [(0, lo, hi)]
-
-
-def _take_records(job, idx, contig, ref_start):
-    r = job["recs"]
-    L = job["read_len"]
-    n = len(idx)
-    dev = idx.device
-    seq = r["seq"].view(-1, L)[idx].reshape(-1).contiguous()
-    n_cig = r["n_cig"][idx]
-    cig_off = torch.cumsum(n_cig.long(), 0) - n_cig.long()
-    pos = torch.repeat_interleave(torch.arange(n, device=dev), n_cig.long())
-    within = torch.arange(len(pos), device=dev) - cig_off[pos]
-    cigar = r["cigar"][r["cig_off"][idx][pos] + within]
-    recs = {"contig": contig.contiguous(), "ref_start": ref_start.contiguous(), "k": r["k"][idx].contiguous(),
-            "seq_off": torch.arange(n, device=dev, dtype=torch.int64) * L, "seq_len": r["seq_len"][idx].contiguous(),
-            "cig_off": cig_off, "n_cig": n_cig.contiguous(), "seq": seq, "cigar": cigar.contiguous()}
-    return {"recs": recs, "read_len": L, "n_runs": int(n_cig.sum()), "n_aln": n}
-
-
 # ---- the end-to-end leg: SAM text -> FASTA through the drop-in CLI ----------------------------------------
 def _samgen():
     path = os.path.join(ROOT, "tools", "_build", "libsamgen.so")
@@ -543,38 +481,42 @@ def main():
         gg.manual_seed(7)
         nd = torch.rand(job["n_aln"], device=device, generator=gg) < args.nd_frac
         job["recs"]["k"] = torch.where(nd, 3, job["recs"]["k"]).int().contiguous()
-    units, full_job = None, None
+    plan = None
     if strong:
-        full_n = job["n_aln"]
-        full_job = job if rank == 0 else None  # rank 0 keeps the whole job to verify the gathered result against
-        job, units = shard_job(job, rank, world)
-        torch.cuda.empty_cache()
+        # ONE job, resident on every rank; a rank polishes with the ranges of its units (pp_shard_plan_create: whole
+        # contigs by longest-processing-time, the single contig in one window per rank) -- the device drops the records
+        # that do not reach them and skips the windows outside them (pp_polish_set_emit)
+        counts = torch.bincount(job["recs"]["contig"].long(), minlength=len(lens)).cpu().numpy()
+        plan = pp.Plan(job["contig_off"], counts, world)
+        job["emit"] = plan.emit_ranges(rank)
     torch.cuda.synchronize()
-    # two send buffers in turn: the gather of step i (enqueued, not waited for) may still be reading its
-    # buffer while step i+1 polishes and fills the other one; the final synchronize closes the timed region
-    cap = job["G"] + (1 << 16)
-    gather_bufs = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+    nc_job = len(job["contig_off"]) - 1
     gdev = "cpu" if share else device
-    caps = None
-    if world > 1:
-        c = torch.tensor([cap], dtype=torch.int64, device=gdev)
-        allc = [torch.zeros(1, dtype=torch.int64, device=gdev) for _ in range(world)]
-        dist.all_gather(allc, c)
-        caps = [int(x.item()) for x in allc]
-    gathered = [torch.empty(caps[r], dtype=torch.uint8, device=gdev) for r in range(world)] if (world > 1 and rank == 0) else None
-    n_steps_done = [0]
+    cap = job["G"] + job["G"] // 16 + (1 << 16)          # polished bytes of one rank, at most
+    total_cap = cap if strong else world * cap
+    rank_lens = rank_offs = None
+    gbuf = None
+    if world > 1 and not share:
+        # the exchange of the path, inside the library: pp_polish_gather (RCCL over xGMI)
+        ident = [pp.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0, device=device)
+        ctx.comm_init(rank, world, ident[0])
+        gbuf = torch.zeros(total_cap, dtype=torch.uint8, device=device) if rank == 0 else None
+    elif world > 1:
+        # one GPU shared by all ranks (tests): RCCL refuses that, the bytes travel over gloo
+        sbuf = torch.zeros(cap, dtype=torch.uint8, device=device)
+        gathered = [torch.empty(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    last = {}
 
     def step():
         run_job(ctx, pp, job)
-        if world > 1:
-            # the only exchange of the path: polished bytes -> rank 0 (RCCL over xGMI): direct sends of each
-            # rank's own bytes, no padding to the largest shard
-            buf = gather_bufs[n_steps_done[0] & 1]
-            n_steps_done[0] += 1
-            pp.lib().pp_polish_result(ctx._h, buf.data_ptr(), pp.MEM_DEVICE, None, None)
-            src = buf.cpu() if share else buf
+        if world > 1 and not share:
+            last["lens"], last["offs"] = ctx.gather(gbuf.data_ptr() if rank == 0 else None, total_cap if rank == 0 else 0)
+        elif world > 1:
+            pp.lib().pp_polish_result(ctx._h, sbuf.data_ptr(), pp.MEM_DEVICE, None, None)
+            src = sbuf.cpu()
             if rank == 0:
-                gathered[0][:cap].copy_(src)
+                gathered[0].copy_(src)
                 ops = [dist.P2POp(dist.irecv, gathered[r], r) for r in range(1, world)]
             else:
                 ops = [dist.P2POp(dist.isend, src, 0)]
@@ -621,34 +563,28 @@ def main():
 
     gather_ok = None
     if world > 1:
-        # every rank's polished bytes must have arrived on rank 0 unchanged: compare byte sums
-        mine, _, _ = ctx.result()
-        sums = torch.zeros(2 * world, dtype=torch.int64, device=gdev)
-        sums[rank] = int(np.frombuffer(mine, dtype=np.uint8).sum(dtype=np.int64))
-        sums[world + rank] = len(mine)
-        dist.all_reduce(sums)
+        # every rank's polished bytes must have arrived on rank 0 unchanged, and -- strong scaling -- put back in
+        # assembly order they must be the bytes ONE GPU produces for the whole job
+        mine, my_offs, _ = ctx.result()
         meta = [None] * world
-        _, my_offs, _ = ctx.result()
-        dist.all_gather_object(meta, (units, [int(x) for x in my_offs]))
+        dist.all_gather_object(meta, (hashlib.sha256(mine).hexdigest(), len(mine), [int(x) for x in my_offs]))
         if rank == 0:
-            gather_ok = all(int(gathered[r][:int(sums[world + r].item())].sum(dtype=torch.int64).item()) == int(sums[r].item())
-                            for r in range(world)) and bytes(gathered[0][:len(mine)].cpu().numpy()) == mine
+            if share:
+                rank_bytes = [bytes(gathered[r][:meta[r][1]].numpy()) for r in range(world)]
+            else:
+                host = gbuf.cpu().numpy()
+                starts = np.concatenate([[0], np.cumsum(last["lens"].astype(np.int64))])
+                rank_bytes = [host[int(starts[r]):int(starts[r + 1])].tobytes() for r in range(world)]
+            gather_ok = all(len(rank_bytes[r]) == meta[r][1] and hashlib.sha256(rank_bytes[r]).hexdigest() == meta[r][0]
+                            for r in range(world))
             if strong:
-                # the shards, put back in assembly order, must be the bytes ONE GPU produces for the whole job
-                pieces = {}
-                for r in range(world):
-                    us, offs_r = meta[r]
-                    host = gathered[r].cpu().numpy()
-                    if len(lens) > 1:
-                        for i, (c, _, _) in enumerate(us):
-                            pieces[(c, 0)] = host[offs_r[i]:offs_r[i + 1]]
-                    else:
-                        pieces[(0, us[0][1])] = host[:offs_r[-1]]
-                whole = np.concatenate([pieces[k] for k in sorted(pieces)]) if pieces else np.zeros(0, np.uint8)
-                run_job(ctx, pp, full_job)
+                whole, _ = plan.assemble(rank_bytes, [np.array(m[2], dtype=np.uint64) for m in meta])
+                full = dict(job)
+                full["emit"] = None
+                run_job(ctx, pp, full)
                 ref, _, _ = ctx.result()
-                gather_ok = bool(gather_ok and whole.tobytes() == ref)
-                run_job(ctx, pp, job)  # leave the shard's result in the context for the report below
+                gather_ok = bool(gather_ok and whole == ref)
+                run_job(ctx, pp, job)  # leave the rank's own result in the context for the report below
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -657,7 +593,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     total_mbp = (G_total if strong else world * G_total) / 1e6
     value = total_mbp / (elapsed / args.steps)
-    b_alg = algorithmic_bytes(job)
+    b_alg = algorithmic_bytes(job) // (world if strong else 1)  # strong scaling: a rank's share of the one job
     dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else 0.0
     achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     peak = 8000.0
@@ -698,11 +634,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u8/u32 counts + f64 depth",
         "data": "synthetic",
-        "config": {"workload": label + f" alignment records resident in HBM ({full_n if strong else job['n_aln']} records"
+        "config": {"workload": label + f" alignment records resident in HBM ({job['n_aln']} records"
                                        f"{' in total' if strong else ''}, {100 * args.indel_frac:g}% with a 1-bp indel)",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
-                   "alignments_per_gpu": job["n_aln"]},
+                   "alignments_per_gpu": job["n_aln"] // (world if strong else 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
                      "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"

@@ -201,6 +201,42 @@ typedef struct {
 int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel group, 2 only the dominant kernel ("tile") */
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
 
+/* ---- multi-GPU: contigs (and windows of a large contig) shard across ranks, one process per GPU -----------------
+ * The reference is one thread on one CPU; the partition is SURVEY.md 8(e) / BASELINE.json configs[3], [4].
+ * A rank polishes with the FULL alignment batch and pp_polish_set_emit(the ranges of its units): the device drops
+ * the records that do not reach its ranges and skips the windows outside them, every owned position still sees all
+ * of its alignments in file order.  The only exchange is pp_polish_gather.
+ *   plan    whole contigs by longest-processing-time on their alignment counts; a contig with more than one rank's
+ *           share of the alignments is cut into up to `world` windows on 2048-bp boundaries (>= min_window bp each,
+ *           0 = 65536), one per rank.  Units are listed contig by contig, windows in position order. */
+typedef struct {
+    uint32_t n_units, world, n_contigs;
+    uint32_t *contig;      /* per unit */
+    uint64_t *lo, *hi;     /* [lo, hi) of the contig */
+    uint32_t *rank;        /* the rank that polishes it */
+} pp_shard_plan;
+int pp_shard_plan_create(uint32_t n_contigs, const uint64_t *contig_off, const uint64_t *aln_per_contig, uint32_t world,
+                         uint64_t min_window, pp_shard_plan **out);
+void pp_shard_plan_free(pp_shard_plan *plan);
+/* the ranges one rank emits, as pp_polish_set_emit takes them (arrays of n_contigs; empty range = not its contig) */
+int pp_shard_emit_ranges(const pp_shard_plan *plan, uint32_t rank, uint64_t *emit_lo, uint64_t *emit_hi);
+/* The ranks' polished bytes back in assembly order (HOST memory): rank_bytes[r] / rank_contig_off[r] are what rank
+ * r's pp_polish_result returned (out, contig_out_off); out may be NULL to get the offsets only. */
+int pp_shard_assemble(const pp_shard_plan *plan, const uint8_t *const *rank_bytes, const uint64_t *const *rank_contig_off,
+                      uint8_t *out, uint64_t *contig_out_off);
+/* RCCL communicator of one rank (librccl is loaded at run time; the process's own copy is used if it has one):
+ * rank 0 calls pp_comm_unique_id, the launcher hands the PP_COMM_ID_BYTES to every rank, every rank calls
+ * pp_comm_init on the context of its GPU. */
+#define PP_COMM_ID_BYTES 128
+int pp_comm_unique_id(void *id);
+int pp_comm_init(pp_ctx *ctx, int rank, int world, const void *id);
+void pp_comm_destroy(pp_ctx *ctx);
+/* After pp_polish_finish, on every rank: the polished bytes of all ranks go to rank 0 (ncclAllGather of the byte
+ * counts and per-contig output offsets, then one group of ncclSend / ncclRecv into exclusive-scan offsets).
+ * gathered: DEVICE buffer on rank 0 (>= the sum of the counts, `cap` bytes; NULL elsewhere), filled rank by rank;
+ * rank_len (world) and rank_contig_off (world x (n_contigs + 1)): HOST, filled on every rank, either may be NULL. */
+int pp_polish_gather(pp_ctx *ctx, uint8_t *gathered, uint64_t cap, uint64_t *rank_len, uint64_t *rank_contig_off);
+
 /* ---- seam A: paired-read insert-size filter --------------------------------------------------
  * Alignments of both SAM files as SoA in file order (Alignment::new_quick, src/alignment.rs:
  * 102-128), plus the read-name grouping the reference builds in its HashMap (src/filter.rs:

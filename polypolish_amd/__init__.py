@@ -95,6 +95,14 @@ class FilterInput(C.Structure):
     _fields_ = [("n_reads", C.c_uint32), ("file", FilterFile * 2)]
 
 
+class ShardPlan(C.Structure):
+    _fields_ = [("n_units", C.c_uint32), ("world", C.c_uint32), ("n_contigs", C.c_uint32), ("contig", C.POINTER(C.c_uint32)),
+                ("lo", C.POINTER(C.c_uint64)), ("hi", C.POINTER(C.c_uint64)), ("rank", C.POINTER(C.c_uint32))]
+
+
+COMM_ID_BYTES = 128
+
+
 class FilterFileCounts(C.Structure):
     _fields_ = [("alignments", C.c_uint64), ("reads", C.c_uint64), ("loaded", C.c_int)]
 
@@ -113,6 +121,8 @@ EXPORTS = [
     "pp_ingest_create", "pp_ingest_sam", "pp_ingest_batch", "pp_ingest_read_name", "pp_ingest_free",
     "pp_bytes_free", "pp_polish_files", "pp_filter_files", "pp_filter_polish_files", "pp_ingest_sam_filtered",
     "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_sam_filtered", "pp_dev_ingest_batch", "pp_dev_ingest_free",
+    "pp_shard_plan_create", "pp_shard_plan_free", "pp_shard_emit_ranges", "pp_shard_assemble",
+    "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather",
 ]
 
 _lib = None
@@ -209,6 +219,16 @@ def lib():
         L.pp_dev_ingest_free.argtypes = [vp]
         L.pp_dev_ingest_free.restype = None
         L.pp_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts), C.c_char_p, C.c_size_t]
+        L.pp_shard_plan_create.argtypes = [C.c_uint32, vp, vp, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(ShardPlan))]
+        L.pp_shard_plan_free.argtypes = [C.POINTER(ShardPlan)]
+        L.pp_shard_plan_free.restype = None
+        L.pp_shard_emit_ranges.argtypes = [C.POINTER(ShardPlan), C.c_uint32, vp, vp]
+        L.pp_shard_assemble.argtypes = [C.POINTER(ShardPlan), vp, vp, vp, vp]
+        L.pp_comm_unique_id.argtypes = [vp]
+        L.pp_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.pp_comm_destroy.argtypes = [vp]
+        L.pp_comm_destroy.restype = None
+        L.pp_polish_gather.argtypes = [vp, vp, C.c_uint64, vp, vp]
         _lib = L
     return _lib
 
@@ -323,6 +343,74 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False):
         if g:
             L.pp_dev_ingest_free(g)
         L.pp_assembly_free(a)
+
+
+class Plan:
+    """pp_shard_plan: which rank polishes which contig / window of a contig (no GPU needed).
+    aln_per_contig: alignment records per contig (e.g. np.bincount(recs["contig"], minlength=n_contigs))."""
+
+    def __init__(self, contig_off, aln_per_contig, world, min_window=0):
+        self.contig_off = np.ascontiguousarray(contig_off, dtype=np.uint64)
+        self.n_contigs = len(self.contig_off) - 1
+        cnt = np.ascontiguousarray(aln_per_contig, dtype=np.uint64)
+        assert len(cnt) == self.n_contigs
+        self._p = C.POINTER(ShardPlan)()
+        rc = lib().pp_shard_plan_create(self.n_contigs, self.contig_off.ctypes.data, cnt.ctypes.data, world, min_window,
+                                        C.byref(self._p))
+        if rc:
+            raise PolypolishError(rc, "pp_shard_plan_create failed")
+        p = self._p.contents
+        n = p.n_units
+        self.world = world
+        self.unit_contig = np.ctypeslib.as_array(p.contig, shape=(n,)).copy()
+        self.unit_lo = np.ctypeslib.as_array(p.lo, shape=(n,)).copy()
+        self.unit_hi = np.ctypeslib.as_array(p.hi, shape=(n,)).copy()
+        self.unit_rank = np.ctypeslib.as_array(p.rank, shape=(n,)).copy()
+
+    def emit_ranges(self, rank):
+        """(n_contigs, 2) array of [lo, hi) the rank emits per contig (pp_polish_set_emit's form)."""
+        lo = np.zeros(self.n_contigs, dtype=np.uint64)
+        hi = np.zeros(self.n_contigs, dtype=np.uint64)
+        rc = lib().pp_shard_emit_ranges(self._p, rank, lo.ctypes.data, hi.ctypes.data)
+        if rc:
+            raise PolypolishError(rc, "pp_shard_emit_ranges failed")
+        return np.stack([lo, hi], axis=1)
+
+    def assemble(self, rank_bytes, rank_contig_off):
+        """Polished bytes of all ranks (what each rank's Context.result() gave) -> (bytes in assembly order, offsets)."""
+        bufs = [np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(1, np.uint8) for b in rank_bytes]
+        offs = [np.ascontiguousarray(o, dtype=np.uint64) for o in rank_contig_off]
+        bp = (C.c_void_p * self.world)(*[b.ctypes.data for b in bufs])
+        op = (C.c_void_p * self.world)(*[o.ctypes.data for o in offs])
+        out_off = np.zeros(self.n_contigs + 1, dtype=np.uint64)
+        L = lib()
+        rc = L.pp_shard_assemble(self._p, bp, op, None, out_off.ctypes.data)
+        out = np.zeros(max(int(out_off[-1]), 1), dtype=np.uint8)
+        if rc == 0:
+            rc = L.pp_shard_assemble(self._p, bp, op, out.ctypes.data, out_off.ctypes.data)
+        if rc:
+            raise PolypolishError(rc, "pp_shard_assemble failed")
+        return out[:int(out_off[-1])].tobytes(), out_off
+
+    def close(self):
+        if self._p:
+            lib().pp_shard_plan_free(self._p)
+            self._p = C.POINTER(ShardPlan)()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    """ncclUniqueId for pp_comm_init (rank 0 makes it, the launcher hands it to every rank)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().pp_comm_unique_id(buf)
+    if rc:
+        raise PolypolishError(rc, "pp_comm_unique_id failed (librccl not loadable?)")
+    return buf.raw
 
 
 class FilterLoaded:
@@ -514,6 +602,20 @@ class Context:
         if len(lo) != self._n_contigs:
             raise PolypolishError(ERR_ARG, "set_emit: one range per contig")
         self._chk(lib().pp_polish_set_emit(self._h, lo.ctypes.data, hi.ctypes.data))
+
+    def comm_init(self, rank, world, unique_id: bytes):
+        """Join the RCCL communicator of the job (pp_comm_init): one context per rank / GPU."""
+        self._chk(lib().pp_comm_init(self._h, rank, world, C.c_char_p(unique_id)))
+        self._comm = (rank, world)
+
+    def gather(self, gathered_ptr, cap):
+        """pp_polish_gather: the polished bytes of all ranks -> rank 0's DEVICE buffer (rank-major).
+        Returns (rank_len, rank_contig_off) as numpy arrays (on every rank)."""
+        rank, world = self._comm
+        lens = np.zeros(world, dtype=np.uint64)
+        offs = np.zeros((world, self._n_contigs + 1), dtype=np.uint64)
+        self._chk(lib().pp_polish_gather(self._h, gathered_ptr, cap, lens.ctypes.data, offs.ctypes.data))
+        return lens, offs
 
     def polish_records(self, contig_off, bases, recs, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2,
                        positions=False, emit=None, cuts=None):

@@ -1,0 +1,152 @@
+// pp_comm.hip -- the one exchange of the multi-GPU polish: the ranks' polished bytes go to rank 0 over RCCL (xGMI).
+// One process per GPU (bench.py / polypolish_amd.distributed under torch.distributed.run): rank 0 makes an
+// ncclUniqueId, the launcher hands it to every rank, each rank joins with ncclCommInitRank on its context's device.
+//   pp_polish_gather = ncclAllGather of (byte count, per-contig output offsets) + ONE group of ncclSend / ncclRecv
+//   straight into rank 0's buffer at the exclusive-scan offsets (RCCL has no gatherv).
+// The messages are small (<= 31 MB per rank for configs[4]) and point-to-point into rank 0: seven xGMI links are
+// used at once, nothing is ring-shaped.
+//
+// librccl is loaded at run time (dlopen): a process that already holds an RCCL -- PyTorch brings its own -- keeps
+// using that one, the CLI loads the system's.  Without a usable librccl pp_comm_* fail with PP_ERR_HIP; nothing
+// else in the library depends on it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <vector>
+
+#include "pp_internal.h"
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl R = [] {
+        Rccl r;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return r;
+#define PP_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
+        PP_SYM(GetUniqueId, "ncclGetUniqueId");
+        PP_SYM(CommInitRank, "ncclCommInitRank");
+        PP_SYM(CommDestroy, "ncclCommDestroy");
+        PP_SYM(AllGather, "ncclAllGather");
+        PP_SYM(Send, "ncclSend");
+        PP_SYM(Recv, "ncclRecv");
+        PP_SYM(GroupStart, "ncclGroupStart");
+        PP_SYM(GroupEnd, "ncclGroupEnd");
+        PP_SYM(GetErrorString, "ncclGetErrorString");
+#undef PP_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart &&
+               r.GroupEnd && r.GetErrorString;
+        return r;
+    }();
+    return R;
+}
+
+#define PP_NCCLCHK(ctx, expr)                                                                       \
+    do {                                                                                            \
+        ncclResult_t r__ = (expr);                                                                  \
+        if (r__ != ncclSuccess)                                                                     \
+            return (ctx)->fail(PP_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString(r__));     \
+    } while (0)
+
+}  // namespace
+
+static_assert(sizeof(ncclUniqueId) == PP_COMM_ID_BYTES, "PP_COMM_ID_BYTES");
+
+extern "C" int pp_comm_unique_id(void *id) {
+    if (!id) return PP_ERR_ARG;
+    if (!rccl().ok) return PP_ERR_HIP;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return PP_ERR_HIP;
+    memcpy(id, &u, sizeof u);
+    return PP_OK;
+}
+
+extern "C" int pp_comm_init(pp_ctx *ctx, int rank, int world, const void *id) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    if (!rccl().ok) return ctx->fail(PP_ERR_HIP, "librccl could not be loaded: the multi-GPU gather is not available");
+    if (ctx->comm) return ctx->fail(PP_ERR_ARG, "pp_comm_init: the context already has a communicator");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t c = nullptr;
+    PP_NCCLCHK(ctx, rccl().CommInitRank(&c, world, u, rank));
+    ctx->comm = c;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return PP_OK;
+}
+
+extern "C" void pp_comm_destroy(pp_ctx *ctx) {
+    if (!ctx || !ctx->comm) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)rccl().CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
+}
+
+extern "C" int pp_polish_gather(pp_ctx *ctx, uint8_t *gathered, uint64_t cap, uint64_t *rank_len, uint64_t *rank_contig_off) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->comm) return ctx->fail(PP_ERR_ARG, "pp_polish_gather without pp_comm_init");
+    if (!ctx->job_done) return ctx->fail(PP_ERR_ARG, "no finished polish job");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    hipStream_t st = ctx->stream;
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    const uint32_t nc = ctx->n_contigs;
+    const size_t words = (size_t)nc + 2;  // byte count, then contig_out_off[0..nc]
+    // ---- every rank learns every rank's byte count and per-contig offsets ----
+    if (int rc = pp::dev_ensure(ctx, ctx->b_comm, (size_t)(world + 1) * words * 8)) return rc;
+    uint64_t *d_mine = (uint64_t *)ctx->b_comm.p, *d_all = d_mine + words;
+    std::vector<uint64_t> mine(words), all((size_t)world * words);
+    mine[0] = ctx->total_out;
+    for (uint32_t c = 0; c <= nc; c++) mine[1 + c] = ctx->contig_out_off[c];
+    PP_HIPCHK(ctx, hipMemcpyAsync(d_mine, mine.data(), words * 8, hipMemcpyHostToDevice, st));
+    PP_NCCLCHK(ctx, rccl().AllGather(d_mine, d_all, words, ncclUint64, comm, st));
+    PP_HIPCHK(ctx, hipMemcpyAsync(all.data(), d_all, (size_t)world * words * 8, hipMemcpyDeviceToHost, st));
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    uint64_t total = 0;
+    std::vector<uint64_t> start(world);
+    for (int r = 0; r < world; r++) {
+        start[r] = total;
+        total += all[(size_t)r * words];
+        if (rank_len) rank_len[r] = all[(size_t)r * words];
+        if (rank_contig_off) memcpy(rank_contig_off + (size_t)r * (nc + 1), &all[(size_t)r * words + 1], ((size_t)nc + 1) * 8);
+    }
+    // ---- the bytes: everybody sends to rank 0, which receives at the exclusive-scan offsets ----
+    if (rank == 0) {
+        if (!gathered && total) return ctx->fail(PP_ERR_ARG, "pp_polish_gather: rank 0 needs a buffer");
+        if (total > cap) return ctx->fail(PP_ERR_ARG, "pp_polish_gather: %llu bytes do not fit the buffer of %llu",
+                                          (unsigned long long)total, (unsigned long long)cap);
+        if (ctx->total_out)
+            PP_HIPCHK(ctx, hipMemcpyAsync(gathered, ctx->b_out.p, ctx->total_out, hipMemcpyDeviceToDevice, st));
+        PP_NCCLCHK(ctx, rccl().GroupStart());
+        for (int r = 1; r < world; r++)
+            if (all[(size_t)r * words]) PP_NCCLCHK(ctx, rccl().Recv(gathered + start[r], all[(size_t)r * words], ncclUint8, r, comm, st));
+        PP_NCCLCHK(ctx, rccl().GroupEnd());
+    } else if (ctx->total_out) {
+        PP_NCCLCHK(ctx, rccl().Send(ctx->b_out.p, ctx->total_out, ncclUint8, 0, comm, st));
+    }
+    PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    return PP_OK;
+}

@@ -108,6 +108,11 @@ struct pp_ctx {
     size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
 
+    // ---- multi-GPU gather (pp_comm.hip) ----
+    void *comm = nullptr;  // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    pp::DevBuf b_comm;
+
     // ---- filter job ----
     pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert;
     pp_filter_input fdev{};

@@ -87,7 +87,7 @@ __device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ c
                                          const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
                                          const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
                                          const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
-                                         const u64 *__restrict__ contig_off, u32 n_contigs,
+                                         const u64 *__restrict__ contig_off, u32 n_contigs, const u32 *__restrict__ own,
                                          u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *fast_len, u64 *status) {
     // independent loads first, then the dependent ones (clamped so that they are unconditional):
     // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
@@ -111,6 +111,10 @@ __device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ c
     } else {
         prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
     }
+    // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits is
+    // somebody else's -- validated like every record (all ranks report the same first bad record), then dropped.
+    // The untrimmed span of the fast class errs on the side of keeping.
+    if (own && nk_out && c < n_contigs && ((u64)rs + nk_out <= own[2 * c] || rs >= own[2 * c + 1])) nk_out = 0;
     gstart[a] = g_out;
     nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
 }
@@ -125,12 +129,13 @@ __global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ con
                                               const u32 *__restrict__ cigar,
                                               const u8 *__restrict__ seq,
                                               const u64 *__restrict__ contig_off, u32 n_contigs,
+                                              const u32 *__restrict__ own,
                                               u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
                                               u32 *__restrict__ maxlen, u64 *status) {
     u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 fast_len = 0;
     if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
-                        gstart, nkeep, &fast_len, status);
+                        own, gstart, nkeep, &fast_len, status);
     // Only every 64th block looks (a sample: the word merely picks the lane-group width that suits the bulk of the
     // reads -- a longer read than the sample saw simply takes the non-plain path), once per wave, and only for reads
     // beyond the narrowest group (<= 160 bases); the word is read from L2, not from a possibly stale CU-local copy.

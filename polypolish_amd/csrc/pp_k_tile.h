@@ -451,6 +451,22 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
 
+    if (A.own) {
+        // Sharded job: a window that lies inside ONE contig and outside the range of it this context emits is
+        // somebody else's (k_prep gave it no work items): nothing to tally, nothing to vote.
+        const u64 last = min(w0 + TILE, A.G) - 1;
+        const u32 c0 = find_contig(A.contig_off, A.n_contigs, w0);
+        const u64 cb = A.contig_off[c0];
+        if (last < A.contig_off[c0 + 1] && (last - cb < A.own[2 * c0] || w0 - cb >= A.own[2 * c0 + 1])) {
+            for (u32 p = tid; p < (u32)TILE && w0 + p < A.G; p += TILE_THREADS) A.code[w0 + p] = 0;
+            if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = 0;
+            if (tid == 0) {
+                A.win_nflag[w] = 0;
+                A.win_len[w] = 0;
+            }
+            return;
+        }
+    }
     for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
     {

@@ -355,11 +355,17 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     uint4 *d_entA = (uint4 *)ctx->b_entA.p, *d_entB = (uint4 *)ctx->b_entB.p;
     u32 *d_ccnt = (u32 *)ctx->b_ccnt.p, *d_coff = (u32 *)ctx->b_coff.p;
 
+    const u32 *d_own = nullptr;  // (lo, hi) per contig this context emits (pp_polish_set_emit), or everything
+    if (!ctx->emit.empty()) {
+        const void *p_own = nullptr;
+        if (int rc = upload(ctx, ctx->b_own, ctx->emit.data(), ctx->emit.size() * sizeof(uint32_t), &p_own)) return rc;
+        d_own = (const u32 *)p_own;
+    }
     if (n) {
         timer_begin(ctx, "prep");
         hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
                            B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
-                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_gstart, d_nkeep, (u32 *)(d_meta + 9), d_status);
+                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own, d_gstart, d_nkeep, (u32 *)(d_meta + 9), d_status);
         timer_end(ctx);
     }
     timer_begin(ctx, "bucket");
@@ -407,12 +413,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.maxlen = (const u32 *)(d_meta + 9);
     T.scr_need = d_meta + 10;
     T.seq_bytes = B.seq_bytes;
-    T.own = nullptr;
-    if (!ctx->emit.empty()) {
-        const void *d_own = nullptr;
-        if (int rc = upload(ctx, ctx->b_own, ctx->emit.data(), ctx->emit.size() * sizeof(uint32_t), &d_own)) return rc;
-        T.own = (const u32 *)d_own;
-    }
+    T.own = d_own;
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status;
     // PP_DEBUG_REPLAY2=1 (tests): per-position records while order-dependent positions still go through k_exact2,
@@ -706,9 +707,10 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
         delete ctx;
         return;
     }
+    pp_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *all[] = {&ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
+    DevBuf *all[] = {&ctx->b_comm, &ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,

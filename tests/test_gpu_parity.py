@@ -443,27 +443,23 @@ def test_emit_ranges_match_oracle_slices(ctx, orc):
 
 
 @pytest.mark.parametrize("world", [2, 5])
-def test_window_tiled_contig_equals_unsharded(ctx, orc, world):
-    """Config C5's partitioning with the ranks run one after the other on this GPU: windows + halos
-    through the device path, pieces concatenated, must equal the unsharded oracle output."""
-    from polypolish_amd import distributed as D
-    contig_off, bases, recs = synth.fast_records(seed=72, contig_lens=(150_000, 3_000), coverage=40,
-                                                 k_choices=(1, 2, 3, 4), indel_read_frac=0.15, n_rate=0.002)
-    units = D.plan_units(contig_off, recs, world, 4096)
-    assert (units[0] == 0).sum() >= world - 1 > 0
-    owner = D.assign_contigs(units[3], world)
-    pieces = {}
-    for rank in range(world):
-        mine, off, b, rr, emit = D.shard_units(contig_off, bases, recs, units, owner, rank)
-        if not len(mine):
-            continue
-        res = ctx.polish_records(off, b, rr, emit=emit)
-        for j, u in enumerate(mine):
-            pieces[int(u)] = res["polished"][int(res["offsets"][j]):int(res["offsets"][j + 1])]
+def test_window_tiled_contig_equals_unsharded(ctx, pp, orc, world):
+    """Config C5 in miniature on the device: every "rank" polishes the FULL record set with the emit ranges the
+    product's planner gives it (k_prep drops the records that do not reach them, k_tile skips foreign windows); the
+    ranks' bytes, put together by pp_shard_assemble, are the unsharded polish -- k = 3 shares (ordered f64 depth),
+    indels across the cuts and a second small contig included."""
+    contig_off, bases, recs = synth.fast_records(seed=61, contig_lens=(14_000, 700), coverage=40, read_len=100,
+                                                 k_choices=(1, 1, 2, 3), indel_read_frac=0.2, n_rate=0.003)
     want = orc.polish_records(contig_off, bases, recs)
-    got = [b"".join(pieces[u] for u in range(len(units[0])) if units[0][u] == c) for c in range(2)]
-    for c in range(2):
-        assert got[c] == want["polished"][int(want["offsets"][c]):int(want["offsets"][c + 1])], c
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=2), world, 2048)
+    assert (plan.unit_contig == 0).sum() == world
+    rank_bytes, rank_offs = [], []
+    for rank in range(world):
+        got = ctx.polish_records(contig_off, bases, recs, emit=plan.emit_ranges(rank))
+        rank_bytes.append(got["polished"])
+        rank_offs.append(got["offsets"])
+    data, out_off = plan.assemble(rank_bytes, rank_offs)
+    assert data == want["polished"] and np.array_equal(out_off, want["offsets"])
 
 
 def test_multi_process_driver_on_one_gpu(orc, tmp_path):
@@ -911,3 +907,41 @@ def test_batches_added_one_after_the_other_equal_one_batch(ctx, pp, orc):
     with pytest.raises(pp.PolypolishError) as e:
         ctx.polish_records(off2, bases2, recs, cuts=[5, 10])
     assert e.value.code == pp.ERR_QUIT and "does not match read sequence" in e.value.msg and "record 8" in e.value.msg, e.value
+
+
+def test_rccl_gather_through_the_library(ctx, pp, orc):
+    """pp_comm_* / pp_polish_gather with a communicator of ONE rank (all a one-GPU box can hold): librccl loads,
+    ncclCommInitRank + ncclAllGather run on the context's stream, and rank 0's buffer receives the polished bytes
+    with the per-contig offsets."""
+    import torch
+    o, b, r = synth.fast_records(seed=33, contig_lens=(20_000, 3_000), coverage=30, indel_read_frac=0.1)
+    want = orc.polish_records(o, b, r)
+    c2 = pp.Context(0)
+    try:
+        c2.comm_init(0, 1, pp.comm_unique_id())
+        got = c2.polish_records(o, b, r)
+        assert got["polished"] == want["polished"]
+        buf = torch.zeros(len(want["polished"]) + 4096, dtype=torch.uint8, device="cuda:0")
+        lens, offs = c2.gather(buf.data_ptr(), buf.numel())
+        assert int(lens[0]) == len(want["polished"]) and np.array_equal(offs[0], want["offsets"])
+        assert bytes(buf[:int(lens[0])].cpu().numpy()) == want["polished"]
+    finally:
+        c2.close()
+
+
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_shards_the_real_configs_across_ranks(tmp_path, config):
+    """bench.py --gpus 2 --config 3 / 4 (reduced size) with both ranks on this GPU: the native planner, the emit-range
+    sharding on the device and the assembly of the gathered bytes give exactly the bytes ONE GPU produces for the
+    whole job (gather_verified)."""
+    import json
+    env = dict(os.environ, PP_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT)
+    port = 35000 + os.getpid() % 2000 + config
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--config", str(config),
+                        "--genome", "3000000", "--steps", "2", "--warmup", "1"], capture_output=True, env=env, cwd=ROOT,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["gather_verified"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong", line
+    assert ("contig-shard" if config == 3 else "window-tile") in line["config"]["parallelism"]
