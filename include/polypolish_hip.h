@@ -57,6 +57,7 @@ enum { PP_ST_KEPT = 0, PP_ST_CHANGED = 1, PP_ST_LOW_DEPTH = 2, PP_ST_NONE = 3, P
 typedef struct pp_ctx pp_ctx;
 
 /* ---- context ------------------------------------------------------------------------------ */
+int pp_device_count(void);             /* usable HIP devices (0 if there is none); initialises the HIP runtime */
 int pp_ctx_create(int device, pp_ctx **out);
 /* Same, but the HIP runtime / device initialisation (a few 100 ms in a fresh process) runs on a helper
  * thread so that host-side work (pp_assembly_load, pp_ingest_sam, the host half of pp_polish_files /
@@ -366,6 +367,13 @@ void pp_bytes_free(pp_bytes *b);
 /* polish::polish (src/polish.rs:26-38): FASTA text exactly as the reference prints to stdout. */
 int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                     const pp_polish_options *opt, pp_bytes *fasta);
+
+/* polish::polish on SEVERAL GPUs from one process: the host ingest runs once, every context (one per device, see
+ * pp_ctx_create) gets the full batches and the emit ranges of its units (pp_shard_plan_create), the contexts polish
+ * side by side and the FASTA is assembled on the host.  Same bytes as pp_polish_files; --debug is not available.
+ * The error text is on ctxs[0]. */
+int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
+                          const pp_polish_options *opt, pp_bytes *fasta);
 
 /* The same ingest on the DEVICE: the raw SAM text is uploaded and tokenized by kernels
  * (newline index, field split, number / CIGAR / tag validation, contig lookup, read groups, gates, 1/k,

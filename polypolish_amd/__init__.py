@@ -109,7 +109,7 @@ class FilterFileCounts(C.Structure):
 
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
-    "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version", "pp_log_text",
+    "pp_device_count", "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version", "pp_log_text",
     "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
@@ -122,7 +122,7 @@ EXPORTS = [
     "pp_bytes_free", "pp_polish_files", "pp_filter_files", "pp_filter_polish_files", "pp_ingest_sam_filtered",
     "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_sam_filtered", "pp_dev_ingest_batch", "pp_dev_ingest_free",
     "pp_shard_plan_create", "pp_shard_plan_free", "pp_shard_emit_ranges", "pp_shard_assemble",
-    "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather",
+    "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather", "pp_polish_files_multi",
 ]
 
 _lib = None

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -103,6 +104,45 @@ static int finish(int code) {
     _exit(code);
 }
 
+// The devices `polish` runs on.  The count comes from the environment or sysfs first: asking HIP initialises the
+// runtime (a few 100 ms that the single-GPU path hides behind the host parse), so it is only asked when there may
+// be more than one GPU.
+static std::vector<int> polish_devices(int device, bool single_only) {
+    std::vector<int> one{device};
+    if (single_only || getenv("PP_DEVICE")) return one;
+    if (const char *sh = getenv("PP_SHARE_GPU")) {
+        const int n = atoi(sh);
+        return n > 1 ? std::vector<int>((size_t)n, device) : one;
+    }
+    int guess = 0;
+    const char *vis = getenv("HIP_VISIBLE_DEVICES") ? getenv("HIP_VISIBLE_DEVICES") : getenv("ROCR_VISIBLE_DEVICES");
+    if (vis && *vis) {
+        guess = 1;
+        for (const char *p = vis; *p; p++) guess += *p == ',';
+    } else {
+        for (int node = 0; node < 64; node++) {  // kfd topology: GPU nodes have SIMDs
+            char path[128];
+            snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+            FILE *f = fopen(path, "r");
+            if (!f) break;
+            char key[64];
+            unsigned long long val;
+            while (fscanf(f, "%63s %llu", key, &val) == 2)
+                if (!strcmp(key, "simd_count") && val > 0) { guess++; break; }
+            fclose(f);
+        }
+    }
+    int want = guess;
+    if (const char *g = getenv("PP_GPUS")) want = std::min(want, std::max(1, atoi(g)));
+    if (want <= 1) return one;
+    const int have = pp_device_count();
+    want = std::min(want, have);
+    if (want <= 1) return one;
+    std::vector<int> v;
+    for (int d = 0; d < want; d++) v.push_back(d);
+    return v;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         fputs(HELP, stderr);
@@ -146,6 +186,25 @@ int main(int argc, char **argv) {
             if (!assembly) assembly = a; else sams.push_back(a);
         }
         if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
+        // All visible GPUs polish (contigs / windows of a large contig shard across them) unless --debug is asked for;
+        // PP_GPUS=n limits them, PP_SHARE_GPU=n (tests on a one-GPU box) runs n contexts on the one device.
+        std::vector<int> devs = polish_devices(device, opt.debug_path != nullptr);
+        if (devs.size() > 1) {
+            std::vector<pp_ctx *> cs(devs.size(), nullptr);
+            for (size_t d = 0; d < devs.size(); d++)
+                if (pp_ctx_create_async(devs[d], &cs[d])) return no_device(devs[d]);
+            pp_bytes fasta{nullptr, 0};
+            int rc = pp_polish_files_multi(cs.data(), (int)cs.size(), assembly, sams.data(), (int)sams.size(), &opt, &fasta);
+            for (size_t d = 0; d < devs.size(); d++)
+                if (pp_ctx_wait(cs[d]) != PP_OK) return no_device(devs[d]);
+            if (rc) {
+                fprintf(stderr, "\nError: %s\n", pp_last_error(cs[0]));
+                for (pp_ctx *c : cs) pp_ctx_destroy(c);
+                return rc == PP_ERR_PANIC ? 101 : 1;
+            }
+            fwrite(fasta.data, 1, fasta.len, stdout);
+            return finish(0);
+        }
         // the device initialises on a helper thread while the host loads and parses the inputs
         pp_ctx *ctx = nullptr;
         int rc = pp_ctx_create_async(device, &ctx);

@@ -141,20 +141,41 @@ static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_
     return PP_OK;
 }
 
-extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
-                                         const pp_polish_options *opt, pp_bytes *fasta,
-                                         const uint8_t *const *pass, const uint64_t *n_pass);
+static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
+                             const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
+                             const uint64_t *n_pass);
 
-extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
-                               const pp_polish_options *opt, pp_bytes *fasta) {
-    return pp_polish_files_filtered_(ctx, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
-}
-
-// pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
 extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                                          const pp_polish_options *opt, pp_bytes *fasta,
                                          const uint8_t *const *pass, const uint64_t *n_pass) {
+    return polish_files_impl(&ctx, 1, assembly, sams, n_sams, opt, fasta, pass, n_pass);
+}
+
+extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
+                               const pp_polish_options *opt, pp_bytes *fasta) {
+    return polish_files_impl(&ctx, 1, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
+}
+
+// One process, several GPUs: the host ingest runs once, every context gets the full alignment batches and the emit
+// ranges of its units (pp_shard_plan_create), the contexts polish side by side on their own threads and their bytes
+// are put back together on the host (pp_shard_assemble) -- the FASTA has to reach host memory anyway, so each device
+// copies its own share out; the RCCL gather (pp_polish_gather) is for the one-process-per-GPU launch.
+extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams,
+                                     int n_sams, const pp_polish_options *opt, pp_bytes *fasta) {
+    if (!ctxs || n_ctx < 1) return PP_ERR_ARG;
+    for (int i = 0; i < n_ctx; i++)
+        if (!ctxs[i]) return PP_ERR_ARG;
+    return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
+}
+
+// pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
+static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
+                             const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
+                             const uint64_t *n_pass) {
+    pp_ctx *const ctx = ctxs[0];  // carries the error text
     if (!ctx || !assembly || !opt || !fasta || (n_sams > 0 && !sams)) return PP_ERR_ARG;
+    const bool multi = n_ctx > 1;
+    if (multi && opt->debug_path) return set_err(ctx, PP_ERR_ARG, "--debug needs a single GPU");
     fasta->data = nullptr;
     fasta->len = 0;
     Log log{opt->quiet != 0};
@@ -207,7 +228,7 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
     // parse) with PP_DEVICE_INGEST=0 and with --debug (the TSV needs the read bytes on the host)
     log("Loading alignments\n");
-    const bool dev_ingest = !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
+    const bool dev_ingest = !multi && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
     // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
@@ -215,11 +236,24 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
     // one after the other as well (alignment.rs:238-265).  --debug keeps ONE host batch (the TSV indexes its SEQ bytes).
     const bool stream_adds = !dev_ingest && !opt->debug_path;
     std::vector<pp_ingest *> gs;
-    std::future<int> pending;
+    std::vector<std::future<int>> pending;  // the uploads of the file before, one per context
+    std::vector<uint64_t> per_contig(nc, 0);  // alignment records per contig (the planner's weights)
     bool begun = false;
     pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
+    auto wait_pending = [&]() {
+        int r = PP_OK;
+        for (size_t i = 0; i < pending.size(); i++) {
+            const int ri = pending[i].get();
+            if (ri && !r) {
+                r = ri;
+                if (i) set_err(ctx, ri, pp_last_error(ctxs[i]));
+            }
+        }
+        pending.clear();
+        return r;
+    };
     auto free_all = [&]() {
-        if (pending.valid()) (void)pending.get();
+        (void)wait_pending();
         for (pp_ingest *x : gs) pp_ingest_free(x);
         pp_ingest_free(g);
         pp_dev_ingest_free(dg);
@@ -244,23 +278,31 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
                       : pp_ingest_sam(gi, sams[i], &c, err, sizeof err);
             if (rc) { set_err(ctx, rc, err); break; }
             if (stream_adds) {
-                if (pending.valid() && (rc = pending.get())) break;  // the upload of the file before
+                if ((rc = wait_pending())) break;  // the uploads of the file before
                 const bool first = !begun;
                 begun = true;
-                pending = std::async(std::launch::async, [ctx, gi, first, nc, off, a, prm]() {
-                    int r = first ? pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
+                if (multi) {
                     pp_aln_batch bi;
                     pp_ingest_batch(gi, &bi);
-                    if (r == PP_OK) r = pp_polish_add(ctx, &bi, PP_MEM_HOST);
-                    return r;
-                });
+                    for (uint64_t q = 0; q < bi.n_aln; q++) per_contig[bi.contig[q]]++;
+                }
+                for (int d = 0; d < n_ctx; d++) {
+                    pp_ctx *cd = ctxs[d];
+                    pending.push_back(std::async(std::launch::async, [cd, gi, first, nc, off, a, prm]() {
+                        int r = first ? pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
+                        pp_aln_batch bi;
+                        pp_ingest_batch(gi, &bi);
+                        if (r == PP_OK) r = pp_polish_add(cd, &bi, PP_MEM_HOST);
+                        return r;
+                    }));
+                }
             }
         }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
         alignment_total += c.alignments;
         used_total += c.used;
     }
-    if (rc == PP_OK && pending.valid()) rc = pending.get();
+    if (rc == PP_OK) rc = wait_pending();
     if (rc) {
         free_all();
         return rc;
@@ -287,21 +329,73 @@ extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, cons
         fputs("name\tpos\tbase\tdepth\tinvalid\tvalid\tpileup\tstatus\tnew_base\n", dbg);
     }
     pp_polish_set_debug(ctx, dbg ? 1 : 0);
-    if (!begun) {  // one batch (device tokenizer, --debug), or no SAM files at all
-        rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
-        if (rc == PP_OK && (dev_ingest || g)) rc = pp_polish_add(ctx, &batch, dev_ingest ? PP_MEM_DEVICE : PP_MEM_HOST);
-    }
-    if (rc == PP_OK) rc = pp_polish_finish(ctx);
-    lap("uploaded + polished on device");
-    if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
-    if (dbg) fclose(dbg);
-    pp_polish_set_debug(ctx, 0);
     uint64_t total = 0;
-    if (rc == PP_OK) rc = pp_polish_result_size(ctx, &total);
-    std::vector<uint8_t> polished(total ? total : 1);
+    std::vector<uint8_t> polished(1);
     std::vector<uint64_t> out_off(nc + 1);
     std::vector<pp_contig_stats> stats(nc);
-    if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
+    if (!multi) {
+        if (!begun) {  // one batch (device tokenizer, --debug), or no SAM files at all
+            rc = pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+            if (rc == PP_OK && (dev_ingest || g)) rc = pp_polish_add(ctx, &batch, dev_ingest ? PP_MEM_DEVICE : PP_MEM_HOST);
+        }
+        if (rc == PP_OK) rc = pp_polish_finish(ctx);
+        lap("uploaded + polished on device");
+        if (rc == PP_OK && dbg) rc = write_debug_tsv(ctx, dbg, a, &batch);
+        if (dbg) fclose(dbg);
+        pp_polish_set_debug(ctx, 0);
+        if (rc == PP_OK) rc = pp_polish_result_size(ctx, &total);
+        polished.resize(total ? total : 1);
+        if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
+    } else {
+        // every context: the ranges of its units, finish, its own bytes to the host -- side by side
+        pp_shard_plan *plan = nullptr;
+        rc = pp_shard_plan_create(nc, off, per_contig.data(), (uint32_t)n_ctx, 0, &plan);
+        std::vector<std::vector<uint8_t>> r_bytes(n_ctx);
+        std::vector<std::vector<uint64_t>> r_off(n_ctx, std::vector<uint64_t>(nc + 1, 0));
+        std::vector<std::vector<pp_contig_stats>> r_stats(n_ctx, std::vector<pp_contig_stats>(nc));
+        std::vector<std::future<int>> jobs;
+        for (int d = 0; rc == PP_OK && d < n_ctx; d++) {
+            jobs.push_back(std::async(std::launch::async, [&, d]() {
+                pp_ctx *cd = ctxs[d];
+                int r = begun ? PP_OK : pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+                std::vector<uint64_t> lo(nc), hi(nc);
+                if (r == PP_OK) r = pp_shard_emit_ranges(plan, (uint32_t)d, lo.data(), hi.data());
+                if (r == PP_OK) r = pp_polish_set_emit(cd, lo.data(), hi.data());
+                if (r == PP_OK) r = pp_polish_finish(cd);
+                uint64_t t = 0;
+                if (r == PP_OK) r = pp_polish_result_size(cd, &t);
+                r_bytes[d].resize(t ? t : 1);
+                if (r == PP_OK) r = pp_polish_result(cd, r_bytes[d].data(), PP_MEM_HOST, r_off[d].data(), r_stats[d].data());
+                return r;
+            }));
+        }
+        for (size_t d = 0; d < jobs.size(); d++) {
+            const int rd = jobs[d].get();
+            if (rd && !rc) {
+                rc = rd;
+                if (d) set_err(ctx, rd, pp_last_error(ctxs[d]));
+            }
+        }
+        lap("uploaded + polished on the devices");
+        if (rc == PP_OK) {
+            std::vector<const uint8_t *> bp(n_ctx);
+            std::vector<const uint64_t *> op(n_ctx);
+            for (int d = 0; d < n_ctx; d++) { bp[d] = r_bytes[d].data(); op[d] = r_off[d].data(); }
+            rc = pp_shard_assemble(plan, bp.data(), op.data(), nullptr, out_off.data());
+            total = out_off[nc];
+            polished.resize(total ? total : 1);
+            if (rc == PP_OK) rc = pp_shard_assemble(plan, bp.data(), op.data(), polished.data(), out_off.data());
+            for (uint32_t c = 0; c < nc; c++) {  // a position is counted by the rank that emits it
+                stats[c] = pp_contig_stats{out_off[c + 1] - out_off[c], 0, 0, 0.0};
+                for (int d = 0; d < n_ctx; d++) {
+                    stats[c].changed += r_stats[d][c].changed;
+                    stats[c].zero_depth += r_stats[d][c].zero_depth;
+                    stats[c].depth_sum += r_stats[d][c].depth_sum;
+                }
+            }
+        }
+        pp_shard_plan_free(plan);
+    }
     if (rc) {
         free_all();
         return rc;

@@ -657,6 +657,11 @@ static int device_init(pp_ctx *ctx) {
     return PP_OK;
 }
 
+extern "C" int pp_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 extern "C" int pp_ctx_create(int device, pp_ctx **out) {
     if (!out) return PP_ERR_ARG;
     *out = nullptr;

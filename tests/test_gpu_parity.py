@@ -945,3 +945,22 @@ def test_bench_shards_the_real_configs_across_ranks(tmp_path, config):
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert line["gather_verified"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong", line
     assert ("contig-shard" if config == 3 else "window-tile") in line["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_cli_polishes_on_several_contexts_in_one_process(orc, tmp_path, n_ctx):
+    """bin/polypolish polish with PP_SHARE_GPU=n: n contexts (here all on this GPU, on a multi-GPU box one per device)
+    get the full batches of both SAM files and the emit ranges of their units; the assembled FASTA and the per-contig
+    figures of the log are those of the single-context run / the oracle."""
+    ds = synth.rich_dataset(str(tmp_path), seed=83, contig_lens=(140_000, 900, 2_000, 30_000), coverage=12, repeat_len=300,
+                            repeat_copies=3)
+    sams = [ds["sam1"], ds["sam2"]]
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    multi = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, PP_SHARE_GPU=str(n_ctx)),
+                           timeout=600)
+    single = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, PP_DEVICE="0"),
+                            timeout=600)
+    assert multi.returncode == 0, multi.stderr.decode()[-2000:]
+    assert multi.stdout == orc.polish_files(ds["fasta"], sams)["fasta"] == single.stdout
+    stat = lambda err: [l for l in err.decode().splitlines() if "changed" in l or "depth of zero" in l or "mean read depth" in l]
+    assert stat(multi.stderr) == stat(single.stderr) and len(stat(multi.stderr)) == 12
