@@ -11,6 +11,7 @@
 // through a lock-free open-addressing table (the reference's HashMap<String, Vec<Alignment>>, keyed by
 // name + "_1"/"_2", becomes a read number shared by both files plus a per-file group index), and the
 // output is formatted per slice and written with pwrite.  Results do not depend on the thread count.
+#include <sys/stat.h>
 #include <sys/uio.h>
 
 #include <algorithm>
@@ -246,8 +247,12 @@ struct NameTable {
         const uint32_t n16 = (uint32_t)(b >> 48);
         if (n16 != std::min<uint32_t>(r->name_n, 0xFFFFu)) return false;
         const char *q = (const char *)(uintptr_t)(b & 0xFFFFFFFFFFFFull);
-        if (memcmp(q, r->name, r->name_n) != 0) return false;
-        return n16 < 0xFFFFu || q[r->name_n] == '\t';
+        if (n16 < 0xFFFFu) return memcmp(q, r->name, n16) == 0;  // equal lengths: n16 bytes exist on both sides
+        // saturated length: the stored name may be SHORTER than r's -- compare byte by byte and stop at its tab, so that
+        // nothing past its line (or past the mapping, for the last line) is read
+        for (uint32_t i = 0; i < r->name_n; i++)
+            if (q[i] != r->name[i] || q[i] == '\t') return false;
+        return q[r->name_n] == '\t';
     }
     static uint64_t wait_b(const Slot &S) {  // the claimer publishes B right after winning A
         uint64_t b;
@@ -574,31 +579,41 @@ extern "C" int pp_filter_write(const pp_filter_loaded *L, int f, const uint8_t *
     });
     for (unsigned t = 0; t < threads; t++) out_first[t + 1] += out_first[t];
     std::atomic<int> bad{0};
-    parallel_for(threads, threads, [&](size_t lo_t, size_t hi_t, unsigned) {
-        for (size_t t = lo_t; t < hi_t; t++) {
-            const Slice &S = X.slices[t];
-            const uint64_t bytes = out_first[t + 1] - out_first[t];
-            if (!bytes) continue;
-            HugeBuf<char> buf;
-            buf.resize(bytes);
-            char *w = buf.data();
-            for (size_t i = 0; i < S.lines.size(); i++) {
-                memcpy(w, X.text.text + S.lines[i].off, S.lines[i].len);
-                w += S.lines[i].len;
-                if (S.lines[i].aln >= 0 && !pass_f[X.aln_first[t] + (size_t)S.lines[i].aln]) {
-                    memcpy(w, "\tZP:Z:fail", 10);
-                    w += 10;
-                }
-                *w++ = '\n';
+    // A pipe, /dev/stdout or a process substitution cannot be written at offsets (ESPIPE): there the slices are
+    // formatted and written one after the other, as the reference's buffered writer streams them (src/filter.rs:305-306).
+    struct stat st_out;
+    const bool seekable = fstat(fd, &st_out) == 0 && S_ISREG(st_out.st_mode);
+    auto write_slice = [&](size_t t) {
+        const Slice &S = X.slices[t];
+        const uint64_t bytes = out_first[t + 1] - out_first[t];
+        if (!bytes) return;
+        HugeBuf<char> buf;
+        buf.resize(bytes);
+        char *w = buf.data();
+        for (size_t i = 0; i < S.lines.size(); i++) {
+            memcpy(w, X.text.text + S.lines[i].off, S.lines[i].len);
+            w += S.lines[i].len;
+            if (S.lines[i].aln >= 0 && !pass_f[X.aln_first[t] + (size_t)S.lines[i].aln]) {
+                memcpy(w, "\tZP:Z:fail", 10);
+                w += 10;
             }
-            uint64_t done = 0;
-            while (done < bytes) {
-                const ssize_t r = pwrite(fd, buf.data() + done, bytes - done, (off_t)(out_first[t] + done));
-                if (r <= 0) { bad = 1; break; }
-                done += (uint64_t)r;
-            }
+            *w++ = '\n';
         }
-    });
+        uint64_t done = 0;
+        while (done < bytes) {
+            const ssize_t r = seekable ? pwrite(fd, buf.data() + done, bytes - done, (off_t)(out_first[t] + done))
+                                       : write(fd, buf.data() + done, bytes - done);
+            if (r <= 0) { bad = 1; break; }
+            done += (uint64_t)r;
+        }
+    };
+    if (!seekable) {
+        for (size_t t = 0; t < threads && !bad; t++) write_slice(t);
+    } else {
+        parallel_for(threads, threads, [&](size_t lo_t, size_t hi_t, unsigned) {
+            for (size_t t = lo_t; t < hi_t; t++) write_slice(t);
+        });
+    }
     if (close(fd) != 0 || bad) return write_failed();
     uint64_t p_ = 0, f_ = 0;
     for (unsigned t = 0; t < threads; t++) { p_ += n_pass[t]; f_ += n_fail[t]; }
@@ -710,6 +725,25 @@ static int write_text_fd(const char *text, uint64_t size, const uint8_t *pass, u
     });
     for (unsigned t = 0; t < threads; t++) off[t + 1] += off[t];
     std::atomic<int> bad{0};
+    // A pipe, /dev/stdout or a process substitution cannot be written at offsets (ESPIPE): there the slices go out
+    // one after the other with writev, as the reference's buffered writer would stream them (src/filter.rs:305-306).
+    struct stat st_out;
+    const bool seekable = fstat(fd, &st_out) == 0 && S_ISREG(st_out.st_mode);
+    if (!seekable) {
+        for (unsigned t = 0; t < threads && !bad; t++) {
+            std::vector<struct iovec> &V = iov[t];
+            size_t i = 0;
+            while (i < V.size()) {
+                const int cnt = (int)std::min<size_t>(1024, V.size() - i);
+                ssize_t r = writev(fd, &V[i], cnt);
+                if (r <= 0) { bad = 1; break; }
+                while (r > 0 && i < V.size()) {
+                    if ((size_t)r >= V[i].iov_len) { r -= (ssize_t)V[i].iov_len; i++; }
+                    else { V[i].iov_base = (char *)V[i].iov_base + r; V[i].iov_len -= (size_t)r; r = 0; }
+                }
+            }
+        }
+    } else
     parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
         for (size_t t = lo; t < hi; t++) {
             std::vector<struct iovec> &V = iov[t];

@@ -544,9 +544,10 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         v.status = PP_ST_LOW_DEPTH;
         v.vthr = 0; v.ithr = 0;
         if (nd) {
-            // depth is an order-dependent f64 sum: exact only in k_exact.  depth <= ntot always,
-            // so ntot < min_depth already decides DepthTooLow.
-            if (ntot >= A.min_depth || A.dbg) flag = true;
+            // depth is an order-dependent f64 sum: exact only in the replay kernels.  depth <= ntot always, so
+            // ntot < min_depth already decides DepthTooLow -- but the depth itself feeds the contig's mean read
+            // depth (polish.rs:173-180), and the integer tallies would count every 1/k share as 1: replay those too.
+            if (ntot > 0 || A.dbg) flag = true;
         } else {
             const u32 ithr = d_bankers(__dmul_rn(depth, A.fi));
             if (!(depth < (double)A.min_depth) && nOth > 0 && nOth >= ithr) flag = true;

@@ -47,6 +47,10 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
     for c in range(len(off) - 1):
         assert got["stats"][c]["changed"] == int((st[off[c]:off[c + 1]] == 1).sum())
         assert got["stats"][c]["zero_depth"] == int((want["positions"]["depth"][off[c]:off[c + 1]] == 0.0).sum())
+        # the contig's depth sum (mean read depth of the log, polish.rs:173-180,206-227): shares 1/2^j are summed exactly,
+        # other shares through the ordered replay, each position rounded to 2^-10
+        dsum = float(want["positions"]["depth"][off[c]:off[c + 1]].sum())
+        assert abs(got["stats"][c]["depth_sum"] - dsum) <= (off[c + 1] - off[c]) * 2.0 ** -11 + 1e-6 * dsum, (c, got["stats"][c], dsum)
     # without the per-position debug planes the same bytes must come out (different flagging rule)
     plain = ctx.polish_records(contig_off, bases, recs, positions=False, **kw)
     assert plain["polished"] == want["polished"]

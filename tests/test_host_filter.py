@@ -241,3 +241,48 @@ def test_write_text_equals_the_loaded_writer(tmp_path, monkeypatch):
             L.close()
     rc = pp.lib().pp_filter_write_text(raw, len(raw), verdicts.ctypes.data, n - 1, str(tmp_path / "got.sam").encode(), None, None, err, 600)
     assert rc == pp.ERR_ARG
+
+
+def test_tagged_output_into_a_pipe(tmp_path, monkeypatch):
+    """--out1/--out2 may be a FIFO or /dev/stdout (the reference streams through a BufWriter, src/filter.rs:305-306):
+    positional writes are impossible there, the slices go out in order -- same bytes as into a regular file; and a
+    QNAME of more than 65535 bytes (its length saturates in the name table) is interned and written like any other."""
+    import ctypes
+    import threading
+    rng = np.random.default_rng(11)
+    long_a, long_b = "L" * 70000, "L" * 70000 + "x"
+    lines = ["@SQ\tSN:c\tLN:100"]
+    for i in range(3000):
+        name = long_a if i == 100 else (long_b if i == 101 else f"r{i}")
+        lines.append(f"{name}\t{16 if i % 3 == 0 else 0}\tc\t{1 + i % 90}\t60\t4M\t*\t0\t0\tACGT\t*\tNM:i:0")
+    p = tmp_path / "in.sam"
+    p.write_bytes(("\n".join(lines) + "\n").encode())
+    other = tmp_path / "other.sam"
+    other.write_text(_line("zz", 0, "c", 1, "4M") + _line(long_b, 0, "c", 5, "4M") + _line(long_a, 0, "c", 9, "4M"))
+    for t in ("1", "5"):
+        monkeypatch.setenv("PP_INGEST_THREADS", t)
+        L = pp.FilterLoaded(str(p), str(other))
+        n = L.counts[0][0]
+        assert L.counts[0] == (3000, 3000) and L.counts[1] == (3, 3), "the two long names are different reads"
+        verdicts = (rng.random(n) < 0.6).astype(np.uint8)
+        want_counts = L.write(0, verdicts, tmp_path / "want.sam")
+        fifo = str(tmp_path / f"out{t}.fifo")
+        os.mkfifo(fifo)
+        got = {}
+        reader = threading.Thread(target=lambda: got.setdefault("bytes", open(fifo, "rb").read()))
+        reader.start()
+        assert L.write(0, verdicts, fifo) == want_counts
+        reader.join(60)
+        assert got["bytes"] == (tmp_path / "want.sam").read_bytes()
+        # the splicing writer (pp_filter_write_text, what the CLI uses) into a pipe as well
+        fifo2 = str(tmp_path / f"out{t}_text.fifo")
+        os.mkfifo(fifo2)
+        got2 = {}
+        reader = threading.Thread(target=lambda: got2.setdefault("bytes", open(fifo2, "rb").read()))
+        reader.start()
+        raw = p.read_bytes()
+        err = ctypes.create_string_buffer(600)
+        rc = pp.lib().pp_filter_write_text(raw, len(raw), verdicts.ctypes.data, n, fifo2.encode(), None, None, err, 600)
+        reader.join(60)
+        assert rc == 0 and got2["bytes"] == (tmp_path / "want.sam").read_bytes(), err.value
+        L.close()
