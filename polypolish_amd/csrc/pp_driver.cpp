@@ -143,7 +143,10 @@ static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_
 
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
-                             const uint64_t *n_pass);
+                             const uint64_t *n_pass, bool host_ingest_only = false);
+extern "C" int pp_ingest_fail_cut_(const pp_ingest *I, uint64_t *cut);
+extern "C" int pp_ingest_sam_prefix_(pp_ingest *I, const char *path, uint64_t cut, const uint8_t *pass, uint64_t n_pass,
+                                     pp_sam_counts *counts, char *err, size_t errlen);
 
 extern "C" int pp_polish_files_filtered_(pp_ctx *ctx, const char *assembly, const char *const *sams, int n_sams,
                                          const pp_polish_options *opt, pp_bytes *fasta,
@@ -171,14 +174,14 @@ extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char 
 // pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
-                             const uint64_t *n_pass) {
+                             const uint64_t *n_pass, bool host_ingest_only) {
     pp_ctx *const ctx = ctxs[0];  // carries the error text
     if (!ctx || !assembly || !opt || !fasta || (n_sams > 0 && !sams)) return PP_ERR_ARG;
     const bool multi = n_ctx > 1;
     if (multi && opt->debug_path) return set_err(ctx, PP_ERR_ARG, "--debug needs a single GPU");
     fasta->data = nullptr;
     fasta->len = 0;
-    Log log{opt->quiet != 0};
+    Log log{opt->quiet != 0 || host_ingest_only};  // (the second look at a failing input does not log twice)
     auto t0 = std::chrono::steady_clock::now();
     char err[1024] = "";
 
@@ -228,7 +231,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
     // parse) with PP_DEVICE_INGEST=0 and with --debug (the TSV needs the read bytes on the host)
     log("Loading alignments\n");
-    const bool dev_ingest = !multi && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
+    const bool dev_ingest = !multi && !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
     // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
@@ -266,6 +269,12 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         pp_sam_counts c;
         if (dev_ingest) {
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
+            if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC) {
+                // A defect in the text.  Which defect the reference reports FIRST also depends on what its CIGAR walk
+                // makes of the records before it: the host ingest works that out (below), on this rare path.
+                free_all();
+                return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, pass, n_pass, true);
+            }
             if (rc) break;
         } else {
             pp_ingest *gi = g;
@@ -276,7 +285,37 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             }
             rc = pass ? pp_ingest_sam_filtered(gi, sams[i], pass[i], n_pass[i], &c, err, sizeof err)
                       : pp_ingest_sam(gi, sams[i], &c, err, sizeof err);
-            if (rc) { set_err(ctx, rc, err); break; }
+            if (rc) {
+                set_err(ctx, rc, err);
+                // The reference streams: every read group before the failing point had already gone through
+                // add_alignment (alignment.rs:297-303), so a record there that only the CIGAR walk rejects (unexpected
+                // op, CIGAR / SEQ length mismatch, past the contig end) is what it reports.  Run the device over exactly
+                // those records: the earlier files and this file up to the group that was pending.
+                uint64_t cut = 0;
+                if (pp_ingest_fail_cut_(gi, &cut) && wait_pending() == PP_OK) {
+                    int rd = begun ? PP_OK : pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+                    begun = true;
+                    pp_aln_batch bi;
+                    if (rd == PP_OK && !stream_adds && g) {
+                        pp_ingest_batch(g, &bi);
+                        if (bi.n_aln) rd = pp_polish_add(ctx, &bi, PP_MEM_HOST);
+                    }
+                    pp_ingest *gp = nullptr;
+                    char err2[256];
+                    pp_sam_counts c2;
+                    if (rd == PP_OK && cut > 0 && pp_ingest_create(a, opt->max_errors, opt->careful, &gp) == PP_OK &&
+                        pp_ingest_sam_prefix_(gp, sams[i], cut, pass ? pass[i] : nullptr, pass ? n_pass[i] : 0, &c2, err2,
+                                              sizeof err2) == PP_OK) {
+                        pp_ingest_batch(gp, &bi);
+                        if (bi.n_aln) rd = pp_polish_add(ctx, &bi, PP_MEM_HOST);
+                    }
+                    if (rd == PP_OK) rd = pp_polish_finish(ctx);
+                    pp_ingest_free(gp);
+                    if (rd == PP_ERR_QUIT || rd == PP_ERR_PANIC) rc = rd;  // the device's message stands
+                    else set_err(ctx, rc, err);
+                }
+                break;
+            }
             if (stream_adds) {
                 if ((rc = wait_pending())) break;  // the uploads of the file before
                 const bool first = !begun;

@@ -232,6 +232,11 @@ struct pp_ingest {
     HugeBuf<uint8_t> seq;
     HugeBuf<char> names;  // NUL-separated QNAMEs, one per record
     std::vector<std::thread> reapers;  // parse-time memory of finished files being released in the background
+    // After a failed pp_ingest_sam: the byte offset in that file of the first line of the read group that was pending
+    // when the reference's streaming loop would have stopped -- everything before it HAD been handed to the pileup
+    // (alignment.rs:238-303), so a defect only the CIGAR walk finds there comes first (pp_driver.cpp).
+    uint64_t fail_cut = 0;
+    bool fail_has_cut = false;
     ~pp_ingest() {
         for (auto &t : reapers) t.join();
     }
@@ -395,7 +400,8 @@ extern "C" int pp_ingest_sam(pp_ingest *I, const char *path, pp_sam_counts *coun
 }
 
 static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, size_t ext_size, uint64_t line_base,
-                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen);
+                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen,
+                       uint64_t prefix_bytes = ~0ull);
 
 extern "C" int pp_ingest_sam_filtered(pp_ingest *I, const char *path, const uint8_t *pass, uint64_t n_pass,
                                       pp_sam_counts *counts, char *err, size_t errlen) {
@@ -411,9 +417,27 @@ extern "C" int pp_ingest_text_(pp_ingest *I, const char *path, const char *text,
     return ingest_impl(I, path, text, size, line_base, nullptr, 0, counts, err, errlen);
 }
 
+// Internal (pp_driver.cpp, error path): was the failure of the last pp_ingest_sam somewhere the records before it are
+// known?  *cut = bytes of the file that hold exactly the read groups the reference had processed by then.
+extern "C" int pp_ingest_fail_cut_(const pp_ingest *I, uint64_t *cut) {
+    if (!I || !cut || !I->fail_has_cut) return 0;
+    *cut = I->fail_cut;
+    return 1;
+}
+
+// Internal: ingest only the first `cut` bytes of the file (whole read groups by construction; none at all is fine).
+extern "C" int pp_ingest_sam_prefix_(pp_ingest *I, const char *path, uint64_t cut, const uint8_t *pass, uint64_t n_pass,
+                                     pp_sam_counts *counts, char *err, size_t errlen) {
+    if (!I || !path) return PP_ERR_ARG;
+    return ingest_impl(I, path, nullptr, 0, 0, pass, n_pass, counts, err, errlen, cut);
+}
+
 static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, size_t ext_size, uint64_t line_base,
-                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen) {
+                       const uint8_t *pass, uint64_t n_pass, pp_sam_counts *counts, char *err, size_t errlen,
+                       uint64_t prefix_bytes) {
     pp_sam_counts c{0, 0, 0};
+    const bool prefix_mode = prefix_bytes != ~0ull;
+    I->fail_has_cut = false;
     int fd = -1;
     void *map = nullptr;
     size_t map_len = 0;
@@ -445,6 +469,8 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             text = fallback.data();
             size = fallback.size();
         }
+        if (prefix_mode) size = std::min<size_t>(size, (size_t)prefix_bytes);
+        const bool regular_input = ext_text == nullptr && map != nullptr;  // a file that can be read again (not a pipe)
         const bool timing = getenv("PP_TIMING") != nullptr;
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
@@ -508,7 +534,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             }
         });
         lap("flatten");
-        if (pass && n_chunks_ok == threads && n_pass != total_recs)
+        if (pass && !prefix_mode && n_chunks_ok == threads && n_pass != total_recs)
             fail(PP_ERR_ARG, "%llu filter verdicts for the %llu aligned records of \"%s\"", (unsigned long long)n_pass,
                  (unsigned long long)total_recs, path);
         const bool parse_failed = n_chunks_ok < threads;  // the group pending at the failing line is never processed
@@ -520,6 +546,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
         struct Part {
             HugeBuf<OutRec> outs;
             uint64_t reads = 0, used = 0, seq_sum = 0, cig_sum = 0, nam_sum = 0;
+            size_t cur_g0 = 0;  // first record of the group being processed (where a failure leaves off)
             int err_code = 0;
             std::string err_msg;
         };
@@ -570,6 +597,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                     size_t j = i + 1;
                     while (j < total_recs && !is_start(j)) j++;
                     if (j == total_recs && parse_failed) break;
+                    P.cur_g0 = i;
                     process_one_read(P, i, j);
                     P.reads++;
                     i = j;
@@ -583,7 +611,24 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
         for (const Part &P : parts) {  // parts are in file order: the first failing group is the one the reference hits
             c.reads += P.reads;
             c.used += P.used;
-            if (P.err_code) throw IngestError{P.err_code, P.err_msg};
+            if (P.err_code) {
+                if (regular_input) {  // every group before the failing one had been processed
+                    I->fail_cut = (uint64_t)(all[P.cur_g0]->name - text);
+                    I->fail_has_cut = true;
+                }
+                throw IngestError{P.err_code, P.err_msg};
+            }
+        }
+        if (parse_failed && regular_input) {  // ... and so had every group before the one pending at the failing line
+            size_t i = total_recs;
+            if (i) {
+                i--;
+                while (i > 0 && !is_start(i)) i--;
+                I->fail_cut = (uint64_t)(all[i]->name - text);
+            } else {
+                I->fail_cut = 0;
+            }
+            I->fail_has_cut = true;
         }
         if (parse_failed) {  // the streaming loop would have stopped at the failing line
             const Chunk &ch = chunks[n_chunks_ok];
@@ -591,6 +636,11 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             for (size_t u = 0; u < n_chunks_ok; u++) line_no += chunks[u].n_lines;
             if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
             fail(ch.err_code, "%s", ch.err_what.c_str());
+        }
+        if (total_recs == 0 && prefix_mode) {  // nothing had been processed before the failure
+            cleanup();
+            if (counts) *counts = c;
+            return PP_OK;
         }
         if (total_recs == 0)  // process_one_read on an empty group after the loop (alignment.rs:268)
             fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");

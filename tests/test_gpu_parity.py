@@ -968,3 +968,47 @@ def test_cli_polishes_on_several_contexts_in_one_process(orc, tmp_path, n_ctx):
     assert multi.stdout == orc.polish_files(ds["fasta"], sams)["fasta"] == single.stdout
     stat = lambda err: [l for l in err.decode().splitlines() if "changed" in l or "depth of zero" in l or "mean read depth" in l]
     assert stat(multi.stderr) == stat(single.stderr) and len(stat(multi.stderr)) == 12
+
+
+def test_two_defects_are_reported_in_streaming_order(orc, tmp_path):
+    """A file with TWO independent defects: one that only the CIGAR walk finds (the device: an N run inside the CIGAR, a
+    CIGAR shorter than SEQ) and one the parse finds (too few columns, a missing NM tag).  The reference streams and
+    stops at whichever comes first -- with the read group that is still pending at a failing line NOT yet processed
+    (alignment.rs:238-303).  Exit code and the kind of message must be the oracle's, with either ingest, also when
+    the two defects sit in different SAM files."""
+    ref = "ACGGTCATTGCAACGGTTATTGCAGGCTTAACGTAGCTAGGCTTAGCATCGATCAGGCTAACGTTAGCCTAGAT" * 4
+    fa = tmp_path / "a.fasta"
+    fa.write_text(">c\n" + ref + "\n")
+
+    def line(name, pos, cigar, n, tags="NM:i:0"):
+        return f"{name}\t0\tc\t{pos}\t60\t{cigar}\t*\t0\t0\t{ref[pos - 1:pos - 1 + n]}\t*\t{tags}\n"
+    good = [line(f"g{i}", 1 + 3 * i, "40M", 40) for i in range(30)]
+    walk_bad = line("w", 5, "10M4N26M", 36)        # passes the gates (M at both ends), the walk rejects the N
+    walk_bad2 = line("w2", 7, "39M", 40)            # CIGAR does not match SEQ
+    parse_bad = "p\t0\tc\t9\t60\t40M\n"             # too few columns
+    parse_bad2 = line("p2", 11, "40M", 40, tags="XS:i:1")   # aligned but no NM tag
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    orc_exe = os.path.join(ROOT, "oracle", "_build", "pp_oracle")
+    cases = {
+        "walk_then_parse": [good[:10] + [walk_bad] + good[10:20] + [parse_bad] + good[20:]],
+        "parse_then_walk": [good[:10] + [parse_bad] + good[10:20] + [walk_bad] + good[20:]],
+        "walk_in_the_pending_group": [good[:10] + [walk_bad, parse_bad2] + good[10:]],   # w is pending when p2 fails
+        "walk_flushed_by_the_failing_line": [good[:10] + [walk_bad2, good[10], parse_bad] + good[11:]],
+        "walk_in_file_1_parse_in_file_2": [good[:10] + [walk_bad] + good[10:], good[:5] + [parse_bad2] + good[5:]],
+        "parse_in_file_1_walk_in_file_2": [good[:10] + [parse_bad] + good[10:], good[:5] + [walk_bad] + good[5:]],
+    }
+    kinds = (b"unexpected character", b"does not match read sequence", b"too few columns", b"missing NM tag")
+    for name, files in cases.items():
+        paths = []
+        for i, lines in enumerate(files):
+            p = tmp_path / f"{name}_{i}.sam"
+            p.write_text("@SQ\tSN:c\tLN:%d\n" % len(ref) + "".join(lines))
+            paths.append(str(p))
+        want = subprocess.run([orc_exe, "polish", str(fa)] + paths, capture_output=True)
+        assert want.returncode != 0, name
+        want_kind = [k for k in kinds if k in want.stderr]
+        assert len(want_kind) == 1, (name, want.stderr)
+        for ingest in ("1", "0"):
+            got = subprocess.run([exe, "polish", str(fa)] + paths, capture_output=True, env=dict(os.environ, PP_DEVICE_INGEST=ingest))
+            assert got.returncode == want.returncode and got.stdout == b"", (name, ingest, got.stderr)
+            assert want_kind[0] in got.stderr, (name, ingest, want.stderr, got.stderr)
