@@ -396,8 +396,21 @@ def end_to_end(device, genome, coverage, seed, keep_dir=None):
         f1, f2 = os.path.join(tmp, "f_1.sam"), os.path.join(tmp, "f_2.sam")
         t = time.perf_counter()
         ra = subprocess.run([orc_exe, "filter", "--in1", sams[0], "--in2", sams[1], "--out1", f1, "--out2", f2], capture_output=True)
+        t_orc_filter = time.perf_counter() - t
         rb = subprocess.run([orc_exe, "polish", fa, f1, f2], capture_output=True)
         t_chain = time.perf_counter() - t
+        # `filter` on its own: two tagged SAM files out (reference contract: src/filter.rs:26-37, 309-349)
+        g1, g2 = os.path.join(tmp, "g_1.sam"), os.path.join(tmp, "g_2.sam")
+        t_f, r_f = _timed([exe, "filter", "--in1", sams[0], "--in2", sams[1], "--out1", g1, "--out2", g2], env, repeat=2)
+        if t_f is not None and ra.returncode == 0:
+            def file_sha(path):
+                h = hashlib.sha256()
+                with open(path, "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        h.update(blk)
+                return h.hexdigest()
+            out["filter"] = {"wall_s": round(t_f, 3), "parity": file_sha(g1) == file_sha(f1) and file_sha(g2) == file_sha(f2),
+                             "oracle_wall_s": round(t_orc_filter, 2), "speedup": round(t_orc_filter / t_f, 1)}
         if t_fp is None or ra.returncode or rb.returncode:
             out["filter_polish"] = {"error": (r_fp.stderr if t_fp is None else (ra.stderr + rb.stderr)).decode(errors="replace")[-400:]}
         else:
@@ -405,7 +418,7 @@ def end_to_end(device, genome, coverage, seed, keep_dir=None):
                                     "parity": sha(r_fp.stdout) == sha(rb.stdout),
                                     "oracle_chain_wall_s": round(t_chain, 2), "speedup": round(t_chain / t_fp, 1)}
         out["parity"] = bool(out["polish"]["parity"] and out["polish_host_ingest"]["parity"] and
-                             out.get("filter_polish", {}).get("parity", False))
+                             out.get("filter_polish", {}).get("parity", False) and out.get("filter", {}).get("parity", False))
     finally:
         if keep_dir is None:
             for p in os.listdir(tmp):

@@ -142,6 +142,8 @@ int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *contig_off,
  * (a job's ONLY batch is used in place; with more than one batch everything is gathered into library-owned arrays
  * with device-to-device copies on the context's stream).  Limits per job: < 2^32-1 records, < 2^40 SEQ bytes. */
 int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *batch, int mem);
+/* Optional, after pp_polish_begin: room for everything the job's batches will hold together (a guess is fine). */
+int pp_polish_reserve(pp_ctx *ctx, uint64_t n_aln, uint64_t seq_bytes, uint64_t n_cig_total);
 /* Run the kernels: CIGAR walk + homopolymer trim (src/alignment.rs:175-201,364-378), pileup
  * accumulation (src/pileup.rs:56-65,189-200), vote (src/pileup.rs:67-134), '-' removal and
  * concatenation (src/polish.rs:185-188).  Results stay on the device until fetched. */

@@ -110,7 +110,7 @@ class FilterFileCounts(C.Structure):
 # every symbol include/polypolish_hip.h declares (tests check that the library exports them all)
 EXPORTS = [
     "pp_device_count", "pp_ctx_create", "pp_ctx_create_async", "pp_ctx_wait", "pp_ctx_destroy", "pp_last_error", "pp_ctx_sync", "pp_ctx_stream", "pp_ctx_download", "pp_version", "pp_log_text",
-    "pp_polish_begin", "pp_polish_add", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
+    "pp_polish_begin", "pp_polish_add", "pp_polish_reserve", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
     "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",

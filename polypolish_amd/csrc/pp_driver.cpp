@@ -237,7 +237,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
     // (pp_polish_begin + pp_polish_add on a helper thread) while file i+1 is parsed -- the reference streams its files
     // one after the other as well (alignment.rs:238-265).  --debug keeps ONE host batch (the TSV indexes its SEQ bytes).
-    const bool stream_adds = !dev_ingest && !opt->debug_path;
+    const bool stream_adds = !dev_ingest && !opt->debug_path && (multi || !(getenv("PP_STREAM_ADDS") && atoi(getenv("PP_STREAM_ADDS")) == 0));
     std::vector<pp_ingest *> gs;
     std::vector<std::future<int>> pending;  // the uploads of the file before, one per context
     std::vector<uint64_t> per_contig(nc, 0);  // alignment records per contig (the planner's weights)
@@ -327,10 +327,22 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                 }
                 for (int d = 0; d < n_ctx; d++) {
                     pp_ctx *cd = ctxs[d];
-                    pending.push_back(std::async(std::launch::async, [cd, gi, first, nc, off, a, prm]() {
+                    // room for all files at once: this file's batch scaled by the files' sizes on disk
+                    double scale = 1.0;
+                    if (first && n_sams > 1) {
+                        struct stat st0;
+                        double all_bytes = 0, this_bytes = 0;
+                        for (int q = 0; q < n_sams; q++)
+                            if (stat(sams[q], &st0) == 0 && S_ISREG(st0.st_mode)) { all_bytes += (double)st0.st_size; if (q == i) this_bytes = (double)st0.st_size; }
+                        if (this_bytes > 0) scale = std::min(64.0, all_bytes / this_bytes * 1.02);
+                    }
+                    pending.push_back(std::async(std::launch::async, [cd, gi, first, nc, off, a, prm, scale]() {
                         int r = first ? pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
                         pp_aln_batch bi;
                         pp_ingest_batch(gi, &bi);
+                        if (r == PP_OK && first && scale > 1.0)
+                            r = pp_polish_reserve(cd, (uint64_t)((double)bi.n_aln * scale) + 1024, (uint64_t)((double)bi.seq_bytes * scale) + 4096,
+                                                  (uint64_t)((double)bi.n_cig_total * scale) + 1024);
                         if (r == PP_OK) r = pp_polish_add(cd, &bi, PP_MEM_HOST);
                         return r;
                     }));

@@ -209,6 +209,22 @@ __global__ void k_rebase(u64 *seq_off, u64 *cig_off, u64 n, u64 seq_base, u64 ci
     }
 }
 
+// Optional, between pp_polish_begin and the first pp_polish_add: room for what all the batches of the job will hold
+// (a guess is fine: the arrays still grow when it was too small, at the price of a reallocation and a copy).
+extern "C" int pp_polish_reserve(pp_ctx *ctx, uint64_t n_aln, uint64_t seq_bytes, uint64_t n_cig_total) {
+    if (!ctx) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_reserve without pp_polish_begin");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
+    const uint64_t cnt[9] = {n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, seq_bytes, n_cig_total};
+    const uint64_t used[9] = {ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_seq, ctx->acc_cig};
+    const bool owned = ctx->have_batch && !ctx->batch_borrowed;
+    for (int i = 0; i < 9; i++)
+        if (int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)cnt[i] * esz[i], owned ? (size_t)used[i] * esz[i] : 0)) return rc;
+    return PP_OK;
+}
+
 // Append one batch (host or device memory) to the library-owned accumulated arrays.
 static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     const uint64_t n0 = ctx->acc_n, s0 = ctx->acc_seq, c0 = ctx->acc_cig;

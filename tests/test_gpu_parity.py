@@ -1012,3 +1012,19 @@ def test_two_defects_are_reported_in_streaming_order(orc, tmp_path):
             got = subprocess.run([exe, "polish", str(fa)] + paths, capture_output=True, env=dict(os.environ, PP_DEVICE_INGEST=ingest))
             assert got.returncode == want.returncode and got.stdout == b"", (name, ingest, got.stderr)
             assert want_kind[0] in got.stderr, (name, ingest, want.stderr, got.stderr)
+
+
+def test_one_percent_of_the_reads_with_three_scattered_alignments(ctx, orc):
+    """The replay's worst case: at 200x, 1 % of the reads have three alignments (share 1/3,
+    order-dependent f64 depth) scattered over the contig, so EVERY window has positions whose depth depends on the
+    order of the additions -- ties at x.5 of depth * fraction_valid included.  Per-position f64 depth, thresholds,
+    status and bytes against the oracle; the small and the large instance of the replay kernel both run (the second
+    contig is 3x as deep)."""
+    contig_off, bases, recs = synth.fast_records(seed=71, contig_lens=(300_000,), coverage=200, k_choices=(1, 3),
+                                                 k_probs=(0.99, 0.01), indel_read_frac=0.01)
+    want, got = _compare_records(ctx, orc, contig_off, bases, recs)
+    nd_touched = int((want["positions"]["depth"] != np.floor(want["positions"]["depth"])).sum())
+    assert nd_touched > 100_000
+    contig_off, bases, recs = synth.fast_records(seed=72, contig_lens=(30_000,), coverage=900, k_choices=(1, 3),
+                                                 k_probs=(0.97, 0.03), indel_read_frac=0.01)
+    _compare_records(ctx, orc, contig_off, bases, recs)   # ~13 K items per window: the 128 KiB instance
