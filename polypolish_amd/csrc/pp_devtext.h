@@ -59,9 +59,23 @@ __global__ __launch_bounds__(1024) void k_nl_write(const u8 *__restrict__ text, 
     u32 before = inc - n;
     for (u32 i = 0; i < wave; i++) before += s_w[i];
     if (!n) return;
+    // the positions come out of the registers: bit 7 of every newline byte, dword by dword (no second look at the text)
     u64 out = blk_off[blockIdx.x] + before;
-    for (u32 i = 0; i < 64; i++)
-        if (text[base + i] == (u8)'\n') nl_pos[out++] = base + i;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const uint4 q = p[v];
+        const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u32 x = w[i] ^ 0x0A0A0A0Au;
+            u32 m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            while (m) {
+                const u32 b = ((u32)__ffs((int)m) - 1u) >> 3;  // byte index inside the dword
+                m &= m - 1u;
+                nl_pos[out++] = base + (u64)(16 * v + 4 * i) + b;
+            }
+        }
+    }
 }
 
 // ---- exclusive scan: u32 in -> T out (n + 1 entries) -- block sums, a single-block scan of the sums,
@@ -164,6 +178,40 @@ __device__ __forceinline__ u32 find_tab(const u8 *L, u32 from, u32 n) {
         i += 8;
     }
     return n;
+}
+
+// ---- the lines of one wave, through LDS -------------------------------------------------------------
+// One lane per line, but the text comes through LDS: the 64 lines of a wave are one contiguous stretch of the file
+// (~35 KB of a 150-bp SAM with QUAL), copied with coalesced 16-byte loads -- every 128-byte line of HBM once -- and
+// then walked byte by byte at LDS speed.  One lane per line straight from HBM (round 1) made every load instruction
+// touch 64 different cache lines: 245 GB/s.  Lines that do not fit the staging (very long reads) are read from HBM.
+// Launch with 64 threads per workgroup; `stage` = TOK_STAGE + 32 bytes of LDS, 16-byte aligned.  Returns false for
+// the lanes past the last line; otherwise *L points at the lane's line (LDS or HBM), *n is its length without
+// "\n" / "\r\n", *li its number.  The text buffer is padded with >= 64 zero bytes past `size`.
+constexpr u32 TOK_STAGE = 40 * 1024 - 64;  // four one-wave workgroups per CU
+
+__device__ __forceinline__ bool stage_wave_lines(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
+                                                 u64 n_nl, u64 n_lines, u8 *stage, const u8 **L, u32 *n, u64 *li) {
+    const u32 lane = threadIdx.x;
+    const u64 l0 = (u64)blockIdx.x * 64u, l1 = min(n_lines, l0 + 64u);  // this wave's lines [l0, l1)
+    const u64 s0 = l0 ? nl_pos[l0 - 1] + 1 : 0;
+    const u64 e1 = (l1 - 1 < n_nl) ? nl_pos[l1 - 1] : size;              // end of its last line
+    const u64 a0 = s0 & ~15ull;
+    // the copy runs 16 bytes past the last line: find_tab looks at eight bytes at a time
+    const u64 want = e1 - a0 + 16;
+    const u32 span = (u32)min((u64)TOK_STAGE + 16u, (want + 15ull) & ~15ull);
+    for (u32 off = lane * 16u; off < span; off += 64u * 16u) *(uint4 *)(stage + off) = *(const uint4 *)(text + a0 + off);
+    __syncthreads();
+    *li = l0 + lane;
+    if (*li >= n_lines) return false;
+    const u64 ls = *li ? nl_pos[*li - 1] + 1 : 0, le = *li < n_nl ? nl_pos[*li] : size;
+    u32 len = (u32)(le - ls);
+    const bool staged = le - a0 + 8 <= (u64)TOK_STAGE + 16u;
+    const u8 *p = staged ? (const u8 *)stage + (ls - a0) : text + ls;
+    if (len > 0 && p[len - 1] == (u8)'\r') len--;
+    *L = p;
+    *n = len;
+    return true;
 }
 
 __device__ __forceinline__ int op_code(u8 c) {

@@ -65,15 +65,22 @@ __device__ __forceinline__ int lookup_contig(const ContigTable &T, const u8 *s, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_tok_parse(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
-                                                   u64 n_nl, u64 n_lines, ContigTable T, LineRec *__restrict__ rec,
-                                                   u32 *__restrict__ is_aln, u64 *__restrict__ status) {
-    const u64 li = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lines) return;
-    const u64 ls = li ? nl_pos[li - 1] + 1 : 0, le = li < n_nl ? nl_pos[li] : size;
-    u32 n = (u32)(le - ls);
-    const u8 *L = text + ls;
-    if (n > 0 && L[n - 1] == (u8)'\r') n--;
+__device__ __forceinline__ void tok_parse_line(const u8 *L, u32 n, u64 li, const ContigTable &T, LineRec *__restrict__ rec,
+                                               u32 *__restrict__ is_aln, u64 *__restrict__ status);
+
+// Alignment::new for every line of the file: one lane per line, the wave's lines staged through LDS (pp_devtext.h)
+__global__ __launch_bounds__(64) void k_tok_parse(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
+                                                  u64 n_nl, u64 n_lines, ContigTable T, LineRec *__restrict__ rec,
+                                                  u32 *__restrict__ is_aln, u64 *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) u8 stage[TOK_STAGE + 32];
+    const u8 *L;
+    u32 n;
+    u64 li;
+    if (stage_wave_lines(text, size, nl_pos, n_nl, n_lines, stage, &L, &n, &li)) tok_parse_line(L, n, li, T, rec, is_aln, status);
+}
+
+__device__ __forceinline__ void tok_parse_line(const u8 *L, u32 n, u64 li, const ContigTable &T, LineRec *__restrict__ rec,
+                                               u32 *__restrict__ is_aln, u64 *__restrict__ status) {
     is_aln[li] = 0;
     if (n == 0 || L[0] == (u8)'@') return;  // alignment.rs:241
     u32 cs[11], cl[11], nc = 0, q = 0;
@@ -277,10 +284,34 @@ __global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, co
     const u32 n = b.seq_len;
     u8 *out = seq + seq_base + seq_scan[r];
     const bool rc = sr != r && ((a.flag & 16u) == 0) != ((b.flag & 16u) == 0);
-    for (u32 i = s; i < n; i += 8) {  // byte-wise: the output offset has no alignment and n is small
-        u8 c = rc ? in[n - 1 - i] : in[i];
+    if (!rc) {
+        // 16 bytes per lane and trip (gfx950 global accesses need no alignment), upper-cased four at a time:
+        // bit 7 of every byte in 'a'..'z' (ASCII only), shifted down to the 0x20 that is taken off
+        const u32 whole = n & ~15u;
+        for (u32 i = 16u * s; i < whole; i += 128u) {
+            uint4 v;
+            __builtin_memcpy(&v, in + i, 16);
+            u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 x = w[q] & 0x7F7F7F7Fu;
+                const u32 m = (x + 0x1F1F1F1Fu) & ~(x + 0x05050505u) & ~w[q] & 0x80808080u;
+                w[q] -= m >> 2;
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+            __builtin_memcpy(out + i, &v, 16);
+        }
+        for (u32 i = whole + s; i < n; i += 8) {
+            u8 c = in[i];
+            if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
+            out[i] = c;
+        }
+        return;
+    }
+    for (u32 i = s; i < n; i += 8) {  // a "*" record on the other strand (rare): byte-wise, reversed and complemented
+        u8 c = in[n - 1 - i];
         if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
-        out[i] = rc ? comp_upper(c) : c;
+        out[i] = comp_upper(c);
     }
 }
 
@@ -495,7 +526,7 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
         ENS(d_isaln, n_lines * 4);
         ENS(d_recofline, (n_lines + 1) * 4);
         ContigTable T{(const u32 *)D->t_slots.p, (const u32 *)D->t_off.p, (const u8 *)D->t_names.p, D->t_mask};
-        hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d_text, size,
+        hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 63) / 64)), dim3(64), 0, st, d_text, size,
                            (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_isaln.p, n_lines, (u32 *)D->d_recofline.p))) return rc;
         if ((rc = fetch(ctx, (const u32 *)D->d_recofline.p + n_lines, &n_aln))) return rc;
