@@ -25,6 +25,16 @@ constexpr uint32_t SORT_MAX = 16384;      // items per window the ordered-depth 
 constexpr uint32_t SORT_SMALL = 10112;    // ... its small instance (80 KiB of LDS: two workgroups per CU)
 constexpr uint32_t SORT_BUCKETS = 4096;   // its counting sort: buckets over the window's range of record indices ...
 constexpr uint32_t SORT_BUCKET_MAX = 48;  // ... finished by insertion sorts unless one holds more than this (-> bitonic)
+// Heavy windows (collapsed repeats, BASELINE configs[2]): a window with several times the average number of items would
+// keep ONE workgroup busy several times as long while the chip drains.  Up to HEAVY_SLOTS of them per job are listed
+// (k_scan_cols / k_heavy); k_tile splits the items of a listed window over HEAVY_PARTS helper blocks that are dispatched
+// first (their partial tallies meet in a global slab, the last arrival adds them up and votes), k_exact2 replays it with one block per
+// TILE / HEAVY_SUB positions.  Windows past the end of the list simply take the ordinary path.
+constexpr uint32_t HEAVY_SLOTS = 32;  // x HEAVY_PARTS = 256 helper blocks: at most one per CU (see k_tile)
+constexpr uint32_t HEAVY_PARTS = 8;
+constexpr uint32_t HEAVY_SUB = 8;
+constexpr uint32_t HEAVY_MIN_ITEMS = 3072;  // ... and never a window below this many items
+constexpr uint32_t HEAVY_WORDS = 1 + 2 * HEAVY_SLOTS;  // u32: count | listed windows | arrival tickets (in the metadata block)
 
 // entry flags (entA.y bits 24..31)
 constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs: walked run by run, trim done by k_prep
@@ -104,6 +114,7 @@ struct pp_ctx {
     pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slabs, b_ents, b_keys, b_own;
+    pp::DevBuf b_win_heavy, b_hslab;  // heavy windows: slot + 1 per window (u8) | the helpers' partial tallies
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;

@@ -55,8 +55,28 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
     }
 }
 
+// heavy-window list (see HEAVY_SLOTS): heavy[0] counts the windows of at least `heavy_min` items, the first HEAVY_SLOTS
+// of them are listed in heavy[1..] and marked in win_heavy (slot + 1)
+__device__ __forceinline__ void note_heavy(u32 w, u32 cnt, u32 heavy_min, u32 *heavy, u8 *win_heavy) {
+    u32 mark = 0;
+    if (cnt >= heavy_min) {
+        const u32 slot = atomicAdd(&heavy[0], 1u);
+        if (slot < HEAVY_SLOTS) { heavy[1 + slot] = w; mark = slot + 1u; }
+    }
+    win_heavy[w] = (u8)mark;
+}
+
+// two-level path: the windows' counts come from k_count's atomics
+__global__ __launch_bounds__(256) void k_heavy(u32 nwin, const u32 *__restrict__ win_cnt, u32 heavy_min,
+                                               u32 *__restrict__ heavy, u8 *__restrict__ win_heavy) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwin) note_heavy(w, win_cnt[w], heavy_min, heavy, win_heavy);
+}
+
+// win_heavy != nullptr (single-level path, the columns ARE the windows): also lists the heavy windows
 __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
-                                                   u32 *__restrict__ win_cnt) {
+                                                   u32 *__restrict__ win_cnt, u32 heavy_min, u32 *__restrict__ heavy,
+                                                   u8 *__restrict__ win_heavy) {
     const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= nwin) return;
     u32 v[8];
@@ -79,7 +99,10 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
         if (b < nblocks) hist[(u64)b * nwin + w] = run;
         run += v[i];
     }
-    if (lane == 63) win_cnt[w] = inc;
+    if (lane == 63) {
+        win_cnt[w] = inc;
+        if (win_heavy) note_heavy(w, inc, heavy_min, heavy, win_heavy);
+    }
 }
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total

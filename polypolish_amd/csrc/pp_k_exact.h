@@ -94,6 +94,8 @@ struct ExactArgs {
     u8 *dbg_status;
     u64 *status;
     int dbg;
+    const u32 *heavy;     // list of the heavy windows (HEAVY_WORDS) ...
+    const u8 *win_heavy;  // ... and, per window, 0 or 1 + its slot in it
 };
 
 constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
@@ -283,20 +285,45 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 //  (4) vote per flagged position; the few whose string-keyed tallies could reach a threshold are
 //      handed to the thread-serial k_exact through the global list.
 // Two instances share the windows by their item count: (0, SORT_SMALL] with 80 KiB of LDS -- two workgroups per CU,
-// the usual case -- and (SORT_SMALL, SORT_MAX] with 128 KiB.
-template <u32 SMAX, u32 NLOW>
-__global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(ExactArgs A, u32 nwin) {
+// the usual case -- and (SORT_SMALL, SORT_MAX] with 128 KiB.  A third one (SUB > 1) takes the listed heavy windows,
+// whatever their size: one block per TILE / SUB positions, which first picks the items that reach its positions out of
+// the window's list (sel[]) and then does the same as the others with those -- the pass over a window of five times
+// the usual depth is spread over SUB CUs instead of holding one for five times as long.
+template <u32 SMAX, u32 NLOW, u32 SUB>
+__global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) void k_exact2(ExactArgs A, u32 nwin) {
     __shared__ u64 pk[SMAX];  // bitonic sort keys (record index << 16 | slot), or the counting sort's arrays
+    __shared__ u32 sel[SUB > 1 ? SMAX : 1];  // SUB > 1: index (in the window's list) of the j-th item picked
     __shared__ u64 s_base;
+    __shared__ u32 s_npick;
     constexpr u32 LDS_LIST_MAX = SMAX * 3u / 8u;  // ordered (start, extent, share) records that fit below ord[]
-    const u32 w = blockIdx.x, tid = threadIdx.x;
-    const int state = w < nwin ? job_state(A.status) : 2;
+    constexpr int PSPAN = TILE / (int)SUB;        // positions of this block
+    static_assert(PSPAN % 128 == 0 && SMAX <= 65536, "a wave owns 64 or 128 positions; slots are 16-bit");
+    const u32 tid = threadIdx.x;
+    u32 w;
+    int plo = 0;
+    if (SUB == 1) {
+        w = blockIdx.x;
+        if (w >= nwin) return;
+    } else {
+        const u32 hs = blockIdx.x / SUB;
+        if (hs >= min(A.heavy[0], HEAVY_SLOTS)) return;
+        w = A.heavy[1 + hs];
+        plo = (int)(blockIdx.x % SUB) * PSPAN;
+    }
+    const int state = job_state(A.status);
     if (state == 2) return;
     if (A.win_nflag[w] == 0) return;
-    const u32 e0 = A.win_off[w], n = A.win_off[w + 1] - e0;
-    if (n > SMAX || n <= NLOW) return;  // the other instance's window, or (n > SORT_MAX) replayed by k_exact
+    const u32 e0 = A.win_off[w], n_all = A.win_off[w + 1] - e0;
+    if (SUB == 1) {
+        if (A.win_heavy[w]) return;                  // the sub-range instance's
+        if (n_all > SMAX || n_all <= NLOW) return;  // the other instance's window, or (n > SORT_MAX) replayed by k_exact
+    } else {
+        u32 any = 0;  // nothing flagged among this block's positions?
+        for (int q = 0; q < PSPAN / 32; q++) any |= A.flag_bits[(u64)w * (TILE / 32) + (u32)(plo / 32 + q)];
+        if (!any) return;
+    }
     if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
-        if (tid == 0 && n > LDS_LIST_MAX) atomicAdd(A.ents_cursor, (u64)n);  // smaller lists stay in LDS
+        if (tid == 0 && (SUB > 1 || n_all > LDS_LIST_MAX)) atomicAdd(A.ents_cursor, (u64)n_all);  // smaller lists stay in LDS
         return;
     }
     const u32 slab = A.win_slab[w];
@@ -312,13 +339,51 @@ __global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(Exa
     unsigned short *ord = (unsigned short *)(pk + SMAX / 2 + SMAX / 4);  // [SMAX] slots in file order (last quarter)
     static_assert((SORT_BUCKETS + 1u) * 4u <= SMAX * 2u, "bkt[] must end before ord[]");
     __shared__ u32 s_lo, s_hi, s_big, s_wtot[16];
-    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0; }
+    if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; s_big = 0; s_npick = 0; }
     for (u32 i = tid; i <= SORT_BUCKETS; i += 1024) bkt[i] = 0;
     __syncthreads();
+    u32 n = n_all;
+    if (SUB > 1) {
+        // the items that can reach [plo, plo + PSPAN): by their untrimmed extent (the trim only shortens it)
+        for (u32 i0 = tid; i0 < n_all; i0 += 4096) {
+            uint4 ent[4];
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) ent[u] = A.entA[e0 + min(i0 + 1024u * u, n_all - 1u)];  // four loads in flight
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) {
+                const u32 i = i0 + 1024u * u;
+                const u32 ext = ((ent[u].y >> 16) & 0xFFu) ? ent[u].x : (ent[u].y >> 24);
+                const int z = (int)ent[u].z;
+                if (i < n_all && z < plo + PSPAN && (long long)z + (long long)ext > (long long)plo) {
+                    const u32 j = atomicAdd(&s_npick, 1u);
+                    if (j < SMAX) sel[j] = i;
+                }
+            }
+        }
+        __syncthreads();
+        n = s_npick;
+        if (n > SMAX || n == 0) {
+            // More than one block sorts (a repeat far deeper than the list is meant for): this block's flagged
+            // positions go to the thread-serial k_exact through the global list, like a window above SORT_MAX.
+            // (n == 0 cannot be, a flagged position is covered; it takes the same exit rather than a special case.)
+            const u32 *tal0 = A.slabs + (u64)slab * 6u * TILE;
+            for (u32 p = (u32)plo + tid; p < (u32)(plo + PSPAN); p += 1024) {
+                if (!((A.flag_bits[(u64)w * (TILE / 32) + (p >> 5)] >> (p & 31u)) & 1u)) continue;
+                const u32 ntot = tal0[0 * TILE + p] + tal0[1 * TILE + p] + tal0[2 * TILE + p] + tal0[3 * TILE + p] +
+                                 tal0[4 * TILE + p] + tal0[5 * TILE + p];
+                const u32 slot = atomicAdd(&A.counters[0], 1u);
+                atomicAdd(A.scr_need, (u64)ntot);
+                if (slot < A.cap_flag) { A.flag_pos_w[slot] = w * (u32)TILE + p; A.flag_cov_w[slot] = ntot; }
+                else report(A.status, slot, DE_CAPACITY_LATE);
+            }
+            return;
+        }
+    }
+    auto item_of_slot = [&](u32 j) -> u32 { return SUB > 1 ? sel[j] : j; };
     {
         u32 lo = 0xFFFFFFFFu, hi = 0;
         for (u32 i = tid; i < n; i += 1024) {
-            const u32 r = A.entA[e0 + i].w;
+            const u32 r = A.entA[e0 + item_of_slot(i)].w;
             rec[i] = r;
             lo = min(lo, r); hi = max(hi, r);
         }
@@ -389,7 +454,7 @@ __global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(Exa
         __syncthreads();
         u32 np2 = 2;
         while (np2 < n) np2 <<= 1;
-        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + i].w << 16) | (u64)i) : ~0ull;
+        for (u32 i = tid; i < np2; i += 1024) pk[i] = i < n ? (((u64)A.entA[e0 + item_of_slot(i)].w << 16) | (u64)i) : ~0ull;
         __syncthreads();
         for (u32 k = 2; k <= np2; k <<= 1) {
             for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {  // partner distance j = 2^lj = k/2 ... 1
@@ -409,7 +474,7 @@ __global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(Exa
     ulonglong2 *ents_lds = (ulonglong2 *)pk;
     // ---- (2) start, trimmed extent and depth share of every item, in file order ----
     for (u32 i = tid; i < n; i += 1024) {
-        const uint4 ent = A.entA[e0 + (bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
+        const uint4 ent = A.entA[e0 + item_of_slot(bitonic ? (u32)(pk[i] & 0xFFFFu) : (u32)ord[i])];
         const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;
@@ -429,55 +494,84 @@ __global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(Exa
     // Wave v owns the 128 consecutive positions [128v, 128v+128): an item overlaps ~2 of the 16 waves, the
     // others never enter the scalar loop (ballot of a per-lane overlap test).
     const u32 lane = tid & 63u;
-    const int wlo = (int)(tid >> 6) * 128;
+    // SUB > 1: a lane owns ONE position and a wave 64 -- the blocks of a heavy window run alone on their CUs, so a
+    // wave's chain of dependent additions is what takes the time, and half as many positions per wave means fewer
+    // items to visit and one fma per visit; the block's positions take only its first waves.
+    constexpr int PPL = SUB > 1 ? 1 : 2, WSPAN = 64 * PPL;
+    const bool pos_wave = (int)(tid >> 6) * WSPAN < PSPAN;
+    const int wlo = plo + (int)(tid >> 6) * WSPAN;
     const int p0 = wlo + (int)lane, p1 = p0 + 64;
     double d0 = 0.0, d1 = 0.0;
-    // Two instances of the loop, one per address space (through a generic pointer the loads would be flat loads,
-    // whose counters force a full wait), and two batch registers in turn, so that the load of the batch after the
-    // current one is in flight while the current one is visited.
-    // An item that reaches a lane's position adds its share there: fma(1.0, share, depth) is the rounded sum
-    // depth + share, and fma(0.0, share, depth) leaves depth as it is -- one select + one fma per position instead
-    // of a branch.  With the list in LDS the item's three words come from ONE broadcast read at a wave-uniform
-    // address; from the global slab they are picked out of the batch registers with v_readlane.
-    auto visit = [&](const ulonglong2 &mine, bool have, u32 bbase, auto item_of) {
+    // The pass runs over (start, extent, share) records in LDS: 64 records per vector read (one per lane) and a ballot
+    // pick the records that reach the wave's positions, each of those is then read once more at a wave-uniform address
+    // (ONE broadcast read for its three words) and added where it applies: fma(1.0, share, depth) is the rounded sum
+    // depth + share, fma(0.0, share, depth) leaves depth as it is -- one select + one fma per position instead of a
+    // branch.  Two batch registers in turn, so that the read of the batch after the current one is in flight while
+    // the current one is visited.  A list that does not fit LDS is taken from the global slab in chunks of CHUNK
+    // records (picking a record's words out of registers with v_readlane instead costs 22 instead of 14 instructions
+    // per visit, and the visits are what the pass consists of).
+    auto visit = [&](const ulonglong2 &mine, bool have, u32 bbase) {
         const int xl = (int)(u32)mine.x, xh = (int)(u32)(mine.x >> 32);
         // one vector compare picks the items of this batch that reach the wave's positions; only those are
         // visited one by one, in ascending order = file order
-        u64 hits = __ballot(have && xl < wlo + 128 && (long long)xl + (long long)(u32)xh > (long long)wlo);
-        while (hits) {
-            const int j = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const ulonglong2 it = item_of(mine, bbase, j);
+        u64 hits = __ballot(have && xl < wlo + WSPAN && (long long)xl + (long long)(u32)xh > (long long)wlo);
+        if (SUB == 1) {
+            // sixteen waves share the CU: the other waves hide the read's latency, the instruction count is what matters
+            while (hits) {
+                const int j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const ulonglong2 it = ents_lds[bbase + (u32)j];
+                const int rel = (int)(u32)it.x;
+                const u32 lim = (u32)(it.x >> 32);
+                const double dc = __longlong_as_double((long long)it.y);
+                d0 = fma(__hiloint2double((u32)(p0 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d0);
+                d1 = fma(__hiloint2double((u32)(p1 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d1);
+            }
+            return;
+        }
+        if (!hits) return;
+        // a few waves alone on their CU: the item after the current one is fetched before the current one is applied
+        // (a lone wave would otherwise wait out one LDS round trip per item)
+        int j = __ffsll((long long)hits) - 1;
+        hits &= hits - 1;
+        ulonglong2 it = ents_lds[bbase + (u32)j];
+        for (;;) {
+            const bool more = hits != 0;
+            ulonglong2 nx = it;
+            if (more) {
+                j = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                nx = ents_lds[bbase + (u32)j];
+            }
             const int rel = (int)(u32)it.x;
             const u32 lim = (u32)(it.x >> 32);
             const double dc = __longlong_as_double((long long)it.y);
             d0 = fma(__hiloint2double((u32)(p0 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d0);
-            d1 = fma(__hiloint2double((u32)(p1 - rel) < lim ? 0x3FF00000 : 0, 0), dc, d1);
+            if (!more) break;
+            it = nx;
         }
     };
-    auto ordered_pass = [&](auto load, auto item_of) {
-        // unconditional loads from clamped indices (a load under a branch would make the wait for the older
-        // batch a wait for everything); `have` masks the lanes past the end
-        ulonglong2 ba = load(min(lane, n - 1u)), bb;
-        for (u32 base = 0; base < n; base += 128) {
-            bb = load(min(base + 64u + lane, n - 1u));
-            visit(ba, base + lane < n, base, item_of);
-            ba = load(min(base + 128u + lane, n - 1u));
-            visit(bb, base + 64u + lane < n, base + 64u, item_of);
+    auto ordered_pass = [&](u32 m) {  // over ents_lds[0, m)
+        ulonglong2 ba = ents_lds[min(lane, m - 1u)], bb;
+        for (u32 base = 0; base < m; base += 128) {
+            bb = ents_lds[min(base + 64u + lane, m - 1u)];
+            visit(ba, base + lane < m, base);
+            ba = ents_lds[min(base + 128u + lane, m - 1u)];
+            visit(bb, base + 64u + lane < m, base + 64u);
         }
     };
-    if (in_lds)
-        ordered_pass([&](u32 i) { return ents_lds[i]; },
-                     [&](const ulonglong2 &, u32 bbase, int j) { return ents_lds[bbase + (u32)j]; });
-    else
-        ordered_pass([&](u32 i) { return ents[i]; }, [&](const ulonglong2 &mine, u32, int j) {
-            ulonglong2 r;
-            r.x = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine.x, j) |
-                  ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine.x >> 32), j) << 32);
-            r.y = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine.y, j) |
-                  ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine.y >> 32), j) << 32);
-            return r;
-        });
+    if (in_lds) {
+        if (pos_wave) ordered_pass(n);
+    } else {
+        constexpr u32 CHUNK = SMAX / 2u;  // 16-byte records in pk[], which nobody needs any more
+        for (u32 c0 = 0; c0 < n; c0 += CHUNK) {
+            const u32 m = min(CHUNK, n - c0);
+            __syncthreads();
+            for (u32 i = tid; i < m; i += 1024) ents_lds[i] = ents[c0 + i];
+            __syncthreads();
+            if (pos_wave) ordered_pass(m);
+        }
+    }
 
     // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
     const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
@@ -486,7 +580,7 @@ __global__ __launch_bounds__(1024, SMAX <= SORT_SMALL ? 8 : 4) void k_exact2(Exa
     const bool one_contig = c_first == find_contig(A.contig_off, A.n_contigs, min(gw0 + TILE, A.G) - 1);
     u32 my_len = 0, my_changed = 0, my_zero = 0;
     u64 my_depth = 0;
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < (pos_wave ? PPL : 0); h++) {
         const u32 p = h ? (u32)p1 : (u32)p0;
         const double depth = h ? d1 : d0;
         if (!((A.flag_bits[(u64)w * (TILE / 32) + (p >> 5)] >> (p & 31u)) & 1u)) continue;

@@ -38,6 +38,12 @@ struct TileArgs {
     const u32 *maxlen;  // longest fast-class read (written by k_prep)
     u64 seq_bytes;
     const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
+    u32 *heavy;           // HEAVY_WORDS: number of heavy windows | the listed ones | their arrival tickets
+    const u8 *win_heavy;  // per window: 0, or 1 + its slot in the list
+    u32 *hslab;           // per slot and part: HSLAB_WORDS partial tallies of that helper block
+#ifdef PP_TILE_STAMPS
+    u64 *stamps;          // profiling build: per block (start, items done, end, window) in 100 MHz ticks
+#endif
     double *dbg_depth;
     u32 *dbg_counts;  // 7 planes of G: a, c, g, t, other, valid_thr, invalid_thr
     u8 *dbg_status;
@@ -438,18 +444,47 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     }
 }
 
+constexpr u32 HSLAB_WORDS = (u32)(N_ROWS * TILE + TILE / 32);  // the nine counter rows + the bitmap of order-dependent positions
+static_assert(HSLAB_WORDS % 4 == 0 && (N_ROWS * TILE) % 4 == 0 && TILE % 128 == 0, "the partial tallies move as 16-byte words");
+constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at the front of k_tile's grid (a multiple of 8)
+
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
-    __shared__ u32 cnt[N_ROWS * TILE];
+    __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_ndbits[TILE / 32], s_nflag;
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket;
+    __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
 
-    // XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD
-    u32 per = gridDim.x >> 3;
-    u32 w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    if (w >= A.nwin || job_state(A.status) == 2) return;
+    // The first HEAVY_BLOCKS blocks are helpers: block HEAVY_PARTS * slot + part tallies one part of the items of the
+    // heavy window in that slot of the list.  They are dispatched first, so the longest windows start at time zero, and
+    // the live ones are the LOWEST block numbers: the dispatcher deals consecutive workgroups round the CUs of an XCD
+    // in order and waits when the next CU in turn is full, so two long-lived blocks on one CU would hold up the
+    // dispatch for the whole XCD (measured: half of the chip's slots empty until the first helper finished).  Numbered
+    // like this every CU gets at most one helper, next to an ordinary window.
+    // Then the windows in XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD.
+    u32 w, part = 0, hslot = 0;
+    const bool heavy = blockIdx.x < HEAVY_BLOCKS;
+    if (heavy) {
+        hslot = blockIdx.x / HEAVY_PARTS;
+        part = blockIdx.x % HEAVY_PARTS;
+        if (hslot >= min(A.heavy[0], HEAVY_SLOTS)) return;
+        w = A.heavy[1 + hslot];
+    } else {
+        const u32 b = blockIdx.x - HEAVY_BLOCKS, per = (gridDim.x - HEAVY_BLOCKS) >> 3;
+        w = (b & 7u) * per + (b >> 3);
+        if (w >= A.nwin || A.win_heavy[w]) return;  // listed windows belong to the helpers
+    }
+    if (job_state(A.status) == 2) return;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
+#ifdef PP_TILE_STAMPS
+    if (tid == 0) {
+        A.stamps[8ull * blockIdx.x] = wall_clock64();
+        A.stamps[8ull * blockIdx.x + 3] = w | ((u64)part << 32) | ((u64)heavy << 40);
+        A.stamps[8ull * blockIdx.x + 4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
+        A.stamps[8ull * blockIdx.x + 5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID
+    }
+#endif
 
     if (A.own) {
         // Sharded job: a window that lies inside ONE contig and outside the range of it this context emits is
@@ -483,15 +518,74 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
 
+#ifdef PP_TILE_STAMPS
+    if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
+#endif
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
     {
+        u32 i0 = e0, i1 = e1;
+        if (heavy) {  // this helper's share of the window's items
+            const u32 chunk = ((e1 - e0 + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
+            i0 = min(e1, e0 + part * chunk);
+            i1 = min(e1, i0 + chunk);
+        }
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
-        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
-        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
-        else tile_items<8>(A, cnt, s_ndbits, asm_w, e0, e1, wave, lane);
+        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
+        else tile_items<8>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
     }
-    if (e1 - e0 >= MAX_BUCKET && tid == 0) report(A.status, w, DE_TOO_DEEP);
+    if (e1 - e0 >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);
     __syncthreads();
+#ifdef PP_TILE_STAMPS
+    if (tid == 0) A.stamps[8ull * blockIdx.x + 1] = wall_clock64();
+#endif
+
+    if (heavy) {
+        // The helpers of one window meet in its slab: every part stores its partial tallies in its own region and takes
+        // a ticket; the last one to arrive adds all parts up -- integers, the order does not matter; the deficit row
+        // carries a flag in bit 31, which is OR-ed -- and goes on to vote like the workgroup of an ordinary window.
+        // The partials travel as agent-scope atomic stores and loads (write-through / L2-bypassing dwords), ordered
+        // against the ticket by waiting for the stores' acknowledgements: a __threadfence() here means a write-back
+        // and an invalidation of the XCD's whole L2 per helper, which slowed every block of the chip's first round to
+        // half its speed (measured: k_tile 0.49 -> 0.64 ms on BASELINE configs[2]).
+        u32 *mine = A.hslab + ((u64)hslot * HEAVY_PARTS + part) * HSLAB_WORDS;
+        for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS)
+            __hip_atomic_store(&mine[i], cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < (u32)(TILE / 32))
+            __hip_atomic_store(&mine[N_ROWS * TILE + tid], s_ndbits[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this lane's stores have been acknowledged
+        __syncthreads();
+        if (tid == 0)
+            s_ticket = __hip_atomic_fetch_add(&A.heavy[1 + HEAVY_SLOTS + hslot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+#ifdef PP_TILE_STAMPS
+        if (tid == 0) A.stamps[8ull * blockIdx.x + 2] = wall_clock64();
+#endif
+        if (s_ticket != HEAVY_PARTS - 1u) return;
+        const u32 *base = A.hslab + (u64)hslot * HEAVY_PARTS * HSLAB_WORDS;
+        for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) {
+            u32 o[HEAVY_PARTS];
+#pragma unroll
+            for (u32 q = 0; q < HEAVY_PARTS; q++)  // all parts' loads in flight (this part's own tallies are there as well)
+                o[q] = __hip_atomic_load(&base[(u64)q * HSLAB_WORDS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 sum = 0, top = 0;
+            const bool def_row = i / (u32)TILE == (u32)ROW_DEF;
+#pragma unroll
+            for (u32 q = 0; q < HEAVY_PARTS; q++) {
+                sum += def_row ? (o[q] & 0x7FFFFFFFu) : o[q];
+                top |= o[q];
+            }
+            cnt[i] = def_row ? ((sum & 0x7FFFFFFFu) | (top & 0x80000000u)) : sum;
+        }
+        if (tid < (u32)(TILE / 32)) {
+            u32 bits = 0;
+#pragma unroll
+            for (u32 q = 0; q < HEAVY_PARTS; q++)
+                bits |= __hip_atomic_load(&base[(u64)q * HSLAB_WORDS + N_ROWS * TILE + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ndbits[tid] = bits;
+        }
+        __syncthreads();
+    }
 
     // ---- coverage of the fast class: prefix sum of the difference array, in place ----
     {
@@ -555,7 +649,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
-            const bool to_list = A.dbg == 1 || e1 - e0 > SORT_MAX;  // dbg 2: test hook, see run_pipeline
+            // dbg 2: test hook, see run_pipeline; a listed heavy window is replayed by k_exact2's sub-range instance
+            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy);
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);
@@ -611,7 +706,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
     if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
-    if (s_nflag && e1 - e0 <= SORT_MAX) {
+    if (s_nflag && (e1 - e0 <= SORT_MAX || heavy)) {
         // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
         if (tid == 0) {
             const u32 slab = atomicAdd(&A.counters[3], 1u);
@@ -631,6 +726,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             }
         }
     }
+#ifdef PP_TILE_STAMPS
+    if (tid == 0) A.stamps[8ull * blockIdx.x + 2] = wall_clock64();
+#endif
     if (tid == 0) {
         A.win_nflag[w] = s_nflag;
         if (s_nflag) atomicAdd(&A.counters[2], s_nflag);

@@ -333,8 +333,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // as the positions are listed) |
     // 5 polished bytes | 6 ordered replay items | 8 key records | 9 longest fast read | 16.. contig output offsets
     // (nc+1) | then per-contig stats (3 words each)
-    const size_t meta_words = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
+    // ... | then the heavy-window list (HEAVY_WORDS u32: count, windows, arrival tickets)
+    const size_t heavy_at = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
+    const size_t meta_words = heavy_at + (HEAVY_WORDS + 1) / 2;
     ENS(b_meta, meta_words * 8);
+    ENS(b_win_heavy, nwin);
+    ENS(b_hslab, (size_t)HEAVY_SLOTS * HEAVY_PARTS * HSLAB_WORDS * 4);
     ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
     // One level (items straight into their windows) while all windows fit one LDS pass of k_fill; two levels
     // (coarse buckets of COARSE_WINDOWS windows, then k_regroup) beyond that: there the single-level k_fill
@@ -364,6 +368,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
     PP_HIPCHK(ctx, hipMemsetAsync(d_meta, 0, meta_words * 8, st));
     PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
+    u32 *d_heavy = (u32 *)(d_meta + heavy_at);
+    u8 *d_win_heavy = (u8 *)ctx->b_win_heavy.p;
+    // a window is heavy from 1.25x the average number of items on (records per window: a few per cent below the items);
+    // in a job of uniform coverage no window gets there (2,900 +- 60 items at 200x)
+    static const long forced_heavy = getenv("PP_HEAVY_MIN") ? atol(getenv("PP_HEAVY_MIN")) : 0;  // tuning / tests
+    const u32 heavy_min = forced_heavy > 0 ? (u32)forced_heavy
+                                           : (u32)std::min<uint64_t>(MAX_BUCKET, std::max<uint64_t>(HEAVY_MIN_ITEMS, 5 * n / 4 / nwin));
 
     u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
     u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
@@ -389,7 +400,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         PP_HIPCHK(ctx, hipMemsetAsync(d_wincnt, 0, (size_t)nwin * 4, st));
         hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
                            d_nkeep, nwin, ncoarse, d_hist, d_wincnt);
-        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt, 0u,
+                           (u32 *)nullptr, (u8 *)nullptr);
+        hipLaunchKernelGGL(k_heavy, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, (const u32 *)d_wincnt, heavy_min,
+                           d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
                            d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
@@ -404,7 +418,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     } else {
         hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
                            nwin, d_hist, d_wincnt);
-        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt);
+        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, heavy_min,
+                           d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
                            d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
         if (n)
@@ -430,6 +445,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.scr_need = d_meta + 10;
     T.seq_bytes = B.seq_bytes;
     T.own = d_own;
+    T.heavy = d_heavy; T.win_heavy = d_win_heavy; T.hslab = (u32 *)ctx->b_hslab.p;
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status;
     // PP_DEBUG_REPLAY2=1 (tests): per-position records while order-dependent positions still go through k_exact2,
@@ -438,7 +454,22 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.dbg = ctx->debug ? (dbg_replay2 ? 2 : 1) : 0;
     const uint32_t per = (nwin + 7) / 8;
     timer_begin(ctx, "tile");
-    hipLaunchKernelGGL(k_tile, dim3(per * 8), dim3(TILE_THREADS), 0, st, T);
+#ifdef PP_TILE_STAMPS
+    static DevBuf b_stamps;
+    const size_t stamp_bytes = (size_t)(HEAVY_BLOCKS + per * 8) * 64;
+    if (int rc2 = dev_ensure(ctx, b_stamps, stamp_bytes)) return rc2;
+    PP_HIPCHK(ctx, hipMemsetAsync(b_stamps.p, 0, stamp_bytes, st));
+    T.stamps = (u64 *)b_stamps.p;
+#endif
+    hipLaunchKernelGGL(k_tile, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
+#ifdef PP_TILE_STAMPS
+    if (const char *path = getenv("PP_TILE_STAMPS_FILE")) {
+        std::vector<uint64_t> hs(stamp_bytes / 8);
+        PP_HIPCHK(ctx, hipMemcpyAsync(hs.data(), b_stamps.p, stamp_bytes, hipMemcpyDeviceToHost, st));
+        PP_HIPCHK(ctx, hipStreamSynchronize(st));
+        if (FILE *f = fopen(path, "wb")) { fwrite(hs.data(), 1, stamp_bytes, f); fclose(f); }
+    }
+#endif
     timer_end(ctx);
 
     u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
@@ -459,10 +490,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
     E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
     E.status = d_status; E.dbg = T.dbg;
+    E.heavy = d_heavy; E.win_heavy = d_win_heavy;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
-    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
-    hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL>), dim3(nwin), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, HEAVY_SUB>), dim3(HEAVY_SLOTS * HEAVY_SUB), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
                        d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);

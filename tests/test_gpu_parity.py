@@ -1028,3 +1028,46 @@ def test_one_percent_of_the_reads_with_three_scattered_alignments(ctx, orc):
     contig_off, bases, recs = synth.fast_records(seed=72, contig_lens=(30_000,), coverage=900, k_choices=(1, 3),
                                                  k_probs=(0.97, 0.03), indel_read_frac=0.01)
     _compare_records(ctx, orc, contig_off, bases, recs)   # ~13 K items per window: the 128 KiB instance
+
+
+def _with_hot_region(seed, length, coverage, hot_lo, hot_hi, hot_coverage, **hot_kw):
+    """fast_records over one contig plus a pile of extra reads that start in [hot_lo, hot_hi) (same truth and assembly:
+    the generator draws them first from the seed) -- a collapsed repeat."""
+    contig_off, bases, base = synth.fast_records(seed=seed, contig_lens=(length,), coverage=coverage, indel_read_frac=0.01)
+    off2, bases2, deep = synth.fast_records(seed=seed, contig_lens=(length,), coverage=hot_coverage, **hot_kw)
+    assert np.array_equal(bases, bases2)
+    keep = np.nonzero((deep["ref_start"] >= hot_lo) & (deep["ref_start"] < hot_hi))[0]
+    hot = dict(deep)
+    for k in ("contig", "ref_start", "k", "seq_len", "n_cig", "seq_off", "cig_off"):
+        hot[k] = np.ascontiguousarray(deep[k][keep])
+    return contig_off, bases, synth.merge_records(base, hot, seed=seed)
+
+
+def test_heavy_windows_are_split_over_helper_blocks(ctx, pp, orc):
+    """Collapsed repeats (BASELINE configs[2] in miniature): a few windows hold many times the average number of items.
+    They are listed as heavy: k_tile tallies each of them with eight helper blocks that meet in a global slab, and
+    the ordered replay (shares 1/3 and 1/5 in the pile) runs with one block per 256 positions.  Everything per
+    position against the oracle, twice on the same context (the slabs clean themselves), then (b) a pile too deep for
+    the sub-range blocks to sort (they hand their positions to the thread-serial replay) and (c) the same job cut
+    into emit ranges through the pile."""
+    contig_off, bases, recs = _with_hot_region(81, 40_000, 100, 19_000, 23_000, 1500, k_choices=(1, 3, 5),
+                                               k_probs=(0.6, 0.2, 0.2), indel_read_frac=0.02)
+    starts = recs["ref_start"].astype(np.int64)
+    w_first, w_last = starts // 2048, (starts + 149) // 2048
+    per_window = np.bincount(w_first, minlength=20) + np.bincount(w_last[w_last != w_first], minlength=20)
+    assert per_window.max() > 16384 and np.median(per_window) < 2000   # heavy, and beyond the one-block replay
+    for _ in range(2):
+        want, got = _compare_records(ctx, orc, contig_off, bases, recs)
+    assert len(np.unique(want["positions"]["depth"][19_000:23_000])) > 500
+    # (c) emit ranges that cut through the pile
+    full = want["polished"]
+    pieces = []
+    for lo, hi in ((0, 20_480), (20_480, 21_000), (21_000, 40_000)):
+        r = ctx.polish_records(contig_off, bases, recs, emit=np.array([[lo, hi]]))
+        pieces.append(r["polished"])
+    assert b"".join(pieces) == full
+    # (b) one window at ~6000x: ~80 K items, more than 10 K for each of its sub-range blocks
+    contig_off, bases, recs = _with_hot_region(82, 30_000, 60, 10_240, 12_100, 6000, k_choices=(1, 3), k_probs=(0.9, 0.1),
+                                               indel_read_frac=0.0)
+    _compare_records(ctx, orc, contig_off, bases, recs)
+
