@@ -82,68 +82,112 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
 #endif
 constexpr u32 PLAIN_NARROW_MAX = PP_PLAIN_ALIGNED ? 129u : 160u;  // = PlainCfg<5>::MAXL below
 
-__device__ __forceinline__ void prep_one(u64 a, u64 n, const u32 *__restrict__ contig,
-                                         const u32 *__restrict__ ref_start, const u32 *__restrict__ kk,
-                                         const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
-                                         const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
-                                         const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
-                                         const u64 *__restrict__ contig_off, u32 n_contigs, const u32 *__restrict__ own,
-                                         u32 *__restrict__ gstart, u32 *__restrict__ nkeep, u32 *fast_len, u64 *status) {
-    // independent loads first, then the dependent ones (clamped so that they are unconditional):
-    // two memory round trips per record.  The bulk (one short M run inside its contig) touches 28
-    // bytes of input per record; k and seq_off are only validated later, by k_fill, which reads them anyway.
-    const u32 c = contig[a], nc = n_cig[a], sl = seq_len[a], rs = ref_start[a];
-    const u64 co = cig_off[a];
-    const u32 cc = min(c, n_contigs - 1u);
-    const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1];
-    const u32 *cg = cigar + co;
-    const u32 op0 = nc ? cg[0] : 0u;
-    u32 g_out = 0, nk_out = 0;
-    u8 fl_out = 0;
-    if (c >= n_contigs) { report(status, a, DE_BAD_CONTIG); }
-    else if (nc == 0) { report(status, a, DE_BAD_RUN); }
-    else if (nc == 1 && (op0 & 15u) == PP_OP_M && (op0 >> 4) == sl && sl > 0 && sl <= FAST_MAX_LEN &&
-             (u64)rs + sl <= c_hi - c_lo) {
-        // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
-        g_out = (u32)(c_lo + rs);
-        nk_out = sl;
-        *fast_len = sl;  // the longest fast-class read picks the lane-group width of k_tile's plain class
-    } else {
-        prep_general(a, rs, sl, seq_off[a], cg, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
-    }
-    // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits is
-    // somebody else's -- validated like every record (all ranks report the same first bad record), then dropped.
-    // The untrimmed span of the fast class errs on the side of keeping.
-    if (own && nk_out && c < n_contigs && ((u64)rs + nk_out <= own[2 * c] || rs >= own[2 * c + 1])) nk_out = 0;
-    gstart[a] = g_out;
-    nkeep[a] = nk_out | ((u32)fl_out << 30);  // kept entries (< 2^30) | class flags
-}
+// The bulk (one short M run inside its contig) touches 28 bytes of input per record and is done in the streaming loop;
+// k and seq_off are only validated later, by k_fill, which reads them anyway.  Every other record (indels, long reads,
+// contig overhang, malformed ones: ~1 % of a typical job) is only NOTED there, in an LDS list, and handled after the
+// loop with one record per lane: inside the loop a single such record would hold its 63 neighbours for the several
+// dependent memory round trips of the CIGAR walk and the trim -- with 1 % of them in random places that is every other
+// wave (measured: half of the kernel's time).
+// COUNT: the block also tallies its records' windows in an LDS histogram (what k_count does as a pass of its own when
+// the windows do not fit one LDS range) and leaves its row of the blocks x windows matrix for k_scan_cols.
+#ifndef PP_PREP_WAVES
+#define PP_PREP_WAVES 8
+#endif
+#ifndef PP_PREP_UNROLL
+#define PP_PREP_UNROLL 1
+#endif
+constexpr u32 PREP_LATER_MAX = 2048;  // noted records per block; beyond that they are handled on the spot
 
-__global__ __launch_bounds__(256) void k_prep(u64 n, const u32 *__restrict__ contig,
-                                              const u32 *__restrict__ ref_start,
-                                              const u32 *__restrict__ kk,
-                                              const u64 *__restrict__ seq_off,
-                                              const u32 *__restrict__ seq_len,
-                                              const u64 *__restrict__ cig_off,
-                                              const u32 *__restrict__ n_cig,
-                                              const u32 *__restrict__ cigar,
-                                              const u8 *__restrict__ seq,
-                                              const u64 *__restrict__ contig_off, u32 n_contigs,
-                                              const u32 *__restrict__ own,
-                                              u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
-                                              u32 *__restrict__ maxlen, u64 *status) {
-    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 fast_len = 0;
-    if (a < n) prep_one(a, n, contig, ref_start, kk, seq_off, seq_len, cig_off, n_cig, cigar, seq, contig_off, n_contigs,
-                        own, gstart, nkeep, &fast_len, status);
-    // Only every 64th block looks (a sample: the word merely picks the lane-group width that suits the bulk of the
-    // reads -- a longer read than the sample saw simply takes the non-plain path), once per wave, and only for reads
-    // beyond the narrowest group (<= 160 bases); the word is read from L2, not from a possibly stale CU-local copy.
-    // A per-record look at that one address costs a millisecond on a 250-base job.
-    if ((blockIdx.x & 63u) == 0 && __ballot(fast_len > PLAIN_NARROW_MAX)) {
+template <bool COUNT>
+__global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, const u32 *__restrict__ contig,
+                                               const u32 *__restrict__ ref_start,
+                                               const u64 *__restrict__ seq_off,
+                                               const u32 *__restrict__ seq_len,
+                                               const u64 *__restrict__ cig_off,
+                                               const u32 *__restrict__ n_cig,
+                                               const u32 *__restrict__ cigar,
+                                               const u8 *__restrict__ seq,
+                                               const u64 *__restrict__ contig_off, u32 n_contigs,
+                                               const u32 *__restrict__ own,
+                                               u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
+                                               u32 *__restrict__ maxlen, u32 nwin, u32 *__restrict__ hist, u64 *status) {
+    __shared__ u32 h[COUNT ? COUNT_RANGE : 1];
+    __shared__ u32 later[PREP_LATER_MAX], n_later;
+    if (threadIdx.x == 0) n_later = 0;
+    if (COUNT)
+        for (u32 i = threadIdx.x; i < (u32)COUNT_RANGE; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    // a record's result: stored, and (COUNT) tallied in the windows it reaches
+    auto finish = [&](u64 a, u32 c, u32 rs, u32 g_out, u32 nk_out, u32 fl_out) {
+        // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits
+        // is somebody else's -- validated like every record (all ranks report the same first bad record), then
+        // dropped.  The untrimmed span of the fast class errs on the side of keeping.
+        if (own && nk_out && c < n_contigs && ((u64)rs + nk_out <= own[2 * c] || rs >= own[2 * c + 1])) nk_out = 0;
+        gstart[a] = g_out;
+        nkeep[a] = nk_out | (fl_out << 30);  // kept entries (< 2^30) | class flags
+        if (COUNT && nk_out) {
+            const u32 w0 = g_out / (u32)TILE, w1 = min((g_out + nk_out - 1u) / (u32)TILE, nwin - 1u);
+            for (u32 w = w0; w <= w1; w++) atomicAdd(&h[w], 1u);
+        }
+    };
+    auto general = [&](u64 a, u32 c, u32 nc, u32 sl, u32 rs, u64 co, u64 c_lo, u64 c_hi) {
+        u32 g_out = 0, nk_out = 0;
+        u8 fl_out = 0;
+        if (c >= n_contigs) report(status, a, DE_BAD_CONTIG);
+        else if (nc == 0) report(status, a, DE_BAD_RUN);
+        else prep_general(a, rs, sl, seq_off[a], cigar + co, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+        finish(a, c, rs, g_out, nk_out, fl_out);
+    };
+    u32 fast_len = 0;  // the longest fast-class read this thread saw: picks the lane-group width of k_tile's plain class
+    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += (u64)PP_PREP_UNROLL * blockDim.x) {
+        u32 c[PP_PREP_UNROLL], nc[PP_PREP_UNROLL], sl[PP_PREP_UNROLL], rs[PP_PREP_UNROLL];
+        u64 co[PP_PREP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PP_PREP_UNROLL; u++) {  // the independent loads of all records of the trip, ...
+            const u64 a = min(a0 + (u64)u * blockDim.x, hi - 1);  // clamped: the loads are unconditional
+            c[u] = contig[a]; nc[u] = n_cig[a]; sl[u] = seq_len[a]; rs[u] = ref_start[a]; co[u] = cig_off[a];
+        }
+        u64 c_lo[PP_PREP_UNROLL], c_hi[PP_PREP_UNROLL];
+        u32 op0[PP_PREP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PP_PREP_UNROLL; u++) {  // ... then the dependent ones
+            const u32 cc = min(c[u], n_contigs - 1u);
+            c_lo[u] = contig_off[cc]; c_hi[u] = contig_off[cc + 1];
+            op0[u] = nc[u] ? cigar[co[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PP_PREP_UNROLL; u++) {
+            const u64 a = a0 + (u64)u * blockDim.x;
+            if (a >= hi) break;
+            if (c[u] < n_contigs && nc[u] == 1 && (op0[u] & 15u) == PP_OP_M && (op0[u] >> 4) == sl[u] && sl[u] > 0 &&
+                sl[u] <= FAST_MAX_LEN && (u64)rs[u] + sl[u] <= c_hi[u] - c_lo[u]) {
+                // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
+                fast_len = max(fast_len, sl[u]);
+                finish(a, c[u], rs[u], (u32)(c_lo[u] + rs[u]), sl[u], 0u);
+            } else {
+                const u32 slot = atomicAdd(&n_later, 1u);
+                if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
+                else general(a, c[u], nc[u], sl[u], rs[u], co[u], c_lo[u], c_hi[u]);
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < min(n_later, PREP_LATER_MAX); i += blockDim.x) {
+        const u64 a = lo + later[i];
+        const u32 c = contig[a], cc = min(c, n_contigs - 1u);
+        general(a, c, n_cig[a], seq_len[a], ref_start[a], cig_off[a], contig_off[cc], contig_off[cc + 1]);
+    }
+    // the job's longest fast-class read, once per wave and only beyond the narrowest lane group (<= 160 bases); the
+    // word is read from L2, not from a possibly stale CU-local copy
+    if (__ballot(fast_len > PLAIN_NARROW_MAX)) {
         for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
         if ((threadIdx.x & 63u) == 0 && fast_len > __hip_atomic_load(maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(maxlen, fast_len);
+    }
+    if (COUNT) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nwin; i += blockDim.x) hist[(u64)blockIdx.x * nwin + i] = h[i];
     }
 }
 

@@ -388,13 +388,19 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         if (int rc = upload(ctx, ctx->b_own, ctx->emit.data(), ctx->emit.size() * sizeof(uint32_t), &p_own)) return rc;
         d_own = (const u32 *)p_own;
     }
-    if (n) {
-        timer_begin(ctx, "prep");
-        hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.contig,
-                           B.ref_start, B.k, (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off,
-                           B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own, d_gstart, d_nkeep, (u32 *)(d_meta + 9), d_status);
-        timer_end(ctx);
-    }
+    // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
+    // records of every block per window (two-level path: k_count, per range of windows)
+    const bool fused_count = !two_level && nranges == 1;
+    timer_begin(ctx, "prep");
+    if (!fused_count)
+        hipLaunchKernelGGL(k_prep<false>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
+                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
+                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, (u32 *)nullptr, d_status);
+    else
+        hipLaunchKernelGGL(k_prep<true>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
+                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
+                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, d_hist, d_status);
+    timer_end(ctx);
     timer_begin(ctx, "bucket");
     if (two_level) {
         PP_HIPCHK(ctx, hipMemsetAsync(d_wincnt, 0, (size_t)nwin * 4, st));
@@ -416,8 +422,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                                (const u32 *)d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         }
     } else {
-        hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
-                           nwin, d_hist, d_wincnt);
+        if (!fused_count)  // one level forced beyond one LDS range of windows (tuning): counted range by range
+            hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
+                               nwin, d_hist, d_wincnt);
         hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, heavy_min,
                            d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
