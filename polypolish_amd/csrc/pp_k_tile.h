@@ -376,6 +376,50 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
     nG += (ro == ROW_G) ? same : 0u; nDel += (ro == ROW_DEL) ? same : 0u; nOth += (ro == ROW_OTH) ? same : 0u;
 }
 
+// ---- slow class with indels, the usual shape: at most four CIGAR runs and at most 256 kept entries --------------------
+// The runs come in scalar registers (fetched for all slow items of a batch at once), lane l owns entries l, l + 64,
+// l + 128, l + 192: one sweep over the runs decides for each of them whether it is a deletion, a multi-base key or one
+// read base (alignment.rs:175-201), ALL read bytes are then loaded together and tallied -- one memory round trip per
+// item, where walking run by run with the runs in memory took eight or nine dependent ones (measured: 1 % of such
+// reads cost k_tile 0.09 of its 0.49 ms).
+__device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int nkeep, u32 nc, u32 r0, u32 r1, u32 r2,
+                                           u32 r3, u32 kc, u32 lane) {
+    constexpr int SRC_NONE = -1, SRC_DEL = -2, SRC_OTH = -3;
+    int src[4] = {SRC_NONE, SRC_NONE, SRC_NONE, SRC_NONE};
+    int ent0 = 0;
+    u32 ro = 0;
+    for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
+        const u32 op = r == 0 ? r0 : (r == 1 ? r1 : (r == 2 ? r2 : r3)), len = op >> 4, o = op & 15u;
+        if (o == PP_OP_I) { ro += len; continue; }
+        u32 ins = 0;  // bases inserted right after this run: they extend its last entry
+        for (u32 q2 = r + 1; q2 < nc; q2++) {
+            const u32 op2 = q2 == 1 ? r1 : (q2 == 2 ? r2 : r3);
+            if ((op2 & 15u) != PP_OP_I) break;
+            ins += op2 >> 4;
+        }
+        const int a = max(ent0, -rel), b = min(min(ent0 + (int)len, nkeep), TILE - rel);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int q = (int)lane + 64 * t;
+            if (q < a || q >= b) continue;
+            const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
+            if (o == PP_OP_D) src[t] = ext ? (ins == 1 ? (int)ro : SRC_OTH) : SRC_DEL;
+            else src[t] = ext ? SRC_OTH : (int)ro + (q - ent0);
+        }
+        ent0 += (int)len;
+        if (o != PP_OP_D) ro += len;
+    }
+    u32 c[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = src[t] >= 0 ? (u32)s[src[t]] : 0u;  // all loads of the item in flight together
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (src[t] == SRC_NONE) continue;
+        const int row = src[t] >= 0 ? row_of(c[t]) : (src[t] == SRC_DEL ? ROW_DEL : ROW_OTH);
+        tile_add(cnt, row, rel + (int)lane + 64 * t, kc);
+    }
+}
+
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
 // The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
@@ -396,6 +440,10 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         const u32 my_flags = (my.y >> 16) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
         const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
+        // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
+        u64 sl_so = 0, sl_co = 0;
+        u32 sl_nc = 0;
+        if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         for (u32 first = 0; first < nb; first += C::IPP)
             plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
@@ -407,20 +455,42 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             fast_apply(cnt, asm_w, f, fast_load(A.seq, f, lane), lane);
         }
         u64 slow = __ballot(my_slow);
-        while (slow) {
-            const int j = __ffsll((long long)slow) - 1;
-            slow &= slow - 1;
-            const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j), idx = (u32)__builtin_amdgcn_readlane((int)my.w, j);
-            const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
-            const u32 kc = (ey >> 8) & 0xFFu;
-            const u8 *s = A.seq + A.seq_off[idx];
-            if (!((ey >> 16) & ENT_COMPLEX)) {
-                // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
-                const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-                for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
-            } else {
-                const u32 *cg = A.cigar + A.cig_off[idx];
-                const u32 nc = A.n_cig[idx];
+        if (slow) {
+            // the first four runs of every item with indels, again one item per lane
+            u32 rr0 = 0, rr1 = 0, rr2 = 0, rr3 = 0;
+            if (my_slow && (my_flags & ENT_COMPLEX)) {
+                const u32 *cg = A.cigar + sl_co;
+                rr0 = cg[0];
+                if (sl_nc > 1) rr1 = cg[1];
+                if (sl_nc > 2) rr2 = cg[2];
+                if (sl_nc > 3) rr3 = cg[3];
+            }
+            while (slow) {
+                const int j = __ffsll((long long)slow) - 1;
+                slow &= slow - 1;
+                const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j);
+                const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
+                const u32 kc = (ey >> 8) & 0xFFu;
+                const u64 so = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)sl_so, j) |
+                               ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(sl_so >> 32), j) << 32);
+                const u8 *s = A.seq + so;
+                if (!((ey >> 16) & ENT_COMPLEX)) {
+                    // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
+                    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+                    for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+                    continue;
+                }
+                const u32 nc = (u32)__builtin_amdgcn_readlane((int)sl_nc, j);
+                if (nc <= 4u && nkeep <= 256) {
+                    slow_short(cnt, s, rel, nkeep, nc, (u32)__builtin_amdgcn_readlane((int)rr0, j),
+                               (u32)__builtin_amdgcn_readlane((int)rr1, j), (u32)__builtin_amdgcn_readlane((int)rr2, j),
+                               (u32)__builtin_amdgcn_readlane((int)rr3, j), kc, lane);
+                    continue;
+                }
+                // many runs or a long read: run by run, with the runs read as they come
+                const u64 co = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)sl_co, j) |
+                               ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(sl_co >> 32), j) << 32);
+                const u32 *cg = A.cigar + co;
                 int ent0 = 0;
                 u64 ro = 0;
                 for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
