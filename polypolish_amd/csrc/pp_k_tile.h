@@ -423,7 +423,7 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
 // The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
-// hidden by the other 7 waves of the SIMD, not by software pipelining (which measured slower).
+// hidden by the other 7 waves of the SIMD, not by software pipelining of the passes (which measured slower).
 template <int GW>
 __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, u32 e0, u32 e1,
                                            u32 wave, u32 lane) {
@@ -434,9 +434,13 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + C::IPP - 1u) / C::IPP * C::IPP;
     const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
     if (lo_w >= hi_w) return;
+    // the records of the batch after the current one are asked for before the current one is worked on (2-5 % of the
+    // kernel: a wave's chain of dependent round trips is what its time consists of)
+    uint4 nxt = A.entA[lo_w + min(lane, min(C::BATCH, hi_w - lo_w) - 1u)];
     for (u32 eb = lo_w; eb < hi_w; eb += C::BATCH) {
         const u32 nb = min(C::BATCH, hi_w - eb);
-        const uint4 my = A.entA[eb + min(lane, nb - 1u)];
+        const uint4 my = nxt;
+        if (eb + C::BATCH < hi_w) nxt = A.entA[eb + C::BATCH + min(lane, min(C::BATCH, hi_w - eb - C::BATCH) - 1u)];
         const u32 my_flags = (my.y >> 16) & 0xFFu;
         const bool my_slow = lane < nb && my_flags != 0;
         const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
