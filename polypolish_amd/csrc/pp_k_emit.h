@@ -16,19 +16,35 @@ __device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32
     return 0;
 }
 
-__global__ __launch_bounds__(TILE_THREADS) void k_compact(const u8 *__restrict__ code, u64 G,
-                                                          const u64 *__restrict__ win_out,
-                                                          const MultiEnt *__restrict__ multi,
-                                                          const u32 *__restrict__ counters,
-                                                          u8 *__restrict__ out, const u64 *__restrict__ status) {
-    __shared__ u32 wsum[TILE_THREADS / 64];
+// One workgroup of 256 threads per window, eight consecutive positions per thread (one 8-byte load of their codes, and,
+// where every position emits exactly one byte -- nearly always -- one 8-byte store).
+constexpr int COMPACT_THREADS = TILE / 8;
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(const u8 *__restrict__ code, u64 G,
+                                                             const u64 *__restrict__ win_out,
+                                                             const MultiEnt *__restrict__ multi,
+                                                             const u32 *__restrict__ counters,
+                                                             u8 *__restrict__ out, const u64 *__restrict__ status) {
+    __shared__ u32 wsum[COMPACT_THREADS / 64];
     if (*status != ~0ull) return;
     const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const u64 p0 = (u64)w * TILE + 2ull * t;
+    const u64 p0 = (u64)w * TILE + 8ull * t;
     const u32 n_multi = counters[1];
-    const u8 c0 = (p0 < G) ? code[p0] : 0, c1 = (p0 + 1 < G) ? code[p0 + 1] : 0;
-    const u32 l0 = code_len(c0, (u32)p0, multi, n_multi), l1 = code_len(c1, (u32)(p0 + 1), multi, n_multi);
-    const u32 s = l0 + l1;
+    u8 c[8];
+    if (p0 + 8 <= G) {
+        const uint2 v = *(const uint2 *)(code + p0);  // p0 is a multiple of 8 and the code array is 256-byte aligned
+        __builtin_memcpy(c, &v, 8);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = (p0 + i < G) ? code[p0 + i] : (u8)0;
+    }
+    u32 len[8], s = 0;
+    bool all_one = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        len[i] = code_len(c[i], (u32)(p0 + i), multi, n_multi);
+        s += len[i];
+        all_one = all_one && c[i] != 0 && c[i] < 0x80u;
+    }
     u32 inc = s;  // inclusive scan within the wave
     for (int o = 1; o < 64; o <<= 1) {
         u32 v = __shfl_up(inc, o, 64);
@@ -38,41 +54,55 @@ __global__ __launch_bounds__(TILE_THREADS) void k_compact(const u8 *__restrict__
     __syncthreads();
     u32 base = 0;
     for (u32 i = 0; i < wave; i++) base += wsum[i];
-    const u64 off = win_out[w] + base + (inc - s);
-    if (c0 && c0 < 0x80u) out[off] = c0;
-    if (c1 && c1 < 0x80u) out[off + l0] = c1;
+    u64 off = win_out[w] + base + (inc - s);
+    if (all_one) {
+        __builtin_memcpy(out + off, c, 8);  // unaligned 8-byte store
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (c[i] && c[i] < 0x80u) out[off] = c[i];
+            off += len[i];
+        }
+    }
 }
 
-// threads [0, n_multi): copy a multi-byte winner into its reserved gap;
-// threads [n_multi, n_multi + n_contigs]: output offset of each contig start (and the total)
-__global__ __launch_bounds__(64) void k_finalize(const u8 *__restrict__ code, u64 G,
-                                                 const u64 *__restrict__ win_out, u32 nwin,
-                                                 const MultiEnt *__restrict__ multi,
-                                                 const u32 *__restrict__ counters,
-                                                 const u8 *__restrict__ seq,
-                                                 const u64 *__restrict__ contig_off, u32 n_contigs,
-                                                 u8 *__restrict__ out, u64 *__restrict__ ctg_out,
-                                                 const u64 *__restrict__ status) {
+// wave [0, n_multi): copies a multi-byte winner into its reserved gap;
+// waves [n_multi, n_multi + n_contigs]: output offset of each contig start (and the total).
+// The bytes emitted between the window's start and the position are added up by the lanes of the wave (a thread on
+// its own walked up to 2047 codes one dependent load after the other: 0.3 ms for the 100 contig starts of configs[3]).
+__global__ __launch_bounds__(256) void k_finalize(const u8 *__restrict__ code, u64 G,
+                                                  const u64 *__restrict__ win_out, u32 nwin,
+                                                  const MultiEnt *__restrict__ multi,
+                                                  const u32 *__restrict__ counters,
+                                                  const u8 *__restrict__ seq,
+                                                  const u64 *__restrict__ contig_off, u32 n_contigs,
+                                                  u8 *__restrict__ out, u64 *__restrict__ ctg_out,
+                                                  const u64 *__restrict__ status) {
     if (*status != ~0ull) return;
     const u32 n_multi = counters[1];
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_multi + n_contigs + 1u) return;
-    u64 gp;
-    if (t < n_multi) gp = multi[t].pos; else gp = contig_off[t - n_multi];
-    u64 off;
-    if (gp >= G) {
-        off = win_out[nwin];
-    } else {
-        const u32 w = (u32)(gp / TILE);
-        off = win_out[w];
-        for (u64 q = (u64)w * TILE; q < gp; q++) off += code_len(code[q], (u32)q, multi, n_multi);
-    }
-    if (t < n_multi) {
-        const u8 *s = seq + multi[t].off;
-        for (u32 b = 0; b < multi[t].len; b++)
-            if (s[b] != (u8)'-') out[off++] = s[b];
-    } else {
-        ctg_out[t - n_multi] = off;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n_todo = n_multi + n_contigs + 1u;
+    for (u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < n_todo; t += (gridDim.x * blockDim.x) >> 6) {
+        u64 gp;
+        if (t < n_multi) gp = multi[t].pos; else gp = contig_off[t - n_multi];
+        u64 off;
+        if (gp >= G) {
+            off = win_out[nwin];
+        } else {
+            const u32 w = (u32)(gp / TILE);
+            u32 part = 0;
+            for (u64 q = (u64)w * TILE + lane; q < gp; q += 64) part += code_len(code[q], (u32)q, multi, n_multi);
+            off = win_out[w] + wave_sum(part);
+        }
+        if (t < n_multi) {
+            if (lane == 0) {
+                const u8 *s = seq + multi[t].off;
+                for (u32 b = 0; b < multi[t].len; b++)
+                    if (s[b] != (u8)'-') out[off++] = s[b];
+            }
+        } else if (lane == 0) {
+            ctg_out[t - n_multi] = off;
+        }
     }
 }
 

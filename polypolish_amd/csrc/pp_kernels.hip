@@ -512,10 +512,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     timer_begin(ctx, "emit");
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
                        d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
-    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(TILE_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
+    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
                        (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, (u8 *)ctx->b_out.p, (const u64 *)d_status);
     const uint64_t nfin = ctx->cap_multi + nc + 1;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((nfin + 63) / 64)), dim3(64), 0, st, (const u8 *)T.code, (u64)G,
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4)), dim3(256), 0, st, (const u8 *)T.code, (u64)G,
                        (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters,
                        B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
     timer_end(ctx);
