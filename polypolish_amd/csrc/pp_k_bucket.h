@@ -9,16 +9,16 @@ namespace pp {
 // =============================================================================================
 // Two-level multisplit of the (alignment, window) items.  Level 1 scatters the items into COARSE buckets of
 // COARSE_WINDOWS windows: a block's items for one coarse bucket form one contiguous run (full-line writes),
-// where a direct scatter into the windows would be 16-byte writes all over HBM.  Level 2 (k_regroup) sorts a
-// coarse bucket into its windows inside a region small enough to stay in L2.
-//   k_count     per-block LDS histogram over the windows -> global per-window counts (atomics) and the
-//               block's per-coarse-bucket counts
-//   k_scan_cols column scan over the blocks of the coarse counts; k_scan: offsets of coarse buckets and windows
-//   k_fill      items -> coarse buckets (LDS cursors);  k_regroup  coarse bucket -> windows
+// where a direct scatter into the windows would be 16-byte writes all over HBM (and, on a 250 Mbp job, all over
+// more pages than the TLB holds).  Level 2 (k_regroup) sorts a coarse bucket into its windows inside a region
+// small enough to stay in L2, and that is also where the windows' counts and offsets come from.
+//   k_count     per-block LDS histogram over the windows -> the block's per-coarse-bucket counts
+//   k_scan_cols column scan over the blocks of the coarse counts; k_scan: offsets of the coarse buckets
+//   k_fill      items -> coarse buckets (LDS cursors);  k_regroup  coarse bucket -> windows (+ win_off)
 template <int CW>  // windows per coarse bucket; 1 = single level (k_fill writes the windows directly)
 __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__restrict__ gstart,
                                                 const u32 *__restrict__ nkeep, u32 nwin, u32 ncoarse,
-                                                u32 *__restrict__ hist_c, u32 *__restrict__ win_cnt) {
+                                                u32 *__restrict__ hist_c) {
     __shared__ u32 h[COUNT_RANGE];
     u32 range_lo = blockIdx.y * (u32)COUNT_RANGE;
     u32 range_n = min((u32)COUNT_RANGE, nwin - range_lo);
@@ -42,10 +42,6 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
         }
     }
     __syncthreads();
-    if (CW > 1) {  // the windows' own totals are needed as well (k_scan_cols only sees the coarse buckets)
-        for (u32 i = threadIdx.x; i < range_n; i += blockDim.x)
-            if (h[i]) atomicAdd(&win_cnt[range_lo + i], h[i]);
-    }
     const u32 c_lo = range_lo / (u32)CW, c_n = (range_n + CW - 1u) / (u32)CW;
     for (u32 c = threadIdx.x; c < c_n; c += blockDim.x) {
         u32 sum = 0;
@@ -66,11 +62,11 @@ __device__ __forceinline__ void note_heavy(u32 w, u32 cnt, u32 heavy_min, u32 *h
     win_heavy[w] = (u8)mark;
 }
 
-// two-level path: the windows' counts come from k_count's atomics
-__global__ __launch_bounds__(256) void k_heavy(u32 nwin, const u32 *__restrict__ win_cnt, u32 heavy_min,
+// two-level path: the windows' offsets come from k_regroup
+__global__ __launch_bounds__(256) void k_heavy(u32 nwin, const u32 *__restrict__ win_off, u32 heavy_min,
                                                u32 *__restrict__ heavy, u8 *__restrict__ win_heavy) {
     const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nwin) note_heavy(w, win_cnt[w], heavy_min, heavy, win_heavy);
+    if (w < nwin) note_heavy(w, win_off[w + 1] - win_off[w], heavy_min, heavy, win_heavy);
 }
 
 // win_heavy != nullptr (single-level path, the columns ARE the windows): also lists the heavy windows
@@ -193,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
             const u32 fl = fl4[u];
             for (u32 w = wa; w <= wb && w >= wa; w++) {
                 u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
-                // work item, 16 bytes (bits 20..22 of y carry the window's index inside its coarse bucket until
+                // work item, 16 bytes (bits 18..23 of y carry the window's index inside its coarse bucket until
                 // k_regroup has used it):
                 //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
                 //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                 uint4 e;
                 e.x = fl ? nk : (u32)so;
                 e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16) |
-                      ((w % (u32)CW) << 20);
+                      ((w % (u32)CW) << 18);
                 e.z = (u32)(int)((long long)g - (long long)w * TILE);
                 e.w = (u32)a;
                 entB[slot] = e;
@@ -210,40 +206,79 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
     }
 }
 
-// Level 2 of the multisplit: one workgroup per coarse bucket moves its items into their windows.  The
-// destination region (COARSE_WINDOWS windows) is small, so the 16-byte writes merge into full lines in L2.
-// Cursors are advanced once per wave and window (ballot + popcount), not once per item.
-__global__ __launch_bounds__(1024) void k_regroup(u32 nwin, const u32 *__restrict__ coarse_off,
-                                                  const u32 *__restrict__ win_off, const uint4 *__restrict__ entB,
+// Level 2 of the multisplit: one workgroup per coarse bucket counts its items per window, turns the counts into the
+// windows' offsets (win_off: nobody else computes them on this path) and moves the items into their windows.  The
+// destination region (COARSE_WINDOWS windows) is small, so the 16-byte writes merge into full lines in L2; the second
+// read of the bucket comes from L2 as well.
+template <int CW>  // 8: cursors advanced once per wave and window (ballot + popcount); 64: one LDS atomic per item
+__global__ __launch_bounds__(1024) void k_regroup(u32 nwin, u32 ncoarse, const u32 *__restrict__ coarse_off,
+                                                  u32 *__restrict__ win_off, const uint4 *__restrict__ entB,
                                                   uint4 *__restrict__ entA, u64 *__restrict__ status) {
-    __shared__ u32 cur[COARSE_WINDOWS];
+    static_assert(CW == 8 || CW == 64, "the sub-index has six bits; one wave scans the windows of a coarse bucket");
+    __shared__ u32 cnt[64], cur[64];
     if (*status != ~0ull) return;
-    const u32 c = blockIdx.x, lane = threadIdx.x & 63u;
-    if (threadIdx.x < (u32)COARSE_WINDOWS) {
-        const u32 w = c * (u32)COARSE_WINDOWS + threadIdx.x;
-        cur[threadIdx.x] = w < nwin ? win_off[w] : 0u;
-        if (w < nwin && win_off[w + 1] - win_off[w] >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+    const u32 c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const u32 lo = coarse_off[c], hi = coarse_off[c + 1];
+    if (tid < 64u) cnt[tid] = 0;
+    __syncthreads();
+    if (CW == 64) {
+        for (u32 i = lo + tid; i < hi; i += 1024) atomicAdd(&cnt[(entB[i].y >> 18) & 63u], 1u);
+    } else {
+        for (u32 i0 = lo + (tid & ~63u); i0 < hi; i0 += 1024) {
+            const u32 i = i0 + lane;
+            const bool valid = i < hi;
+            const u32 sub = valid ? (entB[i].y >> 18) & 63u : 0u;
+#pragma unroll
+            for (u32 t = 0; t < (u32)CW; t++) {
+                const u64 m = __ballot(valid && sub == t);
+                if (m && lane == 0) atomicAdd(&cnt[t], (u32)__popcll(m));
+            }
+        }
     }
     __syncthreads();
-    const u32 lo = coarse_off[c], hi = coarse_off[c + 1];
-    for (u32 i0 = lo + (threadIdx.x & ~63u); i0 < hi; i0 += blockDim.x) {
-        const u32 i = i0 + lane;
-        const bool valid = i < hi;
-        uint4 e = valid ? entB[i] : make_uint4(0, 0, 0, 0);
-        const u32 sub = (e.y >> 20) & 7u;
-        u32 slot = 0;
-#pragma unroll
-        for (u32 t = 0; t < (u32)COARSE_WINDOWS; t++) {
-            const u64 m = __ballot(valid && sub == t);
-            if (!m) continue;
-            u32 base = 0;
-            if (lane == (u32)__ffsll((long long)m) - 1u) base = atomicAdd(&cur[t], (u32)__popcll(m));
-            base = (u32)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
-            if (valid && sub == t) slot = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+    if (tid < 64u) {
+        const u32 v = cnt[tid];
+        u32 inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = (u32)__shfl_up((int)inc, o, 64);
+            if ((int)tid >= o) inc += t;
         }
-        if (valid) {
-            e.y &= ~(7u << 20);
+        const u32 first = lo + inc - v, w = c * (u32)CW + tid;
+        cur[tid] = first;
+        if (tid < (u32)CW && w < nwin) {
+            win_off[w] = first;
+            if (v >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);
+        }
+        if (c == ncoarse - 1u && tid == 0) win_off[nwin] = hi;
+    }
+    __syncthreads();
+    if (CW == 64) {
+        for (u32 i = lo + tid; i < hi; i += 1024) {
+            uint4 e = entB[i];
+            const u32 slot = atomicAdd(&cur[(e.y >> 18) & 63u], 1u);
+            e.y &= ~(63u << 18);
             entA[slot] = e;
+        }
+    } else {
+        for (u32 i0 = lo + (tid & ~63u); i0 < hi; i0 += 1024) {
+            const u32 i = i0 + lane;
+            const bool valid = i < hi;
+            uint4 e = valid ? entB[i] : make_uint4(0, 0, 0, 0);
+            const u32 sub = (e.y >> 18) & 63u;
+            u32 slot = 0;
+#pragma unroll
+            for (u32 t = 0; t < (u32)CW; t++) {
+                const u64 m = __ballot(valid && sub == t);
+                if (!m) continue;
+                u32 base = 0;
+                if (lane == (u32)__ffsll((long long)m) - 1u) base = atomicAdd(&cur[t], (u32)__popcll(m));
+                base = (u32)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+                if (valid && sub == t) slot = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            }
+            if (valid) {
+                e.y &= ~(63u << 18);
+                entA[slot] = e;
+            }
         }
     }
 }

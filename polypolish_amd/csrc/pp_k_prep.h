@@ -88,8 +88,9 @@ constexpr u32 PLAIN_NARROW_MAX = PP_PLAIN_ALIGNED ? 129u : 160u;  // = PlainCfg<
 // loop with one record per lane: inside the loop a single such record would hold its 63 neighbours for the several
 // dependent memory round trips of the CIGAR walk and the trim -- with 1 % of them in random places that is every other
 // wave (measured: half of the kernel's time).
-// COUNT: the block also tallies its records' windows in an LDS histogram (what k_count does as a pass of its own when
-// the windows do not fit one LDS range) and leaves its row of the blocks x windows matrix for k_scan_cols.
+// COUNT: the block also tallies its records' windows (single level) or coarse buckets of cw windows (two levels) in an
+// LDS histogram and leaves its row of the blocks x columns matrix for k_scan_cols; k_count does that as a pass of its
+// own only when the columns do not fit one LDS range.
 #ifndef PP_PREP_WAVES
 #define PP_PREP_WAVES 8
 #endif
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                                                const u64 *__restrict__ contig_off, u32 n_contigs,
                                                const u32 *__restrict__ own,
                                                u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
-                                               u32 *__restrict__ maxlen, u32 nwin, u32 *__restrict__ hist, u64 *status) {
+                                               u32 *__restrict__ maxlen, u32 nwin, u32 cw, u32 ncols,
+                                               u32 *__restrict__ hist, u64 *status) {
     __shared__ u32 h[COUNT ? COUNT_RANGE : 1];
     __shared__ u32 later[PREP_LATER_MAX], n_later;
     if (threadIdx.x == 0) n_later = 0;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         nkeep[a] = nk_out | (fl_out << 30);  // kept entries (< 2^30) | class flags
         if (COUNT && nk_out) {
             const u32 w0 = g_out / (u32)TILE, w1 = min((g_out + nk_out - 1u) / (u32)TILE, nwin - 1u);
-            for (u32 w = w0; w <= w1; w++) atomicAdd(&h[w], 1u);
+            for (u32 w = w0; w <= w1; w++) atomicAdd(&h[w / cw], 1u);  // per window, or per coarse bucket of cw windows
         }
     };
     auto general = [&](u64 a, u32 c, u32 nc, u32 sl, u32 rs, u64 co, u64 c_lo, u64 c_hi) {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     }
     if (COUNT) {
         __syncthreads();
-        for (u32 i = threadIdx.x; i < nwin; i += blockDim.x) hist[(u64)blockIdx.x * nwin + i] = h[i];
+        for (u32 i = threadIdx.x; i < ncols; i += blockDim.x) hist[(u64)blockIdx.x * ncols + i] = h[i];
     }
 }
 

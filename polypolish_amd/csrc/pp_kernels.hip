@@ -346,7 +346,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // vs two 0.21 ms (+ k_tile 4 % slower on the regrouped order); 250 Mbp: one level 6.8 ms vs two 4.1 ms.
     static const int forced_levels = getenv("PP_BUCKET_LEVELS") ? atoi(getenv("PP_BUCKET_LEVELS")) : 0;  // tuning / tests
     const bool two_level = forced_levels ? forced_levels == 2 : nranges > 1;
-    const uint32_t cw = two_level ? COARSE_WINDOWS : 1;
+    const uint32_t cw = !two_level ? 1 : (nwin >= COARSE_BIG_FROM ? COARSE_WINDOWS_BIG : COARSE_WINDOWS);
     const uint32_t ncoarse = (nwin + cw - 1) / cw;
     const uint32_t ncranges = (ncoarse + COUNT_RANGE - 1) / COUNT_RANGE;
     ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
@@ -390,41 +390,52 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     }
     // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
     // records of every block per window (two-level path: k_count, per range of windows)
-    const bool fused_count = !two_level && nranges == 1;
+    const bool fused_count = ncoarse <= (uint32_t)COUNT_RANGE;  // the columns (windows, or coarse buckets) fit one LDS range
     timer_begin(ctx, "prep");
     if (!fused_count)
         hipLaunchKernelGGL(k_prep<false>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
                            (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
-                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, (u32 *)nullptr, d_status);
+                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, (u32 *)nullptr, d_status);
     else
         hipLaunchKernelGGL(k_prep<true>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
                            (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
-                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, d_hist, d_status);
+                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, d_hist, d_status);
     timer_end(ctx);
     timer_begin(ctx, "bucket");
     if (two_level) {
-        PP_HIPCHK(ctx, hipMemsetAsync(d_wincnt, 0, (size_t)nwin * 4, st));
-        hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
-                           d_nkeep, nwin, ncoarse, d_hist, d_wincnt);
+        if (!fused_count) {  // more than 16384 coarse buckets (a 2 Gbp assembly): counted range by range
+            if (cw == (uint32_t)COARSE_WINDOWS_BIG)
+                hipLaunchKernelGGL(k_count<COARSE_WINDOWS_BIG>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk,
+                                   d_gstart, d_nkeep, nwin, ncoarse, d_hist);
+            else
+                hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                                   d_nkeep, nwin, ncoarse, d_hist);
+        }
         hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt, 0u,
                            (u32 *)nullptr, (u8 *)nullptr);
-        hipLaunchKernelGGL(k_heavy, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, (const u32 *)d_wincnt, heavy_min,
-                           d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
                            d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
-        hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
-                           d_winoff, (u64 *)nullptr, ~0ull, d_status);
-        if (n) {
-            hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
-                               d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
-                               (const u32 *)d_coff, d_entB, d_status);
-            hipLaunchKernelGGL(k_regroup, dim3(ncoarse), dim3(1024), 0, st, nwin, (const u32 *)d_coff,
-                               (const u32 *)d_winoff, (const uint4 *)d_entB, d_entA, d_status);
+        if (cw == (uint32_t)COARSE_WINDOWS_BIG) {
+            if (n)
+                hipLaunchKernelGGL(k_fill<COARSE_WINDOWS_BIG>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk,
+                                   d_gstart, d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse,
+                                   (const u32 *)d_hist, (const u32 *)d_coff, d_entB, d_status);
+            hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS_BIG>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
+                               (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
+        } else {
+            if (n)
+                hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
+                                   d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
+                                   (const u32 *)d_coff, d_entB, d_status);
+            hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
+                               (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         }
+        hipLaunchKernelGGL(k_heavy, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, (const u32 *)d_winoff, heavy_min,
+                           d_heavy, d_win_heavy);
     } else {
         if (!fused_count)  // one level forced beyond one LDS range of windows (tuning): counted range by range
             hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
-                               nwin, d_hist, d_wincnt);
+                               nwin, d_hist);
         hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, heavy_min,
                            d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
