@@ -576,8 +576,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
     // ---- (4) vote for the flagged positions; per-window sums are reduced in the block first ----
     const u32 *tal = A.slabs + (u64)slab * 6u * TILE;
     const u64 gw0 = (u64)w * TILE;
-    const u32 c_first = find_contig(A.contig_off, A.n_contigs, gw0);
-    const bool one_contig = c_first == find_contig(A.contig_off, A.n_contigs, min(gw0 + TILE, A.G) - 1);
+    const u32 c_first = find_contig_wave(A.contig_off, A.n_contigs, gw0, lane);
+    const bool one_contig = c_first == find_contig_wave(A.contig_off, A.n_contigs, min(gw0 + TILE, A.G) - 1, lane);
     u32 my_len = 0, my_changed = 0, my_zero = 0;
     u64 my_depth = 0;
     for (int h = 0; h < (pos_wave ? PPL : 0); h++) {
