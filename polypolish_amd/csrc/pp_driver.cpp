@@ -144,6 +144,7 @@ static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
                              const uint64_t *n_pass, bool host_ingest_only = false);
+extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes);
 extern "C" int pp_ingest_fail_cut_(const pp_ingest *I, uint64_t *cut);
 extern "C" int pp_ingest_sam_prefix_(pp_ingest *I, const char *path, uint64_t cut, const uint8_t *pass, uint64_t n_pass,
                                      pp_sam_counts *counts, char *err, size_t errlen);
@@ -203,6 +204,14 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             return set_err(ctx, PP_ERR_QUIT, err);
         }
 
+    // The device tokenizer uploads the SAM text as it is: map the files and pre-fault the mappings NOW, on background
+    // threads, while the HIP runtime is still initialising (a copy out of an untouched mapping runs at a quarter of
+    // the link's rate).
+    const bool dev_ingest = n_ctx == 1 && !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
+    if (dev_ingest)
+        for (int i = 0; i < n_sams; i++) pph::prefetch_file(sams[i]);
+    struct DropPrefetched { ~DropPrefetched() { pph::prefetch_drop_all(); } } drop_prefetched;
+
     // starting_message, polish.rs:41-73
     log("\nStarting Polypolish polish\n%s\n\nInput assembly:\n  %s\n\nInput short-read alignments:\n", pp_version(), assembly);
     for (int i = 0; i < n_sams; i++) log("  %s\n", sams[i]);
@@ -231,7 +240,6 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
     // parse) with PP_DEVICE_INGEST=0 and with --debug (the TSV needs the read bytes on the host)
     log("Loading alignments\n");
-    const bool dev_ingest = !multi && !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
     // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
@@ -264,6 +272,14 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     };
     rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
                     : (stream_adds ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
+    if (rc == PP_OK && dev_ingest) {
+        uint64_t largest = 0;
+        for (int i = 0; i < n_sams; i++) {
+            struct stat st;
+            if (stat(sams[i], &st) == 0 && S_ISREG(st.st_mode)) largest = std::max<uint64_t>(largest, (uint64_t)st.st_size);
+        }
+        if (largest) rc = pp_dev_ingest_reserve_text_(dg, largest);
+    }
     uint64_t alignment_total = 0, used_total = 0;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;

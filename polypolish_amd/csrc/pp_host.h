@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -77,6 +78,81 @@ inline unsigned host_threads(size_t text_bytes) {
     return std::max(1u, std::min({std::thread::hardware_concurrency(), 64u, (unsigned)(text_bytes / (4u << 20)) + 1u}));
 }
 
+// Pre-faulting a file mapping (page-cache pages into this process's page tables) with a few threads.  A host-to-device
+// copy out of a mapping nobody has touched faults it in page by page, 4 KiB at a time: 13 GB/s instead of the 56 GB/s
+// the link delivers (measured on a 1.2 GB SAM file, tools/microbench/h2d2.hip: 89 ms against 3 + 21 ms).
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+inline void populate_mapping(void *map, size_t size, unsigned threads = 8) {
+    if (!map || !size) return;
+    threads = std::max(1u, std::min(threads, (unsigned)(size >> 24) + 1u));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back([=] {
+            const size_t page = 4096;
+            size_t a = (size / threads * t) & ~(page - 1), b = t + 1 == threads ? size : (size / threads * (t + 1)) & ~(page - 1);
+            if (b <= a) return;
+            if (madvise((char *)map + a, b - a, MADV_POPULATE_READ) == 0) return;
+            volatile char sink = 0;  // kernels before 5.14: touch every page
+            for (size_t q = a; q < b; q += page) sink += ((const volatile char *)map)[q];
+            (void)sink;
+        });
+    for (auto &x : th) x.join();
+}
+
+// Files opened ahead of their use (the driver does this while the HIP runtime initialises): mapped, and pre-faulted by a
+// background thread.  FileText::open_file adopts the mapping of a path that was prefetched.
+struct PrefetchedFile {
+    std::string path;
+    void *map = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    std::thread worker;
+};
+inline std::mutex &prefetch_mutex() { static std::mutex m; return m; }
+inline std::vector<PrefetchedFile *> &prefetch_list() { static std::vector<PrefetchedFile *> v; return v; }
+inline void prefetch_file(const char *path) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); return; }
+    void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) { ::close(fd); return; }
+    PrefetchedFile *f = new PrefetchedFile;
+    f->path = path; f->map = map; f->size = (size_t)st.st_size; f->fd = fd;
+    f->worker = std::thread([f] { populate_mapping(f->map, f->size); });
+    std::lock_guard<std::mutex> lock(prefetch_mutex());
+    prefetch_list().push_back(f);
+}
+inline PrefetchedFile *prefetch_take(const char *path) {  // nullptr if the path was not prefetched
+    PrefetchedFile *f = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(prefetch_mutex());
+        auto &v = prefetch_list();
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i]->path == path) { f = v[i]; v.erase(v.begin() + (long)i); break; }
+    }
+    if (f && f->worker.joinable()) f->worker.join();
+    return f;
+}
+inline void prefetch_drop_all() {  // whatever was prefetched and never opened
+    for (;;) {
+        PrefetchedFile *f = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(prefetch_mutex());
+            auto &v = prefetch_list();
+            if (v.empty()) return;
+            f = v.back();
+            v.pop_back();
+        }
+        if (f->worker.joinable()) f->worker.join();
+        munmap(f->map, f->size);
+        ::close(f->fd);
+        delete f;
+    }
+}
+
 // A whole file as read-only bytes: mmap for regular files, read() for pipes.
 struct FileText {
     const char *text = nullptr;
@@ -95,6 +171,12 @@ struct FileText {
         fd = -1;
     }
     bool open_file(const char *path) {
+        if (PrefetchedFile *f = prefetch_take(path)) {  // opened, mapped and pre-faulted ahead of time
+            map = f->map; size = f->size; fd = f->fd;
+            text = (const char *)map;
+            delete f;
+            return true;
+        }
         fd = ::open(path, O_RDONLY);
         if (fd < 0) return false;
         struct stat st;

@@ -470,6 +470,14 @@ static int describe_error(pp_dev_ingest *D, const char *path, const char *text, 
     return ctx->fail(rc, "%s", err);
 }
 
+// room for the text of the largest file of the job, once (internal: the driver knows the sizes; a text buffer that grows
+// from file to file is fresh device memory every time, touched for the first time by the upload)
+extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes) {
+    if (!D) return PP_ERR_ARG;
+    const u64 n_blk = (bytes + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
+    return pp::dev_ensure(D->ctx, D->d_text, (size_t)(padded + 64));
+}
+
 extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_counts *counts) {
     return pp_dev_ingest_sam_filtered(D, path, nullptr, 0, counts);
 }
