@@ -19,14 +19,13 @@ __device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32
 // One workgroup of 256 threads per window, eight consecutive positions per thread (one 8-byte load of their codes, and,
 // where every position emits exactly one byte -- nearly always -- one 8-byte store).
 constexpr int COMPACT_THREADS = TILE / 8;
-__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(const u8 *__restrict__ code, u64 G,
-                                                             const u64 *__restrict__ win_out,
-                                                             const MultiEnt *__restrict__ multi,
-                                                             const u32 *__restrict__ counters,
-                                                             u8 *__restrict__ out, const u64 *__restrict__ status) {
+__device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ code, u64 G,
+                                               const u64 *__restrict__ win_out,
+                                               const MultiEnt *__restrict__ multi,
+                                               const u32 *__restrict__ counters,
+                                               u8 *__restrict__ out) {
     __shared__ u32 wsum[COMPACT_THREADS / 64];
-    if (*status != ~0ull) return;
-    const u32 w = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u64 p0 = (u64)w * TILE + 8ull * t;
     const u32 n_multi = counters[1];
     u8 c[8];
@@ -70,19 +69,17 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact(const u8 *__restric
 // waves [n_multi, n_multi + n_contigs]: output offset of each contig start (and the total).
 // The bytes emitted between the window's start and the position are added up by the lanes of the wave (a thread on
 // its own walked up to 2047 codes one dependent load after the other: 0.3 ms for the 100 contig starts of configs[3]).
-__global__ __launch_bounds__(256) void k_finalize(const u8 *__restrict__ code, u64 G,
-                                                  const u64 *__restrict__ win_out, u32 nwin,
-                                                  const MultiEnt *__restrict__ multi,
-                                                  const u32 *__restrict__ counters,
-                                                  const u8 *__restrict__ seq,
-                                                  const u64 *__restrict__ contig_off, u32 n_contigs,
-                                                  u8 *__restrict__ out, u64 *__restrict__ ctg_out,
-                                                  const u64 *__restrict__ status) {
-    if (*status != ~0ull) return;
+__device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, const u8 *__restrict__ code, u64 G,
+                                                 const u64 *__restrict__ win_out, u32 nwin,
+                                                 const MultiEnt *__restrict__ multi,
+                                                 const u32 *__restrict__ counters,
+                                                 const u8 *__restrict__ seq,
+                                                 const u64 *__restrict__ contig_off, u32 n_contigs,
+                                                 u8 *__restrict__ out, u64 *__restrict__ ctg_out) {
     const u32 n_multi = counters[1];
     const u32 lane = threadIdx.x & 63u;
     const u32 n_todo = n_multi + n_contigs + 1u;
-    for (u32 t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < n_todo; t += (gridDim.x * blockDim.x) >> 6) {
+    for (u32 t = first_wave; t < n_todo; t += n_waves) {
         u64 gp;
         if (t < n_multi) gp = multi[t].pos; else gp = contig_off[t - n_multi];
         u64 off;
@@ -103,6 +100,24 @@ __global__ __launch_bounds__(256) void k_finalize(const u8 *__restrict__ code, u
         } else if (lane == 0) {
             ctg_out[t - n_multi] = off;
         }
+    }
+}
+
+// One launch for both: blocks [0, nwin) compact their window, the blocks behind them finalize (the two touch different
+// bytes of the output and read the same inputs).
+__global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__ code, u64 G, const u64 *__restrict__ win_out,
+                                                          u32 nwin, const MultiEnt *__restrict__ multi,
+                                                          const u32 *__restrict__ counters, const u8 *__restrict__ seq,
+                                                          const u64 *__restrict__ contig_off, u32 n_contigs,
+                                                          u8 *__restrict__ out, u64 *__restrict__ ctg_out,
+                                                          const u64 *__restrict__ status) {
+    if (*status != ~0ull) return;
+    if (blockIdx.x < nwin) {
+        compact_window(blockIdx.x, code, G, win_out, multi, counters, out);
+    } else {
+        constexpr u32 WPB = COMPACT_THREADS / 64;
+        finalize_entries((blockIdx.x - nwin) * WPB + (threadIdx.x >> 6), (gridDim.x - nwin) * WPB, code, G, win_out, nwin, multi,
+                         counters, seq, contig_off, n_contigs, out, ctg_out);
     }
 }
 

@@ -55,7 +55,9 @@ struct ExactArgs {
     u32 cap_flag;
     u32 *flag_pos_w;         // global replay list (k_exact2 appends key-table overflows)
     u32 *flag_cov_w;
-    u64 *scr_need;
+    u64 *flag_scr_w;
+    u64 *scr_need;       // replay scratch handed out so far (a listed position takes its stretch as it is listed)
+    u64 cap_scr;
     const u32 *flag_bits;
     const u32 *win_nflag;
     const u32 *win_slab;
@@ -105,6 +107,10 @@ __device__ void exact_one(const ExactArgs &A, u32 f);
 
 __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
     if (*A.status != ~0ull) return;
+    if (*A.scr_need > A.cap_scr) {  // the scratch is too small: the host grows it and reruns
+        if (blockIdx.x == 0 && threadIdx.x == 0) report(A.status, *A.scr_need, DE_CAPACITY);
+        return;
+    }
     const u32 n_flagged = A.counters[0];
     for (u32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_flagged; f += gridDim.x * blockDim.x) exact_one(A, f);
 }
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
                 const u32 ntot = tal0[0 * TILE + p] + tal0[1 * TILE + p] + tal0[2 * TILE + p] + tal0[3 * TILE + p] +
                                  tal0[4 * TILE + p] + tal0[5 * TILE + p];
                 const u32 slot = atomicAdd(&A.counters[0], 1u);
-                atomicAdd(A.scr_need, (u64)ntot);
-                if (slot < A.cap_flag) { A.flag_pos_w[slot] = w * (u32)TILE + p; A.flag_cov_w[slot] = ntot; }
+                const u64 scr_at = atomicAdd(A.scr_need, (u64)ntot);
+                if (slot < A.cap_flag) { A.flag_pos_w[slot] = w * (u32)TILE + p; A.flag_cov_w[slot] = ntot; A.flag_scr_w[slot] = scr_at; }
                 else report(A.status, slot, DE_CAPACITY_LATE);
             }
             return;
@@ -593,8 +599,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         if (vo.status != PP_ST_LOW_DEPTH && nOth > 0 && nOth >= vo.ithr) {
             // a string-keyed tally could reach a threshold: full replay by the thread-serial kernel
             const u32 slot = atomicAdd(&A.counters[0], 1u);
-            atomicAdd(A.scr_need, (u64)ntot);
-            if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ntot; }
+            const u64 scr_at = atomicAdd(A.scr_need, (u64)ntot);
+            if (slot < A.cap_flag) { A.flag_pos_w[slot] = gp; A.flag_cov_w[slot] = ntot; A.flag_scr_w[slot] = scr_at; }
             else report(A.status, slot, DE_CAPACITY_LATE);
             continue;
         }

@@ -33,6 +33,7 @@ struct TileArgs {
     u32 cap_slabs;
     u32 *flag_pos;
     u32 *flag_cov;
+    u64 *flag_scr;  // per listed position: where its covering alignments go in the replay scratch
     u64 *scr_need;  // replay scratch the listed positions will need (sum of their coverage), counted past cap_flag too
     ContigStatsDev *stats;
     const u32 *maxlen;  // longest fast-class read (written by k_prep)
@@ -748,10 +749,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             if (to_list) {
                 // bucket too large for the wave-per-position replay: global list for k_exact
                 const u32 slot = atomicAdd(&A.counters[0], 1u);
-                atomicAdd(A.scr_need, (u64)ntot);
+                const u64 scr_at = atomicAdd(A.scr_need, (u64)ntot);  // its stretch of the replay scratch
                 if (slot < A.cap_flag) {
                     A.flag_pos[slot] = (u32)gp;
                     A.flag_cov[slot] = ntot;
+                    A.flag_scr[slot] = scr_at;
                 } else {
                     report(A.status, slot, DE_CAPACITY_LATE);
                 }

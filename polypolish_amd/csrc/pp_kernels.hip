@@ -158,13 +158,18 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
         return ctx->fail(PP_ERR_LIMIT, "assembly of %llu bp exceeds the 2^32-4096 bp limit of this version",
                          (unsigned long long)G);
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the contig table goes to the device unless the device already holds this very table (the job before was on the
+    // same assembly: rounds of polishing, the bench's steps)
+    const bool same_table = ctx->b_contig_off.p && ctx->contig_off.size() == (size_t)n_contigs + 1 &&
+                            memcmp(ctx->contig_off.data(), contig_off, ((size_t)n_contigs + 1) * sizeof(uint64_t)) == 0;
     ctx->n_contigs = n_contigs;
     ctx->contig_off.assign(contig_off, contig_off + n_contigs + 1);
     ctx->G = G;
     ctx->params = *params;
     const void *d;
-    int rc = upload(ctx, ctx->b_contig_off, contig_off, (n_contigs + 1) * sizeof(uint64_t), &d);
-    if (rc) return rc;
+    int rc = PP_OK;
+    if (!same_table) rc = upload(ctx, ctx->b_contig_off, contig_off, (n_contigs + 1) * sizeof(uint64_t), &d);
+    if (rc) { ctx->contig_off.clear(); return rc; }
     if (bases_mem == PP_MEM_DEVICE) {
         ctx->d_bases = bases;
     } else {
@@ -461,6 +466,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.stats = d_stats;
     T.maxlen = (const u32 *)(d_meta + 9);
     T.scr_need = d_meta + 10;
+    T.flag_scr = (u64 *)ctx->b_flag_scr.p;
     T.seq_bytes = B.seq_bytes;
     T.own = d_own;
     T.heavy = d_heavy; T.win_heavy = d_win_heavy; T.hslab = (u32 *)ctx->b_hslab.p;
@@ -497,7 +503,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
     E.win_slab = T.win_slab; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
     E.ents_cursor = d_meta + 6;
-    E.scr_need = d_meta + 10;
+    E.scr_need = d_meta + 10; E.cap_scr = (u64)ctx->cap_scr; E.flag_scr_w = d_scr;
     E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
@@ -514,8 +520,6 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, HEAVY_SUB>), dim3(HEAVY_SLOTS * HEAVY_SUB), dim3(1024), 0, st, E, nwin);
-    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.flag_cov, (u64)0, (const u32 *)d_counters,
-                       d_scr, d_meta + 4, (u64)ctx->cap_scr, d_status);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
     timer_end(ctx);
 
@@ -523,12 +527,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     timer_begin(ctx, "emit");
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
                        d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
-    hipLaunchKernelGGL(k_compact, dim3(nwin), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout,
-                       (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, (u8 *)ctx->b_out.p, (const u64 *)d_status);
-    const uint64_t nfin = ctx->cap_multi + nc + 1;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4)), dim3(256), 0, st, (const u8 *)T.code, (u64)G,
-                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters,
-                       B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
+    const uint64_t nfin = ctx->cap_multi + nc + 1;  // multi-byte winners + contig starts: one wave each, grid-stride
+    const unsigned fin_blocks = (unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4);
+    hipLaunchKernelGGL(k_emit, dim3(nwin + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G,
+                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc,
+                       (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
     timer_end(ctx);
     PP_HIPCHK(ctx, hipGetLastError());
 
@@ -580,7 +583,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         };
         grow(ctx->cap_ent, meta[3], "work items");
         grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G), "listed positions");
-        grow(ctx->cap_scr, std::max(meta[4], meta[10]), "replay scratch");
+        grow(ctx->cap_scr, meta[10], "replay scratch");
         grow(ctx->cap_multi, cnt[1], "multi-byte winners");
         grow(ctx->cap_slabs, cnt[3], "tally slabs");
         grow(ctx->cap_ents, meta[6], "ordered replay items");
