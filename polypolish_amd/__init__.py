@@ -559,6 +559,39 @@ class Context:
     def polish_finish(self):
         self._chk(lib().pp_polish_finish(self._h))
 
+    def prepared_job(self, contig_off, bases_ptr, bases_mem, n_aln, ptrs: dict, seq_bytes, n_cig_total, mem,
+                     min_depth=5, fraction_valid=0.5, fraction_invalid=0.2, emit=None):
+        """begin + (set_emit) + add + finish of ONE job with every argument marshalled once: returns run(), which makes
+        the three (four) C calls and nothing else.  For callers that repeat a job on resident data (bench.py's steps): the
+        Python side of polish_begin / polish_add_ptrs costs tens of microseconds per call, during which the GPU idles."""
+        L = lib()
+        off = np.ascontiguousarray(contig_off, dtype=np.uint64)
+        p = Params(min_depth, fraction_valid, fraction_invalid)
+        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+        n_contigs, G = len(off) - 1, int(off[-1])
+        h, off_p, p_ref, b_ref = self._h, off.ctypes.data, C.byref(p), C.byref(b)
+        begin, add, finish, set_emit = L.pp_polish_begin, L.pp_polish_add, L.pp_polish_finish, L.pp_polish_set_emit
+        if emit is not None:
+            e = np.ascontiguousarray(emit, dtype=np.uint64).reshape(n_contigs, 2)
+            lo, hi = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+            lo_p, hi_p = lo.ctypes.data, hi.ctypes.data
+        keep = (off, p, b, emit is not None and (lo, hi))  # the C side reads these during the calls
+
+        def run():
+            self._n_contigs, self._G = n_contigs, G
+            rc = begin(h, n_contigs, off_p, bases_ptr, bases_mem, p_ref)
+            if rc == 0 and emit is not None:
+                rc = set_emit(h, lo_p, hi_p)
+            if rc == 0:
+                rc = add(h, b_ref, mem)
+            if rc == 0:
+                rc = finish(h)
+            if rc:
+                self._chk(rc)
+        run._keep = keep
+        return run
+
     def result_size(self):
         n = C.c_uint64()
         self._chk(lib().pp_polish_result_size(self._h, C.byref(n)))
