@@ -29,6 +29,12 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
     u32 pad;
 };
 
+// the job's metadata block: word 0 is the status ("no error" = all ones: errors are combined with atomicMin), the
+// counters and sizes behind it start at zero -- one launch where two memsets left a gap between them
+__global__ void k_meta_init(u64 *meta, u32 words) {
+    for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
+}
+
 __device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {
     atomicMin(status, (idx << 8) | (u64)code);
 }

@@ -85,8 +85,9 @@ void timer_begin(pp_ctx *ctx, const char *name) {
     if (ctx->event_pool.size() >= 2) {
         t.stop = ctx->event_pool.back(); ctx->event_pool.pop_back();
         t.start = ctx->event_pool.back(); ctx->event_pool.pop_back();
-    } else if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
-        return;
+    } else if (hipEventCreateWithFlags(&t.start, hipEventReleaseToDevice) != hipSuccess ||
+               hipEventCreateWithFlags(&t.stop, hipEventReleaseToDevice) != hipSuccess) {
+        return;  // (device-scope release: the record does not flush the caches to system scope -- HIP's flag for timing)
     }
     (void)hipEventRecord(t.start, ctx->stream);
     ctx->timers.push_back(t);
@@ -371,8 +372,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     u32 *d_counters = (u32 *)(d_meta + 1);
     u64 *d_ctg_out = d_meta + 16;
     ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
-    PP_HIPCHK(ctx, hipMemsetAsync(d_meta, 0, meta_words * 8, st));
-    PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
+    hipLaunchKernelGGL(k_meta_init, dim3(1), dim3(256), 0, st, d_meta, (u32)meta_words);  // zeros, status word = "no error"
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
     u8 *d_win_heavy = (u8 *)ctx->b_win_heavy.p;
     // a window is heavy from 1.25x the average number of items on (records per window: a few per cent below the items);
