@@ -113,9 +113,10 @@ struct PrefetchedFile {
 inline std::mutex &prefetch_mutex() { static std::mutex m; return m; }
 inline std::vector<PrefetchedFile *> &prefetch_list() { static std::vector<PrefetchedFile *> v; return v; }
 inline void prefetch_file(const char *path) {
+    struct stat st;
+    if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return;  // never open a pipe just to look at it
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return;
-    struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); return; }
     void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (map == MAP_FAILED) { ::close(fd); return; }

@@ -71,6 +71,12 @@ RECORD_CASES = {
                        sub_rate=0.0005),
     "many_N": dict(seed=9, contig_lens=(20_000,), coverage=30, n_rate=0.2),
     "big_k": dict(seed=10, contig_lens=(20_000,), coverage=40, k_choices=(1, 1024, 2048, 4096, 1000)),
+    # every read has an indel: more non-bulk records per block of k_prep than its LDS list holds (they are then handled
+    # on the spot), and k_tile's register path for short CIGARs on every item
+    "all_indels": dict(seed=11, contig_lens=(60_000,), coverage=100, indel_read_frac=1.0, k_choices=(1, 2, 3)),
+    # 5000 contigs: three rounds of the wave's 64-ary contig search, windows that span a dozen contigs
+    "many_contigs": dict(seed=12, contig_lens=(300,) * 4990 + (2048, 2049, 4096, 700, 301, 5000, 333, 4097, 310, 999),
+                         coverage=25, read_len=100, indel_read_frac=0.05, k_choices=(1, 1, 3)),
 }
 
 
