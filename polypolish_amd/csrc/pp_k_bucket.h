@@ -103,34 +103,52 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
 
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
 // n_ptr (optional) overrides n with a count held on the device; the total is also stored to *total_out;
-// a total above `limit` (capacity of the buffer the offsets index into) aborts the job with DE_CAPACITY
+// a total above `limit` (capacity of the buffer the offsets index into) aborts the job with DE_CAPACITY.
+// Tiles of 4096 values, four per thread in one 16-byte load: coalesced, and 30 trips for the 122 K windows of a 250 Mbp
+// job where a thread walking its own 120-value stretch took 114 us.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, const u32 *__restrict__ n_ptr,
                                                T *__restrict__ out, u64 *__restrict__ total_out, u64 limit,
                                                u64 *status) {
-    __shared__ u64 part[1024];
+    __shared__ u64 wsum[16];
     if (*status != ~0ull) return;
     if (n_ptr) n = *n_ptr;
-    u32 t = threadIdx.x;
-    u64 per = (n + 1023) / 1024;
-    u64 lo = min(n, (u64)t * per), hi = min(n, lo + per);
-    u64 s = 0;
-    for (u64 i = lo; i < hi; i++) s += in[i];
-    part[t] = s;
-    __syncthreads();
-    for (u32 off = 1; off < 1024; off <<= 1) {
-        u64 v = (t >= off) ? part[t - off] : 0;
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    u64 carry = 0;
+    for (u64 base = 0; base < n; base += 4096) {
+        const u64 i0 = base + 4ull * t;
+        u32 v[4] = {0, 0, 0, 0};
+        if (i0 + 4 <= n) {
+            const uint4 q = *(const uint4 *)(in + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i0 + k < n) v[k] = in[i0 + k];
+        }
+        const u64 s = (u64)v[0] + v[1] + v[2] + v[3];
+        u64 inc = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u64 x = (u64)__shfl_up((long long)inc, o, 64);
+            if ((int)lane >= o) inc += x;
+        }
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        part[t] += v;
+        u64 before = carry + inc - s, tile = 0;
+        for (u32 i = 0; i < 16; i++) {
+            const u64 ws = wsum[i];
+            if (i < wave) before += ws;
+            tile += ws;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) out[i0 + k] = (T)before;
+            before += v[k];
+        }
+        carry += tile;
         __syncthreads();
     }
-    u64 run = part[t] - s;
-    for (u64 i = lo; i < hi; i++) {
-        out[i] = (T)run;
-        run += in[i];
-    }
-    if (t == 1023) {
-        const u64 total = part[1023];
+    if (t == 0) {
+        const u64 total = carry;
         out[n] = (T)total;
         if (total_out) *total_out = total;
         if (sizeof(T) == 4 && total > 0xFFFFFFFFull) report(status, 0, DE_OVERFLOW);

@@ -25,6 +25,7 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
                                                const u32 *__restrict__ counters,
                                                u8 *__restrict__ out) {
     __shared__ u32 wsum[COMPACT_THREADS / 64];
+    if (win_out[w + 1] == win_out[w]) return;  // nothing to emit (a window of another rank, or all deletions)
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u64 p0 = (u64)w * TILE + 8ull * t;
     const u32 n_multi = counters[1];
@@ -88,7 +89,8 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
         } else {
             const u32 w = (u32)(gp / TILE);
             u32 part = 0;
-            for (u64 q = (u64)w * TILE + lane; q < gp; q += 64) part += code_len(code[q], (u32)q, multi, n_multi);
+            if (win_out[w + 1] != win_out[w])  // (a window that emits nothing may be one nobody worked on: no codes there)
+                for (u64 q = (u64)w * TILE + lane; q < gp; q += 64) part += code_len(code[q], (u32)q, multi, n_multi);
             off = win_out[w] + wave_sum(part);
         }
         if (t < n_multi) {
@@ -105,18 +107,31 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
 
 // One launch for both: blocks [0, nwin) compact their window, the blocks behind them finalize (the two touch different
 // bytes of the output and read the same inputs).
+// n_work = windows to compact: all of them, or (sharded job, own_win: see k_tile) the ones this context works on.
 __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__ code, u64 G, const u64 *__restrict__ win_out,
-                                                          u32 nwin, const MultiEnt *__restrict__ multi,
+                                                          u32 nwin, u32 n_work, const u32 *__restrict__ own_win,
+                                                          const MultiEnt *__restrict__ multi,
                                                           const u32 *__restrict__ counters, const u8 *__restrict__ seq,
                                                           const u64 *__restrict__ contig_off, u32 n_contigs,
                                                           u8 *__restrict__ out, u64 *__restrict__ ctg_out,
                                                           const u64 *__restrict__ status) {
     if (*status != ~0ull) return;
-    if (blockIdx.x < nwin) {
-        compact_window(blockIdx.x, code, G, win_out, multi, counters, out);
+    if (blockIdx.x < n_work) {
+        u32 w = blockIdx.x;
+        if (own_win) {
+            const u32 nr = own_win[0];
+            const u32 *first = own_win + 1, *before = own_win + 1 + nr;
+            u32 lo = 0, hi = nr;  // before[lo] <= w < before[hi]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (before[mid] <= w) lo = mid; else hi = mid;
+            }
+            w = first[lo] + (w - before[lo]);
+        }
+        compact_window(w, code, G, win_out, multi, counters, out);
     } else {
         constexpr u32 WPB = COMPACT_THREADS / 64;
-        finalize_entries((blockIdx.x - nwin) * WPB + (threadIdx.x >> 6), (gridDim.x - nwin) * WPB, code, G, win_out, nwin, multi,
+        finalize_entries((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, multi,
                          counters, seq, contig_off, n_contigs, out, ctg_out);
     }
 }

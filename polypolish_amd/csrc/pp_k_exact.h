@@ -61,6 +61,8 @@ struct ExactArgs {
     const u32 *flag_bits;
     const u32 *win_nflag;
     const u32 *win_slab;
+    const u32 *slab_win;  // the window of each tally slab: the list of the windows with flagged positions
+    u32 cap_slabs;
     const u32 *slabs;
     KeyRec *keys;       // debug only
     u64 cap_keys;
@@ -307,17 +309,29 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
     const u32 tid = threadIdx.x;
     u32 w;
     int plo = 0;
+    const int state = job_state(A.status);
+    if (state == 2) return;
     if (SUB == 1) {
-        w = blockIdx.x;
-        if (w >= nwin) return;
+        // Block f replays the f-th window that k_tile found flagged positions in (the windows with a tally slab are
+        // listed in slab_win: a grid over ALL windows costs a launch of 122 K empty blocks per instance on a 250 Mbp
+        // job).  After a late capacity overflow the list may be incomplete: the needs are then added up over all windows.
+        if (state == 1) {
+            if (tid == 0)
+                for (u32 ww = blockIdx.x; ww < nwin; ww += gridDim.x) {
+                    if (!A.win_nflag[ww] || A.win_heavy[ww]) continue;
+                    const u32 nn = A.win_off[ww + 1] - A.win_off[ww];
+                    if (nn <= SMAX && nn > NLOW && nn > LDS_LIST_MAX) atomicAdd(A.ents_cursor, (u64)nn);  // smaller lists stay in LDS
+                }
+            return;
+        }
+        if (blockIdx.x >= min(A.counters[3], A.cap_slabs)) return;
+        w = A.slab_win[blockIdx.x];
     } else {
         const u32 hs = blockIdx.x / SUB;
         if (hs >= min(A.heavy[0], HEAVY_SLOTS)) return;
         w = A.heavy[1 + hs];
         plo = (int)(blockIdx.x % SUB) * PSPAN;
     }
-    const int state = job_state(A.status);
-    if (state == 2) return;
     if (A.win_nflag[w] == 0) return;
     const u32 e0 = A.win_off[w], n_all = A.win_off[w + 1] - e0;
     if (SUB == 1) {
@@ -328,8 +342,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         for (int q = 0; q < PSPAN / 32; q++) any |= A.flag_bits[(u64)w * (TILE / 32) + (u32)(plo / 32 + q)];
         if (!any) return;
     }
-    if (state == 1) {  // a buffer was too small: only add up the replay scratch the rerun will need
-        if (tid == 0 && (SUB > 1 || n_all > LDS_LIST_MAX)) atomicAdd(A.ents_cursor, (u64)n_all);  // smaller lists stay in LDS
+    if (state == 1) {  // (SUB > 1) a buffer was too small: only add up the replay scratch the rerun will need
+        if (tid == 0) atomicAdd(A.ents_cursor, (u64)n_all);
         return;
     }
     const u32 slab = A.win_slab[w];

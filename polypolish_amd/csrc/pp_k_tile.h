@@ -29,6 +29,7 @@ struct TileArgs {
     u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
     u32 *win_nflag;   // per window: number of flagged positions
     u32 *win_slab;    // per window: index of its tally slab (6 x 2048 u32), or ~0
+    u32 *slab_win;    // per tally slab: its window
     u32 *slabs;
     u32 cap_slabs;
     u32 *flag_pos;
@@ -39,6 +40,7 @@ struct TileArgs {
     const u32 *maxlen;  // longest fast-class read (written by k_prep)
     u64 seq_bytes;
     const u32 *own;   // optional (lo, hi) emit range per contig, relative to the contig (pp_polish_set_emit)
+    const u32 *own_win;  // with it: the ranges of windows that touch those ranges [n | first window of each | windows before each]
     u32 *heavy;           // HEAVY_WORDS: number of heavy windows | the listed ones | their arrival tickets
     const u8 *win_heavy;  // per window: 0, or 1 + its slot in the list
     u32 *hslab;           // per slot and part: HSLAB_WORDS partial tallies of that helper block
@@ -562,6 +564,22 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     } else {
         const u32 b = blockIdx.x - HEAVY_BLOCKS, per = (gridDim.x - HEAVY_BLOCKS) >> 3;
         w = (b & 7u) * per + (b >> 3);
+        if (A.own_win) {
+            // Sharded job: the grid only spans the windows this context works on; w is the number of one of them.
+            // (Dealt out like this the XCDs share them evenly; a grid over ALL windows gave a rank's one stretch of a
+            // window-tiled contig to a single XCD -- 7.1 ms per rank where the whole 250 Mbp job takes 6.9.)
+            const u32 nr = A.own_win[0];
+            const u32 *first = A.own_win + 1, *before = A.own_win + 1 + nr;
+            if (w >= before[nr]) return;
+            u32 lo = 0, hi = nr;  // before[lo] <= w < before[hi]
+            while (hi - lo > 1) {
+                const u32 step = (hi - lo + 63u) / 64u, idx = lo + ((threadIdx.x & 63u) + 1u) * step;
+                const u32 k = (u32)__popcll(__ballot(idx < hi && before[idx] <= w));
+                lo += k * step;
+                hi = min(hi, lo + step);
+            }
+            w = first[lo] + (w - before[lo]);
+        }
         if (w >= A.nwin || A.win_heavy[w]) return;  // listed windows belong to the helpers
     }
     if (job_state(A.status) == 2) return;
@@ -803,6 +821,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             if (slab >= A.cap_slabs) report(A.status, slab, DE_CAPACITY_LATE);
             s_c1 = slab;
             A.win_slab[w] = slab;
+            if (slab < A.cap_slabs) A.slab_win[slab] = w;
         }
         __syncthreads();
         const u32 slab = s_c1;

@@ -362,7 +362,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
-    ENS(b_win_slab, (uint64_t)nwin * 4); ENS(b_slabs, (uint64_t)ctx->cap_slabs * 6 * TILE * 4); ENS(b_ents, (uint64_t)ctx->cap_ents * 16);
+    ENS(b_win_slab, (uint64_t)nwin * 4); ENS(b_slab_win, (uint64_t)ctx->cap_slabs * 4); ENS(b_slabs, (uint64_t)ctx->cap_slabs * 6 * TILE * 4); ENS(b_ents, (uint64_t)ctx->cap_ents * 16);
     if (ctx->debug) ENS(b_keys, (uint64_t)ctx->cap_keys * sizeof(KeyRec));
     ENS(b_scratch, ctx->cap_scr * 16); ENS(b_multi, ctx->cap_multi * sizeof(MultiEnt)); ENS(b_out, ctx->cap_out);
     if (ctx->debug) { ENS(b_dbg_depth, G * 8); ENS(b_dbg_counts, G * 28); ENS(b_dbg_status, G); }
@@ -388,10 +388,34 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     u32 *d_ccnt = (u32 *)ctx->b_ccnt.p, *d_coff = (u32 *)ctx->b_coff.p;
 
     const u32 *d_own = nullptr;  // (lo, hi) per contig this context emits (pp_polish_set_emit), or everything
+    // Sharded job: only the windows that touch a range this context emits are worked on.  Their ranges (sorted, merged)
+    // follow the (lo, hi) pairs in the same upload: [n_ranges | first window of each | windows before each (n + 1)].
+    const u32 *d_own_win = nullptr;
+    uint32_t n_own_win = nwin;
     if (!ctx->emit.empty()) {
+        std::vector<uint32_t> up(ctx->emit);
+        std::vector<std::pair<uint32_t, uint32_t>> rng;  // [first, last] window
+        for (uint32_t c = 0; c < nc; c++) {
+            const uint64_t lo = ctx->emit[2 * c], hi = ctx->emit[2 * c + 1];
+            if (hi <= lo) continue;
+            const uint32_t w0 = (uint32_t)((ctx->contig_off[c] + lo) / TILE), w1 = (uint32_t)((ctx->contig_off[c] + hi - 1) / TILE);
+            if (!rng.empty() && w0 <= rng.back().second + 1) rng.back().second = std::max(rng.back().second, w1);
+            else rng.emplace_back(w0, w1);
+        }
+        const size_t at = up.size();
+        up.push_back((uint32_t)rng.size());
+        for (auto &r : rng) up.push_back(r.first);
+        uint32_t before = 0;
+        for (auto &r : rng) { up.push_back(before); before += r.second - r.first + 1; }
+        up.push_back(before);
+        n_own_win = before;
         const void *p_own = nullptr;
-        if (int rc = upload(ctx, ctx->b_own, ctx->emit.data(), ctx->emit.size() * sizeof(uint32_t), &p_own)) return rc;
+        if (int rc = upload(ctx, ctx->b_own, up.data(), up.size() * sizeof(uint32_t), &p_own)) return rc;
         d_own = (const u32 *)p_own;
+        d_own_win = d_own + at;
+        // the windows nobody works on emit nothing and have nothing flagged
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_winlen.p, 0, (size_t)nwin * 4, st));
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_win_nflag.p, 0, (size_t)nwin * 4, st));
     }
     // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
     // records of every block per window (two-level path: k_count, per range of windows)
@@ -462,13 +486,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
     T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
-    T.win_slab = (u32 *)ctx->b_win_slab.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
+    T.win_slab = (u32 *)ctx->b_win_slab.p; T.slab_win = (u32 *)ctx->b_slab_win.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;
     T.stats = d_stats;
     T.maxlen = (const u32 *)(d_meta + 9);
     T.scr_need = d_meta + 10;
     T.flag_scr = (u64 *)ctx->b_flag_scr.p;
     T.seq_bytes = B.seq_bytes;
     T.own = d_own;
+    T.own_win = d_own_win;
     T.heavy = d_heavy; T.win_heavy = d_win_heavy; T.hslab = (u32 *)ctx->b_hslab.p;
     T.dbg_depth = (double *)ctx->b_dbg_depth.p; T.dbg_counts = (u32 *)ctx->b_dbg_counts.p;
     T.dbg_status = (u8 *)ctx->b_dbg_status.p; T.status = d_status;
@@ -476,7 +501,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // so that its f64 depths can be compared bit for bit (the key records of the TSV are then incomplete)
     static const bool dbg_replay2 = getenv("PP_DEBUG_REPLAY2") && atoi(getenv("PP_DEBUG_REPLAY2")) != 0;
     T.dbg = ctx->debug ? (dbg_replay2 ? 2 : 1) : 0;
-    const uint32_t per = (nwin + 7) / 8;
+    const uint32_t per = (n_own_win + 7) / 8;  // windows to work on, dealt to the eight XCDs in stretches
     timer_begin(ctx, "tile");
 #ifdef PP_TILE_STAMPS
     static DevBuf b_stamps;
@@ -501,7 +526,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ExactArgs E;
     E.cap_multi = (u32)ctx->cap_multi; E.cap_flag = (u32)ctx->cap_flag;
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
-    E.win_slab = T.win_slab; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
+    E.win_slab = T.win_slab; E.slab_win = T.slab_win; E.cap_slabs = T.cap_slabs; E.slabs = T.slabs; E.ents = (ulonglong2 *)ctx->b_ents.p; E.cap_ents = ctx->cap_ents;
     E.ents_cursor = d_meta + 6;
     E.scr_need = d_meta + 10; E.cap_scr = (u64)ctx->cap_scr; E.flag_scr_w = d_scr;
     E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
@@ -517,8 +542,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.heavy = d_heavy; E.win_heavy = d_win_heavy;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
-    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
-    hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(nwin), dim3(1024), 0, st, E, nwin);
+    const unsigned n_replay = (unsigned)std::min<uint64_t>(nwin, ctx->cap_slabs);  // one block per window with a tally slab
+    hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
+    hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, HEAVY_SUB>), dim3(HEAVY_SLOTS * HEAVY_SUB), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
     timer_end(ctx);
@@ -529,8 +555,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                        d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
     const uint64_t nfin = ctx->cap_multi + nc + 1;  // multi-byte winners + contig starts: one wave each, grid-stride
     const unsigned fin_blocks = (unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4);
-    hipLaunchKernelGGL(k_emit, dim3(nwin + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G,
-                       (const u64 *)d_winout, nwin, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc,
+    hipLaunchKernelGGL(k_emit, dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G,
+                       (const u64 *)d_winout, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc,
                        (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
     timer_end(ctx);
     PP_HIPCHK(ctx, hipGetLastError());
@@ -788,7 +814,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_comm, &ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient,
                      &ctx->f_insert};

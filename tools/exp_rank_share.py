@@ -1,0 +1,34 @@
+"""What ONE rank of an N-way sharded job costs (strong scaling, measured on one GPU): the job of bench.py --config C with
+the emit ranges the planner gives rank r of `world` -- every rank streams ALL records through k_prep, the rest shrinks.
+    python tools/exp_rank_share.py 4 8        # config 4, world 8: per-rank step time and kernel groups for every rank"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+import polypolish_amd as pp
+
+config, world = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda:0")
+lens, cov, repeat, label = bench.config_shape(config)
+job = bench.make_job(dev, contig_lens=lens, coverage=cov, repeat=repeat)
+ctx = pp.Context(0)
+ctx.set_profiling(1)
+counts = np.bincount(job["recs"]["contig"].cpu().numpy().astype(np.int64), minlength=len(lens))
+plan = pp.Plan(job["contig_off"], counts, world, 0)
+def timed(j, reps=5):
+    bench.run_job(ctx, pp, j)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps):
+        bench.run_job(ctx, pp, j)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps * 1e3, ctx.kernel_times()
+ms, kt = timed(job)
+print(label); print("whole job: %.3f ms" % ms, kt)
+tot = 0
+for r in range(world):
+    j = dict(job); j["emit"] = plan.emit_ranges(r)
+    ms_r, kt = timed(j)
+    tot = max(tot, ms_r)
+    print("rank %d of %d: %.3f ms" % (r, world, ms_r), kt)
+print("slowest rank %.3f ms -> speedup %.2f of %d" % (tot, ms / tot, world))
