@@ -498,7 +498,18 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;
-        else lim = simple_nkeep(A.seq + ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32)), ent.y >> 24);
+        else {
+            // the trim from the read's last four bases, one load (as k_tile's plain class does it); a trailing
+            // homopolymer of four or more, or a read shorter than that, walks byte by byte
+            const u8 *rp = A.seq + ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+            const u32 L = ent.y >> 24;
+            u32 tf = 0;
+            if (L >= 4u) {
+                const u32 tail = load4_unaligned(rp + (L - 4u));
+                tf = nz_flags(tail ^ splat8(tail >> 24));
+            }
+            lim = tf ? L - 4u + (u32)((31 - __clz((int)tf)) >> 3) : simple_nkeep(rp, L);
+        }
         const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[ent.w]);
         ulonglong2 r;
         r.x = (u64)ent.z | ((u64)lim << 32);
