@@ -1,20 +1,23 @@
 // pp_kernels.hip -- gfx950 kernels of the polish hot path (seam B of include/polypolish_hip.h).
 //
-// Pipeline (one pp_polish_finish):
-//   k_prep     one thread per alignment: CIGAR walk validation, reference span and the right-end
-//              homopolymer trim (alignment.rs:175-201,364-378) -> (global start, kept entries)
-//   k_count    per-block LDS histogram of (alignment, window) items   \  atomics-free multisplit
-//   k_scan_cols / k_scan   column scan over blocks + scan over windows  > of the alignments into
-//   k_fill     scatter 16-byte work items into their window's bucket   /  2048-position windows
+// Pipeline (one pp_polish_finish, 13 stream operations):
+//   k_meta_init  the job's metadata block (status, counters, heavy-window list)
+//   k_prep     persistent blocks stream the alignment records: the bulk (one short M run inside its contig) on the
+//              spot, the others (indels, long reads: CIGAR walk validation, reference span and the right-end homopolymer
+//              trim, alignment.rs:175-201,364-378) after the loop, one per lane -> (global start, kept entries); the
+//              same pass counts each block's (alignment, window) items per window / coarse bucket in LDS
+//   k_scan_cols / k_scan   column scan over the blocks + scan over the windows \ atomics-free multisplit of the
+//   k_fill     scatter of 16-byte work items into their window's bucket         > alignments into 2048-position windows
+//   (k_regroup / k_heavy / k_count: the two-level path from 33.5 Mbp on)       /  (+ the list of heavy windows)
 //   k_tile     one workgroup per window: counters for 2048 positions and the window's assembly bytes live in LDS;
 //              groups of 5-8 lanes own one read (32 bytes per lane), compare it with the assembly and tally only the
 //              differing bases (two LDS atomics into a coverage difference array per read, pileup.rs:56-65,189-200);
-//              then one lane per position votes (pileup.rs:67-134) and writes a 1-byte emit code
-//   k_exact    the rare positions whose outcome depends on string-keyed counts (insertions, N...)
-//              or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
-//              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact
-//              key grouping
-//   k_compact / k_finalize  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes
+//              then one lane per position votes (pileup.rs:67-134) and writes a 1-byte emit code.  Heavy windows are
+//              tallied by eight helper blocks each; a sharded job only launches the windows it works on
+//   k_exact2 (three instances) / k_exact   the rare positions whose outcome depends on string-keyed counts
+//              (insertions, N...) or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
+//              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact key grouping
+//   k_scan / k_emit  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes, contig offsets
 //
 // Integer counting, HBM/LDS bound: no MFMA anywhere by design.
 #include "pp_internal.h"
