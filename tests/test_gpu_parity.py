@@ -448,6 +448,9 @@ def test_emit_ranges_match_oracle_slices(ctx, orc):
             own = slice(int(contig_off[c] + lo[c]), int(contig_off[c] + hi[c]))
             assert got["stats"][c]["changed"] == int((full["status"][own] == 1).sum())
             assert got["stats"][c]["zero_depth"] == int((full["depth"][own] == 0.0).sum())
+    # a rank that owns nothing at all: no bytes, every offset zero
+    got = ctx.polish_records(contig_off, bases, recs, emit=np.zeros((3, 2), dtype=np.int64))
+    assert got["polished"] == b"" and not np.any(got["offsets"])
     # the next job on the same context emits everything again
     assert ctx.polish_records(contig_off, bases, recs)["polished"] == orc.polish_records(contig_off, bases, recs)["polished"]
 
