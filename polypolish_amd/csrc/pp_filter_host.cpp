@@ -15,6 +15,7 @@
 #include <sys/uio.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <functional>
@@ -839,8 +840,20 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     if (rc) return rc;
     lap("samples from the device");
     uint64_t counts[4] = {0, 0, 0, 0};
-    for (uint32_t r = 0; r < n_reads; r++)
-        if (orient[r] < 4) counts[orient[r]]++;
+    const unsigned red_threads = std::max(1u, std::min({std::thread::hardware_concurrency(), 16u, n_reads / 65536u + 1u}));
+    {   // orientation counts, a slice of the reads per thread
+        std::vector<std::array<uint64_t, 4>> part(red_threads, std::array<uint64_t, 4>{0, 0, 0, 0});
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < red_threads; t++)
+            th.emplace_back([&, t] {
+                const uint32_t a = (uint32_t)((uint64_t)n_reads * t / red_threads), b = (uint32_t)((uint64_t)n_reads * (t + 1) / red_threads);
+                for (uint32_t r = a; r < b; r++)
+                    if (orient[r] < 4) part[t][orient[r]]++;
+            });
+        for (auto &x : th) x.join();
+        for (auto &p4 : part)
+            for (int o = 0; o < 4; o++) counts[o] += p4[o];
+    }
     if (counts[0] + counts[1] + counts[2] + counts[3] == 0)
         return set_err(PP_ERR_QUIT, "no one-alignment-per-read pairs available to determine orientation and "
                                     "insert size thresholds");
@@ -859,14 +872,48 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
             if (strcmp(orientation, ONAMES[o]) == 0) correct = o;
         log("\nUser-specified correct orientation: %s\n\n", orientation);
     }
-    std::vector<uint32_t> sizes;
-    if (correct >= 0) {
-        sizes.reserve(counts[correct]);
-        for (uint32_t r = 0; r < n_reads; r++)
-            if (orient[r] == correct) sizes.push_back(insert[r]);
+    // get_percentile (filter.rs:249-259) is an order statistic of the correctly oriented pairs' insert sizes: taken
+    // from a histogram (one per thread over its slice of the reads; sizes of 2^16 and more, if any, are kept as a list)
+    // instead of gathering and partially sorting 3.3 M values on one core
+    const uint64_t n_sizes = correct >= 0 ? counts[correct] : 0;
+    if (n_sizes == 0) return set_err(PP_ERR_QUIT, "no read pairs available to determine insert size thresholds");
+    constexpr uint32_t HBINS = 1u << 16;
+    std::vector<uint64_t> hist(HBINS, 0);
+    std::vector<uint32_t> big;
+    {
+        std::vector<std::vector<uint32_t>> hpart(red_threads), bpart(red_threads);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < red_threads; t++)
+            th.emplace_back([&, t] {
+                hpart[t].assign(HBINS, 0);
+                const uint32_t a = (uint32_t)((uint64_t)n_reads * t / red_threads), b = (uint32_t)((uint64_t)n_reads * (t + 1) / red_threads);
+                for (uint32_t r = a; r < b; r++) {
+                    if (orient[r] != correct) continue;
+                    if (insert[r] < HBINS) hpart[t][insert[r]]++;
+                    else bpart[t].push_back(insert[r]);
+                }
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < red_threads; t++) {
+            for (uint32_t i = 0; i < HBINS; i++) hist[i] += hpart[t][i];
+            big.insert(big.end(), bpart[t].begin(), bpart[t].end());
+        }
     }
-    if (sizes.empty()) return set_err(PP_ERR_QUIT, "no read pairs available to determine insert size thresholds");
-    const uint32_t lo = percentile(sizes, low), hi = percentile(sizes, high);
+    auto order_stat = [&](double p) -> uint32_t {  // = percentile() above on the gathered values
+        const double r = ceil(p / 100.0 * (double)n_sizes);
+        size_t rank = r <= 0.0 ? 0 : (r >= 1.8e19 ? SIZE_MAX : (size_t)r);
+        if (rank < 1) rank = 1;
+        if (rank - 1 >= n_sizes) return 0;
+        uint64_t seen = 0;
+        for (uint32_t i = 0; i < HBINS; i++) {
+            seen += hist[i];
+            if (seen >= rank) return i;
+        }
+        const size_t k = rank - 1 - (size_t)seen;  // among the sizes of 2^16 and more
+        std::nth_element(big.begin(), big.begin() + (long)k, big.end());
+        return big[k];
+    };
+    const uint32_t lo = order_stat(low), hi = order_stat(high);
     log("Low threshold:  %u (%s)\nHigh threshold: %u (%s)\n\n", lo, percentile_name(low).c_str(), hi,
         percentile_name(high).c_str());
     lap("thresholds");
