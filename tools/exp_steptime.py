@@ -8,7 +8,7 @@ import polypolish_amd as pp
 dev = torch.device("cuda", 0)
 job = bench.make_job(dev)
 ctx = pp.Context(0)
-for prof in (False, True, False):
+for prof in (0, 2, 1, 0, 2):  # 0 no events, 2 one pair around k_tile (what bench.py's timed steps use), 1 every group
     ctx.set_profiling(prof)
     for _ in range(3):
         bench.run_job(ctx, pp, job)
