@@ -188,8 +188,15 @@ __device__ __forceinline__ u32 find_tab(const u8 *L, u32 from, u32 n) {
 // Launch with 64 threads per workgroup; `stage` = TOK_STAGE + 32 bytes of LDS, 16-byte aligned.  Returns false for
 // the lanes past the last line; otherwise *L points at the lane's line (LDS or HBM), *n is its length without
 // "\n" / "\r\n", *li its number.  The text buffer is padded with >= 64 zero bytes past `size`.
-constexpr u32 TOK_STAGE = 40 * 1024 - 64;  // four one-wave workgroups per CU
+// The stage comes in three sizes, picked per file from its average line length (64 lines + 15 %): the smaller it is, the
+// more one-wave workgroups share a CU (10 / 6 / 4) and hide each other's LDS and memory latency.
+constexpr u32 TOK_STAGE_S = 16 * 1024 - 64, TOK_STAGE_M = 26 * 1024 - 64, TOK_STAGE_L = 40 * 1024 - 64;
+inline u32 tok_stage_for(u64 text_bytes, u64 n_lines) {
+    const u64 need = n_lines ? (text_bytes / n_lines + 1) * 64 * 115 / 100 : 0;
+    return need <= TOK_STAGE_S ? TOK_STAGE_S : (need <= TOK_STAGE_M ? TOK_STAGE_M : TOK_STAGE_L);
+}
 
+template <u32 TOK_STAGE>
 __device__ __forceinline__ bool stage_wave_lines(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
                                                  u64 n_nl, u64 n_lines, u8 *stage, const u8 **L, u32 *n, u64 *li) {
     const u32 lane = threadIdx.x;

@@ -27,13 +27,14 @@ struct FqLines {  // one entry per line of the file
 };
 
 // new_quick for every line of the file: one lane per line, the wave's lines staged through LDS (pp_devtext.h)
+template <u32 TOK_STAGE>
 __global__ __launch_bounds__(64) void k_fq_parse(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
                                                  u64 n_nl, u64 n_lines, FqLines O, u64 *__restrict__ status) {
     __shared__ __attribute__((aligned(16))) u8 stage[TOK_STAGE + 32];
     const u8 *L;
     u32 n;
     u64 li;
-    if (!stage_wave_lines(text, size, nl_pos, n_nl, n_lines, stage, &L, &n, &li)) return;
+    if (!stage_wave_lines<TOK_STAGE>(text, size, nl_pos, n_nl, n_lines, stage, &L, &n, &li)) return;
     O.is_aln[li] = 0;
     if (n > 0 && L[0] == (u8)'@') return;  // header lines are skipped; an EMPTY line is fatal (filter.rs:126-130)
     u32 cs[11], cl[11], nc = 0, q = 0;
@@ -316,8 +317,16 @@ extern "C" int pp_filter_load_device(pp_ctx *ctx, const char *in1, const char *i
             ENS(X.d_namelen, nl * 4); ENS(X.d_refoff, nl * 4); ENS(X.d_reflen, nl * 4); ENS(X.d_recofline, (nl + 1) * 4);
             FqLines O{(u32 *)X.d_isaln.p, (u32 *)X.d_flag.p, (u32 *)X.d_start.p, (u32 *)X.d_namelen.p, (u32 *)X.d_refoff.p,
                       (u32 *)X.d_reflen.p, (u64 *)X.d_end.p};
-            hipLaunchKernelGGL(k_fq_parse, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, st, d_text, size, (const u64 *)X.d_nl.p,
+            {
+                const u32 stage_bytes = tok_stage_for(size, nl);
+                const dim3 grid((unsigned)((nl + 63) / 64));
+                if (stage_bytes == TOK_STAGE_S) hipLaunchKernelGGL(k_fq_parse<TOK_STAGE_S>, grid, dim3(64), 0, st, d_text, size, (const u64 *)X.d_nl.p,
                                X.n_nl, nl, O, d_status);
+                else if (stage_bytes == TOK_STAGE_M) hipLaunchKernelGGL(k_fq_parse<TOK_STAGE_M>, grid, dim3(64), 0, st, d_text, size, (const u64 *)X.d_nl.p,
+                               X.n_nl, nl, O, d_status);
+                else hipLaunchKernelGGL(k_fq_parse<TOK_STAGE_L>, grid, dim3(64), 0, st, d_text, size, (const u64 *)X.d_nl.p,
+                               X.n_nl, nl, O, d_status);
+            }
             if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)X.d_isaln.p, nl, (u32 *)X.d_recofline.p))) return rc;
             if ((rc = fetch(ctx, (const u32 *)X.d_recofline.p + nl, &X.n_aln))) return rc;
         }

@@ -69,6 +69,7 @@ __device__ __forceinline__ void tok_parse_line(const u8 *L, u32 n, u64 li, const
                                                u32 *__restrict__ is_aln, u64 *__restrict__ status);
 
 // Alignment::new for every line of the file: one lane per line, the wave's lines staged through LDS (pp_devtext.h)
+template <u32 TOK_STAGE>
 __global__ __launch_bounds__(64) void k_tok_parse(const u8 *__restrict__ text, u64 size, const u64 *__restrict__ nl_pos,
                                                   u64 n_nl, u64 n_lines, ContigTable T, LineRec *__restrict__ rec,
                                                   u32 *__restrict__ is_aln, u64 *__restrict__ status) {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64) void k_tok_parse(const u8 *__restrict__ text, u
     const u8 *L;
     u32 n;
     u64 li;
-    if (stage_wave_lines(text, size, nl_pos, n_nl, n_lines, stage, &L, &n, &li)) tok_parse_line(L, n, li, T, rec, is_aln, status);
+    if (stage_wave_lines<TOK_STAGE>(text, size, nl_pos, n_nl, n_lines, stage, &L, &n, &li)) tok_parse_line(L, n, li, T, rec, is_aln, status);
 }
 
 __device__ __forceinline__ void tok_parse_line(const u8 *L, u32 n, u64 li, const ContigTable &T, LineRec *__restrict__ rec,
@@ -534,8 +535,16 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
         ENS(d_isaln, n_lines * 4);
         ENS(d_recofline, (n_lines + 1) * 4);
         ContigTable T{(const u32 *)D->t_slots.p, (const u32 *)D->t_off.p, (const u8 *)D->t_names.p, D->t_mask};
-        hipLaunchKernelGGL(k_tok_parse, dim3((unsigned)((n_lines + 63) / 64)), dim3(64), 0, st, d_text, size,
+        {
+            const u32 stage_bytes = tok_stage_for(size, n_lines);
+            const dim3 grid((unsigned)((n_lines + 63) / 64));
+            if (stage_bytes == TOK_STAGE_S) hipLaunchKernelGGL(k_tok_parse<TOK_STAGE_S>, grid, dim3(64), 0, st, d_text, size,
                            (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
+            else if (stage_bytes == TOK_STAGE_M) hipLaunchKernelGGL(k_tok_parse<TOK_STAGE_M>, grid, dim3(64), 0, st, d_text, size,
+                           (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
+            else hipLaunchKernelGGL(k_tok_parse<TOK_STAGE_L>, grid, dim3(64), 0, st, d_text, size,
+                           (const u64 *)D->d_nl.p, n_nl, n_lines, T, (LineRec *)D->d_rec.p, (u32 *)D->d_isaln.p, d_status);
+        }
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_isaln.p, n_lines, (u32 *)D->d_recofline.p))) return rc;
         if ((rc = fetch(ctx, (const u32 *)D->d_recofline.p + n_lines, &n_aln))) return rc;
     }
