@@ -175,10 +175,19 @@ __global__ __launch_bounds__(256) void k_tok_group_start(const u8 *__restrict__ 
         const u32 np = rec[lp].name_len, ncur = rec[lc].name_len;
         if (np == 0) start = 0;
         else if (np == ncur) {
+            // eight bytes at a time (unaligned loads; the text buffer is padded, and a QNAME is followed by ten more
+            // columns): names of neighbouring records tend to differ in their last characters only
             const u8 *a = text + line_start(nl_pos, lp), *b = text + line_start(nl_pos, lc);
-            u32 j = 0;
-            while (j < np && a[j] == b[j]) j++;
-            if (j == np) start = 0;
+            bool same = true;
+            for (u32 j = 0; j < np && same; j += 8) {
+                u64 x, y;
+                __builtin_memcpy(&x, a + j, 8);
+                __builtin_memcpy(&y, b + j, 8);
+                const u32 rem = np - j;
+                const u64 mask = rem < 8u ? (1ull << (8u * rem)) - 1ull : ~0ull;
+                same = ((x ^ y) & mask) == 0;
+            }
+            if (same) start = 0;
         }
     }
     is_start[r] = start;
