@@ -49,6 +49,13 @@ extern "C" {
 /* CIGAR runs are packed (length << 4) | op with these op codes (SAM order). */
 enum { PP_OP_M = 0, PP_OP_I = 1, PP_OP_D = 2, PP_OP_N = 3, PP_OP_S = 4, PP_OP_H = 5, PP_OP_P = 6,
        PP_OP_EQ = 7, PP_OP_X = 8 };
+/* Filter input only: a run with this op code marks an alignment whose CIGAR holds a length that does not fit 64 bits.
+   The reference parses run lengths when it needs an alignment's end (get_ref_end, src/alignment.rs:138-149, called from
+   get_insert_size / get_orientation, src/filter.rs:189-218) and panics there, so such an alignment is only fatal if it
+   takes part in a pair comparison: its ref_end is PP_REF_END_UNPARSEABLE and pp_filter_samples / pp_filter_pairs
+   return PP_ERR_PANIC if they have to evaluate it (a precomputed ref_end array uses the same value). */
+#define PP_OP_UNPARSEABLE 15
+#define PP_REF_END_UNPARSEABLE 0xFFFFFFFFFFFFFFFFull
 
 /* BaseStatus (src/pileup.rs:18-25) in the order of its debug strings (src/pileup.rs:156-163). */
 enum { PP_ST_KEPT = 0, PP_ST_CHANGED = 1, PP_ST_LOW_DEPTH = 2, PP_ST_NONE = 3, PP_ST_MULTIPLE = 4,

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void k_ref_end(u64 n, const u32 *__restrict__ 
     for (u32 r = 0; r < n_cig[a]; r++) {
         u32 op = cg[r], o = op & 15u;
         if (o == PP_OP_M || o == PP_OP_D || o == PP_OP_N || o == PP_OP_EQ || o == PP_OP_X) end += op >> 4;
+        else if (o == (u32)PP_OP_UNPARSEABLE) { end = PP_REF_END_UNPARSEABLE; break; }
     }
     ref_end[a] = end;
 }
@@ -55,8 +56,10 @@ struct FileDev {
 };
 
 // sampling loop of get_insert_size_thresholds, filter.rs:155-167: one lane per read
+// `poisoned`: set when an end is needed that the reference could not have parsed (PP_REF_END_UNPARSEABLE)
 __global__ __launch_bounds__(256) void k_samples(u32 n_reads, FileDev f1, FileDev f2,
-                                                 u8 *__restrict__ orient, u32 *__restrict__ insert) {
+                                                 u8 *__restrict__ orient, u32 *__restrict__ insert,
+                                                 u32 *__restrict__ poisoned) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     u8 o = 255;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256) void k_samples(u32 n_reads, FileDev f1, FileDe
     if (f1.grp_off[r + 1] - f1.grp_off[r] == 1u && f2.grp_off[r + 1] - f2.grp_off[r] == 1u) {
         const u32 a = f1.grp_idx[f1.grp_off[r]], b = f2.grp_idx[f2.grp_off[r]];
         if (f1.ref_id[a] == f2.ref_id[b]) {
+            if (f1.ref_end[a] == PP_REF_END_UNPARSEABLE || f2.ref_end[b] == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
             o = (u8)orientation_of(f1.flags[a], f1.ref_start[a], f1.ref_end[a], f2.flags[b], f2.ref_start[b], f2.ref_end[b]);
             ins = insert_of(f1.ref_start[a], f1.ref_end[a], f2.ref_start[b], f2.ref_end[b]);
         }
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void k_samples(u32 n_reads, FileDev f1, FileDe
 
 // alignment_pass_qc, filter.rs:352-377: one lane per alignment of `self`, mates in `other`
 __global__ __launch_bounds__(256) void k_pairs(FileDev self, FileDev other, u32 low, u32 high,
-                                               u32 correct, u8 *__restrict__ pass) {
+                                               u32 correct, u8 *__restrict__ pass, u32 *__restrict__ poisoned) {
     u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= self.n_aln) return;
     const u32 r = self.read[a];
@@ -89,6 +93,9 @@ __global__ __launch_bounds__(256) void k_pairs(FileDev self, FileDev other, u32 
         for (u32 j = p0; j < p1 && !ok; j++) {
             const u32 b = other.grp_idx[j];
             const u64 s2 = other.ref_start[b], e2 = other.ref_end[b];
+            // get_insert_size comes first in the loop and parses both ends (filter.rs:367-368); a mate that is never
+            // reached -- an earlier one made a good pair -- is never parsed
+            if (e == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
             const u32 ins = insert_of(s, e, s2, e2);
             if (ref == other.ref_id[b] && low <= ins && ins <= high &&
                 orientation_of(fl, s, e, other.flags[b], s2, e2) == correct)
@@ -169,8 +176,20 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
             timer_end(ctx);
         }
     }
+    int rcf = dev_ensure(ctx, ctx->f_poisoned, 4);
+    if (rcf) return rcf;
+    PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_poisoned.p, 0, 4, ctx->stream));
     PP_HIPCHK(ctx, hipGetLastError());
     ctx->filter_open = true;
+    return PP_OK;
+}
+
+// the reference's unwrap() on a run length that does not fit usize (alignment.rs:141)
+static int check_poisoned(pp_ctx *ctx) {
+    uint32_t flag = 0;
+    PP_HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->f_poisoned.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return ctx->fail(PP_ERR_PANIC, "a CIGAR run length that does not fit 64 bits belongs to an alignment whose end a pair comparison needs");
     return PP_OK;
 }
 
@@ -185,14 +204,13 @@ extern "C" int pp_filter_samples(pp_ctx *ctx, uint8_t *orient, uint32_t *insert)
     if (n) {
         timer_begin(ctx, "samples");
         hipLaunchKernelGGL(k_samples, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0),
-                           file_dev(ctx, 1), (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p);
+                           file_dev(ctx, 1), (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
         PP_HIPCHK(ctx, hipMemcpyAsync(orient, ctx->f_orient.p, n, hipMemcpyDeviceToHost, ctx->stream));
         PP_HIPCHK(ctx, hipMemcpyAsync(insert, ctx->f_insert.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PP_OK;
+    return check_poisoned(ctx);
 }
 
 extern "C" int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t orientation,
@@ -209,12 +227,12 @@ extern "C" int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t
         if (!n) continue;
         timer_begin(ctx, "pairs");
         hipLaunchKernelGGL(k_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, file_dev(ctx, f),
-                           file_dev(ctx, 1 - f), low, high, (u32)orientation, (u8 *)pb[f]->p);
+                           file_dev(ctx, 1 - f), low, high, (u32)orientation, (u8 *)pb[f]->p, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
         PP_HIPCHK(ctx, hipMemcpyAsync(outs[f], pb[f]->p, n, hipMemcpyDeviceToHost, ctx->stream));
     }
-    PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcp = check_poisoned(ctx)) return rcp;
     if (ctx->profiling) timers_collect(ctx, &ctx->last_times);
     return PP_OK;
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void k_fq_parse(const u8 *__restrict__ text, u6
             const int op = j < cgl ? op_code(c[j]) : -1;
             if (op >= 0) {
                 u64 num;
-                if (!parse_u(c + i, j - i, ~0ull, num)) { report(status, li); return; }
+                if (!parse_u(c + i, j - i, ~0ull, num)) { end = PP_REF_END_UNPARSEABLE; break; }  // only fatal if needed (lazy)
                 if (op == PP_OP_M || op == PP_OP_D || op == PP_OP_N || op == PP_OP_EQ || op == PP_OP_X) end += num;
                 i = j + 1;
             } else {

@@ -174,7 +174,13 @@ void parse_slice(Slice &S, const char *text) {
                 const int op = j < cl ? cigar_op(c[j]) : -1;
                 if (op >= 0) {
                     uint64_t num;
-                    if (!parse_u(c + i, j - i, UINT64_MAX, num)) { S.err = E_CIGAR_OVERFLOW; return; }
+                    if (!parse_u(c + i, j - i, UINT64_MAX, num)) {
+                        // a length the reference could not parse either -- but it only tries when a pair comparison
+                        // needs this alignment's end (get_ref_end is lazy): the alignment is marked, not refused
+                        S.runs.resize(a.run_lo);
+                        S.runs.push_back((uint32_t)PP_OP_UNPARSEABLE);
+                        break;
+                    }
                     while (num > 0) {  // a packed run holds 28 bits of length
                         const uint32_t piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)num;
                         S.runs.push_back((piece << 4) | (uint32_t)op);

@@ -127,7 +127,7 @@ struct pp_ctx {
     pp::DevBuf b_comm;
 
     // ---- filter job ----
-    pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert;
+    pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert, f_poisoned;
     pp_filter_input fdev{};
     const uint64_t *f_refend_ptr[2] = {nullptr, nullptr};
     bool filter_open = false;

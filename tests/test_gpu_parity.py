@@ -1080,3 +1080,42 @@ def test_heavy_windows_are_split_over_helper_blocks(ctx, pp, orc):
                                                indel_read_frac=0.0)
     _compare_records(ctx, orc, contig_off, bases, recs)
 
+
+def test_filter_only_fails_on_an_unparseable_cigar_when_it_needs_it(tmp_path):
+    """get_ref_end is lazy (src/alignment.rs:138-149: run lengths are parsed when an alignment's end is asked for): a
+    CIGAR with a length beyond 64 bits is only fatal -- a panic, exit 101 -- if that alignment takes part in a pair
+    comparison (src/filter.rs:189-218, 352-377).  Lone alignments and single alignments that are never paired up (the
+    mate on another contig) pass through untouched.  Output bytes and exit codes against the oracle's CLI, both loaders."""
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    orc_exe = os.path.join(ROOT, "oracle", "_build", "pp_oracle")
+    huge = "9" * 25 + "M"
+    head = "@SQ\tSN:c\tLN:100000\n@SQ\tSN:d\tLN:100000\n"
+
+    def line(name, flag, pos, cigar="50M", ref="c"):
+        return f"{name}\t{flag}\t{ref}\t{pos}\t60\t{cigar}\t*\t0\t0\t{'A' * 50}\t{'I' * 50}\tNM:i:0\n"
+    pairs1 = "".join(line(f"p{i}", 0, 100 + 7 * i) for i in range(40))
+    pairs2 = "".join(line(f"p{i}", 16, 400 + 7 * i) for i in range(40))
+    cases = {
+        # a read whose mate has no alignment: never compared
+        "lone": (pairs1 + line("lone", 0, 50, huge), pairs2, 0),
+        # a read with ONE alignment and a mate: passes without a comparison (filter.rs:361-363) -- but it takes part in
+        # the threshold sampling (one alignment per read, same reference): evaluated there
+        "sampled": (pairs1 + line("s", 0, 50, huge), pairs2 + line("s", 16, 300), 101),
+        # two alignments for the read, the mate's only alignment is fine: both ends are needed for the comparison
+        "compared": (pairs1 + line("m", 0, 50, huge) + line("m", 256, 900), pairs2 + line("m", 16, 350), 101),
+        # one alignment each, on different contigs: not sampled (filter.rs:160), and each passes as its read's only
+        # alignment without a comparison
+        "different_reference": (pairs1 + line("x", 0, 50, huge), pairs2 + line("x", 16, 300, ref="d"), 0),
+    }
+    for name, (t1, t2, want_rc) in cases.items():
+        a, b = tmp_path / f"{name}_1.sam", tmp_path / f"{name}_2.sam"
+        a.write_text(head + t1)
+        b.write_text(head + t2)
+        outs = {}
+        for who, binary, env in (("oracle", orc_exe, {}), ("host", exe, {}), ("device", exe, {"PP_DEVICE_FILTER": "1"})):
+            o1, o2 = tmp_path / f"{name}_{who}_1.out", tmp_path / f"{name}_{who}_2.out"
+            r = subprocess.run([binary, "filter", "--in1", str(a), "--in2", str(b), "--out1", str(o1), "--out2", str(o2)],
+                               capture_output=True, env=dict(os.environ, **env))
+            assert r.returncode == want_rc, (name, who, r.returncode, r.stderr.decode()[-600:])
+            outs[who] = (o1.read_bytes(), o2.read_bytes()) if want_rc == 0 else None
+        assert outs["host"] == outs["oracle"] and outs["device"] == outs["oracle"], name
