@@ -41,6 +41,10 @@ extern "C" {
 #define PP_ERR_HIP 3     /* HIP runtime failure, or no usable device                             */
 #define PP_ERR_ARG 4     /* the caller broke this header's contract                               */
 #define PP_ERR_LIMIT 5   /* input exceeds a documented implementation limit                       */
+#define PP_ERR_NOT_ASCII 6 /* device text front ends (pp_dev_ingest_sam*, pp_filter_load_device) only: the file holds
+                              bytes outside ASCII.  Whether all of its lines are valid UTF-8 -- the reference refuses
+                              the others (BufRead::lines) -- is decided by the host parsers: load it with those.  The
+                              file drivers (pp_polish_files, pp_filter_files, ...) do that by themselves           */
 #define PP_ERR_PANIC 101 /* the reference would panic (unwrap / index out of bounds): exit 101    */
 
 #define PP_MEM_HOST 0   /* pointer is host memory: the library copies it to the device             */

@@ -28,13 +28,19 @@ __device__ __forceinline__ u32 count_nl16(uint4 v) {
     return n;
 }
 
-// text is padded with zeros up to a multiple of NL_BLOCK
+// text is padded with zeros up to a multiple of NL_BLOCK.  blk_cnt[gridDim.x] (zeroed by the caller) is set when a byte
+// outside ASCII shows up anywhere: the reference refuses lines that are not valid UTF-8 (BufRead::lines), and which
+// ones are is then left to the host parsers -- SAM text is ASCII in practice.
 __global__ __launch_bounds__(1024) void k_nl_count(const u8 *__restrict__ text, u32 *__restrict__ blk_cnt) {
     __shared__ u32 s_sum;
     if (threadIdx.x == 0) s_sum = 0;
     __syncthreads();
     const uint4 *p = (const uint4 *)(text + (u64)blockIdx.x * NL_BLOCK + (u64)threadIdx.x * 64u);
-    const u32 n = count_nl16(p[0]) + count_nl16(p[1]) + count_nl16(p[2]) + count_nl16(p[3]);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    const u32 high = (q0.x | q0.y | q0.z | q0.w | q1.x | q1.y | q1.z | q1.w | q2.x | q2.y | q2.z | q2.w | q3.x | q3.y | q3.z | q3.w) &
+                     0x80808080u;
+    if (__ballot(high != 0) && (threadIdx.x & 63u) == 0) atomicOr(&blk_cnt[gridDim.x], 1u);
+    const u32 n = count_nl16(q0) + count_nl16(q1) + count_nl16(q2) + count_nl16(q3);
     u32 v = n;
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&s_sum, v);

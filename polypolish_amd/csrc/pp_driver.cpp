@@ -285,7 +285,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         pp_sam_counts c;
         if (dev_ingest) {
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
-            if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC) {
+            if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC || rc == PP_ERR_NOT_ASCII) {
                 // A defect in the text.  Which defect the reference reports FIRST also depends on what its CIGAR walk
                 // makes of the records before it: the host ingest works that out (below), on this rare path.
                 free_all();

@@ -106,7 +106,7 @@ struct FAln {         // Alignment::new_quick, alignment.rs:102-128
     uint32_t name_n, ref_local, ref_start, flags, run_lo, run_n;
 };
 
-enum { E_NONE = 0, E_COLUMNS, E_NUMBER, E_POS_LIMIT, E_CIGAR_OVERFLOW };
+enum { E_NONE = 0, E_COLUMNS, E_NUMBER, E_POS_LIMIT, E_CIGAR_OVERFLOW, E_UTF8 };
 
 struct Slice {
     const char *beg = nullptr, *end = nullptr;
@@ -130,6 +130,7 @@ void parse_slice(Slice &S, const char *text) {
         p += l + (nl ? 1 : 0);
         if (l > 0 && line[l - 1] == '\r') l--;
         S.lines.push_back(FLine{(uint64_t)(line - text), (uint32_t)l, -1});
+        if (!pph::valid_utf8(line, l)) { S.err = E_UTF8; return; }  // `let sam_line = line?`, filter.rs:121
         if (l > 0 && line[0] == '@') continue;
         const char *col[11];
         size_t len[11];
@@ -358,6 +359,7 @@ extern "C" int pp_filter_load(const char *in1, const char *in2, pp_filter_loaded
                 case E_COLUMNS: fail(PP_ERR_QUIT, "too few columns in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 case E_NUMBER: fail(PP_ERR_PANIC, "could not parse FLAG or POS in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 case E_POS_LIMIT: fail(PP_ERR_LIMIT, "POS beyond 2^32 in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
+                case E_UTF8: fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", ins[f]);
                 default: fail(PP_ERR_PANIC, "CIGAR run length overflow in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 }
             }
@@ -642,6 +644,7 @@ extern "C" int pp_filter_line_error_(const char *line, size_t n, const char *pat
     case E_COLUMNS: snprintf(err, errlen, "too few columns in \"%s\" (line %llu)", path, ln); return PP_ERR_QUIT;
     case E_NUMBER: snprintf(err, errlen, "could not parse FLAG or POS in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
     case E_POS_LIMIT: snprintf(err, errlen, "POS beyond 2^32 in \"%s\" (line %llu)", path, ln); return PP_ERR_LIMIT;
+    case E_UTF8: snprintf(err, errlen, "unable to load alignments from \"%s\"", path); return PP_ERR_QUIT;
     default: snprintf(err, errlen, "CIGAR run length overflow in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
     }
 }
@@ -816,12 +819,19 @@ int filter_core(pp_ctx *ctx, const Log &log, const std::function<void(const char
     const char *ins[2] = {in1, in2};
     // PP_DEVICE_FILTER=1: load_alignments as kernels (pp_filter_dev.hip).  Default is the host loader: its parse
     // overlaps the HIP runtime's start-up, which the device loader has to wait for (measured: 0.86 s vs 1.07 s).
-    const bool dev_load = getenv("PP_DEVICE_FILTER") && atoi(getenv("PP_DEVICE_FILTER")) != 0;
+    bool dev_load = getenv("PP_DEVICE_FILTER") && atoi(getenv("PP_DEVICE_FILTER")) != 0;
     pp_filter_file_counts fc[2];
     char err[1400] = "";
-    int rc;
-    if (dev_load) rc = pp_filter_load_device(ctx, in1, in2, &R.DL, fc);
-    else rc = pp_filter_load(in1, in2, &R.L, fc, err, sizeof err);
+    int rc = PP_OK;
+    if (dev_load) {
+        rc = pp_filter_load_device(ctx, in1, in2, &R.DL, fc);
+        if (rc == PP_ERR_NOT_ASCII) {  // whether every line is valid UTF-8 is the host loader's call
+            pp_filter_dev_free(R.DL);
+            R.DL = nullptr;
+            dev_load = false;
+        }
+    }
+    if (!dev_load) rc = pp_filter_load(in1, in2, &R.L, fc, err, sizeof err);
     for (int f = 0; f < 2; f++)
         if (fc[f].loaded)
             log("%s: %s alignments from %s reads\n", ins[f], commas(fc[f].alignments).c_str(), commas(fc[f].reads).c_str());

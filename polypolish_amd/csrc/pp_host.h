@@ -154,6 +154,39 @@ inline void prefetch_drop_all() {  // whatever was prefetched and never opened
     }
 }
 
+// BufRead::lines() yields an error for a line that is not valid UTF-8, and every loader of the reference turns that into
+// "unable to load ..." (src/alignment.rs:238-240, src/filter.rs:119-121, src/misc.rs:109-111).  Lines are ASCII in
+// practice: eight bytes at a time until a byte with its top bit set shows up, the full check (overlong forms, surrogates,
+// code points beyond U+10FFFF as Rust's str::from_utf8 rejects them) only from there.
+inline bool valid_utf8(const char *s, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        if (w & 0x8080808080808080ull) break;
+    }
+    while (i < n) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c < 0x80) { i++; continue; }
+        size_t need;
+        uint32_t cp;
+        if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1Fu; if (cp < 2) return false; }
+        else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0Fu; }
+        else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07u; if (cp > 4) return false; }
+        else return false;
+        for (size_t k = 1; k <= need; k++) {
+            if (i + k >= n) return false;  // truncated sequence
+            const unsigned char cc = (unsigned char)s[i + k];
+            if ((cc & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (cc & 0x3Fu);
+        }
+        if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return false;
+        if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
 // A whole file as read-only bytes: mmap for regular files, read() for pipes.
 struct FileText {
     const char *text = nullptr;

@@ -167,6 +167,7 @@ static void load_fasta(const char *path, pp_assembly &a) {
         a.off.push_back(a.bases.size());
     };
     while (lr.next(line, n)) {
+        if (!pph::valid_utf8(line, n)) fail(PP_ERR_QUIT, "unable to load \"%s\"", path);  // lines() fails, misc.rs:109-111
         if (n == 0) continue;
         if (line[0] == '>') {
             if (have) push();
@@ -256,6 +257,8 @@ struct Rec {
     uint8_t pass_qc;
 };
 
+static const char NOT_UTF8[] = "\x01not-utf8";  // err_what of a line that is not valid UTF-8 (the message names the file)
+
 // A slice of the file, parsed by one thread.
 struct Chunk {
     const char *beg = nullptr, *end = nullptr;
@@ -280,10 +283,12 @@ void parse_chunk(Chunk &c, const pp_assembly *asmb) {
         p += n + (nl ? 1 : 0);
         if (n > 0 && line[n - 1] == '\r') n--;
         c.n_lines++;
-        if (n == 0 || line[0] == '@') continue;
         auto fail = [&](int code, const char *what, bool with_line) {
             c.err_code = code; c.err_what = what; c.err_has_line = with_line; c.err_recs = c.recs.size();
         };
+        // `let sam_line = line?` (alignment.rs:240): a line that is not UTF-8 ends the load before anything looks at it
+        if (!pph::valid_utf8(line, n)) { fail(PP_ERR_QUIT, NOT_UTF8, false); return; }
+        if (n == 0 || line[0] == '@') continue;
         const char *col[11];
         size_t len[11];
         size_t nc = 0;
@@ -635,6 +640,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             uint64_t line_no = line_base + ch.n_lines;
             for (size_t u = 0; u < n_chunks_ok; u++) line_no += chunks[u].n_lines;
             if (ch.err_has_line) fail(ch.err_code, "%s in \"%s\" (line %llu)", ch.err_what.c_str(), path, (unsigned long long)line_no);
+            if (ch.err_what == NOT_UTF8) fail(ch.err_code, "unable to load alignments from \"%s\"", path);
             fail(ch.err_code, "%s", ch.err_what.c_str());
         }
         if (total_recs == 0 && prefix_mode) {  // nothing had been processed before the failure

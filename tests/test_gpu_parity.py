@@ -1119,3 +1119,34 @@ def test_filter_only_fails_on_an_unparseable_cigar_when_it_needs_it(tmp_path):
             assert r.returncode == want_rc, (name, who, r.returncode, r.stderr.decode()[-600:])
             outs[who] = (o1.read_bytes(), o2.read_bytes()) if want_rc == 0 else None
         assert outs["host"] == outs["oracle"] and outs["device"] == outs["oracle"], name
+
+
+def test_device_front_ends_hand_non_ascii_text_to_the_host_parsers(orc, tmp_path):
+    """The device tokenizer and the device filter loader only notice THAT a file holds bytes outside ASCII (newline pass);
+    which lines are valid UTF-8 -- the reference refuses the others -- is the host parsers' call: the drivers fall back.
+    CLI against the oracle's CLI: valid UTF-8 in a tag changes nothing, an invalid byte ends the load."""
+    ds = synth.rich_dataset(str(tmp_path), seed=96, contig_lens=(1500,), coverage=8)
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    orc_exe = os.path.join(ROOT, "oracle", "_build", "pp_oracle")
+    base1 = open(ds["sam1"], "rb").read().split(b"\n")
+    body = [i for i, l in enumerate(base1) if l and not l.startswith(b"@")]
+    for name, blob, ok in (("valid", "日本".encode(), True), ("invalid", b"\xff", False)):
+        i = body[len(body) // 2]
+        f1 = tmp_path / f"{name}_1.sam"
+        f1.write_bytes(b"\n".join(base1[:i] + [base1[i] + b"\tXX:Z:" + blob] + base1[i + 1:]))
+        want = subprocess.run([orc_exe, "polish", ds["fasta"], str(f1), ds["sam2"]], capture_output=True)
+        assert (want.returncode == 0) == ok
+        for ingest in ("1", "0"):
+            got = subprocess.run([exe, "polish", ds["fasta"], str(f1), ds["sam2"]], capture_output=True,
+                                 env=dict(os.environ, PP_DEVICE_INGEST=ingest))
+            assert got.returncode == want.returncode and got.stdout == want.stdout, (name, ingest, got.stderr[-500:])
+            if not ok:
+                assert b"unable to load alignments" in got.stderr and b"unable to load alignments" in want.stderr
+        outs = {}
+        for who, binary, env in (("oracle", orc_exe, {}), ("host", exe, {}), ("device", exe, {"PP_DEVICE_FILTER": "1"})):
+            o1, o2 = tmp_path / f"{name}_{who}_1.out", tmp_path / f"{name}_{who}_2.out"
+            r = subprocess.run([binary, "filter", "--in1", str(f1), "--in2", ds["sam2"], "--out1", str(o1), "--out2", str(o2)],
+                               capture_output=True, env=dict(os.environ, **env))
+            assert (r.returncode == 0) == ok, (name, who, r.stderr[-500:])
+            outs[who] = (o1.read_bytes(), o2.read_bytes()) if ok else r.returncode
+        assert outs["host"] == outs["oracle"] == outs["device"], name

@@ -83,3 +83,114 @@ def test_fuzz_filter_load_against_the_oracle(orc, tmp_path):
             assert sum(c[0] for c in L.counts) == rep["before"], trial
         L.close()
     assert n_same >= 20
+
+
+def test_lines_that_are_not_utf8_end_the_load_like_the_reference(orc, tmp_path):
+    """BufRead::lines() fails on a line that is not valid UTF-8 and every loader turns that into "unable to load ..."
+    (src/alignment.rs:238-240, src/filter.rs:119-121, src/misc.rs:109-111) -- in streaming order: a defect on an
+    earlier line is reported instead, a defect on a later line is not.  Valid multi-byte UTF-8 is just text.  The
+    product's host parsers against the oracle: polish ingest, filter load, FASTA."""
+    ds = synth.rich_dataset(str(tmp_path), seed=95, contig_lens=(900,), coverage=5)
+    base1, base2 = open(ds["sam1"], "rb").read(), open(ds["sam2"], "rb").read()
+    lines = base1.split(b"\n")
+    body = [i for i, l in enumerate(lines) if l and not l.startswith(b"@")]
+    head = [i for i, l in enumerate(lines) if l.startswith(b"@")]
+    bad = {"ff": b"\xff", "overlong": b"\xc0\x80", "surrogate": b"\xed\xa0\x80", "beyond": b"\xf4\x90\x80\x80",
+           "lone_continuation": b"\x80", "five_byte_lead": b"\xf8\x88\x80\x80\x80"}
+    good = {"two": "é".encode(), "three": "日".encode(), "four": "\U0001F600".encode()}
+    f1, f2, o1, o2 = (str(tmp_path / n) for n in ("u1.sam", "u2.sam", "o1.sam", "o2.sam"))
+    open(f2, "wb").write(base2)
+
+    def put(col, blob, where=None, at_end=False):
+        i = body[len(body) // 2] if where is None else where
+        f = lines[i].split(b"\t")
+        f[col] = f[col] + blob if at_end else f[col][:1] + blob + f[col][1:]
+        return lines[:i] + [b"\t".join(f)] + lines[i + 1:]
+
+    def both():
+        try:
+            want, we = orc.polish_files(ds["fasta"], [f1, f2]), None
+        except orc.OrcError as e:
+            want, we = None, (e.code, e.msg)
+        try:
+            got, ge = pp.ingest(ds["fasta"], [f1, f2]), None
+        except pp.PolypolishError as e:
+            got, ge = None, (e.code, e.msg)
+        try:
+            orc.filter_files(f1, f2, o1, o2)
+            fwe = None
+        except orc.OrcError as e:
+            fwe = (e.code, e.msg)
+        try:
+            pp.FilterLoaded(f1, f2).close()
+            fge = None
+        except pp.PolypolishError as e:
+            fge = (e.code, e.msg)
+        return we, ge, fwe, fge
+
+    n_bad = 0
+    for name, blob in bad.items():
+        for col in (0, 5, 9, 10, 11):  # QNAME, CIGAR, SEQ, QUAL, first tag
+            open(f1, "wb").write(b"\n".join(put(col, blob)))
+            we, ge, fwe, fge = both()
+            assert we is not None and "unable to load alignments" in we[1] and ge == we, (name, col, ge, we)
+            assert fwe is not None and "unable to load alignments" in fwe[1] and fge == fwe, (name, col, fge, fwe)
+            n_bad += 1
+        # a truncated sequence at the very end of a line, and in a header line
+        open(f1, "wb").write(b"\n".join(put(len(lines[body[3]].split(b"\t")) - 1, blob[:1] if len(blob) > 1 else blob, body[3], at_end=True)))
+        we, ge, fwe, fge = both()
+        assert we is not None and ge == we and fge == fwe and "unable to load" in we[1], (name, ge, we)
+        if head:
+            hl = lines[:head[0]] + [lines[head[0]] + b"\t" + blob] + lines[head[0] + 1:]
+            open(f1, "wb").write(b"\n".join(hl))
+            we, ge, fwe, fge = both()
+            assert we is not None and ge == we and fge == fwe and "unable to load" in we[1], (name, ge, we)
+    assert n_bad == 30
+    for name, blob in good.items():   # valid UTF-8: in a tag it changes nothing, in a QNAME it is just another name
+        for col in (0, 11):
+            open(f1, "wb").write(b"\n".join(put(col, blob)))
+            we, ge, fwe, fge = both()
+            assert we is None and ge is None and fwe is None and fge is None, (name, col, we, ge, fwe, fge)
+    # streaming order: a parse defect BEFORE the bad line wins, one AFTER it does not
+    early, late = body[2], body[-3]
+    broken = lines[:]
+    broken[early] = b"\t".join(lines[early].split(b"\t")[:5])           # too few columns
+    broken = broken[:late] + put(0, b"\xff", late)[late:]
+    open(f1, "wb").write(b"\n".join(broken))
+    we, ge, fwe, fge = both()
+    assert "too few columns" in we[1] and ge == we and fge == fwe, (ge, we, fge, fwe)
+    broken = put(0, b"\xff", early)
+    broken[late] = b"\t".join(lines[late].split(b"\t")[:5])
+    open(f1, "wb").write(b"\n".join(broken))
+    we, ge, fwe, fge = both()
+    assert "unable to load alignments" in we[1] and ge == we and fge == fwe, (ge, we, fge, fwe)
+
+    # FASTA (src/misc.rs:109-111): a header may hold any valid UTF-8, nothing may hold invalid bytes
+    open(f1, "wb").write(base1)
+    fa = open(ds["fasta"], "rb").read().split(b"\n")
+    alt = str(tmp_path / "alt.fasta")
+    for blob, ok in ((good["three"], True), (b"\xff", False), (b"\xc0\x80", False)):
+        open(alt, "wb").write(b"\n".join([fa[0] + b" " + blob] + fa[1:]))
+        try:
+            orc.polish_files(alt, [f1, f2])
+            we = None
+        except orc.OrcError as e:
+            we = (e.code, e.msg)
+        try:
+            pp.ingest(alt, [f1, f2])
+            ge = None
+        except pp.PolypolishError as e:
+            ge = (e.code, e.msg)
+        assert (we is None) == ok and ge == we, (blob, ge, we)
+    open(alt, "wb").write(b"\n".join(fa[:1] + [fa[1][:5] + b"\xff" + fa[1][5:]] + fa[2:]))
+    try:
+        orc.polish_files(alt, [f1, f2])
+        we = None
+    except orc.OrcError as e:
+        we = (e.code, e.msg)
+    try:
+        pp.ingest(alt, [f1, f2])
+        ge = None
+    except pp.PolypolishError as e:
+        ge = (e.code, e.msg)
+    assert we is not None and "unable to load" in we[1] and ge == we, (ge, we)
