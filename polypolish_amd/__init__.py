@@ -22,6 +22,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("PP_LIB_PATH") or os.path.join(HERE, "_build", "libpolypolish_hip.so")  # PP_LIB_PATH: kernel experiments
 
 OK, ERR_QUIT, ERR_HIP, ERR_ARG, ERR_LIMIT, ERR_PANIC = 0, 1, 3, 4, 5, 101
+ERR_NOT_ASCII = 6  # device text front ends only: bytes outside ASCII, the host parsers take such a file
 MEM_HOST, MEM_DEVICE = 0, 1
 STATUS = ("kept", "changed", "low_depth", "none", "multiple", "too_close")
 OPS = "MIDNSHP=X"
