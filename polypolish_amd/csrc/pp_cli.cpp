@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
 
@@ -186,9 +187,18 @@ int main(int argc, char **argv) {
             if (!assembly) assembly = a; else sams.push_back(a);
         }
         if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
-        // All visible GPUs polish (contigs / windows of a large contig shard across them) unless --debug is asked for;
-        // PP_GPUS=n limits them, PP_SHARE_GPU=n (tests on a one-GPU box) runs n contexts on the one device.
-        std::vector<int> devs = polish_devices(device, opt.debug_path != nullptr);
+        // Several GPUs polish (contigs / windows of a large contig shard across them) when PP_GPUS=n asks for them, or
+        // by themselves from 8 GiB of SAM text on; never with --debug.  Below that one GPU is the faster choice end to
+        // end: the polish itself is a millisecond per 5 Mbp, what a second context adds is its start-up and another
+        // copy of the records over PCIe, and only the single-GPU path tokenizes on the device.  PP_SHARE_GPU=n (tests
+        // on a one-GPU box) runs n contexts on the one device.
+        unsigned long long sam_bytes = 0;
+        for (const char *sp : sams) {
+            struct stat st;
+            if (stat(sp, &st) == 0 && S_ISREG(st.st_mode)) sam_bytes += (unsigned long long)st.st_size;
+        }
+        const bool few = sam_bytes < (8ull << 30) && !getenv("PP_GPUS") && !getenv("PP_SHARE_GPU");
+        std::vector<int> devs = polish_devices(device, opt.debug_path != nullptr || few);
         if (devs.size() > 1) {
             std::vector<pp_ctx *> cs(devs.size(), nullptr);
             for (size_t d = 0; d < devs.size(); d++)
