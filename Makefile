@@ -50,7 +50,18 @@ variant: $(LIB)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pp_kernels.hip -o $(OUT)/var_$(NAME)/pp_kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/var_$(NAME)/libpolypolish_hip.so $(OUT)/var_$(NAME)/pp_kernels.o $(filter-out $(OUT)/pp_kernels.o,$(OBJS)) -lz -lpthread -ldl
 
+# the host side (parsers, filter loader and writer, planner, drivers) under AddressSanitizer; the device objects as they are:
+#   make asan && LD_PRELOAD=$$(hipcc -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 \
+#       PP_LIB_PATH=$(OUT)/asan/libpolypolish_hip.so python -m pytest tests -m "not gpu" -q
+HOSTSRC := pp_ingest pp_filter_host pp_shard pp_driver
+asan: $(LIB)
+	@mkdir -p $(OUT)/asan
+	for f in $(HOSTSRC); do $(HIPCC) --offload-arch=$(ARCH) -O1 -g -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) \
+	    -fsanitize=address -fno-omit-frame-pointer -x c++ -c $(CSRC)/$$f.cpp -o $(OUT)/asan/$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fsanitize=address -o $(OUT)/asan/libpolypolish_hip.so \
+	    $(filter-out $(addprefix $(OUT)/,$(addsuffix .o,$(HOSTSRC))),$(OBJS)) $(addprefix $(OUT)/asan/,$(addsuffix .o,$(HOSTSRC))) -lz -lpthread -ldl
+
 clean:
 	rm -rf $(OUT) bin oracle/_build tools/_build
 
-.PHONY: all oracle clean variant
+.PHONY: all oracle clean variant asan
