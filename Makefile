@@ -29,7 +29,7 @@ $(LIB): $(OBJS)
 
 bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
 	@mkdir -p bin
-	$(HIPCC) -O2 -std=c++17 -Iinclude -x c++ $(CSRC)/pp_cli.cpp -x none -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
+	$(HIPCC) -O2 -std=c++17 -Iinclude -x c++ $(CSRC)/pp_cli.cpp -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
 
 # strict C99: the header is a C header, and nothing but the C ABI is needed on the caller's side
 bin/polish_min: examples/polish_min.c include/polypolish_hip.h $(LIB)
