@@ -106,7 +106,7 @@ struct FAln {         // Alignment::new_quick, alignment.rs:102-128
     uint32_t name_n, ref_local, ref_start, flags, run_lo, run_n;
 };
 
-enum { E_NONE = 0, E_COLUMNS, E_NUMBER, E_POS_LIMIT, E_CIGAR_OVERFLOW, E_UTF8 };
+enum { E_NONE = 0, E_COLUMNS, E_NUMBER, E_POS_LIMIT, E_UTF8 };
 
 struct Slice {
     const char *beg = nullptr, *end = nullptr;
@@ -360,7 +360,7 @@ extern "C" int pp_filter_load(const char *in1, const char *in2, pp_filter_loaded
                 case E_NUMBER: fail(PP_ERR_PANIC, "could not parse FLAG or POS in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 case E_POS_LIMIT: fail(PP_ERR_LIMIT, "POS beyond 2^32 in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 case E_UTF8: fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", ins[f]);
-                default: fail(PP_ERR_PANIC, "CIGAR run length overflow in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
+                default: fail(PP_ERR_HIP, "internal: unknown parse error in \"%s\" (line %llu)", ins[f], (unsigned long long)line_no);
                 }
             }
             X.aln_first.assign(threads + 1, 0);
@@ -645,7 +645,7 @@ extern "C" int pp_filter_line_error_(const char *line, size_t n, const char *pat
     case E_NUMBER: snprintf(err, errlen, "could not parse FLAG or POS in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
     case E_POS_LIMIT: snprintf(err, errlen, "POS beyond 2^32 in \"%s\" (line %llu)", path, ln); return PP_ERR_LIMIT;
     case E_UTF8: snprintf(err, errlen, "unable to load alignments from \"%s\"", path); return PP_ERR_QUIT;
-    default: snprintf(err, errlen, "CIGAR run length overflow in \"%s\" (line %llu)", path, ln); return PP_ERR_PANIC;
+    default: snprintf(err, errlen, "internal: unknown parse error in \"%s\" (line %llu)", path, ln); return PP_ERR_HIP;
     }
 }
 
