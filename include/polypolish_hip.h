@@ -135,11 +135,12 @@ typedef struct {
 } pp_contig_stats;
 
 /* Optional, between pp_polish_begin and pp_polish_finish: restrict what contig c EMITS to its positions
- * [emit_lo[c], emit_hi[c]) (0-based, relative to the contig; arrays of n_contigs, host memory).  Every
- * position is still piled up and voted with all the alignments given, but positions outside the range
- * contribute no polished bytes and no statistics.  This is the window tiling of one large contig across
- * GPUs: a rank receives its window plus a halo of one alignment span on either
- * side, with the alignments overlapping the window, and emits only the window.  NULL, NULL = everything. */
+ * [emit_lo[c], emit_hi[c]) (0-based, relative to the contig; arrays of n_contigs, host memory).  Positions outside
+ * the range contribute no polished bytes and no statistics, records that do not reach the range are validated and
+ * then dropped, windows outside it are not worked on.  This is how one rank of a sharded job (SURVEY 8e, configs
+ * C4 / C5) polishes its contigs or its window of a large contig: it is given the records that reach its ranges
+ * (pp_shard_split -- or simply all records) and emits only what it owns; an owned position sees all of its
+ * alignments in file order either way, so the order-dependent f64 depth is exact.  NULL, NULL = everything. */
 int pp_polish_set_emit(pp_ctx *ctx, const uint64_t *emit_lo, const uint64_t *emit_hi);
 
 /* Start a polish job.  contig_off is a HOST array of n_contigs+1 offsets into `bases` (the

@@ -76,20 +76,88 @@ static bool parse_u32(const char *s, uint32_t &v) {
     return true;
 }
 
-// returns the value of `--name value` / `--name=value` / `-x value`; advances i
-static const char *opt_value(int argc, char **argv, int &i, const char *arg, const char *long_name, const char *short_name) {
-    size_t ln = strlen(long_name);
-    if (strncmp(arg, long_name, ln) == 0 && arg[ln] == '=') return arg + ln + 1;
-    if (strcmp(arg, long_name) == 0 || (short_name && strcmp(arg, short_name) == 0)) {
-        if (i + 1 >= argc) return nullptr;
-        return argv[++i];
-    }
-    return nullptr;
+// ---- clap's argument grammar (the reference derives its parser with clap 4.4, src/main.rs:23-109) ----------------
+//   --name value | --name=value | -x value | -xvalue | -x=value | flags clustered (-hV) | "--" ends the options |
+//   a lone "-" is a positional | an option given twice is an error | unknown options are errors.
+struct OptSpec {
+    const char *long_name;   // "--min_depth"
+    char short_name;         // 'd', or 0
+    bool takes_value;
+    const char *value_name;  // "<MIN_DEPTH>" (error texts)
+};
+
+struct Parsed {
+    std::vector<const char *> value;  // per option: the value (flags: "" when present), nullptr when absent
+    std::vector<const char *> positional;
+    int help = 0, version = 0;
+    std::string error;                // non-empty: usage error (exit 2)
+};
+
+static std::string opt_display(const OptSpec &o) {
+    std::string d = o.long_name;
+    if (o.takes_value) { d += ' '; d += o.value_name; }
+    return d;
 }
-static bool is_opt(const char *arg, const char *long_name, const char *short_name) {
-    size_t ln = strlen(long_name);
-    return strcmp(arg, long_name) == 0 || (strncmp(arg, long_name, ln) == 0 && arg[ln] == '=') ||
-           (short_name && strcmp(arg, short_name) == 0);
+
+static Parsed parse_args(int argc, char **argv, int first, const std::vector<OptSpec> &specs) {
+    Parsed P;
+    P.value.assign(specs.size(), nullptr);
+    bool only_positional = false;
+    auto set = [&](size_t k, const char *v) {
+        if (P.value[k]) { P.error = "the argument '" + opt_display(specs[k]) + "' cannot be used multiple times"; return false; }
+        P.value[k] = v;
+        return true;
+    };
+    for (int i = first; i < argc && P.error.empty(); i++) {
+        const char *a = argv[i];
+        if (only_positional || a[0] != '-' || a[1] == 0) { P.positional.push_back(a); continue; }
+        if (a[1] == '-') {
+            if (a[2] == 0) { only_positional = true; continue; }
+            const char *eq = strchr(a, '=');
+            const std::string name = eq ? std::string(a, (size_t)(eq - a)) : std::string(a);
+            if (name == "--help") { P.help = 1; return P; }
+            if (name == "--version") { P.version = 1; return P; }
+            size_t k = 0;
+            while (k < specs.size() && name != specs[k].long_name) k++;
+            if (k == specs.size()) { P.error = "unexpected argument '" + name + "' found"; break; }
+            if (!specs[k].takes_value) {
+                if (eq) { P.error = "unexpected value '" + std::string(eq + 1) + "' for '" + name + "' found; no more were expected"; break; }
+                set(k, "");
+                continue;
+            }
+            const char *v = eq ? eq + 1 : (i + 1 < argc ? argv[++i] : nullptr);
+            if (!v) { P.error = "a value is required for '" + opt_display(specs[k]) + "' but none was supplied"; break; }
+            set(k, v);
+            continue;
+        }
+        for (const char *c = a + 1; *c && P.error.empty(); c++) {  // a cluster of short options
+            if (*c == 'h') { P.help = 1; return P; }
+            if (*c == 'V') { P.version = 1; return P; }
+            size_t k = 0;
+            while (k < specs.size() && specs[k].short_name != *c) k++;
+            if (k == specs.size()) { P.error = std::string("unexpected argument '-") + *c + "' found"; break; }
+            if (!specs[k].takes_value) { set(k, ""); continue; }
+            const char *v = c[1] ? (c[1] == '=' ? c + 2 : c + 1) : (i + 1 < argc ? argv[++i] : nullptr);
+            if (!v) { P.error = "a value is required for '" + opt_display(specs[k]) + "' but none was supplied"; break; }
+            set(k, v);
+            break;  // the rest of the argument was the value
+        }
+    }
+    return P;
+}
+
+// value of option k as f64 / u32 (clap's value_parser for the field type); false + error text on a bad value
+static bool take_f64(const Parsed &P, const std::vector<OptSpec> &specs, size_t k, double &dst, std::string &err) {
+    if (!P.value[k]) return true;
+    if (parse_f64(P.value[k], dst)) return true;
+    err = std::string("invalid value '") + P.value[k] + "' for '" + opt_display(specs[k]) + "': invalid float literal";
+    return false;
+}
+static bool take_u32(const Parsed &P, const std::vector<OptSpec> &specs, size_t k, uint32_t &dst, std::string &err) {
+    if (!P.value[k]) return true;
+    if (parse_u32(P.value[k], dst)) return true;
+    err = std::string("invalid value '") + P.value[k] + "' for '" + opt_display(specs[k]) + "': invalid digit found in string";
+    return false;
 }
 
 static int no_device(int device) {
@@ -156,36 +224,25 @@ int main(int argc, char **argv) {
 
     if (cmd == "polish") {
         pp_polish_options opt{0.2, 0.5, 10, 5, 0, nullptr, 0};
-        const char *assembly = nullptr;
-        std::vector<const char *> sams;
-        for (int i = 2; i < argc; i++) {
-            const char *a = argv[i];
-            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_POLISH, stdout); return 0; }
-            if (!strcmp(a, "-V") || !strcmp(a, "--version")) { printf("polypolish-polish v0.6.1\n"); return 0; }
-            if (!strcmp(a, "--careful")) { opt.careful = 1; continue; }
-            if (is_opt(a, "--debug", nullptr)) {
-                const char *v = opt_value(argc, argv, i, a, "--debug", nullptr);
-                if (!v) return usage_error("a value is required for '--debug <DEBUG>' but none was supplied");
-                opt.debug_path = v;
-                continue;
-            }
-            struct { const char *l, *s; int kind; void *dst; } table[] = {
-                {"--fraction_invalid", "-i", 0, &opt.fraction_invalid}, {"--fraction_valid", "-v", 0, &opt.fraction_valid},
-                {"--max_errors", "-m", 1, &opt.max_errors}, {"--min_depth", "-d", 1, &opt.min_depth}};
-            bool matched = false;
-            for (auto &t : table) {
-                if (!is_opt(a, t.l, t.s)) continue;
-                const char *v = opt_value(argc, argv, i, a, t.l, t.s);
-                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
-                bool ok = t.kind == 0 ? parse_f64(v, *(double *)t.dst) : parse_u32(v, *(uint32_t *)t.dst);
-                if (!ok) return usage_error((std::string("invalid value '") + v + "' for '" + t.l + "'").c_str());
-                matched = true;
-                break;
-            }
-            if (matched) continue;
-            if (a[0] == '-' && a[1] != 0) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
-            if (!assembly) assembly = a; else sams.push_back(a);
+        const std::vector<OptSpec> specs = {{"--debug", 0, true, "<DEBUG>"},
+                                            {"--fraction_invalid", 'i', true, "<FRACTION_INVALID>"},
+                                            {"--fraction_valid", 'v', true, "<FRACTION_VALID>"},
+                                            {"--max_errors", 'm', true, "<MAX_ERRORS>"},
+                                            {"--min_depth", 'd', true, "<MIN_DEPTH>"},
+                                            {"--careful", 0, false, ""}};
+        const Parsed P = parse_args(argc, argv, 2, specs);
+        if (P.help) { fputs(HELP_POLISH, stdout); return 0; }
+        if (P.version) { printf("polypolish-polish v0.6.1\n"); return 0; }
+        std::string perr = P.error;
+        if (perr.empty()) {
+            opt.debug_path = P.value[0];
+            opt.careful = P.value[5] != nullptr;
+            (void)(take_f64(P, specs, 1, opt.fraction_invalid, perr) && take_f64(P, specs, 2, opt.fraction_valid, perr) &&
+                   take_u32(P, specs, 3, opt.max_errors, perr) && take_u32(P, specs, 4, opt.min_depth, perr));
         }
+        if (!perr.empty()) return usage_error(perr.c_str());
+        const char *assembly = P.positional.empty() ? nullptr : P.positional[0];
+        std::vector<const char *> sams(P.positional.begin() + (P.positional.empty() ? 0 : 1), P.positional.end());
         if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
         // Several GPUs polish (contigs / windows of a large contig shard across them) when PP_GPUS=n asks for them, or
         // by themselves from 8 GiB of SAM text on; never with --debug.  Below that one GPU is the faster choice end to
@@ -233,43 +290,32 @@ int main(int argc, char **argv) {
 
     if (cmd == "filter-polish") {
         pp_polish_options opt{0.2, 0.5, 10, 5, 0, nullptr, 0};
-        const char *assembly = nullptr, *in1 = nullptr, *in2 = nullptr, *out1 = nullptr, *out2 = nullptr, *orientation = "auto";
+        const char *orientation = "auto";
         double low = 0.1, high = 99.9;
-        for (int i = 2; i < argc; i++) {
-            const char *a = argv[i];
-            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_FUSED, stdout); return 0; }
-            if (!strcmp(a, "--careful")) { opt.careful = 1; continue; }
-            struct { const char *l; const char **dst; } paths[] = {{"--in1", &in1}, {"--in2", &in2}, {"--out1", &out1},
-                                                                  {"--out2", &out2}, {"--orientation", &orientation},
-                                                                  {"--debug", &opt.debug_path}};
-            bool matched = false;
-            for (auto &t : paths) {
-                if (!is_opt(a, t.l, nullptr)) continue;
-                const char *v = opt_value(argc, argv, i, a, t.l, nullptr);
-                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
-                *t.dst = v;
-                matched = true;
-                break;
-            }
-            if (matched) continue;
-            struct { const char *l, *s; int kind; void *dst; } table[] = {
-                {"--fraction_invalid", "-i", 0, &opt.fraction_invalid}, {"--fraction_valid", "-v", 0, &opt.fraction_valid},
-                {"--max_errors", "-m", 1, &opt.max_errors}, {"--min_depth", "-d", 1, &opt.min_depth},
-                {"--low", nullptr, 0, &low}, {"--high", nullptr, 0, &high}};
-            for (auto &t : table) {
-                if (!is_opt(a, t.l, t.s)) continue;
-                const char *v = opt_value(argc, argv, i, a, t.l, t.s);
-                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
-                bool ok = t.kind == 0 ? parse_f64(v, *(double *)t.dst) : parse_u32(v, *(uint32_t *)t.dst);
-                if (!ok) return usage_error((std::string("invalid value '") + v + "' for '" + t.l + "'").c_str());
-                matched = true;
-                break;
-            }
-            if (matched) continue;
-            if (a[0] == '-' && a[1] != 0) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
-            if (assembly) return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
-            assembly = a;
+        const std::vector<OptSpec> specs = {{"--in1", 0, true, "<IN1>"}, {"--in2", 0, true, "<IN2>"},
+                                            {"--out1", 0, true, "<OUT1>"}, {"--out2", 0, true, "<OUT2>"},
+                                            {"--orientation", 0, true, "<ORIENTATION>"}, {"--low", 0, true, "<LOW>"},
+                                            {"--high", 0, true, "<HIGH>"}, {"--debug", 0, true, "<DEBUG>"},
+                                            {"--fraction_invalid", 'i', true, "<FRACTION_INVALID>"},
+                                            {"--fraction_valid", 'v', true, "<FRACTION_VALID>"},
+                                            {"--max_errors", 'm', true, "<MAX_ERRORS>"},
+                                            {"--min_depth", 'd', true, "<MIN_DEPTH>"},
+                                            {"--careful", 0, false, ""}};
+        const Parsed P = parse_args(argc, argv, 2, specs);
+        if (P.help || P.version) { fputs(HELP_FUSED, stdout); return 0; }
+        std::string perr = P.error;
+        if (perr.empty()) {
+            if (P.value[4]) orientation = P.value[4];
+            opt.debug_path = P.value[7];
+            opt.careful = P.value[12] != nullptr;
+            (void)(take_f64(P, specs, 5, low, perr) && take_f64(P, specs, 6, high, perr) &&
+                   take_f64(P, specs, 8, opt.fraction_invalid, perr) && take_f64(P, specs, 9, opt.fraction_valid, perr) &&
+                   take_u32(P, specs, 10, opt.max_errors, perr) && take_u32(P, specs, 11, opt.min_depth, perr));
+            if (perr.empty() && P.positional.size() > 1) perr = std::string("unexpected argument '") + P.positional[1] + "' found";
         }
+        if (!perr.empty()) return usage_error(perr.c_str());
+        const char *in1 = P.value[0], *in2 = P.value[1], *out1 = P.value[2], *out2 = P.value[3];
+        const char *assembly = P.positional.empty() ? nullptr : P.positional[0];
         if (!assembly || !in1 || !in2)
             return usage_error("the following required arguments were not provided:\n  --in1 <IN1> --in2 <IN2> <ASSEMBLY>");
         pp_ctx *ctx = nullptr;
@@ -288,32 +334,23 @@ int main(int argc, char **argv) {
     }
 
     if (cmd == "filter") {
-        const char *in1 = nullptr, *in2 = nullptr, *out1 = nullptr, *out2 = nullptr, *orientation = "auto";
+        const char *orientation = "auto";
         double low = 0.1, high = 99.9;
-        for (int i = 2; i < argc; i++) {
-            const char *a = argv[i];
-            if (!strcmp(a, "-h") || !strcmp(a, "--help")) { fputs(HELP_FILTER, stdout); return 0; }
-            if (!strcmp(a, "-V") || !strcmp(a, "--version")) { printf("polypolish-filter v0.6.1\n"); return 0; }
-            struct { const char *l; const char **dst; } paths[] = {{"--in1", &in1}, {"--in2", &in2}, {"--out1", &out1},
-                                                                  {"--out2", &out2}, {"--orientation", &orientation}};
-            bool matched = false;
-            for (auto &t : paths) {
-                if (!is_opt(a, t.l, nullptr)) continue;
-                const char *v = opt_value(argc, argv, i, a, t.l, nullptr);
-                if (!v) return usage_error((std::string("a value is required for '") + t.l + "' but none was supplied").c_str());
-                *t.dst = v;
-                matched = true;
-                break;
-            }
-            if (matched) continue;
-            if (is_opt(a, "--low", nullptr) || is_opt(a, "--high", nullptr)) {
-                bool is_low = is_opt(a, "--low", nullptr);
-                const char *v = opt_value(argc, argv, i, a, is_low ? "--low" : "--high", nullptr);
-                if (!v || !parse_f64(v, is_low ? low : high)) return usage_error("invalid value for '--low/--high'");
-                continue;
-            }
-            return usage_error((std::string("unexpected argument '") + a + "' found").c_str());
+        const std::vector<OptSpec> specs = {{"--in1", 0, true, "<IN1>"}, {"--in2", 0, true, "<IN2>"},
+                                            {"--out1", 0, true, "<OUT1>"}, {"--out2", 0, true, "<OUT2>"},
+                                            {"--orientation", 0, true, "<ORIENTATION>"}, {"--low", 0, true, "<LOW>"},
+                                            {"--high", 0, true, "<HIGH>"}};
+        const Parsed P = parse_args(argc, argv, 2, specs);
+        if (P.help) { fputs(HELP_FILTER, stdout); return 0; }
+        if (P.version) { printf("polypolish-filter v0.6.1\n"); return 0; }
+        std::string perr = P.error;
+        if (perr.empty()) {
+            if (P.value[4]) orientation = P.value[4];
+            (void)(take_f64(P, specs, 5, low, perr) && take_f64(P, specs, 6, high, perr));
+            if (perr.empty() && !P.positional.empty()) perr = std::string("unexpected argument '") + P.positional[0] + "' found";
         }
+        if (!perr.empty()) return usage_error(perr.c_str());
+        const char *in1 = P.value[0], *in2 = P.value[1], *out1 = P.value[2], *out2 = P.value[3];
         if (!in1 || !in2 || !out1 || !out2)
             return usage_error("the following required arguments were not provided:\n  --in1 <IN1> --in2 <IN2> --out1 <OUT1> --out2 <OUT2>");
         pp_ctx *ctx = nullptr;

@@ -10,12 +10,20 @@
 // using that one, the CLI loads the system's.  Without a usable librccl pp_comm_* fail with PP_ERR_HIP; nothing
 // else in the library depends on it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 #include <vector>
 
 #include "pp_internal.h"
+
+// The handful of RCCL declarations this file needs (rccl.h, NCCL 2.x ABI), so that the library builds without the RCCL
+// headers and runs without librccl as long as nobody asks for a communicator.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclUint32 = 3, ncclUint64 = 5 } ncclDataType_t;
+}
 
 namespace {
 
@@ -68,7 +76,7 @@ Rccl &rccl() {
 
 }  // namespace
 
-static_assert(sizeof(ncclUniqueId) == PP_COMM_ID_BYTES, "PP_COMM_ID_BYTES");
+static_assert(sizeof(ncclUniqueId) == PP_COMM_ID_BYTES, "PP_COMM_ID_BYTES");  // NCCL_UNIQUE_ID_BYTES
 
 extern "C" int pp_comm_unique_id(void *id) {
     if (!id) return PP_ERR_ARG;
@@ -114,13 +122,14 @@ extern "C" int pp_polish_gather(pp_ctx *ctx, uint8_t *gathered, uint64_t cap, ui
     hipStream_t st = ctx->stream;
     const int world = ctx->comm_world, rank = ctx->comm_rank;
     const uint32_t nc = ctx->n_contigs;
-    const size_t words = (size_t)nc + 2;  // byte count, then contig_out_off[0..nc]
-    // ---- every rank learns every rank's byte count and per-contig offsets ----
+    // ---- every rank learns every rank's byte count, per-contig offsets and buffer size ----
+    const size_t words = (size_t)nc + 3;  // byte count, contig_out_off[0..nc], cap (rank 0's is the one that counts)
     if (int rc = pp::dev_ensure(ctx, ctx->b_comm, (size_t)(world + 1) * words * 8)) return rc;
     uint64_t *d_mine = (uint64_t *)ctx->b_comm.p, *d_all = d_mine + words;
     std::vector<uint64_t> mine(words), all((size_t)world * words);
     mine[0] = ctx->total_out;
     for (uint32_t c = 0; c <= nc; c++) mine[1 + c] = ctx->contig_out_off[c];
+    mine[nc + 2] = gathered ? cap : 0;
     PP_HIPCHK(ctx, hipMemcpyAsync(d_mine, mine.data(), words * 8, hipMemcpyHostToDevice, st));
     PP_NCCLCHK(ctx, rccl().AllGather(d_mine, d_all, words, ncclUint64, comm, st));
     PP_HIPCHK(ctx, hipMemcpyAsync(all.data(), d_all, (size_t)world * words * 8, hipMemcpyDeviceToHost, st));
@@ -133,17 +142,24 @@ extern "C" int pp_polish_gather(pp_ctx *ctx, uint8_t *gathered, uint64_t cap, ui
         if (rank_len) rank_len[r] = all[(size_t)r * words];
         if (rank_contig_off) memcpy(rank_contig_off + (size_t)r * (nc + 1), &all[(size_t)r * words + 1], ((size_t)nc + 1) * 8);
     }
+    // Whether rank 0's buffer holds it all is decided by EVERY rank from the gathered figures, before anybody posts a
+    // send: a rank 0 that backed out on its own would leave the others waiting in ncclSend for good.
+    const uint64_t cap0 = all[nc + 2];
+    if (total > cap0)
+        return ctx->fail(PP_ERR_ARG, "pp_polish_gather: %llu bytes do not fit rank 0's buffer of %llu (every rank returns this)",
+                         (unsigned long long)total, (unsigned long long)cap0);
     // ---- the bytes: everybody sends to rank 0, which receives at the exclusive-scan offsets ----
     if (rank == 0) {
-        if (!gathered && total) return ctx->fail(PP_ERR_ARG, "pp_polish_gather: rank 0 needs a buffer");
-        if (total > cap) return ctx->fail(PP_ERR_ARG, "pp_polish_gather: %llu bytes do not fit the buffer of %llu",
-                                          (unsigned long long)total, (unsigned long long)cap);
         if (ctx->total_out)
             PP_HIPCHK(ctx, hipMemcpyAsync(gathered, ctx->b_out.p, ctx->total_out, hipMemcpyDeviceToDevice, st));
+        // a group that was opened is closed on every path: an error inside it is kept and reported afterwards
+        ncclResult_t first_bad = ncclSuccess;
         PP_NCCLCHK(ctx, rccl().GroupStart());
-        for (int r = 1; r < world; r++)
-            if (all[(size_t)r * words]) PP_NCCLCHK(ctx, rccl().Recv(gathered + start[r], all[(size_t)r * words], ncclUint8, r, comm, st));
-        PP_NCCLCHK(ctx, rccl().GroupEnd());
+        for (int r = 1; r < world && first_bad == ncclSuccess; r++)
+            if (all[(size_t)r * words]) first_bad = rccl().Recv(gathered + start[r], all[(size_t)r * words], ncclUint8, r, comm, st);
+        const ncclResult_t ended = rccl().GroupEnd();
+        if (first_bad != ncclSuccess) return ctx->fail(PP_ERR_HIP, "ncclRecv failed: %s", rccl().GetErrorString(first_bad));
+        if (ended != ncclSuccess) return ctx->fail(PP_ERR_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString(ended));
     } else if (ctx->total_out) {
         PP_NCCLCHK(ctx, rccl().Send(ctx->b_out.p, ctx->total_out, ncclUint8, 0, comm, st));
     }

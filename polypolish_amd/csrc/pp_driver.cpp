@@ -143,7 +143,7 @@ static int write_debug_tsv(pp_ctx *ctx, FILE *f, const pp_assembly *a, const pp_
 
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
-                             const uint64_t *n_pass, bool host_ingest_only = false);
+                             const uint64_t *n_pass, int resume_log_at = -1);
 extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes);
 extern "C" int pp_ingest_fail_cut_(const pp_ingest *I, uint64_t *cut);
 extern "C" int pp_ingest_sam_prefix_(pp_ingest *I, const char *path, uint64_t cut, const uint8_t *pass, uint64_t n_pass,
@@ -175,14 +175,18 @@ extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char 
 // pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
-                             const uint64_t *n_pass, bool host_ingest_only) {
+                             const uint64_t *n_pass, int resume_log_at) {
     pp_ctx *const ctx = ctxs[0];  // carries the error text
     if (!ctx || !assembly || !opt || !fasta || (n_sams > 0 && !sams)) return PP_ERR_ARG;
     const bool multi = n_ctx > 1;
     if (multi && opt->debug_path) return set_err(ctx, PP_ERR_ARG, "--debug needs a single GPU");
     fasta->data = nullptr;
     fasta->len = 0;
-    Log log{opt->quiet != 0 || host_ingest_only};  // (the second look at a failing input does not log twice)
+    // resume_log_at >= 0: the second look at an input the device tokenizer handed back (a defect in the text, or bytes
+    // outside ASCII that the host parsers must judge), on the host ingest only.  The banner, the assembly section and the
+    // lines of the files before that one are on stderr already: the log resumes at that file.
+    const bool host_ingest_only = resume_log_at >= 0;
+    Log log{opt->quiet != 0 || host_ingest_only};
     auto t0 = std::chrono::steady_clock::now();
     char err[1024] = "";
 
@@ -209,8 +213,8 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     // the link's rate).
     const bool dev_ingest = n_ctx == 1 && !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     if (dev_ingest)
-        for (int i = 0; i < n_sams; i++) pph::prefetch_file(sams[i]);
-    struct DropPrefetched { ~DropPrefetched() { pph::prefetch_drop_all(); } } drop_prefetched;
+        for (int i = 0; i < n_sams; i++) pph::prefetch_file(sams[i], ctx);
+    struct DropPrefetched { const void *owner; ~DropPrefetched() { pph::prefetch_drop_all(owner); } } drop_prefetched{ctx};
 
     // starting_message, polish.rs:41-73
     log("\nStarting Polypolish polish\n%s\n\nInput assembly:\n  %s\n\nInput short-read alignments:\n", pp_version(), assembly);
@@ -283,13 +287,14 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     uint64_t alignment_total = 0, used_total = 0;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
         pp_sam_counts c;
+        if (i == resume_log_at) log.quiet = opt->quiet != 0;
         if (dev_ingest) {
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
             if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC || rc == PP_ERR_NOT_ASCII) {
                 // A defect in the text.  Which defect the reference reports FIRST also depends on what its CIGAR walk
                 // makes of the records before it: the host ingest works that out (below), on this rare path.
                 free_all();
-                return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, pass, n_pass, true);
+                return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, pass, n_pass, i);
             }
             if (rc) break;
         } else {

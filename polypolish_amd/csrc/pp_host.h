@@ -108,11 +108,12 @@ struct PrefetchedFile {
     void *map = nullptr;
     size_t size = 0;
     int fd = -1;
+    const void *owner = nullptr;  // who asked for it (a job's context): prefetch_drop_all releases only its own
     std::thread worker;
 };
 inline std::mutex &prefetch_mutex() { static std::mutex m; return m; }
 inline std::vector<PrefetchedFile *> &prefetch_list() { static std::vector<PrefetchedFile *> v; return v; }
-inline void prefetch_file(const char *path) {
+inline void prefetch_file(const char *path, const void *owner) {
     struct stat st;
     if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return;  // never open a pipe just to look at it
     const int fd = ::open(path, O_RDONLY);
@@ -121,7 +122,7 @@ inline void prefetch_file(const char *path) {
     void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (map == MAP_FAILED) { ::close(fd); return; }
     PrefetchedFile *f = new PrefetchedFile;
-    f->path = path; f->map = map; f->size = (size_t)st.st_size; f->fd = fd;
+    f->path = path; f->map = map; f->size = (size_t)st.st_size; f->fd = fd; f->owner = owner;
     f->worker = std::thread([f] { populate_mapping(f->map, f->size); });
     std::lock_guard<std::mutex> lock(prefetch_mutex());
     prefetch_list().push_back(f);
@@ -137,15 +138,15 @@ inline PrefetchedFile *prefetch_take(const char *path) {  // nullptr if the path
     if (f && f->worker.joinable()) f->worker.join();
     return f;
 }
-inline void prefetch_drop_all() {  // whatever was prefetched and never opened
+inline void prefetch_drop_all(const void *owner) {  // whatever `owner` had prefetched and never opened
     for (;;) {
         PrefetchedFile *f = nullptr;
         {
             std::lock_guard<std::mutex> lock(prefetch_mutex());
             auto &v = prefetch_list();
-            if (v.empty()) return;
-            f = v.back();
-            v.pop_back();
+            for (size_t i = v.size(); i-- > 0;)
+                if (v[i]->owner == owner) { f = v[i]; v.erase(v.begin() + (long)i); break; }
+            if (!f) return;
         }
         if (f->worker.joinable()) f->worker.join();
         munmap(f->map, f->size);

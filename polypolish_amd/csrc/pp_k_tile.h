@@ -655,6 +655,15 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         // against the ticket by waiting for the stores' acknowledgements: a __threadfence() here means a write-back
         // and an invalidation of the XCD's whole L2 per helper, which slowed every block of the chip's first round to
         // half its speed (measured: k_tile 0.49 -> 0.64 ms on BASELINE configs[2]).
+        // Memory-model note: relaxed agent-scope operations on different addresses are unordered in the HIP/LLVM model;
+        // what orders them here is the gfx942/gfx950 implementation of agent scope (LLVM AMDGPU "memory model gfx942":
+        // an agent-scope atomic store is a write-through sc1 store, complete when vmcnt says so; an agent-scope atomic
+        // load bypasses the non-coherent L2 lines) -- i.e. this is the hardware's release sequence minus the L2
+        // write-back, which has nothing to write back because every datum travels as an sc1 atomic.  The guard below
+        // keeps the code from being built for anything else; test_heavy_windows_* stress the rendezvous.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_tile's heavy-window rendezvous relies on gfx942/gfx950 agent-scope store/load semantics"
+#endif
         u32 *mine = A.hslab + ((u64)hslot * HEAVY_PARTS + part) * HSLAB_WORDS;
         for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS)
             __hip_atomic_store(&mine[i], cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -818,6 +818,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
+                     &ctx->b_win_heavy, &ctx->b_hslab,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
                      &ctx->f_insert};

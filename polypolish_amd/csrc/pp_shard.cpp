@@ -70,6 +70,7 @@ extern "C" int pp_shard_plan_create(uint32_t n_contigs, const uint64_t *contig_o
         taken[u.contig].push_back(best);
     }
     pp_shard_plan *p = (pp_shard_plan *)calloc(1, sizeof *p);
+    if (!p) return PP_ERR_LIMIT;
     const size_t n = units.size();
     p->n_units = (uint32_t)n;
     p->world = world;
@@ -78,6 +79,10 @@ extern "C" int pp_shard_plan_create(uint32_t n_contigs, const uint64_t *contig_o
     p->rank = (uint32_t *)malloc((n ? n : 1) * 4);
     p->lo = (uint64_t *)malloc((n ? n : 1) * 8);
     p->hi = (uint64_t *)malloc((n ? n : 1) * 8);
+    if (!p->contig || !p->rank || !p->lo || !p->hi) {  // out of host memory
+        pp_shard_plan_free(p);
+        return PP_ERR_LIMIT;
+    }
     for (size_t i = 0; i < n; i++) {
         p->contig[i] = units[i].contig; p->rank[i] = units[i].rank; p->lo[i] = units[i].lo; p->hi[i] = units[i].hi;
     }

@@ -771,10 +771,57 @@ def test_cli_is_a_drop_in(orc, tmp_path):
     assert r.stdout == want["fasta"]
     assert open(dbg, "rb").read() == want["debug"]
     assert b"positions changed" in r.stderr
+    # clap's other spellings of the same command line (src/main.rs:78-108): attached short values, `=`, `--`
+    for argv in (["-d4", "-i0.15"], ["-d=4", "--fraction_invalid", "0.15", "--"], ["--min_depth=4", "-i=0.15"]):
+        r2 = subprocess.run([exe, "polish"] + argv + [ds["fasta"], f1, f2], capture_output=True)
+        assert r2.returncode == 0 and r2.stdout == want["fasta"], (argv, r2.stderr[-300:])
     r = subprocess.run([exe, "polish", "-i", "0.7", ds["fasta"], f1], capture_output=True)
     assert r.returncode == 1 and r.stdout == b"" and b"Error: --fraction_invalid must be less than --fraction_valid" in r.stderr
     r = subprocess.run([exe, "polish", str(tmp_path / "missing.fasta")], capture_output=True)
     assert r.returncode == 1 and b"file does not exist" in r.stderr
+
+
+def test_configs0_shape_through_the_cli(tmp_path):
+    """BASELINE.json configs[0]: one 50 kbp contig, 10,000 x 150 bp paired reads, text in / FASTA out through
+    bin/polypolish -- polish (both ingests), filter and the fused command against the oracle's CLI, sha256 of every
+    output (the same leg bench.py runs at the other configurations' sizes)."""
+    import torch
+    import bench
+    lens, cov, repeat, _ = bench.config_shape(0)
+    out = bench.end_to_end(torch.device("cuda", 0), 0, lens, cov, repeat, seed=4242, keep_dir=str(tmp_path))
+    assert out.get("parity") is True, out
+    assert "10000 records" in out["files"], out["files"]
+
+
+def test_configs2_from_text_at_full_size(tmp_path):
+    """BASELINE.json configs[2] END TO END FROM SAM TEXT at full size (5 Mbp, 200x, a 5-kbp segment in five copies on both
+    strands): real all-hits files -- every read inside a copy as a primary record plus four secondary records with
+    SEQ / QUAL '*' (src/alignment.rs:290-295,311-322 fill them, reverse-complemented on the inverted copies) -- through
+    `polish` (k = 5 groups, order-dependent f64 depth), `filter` (alignment_pass_qc's n x m loop over the copies,
+    src/filter.rs:352-377), `filter` followed by `polish`, and the fused command; sha256 against the oracle's CLI."""
+    import torch
+    import bench
+    lens, cov, repeat, _ = bench.config_shape(2)
+    out = bench.end_to_end(torch.device("cuda", 0), 2, lens, cov, repeat, seed=4244, keep_dir=str(tmp_path))
+    assert out.get("parity") is True, out
+    assert out["filter_then_polish"]["parity"] and out["filter_then_polish"]["differs_from_unfiltered_polish"], out
+    assert out["filter"]["records_failed_in_file_1"] > 1000, out["filter"]  # the filter had something to reject
+
+
+def test_assembly_of_4_gbp_is_refused_cleanly(ctx, pp):
+    """Positions are 32-bit in this version: an assembly of 2^32-4096 bp or more is refused by pp_polish_begin with
+    PP_ERR_LIMIT before anything is read or allocated (the reference's Vec<PileupBase>, src/pileup.rs:178-187, has no
+    such limit -- a documented deviation), and the context stays usable."""
+    import ctypes as C
+    L = pp.lib()
+    prm = pp.Params(5, 0.5, 0.2)
+    for G, ok in (((1 << 32) - 4096, False), (1 << 32, False), (1 << 33, False)):
+        off = (C.c_uint64 * 2)(0, G)
+        rc = L.pp_polish_begin(ctx._h, 1, off, C.c_void_p(0x1000), pp.MEM_DEVICE, C.byref(prm))
+        assert rc == 5 and b"2^32-4096" in L.pp_last_error(ctx._h), (G, rc)
+    contig_off, bases, recs = synth.fast_records(seed=2, contig_lens=(4000,), coverage=20)
+    got = ctx.polish_records(contig_off, bases, recs)
+    assert len(got["polished"]) == 4000
 
 
 def test_plain_c_host_over_the_abi(orc, tmp_path):
@@ -788,28 +835,44 @@ def test_plain_c_host_over_the_abi(orc, tmp_path):
     assert r.stdout == want["fasta"]
 
 
-def test_full_size_properties(ctx, pp, orc):
-    """BASELINE.json configs[1] size (5 Mbp, 200x): size-independent properties + exact parity on a window."""
+def _interior_matches(whole, start, piece, slack=1500):
+    """The interior of a sub-job's polished bytes must be the full job's bytes for the same stretch of the assembly;
+    where that stretch starts in the full output depends on the indels repaired in front of it, so it is searched for
+    within +- slack of its assembly coordinate."""
+    return whole.find(piece, max(0, start - slack), start + len(piece) + slack) >= 0
+
+
+@pytest.mark.parametrize("recipe", ["survey", "subs"])
+def test_full_size_properties(ctx, pp, orc, recipe):
+    """BASELINE.json configs[1] size (5 Mbp, 200x): size-independent properties + exact parity on a window.  'survey' is
+    SURVEY 8d's recipe (substitutions, deletions and insertions planted in the assembly, half of the indels in
+    homopolymers, reads aligned to the assembly with I / D runs: the case Polypolish exists for, alignment.rs:175-201,
+    349-378); 'subs' (substitutions only) keeps coordinates fixed, which is what the idempotence check needs."""
     import torch
     import bench
     dev = torch.device("cuda", 0)
-    job = bench.make_job(dev, G=5_000_000, coverage=200, seed=7)
+    job = bench.make_job(dev, G=5_000_000, coverage=200, seed=7, recipe=recipe)
     torch.cuda.synchronize()
     bench.run_job(ctx, pp, job)
     a, offs, stats = ctx.result()
     bench.run_job(ctx, pp, job)
     b, _, _ = ctx.result()
     assert a == b, "two runs of the same job differ (atomics must not leak into the result)"
-    truth = bytes(job["truth"].cpu().numpy())
-    assert len(a) == job["G"] and a[1000:-1000] == truth[1000:-1000], "planted assembly errors were not all repaired"
-    n_err = sum(1 for x, y in zip(bytes(job["bases"][1000:-1000].cpu().numpy()), truth[1000:-1000]) if x != y)
+    assert bench.recovered(job, a, offs), f"{bench.recovered(job, a, offs, count=True)} planted assembly errors were not repaired"
+    n_err = sum(job["planted"][k] for k in ("substitutions", "deletions", "insertions"))
     assert stats[0]["changed"] >= n_err > 300
-    # idempotence: polishing the polished assembly with the same reads changes nothing
-    job2 = dict(job)
-    job2["bases"] = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
-    bench.run_job(ctx, pp, job2)
-    c, _, st2 = ctx.result()
-    assert c == a and st2[0]["changed"] == 0
+    if recipe == "survey":
+        p = job["planted"]
+        assert min(p["substitutions"], p["deletions"], p["insertions"]) > 100 and p["indels_in_homopolymers"] > 100
+        assert len(a) == len(job["truth"]) == job["G"] + p["deletions"] - p["insertions"]
+    else:
+        # idempotence: polishing the polished assembly with the same reads changes nothing
+        job2 = dict(job)
+        job2["bases"] = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+        job2.pop("_prepared", None)
+        bench.run_job(ctx, pp, job2)
+        c, _, st2 = ctx.result()
+        assert c == a and st2[0]["changed"] == 0
     # partition invariance + exact oracle parity on a window of the contig
     lo, hi = 1_000_000, 1_300_000
     sub = bench.subset_job(job, lo, hi)
@@ -818,15 +881,16 @@ def test_full_size_properties(ctx, pp, orc):
     s, _, _ = ctx.result()
     want = orc.polish_records(np.array([0, hi - lo], np.uint64), sub["bases"].cpu().numpy(), bench.to_host_records(sub))
     assert s == want["polished"]
-    assert s[400:-400] == a[lo + 400:hi - 400]
+    assert _interior_matches(a, lo + 400, s[400:-400])
 
 
 @pytest.mark.parametrize("config", [2, 3, 4])
 def test_full_size_configs(ctx, pp, orc, config):
-    """BASELINE.json configs[2], [3], [4] at FULL size on one GPU, through whatever bucketing path their size picks
-    by itself (configs[3] / [4] are beyond 16384 windows): determinism, recovery of the planted assembly errors,
-    idempotence, and exact oracle parity + partition invariance on sampled 300 kbp windows (for configs[2] one
-    of them holds a repeat locus: five records of share 1/5 per read, order-dependent f64 depth)."""
+    """BASELINE.json configs[2], [3], [4] at FULL size on one GPU (records resident, SURVEY 8d's recipe with planted
+    indels), through whatever bucketing path their size picks by itself (configs[3] / [4] are beyond 16384 windows):
+    determinism, recovery of every planted assembly error (the truth's bytes AND lengths, contig by contig), and exact
+    oracle parity + partition invariance on sampled 300 kbp windows (for configs[2] one of them holds a repeat locus:
+    five records of share 1/5 per read, on both strands, order-dependent f64 depth)."""
     import torch
     import bench
     dev = torch.device("cuda", 0)
@@ -839,31 +903,16 @@ def test_full_size_configs(ctx, pp, orc, config):
     bench.run_job(ctx, pp, job)
     b, _, _ = ctx.result()
     assert a == b, "two runs of the same job differ (atomics must not leak into the result)"
-    assert np.array_equal(np.asarray(offs, dtype=np.int64), coff), "substitution-only errors must keep every contig's length"
-    got = np.frombuffer(a, dtype=np.uint8)
-    ok = got == job["truth"].cpu().numpy()
-    for c in range(len(coff) - 1):  # no coverage at contig ends
-        ok[coff[c]:coff[c] + 1000] = True
-        ok[max(coff[c], coff[c + 1] - 1000):coff[c + 1]] = True
-    if repeat:  # copies that differ by a SNP out-vote each other there: kept as in the assembly, not "repaired"
-        for l in job["repeat_loci"]:
-            ok[l - 200:l + repeat[0] + 200] = True
-    assert ok.all(), f"{int((~ok).sum())} planted assembly errors were not repaired"
-    n_err = int((job["bases"] != job["truth"]).sum().item())
+    assert bench.recovered(job, a, offs), f"{bench.recovered(job, a, offs, count=True)} planted assembly errors were not repaired"
+    n_err = sum(job["planted"][k] for k in ("substitutions", "deletions", "insertions"))
     assert sum(s["changed"] for s in stats) >= 0.9 * n_err > 300
-    # idempotence: polishing the polished assembly with the same reads changes nothing (outside the repeat copies)
-    job2 = dict(job)
-    job2["bases"] = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
-    bench.run_job(ctx, pp, job2)
-    c2, _, st2 = ctx.result()
-    assert c2 == a and sum(s["changed"] for s in st2) == 0
-    del job2
     # sampled windows: exact oracle parity of the sub-job, and its interior equals the full job's bytes there
     big = int(np.argmax(np.diff(coff)))
     clen = int(coff[big + 1] - coff[big])
     samples = [(big, clen // 3, min(clen, clen // 3 + 300_000)), (len(coff) - 2, 0, min(int(coff[-1] - coff[-2]), 300_000))]
     if repeat:
         samples.append((0, job["repeat_loci"][2] - 100_000, job["repeat_loci"][2] + 200_000))
+    offs = np.asarray(offs, dtype=np.int64)
     for c, lo, hi in samples:
         sub = bench.subset_job(job, lo, hi, contig=c)
         torch.cuda.synchronize()
@@ -871,7 +920,7 @@ def test_full_size_configs(ctx, pp, orc, config):
         s, _, _ = ctx.result()
         want = orc.polish_records(np.array([0, hi - lo], np.uint64), sub["bases"].cpu().numpy(), bench.to_host_records(sub))
         assert s == want["polished"], (config, c, lo, hi)
-        assert len(s) == hi - lo and s[400:-400] == a[coff[c] + lo + 400:coff[c] + hi - 400], (config, c, lo, hi)
+        assert _interior_matches(a, int(offs[c]) + lo + 400, s[400:-400], slack=20_000), (config, c, lo, hi)
 
 
 def test_batches_added_one_after_the_other_equal_one_batch(ctx, pp, orc):
@@ -1136,12 +1185,19 @@ def test_device_front_ends_hand_non_ascii_text_to_the_host_parsers(orc, tmp_path
         f1.write_bytes(b"\n".join(base1[:i] + [base1[i] + b"\tXX:Z:" + blob] + base1[i + 1:]))
         want = subprocess.run([orc_exe, "polish", ds["fasta"], str(f1), ds["sam2"]], capture_output=True)
         assert (want.returncode == 0) == ok
+        logs = {}
         for ingest in ("1", "0"):
             got = subprocess.run([exe, "polish", ds["fasta"], str(f1), ds["sam2"]], capture_output=True,
                                  env=dict(os.environ, PP_DEVICE_INGEST=ingest))
             assert got.returncode == want.returncode and got.stdout == want.stdout, (name, ingest, got.stderr[-500:])
             if not ok:
                 assert b"unable to load alignments" in got.stderr and b"unable to load alignments" in want.stderr
+            logs[ingest] = [l for l in got.stderr.split(b"\n") if not l.startswith(b"Time to run")]
+        # the run log (polish.rs:41-90, 109-134, 206-227) is the same whether the file went through the device tokenizer
+        # and came back (the hand-over resumes the log at that file) or through the host parsers from the start
+        assert logs["1"] == logs["0"], name
+        if ok:
+            assert any(l.startswith(b"Finished!") for l in logs["1"]) and sum(b"alignments from" in l for l in logs["1"]) == 2
         outs = {}
         for who, binary, env in (("oracle", orc_exe, {}), ("host", exe, {}), ("device", exe, {"PP_DEVICE_FILTER": "1"})):
             o1, o2 = tmp_path / f"{name}_{who}_1.out", tmp_path / f"{name}_{who}_2.out"
