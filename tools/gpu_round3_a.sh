@@ -23,7 +23,7 @@ mkdir -p $BIG
 timeout 600 python bench.py --config 3 --e2e-only --e2e-dir $BIG > $O/r3a_e2e_c3.json 2> $O/r3a_e2e_c3.err; echo "c3 rc=$?" >> $O/r3a_probe.txt
 rm -rf $BIG; mkdir -p $BIG
 { free -g; df -h $BIG; } >> $O/r3a_probe.txt 2>&1
-PP_TIMING=1 timeout 1100 python bench.py --config 4 --e2e-only --e2e-dir $BIG > $O/r3a_e2e_c4.json 2> $O/r3a_e2e_c4.err; echo "c4 rc=$?" >> $O/r3a_probe.txt
+timeout 1100 python bench.py --config 4 --e2e-only --e2e-dir $BIG > $O/r3a_e2e_c4.json 2> $O/r3a_e2e_c4.err; echo "c4 rc=$?" >> $O/r3a_probe.txt
 rm -rf $BIG
 tail -3 $O/r3a_tests.log
 cat $O/r3a_probe.txt
