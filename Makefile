@@ -12,7 +12,7 @@ OUT      := polypolish_amd/_build
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 LIB  := $(OUT)/libpolypolish_hip.so
-OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_comm.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o $(OUT)/pp_shard.o
+OBJS := $(OUT)/pp_kernels.o $(OUT)/pp_filter.o $(OUT)/pp_tokenize.o $(OUT)/pp_filter_dev.o $(OUT)/pp_comm.o $(OUT)/pp_shard_dev.o $(OUT)/pp_ingest.o $(OUT)/pp_driver.o $(OUT)/pp_filter_host.o $(OUT)/pp_shard.o
 
 all: $(LIB) bin/polypolish bin/polish_min oracle tools/_build/libsamgen.so
 

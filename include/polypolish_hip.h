@@ -49,6 +49,8 @@ extern "C" {
 
 #define PP_MEM_HOST 0   /* pointer is host memory: the library copies it to the device             */
 #define PP_MEM_DEVICE 1 /* pointer is device memory on the context's device: borrowed, not copied  */
+#define PP_MEM_PEER 2   /* pp_polish_add only: device memory of ANOTHER GPU of this process (a pp_shard_part made on that
+                           GPU's context): copied over the fabric, the source may be released when the call returns   */
 
 /* CIGAR runs are packed (length << 4) | op with these op codes (SAM order). */
 enum { PP_OP_M = 0, PP_OP_I = 1, PP_OP_D = 2, PP_OP_N = 3, PP_OP_S = 4, PP_OP_H = 5, PP_OP_P = 6,
@@ -216,11 +218,12 @@ typedef struct {
 int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel group, 2 only the dominant kernel ("tile") */
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
 
-/* ---- multi-GPU: contigs (and windows of a large contig) shard across ranks, one process per GPU -----------------
+/* ---- multi-GPU: contigs (and windows of a large contig) shard across ranks -----------------------------------------
  * The reference is one thread on one CPU; the partition is SURVEY.md 8(e) / BASELINE.json configs[3], [4].
- * A rank polishes with the FULL alignment batch and pp_polish_set_emit(the ranges of its units): the device drops
- * the records that do not reach its ranges and skips the windows outside them, every owned position still sees all
- * of its alignments in file order.  The only exchange is pp_polish_gather.
+ * A rank polishes the records that reach its units (pp_shard_split picks them out of a batch; giving a rank every
+ * record is allowed too) with pp_polish_set_emit(the ranges of its units): the device works on its windows only, and
+ * every owned position sees all of its alignments in file order.  The only exchange of the polish itself is
+ * pp_polish_gather.
  *   plan    whole contigs by longest-processing-time on their alignment counts; a contig with more than one rank's
  *           share of the alignments is cut into up to `world` windows on 2048-bp boundaries (>= min_window bp each,
  *           0 = 65536), one per rank.  Units are listed contig by contig, windows in position order. */
@@ -239,6 +242,29 @@ int pp_shard_emit_ranges(const pp_shard_plan *plan, uint32_t rank, uint64_t *emi
  * r's pp_polish_result returned (out, contig_out_off); out may be NULL to get the offsets only. */
 int pp_shard_assemble(const pp_shard_plan *plan, const uint8_t *const *rank_bytes, const uint64_t *const *rank_contig_off,
                       uint8_t *out, uint64_t *contig_out_off);
+/* The records of `batch` (file order) that rank `dest` needs under `plan`: a record goes to the rank of every unit its
+ * reference span [ref_start, ref_start + sum of its M/=/X/D/N run lengths) touches -- its contig's owner, or, on a tiled
+ * contig, every window it overlaps (src/alignment.rs:297-303, src/pileup.rs:189-200: an alignment only ever touches
+ * its own contig's positions ref_start + j).  A record that touches no unit (bad contig index, start beyond the
+ * contig's end) goes to one fixed rank, which reports it.  mem = where `batch` lives: PP_MEM_HOST -> the part is host
+ * memory (ctx may be NULL), PP_MEM_DEVICE -> the part is made by kernels on ctx's stream and lives on ctx's GPU.
+ * The part is a pp_aln_batch of its own (offsets relative to its own seq / cigar arrays); orig[i] is the index of its
+ * record i in `batch` (same memory kind as the part): a record number reported by a rank's pp_polish_finish is
+ * rank-local, orig turns it back into the job's, and the job's first bad record is the minimum over the ranks. */
+typedef struct pp_shard_part pp_shard_part;
+int pp_shard_split(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
+                   pp_shard_part **out);
+void pp_shard_part_batch(const pp_shard_part *part, pp_aln_batch *out, const uint32_t **orig); /* borrowed views */
+int pp_shard_part_mem(const pp_shard_part *part);
+void pp_shard_part_free(pp_shard_part *part);
+/* Alignment records per contig -- the planner's weights -- ADDED to aln_per_contig (HOST, n_contigs). */
+int pp_shard_count(pp_ctx *ctx, const pp_aln_batch *batch, int mem, uint32_t n_contigs, uint64_t *aln_per_contig);
+/* The record and the kind of the device error pp_polish_finish last returned on this context (PP_ERR_QUIT / PP_ERR_PANIC
+ * from the CIGAR walk): *record = its index over the batches added to THIS context; returns 0 when there was none.
+ * pp_polish_error_text writes the message for that kind with another record number (the job-wide one). */
+int pp_polish_error_record(const pp_ctx *ctx, uint64_t *record, uint32_t *kind);
+int pp_polish_error_text(pp_ctx *ctx, uint32_t kind, uint64_t record);
+
 /* RCCL communicator of one rank (librccl is loaded at run time; the process's own copy is used if it has one):
  * rank 0 calls pp_comm_unique_id, the launcher hands the PP_COMM_ID_BYTES to every rank, every rank calls
  * pp_comm_init on the context of its GPU. */

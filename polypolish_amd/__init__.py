@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("PP_LIB_PATH") or os.path.join(HERE, "_build", "libpol
 
 OK, ERR_QUIT, ERR_HIP, ERR_ARG, ERR_LIMIT, ERR_PANIC = 0, 1, 3, 4, 5, 101
 ERR_NOT_ASCII = 6  # device text front ends only: bytes outside ASCII, the host parsers take such a file
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_PEER = 0, 1, 2
 STATUS = ("kept", "changed", "low_depth", "none", "multiple", "too_close")
 OPS = "MIDNSHP=X"
 
@@ -124,6 +124,8 @@ EXPORTS = [
     "pp_dev_ingest_create", "pp_dev_ingest_sam", "pp_dev_ingest_sam_filtered", "pp_dev_ingest_batch", "pp_dev_ingest_free",
     "pp_shard_plan_create", "pp_shard_plan_free", "pp_shard_emit_ranges", "pp_shard_assemble",
     "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather", "pp_polish_files_multi",
+    "pp_shard_split", "pp_shard_part_batch", "pp_shard_part_mem", "pp_shard_part_free", "pp_shard_count",
+    "pp_polish_error_record", "pp_polish_error_text",
 ]
 
 _lib = None
@@ -230,6 +232,15 @@ def lib():
         L.pp_comm_destroy.argtypes = [vp]
         L.pp_comm_destroy.restype = None
         L.pp_polish_gather.argtypes = [vp, vp, C.c_uint64, vp, vp]
+        L.pp_shard_split.argtypes = [vp, C.POINTER(ShardPlan), C.c_uint32, C.POINTER(AlnBatch), C.c_int, C.POINTER(vp)]
+        L.pp_shard_part_batch.argtypes = [vp, C.POINTER(AlnBatch), C.POINTER(vp)]
+        L.pp_shard_part_batch.restype = None
+        L.pp_shard_part_mem.argtypes = [vp]
+        L.pp_shard_part_free.argtypes = [vp]
+        L.pp_shard_part_free.restype = None
+        L.pp_shard_count.argtypes = [vp, C.POINTER(AlnBatch), C.c_int, C.c_uint32, vp]
+        L.pp_polish_error_record.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
+        L.pp_polish_error_text.argtypes = [vp, C.c_uint32, C.c_uint64]
         _lib = L
     return _lib
 
@@ -403,6 +414,76 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+class ShardPart:
+    """pp_shard_split: the records of a batch that rank `dest` of a plan needs (its contigs' records; on a tiled contig
+    its window's records plus those that reach in from the neighbours).  The batch is given as raw pointers
+    (`ptrs`: field name -> address, host or device as `mem` says); `ctx` may be None for host memory.
+      .n_aln, .seq_bytes, .n_cig_total, .ptrs (field name -> address of the part's arrays, same memory kind), .orig_ptr
+      .host() -> (recs dict of numpy arrays, orig) for a host part."""
+
+    def __init__(self, ctx, plan, dest, n_aln, ptrs, seq_bytes, n_cig_total, mem):
+        L = lib()
+        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+        self._p = C.c_void_p()
+        self._ctx = ctx  # keeps the context (and with it the part's device memory) alive
+        rc = L.pp_shard_split(ctx._h if ctx is not None else None, plan._p, dest, C.byref(b), mem, C.byref(self._p))
+        if rc:
+            raise PolypolishError(rc, L.pp_last_error(ctx._h).decode() if ctx is not None else "pp_shard_split failed")
+        out, orig = AlnBatch(), C.c_void_p()
+        L.pp_shard_part_batch(self._p, C.byref(out), C.byref(orig))
+        self.mem = mem
+        self.n_aln, self.seq_bytes, self.n_cig_total = int(out.n_aln), int(out.seq_bytes), int(out.n_cig_total)
+        self.ptrs = {name: (C.cast(getattr(out, name), C.c_void_p).value or 0) for name, _ in REC_FIELDS}
+        self.orig_ptr = orig.value or 0
+
+    def host(self):
+        assert self.mem == MEM_HOST
+        sizes = {"seq": self.seq_bytes, "cigar": self.n_cig_total}
+        recs = {}
+        for name, dt in REC_FIELDS:
+            cnt = int(sizes.get(name, self.n_aln))
+            recs[name] = (np.ctypeslib.as_array(C.cast(self.ptrs[name], C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+                          if cnt and self.ptrs[name] else np.zeros(0, dtype=dt))
+        orig = (np.ctypeslib.as_array(C.cast(self.orig_ptr, C.POINTER(C.c_uint32)), shape=(self.n_aln,)).copy()
+                if self.n_aln else np.zeros(0, np.uint32))
+        return recs, orig
+
+    def close(self):
+        if self._p:
+            lib().pp_shard_part_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_split_host(plan, dest, recs):
+    """Host numpy SoA -> (recs of the part, orig)."""
+    keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
+    part = ShardPart(None, plan, dest, len(keep["contig"]), {k: v.ctypes.data for k, v in keep.items()}, len(keep["seq"]),
+                     len(keep["cigar"]), MEM_HOST)
+    out = part.host()
+    part.close()
+    return out
+
+
+def shard_count(ctx, n_aln, contig_ptr, mem, n_contigs, ptrs=None):
+    """pp_shard_count: alignment records per contig of a batch given by pointers."""
+    p = ptrs or {}
+    one = contig_ptr
+    b = AlnBatch(n_aln, contig_ptr, p.get("ref_start", one), p.get("k", one), p.get("seq_off", one), p.get("seq_len", one),
+                 p.get("cig_off", one), p.get("n_cig", one), p.get("seq", one), 0, p.get("cigar", one), 0)
+    cnt = np.zeros(n_contigs, dtype=np.uint64)
+    rc = lib().pp_shard_count(ctx._h if ctx is not None else None, C.byref(b), mem, n_contigs, cnt.ctypes.data)
+    if rc:
+        raise PolypolishError(rc, "pp_shard_count failed")
+    return cnt
 
 
 def comm_unique_id() -> bytes:

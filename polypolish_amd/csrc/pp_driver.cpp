@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <functional>
 #include <future>
 #include <cmath>
 #include <cstdarg>
@@ -172,6 +173,98 @@ extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char 
     return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
 }
 
+extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n);
+extern "C" int pp_dev_ingest_slice_(pp_dev_ingest *D, const char *path, const char *text, uint64_t size, pp_sam_counts *counts);
+
+namespace {
+
+// ---- several GPUs, ONE copy of the text: every GPU uploads and tokenizes a slice of each SAM file ---------------------
+// Where may a file be cut?  At the start of a line that opens a read group (src/alignment.rs:255-263: an aligned record
+// joins the group of the aligned record before it when that one's QNAME is empty or equal; header, empty and unaligned
+// lines neither join nor close anything).  Returns the first such line start at or after `from`, or `size`.
+struct LineView { const char *q; size_t qlen; bool aligned; };
+LineView look_at_line(const char *text, size_t ls, size_t le) {
+    LineView v{text + ls, 0, false};
+    if (le == ls || text[ls] == '@') return v;
+    const char *tab = (const char *)memchr(text + ls, '\t', le - ls);
+    if (!tab) return v;
+    v.qlen = (size_t)(tab - (text + ls));
+    const char *f = tab + 1, *end = text + le;
+    if (f < end && *f == '+') f++;
+    unsigned long long flag = 0;
+    const char *d = f;
+    while (d < end && *d >= '0' && *d <= '9' && d - f < 12) flag = flag * 10 + (unsigned long long)(*d++ - '0');
+    if (d == f || (d < end && *d != '\t')) return v;  // not a number: the tokenizer will say so; no cut here
+    v.aligned = (flag & 4ull) == 0;
+    return v;
+}
+size_t group_cut(const char *text, size_t size, size_t from) {
+    if (from == 0) return 0;
+    if (from >= size) return size;
+    // the start of the first line at or after `from`
+    size_t p = from;
+    if (text[p - 1] != '\n') {
+        const char *nl = (const char *)memchr(text + p, '\n', size - p);
+        if (!nl) return size;
+        p = (size_t)(nl - text) + 1;
+    }
+    // the aligned record before it (scan back over header / empty / unaligned lines; give up after a while: then the
+    // first aligned line at or after p is compared with nothing and the search just moves on one group)
+    bool have_prev = false;
+    const char *pq = nullptr;
+    size_t pql = 0;
+    {
+        size_t e = p;  // e = one past the '\n' that ends the line being looked at
+        for (int tries = 0; tries < 4096 && e > 0; tries++) {
+            const size_t le = e - 1;  // the '\n'
+            size_t ls = le;
+            while (ls > 0 && text[ls - 1] != '\n') ls--;
+            const LineView v = look_at_line(text, ls, le);
+            if (v.aligned) { have_prev = true; pq = v.q; pql = v.qlen; break; }
+            e = ls;
+        }
+        if (!have_prev && e > 0) return size;  // a long stretch without aligned records: do not cut in this neighbourhood
+    }
+    while (p < size) {
+        const char *nl = (const char *)memchr(text + p, '\n', size - p);
+        const size_t le = nl ? (size_t)(nl - text) : size;
+        const LineView v = look_at_line(text, p, le);
+        if (v.aligned) {
+            if (!have_prev || (pql != 0 && (pql != v.qlen || memcmp(pq, v.q, pql) != 0))) return p;
+            have_prev = true; pq = v.q; pql = v.qlen;
+        }
+        p = le + 1;
+    }
+    return size;
+}
+
+// one stretch of records handed to a destination context, for turning its rank-local record numbers back into the job's
+struct Piece { pp_shard_part *part; int src; uint64_t base, n; };
+
+// the job-wide number of the record a context's device error is about, or ~0 (not a record-level error)
+uint64_t job_record_of(pp_ctx *cd, pp_ctx *const *ctxs, const std::vector<Piece> &pieces, uint32_t *kind) {
+    uint64_t local = 0;
+    if (!pp_polish_error_record(cd, &local, kind)) return ~0ull;
+    uint64_t at = 0;
+    for (const Piece &pc : pieces) {
+        if (local < at + pc.n) {
+            const uint32_t *orig = nullptr;
+            pp_shard_part_batch(pc.part, nullptr, &orig);
+            uint32_t o = 0;
+            if (pp_shard_part_mem(pc.part) == PP_MEM_HOST) o = orig[local - at];
+            else if (pp_ctx_download(ctxs[pc.src], &o, orig + (local - at), 4) != PP_OK) return ~0ull;
+            return pc.base + o;
+        }
+        at += pc.n;
+    }
+    return ~0ull;
+}
+
+}  // namespace
+
+// (tests) where the multi-GPU driver would cut `text` at or after `from`
+extern "C" uint64_t pp_sam_group_cut_(const char *text, uint64_t size, uint64_t from) { return group_cut(text, (size_t)size, (size_t)from); }
+
 // pass / n_pass: optional per-file filter verdicts (pp_ingest_sam_filtered), used by pp_filter_polish_files
 static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams, int n_sams,
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
@@ -211,7 +304,10 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     // The device tokenizer uploads the SAM text as it is: map the files and pre-fault the mappings NOW, on background
     // threads, while the HIP runtime is still initialising (a copy out of an untouched mapping runs at a quarter of
     // the link's rate).
-    const bool dev_ingest = n_ctx == 1 && !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
+    // Several contexts: every GPU uploads and tokenizes its own slice of each file (`sharded`), so a byte of text crosses
+    // PCIe once; the host ingest (PP_DEVICE_INGEST=0, or a file the tokenizer handed back) parses once and sends every
+    // context the records that reach its units.
+    const bool dev_ingest = !host_ingest_only && !(getenv("PP_DEVICE_INGEST") && atoi(getenv("PP_DEVICE_INGEST")) == 0) && !opt->debug_path;
     if (dev_ingest)
         for (int i = 0; i < n_sams; i++) pph::prefetch_file(sams[i], ctx);
     struct DropPrefetched { const void *owner; ~DropPrefetched() { pph::prefetch_drop_all(owner); } } drop_prefetched{ctx};
@@ -246,12 +342,15 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     log("Loading alignments\n");
     pp_ingest *g = nullptr;
     pp_dev_ingest *dg = nullptr;
-    // Host ingest without --debug: one ingest object per SAM file, and the batch of file i goes to the device
+    std::vector<pp_dev_ingest *> dgs((size_t)(multi && dev_ingest ? n_ctx : 0), nullptr);  // sharded ingest: one per context
+    // Host ingest without --debug: one ingest object per SAM file, and (one context) the batch of file i goes to the device
     // (pp_polish_begin + pp_polish_add on a helper thread) while file i+1 is parsed -- the reference streams its files
     // one after the other as well (alignment.rs:238-265).  --debug keeps ONE host batch (the TSV indexes its SEQ bytes).
-    const bool stream_adds = !dev_ingest && !opt->debug_path && (multi || !(getenv("PP_STREAM_ADDS") && atoi(getenv("PP_STREAM_ADDS")) == 0));
+    // Several contexts: the files' batches wait until the plan is known, then every context is sent its part.
+    const bool per_file = !dev_ingest && !opt->debug_path && (multi || !(getenv("PP_STREAM_ADDS") && atoi(getenv("PP_STREAM_ADDS")) == 0));
+    const bool stream_adds = per_file && !multi;
     std::vector<pp_ingest *> gs;
-    std::vector<std::future<int>> pending;  // the uploads of the file before, one per context
+    std::vector<std::future<int>> pending;  // the upload of the file before
     std::vector<uint64_t> per_contig(nc, 0);  // alignment records per contig (the planner's weights)
     bool begun = false;
     pp_params prm{opt->min_depth, opt->fraction_valid, opt->fraction_invalid};
@@ -259,24 +358,43 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         int r = PP_OK;
         for (size_t i = 0; i < pending.size(); i++) {
             const int ri = pending[i].get();
-            if (ri && !r) {
-                r = ri;
-                if (i) set_err(ctx, ri, pp_last_error(ctxs[i]));
-            }
+            if (ri && !r) r = ri;
         }
         pending.clear();
         return r;
     };
+    std::vector<std::vector<Piece>> pieces((size_t)n_ctx);  // multi: what every context was sent, in file order
     auto free_all = [&]() {
         (void)wait_pending();
+        for (auto &v : pieces)
+            for (Piece &pc : v) pp_shard_part_free(pc.part);
+        pieces.clear();
         for (pp_ingest *x : gs) pp_ingest_free(x);
         pp_ingest_free(g);
         pp_dev_ingest_free(dg);
+        for (pp_dev_ingest *x : dgs) pp_dev_ingest_free(x);
         pp_assembly_free(a);
     };
-    rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
-                    : (stream_adds ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
-    if (rc == PP_OK && dev_ingest) {
+    // run f(d) for every context on its own thread; the first failure (lowest d) is returned, its text put on ctxs[0]
+    auto on_all = [&](const std::function<int(int)> &f) {
+        std::vector<std::future<int>> jobs;
+        for (int d = 0; d < n_ctx; d++) jobs.push_back(std::async(std::launch::async, f, d));
+        int r = PP_OK;
+        for (int d = 0; d < n_ctx; d++) {
+            const int rd = jobs[(size_t)d].get();
+            if (rd && !r) {
+                r = rd;
+                if (d) set_err(ctx, rd, pp_last_error(ctxs[d]));
+            }
+        }
+        return r;
+    };
+    const bool sharded = multi && dev_ingest;
+    if (multi) pp_ctx_enable_peers_(ctxs, n_ctx);
+    if (sharded) rc = on_all([&](int d) { return pp_dev_ingest_create(ctxs[d], a, opt->max_errors, opt->careful, &dgs[(size_t)d]); });
+    else rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
+                         : (per_file ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
+    if (rc == PP_OK && dev_ingest && !sharded) {
         uint64_t largest = 0;
         for (int i = 0; i < n_sams; i++) {
             struct stat st;
@@ -285,10 +403,41 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         if (largest) rc = pp_dev_ingest_reserve_text_(dg, largest);
     }
     uint64_t alignment_total = 0, used_total = 0;
+    // sharded: the records of file i's slice on context s are records [slice_end[i-1][s], slice_end[i][s]) of its batch
+    std::vector<std::vector<uint64_t>> slice_end;
     for (int i = 0; rc == PP_OK && i < n_sams; i++) {
-        pp_sam_counts c;
+        pp_sam_counts c{0, 0, 0};
         if (i == resume_log_at) log.quiet = opt->quiet != 0;
-        if (dev_ingest) {
+        if (sharded) {
+            // cut the file into one slice per context at read-group boundaries; every context uploads and tokenizes its own
+            pph::FileText F;
+            if (!F.open_file(sams[i])) {
+                snprintf(err, sizeof err, "unable to load alignments from \"%s\"", sams[i]);
+                rc = set_err(ctx, PP_ERR_QUIT, err);
+                break;
+            }
+            std::vector<size_t> cut((size_t)n_ctx + 1, F.size);
+            cut[0] = 0;
+            for (int d = 1; d < n_ctx; d++) cut[(size_t)d] = std::max(cut[(size_t)d - 1], group_cut(F.text, F.size, F.size / (size_t)n_ctx * (size_t)d));
+            std::vector<pp_sam_counts> cs((size_t)n_ctx);
+            int rs = on_all([&](int d) {
+                return pp_dev_ingest_slice_(dgs[(size_t)d], sams[i], F.text + cut[(size_t)d], cut[(size_t)d + 1] - cut[(size_t)d], &cs[(size_t)d]);
+            });
+            for (auto &x : cs) { c.alignments += x.alignments; c.used += x.used; c.reads += x.reads; }
+            if (rs == PP_OK && c.alignments == 0) rs = PP_ERR_PANIC;  // a file without aligned records: the host path has the message
+            if (rs == PP_ERR_QUIT || rs == PP_ERR_PANIC || rs == PP_ERR_NOT_ASCII) {
+                free_all();  // as for one context: the host ingest works out what the reference reports first
+                return polish_files_impl(ctxs, n_ctx, assembly, sams, n_sams, opt, fasta, pass, n_pass, i);
+            }
+            if ((rc = rs)) break;
+            std::vector<uint64_t> ends((size_t)n_ctx);
+            for (int d = 0; d < n_ctx; d++) {
+                pp_aln_batch bd;
+                pp_dev_ingest_batch(dgs[(size_t)d], &bd);
+                ends[(size_t)d] = bd.n_aln;
+            }
+            slice_end.push_back(ends);
+        } else if (dev_ingest) {
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
             if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC || rc == PP_ERR_NOT_ASCII) {
                 // A defect in the text.  Which defect the reference reports FIRST also depends on what its CIGAR walk
@@ -299,7 +448,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             if (rc) break;
         } else {
             pp_ingest *gi = g;
-            if (stream_adds) {
+            if (per_file) {
                 rc = pp_ingest_create(a, opt->max_errors, opt->careful, &gi);
                 if (rc) break;
                 gs.push_back(gi);
@@ -317,10 +466,15 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     int rd = begun ? PP_OK : pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
                     begun = true;
                     pp_aln_batch bi;
-                    if (rd == PP_OK && !stream_adds && g) {
+                    if (rd == PP_OK && !per_file && g) {
                         pp_ingest_batch(g, &bi);
                         if (bi.n_aln) rd = pp_polish_add(ctx, &bi, PP_MEM_HOST);
                     }
+                    if (multi)  // (the earlier files' batches have not gone anywhere yet: the first context takes them whole)
+                        for (size_t q = 0; rd == PP_OK && q + 1 < gs.size(); q++) {
+                            pp_ingest_batch(gs[q], &bi);
+                            if (bi.n_aln) rd = pp_polish_add(ctx, &bi, PP_MEM_HOST);
+                        }
                     pp_ingest *gp = nullptr;
                     char err2[256];
                     pp_sam_counts c2;
@@ -338,36 +492,28 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                 break;
             }
             if (stream_adds) {
-                if ((rc = wait_pending())) break;  // the uploads of the file before
+                if ((rc = wait_pending())) break;  // the upload of the file before
                 const bool first = !begun;
                 begun = true;
-                if (multi) {
+                // room for all files at once: this file's batch scaled by the files' sizes on disk
+                double scale = 1.0;
+                if (first && n_sams > 1) {
+                    struct stat st0;
+                    double all_bytes = 0, this_bytes = 0;
+                    for (int q = 0; q < n_sams; q++)
+                        if (stat(sams[q], &st0) == 0 && S_ISREG(st0.st_mode)) { all_bytes += (double)st0.st_size; if (q == i) this_bytes = (double)st0.st_size; }
+                    if (this_bytes > 0) scale = std::min(64.0, all_bytes / this_bytes * 1.02);
+                }
+                pending.push_back(std::async(std::launch::async, [ctx, gi, first, nc, off, a, prm, scale]() {
+                    int r = first ? pp_polish_begin(ctx, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
                     pp_aln_batch bi;
                     pp_ingest_batch(gi, &bi);
-                    for (uint64_t q = 0; q < bi.n_aln; q++) per_contig[bi.contig[q]]++;
-                }
-                for (int d = 0; d < n_ctx; d++) {
-                    pp_ctx *cd = ctxs[d];
-                    // room for all files at once: this file's batch scaled by the files' sizes on disk
-                    double scale = 1.0;
-                    if (first && n_sams > 1) {
-                        struct stat st0;
-                        double all_bytes = 0, this_bytes = 0;
-                        for (int q = 0; q < n_sams; q++)
-                            if (stat(sams[q], &st0) == 0 && S_ISREG(st0.st_mode)) { all_bytes += (double)st0.st_size; if (q == i) this_bytes = (double)st0.st_size; }
-                        if (this_bytes > 0) scale = std::min(64.0, all_bytes / this_bytes * 1.02);
-                    }
-                    pending.push_back(std::async(std::launch::async, [cd, gi, first, nc, off, a, prm, scale]() {
-                        int r = first ? pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm) : PP_OK;
-                        pp_aln_batch bi;
-                        pp_ingest_batch(gi, &bi);
-                        if (r == PP_OK && first && scale > 1.0)
-                            r = pp_polish_reserve(cd, (uint64_t)((double)bi.n_aln * scale) + 1024, (uint64_t)((double)bi.seq_bytes * scale) + 4096,
-                                                  (uint64_t)((double)bi.n_cig_total * scale) + 1024);
-                        if (r == PP_OK) r = pp_polish_add(cd, &bi, PP_MEM_HOST);
-                        return r;
-                    }));
-                }
+                    if (r == PP_OK && first && scale > 1.0)
+                        r = pp_polish_reserve(ctx, (uint64_t)((double)bi.n_aln * scale) + 1024, (uint64_t)((double)bi.seq_bytes * scale) + 4096,
+                                              (uint64_t)((double)bi.n_cig_total * scale) + 1024);
+                    if (r == PP_OK) r = pp_polish_add(ctx, &bi, PP_MEM_HOST);
+                    return r;
+                }));
             }
         }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
@@ -388,7 +534,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     log("Polishing assembly sequences\n");
     pp_aln_batch batch;
     memset(&batch, 0, sizeof batch);
-    if (dev_ingest) pp_dev_ingest_batch(dg, &batch); else if (g) pp_ingest_batch(g, &batch);
+    if (dev_ingest && !sharded) pp_dev_ingest_batch(dg, &batch); else if (g) pp_ingest_batch(g, &batch);
     // create_debug_file, polish.rs:230-245: the file is created (and the header written) before polishing
     FILE *dbg = nullptr;
     if (opt->debug_path) {
@@ -419,40 +565,129 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         polished.resize(total ? total : 1);
         if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
     } else {
-        // every context: the ranges of its units, finish, its own bytes to the host -- side by side
+        // ---- the plan, from the alignment counts per contig ----
+        // source batches in file order: sharded -> (file, slice) pieces living on the contexts' GPUs; host ingest -> files
+        struct Src { pp_aln_batch view; int mem; int owner; uint64_t base; };
+        std::vector<Src> srcs;
+        uint64_t base = 0;
+        if (sharded) {
+            std::vector<pp_aln_batch> whole((size_t)n_ctx);
+            for (int d = 0; d < n_ctx; d++) pp_dev_ingest_batch(dgs[(size_t)d], &whole[(size_t)d]);
+            for (size_t f = 0; f < slice_end.size(); f++)
+                for (int sidx = 0; sidx < n_ctx; sidx++) {
+                    const uint64_t lo = f ? slice_end[f - 1][(size_t)sidx] : 0, hi = slice_end[f][(size_t)sidx];
+                    pp_aln_batch v = whole[(size_t)sidx];  // seq / cigar: the whole arrays (seq_off / cig_off are absolute)
+                    v.n_aln = hi - lo;
+                    v.contig += lo; v.ref_start += lo; v.k += lo; v.seq_off += lo; v.seq_len += lo; v.cig_off += lo; v.n_cig += lo;
+                    srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base});
+                    base += hi - lo;
+                }
+            // (one context after the other: a histogram kernel each, they add into the same host array)
+            for (int d = 0; rc == PP_OK && d < n_ctx; d++) {
+                rc = pp_shard_count(ctxs[d], &whole[(size_t)d], PP_MEM_DEVICE, nc, per_contig.data());
+                if (rc && d) set_err(ctx, rc, pp_last_error(ctxs[d]));
+            }
+        } else {
+            for (pp_ingest *gi : gs) {
+                pp_aln_batch v;
+                pp_ingest_batch(gi, &v);
+                srcs.push_back(Src{v, PP_MEM_HOST, -1, base});
+                base += v.n_aln;
+                pp_shard_count(nullptr, &v, PP_MEM_HOST, nc, per_contig.data());
+            }
+        }
         pp_shard_plan *plan = nullptr;
-        rc = pp_shard_plan_create(nc, off, per_contig.data(), (uint32_t)n_ctx, 0, &plan);
-        std::vector<std::vector<uint8_t>> r_bytes(n_ctx);
-        std::vector<std::vector<uint64_t>> r_off(n_ctx, std::vector<uint64_t>(nc + 1, 0));
-        std::vector<std::vector<pp_contig_stats>> r_stats(n_ctx, std::vector<pp_contig_stats>(nc));
-        std::vector<std::future<int>> jobs;
-        for (int d = 0; rc == PP_OK && d < n_ctx; d++) {
-            jobs.push_back(std::async(std::launch::async, [&, d]() {
+        if (rc == PP_OK) rc = pp_shard_plan_create(nc, off, per_contig.data(), (uint32_t)n_ctx, 0, &plan);
+        // ---- every source batch is split once per destination (on the GPU that holds it, or on the host) ----
+        std::vector<std::vector<pp_shard_part *>> parts(srcs.size(), std::vector<pp_shard_part *>((size_t)n_ctx, nullptr));
+        if (rc == PP_OK) {
+            if (sharded)
+                rc = on_all([&](int sidx) {  // a context splits the pieces it holds, for every destination
+                    for (size_t q = 0; q < srcs.size(); q++) {
+                        if (srcs[q].owner != sidx) continue;
+                        for (int d = 0; d < n_ctx; d++)
+                            if (int r = pp_shard_split(ctxs[sidx], plan, (uint32_t)d, &srcs[q].view, PP_MEM_DEVICE, &parts[q][(size_t)d])) return r;
+                    }
+                    return (int)PP_OK;
+                });
+            else
+                rc = on_all([&](int d) {
+                    for (size_t q = 0; q < srcs.size(); q++)
+                        if (int r = pp_shard_split(nullptr, plan, (uint32_t)d, &srcs[q].view, PP_MEM_HOST, &parts[q][(size_t)d])) {
+                            set_err(ctxs[d], r, "splitting the records failed");
+                            return r;
+                        }
+                    return (int)PP_OK;
+                });
+        }
+        for (size_t q = 0; q < srcs.size(); q++)
+            for (int d = 0; d < n_ctx; d++)
+                if (parts[q][(size_t)d]) {
+                    pp_aln_batch v;
+                    pp_shard_part_batch(parts[q][(size_t)d], &v, nullptr);
+                    pieces[(size_t)d].push_back(Piece{parts[q][(size_t)d], srcs[q].owner, srcs[q].base, v.n_aln});
+                }
+        lap("records split");
+        // every context: its records, the ranges of its units, finish, its own bytes to the host -- side by side
+        std::vector<std::vector<uint8_t>> r_bytes((size_t)n_ctx);
+        std::vector<std::vector<uint64_t>> r_off((size_t)n_ctx, std::vector<uint64_t>(nc + 1, 0));
+        std::vector<std::vector<pp_contig_stats>> r_stats((size_t)n_ctx, std::vector<pp_contig_stats>(nc));
+        std::vector<int> r_rc((size_t)n_ctx, PP_OK);
+        if (rc == PP_OK) {
+            (void)on_all([&](int d) {
                 pp_ctx *cd = ctxs[d];
-                int r = begun ? PP_OK : pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+                int r = pp_polish_begin(cd, nc, off, pp_assembly_bases(a), PP_MEM_HOST, &prm);
+                uint64_t tn = 0, ts = 0, tc = 0;
+                for (const Piece &pc : pieces[(size_t)d]) {
+                    pp_aln_batch v;
+                    pp_shard_part_batch(pc.part, &v, nullptr);
+                    tn += v.n_aln; ts += v.seq_bytes; tc += v.n_cig_total;
+                }
+                if (r == PP_OK) r = pp_polish_reserve(cd, tn + 16, ts + 64, tc + 16);
+                bool first = true;
+                for (const Piece &pc : pieces[(size_t)d]) {
+                    if (r) break;
+                    pp_aln_batch v;
+                    pp_shard_part_batch(pc.part, &v, nullptr);
+                    if (v.n_aln == 0) continue;
+                    // (a part on this context's own GPU is device memory; the FIRST batch of a job would be used in place,
+                    // which is fine -- the parts live until every context has finished)
+                    const int pm = pp_shard_part_mem(pc.part);
+                    r = pp_polish_add(cd, &v, pm == PP_MEM_HOST ? PP_MEM_HOST : (pc.src == d && !first ? PP_MEM_DEVICE : PP_MEM_PEER));
+                    first = false;
+                }
                 std::vector<uint64_t> lo(nc), hi(nc);
                 if (r == PP_OK) r = pp_shard_emit_ranges(plan, (uint32_t)d, lo.data(), hi.data());
                 if (r == PP_OK) r = pp_polish_set_emit(cd, lo.data(), hi.data());
                 if (r == PP_OK) r = pp_polish_finish(cd);
                 uint64_t t = 0;
                 if (r == PP_OK) r = pp_polish_result_size(cd, &t);
-                r_bytes[d].resize(t ? t : 1);
-                if (r == PP_OK) r = pp_polish_result(cd, r_bytes[d].data(), PP_MEM_HOST, r_off[d].data(), r_stats[d].data());
+                r_bytes[(size_t)d].resize(t ? t : 1);
+                if (r == PP_OK) r = pp_polish_result(cd, r_bytes[(size_t)d].data(), PP_MEM_HOST, r_off[(size_t)d].data(), r_stats[(size_t)d].data());
+                r_rc[(size_t)d] = r;
                 return r;
-            }));
-        }
-        for (size_t d = 0; d < jobs.size(); d++) {
-            const int rd = jobs[d].get();
-            if (rd && !rc) {
-                rc = rd;
-                if (d) set_err(ctx, rd, pp_last_error(ctxs[d]));
+            });
+            // The job's error is the one about its FIRST bad record in file order (the reference streams,
+            // src/alignment.rs:238-303): a context numbers the records it was sent, the parts know where those came from.
+            uint64_t best = ~0ull;
+            int best_d = -1;
+            uint32_t best_kind = 0;
+            for (int d = 0; d < n_ctx; d++) {
+                if (r_rc[(size_t)d] == PP_OK) continue;
+                uint32_t kind = 0;
+                const uint64_t jr = job_record_of(ctxs[d], ctxs, pieces[(size_t)d], &kind);
+                if (best_d < 0 || jr < best) { best = jr; best_d = d; best_kind = kind; }
+            }
+            if (best_d >= 0) {
+                if (best != ~0ull) rc = pp_polish_error_text(ctx, best_kind, best);
+                else { rc = r_rc[(size_t)best_d]; if (best_d) set_err(ctx, rc, pp_last_error(ctxs[best_d])); }
             }
         }
         lap("uploaded + polished on the devices");
         if (rc == PP_OK) {
-            std::vector<const uint8_t *> bp(n_ctx);
-            std::vector<const uint64_t *> op(n_ctx);
-            for (int d = 0; d < n_ctx; d++) { bp[d] = r_bytes[d].data(); op[d] = r_off[d].data(); }
+            std::vector<const uint8_t *> bp((size_t)n_ctx);
+            std::vector<const uint64_t *> op((size_t)n_ctx);
+            for (int d = 0; d < n_ctx; d++) { bp[(size_t)d] = r_bytes[(size_t)d].data(); op[(size_t)d] = r_off[(size_t)d].data(); }
             rc = pp_shard_assemble(plan, bp.data(), op.data(), nullptr, out_off.data());
             total = out_off[nc];
             polished.resize(total ? total : 1);
@@ -460,9 +695,9 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             for (uint32_t c = 0; c < nc; c++) {  // a position is counted by the rank that emits it
                 stats[c] = pp_contig_stats{out_off[c + 1] - out_off[c], 0, 0, 0.0};
                 for (int d = 0; d < n_ctx; d++) {
-                    stats[c].changed += r_stats[d][c].changed;
-                    stats[c].zero_depth += r_stats[d][c].zero_depth;
-                    stats[c].depth_sum += r_stats[d][c].depth_sum;
+                    stats[c].changed += r_stats[(size_t)d][c].changed;
+                    stats[c].zero_depth += r_stats[(size_t)d][c].zero_depth;
+                    stats[c].depth_sum += r_stats[(size_t)d][c].depth_sum;
                 }
             }
         }

@@ -107,6 +107,7 @@ struct pp_ctx {
     bool batch_borrowed = false;       // the one batch so far is caller-owned device memory, used in place
     uint64_t acc_n = 0, acc_seq = 0, acc_cig = 0;  // records / SEQ bytes / CIGAR runs accumulated in b_in[]
     uint64_t total_out = 0, n_multi = 0, n_keys = 0;
+    uint64_t last_dev_error = ~0ull;   // (record index << 8 | DevErr) of the last pp_polish_finish that failed on the device
     std::vector<uint64_t> contig_out_off;
     std::vector<pp_contig_stats> stats;
 

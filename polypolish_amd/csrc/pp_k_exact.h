@@ -106,15 +106,222 @@ constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
 constexpr u64 SL_DONE = 1ull << 63;
 
 __device__ void exact_one(const ExactArgs &A, u32 f);
+__device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 lane);
+
+// One WAVE per listed position (a position whose string-keyed tallies -- an insertion, N ... -- could reach a threshold,
+// every flagged position of a window too deep for k_exact2, and with --debug everything that has such a key): the lanes
+// scan the window's work items together, the covering alignments are sorted by file index in LDS, the keys are tallied
+// and grouped by the whole wave.  An assembly that lacks a base makes every read over that spot vote for a two-byte
+// key (src/alignment.rs:175-201: an I run extends the entry before it; src/pileup.rs:56-63 counts it by string), so
+// these positions are what polishing is about -- one THREAD per position, walking the window's ~3,000 items and
+// heap-sorting 200 of them in global memory, took 10 ms per job at 200x.  Positions covered by more than EXW_MAX
+// alignments keep that thread-serial path.
+constexpr u32 EXW_MAX = 1024;
 
 __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
+    __shared__ ulonglong2 cov[EXW_MAX];
+    __shared__ double rcp[EXW_MAX];
     if (*A.status != ~0ull) return;
     if (*A.scr_need > A.cap_scr) {  // the scratch is too small: the host grows it and reruns
         if (blockIdx.x == 0 && threadIdx.x == 0) report(A.status, *A.scr_need, DE_CAPACITY);
         return;
     }
     const u32 n_flagged = A.counters[0];
-    for (u32 f = blockIdx.x * blockDim.x + threadIdx.x; f < n_flagged; f += gridDim.x * blockDim.x) exact_one(A, f);
+    for (u32 f = blockIdx.x; f < n_flagged; f += gridDim.x) {
+        if (A.flag_cov[f] <= EXW_MAX) exact_wave(A, f, cov, rcp, threadIdx.x);
+        else if (threadIdx.x == 0) exact_one(A, f);
+        __syncthreads();
+    }
+}
+
+__device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 lane) {
+    const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
+    const u32 w = gp / (u32)TILE;
+    const int pr = (int)(gp - w * (u32)TILE);
+    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40) ----
+    u32 n = 0;
+    for (u32 eb = e0; eb < e1; eb += 64) {
+        const u32 e = eb + lane;
+        bool hit = false;
+        ulonglong2 v = make_ulonglong2(0, 0);
+        if (e < e1) {
+            const uint4 ent = A.entA[e];
+            const int q = pr - (int)ent.z;
+            const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
+            if (q >= 0 && q < (int)(fl ? ent.x : (ent.y >> 24))) {
+                const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+                // fast-class items carry their untrimmed length: apply the trim here
+                if (fl != 0 || (u32)q < simple_nkeep(A.seq + so, ent.y >> 24)) {
+                    u64 s_rel;
+                    u32 len;
+                    if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+                    else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
+                    v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+                    v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
+                    hit = true;
+                }
+            }
+        }
+        const u64 m = __ballot(hit);
+        if (hit) {
+            const u32 slot = n + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < EXW_MAX) cov[slot] = v;
+        }
+        n += (u32)__popcll(m);
+    }
+    if (n != cap) { if (lane == 0) report(A.status, gp, DE_INTERNAL); return; }
+    // ---- file order: bitonic network over the next power of two (the padding sorts to the end) ----
+    u32 np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (u32 i = n + lane; i < np2; i += 64) cov[i] = make_ulonglong2(~0ull, 0);
+    __syncthreads();
+    for (u32 k = 2; k <= np2; k <<= 1)
+        for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {
+            const u32 j = 1u << lj;
+            for (u32 t = lane; t < (np2 >> 1); t += 64) {
+                const u32 i = ((t >> lj) << (lj + 1u)) | (t & (j - 1u)), o = i + j;
+                const bool asc = (i & k) == 0;
+                const ulonglong2 x = cov[i], y = cov[o];
+                if ((x.x > y.x) == asc) { cov[i] = y; cov[o] = x; }
+            }
+            __syncthreads();
+        }
+    // ---- tallies (by the wave) and the depth (sequential f64 adds of 1.0/k in file order: pileup.rs:64, alignment.rs:288) ----
+    u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0;
+    for (u32 i = lane; i < n; i += 64) {
+        rcp[i] = 1.0 / (double)(u32)(cov[i].x & 0xFFFFFFFFull);
+        const u64 y = cov[i].y;
+        const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
+        int row = ROW_OTH;
+        if (len == 0) row = ROW_DEL;
+        else if (len == 1) row = row_of(A.seq[y & SL_OFF_MASK]);
+        if (row != ROW_OTH) {
+            if (row == ROW_A) nA++; else if (row == ROW_C) nC++; else if (row == ROW_G) nG++;
+            else if (row == ROW_T) nT++; else nDel++;
+            cov[i].y = y | SL_DONE;
+        } else nOth++;
+    }
+    nA = wave_sum(nA); nC = wave_sum(nC); nG = wave_sum(nG); nT = wave_sum(nT); nDel = wave_sum(nDel); nOth = wave_sum(nOth);
+    __syncthreads();
+    double depth = 0.0;
+    if (lane == 0)
+        for (u32 i = 0; i < n; i++) depth += rcp[i];
+    depth = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(depth)), __builtin_amdgcn_readfirstlane(__double2loint(depth)));
+    const u8 orig = A.bases[gp];
+    VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+    u64 win_off = 0;
+    u32 win_len = 0;  // winning string-keyed sequence, if any
+    const bool low = v.status == PP_ST_LOW_DEPTH;
+    if (A.dbg && nDel > 0 && lane == 0) {  // --debug lists the deletion key like any other
+        const u64 slot = atomicAdd(A.n_keys, 1ull);
+        if (slot < A.cap_keys) {
+            KeyRec kr;
+            kr.off = 0; kr.pos = gp; kr.len = 0; kr.count = nDel; kr.pad = 0;
+            A.keys[slot] = kr;
+        } else report(A.status, slot, DE_CAPACITY);
+    }
+    if (nOth > 0 && (!low || A.dbg)) {
+        // redo the tally of pileup.rs:77-109 with the remaining keys added
+        int nv = 0, ni = 0;
+        u8 win = 0;
+        const u32 c5[5] = {nA, nC, nG, nT, nDel};
+        const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
+        for (int j = 0; j < 5; j++) {
+            if (j == 4 && nDel == 0) break;
+            if (c5[j] >= v.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= v.ithr) ni++;
+        }
+        // one distinct key after the other, in the order of their first appearance: the lanes compare theirs with it
+        for (u32 i = 0; i < n; i++) {
+            const u64 yi = cov[i].y;  // (the same word for every lane: one broadcast read)
+            if (yi & SL_DONE) continue;
+            const u32 li = (u32)((yi >> 40) & 0x7FFFFFu);
+            const u8 *si = A.seq + (yi & SL_OFF_MASK);
+            u32 mine = 0;
+            for (u32 j = i + 1 + lane; j < n; j += 64) {
+                const u64 yj = cov[j].y;
+                if ((yj & SL_DONE) || (u32)((yj >> 40) & 0x7FFFFFu) != li) continue;
+                const u8 *sj = A.seq + (yj & SL_OFF_MASK);
+                bool same = true;
+                for (u32 b = 0; b < li; b++) if (si[b] != sj[b]) { same = false; break; }
+                if (same) { mine++; cov[j].y = yj | SL_DONE; }
+            }
+            const u32 count = 1u + wave_sum(mine);
+            __syncthreads();
+            if (count >= v.vthr) { if (!nv) { win = 0; win_off = yi & SL_OFF_MASK; win_len = li; } nv++; }
+            else if (count >= v.ithr) ni++;
+            if (A.dbg && lane == 0) {
+                const u64 slot = atomicAdd(A.n_keys, 1ull);
+                if (slot < A.cap_keys) {
+                    KeyRec kr;
+                    kr.off = yi & SL_OFF_MASK; kr.pos = gp; kr.len = li; kr.count = count; kr.pad = 0;
+                    A.keys[slot] = kr;
+                } else report(A.status, slot, DE_CAPACITY);
+            }
+        }
+        if (low) {
+            win_len = 0;  // the keys were only walked for the --debug records
+        } else {
+            v.out = (orig == (u8)'-') ? 0 : orig;
+            v.status = PP_ST_KEPT;
+            if (nv == 1) {
+                if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+                else if (win_len == 0) {
+                    v.out = (win == (u8)'-') ? 0 : win;
+                    if (win != orig) v.status = PP_ST_CHANGED;
+                } else {
+                    v.status = (win_len == 1 && A.seq[win_off] == orig) ? PP_ST_KEPT : PP_ST_CHANGED;
+                }
+            } else {
+                win_len = 0;
+                v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+            }
+            if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
+        }
+    }
+    const u32 c = find_contig_wave(A.contig_off, A.n_contigs, gp, lane);
+    if (lane != 0) return;
+    u32 emit;
+    if (win_len > 0) {
+        u32 eff = 0;
+        u8 only = 0;
+        for (u32 b = 0; b < win_len; b++) {
+            const u8 ch = A.seq[win_off + b];
+            if (ch != (u8)'-') { eff++; only = ch; }
+        }
+        if (eff == 0) { A.code[gp] = 0; }
+        else if (eff == 1 && only < 0x80u) { A.code[gp] = only; }
+        else {
+            A.code[gp] = (eff <= 126u) ? (u8)(0x80u | eff) : (u8)0xFFu;
+            const u32 slot = atomicAdd(&A.counters[1], 1u);
+            if (slot < A.cap_multi) {
+                MultiEnt m;
+                m.off = win_off; m.pos = gp; m.len = win_len; m.eff = eff; m.pad = 0;
+                A.multi[slot] = m;
+            } else {
+                report(A.status, slot, DE_CAPACITY);
+            }
+        }
+        emit = eff;
+    } else {
+        A.code[gp] = v.out;
+        emit = v.out ? 1u : 0u;
+    }
+    if (emit) atomicAdd(&A.win_len[w], emit);
+    if (v.status == PP_ST_CHANGED) atomicAdd(&A.stats[c].changed, 1ull);
+    if (n == 0) atomicAdd(&A.stats[c].zero_depth, 1ull);
+    atomicAdd(&A.stats[c].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
+    if (A.dbg) {
+        A.dbg_depth[gp] = depth;
+        A.dbg_counts[0 * A.G + gp] = nA;
+        A.dbg_counts[1 * A.G + gp] = nC;
+        A.dbg_counts[2 * A.G + gp] = nG;
+        A.dbg_counts[3 * A.G + gp] = nT;
+        A.dbg_counts[4 * A.G + gp] = nDel + nOth;
+        A.dbg_counts[5 * A.G + gp] = v.vthr;
+        A.dbg_counts[6 * A.G + gp] = v.ithr;
+        A.dbg_status[gp] = v.status;
+    }
 }
 
 __device__ void exact_one(const ExactArgs &A, u32 f) {

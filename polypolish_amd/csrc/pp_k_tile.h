@@ -765,8 +765,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
-            // dbg 2: test hook, see run_pipeline; a listed heavy window is replayed by k_exact2's sub-range instance
-            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy);
+            // dbg 2: test hook, see run_pipeline; a listed heavy window is replayed by k_exact2's sub-range instance.
+            // A position that is only here for its string-keyed tallies (an insertion that may win: its depth is exact
+            // already) goes straight to the list of k_exact's wave-per-position replay -- k_exact2 would sort the whole
+            // window for the ordered depth it does not need, and then hand it over all the same.
+            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy) || !nd;
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);

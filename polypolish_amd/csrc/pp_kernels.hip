@@ -240,7 +240,8 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     const uint64_t n = b->n_aln;
     if (n0 + n >= 0xFFFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one polish job");
     if (s0 + b->seq_bytes >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "more than 2^40 SEQ bytes in one polish job");
-    const hipMemcpyKind kind = mem == PP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // PP_MEM_PEER: the source is on another GPU of this process -- the runtime picks the route (xGMI peer copy)
+    const hipMemcpyKind kind = mem == PP_MEM_DEVICE ? hipMemcpyDeviceToDevice : (mem == PP_MEM_PEER ? hipMemcpyDefault : hipMemcpyHostToDevice);
     const void *src[9] = {b->contig, b->ref_start, b->k, b->seq_off, b->seq_len, b->cig_off, b->n_cig, b->seq, b->cigar};
     const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
     const uint64_t old_cnt[9] = {n0, n0, n0, n0, n0, n0, n0, s0, c0};
@@ -255,7 +256,7 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     if (n && (s0 || c0))
         hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64 *)ctx->b_in[3].p + n0,
                            (u64 *)ctx->b_in[5].p + n0, (u64)n, (u64)s0, (u64)c0);
-    if (mem != PP_MEM_DEVICE) PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are only borrowed for the call
+    if (mem != PP_MEM_DEVICE) PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host / peer buffers are only borrowed for the call
     ctx->acc_n = n0 + n; ctx->acc_seq = s0 + b->seq_bytes; ctx->acc_cig = c0 + b->n_cig_total;
     pp_aln_batch &d = ctx->dbatch;
     d.n_aln = ctx->acc_n; d.seq_bytes = ctx->acc_seq; d.n_cig_total = ctx->acc_cig;
@@ -274,6 +275,7 @@ extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_add without pp_polish_begin");
     if (!b) return ctx->fail(PP_ERR_ARG, "pp_polish_add: null batch");
+    if (mem != PP_MEM_HOST && mem != PP_MEM_DEVICE && mem != PP_MEM_PEER) return ctx->fail(PP_ERR_ARG, "pp_polish_add: unknown memory kind");
     if (b->n_aln >= 0xFFFFFFFFull)
         return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one batch");
     if (b->n_aln && (!b->contig || !b->ref_start || !b->k || !b->seq_off || !b->seq_len ||
@@ -301,6 +303,7 @@ extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
 static int map_device_error(pp_ctx *ctx, uint64_t key) {
     uint32_t code = (uint32_t)(key & 0xFF);
     unsigned long long idx = (unsigned long long)(key >> 8);
+    ctx->last_dev_error = key;
     switch (code) {
     case DE_UNEXPECTED_OP:
         return ctx->fail(PP_ERR_QUIT, "unexpected character (other than M, =, X, I or D) in CIGAR string "
@@ -571,10 +574,25 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     return PP_OK;
 }
 
+// the record-level device errors of the CIGAR walk, for callers that renumber records (a sharded job's ranks)
+extern "C" int pp_polish_error_record(const pp_ctx *ctx, uint64_t *record, uint32_t *kind) {
+    if (!ctx || ctx->last_dev_error == ~0ull) return 0;
+    const uint32_t code = (uint32_t)(ctx->last_dev_error & 0xFF);
+    if (code < DE_UNEXPECTED_OP || code > DE_BAD_ENDS) return 0;  // not about one alignment record
+    if (record) *record = ctx->last_dev_error >> 8;
+    if (kind) *kind = code;
+    return 1;
+}
+extern "C" int pp_polish_error_text(pp_ctx *ctx, uint32_t kind, uint64_t record) {
+    if (!ctx || kind < DE_UNEXPECTED_OP || kind > DE_BAD_ENDS) return PP_ERR_ARG;
+    return map_device_error(ctx, (record << 8) | kind);
+}
+
 extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (!ctx) return PP_ERR_ARG;
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_finish without pp_polish_begin");
+    ctx->last_dev_error = ~0ull;
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t n = ctx->have_batch ? ctx->dbatch.n_aln : 0;
     const uint64_t G = ctx->G;
@@ -831,6 +849,23 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     delete ctx;
 }
 
+// Several contexts of one process on different GPUs (pp_polish_files_multi): let every GPU reach the others' memory
+// directly, so that the records travel GPU to GPU over xGMI (PP_MEM_PEER copies); best effort -- without peer access the
+// runtime stages such a copy through the host.
+extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n) {
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || pp_ctx_wait(ctxs[i]) != PP_OK) continue;
+        for (int j = 0; j < n; j++) {
+            if (!ctxs[j] || ctxs[j]->device == ctxs[i]->device || pp_ctx_wait(ctxs[j]) != PP_OK) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ctxs[i]->device, ctxs[j]->device) != hipSuccess || !can) continue;
+            if (hipSetDevice(ctxs[i]->device) != hipSuccess) continue;
+            (void)hipDeviceEnablePeerAccess(ctxs[j]->device, 0);  // "already enabled" is fine
+        }
+    }
+    (void)hipGetLastError();
+}
+
 extern "C" int pp_ctx_set_error_(pp_ctx *ctx, int code, const char *msg) {
     if (ctx) ctx->err = msg ? msg : "";
     return code;
@@ -846,6 +881,7 @@ extern "C" int pp_ctx_download(pp_ctx *ctx, void *host_dst, const void *dev_src,
     if (!ctx || (bytes && (!host_dst || !dev_src))) return PP_ERR_ARG;
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!bytes) return PP_OK;
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     PP_HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PP_OK;

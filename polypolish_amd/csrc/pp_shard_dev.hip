@@ -1,0 +1,355 @@
+// pp_shard_dev.hip -- pp_shard_split / pp_shard_count: the RECORDS of a sharded polish job go where they are needed.
+//
+// A position's pileup only ever sees the alignments of its own contig that cover it (src/alignment.rs:297-303 picks the
+// pileup by RNAME, src/pileup.rs:189-200 indexes it by ref_start + j), so a rank that polishes some contigs -- or one
+// window of a large contig -- needs only the records that reach them ("each rank receives only its
+// contigs' bases and alignment records"; "a record is sent to every window it overlaps").  pp_shard_split picks those
+// records out of a batch in file order, for one destination rank of a pp_shard_plan:
+//   * span of a record = the sum of its M / = / X / D / N run lengths (what get_ref_end adds up, src/alignment.rs:
+//     138-149), at least 1: a generous bound of the positions it can touch (the homopolymer trim only shortens it);
+//   * the record goes to the rank of EVERY unit its [ref_start, ref_start + span) touches -- a read across a window
+//     boundary goes to both neighbours, each of which emits only its own positions (pp_polish_set_emit), so an owned
+//     position still sees all of its alignments, in file order, and the order-dependent f64 depth stays exact;
+//   * a record that touches no unit (contig index out of range, start beyond the contig's end) goes to ONE fixed rank,
+//     which reports it: whatever is wrong with a record is found by somebody.
+// The part keeps orig[i] = index of its record i in the source batch, so that a rank-local record number in a device
+// error can be turned back into the job's (the first bad record of the job is the minimum over the ranks).
+// Device batches are split by kernels on the context's stream (flag, three scans, gather of the SoA, the SEQ bytes
+// and the CIGAR runs); host batches by a plain loop.  No reference counterpart: the reference is one thread.
+#include "pp_devtext.h"
+
+#include <cstring>
+#include <vector>
+
+struct pp_shard_part {
+    pp_ctx *ctx = nullptr;
+    int mem = PP_MEM_HOST;
+    pp::DevBuf d[9], d_orig;  // contig ref_start k seq_off seq_len cig_off n_cig seq cigar
+    std::vector<uint32_t> h_contig, h_ref_start, h_k, h_seq_len, h_n_cig, h_cigar, h_orig;
+    std::vector<uint64_t> h_seq_off, h_cig_off;
+    std::vector<uint8_t> h_seq;
+    pp_aln_batch view{};
+    const uint32_t *orig = nullptr;
+};
+
+namespace {
+
+struct UnitTable {       // the plan, per contig: units [first[c], first[c + 1]), in position order
+    const u32 *first;    // n_contigs + 1
+    const u32 *lo, *hi;  // [lo, hi) of the contig
+    const u32 *rank;
+    u32 n_contigs, fallback;
+};
+
+__host__ __device__ inline bool ref_consuming(u32 op) {
+    return op == PP_OP_M || op == PP_OP_EQ || op == PP_OP_X || op == PP_OP_D || op == PP_OP_N;
+}
+
+// does record (c, rs, span) go to `dest`?
+__host__ __device__ inline bool goes_to(const UnitTable &T, u32 c, u64 rs, u64 span, u32 dest) {
+    if (c >= T.n_contigs) return dest == T.fallback;
+    bool hit = false, mine = false;
+    for (u32 u = T.first[c]; u < T.first[c + 1]; u++)
+        if (rs < (u64)T.hi[u] && rs + span > (u64)T.lo[u]) {
+            hit = true;
+            mine |= T.rank[u] == dest;
+        }
+    if (!hit) return T.first[c + 1] > T.first[c] ? T.rank[T.first[c + 1] - 1] == dest : dest == T.fallback;
+    return mine;
+}
+
+__global__ __launch_bounds__(256) void k_split_flag(u64 n, const u32 *__restrict__ contig, const u32 *__restrict__ ref_start,
+                                                    const u32 *__restrict__ seq_len, const u64 *__restrict__ cig_off,
+                                                    const u32 *__restrict__ n_cig, const u32 *__restrict__ cigar, UnitTable T,
+                                                    u32 dest, u32 *__restrict__ flag, u32 *__restrict__ sel_seq,
+                                                    u32 *__restrict__ sel_cig) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 nr = n_cig[i];
+    const u32 *cg = cigar + cig_off[i];
+    u64 span = 0;
+    for (u32 r = 0; r < nr; r++) {
+        const u32 op = cg[r];
+        if (ref_consuming(op & 15u)) span += op >> 4;
+    }
+    if (span == 0) span = 1;
+    const bool sel = goes_to(T, contig[i], ref_start[i], span, dest);
+    flag[i] = sel ? 1u : 0u;
+    sel_seq[i] = sel ? seq_len[i] : 0u;
+    sel_cig[i] = sel ? nr : 0u;
+}
+
+struct SplitOut {
+    u32 *contig, *ref_start, *k, *seq_len, *n_cig, *cigar, *orig;
+    u64 *seq_off, *cig_off;
+    u8 *seq;
+};
+
+__global__ __launch_bounds__(256) void k_split_meta(u64 n, const u32 *__restrict__ contig, const u32 *__restrict__ ref_start,
+                                                    const u32 *__restrict__ kk, const u32 *__restrict__ seq_len,
+                                                    const u32 *__restrict__ n_cig, const u32 *__restrict__ flag,
+                                                    const u32 *__restrict__ out_idx, const u64 *__restrict__ seq_scan,
+                                                    const u64 *__restrict__ cig_scan, SplitOut O) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const u32 o = out_idx[i];
+    O.contig[o] = contig[i];
+    O.ref_start[o] = ref_start[i];
+    O.k[o] = kk[i];
+    O.seq_len[o] = seq_len[i];
+    O.n_cig[o] = n_cig[i];
+    O.seq_off[o] = seq_scan[i];
+    O.cig_off[o] = cig_scan[i];
+    O.orig[o] = (u32)i;
+}
+
+// SEQ bytes: eight lanes per selected record, 16 bytes per lane and trip (gfx950 global accesses need no alignment)
+__global__ __launch_bounds__(256) void k_split_seq(u64 n, const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
+                                                   const u8 *__restrict__ seq, const u32 *__restrict__ flag,
+                                                   const u64 *__restrict__ seq_scan, u8 *__restrict__ out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 3;
+    const u32 s = (u32)(t & 7u);
+    if (i >= n || !flag[i]) return;
+    const u8 *in = seq + seq_off[i];
+    u8 *o = out + seq_scan[i];
+    const u32 len = seq_len[i], whole = len & ~15u;
+    for (u32 b = 16u * s; b < whole; b += 128u) {
+        uint4 v;
+        __builtin_memcpy(&v, in + b, 16);
+        __builtin_memcpy(o + b, &v, 16);
+    }
+    for (u32 b = whole + s; b < len; b += 8) o[b] = in[b];
+}
+
+__global__ __launch_bounds__(256) void k_split_cigar(u64 n, const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
+                                                     const u32 *__restrict__ cigar, const u32 *__restrict__ flag,
+                                                     const u64 *__restrict__ cig_scan, u32 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const u32 *in = cigar + cig_off[i];
+    u32 *o = out + cig_scan[i];
+    const u32 nr = n_cig[i];
+    for (u32 r = 0; r < nr; r++) o[r] = in[r];
+}
+
+// alignment records per contig: per-block LDS histogram while the contigs fit, global atomics beyond
+constexpr u32 HIST_LDS = 8192;
+__global__ __launch_bounds__(1024) void k_contig_hist(u64 n, const u32 *__restrict__ contig, u32 n_contigs,
+                                                      u64 *__restrict__ counts) {
+    __shared__ u32 h[HIST_LDS];
+    const bool lds = n_contigs <= HIST_LDS;
+    if (lds)
+        for (u32 c = threadIdx.x; c < n_contigs; c += blockDim.x) h[c] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 c = contig[i];
+        if (c >= n_contigs) continue;
+        if (lds) atomicAdd(&h[c], 1u); else atomicAdd(&counts[c], 1ull);
+    }
+    __syncthreads();
+    if (lds)
+        for (u32 c = threadIdx.x; c < n_contigs; c += blockDim.x)
+            if (h[c]) atomicAdd(&counts[c], (u64)h[c]);
+}
+
+// the plan as per-contig unit lists (units come contig by contig, windows in position order)
+struct HostUnits {
+    std::vector<u32> first, lo, hi, rank;
+    u32 fallback = 0;
+    bool build(const pp_shard_plan *p) {
+        first.assign((size_t)p->n_contigs + 1, 0);
+        lo.resize(p->n_units); hi.resize(p->n_units); rank.resize(p->n_units);
+        u32 prev = 0;
+        for (u32 u = 0; u < p->n_units; u++) {
+            if (p->contig[u] >= p->n_contigs || p->contig[u] < prev || p->hi[u] > 0xFFFFFFFFull || p->rank[u] >= p->world) return false;
+            prev = p->contig[u];
+            first[p->contig[u] + 1]++;
+            lo[u] = (u32)p->lo[u]; hi[u] = (u32)p->hi[u]; rank[u] = p->rank[u];
+        }
+        for (u32 c = 0; c < p->n_contigs; c++) first[c + 1] += first[c];
+        fallback = p->n_units ? p->rank[p->n_units - 1] : 0;
+        return true;
+    }
+    UnitTable table(u32 n_contigs) const { return UnitTable{first.data(), lo.data(), hi.data(), rank.data(), n_contigs, fallback}; }
+};
+
+void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_total) {
+    pp_aln_batch &v = P->view;
+    v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
+    if (P->mem == PP_MEM_DEVICE) {
+        v.contig = (const u32 *)P->d[0].p; v.ref_start = (const u32 *)P->d[1].p; v.k = (const u32 *)P->d[2].p;
+        v.seq_off = (const uint64_t *)P->d[3].p; v.seq_len = (const u32 *)P->d[4].p; v.cig_off = (const uint64_t *)P->d[5].p;
+        v.n_cig = (const u32 *)P->d[6].p; v.seq = (const u8 *)P->d[7].p; v.cigar = (const u32 *)P->d[8].p;
+        P->orig = (const u32 *)P->d_orig.p;
+    } else {
+        v.contig = P->h_contig.data(); v.ref_start = P->h_ref_start.data(); v.k = P->h_k.data(); v.seq_off = P->h_seq_off.data();
+        v.seq_len = P->h_seq_len.data(); v.cig_off = P->h_cig_off.data(); v.n_cig = P->h_n_cig.data(); v.seq = P->h_seq.data();
+        v.cigar = P->h_cigar.data();
+        P->orig = P->h_orig.data();
+    }
+}
+
+bool batch_ok(const pp_aln_batch *b) {
+    return b && (b->n_aln == 0 || (b->contig && b->ref_start && b->k && b->seq_off && b->seq_len && b->cig_off && b->n_cig &&
+                                  b->seq && b->cigar));
+}
+
+int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B) {
+    const UnitTable T = U.table(n_contigs);
+    const uint64_t n = B->n_aln;
+    uint64_t seq_total = 0, cig_total = 0, cnt = 0;
+    std::vector<uint8_t> sel((size_t)n);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t span = 0;
+        const u32 *cg = B->cigar + B->cig_off[i];
+        for (u32 r = 0; r < B->n_cig[i]; r++)
+            if (ref_consuming(cg[r] & 15u)) span += cg[r] >> 4;
+        if (span == 0) span = 1;
+        sel[i] = goes_to(T, B->contig[i], B->ref_start[i], span, dest);
+        if (sel[i]) { cnt++; seq_total += B->seq_len[i]; cig_total += B->n_cig[i]; }
+    }
+    P->h_contig.reserve(cnt); P->h_ref_start.reserve(cnt); P->h_k.reserve(cnt); P->h_seq_len.reserve(cnt); P->h_n_cig.reserve(cnt);
+    P->h_orig.reserve(cnt); P->h_seq_off.reserve(cnt); P->h_cig_off.reserve(cnt);
+    P->h_seq.resize(seq_total + 64); P->h_cigar.resize(cig_total + 1);
+    uint64_t so = 0, co = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (!sel[i]) continue;
+        P->h_contig.push_back(B->contig[i]); P->h_ref_start.push_back(B->ref_start[i]); P->h_k.push_back(B->k[i]);
+        P->h_seq_len.push_back(B->seq_len[i]); P->h_n_cig.push_back(B->n_cig[i]); P->h_orig.push_back((u32)i);
+        P->h_seq_off.push_back(so); P->h_cig_off.push_back(co);
+        memcpy(P->h_seq.data() + so, B->seq + B->seq_off[i], B->seq_len[i]);
+        memcpy(P->h_cigar.data() + co, B->cigar + B->cig_off[i], (size_t)B->n_cig[i] * 4);
+        so += B->seq_len[i]; co += B->n_cig[i];
+    }
+    set_view(P, cnt, seq_total, cig_total);
+    return PP_OK;
+}
+
+int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B) {
+    pp_ctx *ctx = P->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = B->n_aln;
+    if (n == 0) { set_view(P, 0, 0, 0); return PP_OK; }
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    // the unit table on the device (a few hundred bytes), and the scratch of this call
+    pp::DevBuf t_first, t_units, flag, sel_seq, sel_cig, out_idx, seq_scan, cig_scan, sums, sums_off;
+    pp::DevBuf *scratch[] = {&t_first, &t_units, &flag, &sel_seq, &sel_cig, &out_idx, &seq_scan, &cig_scan, &sums, &sums_off};
+    auto done = [&](int r) { (void)hipStreamSynchronize(st); for (pp::DevBuf *b : scratch) pp::dev_free(*b); return r; };
+    const size_t nu = U.lo.size();
+    if ((rc = pp::dev_ensure(ctx, t_first, ((size_t)n_contigs + 1) * 4)) || (rc = pp::dev_ensure(ctx, t_units, (nu ? nu : 1) * 12)) ||
+        (rc = pp::dev_ensure(ctx, flag, n * 4)) || (rc = pp::dev_ensure(ctx, sel_seq, n * 4)) || (rc = pp::dev_ensure(ctx, sel_cig, n * 4)) ||
+        (rc = pp::dev_ensure(ctx, out_idx, (n + 1) * 4)) || (rc = pp::dev_ensure(ctx, seq_scan, (n + 1) * 8)) ||
+        (rc = pp::dev_ensure(ctx, cig_scan, (n + 1) * 8)))
+        return done(rc);
+    u32 *d_units = (u32 *)t_units.p;
+    if (hipMemcpyAsync(t_first.p, U.first.data(), ((size_t)n_contigs + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        (nu && (hipMemcpyAsync(d_units, U.lo.data(), nu * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_units + nu, U.hi.data(), nu * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_units + 2 * nu, U.rank.data(), nu * 4, hipMemcpyHostToDevice, st) != hipSuccess)))
+        return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: uploading the plan failed"));
+    const UnitTable T{(const u32 *)t_first.p, d_units, d_units + nu, d_units + 2 * nu, n_contigs, U.fallback};
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_split_flag, dim3(blocks), dim3(256), 0, st, (u64)n, B->contig, B->ref_start, B->seq_len,
+                       (const u64 *)B->cig_off, B->n_cig, B->cigar, T, dest, (u32 *)flag.p, (u32 *)sel_seq.p, (u32 *)sel_cig.p);
+    if ((rc = scan_u32<u32>(ctx, sums, sums_off, (const u32 *)flag.p, (u64)n, (u32 *)out_idx.p)) ||
+        (rc = scan_u32<u64>(ctx, sums, sums_off, (const u32 *)sel_seq.p, (u64)n, (u64 *)seq_scan.p)) ||
+        (rc = scan_u32<u64>(ctx, sums, sums_off, (const u32 *)sel_cig.p, (u64)n, (u64 *)cig_scan.p)))
+        return done(rc);
+    u32 cnt = 0;
+    u64 seq_total = 0, cig_total = 0;
+    if ((rc = fetch(ctx, (const u32 *)out_idx.p + n, &cnt)) || (rc = fetch(ctx, (const u64 *)seq_scan.p + n, &seq_total)) ||
+        (rc = fetch(ctx, (const u64 *)cig_scan.p + n, &cig_total)))
+        return done(rc);
+    const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
+    const uint64_t ecnt[9] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total};
+    for (int a = 0; a < 9; a++)
+        if ((rc = pp::dev_ensure(ctx, P->d[a], (size_t)ecnt[a] * esz[a]))) return done(rc);
+    if ((rc = pp::dev_ensure(ctx, P->d_orig, (size_t)cnt * 4))) return done(rc);
+    SplitOut O{(u32 *)P->d[0].p, (u32 *)P->d[1].p, (u32 *)P->d[2].p, (u32 *)P->d[4].p, (u32 *)P->d[6].p, (u32 *)P->d[8].p,
+               (u32 *)P->d_orig.p, (u64 *)P->d[3].p, (u64 *)P->d[5].p, (u8 *)P->d[7].p};
+    if (cnt) {
+        hipLaunchKernelGGL(k_split_meta, dim3(blocks), dim3(256), 0, st, (u64)n, B->contig, B->ref_start, B->k, B->seq_len,
+                           B->n_cig, (const u32 *)flag.p, (const u32 *)out_idx.p, (const u64 *)seq_scan.p,
+                           (const u64 *)cig_scan.p, O);
+        hipLaunchKernelGGL(k_split_seq, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, (u64)n, (const u64 *)B->seq_off,
+                           B->seq_len, B->seq, (const u32 *)flag.p, (const u64 *)seq_scan.p, O.seq);
+        hipLaunchKernelGGL(k_split_cigar, dim3(blocks), dim3(256), 0, st, (u64)n, (const u64 *)B->cig_off, B->n_cig, B->cigar,
+                           (const u32 *)flag.p, (const u64 *)cig_scan.p, O.cigar);
+        if (hipMemsetAsync(O.seq + seq_total, 0, 64, st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: memset failed"));
+    }
+    if (hipGetLastError() != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: a kernel launch failed"));
+    set_view(P, cnt, seq_total, cig_total);
+    return done(PP_OK);  // synchronises: the part is complete when the call returns
+}
+
+}  // namespace
+
+extern "C" int pp_shard_split(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
+                              pp_shard_part **out) {
+    if (!out) return PP_ERR_ARG;
+    *out = nullptr;
+    if (!plan || dest >= plan->world || !batch_ok(batch) || (mem != PP_MEM_HOST && mem != PP_MEM_DEVICE)) return PP_ERR_ARG;
+    if (mem == PP_MEM_DEVICE) {
+        if (!ctx) return PP_ERR_ARG;
+        if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    }
+    if (batch->n_aln >= 0xFFFFFFFFull) return ctx ? ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one batch") : PP_ERR_LIMIT;
+    HostUnits U;
+    if (!U.build(plan)) return ctx ? ctx->fail(PP_ERR_ARG, "pp_shard_split: the plan's units are not listed contig by contig") : PP_ERR_ARG;
+    pp_shard_part *P = new pp_shard_part();
+    P->ctx = ctx;
+    P->mem = mem;
+    const int rc = mem == PP_MEM_DEVICE ? split_device(P, U, plan->n_contigs, dest, batch) : split_host(P, U, plan->n_contigs, dest, batch);
+    if (rc) { pp_shard_part_free(P); return rc; }
+    *out = P;
+    return PP_OK;
+}
+
+extern "C" int pp_shard_part_mem(const pp_shard_part *part) { return part ? part->mem : PP_MEM_HOST; }
+
+extern "C" void pp_shard_part_batch(const pp_shard_part *part, pp_aln_batch *out, const uint32_t **orig) {
+    if (!part) return;
+    if (out) *out = part->view;
+    if (orig) *orig = part->orig;
+}
+
+extern "C" void pp_shard_part_free(pp_shard_part *P) {
+    if (!P) return;
+    if (P->mem == PP_MEM_DEVICE && P->ctx) {
+        (void)hipSetDevice(P->ctx->device);
+        (void)hipStreamSynchronize(P->ctx->stream);
+        for (auto &b : P->d) pp::dev_free(b);
+        pp::dev_free(P->d_orig);
+    }
+    delete P;
+}
+
+// alignment records per contig (the planner's weights), ADDED to aln_per_contig (HOST, n_contigs)
+extern "C" int pp_shard_count(pp_ctx *ctx, const pp_aln_batch *batch, int mem, uint32_t n_contigs, uint64_t *aln_per_contig) {
+    if (!batch_ok(batch) || !aln_per_contig || n_contigs == 0) return PP_ERR_ARG;
+    if (mem == PP_MEM_HOST) {
+        for (uint64_t i = 0; i < batch->n_aln; i++)
+            if (batch->contig[i] < n_contigs) aln_per_contig[batch->contig[i]]++;
+        return PP_OK;
+    }
+    if (!ctx || mem != PP_MEM_DEVICE) return PP_ERR_ARG;
+    if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    if (batch->n_aln == 0) return PP_OK;
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    pp::DevBuf d_cnt;
+    if (int rc = pp::dev_ensure(ctx, d_cnt, (size_t)n_contigs * 8)) return rc;
+    std::vector<uint64_t> h(n_contigs);
+    int rc = PP_OK;
+    if (hipMemsetAsync(d_cnt.p, 0, (size_t)n_contigs * 8, ctx->stream) != hipSuccess) rc = ctx->fail(PP_ERR_HIP, "pp_shard_count: memset failed");
+    if (!rc) {
+        const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (batch->n_aln + 1023) / 1024);
+        hipLaunchKernelGGL(k_contig_hist, dim3(blocks), dim3(1024), 0, ctx->stream, (u64)batch->n_aln, batch->contig, n_contigs,
+                           (u64 *)d_cnt.p);
+        rc = fetch(ctx, (const uint64_t *)d_cnt.p, h.data(), n_contigs);
+    }
+    pp::dev_free(d_cnt);
+    if (rc) return rc;
+    for (uint32_t c = 0; c < n_contigs; c++) aln_per_contig[c] += h[c];
+    return PP_OK;
+}

@@ -375,6 +375,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
     if (!ctx || !a || !out) return PP_ERR_ARG;
     *out = nullptr;
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));  // (the device is a per-thread setting: the multi-GPU driver calls from worker threads)
     pp_dev_ingest *D = new pp_dev_ingest();
     D->ctx = ctx;
     D->asmb = a;
@@ -492,17 +493,41 @@ extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_coun
     return pp_dev_ingest_sam_filtered(D, path, nullptr, 0, counts);
 }
 
+static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64 size, bool slice, const uint8_t *pass,
+                       uint64_t n_pass, pp_sam_counts *counts);
+
 extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, const uint8_t *pass, uint64_t n_pass,
                                           pp_sam_counts *counts) {
     if (!D || !path) return PP_ERR_ARG;
     pp_ctx *ctx = D->ctx;
-    hipStream_t st = ctx->stream;
     pp_sam_counts c{0, 0, 0};
     if (counts) *counts = c;
     pph::FileText F;
     if (!F.open_file(path)) return ctx->fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
-    const u64 size = F.size;
+    return ingest_text(D, path, F.text, F.size, false, pass, n_pass, counts);
+}
+
+// One SLICE of a SAM file -- a byte range that starts and ends on read-group boundaries (src/alignment.rs:255-263: a
+// group is a run of adjacent aligned lines with one QNAME), cut by the multi-GPU driver so that every GPU uploads and
+// tokenizes its own part of the text.  The records are appended to the batch like a file's.  A slice without aligned
+// records is fine (the driver looks at the file's total); any defect in the text only says so (PP_ERR_QUIT): line
+// numbers and the order of two defects are a whole-file matter, the driver then takes the file through the host parsers.
+extern "C" int pp_dev_ingest_slice_(pp_dev_ingest *D, const char *path, const char *text, uint64_t size, pp_sam_counts *counts) {
+    if (!D || !path || (size && !text)) return PP_ERR_ARG;
+    pp_sam_counts c{0, 0, 0};
+    if (counts) *counts = c;
+    if (size == 0) return PP_OK;
+    return ingest_text(D, path, text, size, true, nullptr, 0, counts);
+}
+
+static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64 size, bool slice, const uint8_t *pass,
+                       uint64_t n_pass, pp_sam_counts *counts) {
+    pp_ctx *ctx = D->ctx;
+    hipStream_t st = ctx->stream;
+    pp_sam_counts c{0, 0, 0};
+    struct { const char *text; } F{text};
     if (size >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "\"%s\" is larger than the 1 TiB this tokenizer indexes", path);
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
     const bool timing = getenv("PP_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -609,12 +634,16 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
         if (n_aln && (rc = fetch(ctx, (const u32 *)D->d_recline.p, rec_line.data(), n_aln))) return rc;
         if (n_aln && (rc = fetch(ctx, (const u32 *)D->d_gfirst.p, group_first.data(), (size_t)n_groups + 1))) return rc;
         if (counts) *counts = c;
+        if (slice) return ctx->fail(PP_ERR_QUIT, "a defect in the text of \"%s\" (event %llu of a slice): left to the host ingest", path,
+                                    (unsigned long long)status);
         return describe_error(D, path, F.text, size, status, n_lines, n_nl, rec_line, group_first);
     }
     if (pass_mismatch)
         return ctx->fail(PP_ERR_ARG, "%llu filter verdicts for the %u aligned records of \"%s\"", (unsigned long long)n_pass, n_aln, path);
-    if (n_aln == 0)  // the EOF flush of an empty group (alignment.rs:268, :319)
+    if (n_aln == 0) {  // the EOF flush of an empty group (alignment.rs:268, :319) -- of a FILE: a slice may well be empty
+        if (slice) { if (counts) *counts = c; return PP_OK; }
         return ctx->fail(PP_ERR_PANIC, "no aligned records to process (the reference panics on an empty read group)");
+    }
     u32 n_good = 0;
     u64 seq_total = 0, cig_total = 0;
     if ((rc = fetch(ctx, (const u32 *)D->d_outidx.p + n_aln, &n_good))) return rc;

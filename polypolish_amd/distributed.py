@@ -6,11 +6,13 @@ Everything that decides or moves data is in libpolypolish_hip.so (include/polypo
   pp_shard_plan_create   whole contigs by longest-processing-time on their alignment counts; a contig that carries
                          more than one rank's share (config C5: one 250 Mbp contig) is cut into windows on 2048-bp
                          boundaries, one per rank
-  pp_polish_set_emit     a rank polishes with the FULL alignment batch and the ranges of its units: k_prep drops the
-                         records that do not reach them, k_tile skips the windows outside them.  Every owned position
-                         sees all of its alignments in file order, so the order-dependent f64 depth stays exact
-                         (src/pileup.rs:64), and the read group's share 1/k (src/alignment.rs:288) was fixed by the
-                         ingest before anything was partitioned
+  pp_shard_split         the records that reach a rank's units: its contigs' records, on a tiled contig its window's
+                         records plus those that reach in from the neighbours (an alignment only touches its own
+                         contig's positions ref_start + j: src/alignment.rs:297-303, src/pileup.rs:189-200)
+  pp_polish_set_emit     a rank polishes those records with the ranges of its units: the device works on its windows
+                         only.  Every owned position sees all of its alignments in file order, so the order-dependent
+                         f64 depth stays exact (src/pileup.rs:64), and the read group's share 1/k
+                         (src/alignment.rs:288) was fixed by the ingest before anything was partitioned
   pp_polish_gather       ncclAllGather of byte counts + one group of ncclSend / ncclRecv into rank 0 (RCCL over xGMI)
   pp_shard_assemble      the ranks' bytes back in FASTA order
 
@@ -36,17 +38,40 @@ def gather_objects(polished: bytes, offs, rank: int, world: int):
     return [g[0] for g in got], [g[1] for g in got]
 
 
-def polish_sharded(engine, names, descs, contig_off, bases, recs, rank, world, gather=None, min_window=0, **params):
-    """Sharded polish.  `engine(contig_off, bases, recs, emit=..., **params)` polishes the whole job restricted to
-    the emit ranges and returns {"polished": bytes, "offsets": array} (Context.polish_records on a GPU; the oracle in
-    the CPU tests).  `gather(polished, offsets)` collects every rank's result on rank 0 (default: gloo objects).
-    Rank 0 returns the FASTA text of the whole assembly (src/polish.rs:196-203), other ranks None."""
+def polish_sharded(engine, names, descs, contig_off, bases, recs, rank, world, gather=None, min_window=0, locate=None,
+                   **params):
+    """Sharded polish.  `engine(contig_off, bases, recs, emit=..., **params)` polishes the records it is given restricted
+    to the emit ranges and returns {"polished": bytes, "offsets": array} (Context.polish_records on a GPU; the oracle in
+    the CPU tests).  A rank gives it only the records that reach its units (pp_shard_split).  `gather(polished, offsets)`
+    collects every rank's result on rank 0 (default: gloo objects).  `locate(exc)` (optional) returns the rank-local
+    number of the record an engine failure is about: the ranks then agree on the job's FIRST bad record (the reference
+    streams, so that is the one it reports) and all of them raise.  Rank 0 returns the FASTA text of the whole assembly
+    (src/polish.rs:196-203), other ranks None."""
     import polypolish_amd as pp
     contig_off = np.asarray(contig_off, dtype=np.uint64)
     n_contigs = len(contig_off) - 1
     counts = np.bincount(np.asarray(recs["contig"], dtype=np.int64), minlength=n_contigs)[:n_contigs]
     plan = pp.Plan(contig_off, counts, world, min_window)
-    res = engine(contig_off, bases, recs, emit=plan.emit_ranges(rank), **params)
+    mine, orig = pp.shard_split_host(plan, rank, recs)
+    res, failure = None, None
+    try:
+        res = engine(contig_off, bases, mine, emit=plan.emit_ranges(rank), **params)
+    except Exception as e:  # noqa: BLE001 -- whatever the engine raises travels to every rank
+        local = locate(e) if locate else None
+        failure = (int(orig[local]) if local is not None and local < len(orig) else -1, e)
+    if world > 1:
+        import torch.distributed as dist
+        seen = [None] * world
+        dist.all_gather_object(seen, None if failure is None else (failure[0], type(failure[1]).__name__, str(failure[1]),
+                                                                   getattr(failure[1], "code", 1)))
+        bad = [(s[0], r, s) for r, s in enumerate(seen) if s is not None]
+        if bad:
+            _, r, s = min(bad)
+            if failure is not None and r == rank:
+                raise failure[1]
+            raise pp.PolypolishError(s[3], s[2])
+    elif failure is not None:
+        raise failure[1]
     if gather is None:
         gather = lambda b, o: gather_objects(b, o, rank, world)  # noqa: E731
     all_bytes, all_offs = gather(res["polished"], res["offsets"])
@@ -71,6 +96,7 @@ def main(argv=None):
     to rank 0 over RCCL and rank 0 prints the FASTA.  PP_SHARE_GPU=1 (testing on a one-GPU box): all ranks use GPU 0
     and the bytes travel over gloo."""
     import argparse
+    import ctypes as C
     import os
     import sys
     import torch
@@ -118,7 +144,10 @@ def main(argv=None):
                 host = buf.cpu().numpy()
                 starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
                 return [host[int(starts[r]):int(starts[r + 1])].tobytes() for r in range(world)], list(offs_all)
-        out = polish_sharded(ctx.polish_records, names, descs, off, bases, recs, rank, world, gather=gather,
+        def locate(exc):  # the rank-local record a device error of the CIGAR walk is about
+            rec, kind = C.c_uint64(), C.c_uint32()
+            return int(rec.value) if pp.lib().pp_polish_error_record(ctx._h, C.byref(rec), C.byref(kind)) else None
+        out = polish_sharded(ctx.polish_records, names, descs, off, bases, recs, rank, world, gather=gather, locate=locate,
                              min_depth=a.min_depth, fraction_valid=a.fraction_valid, fraction_invalid=a.fraction_invalid)
     except pp.PolypolishError as e:
         sys.stderr.write(f"\nError: {e.msg}\n")

@@ -2,7 +2,8 @@
 with the oracle standing in for the per-rank device engine (test only), and rank 0's assembled FASTA must equal the
 unsharded oracle output byte for byte.  The partition is the PRODUCT's (pp_shard_plan_create / pp_shard_emit_ranges /
 pp_shard_assemble in libpolypolish_hip.so, no GPU needed for those): whole contigs by longest-processing-time, a
-dominant contig cut into one window per rank; every rank gets the FULL record set and its emit ranges."""
+dominant contig cut into one window per rank; a rank is handed ONLY the records that reach its units (pp_shard_split:
+its contigs' records, plus -- on the tiled contig -- those that reach into its window) and its emit ranges."""
 import os
 import sys
 
@@ -111,3 +112,72 @@ def test_assignment_is_balanced_and_assembly_restores_the_order():
         data, out_off = plan.assemble(rank_bytes, rank_offs)
         assert data == b"".join(marks)
         assert [int(x) for x in out_off] == [0] + list(np.cumsum([len(m) for m in marks]))
+
+
+def _ref_span(recs, i):
+    co, nc = int(recs["cig_off"][i]), int(recs["n_cig"][i])
+    ops = recs["cigar"][co:co + nc]
+    return max(1, int(sum(int(o) >> 4 for o in ops if (int(o) & 15) in (0, 2, 3, 7, 8))))
+
+
+def _split_reference(plan, dest, contig_off, recs):
+    """The routing rule in plain Python: a record goes to the rank of every unit its [ref_start, ref_start + span) touches."""
+    keep = []
+    nc = len(contig_off) - 1
+    last_rank = int(plan.unit_rank[-1])
+    for i in range(len(recs["contig"])):
+        c, rs, span = int(recs["contig"][i]), int(recs["ref_start"][i]), _ref_span(recs, i)
+        if c >= nc:
+            owners = {last_rank}
+        else:
+            us = [u for u in range(len(plan.unit_contig)) if plan.unit_contig[u] == c]
+            owners = {int(plan.unit_rank[u]) for u in us if rs < int(plan.unit_hi[u]) and rs + span > int(plan.unit_lo[u])}
+            if not owners:
+                owners = {int(plan.unit_rank[us[-1]])}
+        if dest in owners:
+            keep.append(i)
+    return np.array(keep, dtype=np.int64)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_split_hands_every_rank_the_records_that_reach_its_units(orc, world):
+    """pp_shard_split on host batches against the rule in plain Python, on a job with whole-contig units AND a tiled contig,
+    reads with indels (D runs lengthen the span), a record with a contig index outside the assembly and one that starts
+    beyond its contig's end (each must still reach exactly one rank, which reports it).  Then the property the partition
+    exists for: the oracle polishing a rank's PART with its emit ranges gives the bytes it gives with ALL records."""
+    contig_off, bases, recs = synth.fast_records(seed=14, contig_lens=(30000, 400, 5000, 2600), coverage=25, read_len=100,
+                                                 k_choices=(1, 2, 3), k_probs=(0.8, 0.1, 0.1), indel_read_frac=0.2)
+    n = len(recs["contig"])
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=4), world, 2048)
+    if world > 1:
+        assert (plan.unit_contig == 0).sum() > 1, "the large contig is tiled"
+    odd = {k: v.copy() for k, v in recs.items()}
+    odd["contig"][7] = 99            # not in the assembly
+    odd["ref_start"][11] = 10 ** 6   # beyond the end of its contig
+    seen = np.zeros(n, dtype=np.int64)
+    for r in range(world):
+        part, orig = pp.shard_split_host(plan, r, odd)
+        want = _split_reference(plan, r, contig_off, odd)
+        assert np.array_equal(orig.astype(np.int64), want), r
+        seen[want] += 1
+        for k in ("contig", "ref_start", "k", "seq_len", "n_cig"):
+            assert np.array_equal(part[k], odd[k][want]), (r, k)
+        so, sl = part["seq_off"].astype(np.int64), part["seq_len"].astype(np.int64)
+        assert np.array_equal(so, np.concatenate([[0], np.cumsum(sl)[:-1]]) if len(sl) else so)
+        for j in (0, len(want) // 2, len(want) - 1) if len(want) else ():
+            i = int(want[j])
+            assert bytes(part["seq"][so[j]:so[j] + sl[j]]) == bytes(odd["seq"][int(odd["seq_off"][i]):int(odd["seq_off"][i]) + int(odd["seq_len"][i])])
+            a, m = int(part["cig_off"][j]), int(part["n_cig"][j])
+            assert np.array_equal(part["cigar"][a:a + m], odd["cigar"][int(odd["cig_off"][i]):int(odd["cig_off"][i]) + m])
+    assert seen.min() >= 1 and seen[7] == 1 and seen[11] == 1
+    if world > 1:
+        assert 1 < seen.max() <= 2 and (seen > 1).mean() < 0.2, "only reads across a window boundary are handed to two ranks"
+        assert seen.sum() < 1.2 * n
+    # the property: a rank's part + its emit ranges == all records + its emit ranges (oracle as the engine)
+    eng = synth.oracle_engine(orc)
+    for r in range(world):
+        part, _ = pp.shard_split_host(plan, r, recs)
+        e = plan.emit_ranges(r)
+        assert eng(contig_off, bases, part, emit=e)["polished"] == eng(contig_off, bases, recs, emit=e)["polished"], r
+    cnt = pp.shard_count(None, n, recs["contig"].ctypes.data, pp.MEM_HOST, 4, {k: v.ctypes.data for k, v in recs.items()})
+    assert np.array_equal(cnt.astype(np.int64), np.bincount(recs["contig"], minlength=4))

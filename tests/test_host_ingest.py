@@ -306,3 +306,71 @@ def test_reference_fasta_vector_through_the_product_loader(tmp_path, gz):
         assert got == gold["records"]
     finally:
         L.pp_assembly_free(a)
+
+
+def test_slices_of_a_sam_file_start_on_read_group_boundaries(tmp_path):
+    """The multi-GPU driver gives every GPU a byte range of each SAM file to upload and tokenize; a cut must not split a
+    read group (src/alignment.rs:255-263: adjacent aligned lines with one QNAME; an aligned line also joins a group whose
+    QNAME is empty; header, empty and unaligned lines neither join nor close a group).  Every cut the driver would make
+    is checked against the grouping of the whole file, and the ingest of the slices, one after the other, gives the
+    records of the whole file (same k per record)."""
+    import ctypes as C
+    import polypolish_amd as pp
+    L = pp.lib()
+    L.pp_sam_group_cut_.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
+    L.pp_sam_group_cut_.restype = C.c_uint64
+    rng = np.random.default_rng(5)
+    lines = ["@HD\tVN:1.6", "@SQ\tSN:c1\tLN:5000"]
+    seq = "ACGT" * 10
+    def rec(name, flag, pos):
+        return f"{name}\t{flag}\tc1\t{pos}\t60\t40M\t*\t0\t0\t{seq if not flag & 256 else '*'}\t{'I' * 40 if not flag & 256 else '*'}\tNM:i:0"
+    r = 0
+    for _ in range(400):
+        kind = rng.integers(0, 10)
+        name = f"read{r}"
+        r += 1
+        if kind < 5:
+            lines.append(rec(name, 0, int(rng.integers(1, 4000))))
+        elif kind < 8:  # an all-hits group, sometimes with an unaligned or empty line in its middle
+            for j in range(int(rng.integers(2, 7))):
+                lines.append(rec(name, 256 if j else 16, int(rng.integers(1, 4000))))
+                if rng.random() < 0.15:
+                    lines.append(rng.choice(["", f"u{r}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*", "@CO\tmid-file comment"]))
+        elif kind == 8:
+            lines.append(f"{name}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*")
+        else:  # an empty QNAME does not close its group: the next record joins it
+            lines.append(rec("", 0, int(rng.integers(1, 4000))))
+            lines.append(rec(name, 0, int(rng.integers(1, 4000))))
+    text = ("\n".join(lines) + "\n").encode()
+    # the grouping of the whole file: start offsets of the lines that open a group
+    starts, prev, p = set(), None, 0
+    for ln in text.split(b"\n")[:-1]:
+        cols = ln.split(b"\t")
+        if ln and not ln.startswith(b"@") and len(cols) > 1 and not int(cols[1]) & 4:
+            if prev is None or (prev != b"" and prev != cols[0]):
+                starts.add(p)
+            prev = cols[0]
+        p += len(ln) + 1
+    cuts = set()
+    for frm in list(range(1, len(text), 97)) + [len(text) - 1, len(text)]:
+        c = int(L.pp_sam_group_cut_(text, len(text), frm))
+        assert c == len(text) or (c >= frm and c in starts), (frm, c)
+        nxt = min([s0 for s0 in starts if s0 >= frm], default=len(text))
+        assert c == nxt, (frm, c, nxt)
+        cuts.add(c)
+    assert len(cuts) > 50
+    # ingest of the slices == ingest of the file
+    fa = tmp_path / "a.fasta"
+    fa.write_text(">c1\n" + "ACGT" * 1250 + "\n")
+    whole = tmp_path / "whole.sam"
+    whole.write_bytes(text)
+    _, _, _, _, want, _ = pp.ingest(str(fa), [str(whole)])
+    edges = [0] + sorted(c for c in cuts if 0 < c < len(text))[::7] + [len(text)]
+    paths = []
+    for i, (a0, b0) in enumerate(zip(edges[:-1], edges[1:])):
+        pth = tmp_path / f"slice{i}.sam"
+        pth.write_bytes(text[a0:b0])
+        paths.append(str(pth))
+    _, _, _, _, got, _ = pp.ingest(str(fa), paths)
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
