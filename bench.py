@@ -89,17 +89,37 @@ from synthjob import make_job, subset_job, algorithmic_bytes, to_host_records, w
 def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
     """One step: begin + add (device-resident, borrowed) + finish.  The arguments of the three C calls are marshalled
     once per job (ctx.prepared_job): a step is then the calls themselves, not tens of microseconds of Python between
-    them while the GPU waits."""
+    them while the GPU waits.  job["part"] (a pp.ShardPart: the records one rank of a sharded job needs) replaces the
+    job's own record arrays."""
+    part = job.get("part")
     key = (id(ctx), params, None if job.get("emit") is None else id(job["emit"]), job["bases"].data_ptr(),
-           job["recs"]["seq"].data_ptr(), job["n_aln"], job["contig_off"].tobytes() if len(job["contig_off"]) < 64 else id(job["contig_off"]))
+           job["recs"]["seq"].data_ptr(), job["n_aln"], id(part),
+           job["contig_off"].tobytes() if len(job["contig_off"]) < 64 else id(job["contig_off"]))
     run = job.setdefault("_prepared", {}).get(key)
     if run is None:
         r = job["recs"]
-        run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, job["n_aln"],
-                               {k: v.data_ptr() for k, v in r.items()}, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
-                               *params, emit=job.get("emit"))
+        if part is not None:
+            run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, part.n_aln, part.ptrs, part.seq_bytes,
+                                   part.n_cig_total, pp.MEM_DEVICE, *params, emit=job.get("emit"))
+        else:
+            run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, job["n_aln"],
+                                   {k: v.data_ptr() for k, v in r.items()}, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
+                                   *params, emit=job.get("emit"))
         job["_prepared"][key] = run
     run()
+
+
+def shard_of(ctx, pp, job, plan, rank):
+    """The job as rank `rank` of the plan sees it: the records that reach its units (pp_shard_split, on the device) and
+    its emit ranges; everything else is shared with `job`."""
+    r = job["recs"]
+    part = pp.ShardPart(ctx, plan, rank, job["n_aln"], {k: v.data_ptr() for k, v in r.items()}, r["seq"].numel(),
+                        r["cigar"].numel(), pp.MEM_DEVICE)
+    mine = dict(job)
+    mine.pop("_prepared", None)
+    mine["part"] = part
+    mine["emit"] = plan.emit_ranges(rank)
+    return mine
 
 
 # ---- the end-to-end leg: SAM text -> FASTA through the drop-in CLI ----------------------------------------
@@ -312,12 +332,13 @@ def main():
         job["recs"]["k"] = torch.where(nd, 3, job["recs"]["k"]).int().contiguous()
     plan = None
     if strong:
-        # ONE job, resident on every rank; a rank polishes with the ranges of its units (pp_shard_plan_create: whole
-        # contigs by longest-processing-time, the single contig in one window per rank) -- the device drops the records
-        # that do not reach them and skips the windows outside them (pp_polish_set_emit)
+        # ONE job; a rank keeps the records that reach its units (pp_shard_plan_create: whole contigs by longest-
+        # processing-time, the single contig in one window per rank; pp_shard_split picks the records, on the device)
+        # and polishes them with the ranges of its units (pp_polish_set_emit)
         counts = torch.bincount(job["recs"]["contig"].long(), minlength=len(lens)).cpu().numpy()
         plan = pp.Plan(job["contig_off"], counts, world)
-        job["emit"] = plan.emit_ranges(rank)
+        whole_job = job
+        job = shard_of(ctx, pp, whole_job, plan, rank)
     torch.cuda.synchronize()
     nc_job = len(job["contig_off"]) - 1
     gdev = "cpu" if share else device
@@ -408,7 +429,7 @@ def main():
                             for r in range(world))
             if strong:
                 whole, _ = plan.assemble(rank_bytes, [np.array(m[2], dtype=np.uint64) for m in meta])
-                full = dict(job)
+                full = dict(whole_job)
                 full["emit"] = None
                 run_job(ctx, pp, full)
                 ref, _, _ = ctx.result()
@@ -427,7 +448,10 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     total_mbp = (G_total if strong else G_all_ranks) / 1e6
     value = total_mbp / (elapsed / args.steps)
-    b_alg = algorithmic_bytes(job) // (world if strong else 1)  # strong scaling: a rank's share of the one job
+    b_alg = algorithmic_bytes(job)
+    if strong:  # this rank's share of the one job: its records, its positions
+        e = job["emit"].astype(np.int64)
+        b_alg = job["part"].n_aln * (job["read_len"] + 16) + 4 * job["part"].n_cig_total + 2 * int((e[:, 1] - e[:, 0]).sum())
     dom_avg_ms = float(np.mean(dom_ms)) if dom_ms else 0.0
     achieved = b_alg / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     peak = 8000.0
@@ -463,7 +487,7 @@ def main():
                                        f"reads aligned to the assembly, {100 * args.indel_frac:g}% with a 1-bp sequencing indel)",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
-                   "alignments_per_gpu": job["n_aln"] // (world if strong else 1)},
+                   "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
                      "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"

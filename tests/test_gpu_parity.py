@@ -1033,6 +1033,57 @@ def test_cli_polishes_on_several_contexts_in_one_process(orc, tmp_path, n_ctx):
         assert stat(multi.stderr) == stat(single.stderr) and len(stat(multi.stderr)) > 12, ingest
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_device_split_equals_host_split(ctx, pp, orc, world):
+    """pp_shard_split on a device batch (kernels: flag, scans, gather of the SoA / SEQ bytes / CIGAR runs) gives the part
+    the host loop gives, array by array incl. orig, on a job with whole-contig units and a tiled contig, indel reads and two
+    records that touch no unit; and polishing a rank's part with its emit ranges gives the bytes of polishing ALL records
+    with them (device engine)."""
+    import ctypes as C
+    import torch
+    contig_off, bases, recs = synth.fast_records(seed=24, contig_lens=(90_000, 700, 12_000, 5_000), coverage=30, read_len=120,
+                                                 k_choices=(1, 2, 3), k_probs=(0.8, 0.1, 0.1), indel_read_frac=0.2)
+    recs = {k: v.copy() for k, v in recs.items()}
+    n = len(recs["contig"])
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=4), world, 4096)
+    odd = {k: v.copy() for k, v in recs.items()}
+    odd["contig"][5] = 77
+    odd["ref_start"][9] = 10 ** 7
+    dev = torch.device("cuda", 0)
+    keep = {k: torch.from_numpy(np.ascontiguousarray(odd[k], dtype=dt).view(np.int64 if dt == np.uint64 else (np.int32 if dt == np.uint32 else np.uint8))).to(dev)
+            for k, dt in pp.REC_FIELDS}
+    torch.cuda.synchronize()
+    L = pp.lib()
+    total = 0
+    for r in range(world):
+        want, want_orig = pp.shard_split_host(plan, r, odd)
+        part = pp.ShardPart(ctx, plan, r, n, {k: v.data_ptr() for k, v in keep.items()}, keep["seq"].numel(), keep["cigar"].numel(),
+                            pp.MEM_DEVICE)
+        assert part.n_aln == len(want_orig) and part.seq_bytes == len(want["seq"]) and part.n_cig_total == len(want["cigar"]), r
+        sizes = {"seq": part.seq_bytes, "cigar": part.n_cig_total}
+        for name, dt in pp.REC_FIELDS:
+            cnt = int(sizes.get(name, part.n_aln))
+            got = np.zeros(cnt, dtype=dt)
+            if cnt:
+                assert L.pp_ctx_download(ctx._h, got.ctypes.data, part.ptrs[name], got.nbytes) == 0
+            assert np.array_equal(got, want[name]), (r, name)
+        orig = np.zeros(part.n_aln, dtype=np.uint32)
+        if part.n_aln:
+            assert L.pp_ctx_download(ctx._h, orig.ctypes.data, part.orig_ptr, orig.nbytes) == 0
+        assert np.array_equal(orig, want_orig), r
+        total += part.n_aln
+        part.close()
+    assert n <= total < 1.2 * n
+    cnt = pp.shard_count(ctx, n, keep["contig"].data_ptr(), pp.MEM_DEVICE, 4, {k: v.data_ptr() for k, v in keep.items()})
+    assert np.array_equal(cnt.astype(np.int64), np.bincount(odd["contig"][odd["contig"] < 4], minlength=4))
+    for r in range(world):  # the property the partition exists for, on the device engine
+        part, _ = pp.shard_split_host(plan, r, recs)
+        e = plan.emit_ranges(r)
+        a = ctx.polish_records(contig_off, bases, part, emit=e)
+        b = ctx.polish_records(contig_off, bases, recs, emit=e)
+        assert a["polished"] == b["polished"] and np.array_equal(a["offsets"], b["offsets"]), r
+
+
 def test_several_contexts_report_the_first_bad_record_of_the_job(orc, tmp_path):
     """Records with defects that only the CIGAR walk finds, on a job sharded over three contexts: every context numbers
     the records it was sent, the job's error is the one about the FIRST bad record in file order with its job-wide

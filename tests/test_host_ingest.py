@@ -365,7 +365,7 @@ def test_slices_of_a_sam_file_start_on_read_group_boundaries(tmp_path):
     whole = tmp_path / "whole.sam"
     whole.write_bytes(text)
     _, _, _, _, want, _ = pp.ingest(str(fa), [str(whole)])
-    edges = [0] + sorted(c for c in cuts if 0 < c < len(text))[::7] + [len(text)]
+    edges = [0] + sorted(c for c in cuts if min(starts) < c < len(text))[::7] + [len(text)]  # (a file of header lines only would be an error)
     paths = []
     for i, (a0, b0) in enumerate(zip(edges[:-1], edges[1:])):
         pth = tmp_path / f"slice{i}.sam"

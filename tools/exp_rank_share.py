@@ -1,5 +1,6 @@
-"""What ONE rank of an N-way sharded job costs (strong scaling, measured on one GPU): the job of bench.py --config C with
-the emit ranges the planner gives rank r of `world` -- every rank streams ALL records through k_prep, the rest shrinks.
+"""What ONE rank of an N-way sharded job costs (strong scaling, measured on one GPU): the job of bench.py --config C as
+rank r of `world` sees it -- the records that reach its units (pp_shard_split) and its emit ranges.  `full` as a third
+argument gives every rank ALL records instead (the scheme of round 2: k_prep / k_fill stream and drop).
     python tools/exp_rank_share.py 4 8        # config 4, world 8: per-rank step time and kernel groups for every rank"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,9 +27,16 @@ def timed(j, reps=5):
 ms, kt = timed(job)
 print(label); print("whole job: %.3f ms" % ms, kt)
 tot = 0
+full = len(sys.argv) > 3 and sys.argv[3] == "full"
 for r in range(world):
-    j = dict(job); j["emit"] = plan.emit_ranges(r)
+    if full:
+        j = dict(job); j.pop("_prepared", None); j["emit"] = plan.emit_ranges(r)
+    else:
+        j = bench.shard_of(ctx, pp, job, plan, r)
     ms_r, kt = timed(j)
+    if not full:
+        print("   records of rank %d: %d of %d" % (r, j["part"].n_aln, job["n_aln"]))
+        j["part"].close()
     tot = max(tot, ms_r)
     print("rank %d of %d: %.3f ms" % (r, world, ms_r), kt)
 print("slowest rank %.3f ms -> speedup %.2f of %d" % (tot, ms / tot, world))
