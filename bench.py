@@ -136,6 +136,44 @@ def _timed(cmd, env=None, repeat=1, stdout_to=None):
     return best, out
 
 
+def live_traffic(argv_tail, kernel):
+    """HBM bytes per launch of `kernel`, measured in THIS run: two child passes of this very command under
+    rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md's HBM section
+    prescribes), a few steps each; mean per dispatch, KiB -> bytes, FETCH_SIZE doubled (gfx950 counts a 128-byte request
+    as 64 bytes), WRITE_SIZE as it is (both factors re-measured on a 2 GiB copy by tools/profile_round.sh:
+    profiles/*traffic.json "calibration").  None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pp_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-live-traffic"] + argv_tail
+            r = subprocess.run(cmd, capture_output=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            if r.returncode != 0:
+                return None
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == counter and kernel + "(" in row["Kernel_Name"].replace("pp::", ""):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            got[counter] = sum(vals) / len(vals) * 1024.0
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_bytes": int(round(2.0 * got["FETCH_SIZE"] + 1.0 * got["WRITE_SIZE"])), "fetch_raw_bytes": int(got["FETCH_SIZE"]),
+            "write_raw_bytes": int(got["WRITE_SIZE"])}
+
+
 def _file_sha(path):
     h = hashlib.sha256()
     with open(path, "rb") as fh:
@@ -262,13 +300,16 @@ def main():
                     help="bp of one contig given to the CPU oracle (default: the whole 5 Mbp job of config 1, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (one GPU)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child passes (the committed figure is used if the workload matches)")
     ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end CLI leg of --config (no kernel bench)")
     ap.add_argument("--recipe", default="survey", choices=["survey", "subs"],
                     help="assembly errors: 'survey' = SURVEY.md 8d (1/3 substitutions, 1/3 1-bp deletions, 1/3 1-bp insertions, "
                          "half of the indels in homopolymers; reads aligned to the assembly with the resulting I/D CIGARs), "
                          "'subs' = substitutions only (the recipe of rounds 1 and 2)")
     ap.add_argument("--e2e-dir", default=None, help="keep the end-to-end files in this directory")
-    ap.add_argument("--indel-frac", type=float, default=0.01, help="experiments only: fraction of reads with a 1-bp indel")
+    ap.add_argument("--indel-frac", type=float, default=None,
+                    help="fraction of reads with a 1-bp SEQUENCING indel (default: the recipe's -- survey 0.0015 = 1e-5 per base, subs 0.01)")
     ap.add_argument("--sub-rate", type=float, default=0.002, help="experiments only: per-base substitution rate")
     ap.add_argument("--n-rate", type=float, default=1e-4, help="experiments only: per-base N rate")
     ap.add_argument("--read-len", type=int, default=150, help="experiments only: read length (coverage is kept)")
@@ -307,7 +348,9 @@ def main():
     lens, coverage, repeat, label = config_shape(args.config, args.genome, args.coverage)
     G_total = int(sum(lens))
     strong = world > 1 and args.config in (3, 4)
-    default_shape = (args.recipe == "survey" and args.indel_frac == 0.01 and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
+    if args.indel_frac is None:
+        args.indel_frac = synthjob.SURVEY_INDEL_READ_FRAC if args.recipe == "survey" else 0.01
+    default_shape = (args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
                      args.repeat_bp == 0 and args.nd_frac == 0.0 and args.genome is None and args.coverage is None)
     # config 1: this rank's own 5 Mbp contig (seed differs per rank); configs 3 / 4 with N > 1: every rank builds
     # the same job and keeps its shard
@@ -460,14 +503,27 @@ def main():
     if not strong and not repeat:  # (repeat copies that differ by SNPs are out-voted by their siblings' reads: not expected)
         recovered = synthjob.recovered(job, polished, offs)
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
-    # figure comes from the committed rocprofv3 counter passes of this same command (tools/profile_round.sh
-    # -> profiles/traffic.json); null when the workload differs from the profiled one.
-    traffic = None
+    # HBM traffic of the dominant kernel (PMC counters): measured in this run by two rocprofv3 child passes of this very
+    # command (N = 1); failing that, the committed figure of the same workload (profiles/traffic.json), else null.
+    traffic = traffic_source = None
+    if world == 1 and dom_name and not args.no_live_traffic:
+        tail = ["--config", str(args.config), "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
+                "--n-rate", repr(args.n_rate), "--read-len", str(args.read_len), "--repeat-bp", str(args.repeat_bp), "--nd-frac", repr(args.nd_frac)]
+        if args.genome is not None:
+            tail += ["--genome", str(args.genome)]
+        if args.coverage is not None:
+            tail += ["--coverage", str(args.coverage)]
+        lt = live_traffic(tail, "k_" + dom_name)
+        if lt is not None:
+            traffic = lt["hbm_bytes"]
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command (3 steps "
+                              f"each), mean per dispatch; 2 x FETCH_SIZE ({lt['fetch_raw_bytes']} B raw) + WRITE_SIZE ({lt['write_raw_bytes']} B)")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if default_shape and args.config == 1 and dom_name and os.path.exists(tpath):
+    if traffic is None and default_shape and args.config == 1 and dom_name and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("kernels", {}).get("k_" + dom_name, {}).get("hbm_bytes")
+        if traffic is not None:
+            traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
     out = {
         "metric": METRIC,
@@ -484,14 +540,12 @@ def main():
         "data": "synthetic",
         "config": {"workload": label + f" alignment records resident in HBM ({job['n_aln']} records"
                                        f"{' in total' if strong else ''}; recipe '{args.recipe}': assembly errors {job['planted']}, "
-                                       f"reads aligned to the assembly, {100 * args.indel_frac:g}% with a 1-bp sequencing indel)",
+                                       f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel)",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
-                     if traffic is not None else None,
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},

@@ -106,21 +106,31 @@ constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
 constexpr u64 SL_DONE = 1ull << 63;
 
 __device__ void exact_one(const ExactArgs &A, u32 f);
-__device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 lane);
+__device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 *s_n);
 
-// One WAVE per listed position (a position whose string-keyed tallies -- an insertion, N ... -- could reach a threshold,
-// every flagged position of a window too deep for k_exact2, and with --debug everything that has such a key): the lanes
-// scan the window's work items together, the covering alignments are sorted by file index in LDS, the keys are tallied
-// and grouped by the whole wave.  An assembly that lacks a base makes every read over that spot vote for a two-byte
-// key (src/alignment.rs:175-201: an I run extends the entry before it; src/pileup.rs:56-63 counts it by string), so
-// these positions are what polishing is about -- one THREAD per position, walking the window's ~3,000 items and
-// heap-sorting 200 of them in global memory, took 10 ms per job at 200x.  Positions covered by more than EXW_MAX
-// alignments keep that thread-serial path.
+// One WORKGROUP per listed position (a position whose string-keyed tallies -- an insertion, N ... -- could reach a
+// threshold, every flagged position of a window too deep for k_exact2, and with --debug everything that has such a key):
+// all its threads scan the window's work items together, then its first wave sorts the covering alignments by file
+// index in LDS, tallies and groups the keys.  An assembly that lacks a base makes every read over that spot vote for a
+// two-byte key (src/alignment.rs:175-201: an I run extends the entry before it; src/pileup.rs:56-63 counts it by
+// string), so these positions are what polishing is about -- one THREAD per position, walking the window's ~3,000 items
+// and heap-sorting 200 of them in global memory, took 10 ms per job at 200x; one wave per position 0.2 ms (the scan is
+// a chain of 45 round trips); the workgroup's scan is six.  Positions covered by more than EXW_MAX alignments keep
+// the thread-serial path.
 constexpr u32 EXW_MAX = 1024;
+constexpr u32 EXW_THREADS = 512;
+constexpr u32 EXW_BLOCKS = 4096;
 
-__global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
+// one wave working on LDS by itself: its DS operations execute in program order, the compiler must keep them there
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(EXW_THREADS) void k_exact(ExactArgs A) {
     __shared__ ulonglong2 cov[EXW_MAX];
     __shared__ double rcp[EXW_MAX];
+    __shared__ u32 s_n;
     if (*A.status != ~0ull) return;
     if (*A.scr_need > A.cap_scr) {  // the scratch is too small: the host grows it and reruns
         if (blockIdx.x == 0 && threadIdx.x == 0) report(A.status, *A.scr_need, DE_CAPACITY);
@@ -128,54 +138,50 @@ __global__ __launch_bounds__(64) void k_exact(ExactArgs A) {
     }
     const u32 n_flagged = A.counters[0];
     for (u32 f = blockIdx.x; f < n_flagged; f += gridDim.x) {
-        if (A.flag_cov[f] <= EXW_MAX) exact_wave(A, f, cov, rcp, threadIdx.x);
+        if (A.flag_cov[f] <= EXW_MAX) exact_block(A, f, cov, rcp, &s_n);
         else if (threadIdx.x == 0) exact_one(A, f);
         __syncthreads();
     }
 }
 
-__device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 lane) {
+__device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 *s_n) {
+    const u32 tid = threadIdx.x, lane = tid & 63u;
     const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
     const u32 w = gp / (u32)TILE;
     const int pr = (int)(gp - w * (u32)TILE);
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40) ----
-    u32 n = 0;
-    for (u32 eb = e0; eb < e1; eb += 64) {
-        const u32 e = eb + lane;
-        bool hit = false;
-        ulonglong2 v = make_ulonglong2(0, 0);
-        if (e < e1) {
-            const uint4 ent = A.entA[e];
-            const int q = pr - (int)ent.z;
-            const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
-            if (q >= 0 && q < (int)(fl ? ent.x : (ent.y >> 24))) {
-                const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
-                // fast-class items carry their untrimmed length: apply the trim here
-                if (fl != 0 || (u32)q < simple_nkeep(A.seq + so, ent.y >> 24)) {
-                    u64 s_rel;
-                    u32 len;
-                    if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
-                    else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
-                    v.x = ((u64)idx << 32) | (u64)A.kk[idx];
-                    v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
-                    hit = true;
-                }
-            }
+    // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40); any order, sorted below ----
+    if (tid == 0) *s_n = 0;
+    __syncthreads();
+    for (u32 e = e0 + tid; e < e1; e += EXW_THREADS) {
+        const uint4 ent = A.entA[e];
+        const int q = pr - (int)ent.z;
+        const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
+        if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
+        const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+        // fast-class items carry their untrimmed length: apply the trim here
+        if (fl == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
+        u64 s_rel;
+        u32 len;
+        if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
+        const u32 slot = atomicAdd(s_n, 1u);
+        if (slot < EXW_MAX) {
+            ulonglong2 v;
+            v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+            v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
+            cov[slot] = v;
         }
-        const u64 m = __ballot(hit);
-        if (hit) {
-            const u32 slot = n + (u32)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < EXW_MAX) cov[slot] = v;
-        }
-        n += (u32)__popcll(m);
     }
+    __syncthreads();
+    const u32 n = *s_n;
+    if (tid >= 64u) return;  // the rest is the first wave's (no workgroup barrier from here on: wave_sync)
     if (n != cap) { if (lane == 0) report(A.status, gp, DE_INTERNAL); return; }
     // ---- file order: bitonic network over the next power of two (the padding sorts to the end) ----
     u32 np2 = 2;
     while (np2 < n) np2 <<= 1;
     for (u32 i = n + lane; i < np2; i += 64) cov[i] = make_ulonglong2(~0ull, 0);
-    __syncthreads();
+    wave_sync();
     for (u32 k = 2; k <= np2; k <<= 1)
         for (u32 lj = 31u - (u32)__clz((int)k); lj-- > 0;) {
             const u32 j = 1u << lj;
@@ -185,7 +191,7 @@ __device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *r
                 const ulonglong2 x = cov[i], y = cov[o];
                 if ((x.x > y.x) == asc) { cov[i] = y; cov[o] = x; }
             }
-            __syncthreads();
+            wave_sync();
         }
     // ---- tallies (by the wave) and the depth (sequential f64 adds of 1.0/k in file order: pileup.rs:64, alignment.rs:288) ----
     u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0;
@@ -203,7 +209,7 @@ __device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *r
         } else nOth++;
     }
     nA = wave_sum(nA); nC = wave_sum(nC); nG = wave_sum(nG); nT = wave_sum(nT); nDel = wave_sum(nDel); nOth = wave_sum(nOth);
-    __syncthreads();
+    wave_sync();
     double depth = 0.0;
     if (lane == 0)
         for (u32 i = 0; i < n; i++) depth += rcp[i];
@@ -247,7 +253,7 @@ __device__ void exact_wave(const ExactArgs &A, u32 f, ulonglong2 *cov, double *r
                 if (same) { mine++; cov[j].y = yj | SL_DONE; }
             }
             const u32 count = 1u + wave_sum(mine);
-            __syncthreads();
+            wave_sync();
             if (count >= v.vthr) { if (!nv) { win = 0; win_off = yi & SL_OFF_MASK; win_len = li; } nv++; }
             else if (count >= v.ithr) ni++;
             if (A.dbg && lane == 0) {

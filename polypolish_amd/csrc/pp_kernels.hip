@@ -552,7 +552,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, HEAVY_SUB>), dim3(HEAVY_SLOTS * HEAVY_SUB), dim3(1024), 0, st, E, nwin);
-    hipLaunchKernelGGL(k_exact, dim3(1024), dim3(64), 0, st, E);
+    hipLaunchKernelGGL(k_exact, dim3(EXW_BLOCKS), dim3(EXW_THREADS), 0, st, E);
     timer_end(ctx);
 
     u64 *d_winout = (u64 *)ctx->b_winout.p;
@@ -842,6 +842,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->f_insert};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &b : ctx->b_in) dev_free(b);
+    for (auto &b : ctx->b_split) dev_free(b);
     for (auto &f : ctx->f_in) for (auto &b : f) dev_free(b);
     timers_release(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

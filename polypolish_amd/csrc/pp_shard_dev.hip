@@ -24,7 +24,8 @@
 struct pp_shard_part {
     pp_ctx *ctx = nullptr;
     int mem = PP_MEM_HOST;
-    pp::DevBuf d[9], d_orig;  // contig ref_start k seq_off seq_len cig_off n_cig seq cigar
+    pp::DevBuf d_all;   // one allocation, carved into: contig ref_start k seq_off seq_len cig_off n_cig seq cigar orig
+    void *d[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<uint32_t> h_contig, h_ref_start, h_k, h_seq_len, h_n_cig, h_cigar, h_orig;
     std::vector<uint64_t> h_seq_off, h_cig_off;
     std::vector<uint8_t> h_seq;
@@ -177,10 +178,10 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
     pp_aln_batch &v = P->view;
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
     if (P->mem == PP_MEM_DEVICE) {
-        v.contig = (const u32 *)P->d[0].p; v.ref_start = (const u32 *)P->d[1].p; v.k = (const u32 *)P->d[2].p;
-        v.seq_off = (const uint64_t *)P->d[3].p; v.seq_len = (const u32 *)P->d[4].p; v.cig_off = (const uint64_t *)P->d[5].p;
-        v.n_cig = (const u32 *)P->d[6].p; v.seq = (const u8 *)P->d[7].p; v.cigar = (const u32 *)P->d[8].p;
-        P->orig = (const u32 *)P->d_orig.p;
+        v.contig = (const u32 *)P->d[0]; v.ref_start = (const u32 *)P->d[1]; v.k = (const u32 *)P->d[2];
+        v.seq_off = (const uint64_t *)P->d[3]; v.seq_len = (const u32 *)P->d[4]; v.cig_off = (const uint64_t *)P->d[5];
+        v.n_cig = (const u32 *)P->d[6]; v.seq = (const u8 *)P->d[7]; v.cigar = (const u32 *)P->d[8];
+        P->orig = (const u32 *)P->d[9];
     } else {
         v.contig = P->h_contig.data(); v.ref_start = P->h_ref_start.data(); v.k = P->h_k.data(); v.seq_off = P->h_seq_off.data();
         v.seq_len = P->h_seq_len.data(); v.cig_off = P->h_cig_off.data(); v.n_cig = P->h_n_cig.data(); v.seq = P->h_seq.data();
@@ -232,10 +233,12 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
     if (n == 0) { set_view(P, 0, 0, 0); return PP_OK; }
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc;
-    // the unit table on the device (a few hundred bytes), and the scratch of this call
-    pp::DevBuf t_first, t_units, flag, sel_seq, sel_cig, out_idx, seq_scan, cig_scan, sums, sums_off;
-    pp::DevBuf *scratch[] = {&t_first, &t_units, &flag, &sel_seq, &sel_cig, &out_idx, &seq_scan, &cig_scan, &sums, &sums_off};
-    auto done = [&](int r) { (void)hipStreamSynchronize(st); for (pp::DevBuf *b : scratch) pp::dev_free(*b); return r; };
+    // the unit table on the device (a few hundred bytes), and the scratch of this call: the context's own buffers, grow-only
+    // (a job is split into world x files parts: a hipMalloc per array and call was most of the split's time)
+    pp::DevBuf &t_first = ctx->b_split[0], &t_units = ctx->b_split[1], &flag = ctx->b_split[2], &sel_seq = ctx->b_split[3],
+               &sel_cig = ctx->b_split[4], &out_idx = ctx->b_split[5], &seq_scan = ctx->b_split[6], &cig_scan = ctx->b_split[7],
+               &sums = ctx->b_split[8], &sums_off = ctx->b_split[9];
+    auto done = [&](int r) { (void)hipStreamSynchronize(st); return r; };
     const size_t nu = U.lo.size();
     if ((rc = pp::dev_ensure(ctx, t_first, ((size_t)n_contigs + 1) * 4)) || (rc = pp::dev_ensure(ctx, t_units, (nu ? nu : 1) * 12)) ||
         (rc = pp::dev_ensure(ctx, flag, n * 4)) || (rc = pp::dev_ensure(ctx, sel_seq, n * 4)) || (rc = pp::dev_ensure(ctx, sel_cig, n * 4)) ||
@@ -261,13 +264,14 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
     if ((rc = fetch(ctx, (const u32 *)out_idx.p + n, &cnt)) || (rc = fetch(ctx, (const u64 *)seq_scan.p + n, &seq_total)) ||
         (rc = fetch(ctx, (const u64 *)cig_scan.p + n, &cig_total)))
         return done(rc);
-    const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
-    const uint64_t ecnt[9] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total};
-    for (int a = 0; a < 9; a++)
-        if ((rc = pp::dev_ensure(ctx, P->d[a], (size_t)ecnt[a] * esz[a]))) return done(rc);
-    if ((rc = pp::dev_ensure(ctx, P->d_orig, (size_t)cnt * 4))) return done(rc);
-    SplitOut O{(u32 *)P->d[0].p, (u32 *)P->d[1].p, (u32 *)P->d[2].p, (u32 *)P->d[4].p, (u32 *)P->d[6].p, (u32 *)P->d[8].p,
-               (u32 *)P->d_orig.p, (u64 *)P->d[3].p, (u64 *)P->d[5].p, (u8 *)P->d[7].p};
+    const size_t esz[10] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 4};
+    const uint64_t ecnt[10] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total, cnt};
+    size_t at[11] = {0};
+    for (int a = 0; a < 10; a++) at[a + 1] = (at[a] + (size_t)ecnt[a] * esz[a] + 255) / 256 * 256;
+    if ((rc = pp::dev_ensure(ctx, P->d_all, at[10]))) return done(rc);
+    for (int a = 0; a < 10; a++) P->d[a] = (char *)P->d_all.p + at[a];
+    SplitOut O{(u32 *)P->d[0], (u32 *)P->d[1], (u32 *)P->d[2], (u32 *)P->d[4], (u32 *)P->d[6], (u32 *)P->d[8],
+               (u32 *)P->d[9], (u64 *)P->d[3], (u64 *)P->d[5], (u8 *)P->d[7]};
     if (cnt) {
         hipLaunchKernelGGL(k_split_meta, dim3(blocks), dim3(256), 0, st, (u64)n, B->contig, B->ref_start, B->k, B->seq_len,
                            B->n_cig, (const u32 *)flag.p, (const u32 *)out_idx.p, (const u64 *)seq_scan.p,
@@ -319,8 +323,7 @@ extern "C" void pp_shard_part_free(pp_shard_part *P) {
     if (P->mem == PP_MEM_DEVICE && P->ctx) {
         (void)hipSetDevice(P->ctx->device);
         (void)hipStreamSynchronize(P->ctx->stream);
-        for (auto &b : P->d) pp::dev_free(b);
-        pp::dev_free(P->d_orig);
+        pp::dev_free(P->d_all);
     }
     delete P;
 }

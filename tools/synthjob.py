@@ -10,7 +10,8 @@ Recipe (`recipe="survey"`, the default; `"subs"` keeps the round-1/2 substitutio
   no error within `end_margin` of a contig end or inside / next to a repeat copy;
 * reads: truth substrings of `read_len` bases (uniform starts; `pairs=True`: fragments with insert ~ N(350, 35) clipped
   to [160, 700], orientation fr, mates in two files) with 0.2 % substitutions, 1e-4 N and -- `indel_read_frac` of the
-  reads, 1 % by default, which is more than the survey's 1e-5 per base -- one 1-bp sequencing insertion or deletion;
+  reads: 0.15 % with the survey recipe (its 1e-5 per base), 1 % with "subs" as in rounds 1 and 2 -- one 1-bp
+  sequencing insertion or deletion;
 * alignment records are computed BY CONSTRUCTION AGAINST THE ASSEMBLY: exact CIGAR with M / I / D runs (an assembly
   deletion under a read is an I, an assembly insertion a D), NM = edit count, POS in assembly coordinates
   (reference semantics: src/alignment.rs:175-201 walks exactly these runs, :349-378 trims them);
@@ -32,6 +33,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OP_M, OP_I, OP_D = 0, 1, 2
 MAX_ERRORS = 10  # the CLI's default --max_errors (src/main.rs:93-95)
+# sequencing indel error 1e-5 per base -> a 150-base read carries one with probability 1 - (1 - 1e-5)^150
+SURVEY_INDEL_READ_FRAC = 0.0015
 
 
 def _excl_cumsum(x):
@@ -40,7 +43,7 @@ def _excl_cumsum(x):
 
 
 def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=42, sub_rate=0.002, n_rate=1e-4,
-             asm_err_rate=1e-4, recipe="survey", indel_read_frac=0.01, repeat=None, repeat_bp=0, repeat_k=5, pairs=False,
+             asm_err_rate=1e-4, recipe="survey", indel_read_frac=None, repeat=None, repeat_bp=0, repeat_k=5, pairs=False,
              unaligned_frac=0.0, G=None, end_margin=1000, asm_sub_rate=None):
     """One synthetic polish job (see the module docstring).  contig_lens are TRUTH lengths; the assembly's differ by
     the planted indels.  Returns a dict: G / contig_off / bases (the assembly), recs (good records, SoA on `device`),
@@ -50,6 +53,8 @@ def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=
         contig_lens = (G,)
     if asm_sub_rate is not None:  # the old keyword
         asm_err_rate = asm_sub_rate
+    if indel_read_frac is None:
+        indel_read_frac = SURVEY_INDEL_READ_FRAC if recipe == "survey" else 0.01
     dev = device
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
