@@ -159,8 +159,19 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
         if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
         const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
-        // fast-class items carry their untrimmed length: apply the trim here
-        if (fl == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
+        // fast-class items carry their untrimmed length: apply the trim here (from the last four bases in one load, as
+        // k_tile's plain class does; a trailing homopolymer of four or more walks byte by byte)
+        if (fl == 0) {
+            const u8 *rp = A.seq + so;
+            const u32 L = ent.y >> 24;
+            u32 tf = 0;
+            if (L >= 4u) {
+                const u32 tail = load4_unaligned(rp + (L - 4u));
+                tf = nz_flags(tail ^ splat8(tail >> 24));
+            }
+            const u32 lim = tf ? L - 4u + (u32)((31 - __clz((int)tf)) >> 3) : simple_nkeep(rp, L);
+            if ((u32)q >= lim) continue;
+        }
         u64 s_rel;
         u32 len;
         if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
@@ -195,8 +206,12 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
         }
     // ---- tallies (by the wave) and the depth (sequential f64 adds of 1.0/k in file order: pileup.rs:64, alignment.rs:288) ----
     u32 nA = 0, nC = 0, nG = 0, nT = 0, nDel = 0, nOth = 0;
+    u64 fx = 0;      // the depth in 2^-DEPTH_FX_BITS units while every share is a power of two (exact in any order)
+    bool odd = false;
     for (u32 i = lane; i < n; i += 64) {
-        rcp[i] = 1.0 / (double)(u32)(cov[i].x & 0xFFFFFFFFull);
+        const u32 kq = (u32)(cov[i].x & 0xFFFFFFFFull), kc = kclass_of(kq);
+        rcp[i] = 1.0 / (double)kq;
+        if (kc == KCLASS_NONDYADIC) odd = true; else fx += (u64)(1u << DEPTH_FX_BITS) >> kc;
         const u64 y = cov[i].y;
         const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
         int row = ROW_OTH;
@@ -210,10 +225,15 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
     }
     nA = wave_sum(nA); nC = wave_sum(nC); nG = wave_sum(nG); nT = wave_sum(nT); nDel = wave_sum(nDel); nOth = wave_sum(nOth);
     wave_sync();
-    double depth = 0.0;
-    if (lane == 0)
-        for (u32 i = 0; i < n; i++) depth += rcp[i];
-    depth = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(depth)), __builtin_amdgcn_readfirstlane(__double2loint(depth)));
+    double depth;
+    if (__ballot(odd)) {  // some share is not a power of two: the sum depends on the order -- one lane adds them up in file order
+        depth = 0.0;
+        if (lane == 0)
+            for (u32 i = 0; i < n; i++) depth += rcp[i];
+        depth = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(depth)), __builtin_amdgcn_readfirstlane(__double2loint(depth)));
+    } else {
+        depth = (double)wave_sum64(fx) * (1.0 / (double)(1u << DEPTH_FX_BITS));
+    }
     const u8 orig = A.bases[gp];
     VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
     u64 win_off = 0;
