@@ -41,6 +41,16 @@ constexpr uint32_t HEAVY_WORDS = 1 + 2 * HEAVY_SLOTS;  // u32: count | listed wi
 // entry flags (entA.y bits 24..31)
 constexpr uint32_t ENT_COMPLEX = 1u;   // CIGAR contains I or D runs: walked run by run, trim done by k_prep
 constexpr uint32_t ENT_PRETRIM = 2u;   // no indel, but too long / overhanging for the fast path: trim done by k_prep
+// A read with ONE 1-base indel (runs aM 1I bM / aM 1D bM: a read across a planted assembly deletion / insertion, or with a
+// sequencing indel) is not walked at all: k_fill cuts it into three work items -- the bases in front of the indel
+// (ENT_NOTRIM: a fast-class item whose end is not the read's end), the entry AT the indel (ENT_POINT: the two-byte key of
+// an insertion, or the empty slot of a deletion: one tally) and the bases behind it (an ordinary fast-class item, trimmed
+// like any read) -- get_read_bases_for_each_target_base's output for such a CIGAR (alignment.rs:175-201), piece by piece.
+// These two flags live in bits 30-31 of the item's z word (the window-relative start below them, 30 bits signed).
+constexpr uint32_t ENT_NOTRIM = 4u;
+constexpr uint32_t ENT_POINT = 8u;
+constexpr uint32_t NKW_INDEL1 = 3u;    // class bits (30-31) of the nkeep word: span | a << 9 | is_deletion << 17 below them
+constexpr uint32_t INDEL1_MIN_SEG = 8; // both flanks at least this long (PLAIN_MIN_LEN), else the general walk
 constexpr uint32_t FAST_MAX_LEN = 252; // a read of <= 252 bases is one dword-per-lane wave load
 constexpr uint32_t KCLASS_NONDYADIC = 255u;
 

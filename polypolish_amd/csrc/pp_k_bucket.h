@@ -30,15 +30,18 @@ __global__ __launch_bounds__(1024) void k_count(u64 n, u64 chunk, const u32 *__r
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
             const u64 a = a0 + (u64)u * blockDim.x;
-            nk[u] = a < hi ? (nkeep[a] & 0x3FFFFFFFu) : 0u;
+            nk[u] = a < hi ? nkeep[a] : 0u;
             g[u] = a < hi ? gstart[a] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (!nk[u]) continue;
-            u32 w0 = g[u] / (u32)TILE, w1 = (g[u] + nk[u] - 1u) / (u32)TILE;
-            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
-            for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+            for_each_piece(g[u], nk[u], [&](u32, u32 gp, u32 sp) {
+                if (!sp) return;
+                u32 w0 = gp / (u32)TILE, w1 = (gp + sp - 1u) / (u32)TILE;
+                u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+                for (u32 w = wa; w <= wb && w >= wa; w++) atomicAdd(&h[w - range_lo], 1u);
+            });
         }
     }
     __syncthreads();
@@ -176,50 +179,63 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
     const u32 range_n = min(crange_n * (u32)CW, nwin - range_lo);
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
-        u32 nk4[4], g4[4], k4[4], fl4[4];
+        u32 nk4[4], g4[4], k4[4], sl4[4];
         u64 so4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
             const u64 a = a0 + (u64)u * blockDim.x;
             const bool ok = a < hi;
-            const u32 nkw = ok ? nkeep[a] : 0u;
-            nk4[u] = nkw & 0x3FFFFFFFu;
-            fl4[u] = nkw >> 30;
+            nk4[u] = ok ? nkeep[a] : 0u;
             g4[u] = ok ? gstart[a] : 0u;
             k4[u] = ok ? kk[a] : 1u;
             so4[u] = ok ? seq_off[a] : 0ull;
+            sl4[u] = ok ? seq_len[a] : 0u;
             if (ok && blockIdx.y == 0) {  // checks that need k / seq_off (not read by k_prep's fast path)
                 if (k4[u] == 0) report(status, a, DE_BAD_K);
-                else if (so4[u] + seq_len[a] > (1ull << 40)) report(status, a, DE_OVERFLOW);
+                else if (so4[u] + sl4[u] > (1ull << 40)) report(status, a, DE_OVERFLOW);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const u32 nk = nk4[u];
-            if (!nk) continue;
+            const u32 word = nk4[u];
+            if (!word) continue;
             const u64 a = a0 + (u64)u * blockDim.x;
-            const u32 g = g4[u];
-            u32 w0 = g / (u32)TILE, w1 = (g + nk - 1u) / (u32)TILE;
-            u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
-            if (wa > wb) continue;
-            const u64 so = so4[u];
             const u32 kc = kclass_of(k4[u]);
-            const u32 fl = fl4[u];
-            for (u32 w = wa; w <= wb && w >= wa; w++) {
-                u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
+            const u32 cls = word >> 30;
+            const u32 ia = (word >> 9) & 0xFFu, idel = (word >> 17) & 1u;  // a one-indel read: run length in front, kind
+            for_each_piece(g4[u], word, [&](u32 piece, u32 g, u32 sp) {
+                if (!sp) return;
+                u32 w0 = g / (u32)TILE, w1 = (g + sp - 1u) / (u32)TILE;
+                u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+                if (wa > wb) return;
                 // work item, 16 bytes (bits 18..23 of y carry the window's index inside its coarse bucket until
                 // k_regroup has used it):
                 //   x  fast class: seq offset bits 0..31          otherwise: kept entries (trim done by k_prep)
-                //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [23:16] flags | [31:24] read length (fast)
-                //   z  global start of the read minus the window start (signed)      w  record index (file order)
-                uint4 e;
-                e.x = fl ? nk : (u32)so;
-                e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (nk << 24))) | (kc << 8) | (fl << 16) |
-                      ((w % (u32)CW) << 18);
-                e.z = (u32)(int)((long long)g - (long long)w * TILE);
-                e.w = (u32)a;
-                entB[slot] = e;
-            }
+                //   y  [7:0] seq offset bits 32..39 (fast) | [15:8] depth-share class | [17:16] class flags | [31:24] length (fast)
+                //   z  [29:0] global start of the piece minus the window start (signed) | [30] ENT_NOTRIM | [31] ENT_POINT
+                //   w  record index (file order)
+                // "fast" = a read without indels (its bytes are the entries, trimmed in k_tile) and the pieces of a
+                // one-indel read: the flank in front (its end is not the read's: ENT_NOTRIM), the entry at the indel
+                // (ENT_POINT: x/y point at its key bytes, the length field holds their number -- 2, or 0 for a deletion)
+                // and the flank behind.
+                u64 so = so4[u];
+                u32 len = sp, fl = 0, zf = 0;
+                if (cls == NKW_INDEL1) {
+                    if (piece == 0u) zf = 1u;                                   // ENT_NOTRIM
+                    else if (piece == 1u) { zf = 2u; so += ia - 1u + idel; len = idel ? 0u : 2u; }  // ENT_POINT
+                    else so += idel ? ia : ia + 1u;
+                } else fl = cls;
+                for (u32 w = wa; w <= wb && w >= wa; w++) {
+                    u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
+                    uint4 e;
+                    e.x = fl ? sp : (u32)so;
+                    e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (len << 24))) | (kc << 8) | (fl << 16) |
+                          ((w % (u32)CW) << 18);
+                    e.z = ((u32)(int)((long long)g - (long long)w * TILE) & 0x3FFFFFFFu) | (zf << 30);
+                    e.w = (u32)a;
+                    entB[slot] = e;
+                }
+            });
         }
     }
 }

@@ -45,6 +45,29 @@ __device__ __forceinline__ int job_state(const u64 *status) {
     return s == ~0ull ? 0 : ((s & 0xFFu) == DE_CAPACITY_LATE ? 1 : 2);
 }
 
+// ---- work items (16 bytes, written by k_fill, see there) ----
+__device__ __forceinline__ int item_rel(u32 z) { return (int)(z << 2) >> 2; }          // start minus window start
+__device__ __forceinline__ u32 item_flags(u32 y, u32 z) { return ((y >> 16) & 3u) | ((z >> 28) & 0xCu); }
+// positions an item can reach before its trim: kept entries (trim done by k_prep), 1 (a point), or the read / piece length
+__device__ __forceinline__ u32 item_extent(u32 x, u32 y, u32 z) {
+    return ((y >> 16) & 3u) ? x : ((z >> 31) ? 1u : (y >> 24));
+}
+// the nkeep word of a record (k_prep -> k_count / k_fill): reference span of the record, for the windows it reaches
+__device__ __forceinline__ u32 nkw_span(u32 word) { return (word >> 30) == NKW_INDEL1 ? (word & 0x1FFu) : (word & 0x3FFFFFFFu); }
+// The pieces of a record, as (global start, positions) pairs: one for most records, three for a one-indel read (the
+// flank in front, the entry at the indel, the flank behind).  f(piece, g, span) is called for pieces 0 [, 1, 2].
+template <typename F>
+__device__ __forceinline__ void for_each_piece(u32 g, u32 word, F f) {
+    if ((word >> 30) != NKW_INDEL1) { f(0u, g, word & 0x3FFFFFFFu); return; }
+    const u32 span = word & 0x1FFu, a = (word >> 9) & 0xFFu, del = (word >> 17) & 1u;
+    // insertion (aM1IbM, span = a + b):   flank [0, a-1) | entry a-1 (two-byte key) | flank from entry a on
+    // deletion  (aM1DbM, span = a + 1 + b): flank [0, a)   | entry a (empty)          | flank from entry a+1 on
+    const u32 l1 = del ? a : a - 1u;
+    f(0u, g, l1);
+    f(1u, g + l1, 1u);
+    f(2u, g + l1 + 1u, span - l1 - 1u);
+}
+
 // misc.rs:208-215 for x >= 0
 __device__ __forceinline__ u32 d_bankers(double x) {
     u32 r = (x >= 4294967295.0) ? 0xFFFFFFFFu : (u32)x;

@@ -155,13 +155,14 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
     __syncthreads();
     for (u32 e = e0 + tid; e < e1; e += EXW_THREADS) {
         const uint4 ent = A.entA[e];
-        const int q = pr - (int)ent.z;
+        const int q = pr - item_rel(ent.z);
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
-        if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
+        const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
+        if (q < 0 || q >= (int)item_extent(ent.x, ent.y, ent.z)) continue;
         const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
         // fast-class items carry their untrimmed length: apply the trim here (from the last four bases in one load, as
         // k_tile's plain class does; a trailing homopolymer of four or more walks byte by byte)
-        if (fl == 0) {
+        if (fl == 0 && !point && !notrim) {
             const u8 *rp = A.seq + so;
             const u32 L = ent.y >> 24;
             u32 tf = 0;
@@ -174,7 +175,8 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
         }
         u64 s_rel;
         u32 len;
-        if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        if (point) { s_rel = 0; len = ent.y >> 24; }  // the entry at a read's single indel: its key bytes, or none
+        else if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
         else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
         const u32 slot = atomicAdd(s_n, 1u);
         if (slot < EXW_MAX) {
@@ -360,15 +362,17 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
     u32 n = 0;
     for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
         const uint4 ent = A.entA[e];
-        const int q = pr - (int)ent.z;
+        const int q = pr - item_rel(ent.z);
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
-        if (q < 0 || q >= (int)(fl ? ent.x : (ent.y >> 24))) continue;
+        const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
+        if (q < 0 || q >= (int)item_extent(ent.x, ent.y, ent.z)) continue;
         const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
         // fast-class items carry their untrimmed length: apply the trim here
-        if (fl == 0 && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
+        if (fl == 0 && !point && !notrim && (u32)q >= simple_nkeep(A.seq + so, ent.y >> 24)) continue;
         u64 s_rel;
         u32 len;
-        if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+        if (point) { s_rel = 0; len = ent.y >> 24; }
+        else if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
         else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
         if (n < cap) {
             ulonglong2 v;
@@ -605,8 +609,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
 #pragma unroll
             for (u32 u = 0; u < 4; u++) {
                 const u32 i = i0 + 1024u * u;
-                const u32 ext = ((ent[u].y >> 16) & 0xFFu) ? ent[u].x : (ent[u].y >> 24);
-                const int z = (int)ent[u].z;
+                const u32 ext = item_extent(ent[u].x, ent[u].y, ent[u].z);
+                const int z = item_rel(ent[u].z);
                 if (i < n_all && z < plo + PSPAN && (long long)z + (long long)ext > (long long)plo) {
                     const u32 j = atomicAdd(&s_npick, 1u);
                     if (j < SMAX) sel[j] = i;
@@ -731,6 +735,8 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         const u32 fl = (ent.y >> 16) & 0xFFu, kc = (ent.y >> 8) & 0xFFu;
         u32 lim;
         if (fl) lim = ent.x;
+        else if (ent.z >> 31) lim = 1u;                    // the entry at a read's single indel
+        else if ((ent.z >> 30) & 1u) lim = ent.y >> 24;    // the flank in front of it: no trim
         else {
             // the trim from the read's last four bases, one load (as k_tile's plain class does it); a trailing
             // homopolymer of four or more, or a read shorter than that, walks byte by byte
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         }
         const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[ent.w]);
         ulonglong2 r;
-        r.x = (u64)ent.z | ((u64)lim << 32);
+        r.x = (u64)(u32)item_rel(ent.z) | ((u64)lim << 32);
         r.y = (u64)__double_as_longlong(1.0 / (double)k);
         if (in_lds) ents_lds[i] = r;
         else ents[i] = r;

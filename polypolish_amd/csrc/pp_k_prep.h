@@ -32,6 +32,23 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     const u64 clen = c_hi - c_lo;
     const u8 *s = seq + so;
     u32 n_entries = (u32)ref_span;
+    if (indel && nc == 3u && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
+        // ONE 1-base indel between two M/= runs (a read over a planted assembly indel, or a sequencing indel): no walk.
+        // k_fill cuts it into the flank in front, the entry at the indel and the flank behind (pp_internal.h, ENT_NOTRIM /
+        // ENT_POINT); the trim has to stay inside the flank behind, which is what the reads of k_tile's plain class assume.
+        const u32 o0 = cg[0] & 15u, o1 = cg[1] & 15u, o2 = cg[2] & 15u, a = cg[0] >> 4, b = cg[2] >> 4;
+        if ((o0 == PP_OP_M || o0 == PP_OP_EQ) && (o2 == PP_OP_M || o2 == PP_OP_EQ) && (o1 == PP_OP_I || o1 == PP_OP_D) &&
+            (cg[1] >> 4) == 1u) {
+            const bool del = o1 == PP_OP_D;
+            const u32 l1 = del ? a : a - 1u;
+            if (l1 >= INDEL1_MIN_SEG && b >= INDEL1_MIN_SEG && simple_trim_start(s + (del ? a : a + 1u), b) >= 1u) {
+                *g_out = (u32)(c_lo + rs);
+                *nk_out = n_entries | (a << 9) | ((del ? 1u : 0u) << 17);
+                *fl_out = (u8)NKW_INDEL1;
+                return;
+            }
+        }
+    }
     if (!indel && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
         // fast class (=/X runs): k_tile loads the whole read anyway and trims it there, so the read
         // bytes are not touched here; bucketed by its untrimmed span
@@ -125,13 +142,17 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits
         // is somebody else's -- validated like every record (all ranks report the same first bad record), then
         // dropped.  The untrimmed span of the fast class errs on the side of keeping.
-        if (own && nk_out && c < n_contigs && ((u64)rs + nk_out <= own[2 * c] || rs >= own[2 * c + 1])) nk_out = 0;
+        u32 word = nk_out | (fl_out << 30);  // kept entries (< 2^30) | class flags (a one-indel read: see for_each_piece)
+        const u32 span = nkw_span(word);
+        if (own && span && c < n_contigs && ((u64)rs + span <= own[2 * c] || rs >= own[2 * c + 1])) word = 0;
         gstart[a] = g_out;
-        nkeep[a] = nk_out | (fl_out << 30);  // kept entries (< 2^30) | class flags
-        if (COUNT && nk_out) {
-            const u32 w0 = g_out / (u32)TILE, w1 = min((g_out + nk_out - 1u) / (u32)TILE, nwin - 1u);
-            for (u32 w = w0; w <= w1; w++) atomicAdd(&h[w / cw], 1u);  // per window, or per coarse bucket of cw windows
-        }
+        nkeep[a] = word;
+        if (COUNT && word)
+            for_each_piece(g_out, word, [&](u32, u32 g, u32 sp) {
+                if (!sp) return;
+                const u32 w0 = g / (u32)TILE, w1 = min((g + sp - 1u) / (u32)TILE, nwin - 1u);
+                for (u32 w = w0; w <= w1; w++) atomicAdd(&h[w / cw], 1u);  // per window, or per coarse bucket of cw windows
+            });
     };
     auto general = [&](u64 a, u32 c, u32 nc, u32 sl, u32 rs, u64 co, u64 c_lo, u64 c_hi) {
         u32 g_out = 0, nk_out = 0;

@@ -194,6 +194,7 @@ struct PlainItem {  // per lane
     u32 L;
     bool plain, active;
     bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
+    bool notrim;       // the flank in front of a read's single indel: its end is not the read's end, nothing to trim
 };
 
 // fields of the group's item (ds_bpermute from the batch registers) and the read loads, issued early
@@ -206,10 +207,12 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, c
     const u32 j = first + g;  // item of the batch owned by this group
     const int src = (int)(min(j, nb - 1u) << 2);
     const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
-    it.rel = __builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    const u32 ez = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    it.rel = item_rel(ez);
+    it.notrim = ((ez >> 30) & 1u) != 0;
     it.L = ey >> 24;
     it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
-    it.plain = g < C::IPP && j < nb && C::ok(ex, ey, seq_bytes);
+    it.plain = g < C::IPP && j < nb && (ez >> 31) == 0 && C::ok(ex, ey, seq_bytes);
     const u8 *rp = seq + ((u64)ex | ((u64)(ey & 0xFFu) << 32));
     const u32 mis = PP_PLAIN_ALIGNED ? (u32)((uintptr_t)rp & 31u) : 0u;
     it.ib = (int)(32u * s) - (int)mis;
@@ -238,7 +241,8 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
     const u32 last = it.tail >> 24;
     const u32 tf = nz_flags(it.tail ^ splat8(last));
     int nkeep = (int)L - 4 + ((31 - __clz((int)tf)) >> 3);
-    if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
+    if (it.notrim) nkeep = (int)L;
+    else if (it.plain && tf == 0) {  // rare: walk left over the homopolymer
         const u8 *rp = it.lane_p - it.ib;
         u32 i = L - 4u;
         while (i > 0 && rp[i - 1] == (u8)last) i--;
@@ -302,6 +306,7 @@ struct FastItem {  // wave-uniform (built from v_readlane results)
     u32 kc;    // depth-share class of 1/k
     u32 mis;   // (address of the read) & 3
     bool on;
+    bool notrim;  // see PlainItem
 };
 
 __device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, const u8 *seq) {
@@ -309,7 +314,9 @@ __device__ __forceinline__ FastItem fast_fetch(const uint4 &my, u32 j, u32 nb, c
     const u32 x = (u32)__builtin_amdgcn_readlane((int)my.x, jj), y = (u32)__builtin_amdgcn_readlane((int)my.y, jj);
     FastItem f;
     f.so = (u64)x | ((u64)(y & 0xFFu) << 32);
-    f.rel = __builtin_amdgcn_readlane((int)my.z, jj);
+    const u32 z = (u32)__builtin_amdgcn_readlane((int)my.z, jj);
+    f.rel = item_rel(z);
+    f.notrim = ((z >> 30) & 1u) != 0;
     f.L = y >> 24;
     f.kc = (y >> 8) & 0xFFu;
     f.mis = (u32)(((uintptr_t)(seq + f.so)) & 3u);
@@ -346,6 +353,7 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
     const u64 m = __ballot(hi_i >= 0);
     int nkeep = 0;  // index of the last base that differs: the run after it and that base are popped
     if (m) nkeep = __builtin_amdgcn_readlane(hi_i, 63 - __clzll((long long)m));
+    if (f.notrim) nkeep = (int)f.L;
     const int lo = max(0, -f.rel), hi = min(nkeep, TILE - f.rel);
     if (hi <= lo) return;
     if (f.kc != 0) {
@@ -459,17 +467,24 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         const u32 nb = min(C::BATCH, hi_w - eb);
         const uint4 my = nxt;
         if (eb + C::BATCH < hi_w) nxt = A.entA[eb + C::BATCH + min(lane, min(C::BATCH, hi_w - eb - C::BATCH) - 1u)];
-        const u32 my_flags = (my.y >> 16) & 0xFFu;
-        const bool my_slow = lane < nb && my_flags != 0;
-        const bool my_plain = lane < nb && C::ok(my.x, my.y, A.seq_bytes);
+        const u32 my_flags = item_flags(my.y, my.z);
+        const bool my_slow = lane < nb && (my_flags & 3u) != 0;
+        const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
+        const bool my_plain = lane < nb && !my_point && C::ok(my.x, my.y, A.seq_bytes);
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
         if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         for (u32 first = 0; first < nb; first += C::IPP)
             plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+        // the entry AT a read's single indel (ENT_POINT): one tally, one item per lane -- the two-byte key of an
+        // insertion is counted by string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
+        if (my_point) {
+            const int p = item_rel(my.z);
+            if (p >= 0 && p < TILE) tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, p, (my.y >> 8) & 0xFFu);
+        }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
-        u64 rest = __ballot(lane < nb && !my_slow && !my_plain);
+        u64 rest = __ballot(lane < nb && !my_slow && !my_plain && !my_point);
         while (rest) {
             const u32 j = (u32)__ffsll((long long)rest) - 1u;
             rest &= rest - 1;
@@ -491,7 +506,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                 const int j = __ffsll((long long)slow) - 1;
                 slow &= slow - 1;
                 const u32 ey = (u32)__builtin_amdgcn_readlane((int)my.y, j);
-                const int rel = __builtin_amdgcn_readlane((int)my.z, j), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
+                const int rel = item_rel((u32)__builtin_amdgcn_readlane((int)my.z, j)), nkeep = __builtin_amdgcn_readlane((int)my.x, j);
                 const u32 kc = (ey >> 8) & 0xFFu;
                 const u64 so = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)sl_so, j) |
                                ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(sl_so >> 32), j) << 32);
