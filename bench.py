@@ -447,10 +447,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctx.set_profiling(1)
-    all_ms, n_break = {}, 5
+    all_ms, n_break, work = {}, 5, {}
     for _ in range(n_break):
         step()
-        for k, v in ctx.kernel_times()["ms"].items():
+        kt = ctx.kernel_times()
+        work = {"work_items": kt["n_entries"], "positions_replayed_exactly": kt["n_flagged"], "pipeline_passes": kt["n_passes"]}
+        for k, v in kt["ms"].items():
             all_ms[k] = all_ms.get(k, 0.0) + v
     ctx.set_profiling(0)
 
@@ -549,6 +551,7 @@ def main():
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
+        "work": work,
         "planted_errors_recovered": recovered,
         "gather_verified": gather_ok,
         "changed_positions": int(sum(s["changed"] for s in stats)),

@@ -129,6 +129,9 @@ struct pp_ctx {
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slab_win, b_slabs, b_ents, b_keys, b_own;
     pp::DevBuf b_win_heavy, b_hslab;  // heavy windows: slot + 1 per window (u8) | the helpers' partial tallies
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
+    std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
+    uint32_t run_nc = 0;                // contigs of the last run
+    pp::DevBuf b_sub_bases;             // ... and its assembly bytes
     size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;
 

@@ -8,8 +8,9 @@ namespace pp {
 // k_prep
 // =============================================================================================
 // every record that is not a single short M run inside its contig
+// g0: where the record's contig starts in the run's coordinates (k_prep's g_base); clen: the contig's length
 __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
-                                               u64 c_lo, u64 c_hi, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
+                                               u64 g0, u64 clen, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
     // walk the runs (alignment.rs:178-194): spans and validity
     u64 ref_span = 0, read_span = 0;
     bool indel = false;
@@ -29,7 +30,6 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
     if (ref_span >= 0x3FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
 
-    const u64 clen = c_hi - c_lo;
     const u8 *s = seq + so;
     u32 n_entries = (u32)ref_span;
     if (indel && nc == 3u && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
@@ -42,7 +42,7 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
             const bool del = o1 == PP_OP_D;
             const u32 l1 = del ? a : a - 1u;
             if (l1 >= INDEL1_MIN_SEG && b >= INDEL1_MIN_SEG && simple_trim_start(s + (del ? a : a + 1u), b) >= 1u) {
-                *g_out = (u32)(c_lo + rs);
+                *g_out = (u32)(g0 + rs);
                 *nk_out = n_entries | (a << 9) | ((del ? 1u : 0u) << 17);
                 *fl_out = (u8)NKW_INDEL1;
                 return;
@@ -52,7 +52,7 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     if (!indel && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
         // fast class (=/X runs): k_tile loads the whole read anyway and trims it there, so the read
         // bytes are not touched here; bucketed by its untrimmed span
-        *g_out = (u32)(c_lo + rs);
+        *g_out = (u32)(g0 + rs);
         *nk_out = n_entries;
         return;
     }
@@ -89,7 +89,7 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
     if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
     if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
-    *g_out = (u32)(c_lo + rs);
+    *g_out = (u32)(g0 + rs);
     *nk_out = nk;
     *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
 }
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                                                const u32 *__restrict__ cigar,
                                                const u8 *__restrict__ seq,
                                                const u64 *__restrict__ contig_off, u32 n_contigs,
+                                               const u64 *__restrict__ g_base,
                                                const u32 *__restrict__ own,
                                                u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
                                                u32 *__restrict__ maxlen, u32 nwin, u32 cw, u32 ncols,
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     // a record's result: stored, and (COUNT) tallied in the windows it reaches
+    // contig_off / n_contigs / own are the JOB's (a record names its contig by the job's index); g_base[c] is where contig
+    // c starts in the coordinates of this RUN -- the same table, or a compact one over the contigs this context owns
+    // (run_pipeline), with ~0 for the others: their records are validated like any record, then dropped.
     auto finish = [&](u64 a, u32 c, u32 rs, u32 g_out, u32 nk_out, u32 fl_out) {
         // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits
         // is somebody else's -- validated like every record (all ranks report the same first bad record), then
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         u32 word = nk_out | (fl_out << 30);  // kept entries (< 2^30) | class flags (a one-indel read: see for_each_piece)
         const u32 span = nkw_span(word);
         if (own && span && c < n_contigs && ((u64)rs + span <= own[2 * c] || rs >= own[2 * c + 1])) word = 0;
+        if (c < n_contigs && g_base[c] == ~0ull) word = 0;
         gstart[a] = g_out;
         nkeep[a] = word;
         if (COUNT && word)
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         u8 fl_out = 0;
         if (c >= n_contigs) report(status, a, DE_BAD_CONTIG);
         else if (nc == 0) report(status, a, DE_BAD_RUN);
-        else prep_general(a, rs, sl, seq_off[a], cigar + co, nc, seq, c_lo, c_hi, &g_out, &nk_out, &fl_out, status);
+        else prep_general(a, rs, sl, seq_off[a], cigar + co, nc, seq, g_base[c], c_hi - c_lo, &g_out, &nk_out, &fl_out, status);
         finish(a, c, rs, g_out, nk_out, fl_out);
     };
     u32 fast_len = 0;  // the longest fast-class read this thread saw: picks the lane-group width of k_tile's plain class
@@ -171,12 +176,12 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
             const u64 a = min(a0 + (u64)u * blockDim.x, hi - 1);  // clamped: the loads are unconditional
             c[u] = contig[a]; nc[u] = n_cig[a]; sl[u] = seq_len[a]; rs[u] = ref_start[a]; co[u] = cig_off[a];
         }
-        u64 c_lo[PP_PREP_UNROLL], c_hi[PP_PREP_UNROLL];
+        u64 c_lo[PP_PREP_UNROLL], c_hi[PP_PREP_UNROLL], gb[PP_PREP_UNROLL];
         u32 op0[PP_PREP_UNROLL];
 #pragma unroll
         for (int u = 0; u < PP_PREP_UNROLL; u++) {  // ... then the dependent ones
             const u32 cc = min(c[u], n_contigs - 1u);
-            c_lo[u] = contig_off[cc]; c_hi[u] = contig_off[cc + 1];
+            c_lo[u] = contig_off[cc]; c_hi[u] = contig_off[cc + 1]; gb[u] = g_base[cc];
             op0[u] = nc[u] ? cigar[co[u]] : 0u;
         }
 #pragma unroll
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                 sl[u] <= FAST_MAX_LEN && (u64)rs[u] + sl[u] <= c_hi[u] - c_lo[u]) {
                 // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
                 fast_len = max(fast_len, sl[u]);
-                finish(a, c[u], rs[u], (u32)(c_lo[u] + rs[u]), sl[u], 0u);
+                finish(a, c[u], rs[u], (u32)(gb[u] + rs[u]), sl[u], 0u);
             } else {
                 const u32 slot = atomicAdd(&n_later, 1u);
                 if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);

@@ -333,8 +333,40 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     hipStream_t st = ctx->stream;
     const pp_aln_batch &B = ctx->dbatch;
     const uint64_t n = ctx->have_batch ? B.n_aln : 0;
-    const uint64_t G = ctx->G;
-    const uint32_t nc = ctx->n_contigs;
+    // ---- geometry of this run ----
+    // A context of a sharded job that owns whole contigs (pp_polish_set_emit leaves the others empty) runs over a COMPACT
+    // assembly of just those: k_prep puts a record at its contig's place in it (g_base) and drops the records of the other
+    // contigs, everything behind k_prep only ever sees global positions, and the per-contig results are spread back
+    // over the job's numbering at the end.  One eighth of a 50 Mbp metagenome is then a 6 Mbp job -- single-level
+    // bucketing, scans and grids over 3 K windows instead of 24 K -- and not a 50 Mbp job with seven eighths missing.
+    // Not with --debug records (they are indexed by the job's positions), and not when little would be saved.
+    const uint32_t nc_full = ctx->n_contigs;
+    std::vector<uint64_t> run_off(ctx->contig_off);  // the run's contig table (host copy)
+    std::vector<uint32_t> run_emit(ctx->emit);       // (lo, hi) per contig of the run
+    std::vector<uint64_t> g_base;                    // per contig of the JOB: its start in the run's coordinates, ~0 = not in it
+    ctx->run_full_of.clear();
+    if (!ctx->emit.empty() && !ctx->debug) {
+        uint64_t g_sub = 0;
+        std::vector<uint32_t> owned;
+        for (uint32_t c = 0; c < nc_full; c++)
+            if (ctx->emit[2 * c + 1] > ctx->emit[2 * c]) { owned.push_back(c); g_sub += ctx->contig_off[c + 1] - ctx->contig_off[c]; }
+        if (!owned.empty() && g_sub * 4 <= ctx->G * 3) {
+            g_base.assign(nc_full, ~0ull);
+            run_off.assign(1, 0);
+            run_emit.clear();
+            for (uint32_t c : owned) {
+                g_base[c] = run_off.back();
+                run_off.push_back(run_off.back() + (ctx->contig_off[c + 1] - ctx->contig_off[c]));
+                run_emit.push_back(ctx->emit[2 * c]);
+                run_emit.push_back(ctx->emit[2 * c + 1]);
+            }
+            ctx->run_full_of = owned;
+        }
+    }
+    const bool compact = !ctx->run_full_of.empty();
+    const uint32_t nc = (uint32_t)run_off.size() - 1;
+    const uint64_t G = run_off.back();
+    ctx->run_nc = nc;
     const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
     const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (n + 4095) / 4096));  // k_scan_cols: <= 512
     const uint64_t chunk = (n + NB - 1) / NB;
@@ -389,22 +421,33 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
 
     u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
     u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
-    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;
+    const u64 *d_ctg = (const u64 *)ctx->b_contig_off.p;  // the RUN's contig table (the compact one below, if any)
     uint4 *d_entA = (uint4 *)ctx->b_entA.p, *d_entB = (uint4 *)ctx->b_entB.p;
     u32 *d_ccnt = (u32 *)ctx->b_ccnt.p, *d_coff = (u32 *)ctx->b_coff.p;
 
-    const u32 *d_own = nullptr;  // (lo, hi) per contig this context emits (pp_polish_set_emit), or everything
+    const u32 *d_own = nullptr;       // (lo, hi) per contig of the RUN that this context emits (pp_polish_set_emit), or everything
+    const u32 *d_own_full = nullptr;  // the same per contig of the JOB (k_prep looks records up by the job's contig index)
+    const u64 *d_gbase = d_ctg;       // per contig of the job: where it starts in the run's coordinates
+    const u8 *d_bases = ctx->d_bases;
     // Sharded job: only the windows that touch a range this context emits are worked on.  Their ranges (sorted, merged)
     // follow the (lo, hi) pairs in the same upload: [n_ranges | first window of each | windows before each (n + 1)].
     const u32 *d_own_win = nullptr;
     uint32_t n_own_win = nwin;
     if (!ctx->emit.empty()) {
+        // one upload: [g_base (u64 x job contigs) | run contig table (u64 x nc + 1)] (compact runs only), then the u32 words
+        std::vector<uint64_t> up64;
+        if (compact) {
+            up64.insert(up64.end(), g_base.begin(), g_base.end());
+            up64.insert(up64.end(), run_off.begin(), run_off.end());
+        }
         std::vector<uint32_t> up(ctx->emit);
+        const size_t at_run = up.size();
+        if (compact) up.insert(up.end(), run_emit.begin(), run_emit.end());
         std::vector<std::pair<uint32_t, uint32_t>> rng;  // [first, last] window
         for (uint32_t c = 0; c < nc; c++) {
-            const uint64_t lo = ctx->emit[2 * c], hi = ctx->emit[2 * c + 1];
+            const uint64_t lo = run_emit[2 * c], hi = run_emit[2 * c + 1];
             if (hi <= lo) continue;
-            const uint32_t w0 = (uint32_t)((ctx->contig_off[c] + lo) / TILE), w1 = (uint32_t)((ctx->contig_off[c] + hi - 1) / TILE);
+            const uint32_t w0 = (uint32_t)((run_off[c] + lo) / TILE), w1 = (uint32_t)((run_off[c] + hi - 1) / TILE);
             if (!rng.empty() && w0 <= rng.back().second + 1) rng.back().second = std::max(rng.back().second, w1);
             else rng.emplace_back(w0, w1);
         }
@@ -415,10 +458,25 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         for (auto &r : rng) { up.push_back(before); before += r.second - r.first + 1; }
         up.push_back(before);
         n_own_win = before;
+        const size_t at_full_of = up.size();
+        up.insert(up.end(), ctx->run_full_of.begin(), ctx->run_full_of.end());  // compact run: the job's contig behind each of the run's
+        std::vector<uint8_t> blob(up64.size() * 8 + up.size() * 4);
+        if (!up64.empty()) memcpy(blob.data(), up64.data(), up64.size() * 8);
+        memcpy(blob.data() + up64.size() * 8, up.data(), up.size() * 4);
         const void *p_own = nullptr;
-        if (int rc = upload(ctx, ctx->b_own, up.data(), up.size() * sizeof(uint32_t), &p_own)) return rc;
-        d_own = (const u32 *)p_own;
-        d_own_win = d_own + at;
+        if (int rc = upload(ctx, ctx->b_own, blob.data(), blob.size(), &p_own)) return rc;
+        const u32 *words = (const u32 *)((const u8 *)p_own + up64.size() * 8);
+        d_own_full = words;
+        d_own = compact ? words + at_run : words;
+        d_own_win = words + at;
+        if (compact) {
+            d_gbase = (const u64 *)p_own;
+            d_ctg = d_gbase + nc_full;
+            if (int rc = dev_ensure(ctx, ctx->b_sub_bases, G + 64)) return rc;
+            hipLaunchKernelGGL(k_sub_bases, dim3((unsigned)((G + 8 * 256 - 1) / (8 * 256))), dim3(256), 0, st, ctx->d_bases,
+                               (const u64 *)ctx->b_contig_off.p, d_ctg, nc, words + at_full_of, (u8 *)ctx->b_sub_bases.p, (u64)G);
+            d_bases = (const u8 *)ctx->b_sub_bases.p;
+        }
         // the windows nobody works on emit nothing and have nothing flagged
         PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_winlen.p, 0, (size_t)nwin * 4, st));
         PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_win_nflag.p, 0, (size_t)nwin * 4, st));
@@ -429,11 +487,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     timer_begin(ctx, "prep");
     if (!fused_count)
         hipLaunchKernelGGL(k_prep<false>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
-                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
+                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
+                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_own_full,
                            d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, (u32 *)nullptr, d_status);
     else
         hipLaunchKernelGGL(k_prep<true>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
-                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, d_ctg, nc, d_own,
+                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
+                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_own_full,
                            d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, d_hist, d_status);
     timer_end(ctx);
     timer_begin(ctx, "bucket");
@@ -486,7 +546,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
     T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
     T.n_cig = B.n_cig; T.cigar = B.cigar;
-    T.bases = ctx->d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
+    T.bases = d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
     T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
@@ -539,7 +599,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
-    E.bases = ctx->d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
+    E.bases = d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
     E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
     E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
     E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
@@ -640,17 +700,27 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     }
     const uint32_t *cnt = (const uint32_t *)&meta[1];
     ctx->total_out = meta[5];
-    ctx->contig_out_off.assign(meta.begin() + 16, meta.begin() + 16 + nc + 1);
-    const ContigStatsDev *hs = (const ContigStatsDev *)&meta[17 + nc];
     ctx->n_multi = cnt[1];
     ctx->n_keys = meta[8];
-    ctx->stats.resize(nc);
+    // per-contig results: the run's contigs are the job's, or (compact run) the ones this context owns -- the others
+    // have no bytes and no statistics here
+    const uint32_t rnc = ctx->run_nc;
+    const uint64_t *r_out = &meta[16];
+    const ContigStatsDev *hs = (const ContigStatsDev *)&meta[17 + rnc];
+    ctx->contig_out_off.assign((size_t)nc + 1, 0);
+    ctx->stats.assign(nc, pp_contig_stats{0, 0, 0, 0.0});
+    uint32_t j = 0;  // contigs of the run seen so far
     for (uint32_t c = 0; c < nc; c++) {
-        ctx->stats[c].polished_len = ctx->contig_out_off[c + 1] - ctx->contig_out_off[c];
-        ctx->stats[c].changed = hs[c].changed;
-        ctx->stats[c].zero_depth = hs[c].zero_depth;
-        ctx->stats[c].depth_sum = (double)hs[c].depth_fx / (double)(1u << DEPTH_FX_BITS);
+        ctx->contig_out_off[c] = r_out[j];
+        const bool mine = ctx->run_full_of.empty() || (j < rnc && ctx->run_full_of[j] == c);
+        if (!mine) continue;
+        ctx->stats[c].polished_len = r_out[j + 1] - r_out[j];
+        ctx->stats[c].changed = hs[j].changed;
+        ctx->stats[c].zero_depth = hs[j].zero_depth;
+        ctx->stats[c].depth_sum = (double)hs[j].depth_fx / (double)(1u << DEPTH_FX_BITS);
+        j++;
     }
+    ctx->contig_out_off[nc] = r_out[rnc];
     if (ctx->profiling) {
         timers_collect(ctx, &ctx->last_times);
         ctx->last_times.n_entries = n_entries;
@@ -836,7 +906,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
-                     &ctx->b_win_heavy, &ctx->b_hslab,
+                     &ctx->b_win_heavy, &ctx->b_hslab, &ctx->b_sub_bases,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
                      &ctx->f_insert};
