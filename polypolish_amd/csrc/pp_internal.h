@@ -131,6 +131,7 @@ struct pp_ctx {
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run
+    std::vector<uint8_t> own_blob;      // what b_own holds (emit ranges, window ranges, compact tables), to skip identical uploads
     pp::DevBuf b_sub_bases;             // ... and its assembly bytes
     size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers
     pp::DevBuf b_dbg_depth, b_dbg_counts, b_dbg_status;

@@ -153,8 +153,15 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
     // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40); any order, sorted below ----
     if (tid == 0) *s_n = 0;
     __syncthreads();
-    for (u32 e = e0 + tid; e < e1; e += EXW_THREADS) {
-        const uint4 ent = A.entA[e];
+    constexpr u32 EXW_UNROLL = 4;  // items a thread asks for before it looks at the first (their loads are in flight together)
+    for (u32 eb = e0 + tid; eb < e1; eb += EXW_UNROLL * EXW_THREADS) {
+      uint4 ents[EXW_UNROLL];
+#pragma unroll
+      for (u32 u = 0; u < EXW_UNROLL; u++) ents[u] = A.entA[min(eb + u * EXW_THREADS, e1 - 1u)];
+#pragma unroll
+      for (u32 u = 0; u < EXW_UNROLL; u++) {
+        if (eb + u * EXW_THREADS >= e1) break;
+        const uint4 ent = ents[u];
         const int q = pr - item_rel(ent.z);
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
         const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
@@ -185,6 +192,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
             cov[slot] = v;
         }
+      }
     }
     __syncthreads();
     const u32 n = *s_n;
@@ -259,10 +267,19 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             if (j == 4 && nDel == 0) break;
             if (c5[j] >= v.vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= v.ithr) ni++;
         }
-        // one distinct key after the other, in the order of their first appearance: the lanes compare theirs with it
-        for (u32 i = 0; i < n; i++) {
+        // one distinct key after the other, in the order of their first appearance: the lanes compare theirs with it.
+        // The next key is the first entry that is still open: every lane looks through its own entries (a few), the
+        // wave takes the minimum -- walking all n entries one broadcast read at a time was a third of the kernel.
+        u32 from = 0;
+        for (;;) {
+            u32 mine_first = 0xFFFFFFFFu;
+            for (u32 j = from + lane; j < n; j += 64)
+                if (!(cov[j].y & SL_DONE)) { mine_first = j; break; }
+            for (int o = 32; o > 0; o >>= 1) mine_first = min(mine_first, (u32)__shfl_xor((int)mine_first, o, 64));
+            if (mine_first == 0xFFFFFFFFu) break;
+            const u32 i = mine_first;
+            from = i + 1;
             const u64 yi = cov[i].y;  // (the same word for every lane: one broadcast read)
-            if (yi & SL_DONE) continue;
             const u32 li = (u32)((yi >> 40) & 0x7FFFFFu);
             const u8 *si = A.seq + (yi & SL_OFF_MASK);
             u32 mine = 0;
