@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000,
                     help="bp of one contig given to the CPU oracle (default: the whole 5 Mbp job of config 1, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seq-layout", default="file", choices=["file", "window"],
+                    help="experiments only: 'window' lays the SEQ bytes out window-grouped (tools/synthjob.py window_grouped); "
+                         "the headline is 'file' -- SAM order, what an ingest delivers")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (one GPU)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes (the committed figure is used if the workload matches)")
@@ -350,7 +353,7 @@ def main():
     strong = world > 1 and args.config in (3, 4)
     if args.indel_frac is None:
         args.indel_frac = synthjob.SURVEY_INDEL_READ_FRAC if args.recipe == "survey" else 0.01
-    default_shape = (args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
+    default_shape = (args.seq_layout == "file" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
                      args.repeat_bp == 0 and args.nd_frac == 0.0 and args.genome is None and args.coverage is None)
     # config 1: this rank's own 5 Mbp contig (seed differs per rank); configs 3 / 4 with N > 1: every rank builds
     # the same job and keeps its shard
@@ -368,6 +371,8 @@ def main():
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate, repeat=repeat,
                    repeat_bp=args.repeat_bp, recipe=args.recipe)
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
+    if args.seq_layout == "window":
+        job = synthjob.window_grouped(job)
     if args.nd_frac > 0:
         gg = torch.Generator(device=device)
         gg.manual_seed(7)
@@ -509,7 +514,7 @@ def main():
     # command (N = 1); failing that, the committed figure of the same workload (profiles/traffic.json), else null.
     traffic = traffic_source = None
     if world == 1 and dom_name and not args.no_live_traffic:
-        tail = ["--config", str(args.config), "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
+        tail = ["--config", str(args.config), "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
                 "--n-rate", repr(args.n_rate), "--read-len", str(args.read_len), "--repeat-bp", str(args.repeat_bp), "--nd-frac", repr(args.nd_frac)]
         if args.genome is not None:
             tail += ["--genome", str(args.genome)]
@@ -542,7 +547,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": label + f" alignment records resident in HBM ({job['n_aln']} records"
                                        f"{' in total' if strong else ''}; recipe '{args.recipe}': assembly errors {job['planted']}, "
-                                       f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel)",
+                                       f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel"
+                                       + ("; SEQ bytes WINDOW-GROUPED (experiment, not the headline layout)" if args.seq_layout == "window" else "") + ")",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},

@@ -69,6 +69,7 @@ enum DevErr : uint32_t {
     DE_TOO_DEEP = 10,
     DE_OVERFLOW = 11,
     DE_CAPACITY = 12,       // an optimistic device buffer was too small: the host grows it and reruns
+    DE_HALO = 14,           // compact run (run_pipeline): a record reaches an owned stretch from outside its slice -> rerun uncompacted
     DE_CAPACITY_LATE = 13,  // the same, raised from k_tile on: the work items are valid, so k_tile and k_exact2 keep
                             // COUNTING what they would need (guarded writes) and one rerun is enough
 };
@@ -131,6 +132,9 @@ struct pp_ctx {
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run
+    bool no_compact = false;            // this job is being rerun over the whole assembly (DE_HALO)
+    uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block
+    size_t h_meta_words = 0;
     std::vector<uint8_t> own_blob;      // what b_own holds (emit ranges, window ranges, compact tables), to skip identical uploads
     pp::DevBuf b_sub_bases;             // ... and its assembly bytes
     size_t cap_ent = 0, cap_scr = 0, cap_multi = 0, cap_out = 0, cap_flag = 0, cap_slabs = 0, cap_ents = 0, cap_keys = 0;  // element capacities of the optimistic buffers

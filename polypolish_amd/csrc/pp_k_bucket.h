@@ -167,11 +167,13 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                                                const u32 *__restrict__ seq_len, u32 nwin, u32 ncoarse,
                                                const u32 *__restrict__ hist_c,
                                                const u32 *__restrict__ coarse_off,
-                                               uint4 *__restrict__ entB, u64 *__restrict__ status) {
+                                               uint4 *__restrict__ entB, u32 frange, u64 *__restrict__ status) {
     __shared__ u32 cur[COUNT_RANGE];  // cursors of the coarse buckets of this pass
     if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
-    const u32 crange_lo = blockIdx.y * (u32)COUNT_RANGE;
-    const u32 crange_n = min((u32)COUNT_RANGE, ncoarse - crange_lo);
+    // blockIdx.y: the pass -- frange (<= COUNT_RANGE) columns each.  The blocks of one pass are dispatched together (x runs
+    // fastest), so the lines a pass writes to are few enough to stay in the L2s until they are full (see run_pipeline).
+    const u32 crange_lo = blockIdx.y * frange;
+    const u32 crange_n = min(frange, ncoarse - crange_lo);
     for (u32 i = threadIdx.x; i < crange_n; i += blockDim.x)
         cur[i] = coarse_off[crange_lo + i] + hist_c[(u64)blockIdx.x * ncoarse + crange_lo + i];
     __syncthreads();

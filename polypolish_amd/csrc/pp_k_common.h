@@ -31,8 +31,14 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
 
 // the job's metadata block: word 0 is the status ("no error" = all ones: errors are combined with atomicMin), the
 // counters and sizes behind it start at zero -- one launch where two memsets left a gap between them
-__global__ void k_meta_init(u64 *meta, u32 words) {
-    for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
+__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 n_zero) {
+    if (blockIdx.x == 0) {
+        for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
+        return;
+    }
+    // blocks 1..: 4096 elements of the two arrays each (a sharded job's win_len / win_nflag)
+    const u32 lo = (blockIdx.x - 1u) * 4096u, hi = min(n_zero, lo + 4096u);
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) { zero_a[i] = 0; zero_b[i] = 0; }
 }
 
 __device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {

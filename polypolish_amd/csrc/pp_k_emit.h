@@ -4,11 +4,10 @@
 
 namespace pp {
 
-// The assembly bytes of a compact run (run_pipeline): contig j of the run is contig full_of[j] of the job; eight bytes per
-// thread, one 8-byte load and store where the stretch lies inside one contig.
-__global__ __launch_bounds__(256) void k_sub_bases(const u8 *__restrict__ bases, const u64 *__restrict__ full_off,
-                                                   const u64 *__restrict__ sub_off, u32 n_sub, const u32 *__restrict__ full_of,
-                                                   u8 *__restrict__ out, u64 g_sub) {
+// The assembly bytes of a compact run (run_pipeline): contig j of the run is the stretch of the job's assembly that starts
+// at src_start[j]; eight bytes per thread, one 8-byte load and store where the stretch lies inside one contig.
+__global__ __launch_bounds__(256) void k_sub_bases(const u8 *__restrict__ bases, const u64 *__restrict__ sub_off, u32 n_sub,
+                                                   const u64 *__restrict__ src_start, u8 *__restrict__ out, u64 g_sub) {
     const u64 p0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8ull;
     if (p0 >= g_sub) return;
     u32 lo = 0, hi = n_sub;  // sub_off[lo] <= p0 < sub_off[hi]
@@ -18,13 +17,13 @@ __global__ __launch_bounds__(256) void k_sub_bases(const u8 *__restrict__ bases,
     }
     if (p0 + 8 <= sub_off[lo + 1]) {
         u64 v;
-        __builtin_memcpy(&v, bases + full_off[full_of[lo]] + (p0 - sub_off[lo]), 8);
+        __builtin_memcpy(&v, bases + src_start[lo] + (p0 - sub_off[lo]), 8);
         __builtin_memcpy(out + p0, &v, 8);
         return;
     }
     for (u64 p = p0; p < min(p0 + 8, g_sub); p++) {  // a contig boundary inside the stretch (once per contig)
         while (p >= sub_off[lo + 1]) lo++;
-        out[p] = bases[full_off[full_of[lo]] + (p - sub_off[lo])];
+        out[p] = bases[src_start[lo] + (p - sub_off[lo])];
     }
 }
 

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                                                const u8 *__restrict__ seq,
                                                const u64 *__restrict__ contig_off, u32 n_contigs,
                                                const u64 *__restrict__ g_base,
+                                               const u32 *__restrict__ slice,
                                                const u32 *__restrict__ own,
                                                u32 *__restrict__ gstart, u32 *__restrict__ nkeep,
                                                u32 *__restrict__ maxlen, u32 nwin, u32 cw, u32 ncols,
@@ -150,6 +151,12 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         const u32 span = nkw_span(word);
         if (own && span && c < n_contigs && ((u64)rs + span <= own[2 * c] || rs >= own[2 * c + 1])) word = 0;
         if (c < n_contigs && g_base[c] == ~0ull) word = 0;
+        // compact run: what is kept has to lie inside the stretch of its contig that the run holds (a read longer than
+        // the halo does not: the host reruns the job over the whole assembly)
+        if (slice && word && c < n_contigs && ((u64)rs < slice[2 * c] || (u64)rs + span > slice[2 * c + 1])) {
+            report(status, a, DE_HALO);
+            word = 0;
+        }
         gstart[a] = g_out;
         nkeep[a] = word;
         if (COUNT && word)

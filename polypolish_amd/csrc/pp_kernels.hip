@@ -334,31 +334,47 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const pp_aln_batch &B = ctx->dbatch;
     const uint64_t n = ctx->have_batch ? B.n_aln : 0;
     // ---- geometry of this run ----
-    // A context of a sharded job that owns whole contigs (pp_polish_set_emit leaves the others empty) runs over a COMPACT
-    // assembly of just those: k_prep puts a record at its contig's place in it (g_base) and drops the records of the other
-    // contigs, everything behind k_prep only ever sees global positions, and the per-contig results are spread back
-    // over the job's numbering at the end.  One eighth of a 50 Mbp metagenome is then a 6 Mbp job -- single-level
-    // bucketing, scans and grids over 3 K windows instead of 24 K -- and not a 50 Mbp job with seven eighths missing.
-    // Not with --debug records (they are indexed by the job's positions), and not when little would be saved.
+    // A context of a sharded job runs over a COMPACT assembly of what it owns (pp_polish_set_emit: whole contigs, or one
+    // stretch of a tiled contig plus a halo of HALO positions either side, where the reads that reach in from the
+    // neighbours lie): k_prep puts a record at its contig's place in it (g_base) and drops the records of the other
+    // contigs, everything behind k_prep only ever sees global positions, and the per-contig results are spread back over
+    // the job's numbering at the end.  One eighth of a 50 Mbp metagenome is then a 6 Mbp job, one eighth of a 250 Mbp
+    // contig a 31 Mbp job -- single-level bucketing, scans and grids over an eighth of the windows -- and not the whole
+    // assembly with seven eighths missing.  A record that reaches an owned stretch but does not lie inside its slice
+    // (a read longer than the halo) makes k_prep raise DE_HALO: the job is then rerun uncompacted.  Not with --debug
+    // records (they are indexed by the job's positions), and not when little would be saved.
+    constexpr uint64_t HALO = 16384;
     const uint32_t nc_full = ctx->n_contigs;
     std::vector<uint64_t> run_off(ctx->contig_off);  // the run's contig table (host copy)
     std::vector<uint32_t> run_emit(ctx->emit);       // (lo, hi) per contig of the run
-    std::vector<uint64_t> g_base;                    // per contig of the JOB: its start in the run's coordinates, ~0 = not in it
+    std::vector<uint64_t> g_base;                    // per contig of the JOB: where its position 0 falls in the run's coordinates, ~0 = not in it
+    std::vector<uint64_t> src_start;                 // per contig of the RUN: where its bytes start in the job's assembly
+    std::vector<uint32_t> slice;                     // per contig of the JOB: [lo, hi) of it that the run holds
     ctx->run_full_of.clear();
-    if (!ctx->emit.empty() && !ctx->debug) {
+    if (!ctx->emit.empty() && !ctx->debug && !ctx->no_compact) {
         uint64_t g_sub = 0;
         std::vector<uint32_t> owned;
-        for (uint32_t c = 0; c < nc_full; c++)
-            if (ctx->emit[2 * c + 1] > ctx->emit[2 * c]) { owned.push_back(c); g_sub += ctx->contig_off[c + 1] - ctx->contig_off[c]; }
+        slice.assign(2 * (size_t)nc_full, 0);
+        for (uint32_t c = 0; c < nc_full; c++) {
+            const uint64_t lo = ctx->emit[2 * c], hi = ctx->emit[2 * c + 1], len = ctx->contig_off[c + 1] - ctx->contig_off[c];
+            if (hi <= lo) continue;
+            const uint64_t slo = lo > HALO ? lo - HALO : 0, shi = std::min(len, hi + HALO);
+            slice[2 * c] = (uint32_t)slo;
+            slice[2 * c + 1] = (uint32_t)shi;
+            owned.push_back(c);
+            g_sub += shi - slo;
+        }
         if (!owned.empty() && g_sub * 4 <= ctx->G * 3) {
             g_base.assign(nc_full, ~0ull);
             run_off.assign(1, 0);
             run_emit.clear();
             for (uint32_t c : owned) {
-                g_base[c] = run_off.back();
-                run_off.push_back(run_off.back() + (ctx->contig_off[c + 1] - ctx->contig_off[c]));
-                run_emit.push_back(ctx->emit[2 * c]);
-                run_emit.push_back(ctx->emit[2 * c + 1]);
+                const uint64_t slo = slice[2 * c], shi = slice[2 * c + 1];
+                g_base[c] = run_off.back() - slo;  // (wraps below zero for a slice that does not start at the contig's start: only ever added to a start >= slo)
+                src_start.push_back(ctx->contig_off[c] + slo);
+                run_off.push_back(run_off.back() + (shi - slo));
+                run_emit.push_back((uint32_t)(ctx->emit[2 * c] - slo));
+                run_emit.push_back((uint32_t)(ctx->emit[2 * c + 1] - slo));
             }
             ctx->run_full_of = owned;
         }
@@ -392,7 +408,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const bool two_level = forced_levels ? forced_levels == 2 : nranges > 1;
     const uint32_t cw = !two_level ? 1 : (nwin >= COARSE_BIG_FROM ? COARSE_WINDOWS_BIG : COARSE_WINDOWS);
     const uint32_t ncoarse = (nwin + cw - 1) / cw;
-    const uint32_t ncranges = (ncoarse + COUNT_RANGE - 1) / COUNT_RANGE;
+    // columns (windows, or coarse buckets) per pass of k_fill: PP_FILL_RANGE (tuning), default one LDS range
+    static const long forced_frange = getenv("PP_FILL_RANGE") ? atol(getenv("PP_FILL_RANGE")) : 0;
+    const uint32_t frange = forced_frange > 0 ? (uint32_t)std::min<long>(forced_frange, COUNT_RANGE) : (uint32_t)COUNT_RANGE;
+    const uint32_t ncranges = (ncoarse + frange - 1) / frange;
     ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
     ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
     if (two_level) ENS(b_entB, ctx->cap_ent * 16);
@@ -410,7 +429,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     u32 *d_counters = (u32 *)(d_meta + 1);
     u64 *d_ctg_out = d_meta + 16;
     ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
-    hipLaunchKernelGGL(k_meta_init, dim3(1), dim3(256), 0, st, d_meta, (u32)meta_words);  // zeros, status word = "no error"
+    // zeros, status word = "no error"; a sharded job also gets its per-window output lengths and flag counts zeroed (the
+    // windows nobody works on emit nothing and have nothing flagged) -- one launch instead of a kernel and two memsets
+    {
+        const bool sharded = !ctx->emit.empty();
+        hipLaunchKernelGGL(k_meta_init, dim3(sharded ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
+                           sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr, nwin);
+    }
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
     u8 *d_win_heavy = (u8 *)ctx->b_win_heavy.p;
     // A window is heavy from 1.5x the average number of records per window on (a few per cent below the items).  In a job
@@ -430,6 +455,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const u32 *d_own = nullptr;       // (lo, hi) per contig of the RUN that this context emits (pp_polish_set_emit), or everything
     const u32 *d_own_full = nullptr;  // the same per contig of the JOB (k_prep looks records up by the job's contig index)
     const u64 *d_gbase = d_ctg;       // per contig of the job: where it starts in the run's coordinates
+    const u32 *d_slice = nullptr;     // compact run: [lo, hi) of every contig of the job that the run holds
     const u8 *d_bases = ctx->d_bases;
     // Sharded job: only the windows that touch a range this context emits are worked on.  Their ranges (sorted, merged)
     // follow the (lo, hi) pairs in the same upload: [n_ranges | first window of each | windows before each (n + 1)].
@@ -441,6 +467,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         if (compact) {
             up64.insert(up64.end(), g_base.begin(), g_base.end());
             up64.insert(up64.end(), run_off.begin(), run_off.end());
+            up64.insert(up64.end(), src_start.begin(), src_start.end());
         }
         std::vector<uint32_t> up(ctx->emit);
         const size_t at_run = up.size();
@@ -460,8 +487,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         for (auto &r : rng) { up.push_back(before); before += r.second - r.first + 1; }
         up.push_back(before);
         n_own_win = before;
-        const size_t at_full_of = up.size();
-        up.insert(up.end(), ctx->run_full_of.begin(), ctx->run_full_of.end());  // compact run: the job's contig behind each of the run's
+        const size_t at_slice = up.size();
+        if (compact) up.insert(up.end(), slice.begin(), slice.end());  // compact run: the stretch of every contig of the job that the run holds
         std::vector<uint8_t> blob(up64.size() * 8 + up.size() * 4);
         if (!up64.empty()) memcpy(blob.data(), up64.data(), up64.size() * 8);
         memcpy(blob.data() + up64.size() * 8, up.data(), up.size() * 4);
@@ -478,14 +505,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         if (compact) {
             d_gbase = (const u64 *)p_own;
             d_ctg = d_gbase + nc_full;
+            d_slice = words + at_slice;
             if (int rc = dev_ensure(ctx, ctx->b_sub_bases, G + 64)) return rc;
             hipLaunchKernelGGL(k_sub_bases, dim3((unsigned)((G + 8 * 256 - 1) / (8 * 256))), dim3(256), 0, st, ctx->d_bases,
-                               (const u64 *)ctx->b_contig_off.p, d_ctg, nc, words + at_full_of, (u8 *)ctx->b_sub_bases.p, (u64)G);
+                               d_ctg, nc, d_ctg + nc + 1, (u8 *)ctx->b_sub_bases.p, (u64)G);
             d_bases = (const u8 *)ctx->b_sub_bases.p;
         }
-        // the windows nobody works on emit nothing and have nothing flagged
-        PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_winlen.p, 0, (size_t)nwin * 4, st));
-        PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_win_nflag.p, 0, (size_t)nwin * 4, st));
+        // (the windows nobody works on emit nothing and have nothing flagged: k_meta_init zeroes win_len / win_nflag)
     }
     // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
     // records of every block per window (two-level path: k_count, per range of windows)
@@ -494,12 +520,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     if (!fused_count)
         hipLaunchKernelGGL(k_prep<false>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
                            (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
-                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_own_full,
+                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full,
                            d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, (u32 *)nullptr, d_status);
     else
         hipLaunchKernelGGL(k_prep<true>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
                            (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
-                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_own_full,
+                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full,
                            d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, d_hist, d_status);
     timer_end(ctx);
     timer_begin(ctx, "bucket");
@@ -520,14 +546,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
             if (n)
                 hipLaunchKernelGGL(k_fill<COARSE_WINDOWS_BIG>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk,
                                    d_gstart, d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse,
-                                   (const u32 *)d_hist, (const u32 *)d_coff, d_entB, d_status);
+                                   (const u32 *)d_hist, (const u32 *)d_coff, d_entB, frange, d_status);
             hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS_BIG>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
                                (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         } else {
             if (n)
                 hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
                                    d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
-                                   (const u32 *)d_coff, d_entB, d_status);
+                                   (const u32 *)d_coff, d_entB, frange, d_status);
             hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
                                (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         }
@@ -544,7 +570,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         if (n)
             hipLaunchKernelGGL(k_fill<1>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
                                B.k, (const u64 *)B.seq_off, B.seq_len, nwin, nwin, (const u32 *)d_hist,
-                               (const u32 *)d_winoff, d_entA, d_status);
+                               (const u32 *)d_winoff, d_entA, frange, d_status);
     }
     timer_end(ctx);
 
@@ -633,9 +659,18 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     timer_end(ctx);
     PP_HIPCHK(ctx, hipGetLastError());
 
-    meta.resize(meta_words);
-    PP_HIPCHK(ctx, hipMemcpyAsync(meta.data(), d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
+    // the job's one read-back, into pinned memory (a copy into pageable memory goes through the runtime's staging buffer
+    // and keeps the host waiting for longer than the GPU needs)
+    if (ctx->h_meta_words < meta_words) {
+        if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+        ctx->h_meta = nullptr;
+        ctx->h_meta_words = 0;
+        PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocDefault));
+        ctx->h_meta_words = meta_words + 64;
+    }
+    PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    meta.assign(ctx->h_meta, ctx->h_meta + meta_words);
     *n_entries_out = (uint32_t)meta[3];
     return PP_OK;
 }
@@ -676,12 +711,17 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     std::vector<uint64_t> meta;
     uint32_t n_entries = 0;
     int attempt = 0;
+    ctx->no_compact = false;
     for (;; attempt++) {
         timers_release(ctx);
         int rc = run_pipeline(ctx, meta, &n_entries);
         if (rc) return rc;
         const uint64_t key = meta[0];
         if (key == ~0ull) break;
+        if ((key & 0xFF) == DE_HALO && !ctx->no_compact) {  // a read longer than the halo of a compact run: run over the whole assembly
+            ctx->no_compact = true;
+            continue;
+        }
         if ((key & 0xFF) != DE_CAPACITY && (key & 0xFF) != DE_CAPACITY_LATE) return map_device_error(ctx, key);
         if (attempt >= 6) return ctx->fail(PP_ERR_HIP, "device buffers kept overflowing after %d attempts", attempt);
         // grow whatever was too small (sizes the device got to before it stopped), then rerun
@@ -921,6 +961,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     for (auto &b : ctx->b_split) dev_free(b);
     for (auto &f : ctx->f_in) for (auto &b : f) dev_free(b);
     timers_release(ctx);
+    if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -475,6 +475,42 @@ def test_window_tiled_contig_equals_unsharded(ctx, pp, orc, world):
     assert data == want["polished"] and np.array_equal(out_off, want["offsets"])
 
 
+@pytest.mark.parametrize("long_read", [False, True])
+def test_compact_runs_of_sharded_jobs(ctx, pp, orc, long_read):
+    """A context of a sharded job runs over a compact assembly of what it owns: whole contigs, and -- on a tiled contig --
+    its stretch plus a halo (run_pipeline).  Three ranks over a 400 kbp contig in three windows and two small contigs:
+    every rank's part (pp_shard_split) and also ALL records with its emit ranges give the bytes whose assembly is the
+    oracle's unsharded polish.  long_read: a 20,000-base alignment across the first cut is longer than the halo -- the
+    device notices (DE_HALO) and the job is rerun over the whole assembly, with the same result."""
+    contig_off, bases, recs = synth.fast_records(seed=67, contig_lens=(400_000, 3_000, 60_000), coverage=12, read_len=100,
+                                                 k_choices=(1, 1, 2, 3), indel_read_frac=0.2, n_rate=0.003)
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=3), 3, 65536)
+    assert (plan.unit_contig == 0).sum() == 3
+    if long_read:
+        cut = int(plan.unit_hi[0])
+        rng = np.random.default_rng(1)
+        n_long = 20_000
+        extra = {"contig": np.array([0], np.uint32), "ref_start": np.array([cut - 18_000], np.uint32), "k": np.array([1], np.uint32),
+                 "seq_off": np.array([0], np.uint64), "seq_len": np.array([n_long], np.uint32), "cig_off": np.array([0], np.uint64),
+                 "n_cig": np.array([1], np.uint32), "seq": np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_long)].copy(),
+                 "cigar": np.array([(n_long << 4) | 0], np.uint32)}
+        recs = synth.merge_records(recs, extra, seed=3)
+    want = orc.polish_records(contig_off, bases, recs)
+    for parts in (True, False):
+        rank_bytes, rank_offs = [], []
+        for rank in range(3):
+            mine = pp.shard_split_host(plan, rank, recs)[0] if parts else recs
+            got = ctx.polish_records(contig_off, bases, mine, emit=plan.emit_ranges(rank))
+            rank_bytes.append(got["polished"])
+            rank_offs.append(got["offsets"])
+            owned = plan.emit_ranges(rank)
+            for c in range(3):  # a contig the rank has no unit of has no bytes there
+                if owned[c, 1] == owned[c, 0]:
+                    assert got["offsets"][c + 1] == got["offsets"][c]
+        data, out_off = plan.assemble(rank_bytes, rank_offs)
+        assert data == want["polished"] and np.array_equal(out_off, want["offsets"]), parts
+
+
 def test_multi_process_driver_on_one_gpu(orc, tmp_path):
     """`python -m polypolish_amd.distributed polish` with two ranks sharing this GPU (gloo gather): the
     one-process-per-GPU driver end to end, contigs and windows sharded, FASTA identical."""

@@ -390,6 +390,29 @@ def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=
             "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi]}
 
 
+def window_grouped(job, window=2048):
+    """The same job with the SEQ bytes laid out WINDOW-GROUPED: the reads of one 2048-position window are adjacent in the
+    seq array (windows in order, file order inside a window); every other array -- and the order of the records -- is
+    unchanged, seq_off simply points there.  The C ABI allows any seq_off, so this is not a new batch format but a choice
+    the producer of a batch has (an ingest that knows the windows could write its SEQ bytes this way): the layout probe
+    of DESIGN.md section 9."""
+    r = job["recs"]
+    L = job["read_len"]
+    n = job["n_aln"]
+    dev = r["seq"].device
+    win = job["gstart"] // window
+    order = torch.argsort(win, stable=True)           # records by window, file order inside
+    slot = torch.empty(n, dtype=torch.int64, device=dev)
+    slot[order] = torch.arange(n, device=dev)
+    out = dict(job)
+    out.pop("_prepared", None)
+    recs = dict(r)
+    recs["seq"] = r["seq"].view(n, L)[order].reshape(-1).contiguous()
+    recs["seq_off"] = (slot * L).contiguous()
+    out["recs"] = recs
+    return out
+
+
 def recovered(job, polished, offs, margin=1000, count=False):
     """Did the polish turn the assembly back into the truth?  Contig by contig (their lengths change where indels were
     repaired), ignoring `margin` bp at either end, where coverage runs out and nothing was planted, and the repeat
