@@ -153,7 +153,7 @@ def live_traffic(argv_tail, kernel):
         d = tempfile.mkdtemp(prefix="pp_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-live-traffic"] + argv_tail
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-live-traffic", "--no-second-layout"] + argv_tail
             r = subprocess.run(cmd, capture_output=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             if r.returncode != 0:
                 return None
@@ -237,6 +237,16 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
         out["oracle_polish"] = {"wall_s": round(t_cpu, 2), "mbp_per_s": round(genome / 1e6 / t_cpu, 4), "cores": 1,
                                 "sha256": want[:16]}
         out["speedup_polish"] = round(t_cpu / min(t for t in (t_dev, t_host) if t is not None), 1)
+        if not big:
+            # the tokenizer's other SEQ layout (window-grouped): same bytes out; what it costs the
+            # tokenizer is read off its own stage timer
+            env["PP_DEVICE_INGEST"] = "1"
+            t_win, r_win = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="window", PP_TIMING="1"), repeat=rep)
+            if t_win is not None:
+                extra = sum(float(l.split()[-2]) for l in r_win.stderr.decode(errors="replace").splitlines()
+                            if l.startswith("[timing]") and "window layout" in l)
+                out["polish_window_grouped_seq"] = {"wall_s": round(t_win, 3), "parity": sha(r_win.stdout) == want,
+                                                    "tokenizer_extra_ms": round(1e3 * extra, 2)}
         ok = out["polish"]["parity"] and out.get("polish_host_ingest", {}).get("parity", True)
         del r_dev, r_host, r_cpu
         if not big:
@@ -302,6 +312,7 @@ def main():
     ap.add_argument("--seq-layout", default="file", choices=["file", "window"],
                     help="experiments only: 'window' lays the SEQ bytes out window-grouped (tools/synthjob.py window_grouped); "
                          "the headline is 'file' -- SAM order, what an ingest delivers")
+    ap.add_argument("--no-second-layout", action="store_true", help="skip the second roofline entry (window-grouped SEQ bytes)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (one GPU)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes (the committed figure is used if the workload matches)")
@@ -532,6 +543,41 @@ def main():
         if traffic is not None:
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
+    second = None
+    if world == 1 and args.seq_layout == "file" and not args.no_second_layout:
+        # The same job with its SEQ bytes window-grouped (what the tokenizer writes with PP_SEQ_WINDOW_GROUPED): a second
+        # roofline entry beside the headline's file order, measured the same way; what the layout costs the tokenizer is in
+        # the e2e block (polish_window_grouped_seq.tokenizer_extra_ms).
+        wj = synthjob.window_grouped(job)
+        ctx.set_profiling(0)
+        for _ in range(args.warmup):
+            run_job(ctx, pp, wj)
+        ctx.set_profiling(2)
+        w_ms = []
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            run_job(ctx, pp, wj)
+            kt = ctx.kernel_times()["ms"]
+            if kt:
+                w_ms.append(next(iter(kt.values())))
+        ctx.sync()
+        torch.cuda.synchronize()
+        w_step = 1e3 * (time.perf_counter() - tw) / args.steps
+        ctx.set_profiling(0)
+        w_polished, _, _ = ctx.result()
+        w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
+        w_traffic = None
+        if dom_name and not args.no_live_traffic:
+            lt = live_traffic(["--config", str(args.config), "--seq-layout", "window", "--recipe", args.recipe,
+                               "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
+            w_traffic = lt["hbm_bytes"] if lt else None
+        second = {"layout": "SEQ bytes window-grouped (pp_dev_ingest_set_seq_layout; every other array and every result unchanged)",
+                  "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(w_kernel, 4),
+                  "achieved": round(b_alg / (w_kernel * 1e-3) / 1e9, 1) if w_kernel else 0.0, "peak": peak, "unit": "GB/s",
+                  "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
+                  "ms_per_step": round(w_step, 4), "same_polished_bytes": bool(w_polished == polished)}
+        del wj
     out = {
         "metric": METRIC,
         "value": round(value, 2),
@@ -556,6 +602,7 @@ def main():
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
+        "roofline_window_grouped_seq": second,
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
         "work": work,
         "planted_errors_recovered": recovered,

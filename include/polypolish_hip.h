@@ -426,6 +426,16 @@ int pp_dev_ingest_sam(pp_dev_ingest *g, const char *path, pp_sam_counts *counts)
 /* with the filter's verdicts, as pp_ingest_sam_filtered (pass: HOST array over the file's aligned records) */
 int pp_dev_ingest_sam_filtered(pp_dev_ingest *g, const char *path, const uint8_t *pass, uint64_t n_pass,
                                pp_sam_counts *counts);
+/* How the batch's SEQ bytes are laid out (seq_off may point anywhere, so this is the producer's choice, not a format):
+ * PP_SEQ_FILE_ORDER (default) = in the order of the records; PP_SEQ_WINDOW_GROUPED = the reads that start in one
+ * 2048-position window of the assembly are adjacent (per SAM file) -- the pileup kernel then fetches a window's reads
+ * from one stretch of memory instead of all over the array (1.2 GB moved instead of 2.1 GB on a 5 Mbp / 200x job,
+ * k_tile 17 % faster) at the price of a count / scan / placement pass in the tokenizer.  Every other array, the order of
+ * the records and every result are the same.  Set before the first pp_dev_ingest_sam*; `PP_SEQ_LAYOUT=window` in the
+ * environment selects it for the file drivers. */
+#define PP_SEQ_FILE_ORDER 0
+#define PP_SEQ_WINDOW_GROUPED 1
+int pp_dev_ingest_set_seq_layout(pp_dev_ingest *g, int layout);
 void pp_dev_ingest_batch(const pp_dev_ingest *g, pp_aln_batch *out); /* borrowed view, DEVICE memory */
 void pp_dev_ingest_free(pp_dev_ingest *g);
 

@@ -125,7 +125,7 @@ EXPORTS = [
     "pp_shard_plan_create", "pp_shard_plan_free", "pp_shard_emit_ranges", "pp_shard_assemble",
     "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather", "pp_polish_files_multi",
     "pp_shard_split", "pp_shard_part_batch", "pp_shard_part_mem", "pp_shard_part_free", "pp_shard_count",
-    "pp_polish_error_record", "pp_polish_error_text",
+    "pp_polish_error_record", "pp_polish_error_text", "pp_dev_ingest_set_seq_layout",
 ]
 
 _lib = None
@@ -217,6 +217,7 @@ def lib():
         L.pp_dev_ingest_create.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
         L.pp_dev_ingest_sam.argtypes = [vp, C.c_char_p, C.POINTER(SamCounts)]
         L.pp_dev_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts)]
+        L.pp_dev_ingest_set_seq_layout.argtypes = [vp, C.c_int]
         L.pp_dev_ingest_batch.argtypes = [vp, C.POINTER(AlnBatch)]
         L.pp_dev_ingest_batch.restype = None
         L.pp_dev_ingest_free.argtypes = [vp]
@@ -318,8 +319,9 @@ def ingest(assembly, sams, max_errors=10, careful=False):
         L.pp_assembly_free(a)
 
 
-def ingest_device(ctx, assembly, sams, max_errors=10, careful=False):
-    """The device tokenizer (pp_dev_ingest_*): same return value as ingest(), the records copied back from HBM."""
+def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=0):
+    """The device tokenizer (pp_dev_ingest_*): same return value as ingest(), the records copied back from HBM.
+    seq_layout: 0 = SEQ bytes in file order, 1 = window-grouped (pp_dev_ingest_set_seq_layout)."""
     L = lib()
     err = C.create_string_buffer(1024)
     a = C.c_void_p()
@@ -334,6 +336,7 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False):
         off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,)).copy()
         bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),)).copy()
         ctx._chk(L.pp_dev_ingest_create(ctx._h, a, max_errors, int(careful), C.byref(g)))
+        ctx._chk(L.pp_dev_ingest_set_seq_layout(g, int(seq_layout)))
         counts = []
         for s in sams:
             c = SamCounts()

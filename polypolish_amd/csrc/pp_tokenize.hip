@@ -325,6 +325,31 @@ __global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, co
     }
 }
 
+// ---- window-grouped SEQ layout (pp_dev_ingest_set_seq_layout) ----------------------------------------
+// Where a good record's SEQ bytes go when the reads of one 2048-position window are to be adjacent in the seq array: the
+// bytes per window are counted, scanned, and every record takes its stretch of its window's region with an atomic
+// (the order inside a window is whatever the atomics make it: seq_off goes with the record, nothing depends on it).
+__global__ __launch_bounds__(256) void k_tok_win_bytes(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
+                                                       const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
+                                                       const u64 *__restrict__ ctg_off, u32 n_win, u32 *__restrict__ wbytes) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln || !good[r]) return;
+    const LineRec &a = rec[rec_line[r]];
+    const u64 w = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
+    atomicAdd(&wbytes[w < n_win ? (u32)w : n_win - 1u], g_seq_len[r]);
+}
+__global__ __launch_bounds__(256) void k_tok_win_place(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
+                                                       const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
+                                                       const u64 *__restrict__ ctg_off, u32 n_win, const u64 *__restrict__ wbase,
+                                                       u32 *__restrict__ wcur, u64 *__restrict__ seq_pos) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln || !good[r]) return;
+    const LineRec &a = rec[rec_line[r]];
+    const u64 w0 = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
+    const u32 w = w0 < n_win ? (u32)w0 : n_win - 1u;
+    seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], g_seq_len[r]);
+}
+
 __global__ __launch_bounds__(256) void k_tok_cigar(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
                                                    const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
                                                    u32 n_aln, const u32 *__restrict__ good,
@@ -356,8 +381,10 @@ struct pp_dev_ingest {
     u32 max_errors;
     int careful;
     // contig table
-    pp::DevBuf t_slots, t_off, t_names;
+    pp::DevBuf t_slots, t_off, t_names, t_ctgoff;
     u32 t_mask = 0;
+    int seq_layout = PP_SEQ_FILE_ORDER;
+    pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos;
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
         d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
@@ -403,6 +430,10 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
     int rc = pp::dev_ensure(ctx, D->t_slots, cap * 4);
     if (!rc) rc = pp::dev_ensure(ctx, D->t_off, (nc + 1) * 4);
     if (!rc) rc = pp::dev_ensure(ctx, D->t_names, names.size() + 16);
+    if (!rc) rc = pp::dev_ensure(ctx, D->t_ctgoff, ((size_t)nc + 1) * 8);
+    if (!rc && hipMemcpy(D->t_ctgoff.p, pp_assembly_offsets(a), ((size_t)nc + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = ctx->fail(PP_ERR_HIP, "uploading the contig offsets failed");
+    if (const char *e = getenv("PP_SEQ_LAYOUT")) D->seq_layout = !strcmp(e, "window") ? PP_SEQ_WINDOW_GROUPED : PP_SEQ_FILE_ORDER;
     if (!rc && (hipMemcpy(D->t_slots.p, slots.data(), cap * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(D->t_off.p, off.data(), (nc + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 (names.size() && hipMemcpy(D->t_names.p, names.data(), names.size(), hipMemcpyHostToDevice) != hipSuccess)))
@@ -415,13 +446,19 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
 extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     if (!D) return;
     (void)hipStreamSynchronize(D->ctx->stream);
-    pp::DevBuf *all[] = {&D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
+    pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
                          &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
                          &D->o_cig_off, &D->o_seq};
     for (pp::DevBuf *b : all) pp::dev_free(*b);
     delete D;
+}
+
+extern "C" int pp_dev_ingest_set_seq_layout(pp_dev_ingest *D, int layout) {
+    if (!D || (layout != PP_SEQ_FILE_ORDER && layout != PP_SEQ_WINDOW_GROUPED)) return PP_ERR_ARG;
+    D->seq_layout = layout;
+    return PP_OK;
 }
 
 extern "C" void pp_dev_ingest_batch(const pp_dev_ingest *D, pp_aln_batch *out) {
@@ -659,13 +696,32 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
 #undef GROW
     OutArrays O{(u32 *)D->o_contig.p, (u32 *)D->o_ref_start.p, (u32 *)D->o_k.p, (u32 *)D->o_seq_len.p, (u32 *)D->o_n_cig.p,
                 (u32 *)D->o_cigar.p, (u64 *)D->o_seq_off.p, (u64 *)D->o_cig_off.p, (u8 *)D->o_seq.p};
+    // where every good record's SEQ bytes go inside this file's stretch of the seq array: in file order (the scan), or
+    // window-grouped
+    const u64 *seq_place = (const u64 *)D->d_seqscan.p;
+    if (D->seq_layout == PP_SEQ_WINDOW_GROUPED) {
+        const u64 G = pp_assembly_offsets(D->asmb)[pp_assembly_n_contigs(D->asmb)];
+        const u32 n_win = (u32)((G + pp::TILE - 1) / pp::TILE);
+        ENS(d_wbytes, ((u64)n_win + 1) * 4); ENS(d_wbase, ((u64)n_win + 1) * 8); ENS(d_wcur, (u64)n_win * 4); ENS(d_seqpos, (u64)n_aln * 8);
+        PP_HIPCHK(ctx, hipMemsetAsync(D->d_wbytes.p, 0, ((size_t)n_win + 1) * 4, st));
+        PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 4, st));
+        hipLaunchKernelGGL(k_tok_win_bytes, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
+                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                           (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_wbytes.p);
+        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
+        hipLaunchKernelGGL(k_tok_win_place, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
+                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                           (const u64 *)D->t_ctgoff.p, n_win, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
+        seq_place = (const u64 *)D->d_seqpos.p;
+        lap("window layout");
+    }
     hipLaunchKernelGGL(k_tok_meta, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
                        (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_k.p,
-                       (const u32 *)D->d_gseq.p, (const u32 *)D->d_outidx.p, (const u64 *)D->d_seqscan.p,
+                       (const u32 *)D->d_gseq.p, (const u32 *)D->d_outidx.p, seq_place,
                        (const u64 *)D->d_cigscan.p, O, no, D->seq_bytes, D->n_cig_total);
     hipLaunchKernelGGL(k_tok_seq, dim3((unsigned)(((u64)n_aln * 8 + 255) / 256)), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
-                       (const u32 *)D->d_src.p, (const u64 *)D->d_seqscan.p, O.seq, D->seq_bytes);
+                       (const u32 *)D->d_src.p, seq_place, O.seq, D->seq_bytes);
     hipLaunchKernelGGL(k_tok_cigar, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
                        (const u64 *)D->d_cigscan.p, O.cigar, D->n_cig_total);

@@ -511,6 +511,41 @@ def test_compact_runs_of_sharded_jobs(ctx, pp, orc, long_read):
         assert data == want["polished"] and np.array_equal(out_off, want["offsets"]), parts
 
 
+def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
+    """pp_dev_ingest_set_seq_layout(PP_SEQ_WINDOW_GROUPED): the tokenizer writes the SEQ bytes of the reads that start in
+    one 2048-position window next to each other (per SAM file).  Every record array but seq_off equals the host ingest's,
+    every record's bytes are its bytes, the windows come in order inside a file's stretch of the seq array, and the
+    polish of that batch -- and the CLI with PP_SEQ_LAYOUT=window -- gives the oracle's bytes (repeats with SEQ '*'
+    records on both strands, indels, several contigs)."""
+    ds = synth.rich_dataset(str(tmp_path), seed=97, contig_lens=(30_000, 2_500, 9_000), coverage=25, repeat_len=300,
+                            repeat_copies=3, lowercase_frac=0.1)
+    sams = [ds["sam1"], ds["sam2"]]
+    _, _, off, bases, want, counts = pp.ingest(ds["fasta"], sams)
+    _, _, off2, bases2, got, counts2 = pp.ingest_device(ctx, ds["fasta"], sams, seq_layout=1)
+    assert counts == counts2 and np.array_equal(off, off2) and np.array_equal(bases, bases2)
+    for k in ("contig", "ref_start", "k", "seq_len", "cig_off", "n_cig", "cigar"):
+        assert np.array_equal(want[k], got[k]), k
+    assert len(got["seq"]) == len(want["seq"]) and not np.array_equal(got["seq_off"], want["seq_off"])
+    so_w, so_g, sl = want["seq_off"].astype(np.int64), got["seq_off"].astype(np.int64), want["seq_len"].astype(np.int64)
+    for i in list(range(0, len(sl), 37)) + [len(sl) - 1]:
+        assert bytes(got["seq"][so_g[i]:so_g[i] + sl[i]]) == bytes(want["seq"][so_w[i]:so_w[i] + sl[i]]), i
+    covered = np.zeros(len(got["seq"]) + 1, dtype=np.int64)   # the records' stretches tile the seq array exactly
+    np.add.at(covered, so_g, 1)
+    np.add.at(covered, so_g + sl, -1)
+    assert (np.cumsum(covered)[:-1] == 1).all()
+    n1 = counts[0][1]                                        # good records of file 1: their stretch comes first
+    win = (off[got["contig"]].astype(np.int64) + got["ref_start"].astype(np.int64)) // 2048
+    for lo, hi in ((0, n1), (n1, len(sl))):
+        order = np.argsort(so_g[lo:hi], kind="stable")
+        assert (np.diff(win[lo:hi][order]) >= 0).all(), "inside a file's stretch the windows come in order"
+    assert so_g[:n1].max() < so_g[n1:].min()
+    res = ctx.polish_records(off, bases, got)
+    assert res["polished"] == orc.polish_records(off, bases, want)["polished"]
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, PP_SEQ_LAYOUT="window"))
+    assert r.returncode == 0 and r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"], r.stderr[-400:]
+
+
 def test_multi_process_driver_on_one_gpu(orc, tmp_path):
     """`python -m polypolish_amd.distributed polish` with two ranks sharing this GPU (gloo gather): the
     one-process-per-GPU driver end to end, contigs and windows sharded, FASTA identical."""

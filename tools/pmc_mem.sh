@@ -5,7 +5,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_mem
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-live-traffic"
+BENCH="python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-live-traffic --no-second-layout"
 MB="$ROOT/tools/microbench/gather"
 cd /tmp
 i=0

@@ -6,7 +6,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic --no-second-layout"
 cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/sq1 -- $BENCH > /dev/null 2> "$OUT/sq1.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d /tmp/sq2 -- $BENCH > /dev/null 2> "$OUT/sq2.log"

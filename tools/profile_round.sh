@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic --no-second-layout"
 cd /tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.log"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- $BENCH > /dev/null 2> "$OUT/fetch.log"
