@@ -558,7 +558,8 @@ constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket;
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty;
+    __shared__ unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below)
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
 
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         if (tid < (u32)ASM_PAD) ab[tid] = 0;
         if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
-    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; }
+    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; }
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
         if (lane == 0) { if (wave == 0) s_c0 = cw; else s_c1 = cw; }
@@ -738,21 +739,58 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     }
     __syncthreads();
 
-    // ---- vote: one lane per position ----
+    // ---- vote ----
+    // Pass 1, one lane per position: a position where NOTHING was tallied explicitly -- every read that covers it shows
+    // the assembly's own A/C/G/T there (no mismatch, no indel, no shared or odd depth share) -- needs no vote: the
+    // assembly's base is the only key with a count, its count is the depth, and whatever pileup.rs:67-134 makes of that
+    // (kept, low depth, or with a zero invalid threshold "too close" / "multiple") the base stays.  That is two thirds of
+    // the positions at 200x and nine tenths at 50x.  The others are listed in LDS and voted in pass 2, densely: the vote
+    // proper is ~200 instructions with two f64 multiplies per position, and a wave runs it for all of its 64 lanes or
+    // for none.
     u32 my_len = 0, my_changed = 0, my_zero = 0;
     u64 my_depth = 0;
     const bool one_contig = (s_c0 == s_c1);
-    for (u32 p = tid; p < (u32)TILE; p += TILE_THREADS) {
-        const u64 gp = w0 + p;
-        if (gp >= A.G) break;
-        if (A.own) {  // window tiling: halo positions are voted by the rank that owns them
-            const u32 c = one_contig ? s_c0 : find_contig(A.contig_off, A.n_contigs, gp);
-            const u32 rel = (u32)(gp - A.contig_off[c]);
-            if (rel < A.own[2 * c] || rel >= A.own[2 * c + 1]) {
-                A.code[gp] = 0;
-                continue;
+    for (u32 p0 = tid; p0 < (u32)TILE; p0 += TILE_THREADS) {
+        const u64 gp = w0 + p0;
+        bool dirty = false;
+        if (gp < A.G) {
+            bool mine = true;
+            if (A.own) {  // window tiling: halo positions are voted by the rank that owns them
+                const u32 c = one_contig ? s_c0 : find_contig(A.contig_off, A.n_contigs, gp);
+                const u32 rel = (u32)(gp - A.contig_off[c]);
+                if (rel < A.own[2 * c] || rel >= A.own[2 * c + 1]) {
+                    A.code[gp] = 0;
+                    mine = false;
+                }
+            }
+            if (mine) {
+                const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p0];
+                const u32 any = cnt[ROW_A * TILE + p0] | cnt[ROW_C * TILE + p0] | cnt[ROW_T * TILE + p0] | cnt[ROW_G * TILE + p0] |
+                                cnt[ROW_DEL * TILE + p0] | cnt[ROW_OTH * TILE + p0] | cnt[ROW_DEF * TILE + p0] | cnt[ROW_MIS * TILE + p0] |
+                                ((s_ndbits[p0 >> 5] >> (p0 & 31u)) & 1u);
+                if (any == 0 && row_of(orig) < 4 && one_contig && !A.dbg) {
+                    const u32 cov = cnt[ROW_COV * TILE + p0];
+                    A.code[gp] = orig;
+                    my_len += 1u;
+                    my_zero += cov == 0;
+                    my_depth += (u64)cov << DEPTH_FX_BITS;
+                } else dirty = true;
             }
         }
+        const u64 dm = __ballot(dirty);
+        if (dm) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&s_ndirty, (u32)__popcll(dm));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (dirty) s_dirty[base + (u32)__popcll(dm & ((1ull << lane) - 1ull))] = (unsigned short)p0;
+        }
+    }
+    __syncthreads();
+    // Pass 2: the vote proper (pileup.rs:67-134) for the listed positions
+    const u32 n_dirty = s_ndirty;
+    for (u32 di = tid; di < n_dirty; di += TILE_THREADS) {
+        const u32 p = s_dirty[di];
+        const u64 gp = w0 + p;
         u32 nA, nC, nG, nT, nDel, nOth;
         const u32 defw = cnt[ROW_DEF * TILE + p];
         const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
