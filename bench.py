@@ -216,7 +216,6 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                     f"(QUAL strings included), recipe {recipe} {planted}, generated in {gen_s:.1f} s",
            "host_cores": os.cpu_count(), "text_bytes": text_bytes}
     rep = 1 if big else 2
-    made = []
     try:
         env = dict(os.environ)
         env["PP_DEVICE_INGEST"] = "1"
@@ -255,7 +254,6 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
             t_fp, r_fp = _timed([exe, "filter-polish", "--in1", sams[0], "--in2", sams[1], fa], env, repeat=rep)
             f1, f2 = os.path.join(tmp, "f_1.sam"), os.path.join(tmp, "f_2.sam")
             g1, g2 = os.path.join(tmp, "g_1.sam"), os.path.join(tmp, "g_2.sam")
-            made += [f1, f2, g1, g2]
             t = time.perf_counter()
             ra = subprocess.run([orc_exe, "filter", "--in1", sams[0], "--in2", sams[1], "--out1", f1, "--out2", f2], capture_output=True)
             t_orc_filter = time.perf_counter() - t

@@ -155,44 +155,44 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
     __syncthreads();
     constexpr u32 EXW_UNROLL = 4;  // items a thread asks for before it looks at the first (their loads are in flight together)
     for (u32 eb = e0 + tid; eb < e1; eb += EXW_UNROLL * EXW_THREADS) {
-      uint4 ents[EXW_UNROLL];
+        uint4 ents[EXW_UNROLL];
 #pragma unroll
-      for (u32 u = 0; u < EXW_UNROLL; u++) ents[u] = A.entA[min(eb + u * EXW_THREADS, e1 - 1u)];
+        for (u32 u = 0; u < EXW_UNROLL; u++) ents[u] = A.entA[min(eb + u * EXW_THREADS, e1 - 1u)];
 #pragma unroll
-      for (u32 u = 0; u < EXW_UNROLL; u++) {
-        if (eb + u * EXW_THREADS >= e1) break;
-        const uint4 ent = ents[u];
-        const int q = pr - item_rel(ent.z);
-        const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
-        const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
-        if (q < 0 || q >= (int)item_extent(ent.x, ent.y, ent.z)) continue;
-        const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
-        // fast-class items carry their untrimmed length: apply the trim here (from the last four bases in one load, as
-        // k_tile's plain class does; a trailing homopolymer of four or more walks byte by byte)
-        if (fl == 0 && !point && !notrim) {
-            const u8 *rp = A.seq + so;
-            const u32 L = ent.y >> 24;
-            u32 tf = 0;
-            if (L >= 4u) {
-                const u32 tail = load4_unaligned(rp + (L - 4u));
-                tf = nz_flags(tail ^ splat8(tail >> 24));
+        for (u32 u = 0; u < EXW_UNROLL; u++) {
+            if (eb + u * EXW_THREADS >= e1) break;
+            const uint4 ent = ents[u];
+            const int q = pr - item_rel(ent.z);
+            const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
+            const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
+            if (q < 0 || q >= (int)item_extent(ent.x, ent.y, ent.z)) continue;
+            const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+            // fast-class items carry their untrimmed length: apply the trim here (from the last four bases in one load,
+            // as k_tile's plain class does; a trailing homopolymer of four or more walks byte by byte)
+            if (fl == 0 && !point && !notrim) {
+                const u8 *rp = A.seq + so;
+                const u32 L = ent.y >> 24;
+                u32 tf = 0;
+                if (L >= 4u) {
+                    const u32 tail = load4_unaligned(rp + (L - 4u));
+                    tf = nz_flags(tail ^ splat8(tail >> 24));
+                }
+                const u32 lim = tf ? L - 4u + (u32)((31 - __clz((int)tf)) >> 3) : simple_nkeep(rp, L);
+                if ((u32)q >= lim) continue;
             }
-            const u32 lim = tf ? L - 4u + (u32)((31 - __clz((int)tf)) >> 3) : simple_nkeep(rp, L);
-            if ((u32)q >= lim) continue;
+            u64 s_rel;
+            u32 len;
+            if (point) { s_rel = 0; len = ent.y >> 24; }  // the entry at a read's single indel: its key bytes, or none
+            else if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
+            else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
+            const u32 slot = atomicAdd(s_n, 1u);
+            if (slot < EXW_MAX) {
+                ulonglong2 v;
+                v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+                v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
+                cov[slot] = v;
+            }
         }
-        u64 s_rel;
-        u32 len;
-        if (point) { s_rel = 0; len = ent.y >> 24; }  // the entry at a read's single indel: its key bytes, or none
-        else if (!(fl & ENT_COMPLEX)) { s_rel = (u64)q; len = 1; }
-        else entry_slice(A.cigar + A.cig_off[idx], A.n_cig[idx], (u32)q, &s_rel, &len);
-        const u32 slot = atomicAdd(s_n, 1u);
-        if (slot < EXW_MAX) {
-            ulonglong2 v;
-            v.x = ((u64)idx << 32) | (u64)A.kk[idx];
-            v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
-            cov[slot] = v;
-        }
-      }
     }
     __syncthreads();
     const u32 n = *s_n;

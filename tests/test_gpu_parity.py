@@ -1062,11 +1062,12 @@ def test_rccl_gather_through_the_library(ctx, pp, orc):
         c2.close()
 
 
-@pytest.mark.parametrize("config", [3, 4])
+@pytest.mark.parametrize("config", [1, 3, 4])
 def test_bench_shards_the_real_configs_across_ranks(tmp_path, config):
-    """bench.py --gpus 2 --config 3 / 4 (reduced size) with both ranks on this GPU: the native planner, the emit-range
-    sharding on the device and the assembly of the gathered bytes give exactly the bytes ONE GPU produces for the
-    whole job (gather_verified)."""
+    """bench.py --gpus 2 --config 3 / 4 (reduced size) with both ranks on this GPU: the native planner, the records split
+    on the device, the compact runs and the assembly of the gathered bytes give exactly the bytes ONE GPU produces for
+    the whole job (gather_verified).  config 1 = the driver's own multi-GPU launch (weak scaling: every rank its own
+    contig; the gathered bytes are the ranks' bytes)."""
     import json
     env = dict(os.environ, PP_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT)
     port = 35000 + os.getpid() % 2000 + config
@@ -1076,8 +1077,10 @@ def test_bench_shards_the_real_configs_across_ranks(tmp_path, config):
                        timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
-    assert line["gather_verified"] is True and line["n_gpus"] == 2 and line["scaling"] == "strong", line
-    assert ("contig-shard" if config == 3 else "window-tile") in line["config"]["parallelism"]
+    assert line["gather_verified"] is True and line["n_gpus"] == 2 and line["scaling"] == ("weak" if config == 1 else "strong"), line
+    assert ("window-tile" if config == 4 else "contig-shard") in line["config"]["parallelism"]
+    if config == 1:
+        assert line["planted_errors_recovered"] is True and abs(line["value"] * line["ms_per_step"] / 1e3 - 6.0) < 0.01  # 2 x 3 Mbp per step
 
 
 @pytest.mark.parametrize("n_ctx", [2, 3])
