@@ -4,19 +4,24 @@
 //   k_meta_init  the job's metadata block (status, counters, heavy-window list)
 //   k_prep     persistent blocks stream the alignment records: the bulk (one short M run inside its contig) on the
 //              spot, the others (indels, long reads: CIGAR walk validation, reference span and the right-end homopolymer
-//              trim, alignment.rs:175-201,364-378) after the loop, one per lane -> (global start, kept entries); the
-//              same pass counts each block's (alignment, window) items per window / coarse bucket in LDS
+//              trim, alignment.rs:175-201,364-378) after the loop, one per lane -> (global start, kept entries / class);
+//              a read with ONE 1-base indel is only classified (its pieces are cut by k_fill); the same pass counts each
+//              block's (piece, window) items per window / coarse bucket in LDS.  A sharded job's context runs over a
+//              compact assembly of what it owns: k_prep places the records there (g_base) and drops the others'
 //   k_scan_cols / k_scan   column scan over the blocks + scan over the windows \ atomics-free multisplit of the
-//   k_fill     scatter of 16-byte work items into their window's bucket         > alignments into 2048-position windows
+//   k_fill     scatter of 16-byte work items into their window's bucket         > pieces into 2048-position windows
 //   (k_regroup / k_heavy / k_count: the two-level path from 33.5 Mbp on)       /  (+ the list of heavy windows)
 //   k_tile     one workgroup per window: counters for 2048 positions and the window's assembly bytes live in LDS;
-//              groups of 5-8 lanes own one read (32 bytes per lane), compare it with the assembly and tally only the
-//              differing bases (two LDS atomics into a coverage difference array per read, pileup.rs:56-65,189-200);
-//              then one lane per position votes (pileup.rs:67-134) and writes a 1-byte emit code.  Heavy windows are
-//              tallied by eight helper blocks each; a sharded job only launches the windows it works on
-//   k_exact2 (three instances) / k_exact   the rare positions whose outcome depends on string-keyed counts
-//              (insertions, N...) or on the ORDER of f64 depth additions (non-power-of-two 1/k shares) are replayed
-//              exactly: covering alignments sorted by file order, sequential f64 adds, byte-exact key grouping
+//              groups of 5-8 lanes own one read or flank of a read (32 bytes per lane), compare it with the assembly and
+//              tally only the differing bases (two LDS atomics into a coverage difference array per piece,
+//              pileup.rs:56-65,189-200); the entry AT a read's single indel is one tally per lane.  Then the positions where
+//              anything was tallied are voted, one lane each (pileup.rs:67-134), the others keep the assembly's base; a
+//              1-byte emit code per position.  Heavy windows are tallied by eight helper blocks each; a sharded job only
+//              launches the windows it works on
+//   k_exact2 (three instances)   the positions whose depth depends on the ORDER of f64 additions (non-power-of-two 1/k
+//              shares) are replayed exactly: the window's items sorted by file order, one sequential f64 pass
+//   k_exact    the positions whose string-keyed counts (insertions, N...) could reach a threshold: one workgroup per
+//              position scans the window's items, its first wave sorts the covering alignments, tallies and groups keys
 //   k_scan / k_emit  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes, contig offsets
 //
 // Integer counting, HBM/LDS bound: no MFMA anywhere by design.

@@ -4,10 +4,11 @@
 //   * whole contigs, longest-processing-time greedy on their alignment counts (configs[3]);
 //   * a contig that carries more than one rank's share of the alignments is cut into up to `world` windows on
 //     2048-bp tile boundaries, one per rank (configs[4]).
-// A rank polishes with the FULL alignment batch and pp_polish_set_emit(ranges of its units): the device drops the
-// records that do not reach its ranges (k_prep) and skips the windows outside them (k_tile), so every owned position
-// still sees ALL of its alignments in file order -- the order-dependent f64 depth (src/pileup.rs:64) stays exact and
-// no halo bookkeeping is needed.  The only exchange is the collection of the polished bytes (pp_comm.hip).
+// A rank polishes the records that reach its units (pp_shard_split, pp_shard_dev.hip -- or simply all records) with
+// pp_polish_set_emit(ranges of its units): the device works on its windows only, over a compact assembly of what the rank
+// owns, and every owned position still sees ALL of its alignments in file order -- the order-dependent f64 depth
+// (src/pileup.rs:64) stays exact and no halo bookkeeping is needed.  The only exchange of the polish itself is the
+// collection of the polished bytes (pp_comm.hip).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
