@@ -399,7 +399,12 @@ def main():
     torch.cuda.synchronize()
     nc_job = len(job["contig_off"]) - 1
     gdev = "cpu" if share else device
-    cap = job["G"] + job["G"] // 16 + (1 << 16)          # polished bytes of one rank, at most
+    g_max = job["G"]
+    if world > 1:  # weak scaling: the ranks' contigs differ in length by their planted indels -- one buffer size for all
+        t = torch.tensor([g_max], dtype=torch.int64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g_max = int(t.item())
+    cap = g_max + g_max // 16 + (1 << 16)          # polished bytes of one rank, at most
     total_cap = cap if strong else world * cap
     rank_lens = rank_offs = None
     gbuf = None

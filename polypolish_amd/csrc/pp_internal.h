@@ -132,6 +132,7 @@ struct pp_ctx {
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run
+    uint32_t last_listed = ~0u;         // positions the last job listed for k_exact (sizes its grid for the next one)
     bool no_compact = false;            // this job is being rerun over the whole assembly (DE_HALO)
     uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block
     size_t h_meta_words = 0;

@@ -98,6 +98,7 @@ struct ExactArgs {
     u8 *dbg_status;
     u64 *status;
     int dbg;
+    u64 seq_bytes;        // size of the seq array (unaligned word loads stay inside it)
     const u32 *heavy;     // list of the heavy windows (HEAVY_WORDS) ...
     const u8 *win_heavy;  // ... and, per window, 0 or 1 + its slot in it
 };
@@ -106,7 +107,7 @@ constexpr u64 SL_OFF_MASK = (1ull << 40) - 1;
 constexpr u64 SL_DONE = 1ull << 63;
 
 __device__ void exact_one(const ExactArgs &A, u32 f);
-__device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 *s_n);
+__device__ void exact_block(const ExactArgs &A, u32 f, u32 cap, ulonglong2 *cov, double *rcp, u32 *kw, u32 *s_n);
 
 // One WORKGROUP per listed position (a position whose string-keyed tallies -- an insertion, N ... -- could reach a
 // threshold, every flagged position of a window too deep for k_exact2, and with --debug everything that has such a key):
@@ -130,6 +131,7 @@ __device__ __forceinline__ void wave_sync() {
 __global__ __launch_bounds__(EXW_THREADS) void k_exact(ExactArgs A) {
     __shared__ ulonglong2 cov[EXW_MAX];
     __shared__ double rcp[EXW_MAX];
+    __shared__ u32 kw[EXW_MAX];  // the first four bytes of every entry's key
     __shared__ u32 s_n;
     if (*A.status != ~0ull) return;
     if (*A.scr_need > A.cap_scr) {  // the scratch is too small: the host grows it and reruns
@@ -138,18 +140,23 @@ __global__ __launch_bounds__(EXW_THREADS) void k_exact(ExactArgs A) {
     }
     const u32 n_flagged = A.counters[0];
     for (u32 f = blockIdx.x; f < n_flagged; f += gridDim.x) {
-        if (A.flag_cov[f] <= EXW_MAX) exact_block(A, f, cov, rcp, &s_n);
+        const u32 cap = A.flag_cov[f];
+        if (cap <= EXW_MAX) exact_block(A, f, cap, cov, rcp, kw, &s_n);
         else if (threadIdx.x == 0) exact_one(A, f);
         __syncthreads();
     }
 }
 
-__device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *rcp, u32 *s_n) {
+// (the kernel is a chain of dependent memory round trips: whatever is known early -- the assembly's base, the position's
+// contig, an item's share next to its trim bytes, a key's bytes next to its row -- is asked for early)
+__device__ void exact_block(const ExactArgs &A, u32 f, u32 cap, ulonglong2 *cov, double *rcp, u32 *kw, u32 *s_n) {
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    const u32 gp = A.flag_pos[f], cap = A.flag_cov[f];
+    const u32 gp = A.flag_pos[f];
     const u32 w = gp / (u32)TILE;
     const int pr = (int)(gp - w * (u32)TILE);
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    const u8 orig = A.bases[gp];
+    const u32 c = find_contig_wave(A.contig_off, A.n_contigs, gp, lane);
     // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40); any order, sorted below ----
     if (tid == 0) *s_n = 0;
     __syncthreads();
@@ -167,6 +174,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             const bool point = (ent.z >> 31) != 0, notrim = ((ent.z >> 30) & 1u) != 0;
             if (q < 0 || q >= (int)item_extent(ent.x, ent.y, ent.z)) continue;
             const u64 so = fl ? A.seq_off[idx] : ((u64)ent.x | ((u64)(ent.y & 0xFFu) << 32));
+            const u32 kq = A.kk[idx];
             // fast-class items carry their untrimmed length: apply the trim here (from the last four bases in one load,
             // as k_tile's plain class does; a trailing homopolymer of four or more walks byte by byte)
             if (fl == 0 && !point && !notrim) {
@@ -188,7 +196,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             const u32 slot = atomicAdd(s_n, 1u);
             if (slot < EXW_MAX) {
                 ulonglong2 v;
-                v.x = ((u64)idx << 32) | (u64)A.kk[idx];
+                v.x = ((u64)idx << 32) | (u64)kq;
                 v.y = ((so + s_rel) & SL_OFF_MASK) | ((u64)(len & 0x7FFFFFu) << 40);
                 cov[slot] = v;
             }
@@ -224,9 +232,18 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
         if (kc == KCLASS_NONDYADIC) odd = true; else fx += (u64)(1u << DEPTH_FX_BITS) >> kc;
         const u64 y = cov[i].y;
         const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
+        // the key's first (up to four) bytes: one load where four bytes lie inside the seq array, else byte by byte
+        u32 word = 0;
+        if (len) {
+            const u64 ko = y & SL_OFF_MASK;
+            if (ko + 4 <= A.seq_bytes) word = load4_unaligned(A.seq + ko);
+            else for (u32 b = 0; b < min(len, 4u); b++) word |= (u32)A.seq[ko + b] << (8u * b);
+            if (len < 4u) word &= (1u << (8u * len)) - 1u;
+        }
+        kw[i] = word;
         int row = ROW_OTH;
         if (len == 0) row = ROW_DEL;
-        else if (len == 1) row = row_of(A.seq[y & SL_OFF_MASK]);
+        else if (len == 1) row = row_of(word);
         if (row != ROW_OTH) {
             if (row == ROW_A) nA++; else if (row == ROW_C) nC++; else if (row == ROW_G) nG++;
             else if (row == ROW_T) nT++; else nDel++;
@@ -244,7 +261,6 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
     } else {
         depth = (double)wave_sum64(fx) * (1.0 / (double)(1u << DEPTH_FX_BITS));
     }
-    const u8 orig = A.bases[gp];
     VoteOut v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
     u64 win_off = 0;
     u32 win_len = 0;  // winning string-keyed sequence, if any
@@ -282,13 +298,16 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             const u64 yi = cov[i].y;  // (the same word for every lane: one broadcast read)
             const u32 li = (u32)((yi >> 40) & 0x7FFFFFu);
             const u8 *si = A.seq + (yi & SL_OFF_MASK);
+            const u32 wi = kw[i];
             u32 mine = 0;
             for (u32 j = i + 1 + lane; j < n; j += 64) {
                 const u64 yj = cov[j].y;
-                if ((yj & SL_DONE) || (u32)((yj >> 40) & 0x7FFFFFu) != li) continue;
-                const u8 *sj = A.seq + (yj & SL_OFF_MASK);
+                if ((yj & SL_DONE) || (u32)((yj >> 40) & 0x7FFFFFu) != li || kw[j] != wi) continue;
                 bool same = true;
-                for (u32 b = 0; b < li; b++) if (si[b] != sj[b]) { same = false; break; }
+                if (li > 4u) {  // (keys of up to four bytes are compared in their words: the usual case)
+                    const u8 *sj = A.seq + (yj & SL_OFF_MASK);
+                    for (u32 b = 4; b < li; b++) if (si[b] != sj[b]) { same = false; break; }
+                }
                 if (same) { mine++; cov[j].y = yj | SL_DONE; }
             }
             const u32 count = 1u + wave_sum(mine);
@@ -324,7 +343,6 @@ __device__ void exact_block(const ExactArgs &A, u32 f, ulonglong2 *cov, double *
             if (v.status == PP_ST_TOO_CLOSE) win_len = 0;
         }
     }
-    const u32 c = find_contig_wave(A.contig_off, A.n_contigs, gp, lane);
     if (lane != 0) return;
     u32 emit;
     if (win_len > 0) {

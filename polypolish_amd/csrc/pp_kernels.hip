@@ -636,7 +636,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
     E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
-    E.bases = d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc;
+    E.bases = d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc; E.seq_bytes = B.seq_bytes;
     E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
     E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
     E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
@@ -649,7 +649,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, HEAVY_SUB>), dim3(HEAVY_SLOTS * HEAVY_SUB), dim3(1024), 0, st, E, nwin);
-    hipLaunchKernelGGL(k_exact, dim3(EXW_BLOCKS), dim3(EXW_THREADS), 0, st, E);
+    // one workgroup per listed position; how many there will be is only known on the device -- the grid follows what the
+    // context's job before listed (twice that, at least 256 and at most EXW_BLOCKS workgroups; the kernel strides)
+    {
+        uint32_t blocks = 256;
+        while (blocks < EXW_BLOCKS && blocks < 2 * ctx->last_listed) blocks <<= 1;
+        hipLaunchKernelGGL(k_exact, dim3(ctx->last_listed == ~0u ? EXW_BLOCKS / 4 : blocks), dim3(EXW_THREADS), 0, st, E);
+    }
     timer_end(ctx);
 
     u64 *d_winout = (u64 *)ctx->b_winout.p;
@@ -751,6 +757,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     }
     const uint32_t *cnt = (const uint32_t *)&meta[1];
     ctx->total_out = meta[5];
+    ctx->last_listed = cnt[0];
     ctx->n_multi = cnt[1];
     ctx->n_keys = meta[8];
     // per-contig results: the run's contigs are the job's, or (compact run) the ones this context owns -- the others
