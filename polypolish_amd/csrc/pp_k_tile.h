@@ -786,6 +786,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
     }
     __syncthreads();
+#ifdef PP_TILE_STAMPS
+    if (tid == 0) A.stamps[8ull * blockIdx.x + 7] = wall_clock64();
+#endif
     // Pass 2: the vote proper (pileup.rs:67-134) for the listed positions
     const u32 n_dirty = s_ndirty;
     for (u32 di = tid; di < n_dirty; di += TILE_THREADS) {

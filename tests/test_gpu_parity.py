@@ -51,9 +51,15 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         # other shares through the ordered replay, each position rounded to 2^-10
         dsum = float(want["positions"]["depth"][off[c]:off[c + 1]].sum())
         assert abs(got["stats"][c]["depth_sum"] - dsum) <= (off[c + 1] - off[c]) * 2.0 ** -11 + 1e-6 * dsum, (c, got["stats"][c], dsum)
-    # without the per-position debug planes the same bytes must come out (different flagging rule)
+    # without the per-position debug planes the same bytes must come out (different flagging rule; positions where
+    # nothing was tallied explicitly skip the vote proper) -- and the same per-contig figures
     plain = ctx.polish_records(contig_off, bases, recs, positions=False, **kw)
-    assert plain["polished"] == want["polished"]
+    assert plain["polished"] == want["polished"] and np.array_equal(plain["offsets"], want["offsets"])
+    for c in range(len(off) - 1):
+        assert plain["stats"][c]["changed"] == got["stats"][c]["changed"], c
+        assert plain["stats"][c]["zero_depth"] == got["stats"][c]["zero_depth"], c
+        dsum = float(want["positions"]["depth"][off[c]:off[c + 1]].sum())
+        assert abs(plain["stats"][c]["depth_sum"] - dsum) <= (off[c + 1] - off[c]) * 2.0 ** -11 + 1e-6 * dsum, (c, plain["stats"][c], dsum)
     return want, got
 
 
@@ -347,6 +353,48 @@ def test_fuzz_cigar_walk_against_the_oracle(ctx, pp, orc):
         kind = next(k for k in kinds if k in we.msg)
         assert ge.value.code == we.code and kind in ge.value.msg and f"record {idx}" in ge.value.msg, (seed, ge.value, we.msg)
     assert n_ok >= 15 and n_err >= 5, (n_ok, n_err)
+
+
+def test_one_indel_reads_edge_cases(ctx, pp, orc):
+    """Reads with ONE 1-base indel (aM1IbM / aM1DbM) are cut into flank / entry at the indel / flank work items instead of
+    being walked (alignment.rs:175-201) -- unless a flank is shorter than 8 bases or the homopolymer trim
+    (alignment.rs:364-378) would reach the indel, which take the general walk.  Every indel position of a 40-base read,
+    both kinds, read ends of homopolymers of 1..7 bases (so the trim ends before, at and beyond the indel), starts on both
+    sides of a 2048-position window boundary, depth shares 1, 1/2 and 1/3: per-position depth / counts / thresholds /
+    status and the bytes against the oracle, with and without the per-position records."""
+    rng = np.random.default_rng(11)
+    G, L = 6000, 40
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, G)].copy()
+    rec = {k: [] for k in ("contig", "ref_start", "k", "seq_len", "n_cig")}
+    seqs, cigs = [], []
+    for a in range(1, L - 1):
+        for kind in (1, 2):                      # 1 insertion, 2 deletion
+            for tail in (1, 2, 3, 5, 7, L - a):  # length of the homopolymer the read ends in (L - a: it reaches the indel)
+                for start in (2048 - L // 2, 2048 - a, 2048 - a - 1, 2048 + 5, 4096 - 3):
+                    kk = int(rng.choice((1, 1, 2, 3)))
+                    b = L - a - (1 if kind == 1 else 0)
+                    if b < 1 or start < 0 or start + L + 2 >= G:
+                        continue
+                    s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+                    t = min(tail, L)
+                    s[L - t:] = s[L - 1]
+                    if L - t - 1 >= 0 and s[L - t - 1] == s[L - 1]:
+                        s[L - t - 1] = b"ACGT"[(b"ACGT".index(bytes([s[L - 1]])) + 1) % 4]
+                    rec["contig"].append(0); rec["ref_start"].append(start); rec["k"].append(kk)
+                    rec["seq_len"].append(L); rec["n_cig"].append(3)
+                    seqs.append(s)
+                    cigs.append([(a << 4) | 0, (1 << 4) | kind, (b << 4) | 0])
+    n = len(seqs)
+    assert n > 1500
+    order = rng.permutation(n)
+    recs = {k: np.array(v, dtype=np.uint32)[order] for k, v in rec.items()}
+    recs["seq"] = np.concatenate([seqs[i] for i in order])
+    recs["cigar"] = np.array([c for i in order for c in cigs[i]], dtype=np.uint32)
+    recs["seq_off"] = (np.arange(n, dtype=np.uint64) * np.uint64(L))
+    recs["cig_off"] = (np.arange(n, dtype=np.uint64) * np.uint64(3))
+    contig_off = np.array([0, G], dtype=np.uint64)
+    _compare_records(ctx, orc, contig_off, bases, recs)
+    _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_invalid=0.1)
 
 
 FILE_CASES = [

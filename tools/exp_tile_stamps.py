@@ -37,6 +37,23 @@ if len(h):
     on_h = np.array([c in hc for c in cu[early]])
     print("  started in the first 50 us on CUs with a helper: %d, elsewhere: %d" % (on_h.sum(), (~on_h).sum()))
 print("ordinary blocks: prologue %.1f us mean, items %.1f" % ((pro - start)[ran & ~heavy].mean(), (mid - pro)[ran & ~heavy].mean()))
+p1 = us(a[:, 7])
+oo = ran & ~heavy & (a[:, 7] > 0)
+if oo.any():
+    print("ordinary blocks: prefix sum + vote pass 1 %.1f us mean, pass 2 + epilogue %.1f, whole block %.1f" %
+          ((p1 - mid)[oo].mean(), (end - p1)[oo].mean(), (end - start)[oo].mean()))
+    # the gap between a block's end and the start of the next block on the same CU slot: dispatch cost
+    order = np.argsort(start[oo]); cus = cu[oo][order]; st = start[oo][order]; en = end[oo][order]
+    gaps = []
+    for c in np.unique(cus)[:64]:
+        m = cus == c
+        s_c, e_c = st[m], np.sort(en[m])
+        # k-th start after the first two on this CU follows the (k-2)-th end
+        for k in range(2, min(len(s_c), len(e_c) + 2)):
+            gaps.append(s_c[k] - e_c[k - 2])
+    if gaps:
+        g = np.array(gaps)
+        print("end of a block -> start of the next one on its CU: median %.1f us, mean %.1f, p90 %.1f" % (np.median(g), g.mean(), np.percentile(g, 90)))
 o = idx[~heavy[idx]]
 bins = (start[o] // 50).astype(int)
 print("ordinary blocks by start time (50 us bins): count, mean items us:",
