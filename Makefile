@@ -24,6 +24,12 @@ $(OUT)/%.o: $(CSRC)/%.cpp include/polypolish_hip.h $(CSRC)/pp_host.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -x c++ -c $< -o $@
 
+# pp_kernels.hip without MachineLICM: the pass hoists constants and thread-number arithmetic out of k_tile's item loops and
+# the allocator then spills what the loops need (k_tile with a whole read per lane: 14 spilled VGPRs with it, reloaded
+# inside the pass; without it the few spills left sit outside the loops).  Same speed for every other kernel (measured).
+KFLAGS ?= -mllvm -disable-machine-licm
+$(OUT)/pp_kernels.o: HIPFLAGS += $(KFLAGS)
+
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread -ldl
 
@@ -47,7 +53,7 @@ tools/_build/libsamgen.so: tools/samgen.c
 # kernel experiments: make variant NAME=x DEFS="-DPP_..." -> $(OUT)/var_x/libpolypolish_hip.so (use with PP_LIB_PATH)
 variant: $(LIB)
 	@mkdir -p $(OUT)/var_$(NAME)
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $(CSRC)/pp_kernels.hip -o $(OUT)/var_$(NAME)/pp_kernels.o
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) $(DEFS) -c $(CSRC)/pp_kernels.hip -o $(OUT)/var_$(NAME)/pp_kernels.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/var_$(NAME)/libpolypolish_hip.so $(OUT)/var_$(NAME)/pp_kernels.o $(filter-out $(OUT)/pp_kernels.o,$(OBJS)) -lz -lpthread -ldl
 
 # the host side (parsers, filter loader and writer, planner, drivers) under AddressSanitizer; the device objects as they are:

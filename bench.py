@@ -92,8 +92,9 @@ def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
     them while the GPU waits.  job["part"] (a pp.ShardPart: the records one rank of a sharded job needs) replaces the
     job's own record arrays."""
     part = job.get("part")
+    seq4 = job.get("seq4")  # the 4-bit mirror of the seq array (pp_aln_batch.seq4), when the job has one
     key = (id(ctx), params, None if job.get("emit") is None else id(job["emit"]), job["bases"].data_ptr(),
-           job["recs"]["seq"].data_ptr(), job["n_aln"], id(part),
+           job["recs"]["seq"].data_ptr(), None if seq4 is None else seq4.data_ptr(), job["n_aln"], id(part),
            job["contig_off"].tobytes() if len(job["contig_off"]) < 64 else id(job["contig_off"]))
     run = job.setdefault("_prepared", {}).get(key)
     if run is None:
@@ -102,8 +103,11 @@ def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
             run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, part.n_aln, part.ptrs, part.seq_bytes,
                                    part.n_cig_total, pp.MEM_DEVICE, *params, emit=job.get("emit"))
         else:
+            ptrs = {k: v.data_ptr() for k, v in r.items()}
+            if seq4 is not None:
+                ptrs["seq4"] = seq4.data_ptr()
             run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, job["n_aln"],
-                                   {k: v.data_ptr() for k, v in r.items()}, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
+                                   ptrs, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
                                    *params, emit=job.get("emit"))
         job["_prepared"][key] = run
     run()
@@ -307,6 +311,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000,
                     help="bp of one contig given to the CPU oracle (default: the whole 5 Mbp job of config 1, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seq4", default="off", choices=["on", "off"],
+                    help="hand the 4-bit mirror of the seq array over with the batch (pp_aln_batch.seq4), as the device tokenizer does")
     ap.add_argument("--seq-layout", default="file", choices=["file", "window"],
                     help="experiments only: 'window' lays the SEQ bytes out window-grouped (tools/synthjob.py window_grouped); "
                          "the headline is 'file' -- SAM order, what an ingest delivers")
@@ -380,6 +386,8 @@ def main():
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate, repeat=repeat,
                    repeat_bp=args.repeat_bp, recipe=args.recipe)
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
+    if args.seq4 == "on":
+        job = synthjob.with_seq4(job)
     if args.seq_layout == "window":
         job = synthjob.window_grouped(job)
     if args.nd_frac > 0:
@@ -528,7 +536,7 @@ def main():
     # command (N = 1); failing that, the committed figure of the same workload (profiles/traffic.json), else null.
     traffic = traffic_source = None
     if world == 1 and dom_name and not args.no_live_traffic:
-        tail = ["--config", str(args.config), "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
+        tail = ["--config", str(args.config), "--seq4", args.seq4, "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
                 "--n-rate", repr(args.n_rate), "--read-len", str(args.read_len), "--repeat-bp", str(args.repeat_bp), "--nd-frac", repr(args.nd_frac)]
         if args.genome is not None:
             tail += ["--genome", str(args.genome)]
@@ -572,7 +580,7 @@ def main():
         w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
         w_traffic = None
         if dom_name and not args.no_live_traffic:
-            lt = live_traffic(["--config", str(args.config), "--seq-layout", "window", "--recipe", args.recipe,
+            lt = live_traffic(["--config", str(args.config), "--seq4", args.seq4, "--seq-layout", "window", "--recipe", args.recipe,
                                "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
             w_traffic = lt["hbm_bytes"] if lt else None
         second = {"layout": "SEQ bytes window-grouped (pp_dev_ingest_set_seq_layout; every other array and every result unchanged)",
@@ -581,6 +589,19 @@ def main():
                   "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
                   "ms_per_step": round(w_step, 4), "same_polished_bytes": bool(w_polished == polished)}
         del wj
+    # What the dominant kernel actually moves, as a rate: the algorithmic fraction above prices a 150-byte read at 150
+    # bytes, the memory system fetches the 128-byte lines it touches (2.16 of them at an arbitrary byte offset).  6290 GB/s
+    # is the copy rate an MI355X reaches in practice (MI355X_MICROARCH.md, chip-level parameters).
+    PRACTICAL = 6290.0
+    def moved(traffic_bytes, kernel_ms):
+        if not traffic_bytes or not kernel_ms:
+            return None
+        rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9
+        return {"rate": round(rate, 1), "unit": "GB/s", "frac_of_peak": round(rate / peak, 4),
+                "frac_of_practical_copy_rate": round(rate / PRACTICAL, 4), "practical_copy_rate": PRACTICAL,
+                "bytes_moved_per_algorithmic_byte": round(traffic_bytes / b_alg, 3)}
+    if second is not None:
+        second["hbm_actual"] = moved(second.get("traffic"), second.get("kernel_ms"))
     out = {
         "metric": METRIC,
         "value": round(value, 2),
@@ -603,6 +624,7 @@ def main():
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "hbm_actual": moved(traffic, dom_avg_ms),
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
         "roofline_window_grouped_seq": second,

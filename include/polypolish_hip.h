@@ -126,7 +126,23 @@ typedef struct {
     uint64_t seq_bytes;
     const uint32_t *cigar;
     uint64_t n_cig_total;
+    /* Optional (NULL = none): a 4-bit mirror of seq, two bases per byte -- base seq[i] in bits 4*(i&1).. of seq4[i >> 1]
+     * (the mirror is a function of the whole seq ARRAY, position by position, not of the records), (seq_bytes + 1) / 2
+     * bytes followed by at least 32 readable bytes; codes PP_SEQ4_*.  The device tokenizer hands it over with its batch
+     * (pp_dev_ingest_batch); with it the pileup kernel fetches the reads without indels at half the bytes -- it is HBM-bound
+     * on the 128-byte lines a read touches.  Used for a PP_MEM_DEVICE batch that is polished in place (the only batch of its
+     * job); every result is the same with and without it.  seq must be there all the same: everything that needs a byte
+     * as it was delivered (string-keyed tallies, trims through bytes other than A/C/G/T/N/-) reads seq. */
+    const uint8_t *seq4;
 } pp_aln_batch;
+/* codes of seq4: the four bases as their counter rows, N, '-' (the deletion key, src/pileup.rs:194-197), anything else */
+#define PP_SEQ4_A 0
+#define PP_SEQ4_C 1
+#define PP_SEQ4_T 2
+#define PP_SEQ4_G 3
+#define PP_SEQ4_N 4
+#define PP_SEQ4_DASH 5
+#define PP_SEQ4_OTHER 15
 
 /* Per-contig figures the reference prints to stderr (src/polish.rs:206-227). */
 typedef struct {

@@ -41,7 +41,8 @@ class Params(C.Structure):
 class AlnBatch(C.Structure):
     _fields_ = [("n_aln", C.c_uint64), ("contig", C.c_void_p), ("ref_start", C.c_void_p), ("k", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seq_len", C.c_void_p), ("cig_off", C.c_void_p), ("n_cig", C.c_void_p),
-                ("seq", C.c_void_p), ("seq_bytes", C.c_uint64), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64)]
+                ("seq", C.c_void_p), ("seq_bytes", C.c_uint64), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64),
+                ("seq4", C.c_void_p)]  # optional 4-bit mirror of seq (include/polypolish_hip.h); None = none
 
 
 class ContigStats(C.Structure):
@@ -319,6 +320,23 @@ def ingest(assembly, sams, max_errors=10, careful=False):
         L.pp_assembly_free(a)
 
 
+_SEQ4_LUT = np.full(256, 15, dtype=np.uint8)
+for _c, _v in ((ord("A"), 0), (ord("C"), 1), (ord("T"), 2), (ord("G"), 3), (ord("N"), 4), (ord("-"), 5)):
+    _SEQ4_LUT[_c] = _v
+
+
+def pack_seq4(seq):
+    """The 4-bit mirror of a seq array (pp_aln_batch.seq4): base i in bits 4*(i&1).. of byte i >> 1, codes PP_SEQ4_*;
+    32 bytes of slack behind, as the header asks for."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    codes = _SEQ4_LUT[seq]
+    if codes.size & 1:
+        codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+    out = np.zeros(codes.size // 2 + 32, dtype=np.uint8)
+    out[:codes.size // 2] = codes[0::2] | (codes[1::2] << 4)
+    return out
+
+
 def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=0):
     """The device tokenizer (pp_dev_ingest_*): same return value as ingest(), the records copied back from HBM.
     seq_layout: 0 = SEQ bytes in file order, 1 = window-grouped (pp_dev_ingest_set_seq_layout)."""
@@ -353,6 +371,11 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=
             if cnt and ptr:
                 ctx._chk(L.pp_ctx_download(ctx._h, arr.ctypes.data, ptr, arr.nbytes))
             recs[name] = arr
+        if b.seq4:  # the 4-bit mirror of the seq array (two bases per byte), as the tokenizer hands it to the polish
+            m = np.zeros((int(b.seq_bytes) + 1) // 2, dtype=np.uint8)
+            if m.size:
+                ctx._chk(L.pp_ctx_download(ctx._h, m.ctypes.data, b.seq4, m.nbytes))
+            recs["seq4"] = m
         return names, descs, off, bases, recs, counts
     finally:
         if g:
@@ -429,7 +452,7 @@ class ShardPart:
     def __init__(self, ctx, plan, dest, n_aln, ptrs, seq_bytes, n_cig_total, mem):
         L = lib()
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
         self._p = C.c_void_p()
         self._ctx = ctx  # keeps the context (and with it the part's device memory) alive
         rc = L.pp_shard_split(ctx._h if ctx is not None else None, plan._p, dest, C.byref(b), mem, C.byref(self._p))
@@ -638,7 +661,7 @@ class Context:
 
     def polish_add_ptrs(self, n_aln, ptrs: dict, seq_bytes, n_cig_total, mem):
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
         self._chk(lib().pp_polish_add(self._h, C.byref(b), mem))
 
     def polish_finish(self):
@@ -653,7 +676,7 @@ class Context:
         off = np.ascontiguousarray(contig_off, dtype=np.uint64)
         p = Params(min_depth, fraction_valid, fraction_invalid)
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
         n_contigs, G = len(off) - 1, int(off[-1])
         h, off_p, p_ref, b_ref = self._h, off.ctypes.data, C.byref(p), C.byref(b)
         begin, add, finish, set_emit = L.pp_polish_begin, L.pp_polish_add, L.pp_polish_finish, L.pp_polish_set_emit

@@ -783,6 +783,7 @@ extern "C" void pp_ingest_batch(const pp_ingest *I, pp_aln_batch *out) {
     out->n_cig = I->n_cig.data();
     out->seq = I->seq.data();
     out->seq_bytes = I->seq.size();
+    out->seq4 = nullptr;
     out->cigar = I->cigar.data();
     out->n_cig_total = I->cigar.size();
 }

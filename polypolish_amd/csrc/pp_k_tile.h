@@ -12,6 +12,7 @@ struct TileArgs {
     const u32 *win_off;
     u32 nwin;
     const u8 *seq;
+    const u8 *seq4;   // optional 4-bit mirror of seq (pp_aln_batch.seq4): the plain class reads the bases from it
     const u64 *seq_off;
     const u64 *cig_off;
     const u32 *n_cig;
@@ -298,6 +299,235 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
     }
 }
 
+// ---- the plain class over the 4-bit mirror of the seq array (TileArgs::seq4) ------------------------------------------
+// k_tile is HBM-bound on what the memory system fetches for a read, the 128-byte lines it touches: 2.16 for 150 bytes at
+// an arbitrary offset, 1.58 for the 75 bytes of its mirror.  Lane s of a group owns bases [32s, 32s + 32) as before -- 16
+// bytes now, ONE load -- and the compare runs on nibbles: the window's assembly bases are kept a second time in LDS, packed
+// with the same codes (asm4), a funnel shift lines them up with the lane's bases, XOR, one bit per differing nibble.
+// Codes (PP_SEQ4_*): A C T G = their counter rows, N, '-', 15 for any other read byte and 14 for any other assembly byte --
+// the two never compare equal, so such a base is tallied explicitly where the byte compare might have found it equal to
+// the assembly's: the same integers come out (the explicit tally and the mismatch row go up together, position_tallies).
+// What needs a byte as it was delivered reads seq as before: the walk over a long homopolymer tail, and the whole trim
+// when the read ends in a byte that has no code of its own (two different bytes may share code 15).
+constexpr int ASM4_PAD = 32;                     // nibbles in front of the window's first position (as ASM_PAD)
+constexpr int ASM4_WORDS = TILE / 8 + 12;        // 8 positions per dword; a lane reads five dwords from (P0 + ASM4_PAD) / 8 on
+constexpr u32 SEQ4_ASM_OTHER = 14;
+
+// bit k of the result <=> nibble k of x is not zero
+__device__ __forceinline__ u32 nz_nibbles(u32 x) {
+    u32 y = x | (x >> 1);
+    y |= y >> 2;
+    y &= 0x11111111u;                                  // bit 4k <=> nibble k
+    const u32 z = (y | (y >> 3)) & 0x03030303u;        // two flags per byte: bits 0, 1 of byte b <=> nibbles 2b, 2b + 1
+    return __builtin_amdgcn_udot4(z, 0x40100401u, 0u, false);
+}
+__device__ __forceinline__ int row_of_code(u32 code) {
+    return code < 4u ? (int)code : (code == (u32)PP_SEQ4_DASH ? ROW_DEL : ROW_OTH);
+}
+
+// The trim (alignment.rs:364-378) off the codes of the read's last EIGHT bases: `t` = the four bytes of the mirror that end
+// with the read's last base (nibble index e = so + L - 1), loaded from seq4 + (e >> 1) - 3.  Returns the number of kept
+// entries, or -1 when the bytes have to decide: the last seven bases all equal the last one (4^-6 of the reads), or the
+// last byte has no code of its own (two different bytes may share code 15).  With a whole read per lane 64 reads share a
+// pass, and a walk through the bytes -- a chain of dependent loads -- in two passes of three held up all of them.
+__device__ __forceinline__ int trim4(u32 t, u64 e, u32 L) {
+    const bool even = ((u32)e & 1u) == 0;   // then the top nibble of t belongs to the next read: move it out
+    if (even) t <<= 4;
+    const u32 last = t >> 28;
+    u32 f = t ^ (last * 0x11111111u);
+    f = (f | (f >> 1) | (f >> 2) | (f >> 3)) & (even ? 0x01111110u : 0x01111111u);  // bit 4p <=> base L-8+p differs (p <= 6)
+    if (f == 0 || last == (u32)PP_SEQ4_OTHER) return -1;
+    return (int)L - 8 + ((31 - __clz((int)f)) >> 2);
+}
+__device__ __forceinline__ int trim_bytes(const u8 *rp, u32 L) {  // the same through the bytes
+    const u8 lastc = rp[L - 1u];
+    u32 i = L - 1u;
+    while (i > 0 && rp[i - 1] == lastc) i--;
+    return i > 0 ? (int)i - 1 : 0;
+}
+
+struct PlainItem4 {  // per lane
+    uint4 W;           // this lane's 32 bases, four bits each, base 0 in bits 0-3 of W.x
+    u32 tail;          // the four bytes of the mirror that end with the read's last base (trim4)
+    u64 e;             // index of the read's last base
+    const u8 *rp;      // the read's bytes in seq (the rare trims that need them)
+    int rel, ib;
+    bool first;
+    u32 L;
+    bool plain, active, nd, notrim;
+};
+
+template <int GW>
+__device__ __forceinline__ PlainItem4 plain_fetch4(const u8 *seq, const u8 *seq4, u64 seq_bytes, const uint4 &my, u32 nb, u32 first,
+                                                   u32 lane) {
+    typedef PlainCfg<GW> C;
+    static_assert(!PP_PLAIN_ALIGNED, "the 4-bit plain class owns read-relative chunks");
+    PlainItem4 it;
+    const u32 g = C::group(lane), s = lane - (u32)GW * g;
+    const u32 j = first + g;
+    const int src = (int)(min(j, nb - 1u) << 2);
+    const u32 ex = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.x), ey = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.y);
+    const u32 ez = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.z);
+    it.rel = item_rel(ez);
+    it.notrim = ((ez >> 30) & 1u) != 0;
+    it.L = ey >> 24;
+    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.plain = g < C::IPP && j < nb && (ez >> 31) == 0 && C::ok(ex, ey, seq_bytes);
+    const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
+    it.rp = seq + so;
+    it.ib = (int)(32u * s);
+    it.first = s == 0;
+    it.active = it.plain && 32u * s < it.L;
+    it.W = make_uint4(0, 0, 0, 0);
+    it.tail = 0;
+    if (it.plain) it.tail = load4_unaligned(seq4 + ((so + (it.L - 1u)) >> 1) - 3);
+    it.e = so + (it.L - 1u);
+    if (it.active) {
+        const u64 n0 = so + 32u * s;
+        const u8 *q = seq4 + (n0 >> 1);
+        it.W = load16_unaligned(q);
+        if ((u32)n0 & 1u) {  // the piece starts on an odd base of the array (the flank behind an indel, a read after an odd-length one)
+            const u32 xb = q[16];
+            it.W = make_uint4(__builtin_amdgcn_alignbit(it.W.y, it.W.x, 4), __builtin_amdgcn_alignbit(it.W.z, it.W.y, 4),
+                              __builtin_amdgcn_alignbit(it.W.w, it.W.z, 4), __builtin_amdgcn_alignbit(xb, it.W.w, 4));
+        }
+    }
+    return it;
+}
+
+__device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const u32 *asm4, const PlainItem4 &it, u32 lane) {
+    const int rel = it.rel;
+    const u32 L = it.L;
+    int nkeep = trim4(it.tail, it.e, L);
+    if (it.notrim) nkeep = (int)L;
+    else if (it.plain && nkeep < 0) nkeep = trim_bytes(it.rp, L);  // rare
+    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+    const bool live = it.plain && hi > lo;
+    if (live && it.first) {
+        atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+        if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+        if (it.nd) {
+            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+            }
+        }
+    }
+    const int ib = it.ib;
+    const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
+    if (live && it.active && b1 > b0) {
+        const int P0 = rel + ib;  // window position of base 0 (> -32 here)
+        const u32 ai = (u32)(P0 + ASM4_PAD);
+        const u32 *ap = asm4 + (ai >> 3);
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+        const u32 sh = 4u * (ai & 7u);
+        u32 D = nz_nibbles(it.W.x ^ __builtin_amdgcn_alignbit(a1, a0, sh)) |
+                (nz_nibbles(it.W.y ^ __builtin_amdgcn_alignbit(a2, a1, sh)) << 8) |
+                (nz_nibbles(it.W.z ^ __builtin_amdgcn_alignbit(a3, a2, sh)) << 16) |
+                (nz_nibbles(it.W.w ^ __builtin_amdgcn_alignbit(a4, a3, sh)) << 24);
+        D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
+        while (D) {  // one trip per differing base
+            const int i = __ffs((int)D) - 1;
+            D &= D - 1u;
+            const u32 m8 = (u32)(((int)((u32)i << 28)) >> 31), m16 = (u32)(((int)((u32)i << 27)) >> 31);
+            const u32 wlo = (m8 & it.W.y) | (~m8 & it.W.x), whi = (m8 & it.W.w) | (~m8 & it.W.z);
+            const u32 code = (((m16 & whi) | (~m16 & wlo)) >> (4 * (i & 7))) & 15u;
+            const int p = P0 + i;
+            atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+        }
+    }
+}
+
+// ---- the plain class, ONE LANE PER READ (4-bit mirror, reads up to 192 bases) ------------------------------------------
+// What the item loop costs is VALU issue: a CDNA SIMD is 16 lanes wide, a wave instruction takes four cycles, and a pass of
+// the lane-group scheme above is ~350 of them for 12 reads -- the fields of the item, the trim, the coverage atomics are
+// worked out by all five lanes of a group, once per read (measured: 159 M wave instructions per configs[1] job = 0.26 ms of
+// issue on 256 CUs; halving the bytes with the mirror moved k_tile by 4 %).  With 75 bytes per read a lane can hold a whole
+// read: NCH 16-byte loads (20 VGPRs at 160 bases), and the same ~450 instructions then serve 64 reads instead of 12.
+// Lane l works on item l of the batch, straight from the batch registers (no ds_bpermute); its chunks are compared one
+// after the other against asm4 exactly as a lane of plain_apply4 compares its one.
+template <int NCH>
+__device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const u32 *asm4, const u8 *seq, const u8 *seq4, const uint4 &my,
+                                           bool mine) {
+    const u32 ex = my.x, ey = my.y, ez = my.z;
+    const int rel = item_rel(ez);
+    const bool notrim = ((ez >> 30) & 1u) != 0;
+    const u32 L = ey >> 24;
+    const bool nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
+    const u8 *q = seq4 + (so >> 1);
+    const bool odd = mine && ((u32)so & 1u) != 0;
+    uint4 W[NCH];
+    u32 tail = 0, xb = 0;
+    if (mine) tail = load4_unaligned(seq4 + ((so + (L - 1u)) >> 1) - 3);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        W[c] = make_uint4(0, 0, 0, 0);
+        if (mine && 32u * (u32)c < L) W[c] = load16_unaligned(q + 16 * c);
+    }
+    const u32 nch = (L + 31u) >> 5;  // chunks of this lane's read
+    if (odd) xb = q[16u * nch];
+    if (__ballot(odd)) {
+        // some read of the pass starts on an odd base of the array (the flank behind an indel, a read after one of odd
+        // length): its nibbles move down by one, the byte behind its last chunk fills the top
+        const u32 sh = odd ? 4u : 0u;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {  // in place, upwards: every dword takes its top nibble from the one after it
+            u32 nx = 0;                  // (chunks past the read's last one are zero)
+            if (c + 1 < NCH) nx = W[c + 1].x;
+            if ((u32)(c + 1) == nch) nx = xb;
+            W[c].x = __builtin_amdgcn_alignbit(W[c].y, W[c].x, sh);
+            W[c].y = __builtin_amdgcn_alignbit(W[c].z, W[c].y, sh);
+            W[c].z = __builtin_amdgcn_alignbit(W[c].w, W[c].z, sh);
+            W[c].w = __builtin_amdgcn_alignbit(nx, W[c].w, sh);
+        }
+    }
+    int nkeep = trim4(tail, so + (L - 1u), L);
+    if (notrim) nkeep = (int)L;
+    else if (mine && nkeep < 0) nkeep = trim_bytes(seq + so, L);  // rare: see trim4
+    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+    const bool live = mine && hi > lo;
+    if (live) {
+        atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+        if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+        if (nd) {
+            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
+            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int b0 = min(max(lo - 32 * c, 0), 32), b1 = min(max(hi - 32 * c, 0), 32);
+        if (live && b1 > b0) {
+            const int P0 = rel + 32 * c;  // window position of the chunk's base 0 (> -32 here)
+            const u32 ai = (u32)(P0 + ASM4_PAD);
+            const u32 *ap = asm4 + (ai >> 3);
+            const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+            const u32 sh = 4u * (ai & 7u);
+            u32 D = nz_nibbles(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh)) |
+                    (nz_nibbles(W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh)) << 8) |
+                    (nz_nibbles(W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh)) << 16) |
+                    (nz_nibbles(W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh)) << 24);
+            D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
+            while (D) {  // one trip per differing base
+                const int i = __ffs((int)D) - 1;
+                D &= D - 1u;
+                const u32 m8 = (u32)(((int)((u32)i << 28)) >> 31), m16 = (u32)(((int)((u32)i << 27)) >> 31);
+                const u32 wlo = (m8 & W[c].y) | (~m8 & W[c].x), whi = (m8 & W[c].w) | (~m8 & W[c].z);
+                const u32 code = (((m16 & whi) | (~m16 & wlo)) >> (4 * (i & 7))) & 15u;
+                const int p = P0 + i;
+                atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
+                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+            }
+        }
+    }
+}
+
 // ---- fast class of work items: a read without indels, <= FAST_MAX_LEN bases, inside its contig ----
 struct FastItem {  // wave-uniform (built from v_readlane results)
     u64 so;    // offset of the read in the seq array
@@ -450,23 +680,26 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
 // The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
 // hidden by the other 7 waves of the SIMD, not by software pipelining of the passes (which measured slower).
-template <int GW>
-__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, u32 e0, u32 e1,
-                                           u32 wave, u32 lane) {
+template <int GW, bool P4>
+__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, const u32 *asm4, u32 e0,
+                                           u32 e1, u32 wave, u32 lane) {
     typedef PlainCfg<GW> C;
+    // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
+    constexpr bool WIDE = P4 && GW == 5;
+    constexpr u32 IPP = WIDE ? 1u : C::IPP, BATCH = WIDE ? 64u : C::BATCH;
     // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
     // of the items does not matter: the counters are integers)
     constexpr u32 WAVES = TILE_THREADS / 64;
-    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + C::IPP - 1u) / C::IPP * C::IPP;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
     const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
     if (lo_w >= hi_w) return;
     // the records of the batch after the current one are asked for before the current one is worked on (2-5 % of the
     // kernel: a wave's chain of dependent round trips is what its time consists of)
-    uint4 nxt = A.entA[lo_w + min(lane, min(C::BATCH, hi_w - lo_w) - 1u)];
-    for (u32 eb = lo_w; eb < hi_w; eb += C::BATCH) {
-        const u32 nb = min(C::BATCH, hi_w - eb);
+    uint4 nxt = A.entA[lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u)];
+    for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
+        const u32 nb = min(BATCH, hi_w - eb);
         const uint4 my = nxt;
-        if (eb + C::BATCH < hi_w) nxt = A.entA[eb + C::BATCH + min(lane, min(C::BATCH, hi_w - eb - C::BATCH) - 1u)];
+        if (eb + BATCH < hi_w) nxt = A.entA[eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u)];
         const u32 my_flags = item_flags(my.y, my.z);
         const bool my_slow = lane < nb && (my_flags & 3u) != 0;
         const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
@@ -474,9 +707,14 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
-        if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
-        for (u32 first = 0; first < nb; first += C::IPP)
-            plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+        if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
+        if (WIDE) {
+            wide4_pass<GW>(cnt, s_ndbits, asm4, A.seq, A.seq4, my, my_plain);
+            if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
+        } else for (u32 first = 0; first < nb; first += C::IPP) {
+            if (P4) plain_apply4(cnt, s_ndbits, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, my, nb, first, lane), lane);
+            else plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+        }
         // the entry AT a read's single indel (ENT_POINT): one tally, one item per lane -- the two-byte key of an
         // insertion is counted by string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
         if (my_point) {
@@ -558,6 +796,7 @@ constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
+    __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty;
     __shared__ unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below)
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
@@ -634,6 +873,33 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         if (tid < (u32)ASM_PAD) ab[tid] = 0;
         if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
+    if (A.seq4 && tid >= TILE_THREADS - (u32)ASM4_WORDS) {  // (the last waves: the first two search the contig table)
+        const u32 t = tid - (TILE_THREADS - (u32)ASM4_WORDS);
+        const int p0 = 8 * (int)t - ASM4_PAD;  // dword t holds positions p0 .. p0 + 7
+        u32 lo8 = 0, hi8 = 0;                  // their bytes; 0 where there is no position (code "other": never compared)
+        if (p0 >= 0 && p0 + 8 <= TILE && w0 + (u64)p0 + 8u <= A.G) {
+            uint2 two;
+            __builtin_memcpy(&two, A.bases + w0 + (u64)p0, 8);  // one load
+            lo8 = two.x; hi8 = two.y;
+        } else {
+            for (int jj = 0; jj < 8; jj++) {
+                const int p = p0 + jj;
+                if (p >= 0 && p < TILE && w0 + (u64)p < A.G) {
+                    const u32 c = A.bases[w0 + (u64)p];
+                    if (jj < 4) lo8 |= c << (8 * jj); else hi8 |= c << (8 * (jj - 4));
+                }
+            }
+        }
+        u32 v = 0;
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const u32 c = ((jj < 4 ? lo8 : hi8) >> (8 * (jj & 3))) & 0xFFu;
+            const u32 tt = (c >> 1) & 3u, expect = (0x47544341u >> (tt * 8u)) & 0xFFu;
+            const u32 code = c == expect ? tt : (c == (u32)'N' ? (u32)PP_SEQ4_N : (c == (u32)'-' ? (u32)PP_SEQ4_DASH : SEQ4_ASM_OTHER));
+            v |= code << (4 * jj);
+        }
+        asm4[t] = v;
+    }
     if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; }
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
@@ -653,9 +919,13 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             i1 = min(e1, i0 + chunk);
         }
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
-        if (longest <= PlainCfg<5>::MAXL) tile_items<5>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
-        else if (longest <= PlainCfg<6>::MAXL) tile_items<6>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
-        else tile_items<8>(A, cnt, s_ndbits, asm_w, i0, i1, wave, lane);
+        if (A.seq4) {
+            if (longest <= PlainCfg<5>::MAXL) tile_items<5, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+            else if (longest <= PlainCfg<6>::MAXL) tile_items<6, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+            else tile_items<8, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+        } else if (longest <= PlainCfg<5>::MAXL) tile_items<5, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+        else tile_items<8, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
     }
     if (e1 - e0 >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);
     __syncthreads();

@@ -269,6 +269,7 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     d.seq_off = (const uint64_t *)ctx->b_in[3].p; d.seq_len = (const uint32_t *)ctx->b_in[4].p;
     d.cig_off = (const uint64_t *)ctx->b_in[5].p; d.n_cig = (const uint32_t *)ctx->b_in[6].p;
     d.seq = (const uint8_t *)ctx->b_in[7].p; d.cigar = (const uint32_t *)ctx->b_in[8].p;
+    d.seq4 = nullptr;  // gathered batches: no 4-bit mirror (it would have to be re-packed at every odd joint)
     return PP_OK;
 }
 
@@ -582,6 +583,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     TileArgs T;
     T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
     T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
+    static const bool no_seq4 = getenv("PP_SEQ4") && atoi(getenv("PP_SEQ4")) == 0;  // tuning / tests: ignore a batch's 4-bit mirror
+    T.seq4 = no_seq4 ? nullptr : B.seq4;
     T.n_cig = B.n_cig; T.cigar = B.cigar;
     T.bases = d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;

@@ -177,6 +177,7 @@ struct HostUnits {
 void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_total) {
     pp_aln_batch &v = P->view;
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
+    v.seq4 = nullptr;  // a part carries no 4-bit mirror
     if (P->mem == PP_MEM_DEVICE) {
         v.contig = (const u32 *)P->d[0]; v.ref_start = (const u32 *)P->d[1]; v.k = (const u32 *)P->d[2];
         v.seq_off = (const uint64_t *)P->d[3]; v.seq_len = (const u32 *)P->d[4]; v.cig_off = (const uint64_t *)P->d[5];

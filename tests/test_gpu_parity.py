@@ -34,6 +34,31 @@ def _seqs(fasta_bytes):
     return [l for l in fasta_bytes.decode().split("\n") if l and not l.startswith(">")]
 
 
+def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False, min_depth=5, fraction_valid=0.5,
+                         fraction_invalid=0.2):
+    """The records as ONE device-resident batch that is polished in place (what the device tokenizer hands over), with or
+    without the 4-bit mirror of the seq array (pp_aln_batch.seq4)."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(recs[k], dtype=dt)).to(dev) for k, dt in pp.REC_FIELDS}
+    tb = torch.from_numpy(np.ascontiguousarray(bases, dtype=np.uint8)).to(dev)
+    ptrs = {k: v.data_ptr() for k, v in t.items()}
+    if seq4:
+        mirror = torch.from_numpy(pp.pack_seq4(recs["seq"])).to(dev)
+        ptrs["seq4"] = mirror.data_ptr()
+    torch.cuda.synchronize()
+    pp.lib().pp_polish_set_debug(ctx._h, int(positions))
+    try:
+        ctx.polish_begin(contig_off, tb.data_ptr(), pp.MEM_DEVICE, min_depth, fraction_valid, fraction_invalid)
+        ctx.polish_add_ptrs(len(recs["contig"]), ptrs, len(recs["seq"]), len(recs["cigar"]), pp.MEM_DEVICE)
+        ctx.polish_finish()
+        polished, offs, stats = ctx.result()
+        res = {"polished": polished, "offsets": offs, "stats": stats, "positions": ctx.positions() if positions else None}
+    finally:
+        pp.lib().pp_polish_set_debug(ctx._h, 0)
+    return res
+
+
 def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
     want = orc.polish_records(contig_off, bases, recs, positions=True, **kw)
     got = ctx.polish_records(contig_off, bases, recs, positions=True, **kw)
@@ -60,6 +85,20 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         assert plain["stats"][c]["zero_depth"] == got["stats"][c]["zero_depth"], c
         dsum = float(want["positions"]["depth"][off[c]:off[c + 1]].sum())
         assert abs(plain["stats"][c]["depth_sum"] - dsum) <= (off[c + 1] - off[c]) * 2.0 ** -11 + 1e-6 * dsum, (c, plain["stats"][c], dsum)
+    # the same records as one device batch with the 4-bit mirror of the seq array (the plain class then reads nibbles):
+    # per position with the debug planes, bytes and figures without
+    if len(recs["contig"]):
+        import polypolish_amd as pp
+        m = _polish_device_batch(ctx, pp, contig_off, bases, recs, True, positions=True, **kw)
+        for k in POS_KEYS:
+            bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
+            assert len(bad) == 0, ("seq4", k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
+        assert m["polished"] == want["polished"]
+        m = _polish_device_batch(ctx, pp, contig_off, bases, recs, True, positions=False, **kw)
+        assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
+        for c in range(len(off) - 1):
+            assert m["stats"][c]["changed"] == got["stats"][c]["changed"], ("seq4", c)
+            assert m["stats"][c]["zero_depth"] == got["stats"][c]["zero_depth"], ("seq4", c)
     return want, got
 
 
@@ -397,6 +436,50 @@ def test_one_indel_reads_edge_cases(ctx, pp, orc):
     _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_invalid=0.1)
 
 
+def test_plain_reads_over_the_4bit_mirror_edge_cases(ctx, pp, orc):
+    """The plain class reads its bases from the 4-bit mirror of the seq array when a batch brings one (pp_aln_batch.seq4).
+    Reads without indels of every length 8..161 back to back (so every other one starts on an odd base of the array),
+    bytes from A C G T N and the bytes that have no code of their own (R, Y, '-', '.'), tails of one base repeated 1..9
+    times -- also of N, of R (shares its code with Y: the trim then goes through the bytes), of a read that IS one
+    homopolymer --, an assembly that holds N, R and '-' itself; against the oracle per position (_compare_records runs
+    the records with and without the mirror)."""
+    rng = np.random.default_rng(23)
+    G = 9000
+    alpha = np.frombuffer(b"ACGTNRY-.", np.uint8)
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, G)].copy()
+    for ch, cnt in ((b"N", 60), (b"R", 40), (b"-", 30)):
+        bases[rng.integers(0, G, cnt)] = ch[0]
+    rec = {k: [] for k in ("contig", "ref_start", "k", "seq_len", "n_cig")}
+    seqs = []
+    for rep in range(4):
+        for L in range(8, 162):
+            start = int(rng.integers(0, G - L))
+            s = bases[start:start + L].copy()                      # mostly the assembly's own bytes ...
+            mut = rng.random(L) < 0.08
+            s[mut] = alpha[rng.choice(len(alpha), int(mut.sum()), p=(.2, .2, .2, .2, .08, .04, .04, .02, .02))]
+            t = int(rng.integers(1, 10)) if rep != 3 else L        # ... ending in a run of t equal bytes
+            tb = alpha[int(rng.choice(len(alpha), p=(.2, .2, .2, .2, .08, .05, .03, .02, .02)))]
+            t = min(t, L)
+            s[L - t:] = tb
+            if L - t - 1 >= 0 and s[L - t - 1] == tb:
+                s[L - t - 1] = b"A"[0] if tb != b"A"[0] else b"C"[0]
+            rec["contig"].append(0); rec["ref_start"].append(start); rec["k"].append(int(rng.choice((1, 1, 1, 2, 3))))
+            rec["seq_len"].append(L); rec["n_cig"].append(1)
+            seqs.append(s)
+    n = len(seqs)
+    order = rng.permutation(n)
+    recs = {k: np.array(v, dtype=np.uint32)[order] for k, v in rec.items()}
+    lens = recs["seq_len"].astype(np.uint64)
+    recs["seq"] = np.concatenate([seqs[i] for i in order])
+    recs["seq_off"] = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    recs["cigar"] = ((recs["seq_len"] << 4) | 0).astype(np.uint32)
+    recs["cig_off"] = np.arange(n, dtype=np.uint64)
+    assert (recs["seq_off"] & 1).sum() > n // 4
+    contig_off = np.array([0, G], dtype=np.uint64)
+    _compare_records(ctx, orc, contig_off, bases, recs)
+    _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_invalid=0.05, fraction_valid=0.3)
+
+
 FILE_CASES = [
     dict(seed=31),
     dict(seed=32, contig_lens=(6000, 1200, 900), coverage=30, repeat_len=400, repeat_copies=3),
@@ -574,6 +657,7 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     for k in ("contig", "ref_start", "k", "seq_len", "cig_off", "n_cig", "cigar"):
         assert np.array_equal(want[k], got[k]), k
     assert len(got["seq"]) == len(want["seq"]) and not np.array_equal(got["seq_off"], want["seq_off"])
+    _check_mirror(pp, got, expect=True)   # the window-grouped batch brings the 4-bit mirror of its seq array
     so_w, so_g, sl = want["seq_off"].astype(np.int64), got["seq_off"].astype(np.int64), want["seq_len"].astype(np.int64)
     for i in list(range(0, len(sl), 37)) + [len(sl) - 1]:
         assert bytes(got["seq"][so_g[i]:so_g[i] + sl[i]]) == bytes(want["seq"][so_w[i]:so_w[i] + sl[i]]), i
@@ -592,6 +676,10 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     exe = os.path.join(ROOT, "bin", "polypolish")
     r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, PP_SEQ_LAYOUT="window"))
     assert r.returncode == 0 and r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"], r.stderr[-400:]
+    # ... the mirror without the layout, and the layout without the mirror
+    for env in (dict(PP_SEQ4="1"), dict(PP_SEQ_LAYOUT="window", PP_SEQ4="0")):
+        r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"], (env, r.stderr[-400:])
 
 
 def test_multi_process_driver_on_one_gpu(orc, tmp_path):
@@ -625,14 +713,32 @@ def _same_ingest(pp, ctx, fasta, sams, **kw):
         assert got[5] == want[5], (got[5], want[5])
         for k in want[4]:
             assert np.array_equal(got[4][k], want[4][k]), k
+        # the 4-bit mirror the tokenizer hands over with its batch (pp_aln_batch.seq4): base i of the seq ARRAY in nibble i
+        _check_mirror(pp, got[4], expect=os.environ.get("PP_SEQ4") == "1")
     return want, we
+
+
+def _check_mirror(pp, recs, expect):
+    """The 4-bit mirror the tokenizer hands over with its batch (pp_aln_batch.seq4): base i of the seq ARRAY in nibble i."""
+    assert ("seq4" in recs) == expect
+    if expect:
+        n = len(recs["seq"])
+        assert len(recs["seq4"]) == (n + 1) // 2
+        ref4 = pp.pack_seq4(recs["seq"])
+        assert np.array_equal(recs["seq4"][:n // 2], ref4[:n // 2])
+        if n & 1:
+            assert (recs["seq4"][n // 2] & 15) == (ref4[n // 2] & 15)
 
 
 @pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
 @pytest.mark.parametrize("careful", [False, True])
-def test_device_tokenizer_equals_host_ingest(pp, ctx, tmp_path, case, careful):
+def test_device_tokenizer_equals_host_ingest(pp, ctx, tmp_path, case, careful, monkeypatch):
     """pp_dev_ingest_*: SAM text tokenized by kernels; the batch must equal the host ingest's array by array
-    (and therefore what the reference's process_one_read would feed the pileup)."""
+    (and therefore what the reference's process_one_read would feed the pileup).  With PP_SEQ4=1 (every other case) the
+    batch brings the 4-bit mirror of its seq array: checked nibble by nibble (secondaries' SEQ filled in from the other
+    strand, lower case, bytes other than A/C/G/T)."""
+    if careful:
+        monkeypatch.setenv("PP_SEQ4", "1")
     ds = synth.rich_dataset(str(tmp_path), lowercase_frac=0.2, **case)
     want, err = _same_ingest(pp, ctx, ds["fasta"], [ds["sam1"], ds["sam2"]], max_errors=10, careful=careful)
     assert err is None and len(want[4]["contig"]) > 0

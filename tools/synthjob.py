@@ -390,6 +390,32 @@ def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=
             "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi]}
 
 
+def seq4_of(seq, chunk=1 << 27):
+    """The 4-bit mirror of a seq array (pp_aln_batch.seq4), as the device tokenizer produces it next to the bytes: base i
+    of the array in bits 4*(i&1).. of byte i >> 1, codes PP_SEQ4_* (A C T G = 0..3, N 4, '-' 5, anything else 15); 64
+    bytes of slack behind."""
+    dev = seq.device
+    lut = torch.full((256,), 15, dtype=torch.uint8, device=dev)
+    for ch, v in ((65, 0), (67, 1), (84, 2), (71, 3), (78, 4), (45, 5)):
+        lut[ch] = v
+    n = seq.numel()
+    out = torch.zeros((n + 1) // 2 + 64, dtype=torch.uint8, device=dev)
+    for lo in range(0, n, chunk):                       # (chunk is even: every piece starts on a byte of the mirror)
+        c = lut[seq[lo:lo + chunk].long()]
+        if c.numel() & 1:
+            c = torch.cat([c, torch.zeros(1, dtype=torch.uint8, device=dev)])
+        out[lo // 2:lo // 2 + c.numel() // 2] = c[0::2] | (c[1::2] << 4)
+    return out
+
+
+def with_seq4(job, on=True):
+    """The job with (or without) the 4-bit mirror of its seq array: job["seq4"], handed to the library as pp_aln_batch.seq4."""
+    out = dict(job)
+    out.pop("_prepared", None)
+    out["seq4"] = seq4_of(job["recs"]["seq"]) if on else None
+    return out
+
+
 def window_grouped(job, window=2048):
     """The same job with the SEQ bytes laid out WINDOW-GROUPED: the reads of one 2048-position window are adjacent in the
     seq array (windows in order, file order inside a window); every other array -- and the order of the records -- is
@@ -410,6 +436,8 @@ def window_grouped(job, window=2048):
     recs["seq"] = r["seq"].view(n, L)[order].reshape(-1).contiguous()
     recs["seq_off"] = (slot * L).contiguous()
     out["recs"] = recs
+    if job.get("seq4") is not None:
+        out["seq4"] = seq4_of(recs["seq"])
     return out
 
 
