@@ -246,10 +246,13 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
             env["PP_DEVICE_INGEST"] = "1"
             t_win, r_win = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="window", PP_TIMING="1"), repeat=rep)
             if t_win is not None:
-                extra = sum(float(l.split()[-2]) for l in r_win.stderr.decode(errors="replace").splitlines()
-                            if l.startswith("[timing]") and "window layout" in l)
+                lines = [l for l in r_win.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")]
+                extra = sum(float(l.split()[-2]) for l in lines if "window layout" in l)
+                mirror = sum(float(l.split()[-2]) for l in lines if "4-bit mirror" in l)
                 out["polish_window_grouped_seq"] = {"wall_s": round(t_win, 3), "parity": sha(r_win.stdout) == want,
-                                                    "tokenizer_extra_ms": round(1e3 * extra, 2)}
+                                                    "tokenizer_extra_ms": round(1e3 * extra, 2),
+                                                    "tokenizer_mirror_ms": round(1e3 * mirror, 2),
+                                                    "batch": "SEQ window-grouped + the 4-bit mirror (pp_aln_batch.seq4)"}
         ok = out["polish"]["parity"] and out.get("polish_host_ingest", {}).get("parity", True)
         del r_dev, r_host, r_cpu
         if not big:
@@ -554,40 +557,48 @@ def main():
         if traffic is not None:
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
-    second = None
-    if world == 1 and args.seq_layout == "file" and not args.no_second_layout:
-        # The same job with its SEQ bytes window-grouped (what the tokenizer writes with PP_SEQ_WINDOW_GROUPED): a second
-        # roofline entry beside the headline's file order, measured the same way; what the layout costs the tokenizer is in
-        # the e2e block (polish_window_grouped_seq.tokenizer_extra_ms).
+    second = third = None
+    if world == 1 and args.seq_layout == "file" and args.seq4 == "off" and not args.no_second_layout:
+        # The same job as the device tokenizer hands it over with PP_SEQ_LAYOUT=window: (second entry) its SEQ bytes
+        # window-grouped; (third) that layout with the 4-bit mirror of the seq array the tokenizer writes next to it
+        # (pp_aln_batch.seq4).  Measured like the headline; what the layout and the mirror cost the tokenizer is in the e2e
+        # block (polish_window_grouped_seq.tokenizer_extra_ms).
+        def other_layout(wj, what, seq4_flag):
+            ctx.set_profiling(0)
+            for _ in range(args.warmup):
+                run_job(ctx, pp, wj)
+            ctx.set_profiling(2)
+            w_ms = []
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                run_job(ctx, pp, wj)
+                kt = ctx.kernel_times()["ms"]
+                if kt:
+                    w_ms.append(next(iter(kt.values())))
+            ctx.sync()
+            torch.cuda.synchronize()
+            w_step = 1e3 * (time.perf_counter() - tw) / args.steps
+            ctx.set_profiling(0)
+            w_polished, _, _ = ctx.result()
+            w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
+            w_traffic = None
+            if dom_name and not args.no_live_traffic:
+                lt = live_traffic(["--config", str(args.config), "--seq4", seq4_flag, "--seq-layout", "window", "--recipe", args.recipe,
+                                   "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
+                w_traffic = lt["hbm_bytes"] if lt else None
+            return {"layout": what, "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(w_kernel, 4),
+                    "achieved": round(b_alg / (w_kernel * 1e-3) / 1e9, 1) if w_kernel else 0.0, "peak": peak, "unit": "GB/s",
+                    "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
+                    "ms_per_step": round(w_step, 4), "mbp_per_s": round(G_total / 1e6 / (w_step * 1e-3), 1) if w_step else None,
+                    "same_polished_bytes": bool(w_polished == polished)}
         wj = synthjob.window_grouped(job)
-        ctx.set_profiling(0)
-        for _ in range(args.warmup):
-            run_job(ctx, pp, wj)
-        ctx.set_profiling(2)
-        w_ms = []
-        torch.cuda.synchronize()
-        tw = time.perf_counter()
-        for _ in range(args.steps):
-            run_job(ctx, pp, wj)
-            kt = ctx.kernel_times()["ms"]
-            if kt:
-                w_ms.append(next(iter(kt.values())))
-        ctx.sync()
-        torch.cuda.synchronize()
-        w_step = 1e3 * (time.perf_counter() - tw) / args.steps
-        ctx.set_profiling(0)
-        w_polished, _, _ = ctx.result()
-        w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
-        w_traffic = None
-        if dom_name and not args.no_live_traffic:
-            lt = live_traffic(["--config", str(args.config), "--seq4", args.seq4, "--seq-layout", "window", "--recipe", args.recipe,
-                               "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
-            w_traffic = lt["hbm_bytes"] if lt else None
-        second = {"layout": "SEQ bytes window-grouped (pp_dev_ingest_set_seq_layout; every other array and every result unchanged)",
-                  "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(w_kernel, 4),
-                  "achieved": round(b_alg / (w_kernel * 1e-3) / 1e9, 1) if w_kernel else 0.0, "peak": peak, "unit": "GB/s",
-                  "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
-                  "ms_per_step": round(w_step, 4), "same_polished_bytes": bool(w_polished == polished)}
+        second = other_layout(wj, "SEQ bytes window-grouped (pp_dev_ingest_set_seq_layout; every other array and every result unchanged)",
+                              "off")
+        wj = synthjob.with_seq4(wj)
+        third = other_layout(wj, "SEQ bytes window-grouped + the 4-bit mirror of the seq array (pp_aln_batch.seq4): the batch of the device "
+                                 "tokenizer with PP_SEQ_LAYOUT=window; the reads without indels are fetched from the mirror, one lane per read",
+                             "on")
         del wj
     # What the dominant kernel actually moves, as a rate: the algorithmic fraction above prices a 150-byte read at 150
     # bytes, the memory system fetches the 128-byte lines it touches (2.16 of them at an arbitrary byte offset).  6290 GB/s
@@ -600,8 +611,9 @@ def main():
         return {"rate": round(rate, 1), "unit": "GB/s", "frac_of_peak": round(rate / peak, 4),
                 "frac_of_practical_copy_rate": round(rate / PRACTICAL, 4), "practical_copy_rate": PRACTICAL,
                 "bytes_moved_per_algorithmic_byte": round(traffic_bytes / b_alg, 3)}
-    if second is not None:
-        second["hbm_actual"] = moved(second.get("traffic"), second.get("kernel_ms"))
+    for extra in (second, third):
+        if extra is not None:
+            extra["hbm_actual"] = moved(extra.get("traffic"), extra.get("kernel_ms"))
     out = {
         "metric": METRIC,
         "value": round(value, 2),
@@ -618,7 +630,8 @@ def main():
         "config": {"workload": label + f" alignment records resident in HBM ({job['n_aln']} records"
                                        f"{' in total' if strong else ''}; recipe '{args.recipe}': assembly errors {job['planted']}, "
                                        f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel"
-                                       + ("; SEQ bytes WINDOW-GROUPED (experiment, not the headline layout)" if args.seq_layout == "window" else "") + ")",
+                                       + ("; SEQ bytes WINDOW-GROUPED (experiment, not the headline layout)" if args.seq_layout == "window" else "")
+                                       + ("; with the 4-bit mirror of the seq array, pp_aln_batch.seq4 (experiment, not the headline batch)" if args.seq4 == "on" else "") + ")",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},
@@ -628,6 +641,7 @@ def main():
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
         "roofline_window_grouped_seq": second,
+        "roofline_window_grouped_seq4": third,
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
         "work": work,
         "planted_errors_recovered": recovered,

@@ -766,9 +766,11 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
                        (const u32 *)D->d_src.p, seq_place, O.seq, D->seq_bytes);
     if (D->mirror() && seq_total) {  // the mirror of this file's stretch of the seq array (from the 32-byte boundary in front of it)
+        if (timing) lap("seq bytes");
         const u64 lo = D->seq_bytes & ~31ull, hi = D->seq_bytes + seq_total;
         hipLaunchKernelGGL(k_tok_pack4, dim3((unsigned)(((hi - lo + 31) / 32 + 255) / 256)), dim3(256), 0, st, (const u8 *)D->o_seq.p,
                            (u8 *)D->o_seq4.p, lo, hi);
+        if (timing) lap("4-bit mirror");
     }
     hipLaunchKernelGGL(k_tok_cigar, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
