@@ -436,9 +436,11 @@ def test_one_indel_reads_edge_cases(ctx, pp, orc):
     _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_invalid=0.1)
 
 
-def test_plain_reads_over_the_4bit_mirror_edge_cases(ctx, pp, orc):
-    """The plain class reads its bases from the 4-bit mirror of the seq array when a batch brings one (pp_aln_batch.seq4).
-    Reads without indels of every length 8..161 back to back (so every other one starts on an odd base of the array),
+@pytest.mark.parametrize("max_len", [160, 171], ids=["one_lane_per_read", "lane_groups"])
+def test_plain_reads_over_the_4bit_mirror_edge_cases(ctx, pp, orc, max_len):
+    """The plain class reads its bases from the 4-bit mirror of the seq array when a batch brings one (pp_aln_batch.seq4):
+    with a whole read per lane while no read of the job is longer than 160 bases (wide4_pass), with lane groups beyond.
+    Reads without indels of every length 8..max_len back to back (so every other one starts on an odd base of the array),
     bytes from A C G T N and the bytes that have no code of their own (R, Y, '-', '.'), tails of one base repeated 1..9
     times -- also of N, of R (shares its code with Y: the trim then goes through the bytes), of a read that IS one
     homopolymer --, an assembly that holds N, R and '-' itself; against the oracle per position (_compare_records runs
@@ -452,7 +454,7 @@ def test_plain_reads_over_the_4bit_mirror_edge_cases(ctx, pp, orc):
     rec = {k: [] for k in ("contig", "ref_start", "k", "seq_len", "n_cig")}
     seqs = []
     for rep in range(4):
-        for L in range(8, 162):
+        for L in range(8, max_len + 1):
             start = int(rng.integers(0, G - L))
             s = bases[start:start + L].copy()                      # mostly the assembly's own bytes ...
             mut = rng.random(L) < 0.08
