@@ -446,12 +446,17 @@ int pp_dev_ingest_sam_filtered(pp_dev_ingest *g, const char *path, const uint8_t
  * PP_SEQ_FILE_ORDER (default) = in the order of the records; PP_SEQ_WINDOW_GROUPED = the reads that start in one
  * 2048-position window of the assembly are adjacent (per SAM file) -- the pileup kernel then fetches a window's reads
  * from one stretch of memory instead of all over the array (1.2 GB moved instead of 2.1 GB on a 5 Mbp / 200x job,
- * k_tile 17 % faster) at the price of a count / scan / placement pass in the tokenizer.  Every other array, the order of
- * the records and every result are the same.  Set before the first pp_dev_ingest_sam*; `PP_SEQ_LAYOUT=window` in the
+ * k_tile 17 % faster) at the price of a count / scan / placement pass in the tokenizer (well under a millisecond per GB of
+ * text); the batch then also brings the 4-bit mirror of its seq array (pp_aln_batch.seq4), which takes k_tile to 0.6 of
+ * the HBM roofline.  Every other array, the order of the records and every result are the same.  Set before the first pp_dev_ingest_sam*; `PP_SEQ_LAYOUT=window` in the
  * environment selects it for the file drivers. */
 #define PP_SEQ_FILE_ORDER 0
 #define PP_SEQ_WINDOW_GROUPED 1
 int pp_dev_ingest_set_seq_layout(pp_dev_ingest *g, int layout);
+/* Optional hint, before the first file: the bytes of SAM text of ALL the files that will be handed to this ingest.  The
+ * batch's arrays are then sized once, for all of them, off the first file (without it the second file makes every array
+ * grow: a device allocation and a copy of what the first one filled -- 6 ms on a 2 x 1.2 GB pair). */
+int pp_dev_ingest_expect(pp_dev_ingest *g, uint64_t total_text_bytes);
 void pp_dev_ingest_batch(const pp_dev_ingest *g, pp_aln_batch *out); /* borrowed view, DEVICE memory */
 void pp_dev_ingest_free(pp_dev_ingest *g);
 

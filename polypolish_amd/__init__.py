@@ -126,7 +126,7 @@ EXPORTS = [
     "pp_shard_plan_create", "pp_shard_plan_free", "pp_shard_emit_ranges", "pp_shard_assemble",
     "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather", "pp_polish_files_multi",
     "pp_shard_split", "pp_shard_part_batch", "pp_shard_part_mem", "pp_shard_part_free", "pp_shard_count",
-    "pp_polish_error_record", "pp_polish_error_text", "pp_dev_ingest_set_seq_layout",
+    "pp_polish_error_record", "pp_polish_error_text", "pp_dev_ingest_set_seq_layout", "pp_dev_ingest_expect",
 ]
 
 _lib = None

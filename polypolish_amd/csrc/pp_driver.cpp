@@ -395,12 +395,16 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     else rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
                          : (per_file ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
     if (rc == PP_OK && dev_ingest && !sharded) {
-        uint64_t largest = 0;
+        uint64_t largest = 0, total = 0;
         for (int i = 0; i < n_sams; i++) {
             struct stat st;
-            if (stat(sams[i], &st) == 0 && S_ISREG(st.st_mode)) largest = std::max<uint64_t>(largest, (uint64_t)st.st_size);
+            if (stat(sams[i], &st) == 0 && S_ISREG(st.st_mode)) {
+                largest = std::max<uint64_t>(largest, (uint64_t)st.st_size);
+                total += (uint64_t)st.st_size;
+            }
         }
         if (largest) rc = pp_dev_ingest_reserve_text_(dg, largest);
+        if (rc == PP_OK && n_sams > 1) rc = pp_dev_ingest_expect(dg, total);  // the batch's arrays sized once, for all the files
     }
     uint64_t alignment_total = 0, used_total = 0;
     // sharded: the records of file i's slice on context s are records [slice_end[i-1][s], slice_end[i][s]) of its batch
