@@ -96,3 +96,26 @@ def test_cli_argument_grammar_is_claps():
     for args in (["-h"], ["--help"], ["polish", "-h"], ["polish", "-hV"], ["filter", "--help"], ["-V"], ["polish", "-V"]):
         r = subprocess.run([exe] + args, capture_output=True)
         assert r.returncode == 0 and r.stdout, args
+
+
+def test_the_4bit_mirror_of_a_seq_array_as_the_header_defines_it():
+    """pp_aln_batch.seq4 (include/polypolish_hip.h): base i of the seq ARRAY in bits 4*(i&1).. of byte i >> 1, codes
+    PP_SEQ4_* read off the header; the binding's packer (the tests' reference for the device tokenizer's mirror) and the
+    bench's torch packer agree with that definition and with each other, for even and odd lengths."""
+    import re
+    import torch
+    import polypolish_amd as pp
+    hdr = open(os.path.join(ROOT, "include", "polypolish_hip.h")).read()
+    code = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define PP_SEQ4_(\w+) (\d+)", hdr)}
+    assert code == {"A": 0, "C": 1, "T": 2, "G": 3, "N": 4, "DASH": 5, "OTHER": 15}
+    want = {ord("A"): code["A"], ord("C"): code["C"], ord("T"): code["T"], ord("G"): code["G"], ord("N"): code["N"],
+            ord("-"): code["DASH"]}
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 9, 1000, 1001):
+        seq = np.frombuffer(b"ACGTNRYacgtn-.*", np.uint8)[rng.integers(0, 15, n)].copy()
+        m = pp.pack_seq4(seq)
+        assert len(m) >= (n + 1) // 2 + 32                     # the slack the header asks for
+        for i in range(n):
+            assert (int(m[i >> 1]) >> (4 * (i & 1))) & 15 == want.get(int(seq[i]), code["OTHER"]), (n, i)
+        t = synthjob.seq4_of(torch.from_numpy(seq), chunk=64).numpy()
+        assert np.array_equal(t[:(n + 1) // 2], m[:(n + 1) // 2])
