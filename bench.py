@@ -314,6 +314,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000,
                     help="bp of one contig given to the CPU oracle (default: the whole 5 Mbp job of config 1, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seq-pitch", type=int, default=-1,
+                    help="bytes of the seq array per record: -1 (default) = as the product's ingests lay it out, every record's SEQ on a "
+                         "32-byte boundary (PP_SEQ_ALIGN); 0 = packed back to back (the bench lines of rounds 1-3)")
     ap.add_argument("--seq4", default="off", choices=["on", "off"],
                     help="hand the 4-bit mirror of the seq array over with the batch (pp_aln_batch.seq4), as the device tokenizer does")
     ap.add_argument("--seq-layout", default="file", choices=["file", "window"],
@@ -371,7 +374,7 @@ def main():
     strong = world > 1 and args.config in (3, 4)
     if args.indel_frac is None:
         args.indel_frac = synthjob.SURVEY_INDEL_READ_FRAC if args.recipe == "survey" else 0.01
-    default_shape = (args.seq_layout == "file" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
+    default_shape = (args.seq_layout == "file" and args.seq_pitch == -1 and args.seq4 == "off" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
                      args.repeat_bp == 0 and args.nd_frac == 0.0 and args.genome is None and args.coverage is None)
     # config 1: this rank's own 5 Mbp contig (seed differs per rank); configs 3 / 4 with N > 1: every rank builds
     # the same job and keeps its shard
@@ -387,7 +390,7 @@ def main():
     job = make_job(device, contig_lens=lens, coverage=coverage, read_len=args.read_len,
                    seed=42 + args.config + 1 + (0 if strong else 1000 * rank),
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate, repeat=repeat,
-                   repeat_bp=args.repeat_bp, recipe=args.recipe)
+                   repeat_bp=args.repeat_bp, recipe=args.recipe, seq_pitch=None if args.seq_pitch < 0 else args.seq_pitch)
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
     if args.seq4 == "on":
         job = synthjob.with_seq4(job)
@@ -539,7 +542,7 @@ def main():
     # command (N = 1); failing that, the committed figure of the same workload (profiles/traffic.json), else null.
     traffic = traffic_source = None
     if world == 1 and dom_name and not args.no_live_traffic:
-        tail = ["--config", str(args.config), "--seq4", args.seq4, "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
+        tail = ["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--seq4", args.seq4, "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
                 "--n-rate", repr(args.n_rate), "--read-len", str(args.read_len), "--repeat-bp", str(args.repeat_bp), "--nd-frac", repr(args.nd_frac)]
         if args.genome is not None:
             tail += ["--genome", str(args.genome)]
@@ -584,7 +587,7 @@ def main():
             w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
             w_traffic = None
             if dom_name and not args.no_live_traffic:
-                lt = live_traffic(["--config", str(args.config), "--seq4", seq4_flag, "--seq-layout", "window", "--recipe", args.recipe,
+                lt = live_traffic(["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--seq4", seq4_flag, "--seq-layout", "window", "--recipe", args.recipe,
                                    "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
                 w_traffic = lt["hbm_bytes"] if lt else None
             return {"layout": what, "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(w_kernel, 4),
@@ -631,7 +634,9 @@ def main():
                                        f"{' in total' if strong else ''}; recipe '{args.recipe}': assembly errors {job['planted']}, "
                                        f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel"
                                        + ("; SEQ bytes WINDOW-GROUPED (experiment, not the headline layout)" if args.seq_layout == "window" else "")
-                                       + ("; with the 4-bit mirror of the seq array, pp_aln_batch.seq4 (experiment, not the headline batch)" if args.seq4 == "on" else "") + ")",
+                                       + ("; with the 4-bit mirror of the seq array, pp_aln_batch.seq4 (experiment, not the headline batch)" if args.seq4 == "on" else "")
+                                       + ("; every record's SEQ on a 32-byte boundary of the seq array, as pp_ingest_* / pp_dev_ingest_* lay it out"
+                                          if args.seq_pitch < 0 else ("; SEQ packed back to back" if args.seq_pitch == 0 else f"; SEQ pitch {args.seq_pitch} bytes")) + ")",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},

@@ -34,6 +34,8 @@ using pph::HugeBuf;
 using pph::parallel_for;
 
 namespace {
+// bytes of the seq array a record of n SEQ bytes takes (include/polypolish_hip.h: PP_SEQ_ALIGN)
+inline size_t seq_room(size_t n) { return (n + (size_t)PP_SEQ_ALIGN - 1) & ~((size_t)PP_SEQ_ALIGN - 1); }
 
 struct IngestError {
     int code;
@@ -623,7 +625,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                 if (a.ref_start > 0xFFFFFFFEull)
                     fail(PP_ERR_PANIC, "alignment of read %.*s starts past the end of %.*s", (int)a.name_n, a.name, (int)a.ref_n, a.ref);
                 o.k = n_good;
-                P.seq_sum += o.star ? o.src->seq_n : a.seq_n;
+                P.seq_sum += seq_room(o.star ? o.src->seq_n : a.seq_n);
                 P.cig_sum += a.run_n;
                 P.nam_sum += a.name_n + 1;
             }
@@ -731,7 +733,8 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                             dst[j] = (ch >= 'a' && ch <= 'z') ? (unsigned char)(ch - 32) : ch;  // to_ascii_uppercase
                         }
                     }
-                    so += sn;
+                    memset(dst + sn, 0, seq_room(sn) - sn);  // every record's SEQ starts on a PP_SEQ_ALIGN boundary
+                    so += seq_room(sn);
                     I->cig_off[d] = co;
                     I->n_cig[d] = a.run_n;
                     memcpy(I->cigar.data() + co, o.runs, (size_t)a.run_n * 4);

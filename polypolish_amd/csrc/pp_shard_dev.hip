@@ -34,6 +34,8 @@ struct pp_shard_part {
 };
 
 namespace {
+// bytes of the part's seq array a record takes: its SEQ bytes up to the next PP_SEQ_ALIGN boundary (include/polypolish_hip.h)
+__host__ __device__ inline u32 seq_room(u32 n) { return (n + (u32)PP_SEQ_ALIGN - 1u) & ~((u32)PP_SEQ_ALIGN - 1u); }
 
 struct UnitTable {       // the plan, per contig: units [first[c], first[c + 1]), in position order
     const u32 *first;    // n_contigs + 1
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_split_flag(u64 n, const u32 *__restrict
     if (span == 0) span = 1;
     const bool sel = goes_to(T, contig[i], ref_start[i], span, dest);
     flag[i] = sel ? 1u : 0u;
-    sel_seq[i] = sel ? seq_len[i] : 0u;
+    sel_seq[i] = sel ? seq_room(seq_len[i]) : 0u;
     sel_cig[i] = sel ? nr : 0u;
 }
 
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void k_split_seq(u64 n, const u64 *__restrict_
         __builtin_memcpy(o + b, &v, 16);
     }
     for (u32 b = whole + s; b < len; b += 8) o[b] = in[b];
+    for (u32 b = len + s; b < seq_room(len); b += 8) o[b] = 0;  // up to the next record's boundary
 }
 
 __global__ __launch_bounds__(256) void k_split_cigar(u64 n, const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
@@ -208,7 +211,7 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
             if (ref_consuming(cg[r] & 15u)) span += cg[r] >> 4;
         if (span == 0) span = 1;
         sel[i] = goes_to(T, B->contig[i], B->ref_start[i], span, dest);
-        if (sel[i]) { cnt++; seq_total += B->seq_len[i]; cig_total += B->n_cig[i]; }
+        if (sel[i]) { cnt++; seq_total += seq_room(B->seq_len[i]); cig_total += B->n_cig[i]; }
     }
     P->h_contig.reserve(cnt); P->h_ref_start.reserve(cnt); P->h_k.reserve(cnt); P->h_seq_len.reserve(cnt); P->h_n_cig.reserve(cnt);
     P->h_orig.reserve(cnt); P->h_seq_off.reserve(cnt); P->h_cig_off.reserve(cnt);
@@ -221,7 +224,7 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
         P->h_seq_off.push_back(so); P->h_cig_off.push_back(co);
         memcpy(P->h_seq.data() + so, B->seq + B->seq_off[i], B->seq_len[i]);
         memcpy(P->h_cigar.data() + co, B->cigar + B->cig_off[i], (size_t)B->n_cig[i] * 4);
-        so += B->seq_len[i]; co += B->n_cig[i];
+        so += seq_room(B->seq_len[i]); co += B->n_cig[i];  // (h_seq was zero-filled: so are the bytes up to the boundary)
     }
     set_view(P, cnt, seq_total, cig_total);
     return PP_OK;

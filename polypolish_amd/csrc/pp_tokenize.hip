@@ -245,6 +245,13 @@ __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, 
     }
 }
 
+// bytes of the seq array a good record takes: its SEQ bytes up to the next PP_SEQ_ALIGN boundary (include/polypolish_hip.h)
+__device__ __host__ __forceinline__ u32 seq_room(u32 n) { return (n + (u32)PP_SEQ_ALIGN - 1u) & ~((u32)PP_SEQ_ALIGN - 1u); }
+__global__ __launch_bounds__(256) void k_tok_room(u32 n_aln, const u32 *__restrict__ g_seq_len, u32 *__restrict__ g_room) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_aln) g_room[r] = seq_room(g_seq_len[r]);
+}
+
 // ---- output: the structure of arrays of pp_aln_batch ----------------------------------------------
 struct OutArrays {
     u32 *contig, *ref_start, *k, *seq_len, *n_cig, *cigar;
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, co
             if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
             out[i] = c;
         }
+        for (u32 i = n + s; i < seq_room(n); i += 8) out[i] = 0;  // up to the next record's boundary
         return;
     }
     for (u32 i = s; i < n; i += 8) {  // a "*" record on the other strand (rare): byte-wise, reversed and complemented
@@ -323,6 +331,7 @@ __global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, co
         if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
         out[i] = comp_upper(c);
     }
+    for (u32 i = n + s; i < seq_room(n); i += 8) out[i] = 0;
 }
 
 // ---- the 4-bit mirror of the seq array (pp_aln_batch.seq4) ---------------------------------------------
@@ -474,7 +483,7 @@ struct pp_dev_ingest {
     pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos;
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
-        d_good, d_k, d_src, d_gseq, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
+        d_good, d_k, d_src, d_gseq, d_groom, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
     // output (grows over the files)
     pp::DevBuf o_contig, o_ref_start, o_k, o_seq_len, o_n_cig, o_cigar, o_seq_off, o_cig_off, o_seq;
     pp::DevBuf o_seq4;   // the 4-bit mirror of o_seq (pp_aln_batch.seq4)
@@ -541,7 +550,7 @@ extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     (void)hipStreamSynchronize(D->ctx->stream);
     pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
-                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
+                         &D->d_k, &D->d_src, &D->d_gseq, &D->d_groom, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
                          &D->o_cig_off, &D->o_seq, &D->o_seq4};
     for (pp::DevBuf *b : all) pp::dev_free(*b);
@@ -751,7 +760,7 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         if ((rc = fetch(ctx, (const u32 *)D->d_grpofrec.p + n_aln, &n_groups))) return rc;
         ENS(d_gfirst, ((u64)n_groups + 1) * 4);
         ENS(d_good, (u64)n_aln * 4); ENS(d_k, (u64)n_aln * 4); ENS(d_src, (u64)n_aln * 4);
-        ENS(d_gseq, (u64)n_aln * 4); ENS(d_gcig, (u64)n_aln * 4);
+        ENS(d_gseq, (u64)n_aln * 4); ENS(d_groom, (u64)n_aln * 4); ENS(d_gcig, (u64)n_aln * 4);
         ENS(d_outidx, ((u64)n_aln + 1) * 4); ENS(d_seqscan, ((u64)n_aln + 1) * 8); ENS(d_cigscan, ((u64)n_aln + 1) * 8);
         hipLaunchKernelGGL(k_tok_group_first, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_isstart.p,
                            (const u32 *)D->d_grpofrec.p, n_groups, (u32 *)D->d_gfirst.p);
@@ -760,7 +769,8 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
                            n_lines, D->max_errors, D->careful, d_pass, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
                            (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, d_status);
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p))) return rc;
-        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gseq.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
+        hipLaunchKernelGGL(k_tok_room, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_gseq.p, (u32 *)D->d_groom.p);
+        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_groom.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
         if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p))) return rc;
     }
     u64 status = ~0ull;
@@ -814,20 +824,20 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         const unsigned wg = (unsigned)((n_aln + 1024u * WIN_RPT - 1u) / (1024u * WIN_RPT));
         if (in_lds)
             hipLaunchKernelGGL(k_tok_win_bytes_lds, dim3(wg), dim3(1024), 0, st, (const LineRec *)D->d_rec.p,
-                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
                                (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_wbytes.p);
         else
         hipLaunchKernelGGL(k_tok_win_bytes, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
-                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
                            (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_wbytes.p);
         if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
         if (in_lds)
             hipLaunchKernelGGL(k_tok_win_place_lds, dim3(wg), dim3(1024), 0, st, (const LineRec *)D->d_rec.p,
-                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
                                (const u64 *)D->t_ctgoff.p, n_win, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
         else
         hipLaunchKernelGGL(k_tok_win_place, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
-                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_gseq.p,
+                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
                            (const u64 *)D->t_ctgoff.p, n_win, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
         seq_place = (const u64 *)D->d_seqpos.p;
         lap("window layout");

@@ -663,10 +663,10 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     so_w, so_g, sl = want["seq_off"].astype(np.int64), got["seq_off"].astype(np.int64), want["seq_len"].astype(np.int64)
     for i in list(range(0, len(sl), 37)) + [len(sl) - 1]:
         assert bytes(got["seq"][so_g[i]:so_g[i] + sl[i]]) == bytes(want["seq"][so_w[i]:so_w[i] + sl[i]]), i
-    covered = np.zeros(len(got["seq"]) + 1, dtype=np.int64)   # the records' stretches tile the seq array exactly
+    covered = np.zeros(len(got["seq"]) + 1, dtype=np.int64)   # the records' stretches (each up to its PP_SEQ_ALIGN boundary) tile the seq array exactly
     np.add.at(covered, so_g, 1)
-    np.add.at(covered, so_g + sl, -1)
-    assert (np.cumsum(covered)[:-1] == 1).all()
+    np.add.at(covered, so_g + ((sl + 31) & ~31), -1)
+    assert (np.cumsum(covered)[:-1] == 1).all() and (so_g % 32 == 0).all()
     n1 = counts[0][1]                                        # good records of file 1: their stretch comes first
     win = (off[got["contig"]].astype(np.int64) + got["ref_start"].astype(np.int64)) // 2048
     for lo, hi in ((0, n1), (n1, len(sl))):

@@ -43,6 +43,7 @@ def _excl_cumsum(x):
 
 
 def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=42, sub_rate=0.002, n_rate=1e-4,
+             seq_pitch=None,
              asm_err_rate=1e-4, recipe="survey", indel_read_frac=None, repeat=None, repeat_bp=0, repeat_k=5, pairs=False,
              unaligned_frac=0.0, G=None, end_margin=1000, asm_sub_rate=None):
     """One synthetic polish job (see the module docstring).  contig_lens are TRUTH lengths; the assembly's differ by
@@ -384,10 +385,14 @@ def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=
                "contig": contig.int(), "ref_start": rs_a.int(), "cig_off": cig_off, "n_cig": n_cig.int(), "cigar": cigar.int(),
                "seq_off": torch.arange(n, device=dev, dtype=i64) * L, "seq_len": seq_len_text.int(), "seq": seq,
                "half": half, "n": n}
-    return {"G": Ga, "contig_off": aoff.cpu().numpy().astype(np.uint64), "bases": bases, "recs": recs,
-            "truth": lut[truth.long()], "truth_off": toff.cpu().numpy().astype(np.uint64), "read_len": L,
-            "n_runs": int(r_ncig.sum().item()), "n_aln": ng, "n_records": n, "sam": sam, "planted": planted, "recipe": recipe,
-            "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi]}
+    job = {"G": Ga, "contig_off": aoff.cpu().numpy().astype(np.uint64), "bases": bases, "recs": recs,
+           "truth": lut[truth.long()], "truth_off": toff.cpu().numpy().astype(np.uint64), "read_len": L,
+           "n_runs": int(r_ncig.sum().item()), "n_aln": ng, "n_records": n, "sam": sam, "planted": planted, "recipe": recipe,
+           "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi]}
+    # the resident records as the product's ingests lay them out: every record's SEQ on a PP_SEQ_ALIGN (32-byte) boundary of
+    # the seq array, zeros in between (seq_pitch=0: packed back to back, the layout of rounds 1-3's bench lines)
+    pitch = (L + 31) // 32 * 32 if seq_pitch is None else (seq_pitch or L)
+    return job if pitch == L else with_pitch(job, pitch)
 
 
 def seq4_of(seq, chunk=1 << 27):
@@ -416,6 +421,26 @@ def with_seq4(job, on=True):
     return out
 
 
+def with_pitch(job, pitch):
+    """The same job with every read's SEQ bytes starting on a multiple of `pitch` bytes (an experiment of DESIGN.md section
+    9: 150-byte reads at pitch 160 start on 32-byte boundaries and touch 2.0 instead of 2.16 lines of 128 bytes)."""
+    r = job["recs"]
+    L, n = job["read_len"], job["n_aln"]
+    assert pitch >= L
+    dev = r["seq"].device
+    out = dict(job)
+    out.pop("_prepared", None)
+    recs = dict(r)
+    padded = torch.zeros((n, pitch), dtype=torch.uint8, device=dev)
+    padded[:, :L] = r["seq"].view(n, job.get("pitch", L))[:, :L]   # (file-order layout of constant pitch on the way in)
+    recs["seq"] = padded.reshape(-1).contiguous()
+    recs["seq_off"] = (torch.arange(n, device=dev, dtype=torch.int64) * pitch).contiguous()
+    out["recs"] = recs
+    out["pitch"] = pitch
+    out["seq4"] = None
+    return out
+
+
 def window_grouped(job, window=2048):
     """The same job with the SEQ bytes laid out WINDOW-GROUPED: the reads of one 2048-position window are adjacent in the
     seq array (windows in order, file order inside a window); every other array -- and the order of the records -- is
@@ -433,8 +458,9 @@ def window_grouped(job, window=2048):
     out = dict(job)
     out.pop("_prepared", None)
     recs = dict(r)
-    recs["seq"] = r["seq"].view(n, L)[order].reshape(-1).contiguous()
-    recs["seq_off"] = (slot * L).contiguous()
+    P = job.get("pitch", L)                            # bytes of the seq array per record (its SEQ up to the next boundary)
+    recs["seq"] = r["seq"].view(n, P)[order].reshape(-1).contiguous()
+    recs["seq_off"] = (slot * P).contiguous()
     out["recs"] = recs
     if job.get("seq4") is not None:
         out["seq4"] = seq4_of(recs["seq"])
