@@ -93,6 +93,15 @@ def test_ingest_records_reproduce_the_text_path(orc, tmp_path, case, careful):
     if not careful and case.get("repeat_copies"):
         assert recs["k"].max() > 1, "no multi-mapped read survived: the 1/k path is not exercised"
     assert names == [c.name for c in ds["contigs"]] and descs[0] == "some description"
+    # the layout of the seq array (include/polypolish_hip.h: PP_SEQ_ALIGN): every record's SEQ on a 32-byte boundary, the
+    # bytes up to the next record zero, nothing else in the array
+    so, sl = recs["seq_off"].astype(np.int64), recs["seq_len"].astype(np.int64)
+    room = (sl + 31) & ~31
+    assert (so % 32 == 0).all() and np.array_equal(so, np.cumsum(room) - room) and len(recs["seq"]) == int(room.sum())
+    used = np.zeros(len(recs["seq"]) + 1, dtype=np.int64)
+    np.add.at(used, so, 1)
+    np.add.at(used, so + sl, -1)
+    assert (recs["seq"][np.cumsum(used)[:-1] == 0] == 0).all() and (recs["seq"][np.cumsum(used)[:-1] == 1] != 0).all()
 
 
 def _line(name, flag, ref, pos, cigar, seq, tags="NM:i:0"):
