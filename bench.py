@@ -241,18 +241,30 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                                 "sha256": want[:16]}
         out["speedup_polish"] = round(t_cpu / min(t for t in (t_dev, t_host) if t is not None), 1)
         if not big:
-            # the tokenizer's other SEQ layout (window-grouped): same bytes out; what it costs the
-            # tokenizer is read off its own stage timer
+            # What the default SEQ layout costs the tokenizer, read off its own stage timers (PP_TIMING=1: a synchronisation
+            # after every stage): "window layout" = the multisplit of the rooms into the windows, against "file-order layout" =
+            # the scan of the rooms it replaces; the 4-bit mirror is written by the pass that writes the bytes.  And the same
+            # command in the layout of rounds 1-3 (SEQ bytes in file order, no mirror): same bytes out.
             env["PP_DEVICE_INGEST"] = "1"
-            t_win, r_win = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="window", PP_TIMING="1"), repeat=rep)
-            if t_win is not None:
-                lines = [l for l in r_win.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")]
-                extra = sum(float(l.split()[-2]) for l in lines if "window layout" in l)
-                mirror = sum(float(l.split()[-2]) for l in lines if "4-bit mirror" in l)
-                out["polish_window_grouped_seq"] = {"wall_s": round(t_win, 3), "parity": sha(r_win.stdout) == want,
-                                                    "tokenizer_extra_ms": round(1e3 * extra, 2),
-                                                    "tokenizer_mirror_ms": round(1e3 * mirror, 2),
-                                                    "batch": "SEQ window-grouped + the 4-bit mirror (pp_aln_batch.seq4)"}
+            def stages(r):
+                lines = [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]   tokenizer:")]
+                tot = {}
+                for l in lines:
+                    name = l.split("tokenizer:")[1].rsplit(None, 2)[0].strip()
+                    tot[name] = tot.get(name, 0.0) + float(l.split()[-2])
+                return {k: round(1e3 * v, 3) for k, v in tot.items()}
+            t_w, r_w = _timed([exe, "polish", fa] + sams, dict(env, PP_TIMING="1"), repeat=rep)
+            t_f, r_f = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_TIMING="1"), repeat=rep)
+            t_file, r_file = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0"), repeat=rep)
+            if t_w is not None and t_f is not None and t_file is not None:
+                sw, sf = stages(r_w), stages(r_f)
+                out["tokenizer_stages_ms"] = {"default (window-grouped + mirror)": sw, "PP_SEQ_LAYOUT=file PP_SEQ4=0": sf,
+                                              "layout_extra_ms": round(sw.get("window layout", 0.0) - sf.get("file-order layout", 0.0), 3),
+                                              "seq_and_mirror_extra_ms": round(sw.get("seq bytes + mirror", 0.0) - sf.get("seq bytes + mirror", 0.0), 3),
+                                              "note": "sums over the two SAM files; every stage ends in a stream synchronisation under PP_TIMING"}
+                out["polish_file_order_seq"] = {"wall_s": round(t_file, 3), "parity": sha(r_file.stdout) == want,
+                                                "batch": "PP_SEQ_LAYOUT=file PP_SEQ4=0: SEQ bytes in the order of the records, no 4-bit mirror (rounds 1-3)"}
+            del r_w, r_f, r_file
         ok = out["polish"]["parity"] and out.get("polish_host_ingest", {}).get("parity", True)
         del r_dev, r_host, r_cpu
         if not big:
@@ -317,12 +329,14 @@ def main():
     ap.add_argument("--seq-pitch", type=int, default=-1,
                     help="bytes of the seq array per record: -1 (default) = as the product's ingests lay it out, every record's SEQ on a "
                          "32-byte boundary (PP_SEQ_ALIGN); 0 = packed back to back (the bench lines of rounds 1-3)")
-    ap.add_argument("--seq4", default="off", choices=["on", "off"],
-                    help="hand the 4-bit mirror of the seq array over with the batch (pp_aln_batch.seq4), as the device tokenizer does")
-    ap.add_argument("--seq-layout", default="file", choices=["file", "window"],
-                    help="experiments only: 'window' lays the SEQ bytes out window-grouped (tools/synthjob.py window_grouped); "
-                         "the headline is 'file' -- SAM order, what an ingest delivers")
-    ap.add_argument("--no-second-layout", action="store_true", help="skip the second roofline entry (window-grouped SEQ bytes)")
+    ap.add_argument("--seq4", default="on", choices=["on", "off"],
+                    help="hand the 4-bit mirror of the seq array over with the batch (pp_aln_batch.seq4), as the device tokenizer does "
+                         "(default; 'off' = PP_SEQ4=0)")
+    ap.add_argument("--seq-layout", default="window", choices=["file", "window"],
+                    help="'window' (default): the SEQ bytes of a SAM file window-grouped, as both ingests lay them out since round 4 "
+                         "(PP_SEQ_WINDOW_GROUPED; tools/synthjob.py window_grouped); 'file' = in the order of the records "
+                         "(PP_SEQ_LAYOUT=file: the layout of rounds 1-3)")
+    ap.add_argument("--no-second-layout", action="store_true", help="skip the second roofline entry (SEQ bytes in file order, no mirror: rounds 1-3)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (one GPU)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes (the committed figure is used if the workload matches)")
@@ -374,7 +388,7 @@ def main():
     strong = world > 1 and args.config in (3, 4)
     if args.indel_frac is None:
         args.indel_frac = synthjob.SURVEY_INDEL_READ_FRAC if args.recipe == "survey" else 0.01
-    default_shape = (args.seq_layout == "file" and args.seq_pitch == -1 and args.seq4 == "off" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
+    default_shape = (args.seq_layout == "window" and args.seq_pitch == -1 and args.seq4 == "on" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
                      args.repeat_bp == 0 and args.nd_frac == 0.0 and args.genome is None and args.coverage is None)
     # config 1: this rank's own 5 Mbp contig (seed differs per rank); configs 3 / 4 with N > 1: every rank builds
     # the same job and keeps its shard
@@ -390,12 +404,11 @@ def main():
     job = make_job(device, contig_lens=lens, coverage=coverage, read_len=args.read_len,
                    seed=42 + args.config + 1 + (0 if strong else 1000 * rank),
                    indel_read_frac=args.indel_frac, sub_rate=args.sub_rate, n_rate=args.n_rate, repeat=repeat,
-                   repeat_bp=args.repeat_bp, recipe=args.recipe, seq_pitch=None if args.seq_pitch < 0 else args.seq_pitch)
+                   repeat_bp=args.repeat_bp, recipe=args.recipe, seq_pitch=None if args.seq_pitch < 0 else args.seq_pitch,
+                   seq_layout=args.seq_layout)
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
-    if args.seq4 == "on":
+    if args.seq4 == "on":   # the mirror the device tokenizer hands over with its batch (and pp_polish_add packs for any other)
         job = synthjob.with_seq4(job)
-    if args.seq_layout == "window":
-        job = synthjob.window_grouped(job)
     if args.nd_frac > 0:
         gg = torch.Generator(device=device)
         gg.manual_seed(7)
@@ -560,13 +573,11 @@ def main():
         if traffic is not None:
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
-    second = third = None
-    if world == 1 and args.seq_layout == "file" and args.seq4 == "off" and not args.no_second_layout:
-        # The same job as the device tokenizer hands it over with PP_SEQ_LAYOUT=window: (second entry) its SEQ bytes
-        # window-grouped; (third) that layout with the 4-bit mirror of the seq array the tokenizer writes next to it
-        # (pp_aln_batch.seq4).  Measured like the headline; what the layout and the mirror cost the tokenizer is in the e2e
-        # block (polish_window_grouped_seq.tokenizer_extra_ms).
-        def other_layout(wj, what, seq4_flag):
+    second = None
+    if world == 1 and args.seq_layout == "window" and args.seq4 == "on" and args.seq_pitch < 0 and not args.no_second_layout:
+        # The same job as rounds 1-3 measured it (and as the ingests still deliver it with PP_SEQ_LAYOUT=file PP_SEQ4=0): SEQ bytes
+        # in the order of the records, no 4-bit mirror -- the lane-group plain class over the bytes.  Measured like the headline.
+        def other_layout(wj, what, tail):
             ctx.set_profiling(0)
             for _ in range(args.warmup):
                 run_job(ctx, pp, wj)
@@ -587,21 +598,17 @@ def main():
             w_kernel = float(np.mean(w_ms)) if w_ms else 0.0
             w_traffic = None
             if dom_name and not args.no_live_traffic:
-                lt = live_traffic(["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--seq4", seq4_flag, "--seq-layout", "window", "--recipe", args.recipe,
-                                   "--indel-frac", repr(args.indel_frac)], "k_" + dom_name)
+                lt = live_traffic(["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--recipe", args.recipe,
+                                   "--indel-frac", repr(args.indel_frac)] + tail, "k_" + dom_name)
                 w_traffic = lt["hbm_bytes"] if lt else None
             return {"layout": what, "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(w_kernel, 4),
                     "achieved": round(b_alg / (w_kernel * 1e-3) / 1e9, 1) if w_kernel else 0.0, "peak": peak, "unit": "GB/s",
                     "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
                     "ms_per_step": round(w_step, 4), "mbp_per_s": round(G_total / 1e6 / (w_step * 1e-3), 1) if w_step else None,
                     "same_polished_bytes": bool(w_polished == polished)}
-        wj = synthjob.window_grouped(job)
-        second = other_layout(wj, "SEQ bytes window-grouped (pp_dev_ingest_set_seq_layout; every other array and every result unchanged)",
-                              "off")
-        wj = synthjob.with_seq4(wj)
-        third = other_layout(wj, "SEQ bytes window-grouped + the 4-bit mirror of the seq array (pp_aln_batch.seq4): the batch of the device "
-                                 "tokenizer with PP_SEQ_LAYOUT=window; the reads without indels are fetched from the mirror, one lane per read",
-                             "on")
+        wj = synthjob.with_seq4(synthjob.file_ordered(job), on=False)
+        second = other_layout(wj, "SEQ bytes in the order of the records, no 4-bit mirror (PP_SEQ_LAYOUT=file PP_SEQ4=0: the resident layout "
+                                  "of rounds 1-3; every other array and every result unchanged)", ["--seq-layout", "file", "--seq4", "off"])
         del wj
     # What the dominant kernel actually moves, as a rate: the algorithmic fraction above prices a 150-byte read at 150
     # bytes, the memory system fetches the 128-byte lines it touches (2.16 of them at an arbitrary byte offset).  6290 GB/s
@@ -614,9 +621,8 @@ def main():
         return {"rate": round(rate, 1), "unit": "GB/s", "frac_of_peak": round(rate / peak, 4),
                 "frac_of_practical_copy_rate": round(rate / PRACTICAL, 4), "practical_copy_rate": PRACTICAL,
                 "bytes_moved_per_algorithmic_byte": round(traffic_bytes / b_alg, 3)}
-    for extra in (second, third):
-        if extra is not None:
-            extra["hbm_actual"] = moved(extra.get("traffic"), extra.get("kernel_ms"))
+    if second is not None:
+        second["hbm_actual"] = moved(second.get("traffic"), second.get("kernel_ms"))
     out = {
         "metric": METRIC,
         "value": round(value, 2),
@@ -633,10 +639,14 @@ def main():
         "config": {"workload": label + f" alignment records resident in HBM ({job['n_aln']} records"
                                        f"{' in total' if strong else ''}; recipe '{args.recipe}': assembly errors {job['planted']}, "
                                        f"reads aligned to the assembly (I/D runs over the planted indels), {100 * args.indel_frac:g}% with a 1-bp sequencing indel"
-                                       + ("; SEQ bytes WINDOW-GROUPED (experiment, not the headline layout)" if args.seq_layout == "window" else "")
-                                       + ("; with the 4-bit mirror of the seq array, pp_aln_batch.seq4 (experiment, not the headline batch)" if args.seq4 == "on" else "")
-                                       + ("; every record's SEQ on a 32-byte boundary of the seq array, as pp_ingest_* / pp_dev_ingest_* lay it out"
-                                          if args.seq_pitch < 0 else ("; SEQ packed back to back" if args.seq_pitch == 0 else f"; SEQ pitch {args.seq_pitch} bytes")) + ")",
+                                       + ("; resident as the product's ingests lay a batch out (include/polypolish_hip.h): records in SAM order, every "
+                                          "record's SEQ on a 32-byte boundary of the seq array, the SEQ bytes of each of the two SAM files "
+                                          "window-grouped (PP_SEQ_WINDOW_GROUPED, the default of pp_ingest_* / pp_dev_ingest_* since round 4)"
+                                          if args.seq_layout == "window" and args.seq_pitch < 0 else
+                                          ("; SEQ bytes in the order of the records (PP_SEQ_LAYOUT=file: not the default layout)" if args.seq_pitch < 0
+                                           else ("; SEQ packed back to back in file order" if args.seq_pitch == 0 else f"; SEQ pitch {args.seq_pitch} bytes, file order")))
+                                       + ("; with the 4-bit mirror of the seq array the device tokenizer hands over (pp_aln_batch.seq4)" if args.seq4 == "on"
+                                          else "; WITHOUT the 4-bit mirror (PP_SEQ4=0: not the default batch)") + ")",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},
@@ -645,8 +655,7 @@ def main():
                      "hbm_actual": moved(traffic, dom_avg_ms),
                      "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
-        "roofline_window_grouped_seq": second,
-        "roofline_window_grouped_seq4": third,
+        "roofline_file_order_seq": second,
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
         "work": work,
         "planted_errors_recovered": recovered,

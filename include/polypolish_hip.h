@@ -128,17 +128,19 @@ typedef struct {
     uint64_t n_cig_total;
     /* Optional (NULL = none): a 4-bit mirror of seq, two bases per byte -- base seq[i] in bits 4*(i&1).. of seq4[i >> 1]
      * (the mirror is a function of the whole seq ARRAY, position by position, not of the records), (seq_bytes + 1) / 2
-     * bytes followed by at least 32 readable bytes; codes PP_SEQ4_*.  The device tokenizer hands it over with its batch
-     * (pp_dev_ingest_batch); with it the pileup kernel fetches the reads without indels at half the bytes -- it is HBM-bound
-     * on the 128-byte lines a read touches.  Used for a PP_MEM_DEVICE batch that is polished in place (the only batch of its
-     * job); every result is the same with and without it.  seq must be there all the same: everything that needs a byte
-     * as it was delivered (string-keyed tallies, trims through bytes other than A/C/G/T/N/-) reads seq. */
+     * bytes followed by at least 32 readable bytes; codes PP_SEQ4_*.  With it the pileup kernel fetches the reads without
+     * indels at half the bytes, one lane per read.  The library's own producers bring one (pp_dev_ingest_batch,
+     * device parts of pp_shard_split); pp_polish_add copies it along, and packs one on the device for a batch that comes
+     * without (host batches: the host ingest's, anybody's) whenever the batch is copied into the library's arrays anyway --
+     * only a foreign PP_MEM_DEVICE batch that is polished in place (the only batch of its job) runs without.  Every result
+     * is the same with and without it.  seq must be there all the same: everything that needs a byte as it was delivered
+     * (string-keyed tallies, trims through bytes other than A/C/G/T/N/-) reads seq. */
     const uint8_t *seq4;
 } pp_aln_batch;
 /* The library's own producers of batches (pp_ingest_*, pp_dev_ingest_*, pp_shard_split) start every record's SEQ on a multiple
- * of PP_SEQ_ALIGN bytes of the seq array, the bytes in between zero: a 150-byte read then touches two 128-byte lines instead of
- * 2.16 on average, which is what the pileup kernel waits for (7 % of its time on the 5 Mbp / 200x job).  A batch from elsewhere
- * may place its SEQ bytes anywhere (seq_off). */
+ * of PP_SEQ_ALIGN bytes of the seq array, the bytes in between zero, and lay the SEQ bytes of a SAM file out WINDOW-GROUPED
+ * (PP_SEQ_WINDOW_GROUPED below: the default since round 4): the pileup kernel waits for the 128-byte lines a read touches,
+ * and fetches a window's reads from one stretch of memory.  A batch from elsewhere may place its SEQ bytes anywhere (seq_off). */
 #define PP_SEQ_ALIGN 32
 /* codes of seq4: the four bases as their counter rows, N, '-' (the deletion key, src/pileup.rs:194-197), anything else */
 #define PP_SEQ4_A 0
@@ -448,16 +450,18 @@ int pp_dev_ingest_sam(pp_dev_ingest *g, const char *path, pp_sam_counts *counts)
 int pp_dev_ingest_sam_filtered(pp_dev_ingest *g, const char *path, const uint8_t *pass, uint64_t n_pass,
                                pp_sam_counts *counts);
 /* How the batch's SEQ bytes are laid out (seq_off may point anywhere, so this is the producer's choice, not a format):
- * PP_SEQ_FILE_ORDER (default) = in the order of the records; PP_SEQ_WINDOW_GROUPED = the reads that start in one
- * 2048-position window of the assembly are adjacent (per SAM file) -- the pileup kernel then fetches a window's reads
- * from one stretch of memory instead of all over the array (1.2 GB moved instead of 2.1 GB on a 5 Mbp / 200x job,
- * k_tile 17 % faster) at the price of a count / scan / placement pass in the tokenizer (well under a millisecond per GB of
- * text); the batch then also brings the 4-bit mirror of its seq array (pp_aln_batch.seq4), which takes k_tile to 0.6 of
- * the HBM roofline.  Every other array, the order of the records and every result are the same.  Set before the first pp_dev_ingest_sam*; `PP_SEQ_LAYOUT=window` in the
- * environment selects it for the file drivers. */
+ * PP_SEQ_WINDOW_GROUPED (the default since round 4) = the reads that start in one 2048-position window of the assembly are
+ * adjacent (per SAM file; inside a window in no particular order) -- the pileup kernel then fetches a window's reads from
+ * one stretch of memory instead of all over the array; PP_SEQ_FILE_ORDER = in the order of the records.  The window layout
+ * costs the tokenizer a count / scan / placement pass over eight bytes per record (no second look at the text or the parse
+ * records).  Every other array, the order of the records and every result are the same.  Set before the first
+ * pp_dev_ingest_sam* / pp_ingest_sam*; `PP_SEQ_LAYOUT=file` in the environment selects file order for the file drivers.
+ * Both ingests write the same layout (the host ingest in file order inside a window); the device tokenizer's batch also
+ * brings the 4-bit mirror of its seq array (pp_aln_batch.seq4; `PP_SEQ4=0`: none). */
 #define PP_SEQ_FILE_ORDER 0
 #define PP_SEQ_WINDOW_GROUPED 1
 int pp_dev_ingest_set_seq_layout(pp_dev_ingest *g, int layout);
+int pp_ingest_set_seq_layout(pp_ingest *g, int layout);
 /* Optional hint, before the first file: the bytes of SAM text of ALL the files that will be handed to this ingest.  The
  * batch's arrays are then sized once, for all of them, off the first file (without it the second file makes every array
  * grow: a device allocation and a copy of what the first one filled -- 6 ms on a 2 x 1.2 GB pair). */

@@ -127,6 +127,7 @@ EXPORTS = [
     "pp_comm_unique_id", "pp_comm_init", "pp_comm_destroy", "pp_polish_gather", "pp_polish_files_multi",
     "pp_shard_split", "pp_shard_part_batch", "pp_shard_part_mem", "pp_shard_part_free", "pp_shard_count",
     "pp_polish_error_record", "pp_polish_error_text", "pp_dev_ingest_set_seq_layout", "pp_dev_ingest_expect",
+    "pp_ingest_set_seq_layout",
 ]
 
 _lib = None
@@ -219,6 +220,7 @@ def lib():
         L.pp_dev_ingest_sam.argtypes = [vp, C.c_char_p, C.POINTER(SamCounts)]
         L.pp_dev_ingest_sam_filtered.argtypes = [vp, C.c_char_p, vp, C.c_uint64, C.POINTER(SamCounts)]
         L.pp_dev_ingest_set_seq_layout.argtypes = [vp, C.c_int]
+        L.pp_ingest_set_seq_layout.argtypes = [vp, C.c_int]
         L.pp_dev_ingest_batch.argtypes = [vp, C.POINTER(AlnBatch)]
         L.pp_dev_ingest_batch.restype = None
         L.pp_dev_ingest_free.argtypes = [vp]
@@ -278,8 +280,10 @@ def split_records(recs, cuts):
     return out
 
 
-def ingest(assembly, sams, max_errors=10, careful=False):
-    """Host ingest only (no GPU needed): FASTA + SAM text -> (names, descs, contig_off, bases, recs, counts)."""
+def ingest(assembly, sams, max_errors=10, careful=False, seq_layout=None):
+    """Host ingest only (no GPU needed): FASTA + SAM text -> (names, descs, contig_off, bases, recs, counts).
+    seq_layout: None = the library's default (window-grouped unless PP_SEQ_LAYOUT=file), 0 = SEQ bytes in file order,
+    1 = window-grouped (pp_ingest_set_seq_layout)."""
     L = lib()
     err = C.create_string_buffer(1024)
     a = C.c_void_p()
@@ -294,6 +298,8 @@ def ingest(assembly, sams, max_errors=10, careful=False):
         off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,)).copy()
         bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),)).copy()
         L.pp_ingest_create(a, max_errors, int(careful), C.byref(g))
+        if seq_layout is not None:
+            L.pp_ingest_set_seq_layout(g, int(seq_layout))
         counts = []
         for s in sams:
             c = SamCounts()
@@ -337,9 +343,10 @@ def pack_seq4(seq):
     return out
 
 
-def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=0):
+def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=None):
     """The device tokenizer (pp_dev_ingest_*): same return value as ingest(), the records copied back from HBM.
-    seq_layout: 0 = SEQ bytes in file order, 1 = window-grouped (pp_dev_ingest_set_seq_layout)."""
+    seq_layout: None = the library's default (window-grouped unless PP_SEQ_LAYOUT=file), 0 = SEQ bytes in file order,
+    1 = window-grouped (pp_dev_ingest_set_seq_layout)."""
     L = lib()
     err = C.create_string_buffer(1024)
     a = C.c_void_p()
@@ -354,7 +361,8 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=
         off = np.ctypeslib.as_array(L.pp_assembly_offsets(a), shape=(n + 1,)).copy()
         bases = np.ctypeslib.as_array(L.pp_assembly_bases(a), shape=(int(off[-1]),)).copy()
         ctx._chk(L.pp_dev_ingest_create(ctx._h, a, max_errors, int(careful), C.byref(g)))
-        ctx._chk(L.pp_dev_ingest_set_seq_layout(g, int(seq_layout)))
+        if seq_layout is not None:
+            ctx._chk(L.pp_dev_ingest_set_seq_layout(g, int(seq_layout)))
         counts = []
         for s in sams:
             c = SamCounts()
@@ -463,6 +471,8 @@ class ShardPart:
         self.mem = mem
         self.n_aln, self.seq_bytes, self.n_cig_total = int(out.n_aln), int(out.seq_bytes), int(out.n_cig_total)
         self.ptrs = {name: (C.cast(getattr(out, name), C.c_void_p).value or 0) for name, _ in REC_FIELDS}
+        if out.seq4:  # a device part brings the 4-bit mirror of its seq array
+            self.ptrs["seq4"] = out.seq4
         self.orig_ptr = orig.value or 0
 
     def host(self):

@@ -99,6 +99,8 @@ static std::string opt_display(const OptSpec &o) {
     return d;
 }
 
+static bool looks_like_option(const char *a) { return a[0] == '-' && a[1] != 0; }
+
 static Parsed parse_args(int argc, char **argv, int first, const std::vector<OptSpec> &specs) {
     Parsed P;
     P.value.assign(specs.size(), nullptr);
@@ -125,7 +127,9 @@ static Parsed parse_args(int argc, char **argv, int first, const std::vector<Opt
                 set(k, "");
                 continue;
             }
-            const char *v = eq ? eq + 1 : (i + 1 < argc ? argv[++i] : nullptr);
+            // clap takes the next argument as the value unless it looks like an option (a leading '-', other than a lone
+            // "-"): `--debug --careful x.fa` is "a value is required", not a file named "--careful"
+            const char *v = eq ? eq + 1 : (i + 1 < argc && !looks_like_option(argv[i + 1]) ? argv[++i] : nullptr);
             if (!v) { P.error = "a value is required for '" + opt_display(specs[k]) + "' but none was supplied"; break; }
             set(k, v);
             continue;
@@ -137,7 +141,7 @@ static Parsed parse_args(int argc, char **argv, int first, const std::vector<Opt
             while (k < specs.size() && specs[k].short_name != *c) k++;
             if (k == specs.size()) { P.error = std::string("unexpected argument '-") + *c + "' found"; break; }
             if (!specs[k].takes_value) { set(k, ""); continue; }
-            const char *v = c[1] ? (c[1] == '=' ? c + 2 : c + 1) : (i + 1 < argc ? argv[++i] : nullptr);
+            const char *v = c[1] ? (c[1] == '=' ? c + 2 : c + 1) : (i + 1 < argc && !looks_like_option(argv[i + 1]) ? argv[++i] : nullptr);
             if (!v) { P.error = "a value is required for '" + opt_display(specs[k]) + "' but none was supplied"; break; }
             set(k, v);
             break;  // the rest of the argument was the value
@@ -244,17 +248,12 @@ int main(int argc, char **argv) {
         const char *assembly = P.positional.empty() ? nullptr : P.positional[0];
         std::vector<const char *> sams(P.positional.begin() + (P.positional.empty() ? 0 : 1), P.positional.end());
         if (!assembly) return usage_error("the following required arguments were not provided:\n  <ASSEMBLY>");
-        // Several GPUs polish (contigs / windows of a large contig shard across them) when PP_GPUS=n asks for them, or
-        // by themselves from 8 GiB of SAM text on; never with --debug.  Below that one GPU is the faster choice end to
-        // end: the polish itself is a millisecond per 5 Mbp, what a second context adds is its start-up and another
-        // copy of the records over PCIe, and only the single-GPU path tokenizes on the device.  PP_SHARE_GPU=n (tests
-        // on a one-GPU box) runs n contexts on the one device.
-        unsigned long long sam_bytes = 0;
-        for (const char *sp : sams) {
-            struct stat st;
-            if (stat(sp, &st) == 0 && S_ISREG(st.st_mode)) sam_bytes += (unsigned long long)st.st_size;
-        }
-        const bool few = sam_bytes < (8ull << 30) && !getenv("PP_GPUS") && !getenv("PP_SHARE_GPU");
+        // Several GPUs polish (contigs / windows of a large contig shard across them) when PP_GPUS=n asks for them; never
+        // with --debug.  On small jobs one GPU is the faster choice end to end: the polish itself is a millisecond per 5 Mbp,
+        // what a second context adds is its start-up.  (Until round 4 the CLI switched by itself from 8 GiB of SAM text on;
+        // the path has only ever run with several contexts on ONE device -- PP_SHARE_GPU=n, tests on a one-GPU box -- so it
+        // stays opt-in until it has been run on a multi-GPU node.)
+        const bool few = !getenv("PP_GPUS") && !getenv("PP_SHARE_GPU");
         std::vector<int> devs = polish_devices(device, opt.debug_path != nullptr || few);
         if (devs.size() > 1) {
             std::vector<pp_ctx *> cs(devs.size(), nullptr);

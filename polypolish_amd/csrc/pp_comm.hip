@@ -166,3 +166,26 @@ extern "C" int pp_polish_gather(pp_ctx *ctx, uint8_t *gathered, uint64_t cap, ui
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
     return PP_OK;
 }
+
+// pp_polish_gather for a caller without HIP of its own (the one-process multi-GPU driver, pp_driver.cpp): rank 0 receives
+// into a library-owned device buffer and copies the whole FASTA payload to `host_out` (>= cap bytes) in ONE transfer;
+// the other ranks pass host_out = nullptr.  Same collective contract as pp_polish_gather: every rank calls it.
+extern "C" int pp_polish_gather_to_host_(pp_ctx *ctx, uint8_t *host_out, uint64_t cap, uint64_t *rank_len, uint64_t *rank_contig_off) {
+    if (!ctx) return PP_ERR_ARG;
+    if (!ctx->comm) return ctx->fail(PP_ERR_ARG, "pp_polish_gather without pp_comm_init");
+    PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool root = ctx->comm_rank == 0;
+    if (root && !host_out) return ctx->fail(PP_ERR_ARG, "pp_polish_gather_to_host_: rank 0 needs a buffer");
+    if (root)
+        if (int rc = pp::dev_ensure(ctx, ctx->b_gather, (size_t)cap + 16)) return rc;
+    std::vector<uint64_t> lens((size_t)ctx->comm_world, 0);
+    if (int rc = pp_polish_gather(ctx, root ? (uint8_t *)ctx->b_gather.p : nullptr, root ? cap : 0, lens.data(), rank_contig_off)) return rc;
+    if (rank_len) memcpy(rank_len, lens.data(), lens.size() * 8);
+    if (root) {
+        uint64_t total = 0;
+        for (uint64_t l : lens) total += l;
+        if (total) PP_HIPCHK(ctx, hipMemcpyAsync(host_out, ctx->b_gather.p, total, hipMemcpyDeviceToHost, ctx->stream));
+        PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PP_OK;
+}

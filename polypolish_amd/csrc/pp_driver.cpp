@@ -161,10 +161,13 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
     return polish_files_impl(&ctx, 1, assembly, sams, n_sams, opt, fasta, nullptr, nullptr);
 }
 
-// One process, several GPUs: the host ingest runs once, every context gets the full alignment batches and the emit
-// ranges of its units (pp_shard_plan_create), the contexts polish side by side on their own threads and their bytes
-// are put back together on the host (pp_shard_assemble) -- the FASTA has to reach host memory anyway, so each device
-// copies its own share out; the RCCL gather (pp_polish_gather) is for the one-process-per-GPU launch.
+// One process, several GPUs (polish::polish has no counterpart: src/polish.rs:137-154 is one thread): every context
+// uploads and tokenizes its own slice of every SAM file (or the host ingest parses once), the records are partitioned --
+// a context is sent the records that reach its units (pp_shard_split) -- the contexts polish side by side on their own
+// threads, and the polished bytes meet on the first context's GPU in ONE RCCL gather over xGMI (pp_polish_gather: the
+// north star's "single RCCL gather for the final FASTA") followed by one device-to-host copy.  Where RCCL cannot run --
+// librccl not loadable, two contexts on one device (PP_SHARE_GPU, tests), PP_GATHER=host -- every device copies its own
+// share out and the host puts them together; PP_TIMING prints the route that was taken.
 extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams,
                                      int n_sams, const pp_polish_options *opt, pp_bytes *fasta) {
     if (!ctxs || n_ctx < 1) return PP_ERR_ARG;
@@ -174,6 +177,8 @@ extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char 
 }
 
 extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n);
+extern "C" int pp_ctx_device_(const pp_ctx *ctx);
+extern "C" int pp_polish_gather_to_host_(pp_ctx *ctx, uint8_t *host_out, uint64_t cap, uint64_t *rank_len, uint64_t *rank_contig_off);
 extern "C" int pp_dev_ingest_slice_(pp_dev_ingest *D, const char *path, const char *text, uint64_t size, pp_sam_counts *counts);
 
 namespace {
@@ -631,8 +636,27 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     pp_shard_part_batch(parts[q][(size_t)d], &v, nullptr);
                     pieces[(size_t)d].push_back(Piece{parts[q][(size_t)d], srcs[q].owner, srcs[q].base, v.n_aln});
                 }
+        // the tokenizers' batches (and their text buffers) are not needed once every part has been cut out of them
+        for (pp_dev_ingest *&x : dgs) { pp_dev_ingest_free(x); x = nullptr; }
         lap("records split");
         // every context: its records, the ranges of its units, finish, its own bytes to the host -- side by side
+        // ---- how the polished bytes will reach the host: one RCCL gather to the first context's GPU, or every device by itself ----
+        bool use_rccl = !(getenv("PP_GATHER") && !strcmp(getenv("PP_GATHER"), "host"));
+        for (int d = 0; d < n_ctx && use_rccl; d++)
+            for (int e = 0; e < d; e++)
+                if (pp_ctx_device_(ctxs[d]) == pp_ctx_device_(ctxs[e])) use_rccl = false;  // RCCL refuses two ranks on one device
+        if (use_rccl && rc == PP_OK) {
+            uint8_t id[PP_COMM_ID_BYTES];
+            if (pp_comm_unique_id(id) != PP_OK) use_rccl = false;  // librccl not loadable
+            else if (on_all([&](int d) { return pp_comm_init(ctxs[d], d, n_ctx, id); }) != PP_OK) {
+                for (int d = 0; d < n_ctx; d++) pp_comm_destroy(ctxs[d]);
+                use_rccl = false;
+            }
+        }
+        if (timing) fprintf(stderr, "[timing] polished bytes -> host: %s\n", use_rccl ? "ONE RCCL gather (ncclSend/ncclRecv over xGMI) to the first GPU + one D2H"
+                                                                                    : "every device copies its share out, assembled on the host (no RCCL: PP_GATHER=host, shared device, or librccl missing)");
+        std::vector<uint8_t> gathered;
+        std::vector<uint64_t> r_total((size_t)n_ctx, 0);
         std::vector<std::vector<uint8_t>> r_bytes((size_t)n_ctx);
         std::vector<std::vector<uint64_t>> r_off((size_t)n_ctx, std::vector<uint64_t>(nc + 1, 0));
         std::vector<std::vector<pp_contig_stats>> r_stats((size_t)n_ctx, std::vector<pp_contig_stats>(nc));
@@ -666,11 +690,32 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                 if (r == PP_OK) r = pp_polish_finish(cd);
                 uint64_t t = 0;
                 if (r == PP_OK) r = pp_polish_result_size(cd, &t);
-                r_bytes[(size_t)d].resize(t ? t : 1);
-                if (r == PP_OK) r = pp_polish_result(cd, r_bytes[(size_t)d].data(), PP_MEM_HOST, r_off[(size_t)d].data(), r_stats[(size_t)d].data());
+                r_total[(size_t)d] = t;
+                // offsets and statistics now; the bytes follow over RCCL, or (host route) with this very call
+                if (r == PP_OK && !use_rccl) r_bytes[(size_t)d].resize(t ? t : 1);
+                if (r == PP_OK) r = pp_polish_result(cd, use_rccl ? nullptr : r_bytes[(size_t)d].data(), PP_MEM_HOST, r_off[(size_t)d].data(), r_stats[(size_t)d].data());
                 r_rc[(size_t)d] = r;
                 return r;
             });
+            bool all_ok = true;
+            for (int d = 0; d < n_ctx; d++) all_ok = all_ok && r_rc[(size_t)d] == PP_OK;
+            if (all_ok && use_rccl) {
+                // the one exchange of the job: every context's bytes to the first context's GPU, then one copy to the host
+                uint64_t sum = 0;
+                for (uint64_t t : r_total) sum += t;
+                gathered.resize(sum ? sum : 1);
+                std::vector<uint64_t> lens((size_t)n_ctx, 0);
+                const auto tg = std::chrono::steady_clock::now();
+                const int rg = on_all([&](int d) {
+                    return pp_polish_gather_to_host_(ctxs[d], d == 0 ? gathered.data() : nullptr, d == 0 ? sum : 0, d == 0 ? lens.data() : nullptr, nullptr);
+                });
+                if (timing) fprintf(stderr, "[timing] RCCL gather of %llu bytes from %d contexts + one D2H: %.3f ms\n", (unsigned long long)sum, n_ctx,
+                                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count());
+                if (rg) rc = rg;
+                else
+                    for (int d = 0; d < n_ctx; d++)
+                        if (lens[(size_t)d] != r_total[(size_t)d]) rc = set_err(ctx, PP_ERR_HIP, "the RCCL gather delivered a rank's bytes short");
+            }
             // The job's error is the one about its FIRST bad record in file order (the reference streams,
             // src/alignment.rs:238-303): a context numbers the records it was sent, the parts know where those came from.
             uint64_t best = ~0ull;
@@ -691,7 +736,12 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         if (rc == PP_OK) {
             std::vector<const uint8_t *> bp((size_t)n_ctx);
             std::vector<const uint64_t *> op((size_t)n_ctx);
-            for (int d = 0; d < n_ctx; d++) { bp[(size_t)d] = r_bytes[(size_t)d].data(); op[(size_t)d] = r_off[(size_t)d].data(); }
+            uint64_t at = 0;
+            for (int d = 0; d < n_ctx; d++) {
+                bp[(size_t)d] = use_rccl ? gathered.data() + at : r_bytes[(size_t)d].data();
+                at += r_total[(size_t)d];
+                op[(size_t)d] = r_off[(size_t)d].data();
+            }
             rc = pp_shard_assemble(plan, bp.data(), op.data(), nullptr, out_off.data());
             total = out_off[nc];
             polished.resize(total ? total : 1);
@@ -705,6 +755,8 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                 }
             }
         }
+        if (use_rccl)
+            for (int d = 0; d < n_ctx; d++) pp_comm_destroy(ctxs[d]);
         pp_shard_plan_free(plan);
     }
     if (rc) {

@@ -266,6 +266,9 @@ struct pp_ingest {
     const pp_assembly *asmb;
     uint32_t max_errors;
     bool careful;
+    // how the SEQ bytes of a file are laid out in the seq array (include/polypolish_hip.h, pp_dev_ingest_set_seq_layout):
+    // window-grouped by default, as the device tokenizer lays them out; PP_SEQ_LAYOUT=file / pp_ingest_set_seq_layout
+    int seq_layout = PP_SEQ_WINDOW_GROUPED;
     HugeBuf<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
     HugeBuf<uint64_t> seq_off, cig_off, name_off;
     HugeBuf<uint8_t> seq;
@@ -430,7 +433,14 @@ extern "C" int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int c
     g->asmb = a;
     g->max_errors = max_errors;
     g->careful = careful != 0;
+    if (const char *e = getenv("PP_SEQ_LAYOUT")) g->seq_layout = !strcmp(e, "file") ? PP_SEQ_FILE_ORDER : PP_SEQ_WINDOW_GROUPED;
     *out = g;
+    return PP_OK;
+}
+
+extern "C" int pp_ingest_set_seq_layout(pp_ingest *g, int layout) {
+    if (!g || (layout != PP_SEQ_FILE_ORDER && layout != PP_SEQ_WINDOW_GROUPED)) return PP_ERR_ARG;
+    g->seq_layout = layout;
     return PP_OK;
 }
 
@@ -705,6 +715,54 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
         I->n_cig.resize(base + n_out); I->name_off.resize(base + n_out);
         I->seq.resize(seq0 + p_seq[threads]); I->cigar.resize(cig0 + p_cig[threads]); I->names.resize(nam0 + p_nam[threads]);
         lap("offsets + resize");
+        // Window-grouped SEQ layout (the default, as the device tokenizer's): the reads that start in one 2048-position
+        // window of the assembly are adjacent in this file's stretch of the seq array -- the pileup kernel then fetches a
+        // window's reads from one place.  A multisplit of the rooms: every part adds its records' rooms up per window, the
+        // windows' totals are scanned, and a part's records of a window follow those of the parts before it, in file order
+        // (so the layout does not depend on the thread count).  seq_off goes with the record; nothing else changes.
+        constexpr uint64_t WINDOW = 2048;  // = pp::TILE (pp_internal.h), the pileup kernel's window
+        const uint64_t *ctg_off = pp_assembly_offsets(I->asmb);
+        const uint64_t G_asm = ctg_off[pp_assembly_n_contigs(I->asmb)];
+        const size_t n_win = (size_t)std::max<uint64_t>(1, (G_asm + WINDOW - 1) / WINDOW);
+        const bool grouped = I->seq_layout == PP_SEQ_WINDOW_GROUPED && n_out > 0;
+        auto window_of = [&](const Rec &a) {
+            const uint64_t w = (ctg_off[a.contig] + a.ref_start) / WINDOW;
+            return (size_t)std::min<uint64_t>(w, n_win - 1);
+        };
+        HugeBuf<uint64_t> wcur;  // [part][window]: first the bytes, then where the part's next record of the window goes
+        if (grouped) {
+            wcur.resize(threads * n_win);
+            parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t t = lo; t < hi; t++) {
+                    uint64_t *row = wcur.data() + t * n_win;
+                    memset(row, 0, n_win * sizeof(uint64_t));
+                    for (size_t i = 0; i < parts[t].outs.size(); i++) {
+                        const OutRec &o = parts[t].outs[i];
+                        row[window_of(*o.rec)] += seq_room(o.star ? o.src->seq_n : o.rec->seq_n);
+                    }
+                }
+            });
+            std::vector<uint64_t> wtot(n_win + 1, 0);
+            parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t w = lo; w < hi; w++) {
+                    uint64_t sum = 0;
+                    for (size_t t = 0; t < threads; t++) sum += wcur[t * n_win + w];
+                    wtot[w + 1] = sum;
+                }
+            });
+            for (size_t w = 0; w < n_win; w++) wtot[w + 1] += wtot[w];
+            parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t w = lo; w < hi; w++) {
+                    uint64_t run = seq0 + wtot[w];
+                    for (size_t t = 0; t < threads; t++) {
+                        const uint64_t v = wcur[t * n_win + w];
+                        wcur[t * n_win + w] = run;
+                        run += v;
+                    }
+                }
+            });
+            lap("window layout");
+        }
         parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
             for (size_t t = lo; t < hi; t++) {
                 const Part &P = parts[t];
@@ -716,9 +774,14 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                     I->contig[d] = (uint32_t)a.contig;
                     I->ref_start[d] = (uint32_t)a.ref_start;
                     I->k[d] = o.k;
-                    I->seq_off[d] = so;
                     const char *s = o.star ? o.src->seq : a.seq;
                     const size_t sn = o.star ? o.src->seq_n : a.seq_n;
+                    if (grouped) {  // its place in its window's region
+                        uint64_t &cur = wcur[t * n_win + window_of(a)];
+                        so = cur;
+                        cur += seq_room(sn);
+                    }
+                    I->seq_off[d] = so;
                     I->seq_len[d] = (uint32_t)sn;
                     uint8_t *dst = I->seq.data() + so;
                     if (o.revcomp) {  // add_read_seq (alignment.rs:161-167): reverse complement of the upper-cased group SEQ

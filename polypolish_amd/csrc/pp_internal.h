@@ -124,7 +124,7 @@ struct pp_ctx {
 
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
-    pp::DevBuf b_in[9];  // the accumulated batch arrays (uploaded or gathered)
+    pp::DevBuf b_in[10];  // the accumulated batch arrays (uploaded or gathered); [9] = the 4-bit mirror of [7], the seq array
     pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slab_win, b_slabs, b_ents, b_keys, b_own;
@@ -144,8 +144,8 @@ struct pp_ctx {
     // ---- multi-GPU gather (pp_comm.hip) ----
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 1;
-    pp::DevBuf b_comm;
-    pp::DevBuf b_split[10];  // pp_shard_split's scratch (pp_shard_dev.hip)
+    pp::DevBuf b_comm, b_gather;  // the gather's size exchange | rank 0's receive buffer (pp_polish_gather_to_host_)
+    pp::DevBuf b_split[12];  // pp_shard_split's scratch (pp_shard_dev.hip)
 
     // ---- filter job ----
     pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert, f_poisoned;

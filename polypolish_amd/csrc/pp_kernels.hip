@@ -230,18 +230,56 @@ extern "C" int pp_polish_reserve(pp_ctx *ctx, uint64_t n_aln, uint64_t seq_bytes
     if (int rdy = pp_ctx_wait(ctx)) return rdy;
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_reserve without pp_polish_begin");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
-    const uint64_t cnt[9] = {n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, seq_bytes, n_cig_total};
-    const uint64_t used[9] = {ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_seq, ctx->acc_cig};
+    // (room for up to 31 unused bytes at every joint of the seq array, and for its 4-bit mirror)
+    const size_t esz[10] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 1};
+    const uint64_t cnt[10] = {n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, seq_bytes + 4096, n_cig_total, (seq_bytes + 4096) / 2 + 96};
+    const uint64_t used[10] = {ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_seq, ctx->acc_cig, (ctx->acc_seq + 1) / 2};
     const bool owned = ctx->have_batch && !ctx->batch_borrowed;
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < 10; i++)
         if (int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)cnt[i] * esz[i], owned ? (size_t)used[i] * esz[i] : 0)) return rc;
     return PP_OK;
 }
 
-// Append one batch (host or device memory) to the library-owned accumulated arrays.
+// The 4-bit mirror (pp_aln_batch.seq4) of a stretch of the accumulated seq array, for a batch that came without one:
+// one thread turns 32 bytes into 16 (codes PP_SEQ4_*; A C T G = their counter rows).  [lo, hi): lo a multiple of 32.
+__device__ __forceinline__ u32 seq4_code_of(u32 c) {
+    const u32 t = (c >> 1) & 3u;
+    const u32 expect = (0x47544341u >> (t * 8u)) & 0xFFu;
+    return c == expect ? t : (c == (u32)'N' ? (u32)PP_SEQ4_N : (c == (u32)'-' ? (u32)PP_SEQ4_DASH : (u32)PP_SEQ4_OTHER));
+}
+__global__ __launch_bounds__(256) void k_pack4(const u8 *__restrict__ seq, u8 *__restrict__ seq4, u64 lo, u64 hi) {
+    const u64 i0 = lo + ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 32u;
+    if (i0 >= hi) return;
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i0 + 32u <= hi) {
+        uint4 a, b;
+        __builtin_memcpy(&a, seq + i0, 16);
+        __builtin_memcpy(&b, seq + i0 + 16, 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+        for (u32 j = 0; i0 + j < hi; j++) w[j >> 2] |= (u32)seq[i0 + j] << (8u * (j & 3u));
+    }
+    u32 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v |= seq4_code_of((w[2 * q + (j >> 2)] >> (8 * (j & 3))) & 0xFFu) << (4 * j);
+        o[q] = v;
+    }
+    const uint4 out = make_uint4(o[0], o[1], o[2], o[3]);
+    __builtin_memcpy(seq4 + (i0 >> 1), &out, 16);
+}
+
+// Append one batch (host or device memory) to the library-owned accumulated arrays.  Every batch's SEQ bytes start on a
+// multiple of PP_SEQ_ALIGN of the accumulated seq array (up to 31 unused bytes at a joint), so that the 4-bit mirror of the
+// batch lands on whole bytes of the accumulated mirror: it is copied when the batch brings one (the library's ingests and
+// pp_shard_split do) and packed from the bytes on the device when it does not -- a gathered job is polished from the
+// mirror like a job of one in-place batch.
 static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
-    const uint64_t n0 = ctx->acc_n, s0 = ctx->acc_seq, c0 = ctx->acc_cig;
+    static const bool no_seq4 = getenv("PP_SEQ4") && atoi(getenv("PP_SEQ4")) == 0;  // tuning / tests
+    const uint64_t n0 = ctx->acc_n, c0 = ctx->acc_cig;
+    const uint64_t s0 = (ctx->acc_seq + (uint64_t)PP_SEQ_ALIGN - 1) & ~((uint64_t)PP_SEQ_ALIGN - 1);
     const uint64_t n = b->n_aln;
     if (n0 + n >= 0xFFFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "more than 2^32-1 alignments in one polish job");
     if (s0 + b->seq_bytes >= (1ull << 40)) return ctx->fail(PP_ERR_LIMIT, "more than 2^40 SEQ bytes in one polish job");
@@ -250,13 +288,22 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     const void *src[9] = {b->contig, b->ref_start, b->k, b->seq_off, b->seq_len, b->cig_off, b->n_cig, b->seq, b->cigar};
     const size_t esz[9] = {4, 4, 4, 8, 4, 8, 4, 1, 4};
     const uint64_t old_cnt[9] = {n0, n0, n0, n0, n0, n0, n0, s0, c0};
+    const uint64_t kept[9] = {n0, n0, n0, n0, n0, n0, n0, ctx->acc_seq, c0};
     const uint64_t add_cnt[9] = {n, n, n, n, n, n, n, b->seq_bytes, b->n_cig_total};
     for (int i = 0; i < 9; i++) {
-        int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)(old_cnt[i] + add_cnt[i]) * esz[i], (size_t)old_cnt[i] * esz[i]);
+        int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)(old_cnt[i] + add_cnt[i]) * esz[i] + (i == 7 ? 64 : 0), (size_t)kept[i] * esz[i]);
         if (rc) return rc;
         if (add_cnt[i])
             PP_HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_in[i].p + old_cnt[i] * esz[i], src[i], (size_t)add_cnt[i] * esz[i], kind,
                                           ctx->stream));
+    }
+    if (!no_seq4) {
+        if (int rc = dev_grow_keep(ctx, ctx->b_in[9], (size_t)((s0 + b->seq_bytes + 1) / 2 + 96), (size_t)((ctx->acc_seq + 1) / 2))) return rc;
+        if (b->seq_bytes && b->seq4)
+            PP_HIPCHK(ctx, hipMemcpyAsync((char *)ctx->b_in[9].p + s0 / 2, b->seq4, (size_t)((b->seq_bytes + 1) / 2), kind, ctx->stream));
+        else if (b->seq_bytes)
+            hipLaunchKernelGGL(k_pack4, dim3((unsigned)(((b->seq_bytes + 31) / 32 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const u8 *)ctx->b_in[7].p, (u8 *)ctx->b_in[9].p, (u64)s0, (u64)(s0 + b->seq_bytes));
     }
     if (n && (s0 || c0))
         hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64 *)ctx->b_in[3].p + n0,
@@ -269,7 +316,7 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     d.seq_off = (const uint64_t *)ctx->b_in[3].p; d.seq_len = (const uint32_t *)ctx->b_in[4].p;
     d.cig_off = (const uint64_t *)ctx->b_in[5].p; d.n_cig = (const uint32_t *)ctx->b_in[6].p;
     d.seq = (const uint8_t *)ctx->b_in[7].p; d.cigar = (const uint32_t *)ctx->b_in[8].p;
-    d.seq4 = nullptr;  // gathered batches: no 4-bit mirror (it would have to be re-packed at every odd joint)
+    d.seq4 = no_seq4 ? nullptr : (const uint8_t *)ctx->b_in[9].p;
     return PP_OK;
 }
 
@@ -963,7 +1010,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     pp_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *all[] = {&ctx->b_comm, &ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
+    DevBuf *all[] = {&ctx->b_comm, &ctx->b_gather, &ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
@@ -999,6 +1046,7 @@ extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n) {
     (void)hipGetLastError();
 }
 
+extern "C" int pp_ctx_device_(const pp_ctx *ctx) { return ctx ? ctx->device : -1; }
 extern "C" int pp_ctx_set_error_(pp_ctx *ctx, int code, const char *msg) {
     if (ctx) ctx->err = msg ? msg : "";
     return code;

@@ -18,14 +18,15 @@
 // and the CIGAR runs); host batches by a plain loop.  No reference counterpart: the reference is one thread.
 #include "pp_devtext.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 struct pp_shard_part {
     pp_ctx *ctx = nullptr;
     int mem = PP_MEM_HOST;
-    pp::DevBuf d_all;   // one allocation, carved into: contig ref_start k seq_off seq_len cig_off n_cig seq cigar orig
-    void *d[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pp::DevBuf d_all;   // one allocation, carved into: contig ref_start k seq_off seq_len cig_off n_cig seq cigar orig seq4
+    void *d[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<uint32_t> h_contig, h_ref_start, h_k, h_seq_len, h_n_cig, h_cigar, h_orig;
     std::vector<uint64_t> h_seq_off, h_cig_off;
     std::vector<uint8_t> h_seq;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void k_split_flag(u64 n, const u32 *__restrict
                                                     const u32 *__restrict__ seq_len, const u64 *__restrict__ cig_off,
                                                     const u32 *__restrict__ n_cig, const u32 *__restrict__ cigar, UnitTable T,
                                                     u32 dest, u32 *__restrict__ flag, u32 *__restrict__ sel_seq,
-                                                    u32 *__restrict__ sel_cig) {
+                                                    u32 *__restrict__ sel_cig, const u64 *__restrict__ seq_off,
+                                                    u32 *__restrict__ slots, u64 n_slots, u32 *__restrict__ bad) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 nr = n_cig[i];
@@ -80,6 +82,21 @@ __global__ __launch_bounds__(256) void k_split_flag(u64 n, const u32 *__restrict
     flag[i] = sel ? 1u : 0u;
     sel_seq[i] = sel ? seq_room(seq_len[i]) : 0u;
     sel_cig[i] = sel ? nr : 0u;
+    // the order of the SEQ bytes in the source's seq array is kept (a window-grouped batch gives window-grouped parts):
+    // the array as slots of PP_SEQ_ALIGN bytes, a selected record's room noted at its first slot, scanned by the caller.
+    // A batch whose records do not start on slots of their own (not from this library's producers) says so in *bad and
+    // the part is laid out in the order of the records.
+    if (sel && slots) {
+        const u64 so = seq_off[i];
+        if ((so & ((u64)PP_SEQ_ALIGN - 1u)) || (so >> 5) >= n_slots || atomicExch(&slots[so >> 5], seq_room(seq_len[i]) >> 5) != 0u) atomicOr(bad, 1u);
+    }
+}
+
+// a selected record's place in the part's seq array: the scan of the slots in front of its own
+__global__ __launch_bounds__(256) void k_split_place(u64 n, const u32 *__restrict__ flag, const u64 *__restrict__ seq_off,
+                                                     const u32 *__restrict__ slot_scan, u64 *__restrict__ seq_scan) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) seq_scan[i] = (u64)slot_scan[seq_off[i] >> 5] << 5;
 }
 
 struct SplitOut {
@@ -106,23 +123,45 @@ __global__ __launch_bounds__(256) void k_split_meta(u64 n, const u32 *__restrict
     O.orig[o] = (u32)i;
 }
 
-// SEQ bytes: eight lanes per selected record, 16 bytes per lane and trip (gfx950 global accesses need no alignment)
+// SEQ bytes and their 4-bit mirror (pp_aln_batch.seq4: the bytes are in registers anyway -- a part always brings one):
+// eight lanes per selected record, one 16-byte chunk of its room per lane and trip (gfx950 global accesses need no alignment)
+__device__ __forceinline__ u32 split_code4(u32 c) {
+    const u32 t = (c >> 1) & 3u;
+    const u32 expect = (0x47544341u >> (t * 8u)) & 0xFFu;
+    return c == expect ? t : (c == (u32)'N' ? (u32)PP_SEQ4_N : (c == (u32)'-' ? (u32)PP_SEQ4_DASH : (u32)PP_SEQ4_OTHER));
+}
 __global__ __launch_bounds__(256) void k_split_seq(u64 n, const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
                                                    const u8 *__restrict__ seq, const u32 *__restrict__ flag,
-                                                   const u64 *__restrict__ seq_scan, u8 *__restrict__ out) {
+                                                   const u64 *__restrict__ seq_scan, u8 *__restrict__ out, u8 *__restrict__ out4) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = t >> 3;
     const u32 s = (u32)(t & 7u);
     if (i >= n || !flag[i]) return;
     const u8 *in = seq + seq_off[i];
-    u8 *o = out + seq_scan[i];
-    const u32 len = seq_len[i], whole = len & ~15u;
-    for (u32 b = 16u * s; b < whole; b += 128u) {
-        uint4 v;
-        __builtin_memcpy(&v, in + b, 16);
+    const u64 at = seq_scan[i];  // a multiple of PP_SEQ_ALIGN
+    u8 *o = out + at, *o4 = out4 + (at >> 1);
+    const u32 len = seq_len[i], room = seq_room(len);
+    for (u32 b = 16u * s; b < room; b += 128u) {
+        u32 w[4] = {0, 0, 0, 0};
+        if (b + 16u <= len) {
+            uint4 v;
+            __builtin_memcpy(&v, in + b, 16);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (u32 j = 0; b + j < len; j++) w[j >> 2] |= (u32)in[b + j] << (8u * (j & 3u));  // zeros up to the next boundary
+        }
+        const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
         __builtin_memcpy(o + b, &v, 16);
+        u32 q4[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            u32 x = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) x |= split_code4((w[2 * q + (j >> 2)] >> (8 * (j & 3))) & 0xFFu) << (4 * j);
+            q4[q] = x;
+        }
+        const uint2 p4 = make_uint2(q4[0], q4[1]);
+        __builtin_memcpy(o4 + (b >> 1), &p4, 8);
     }
-    for (u32 b = whole + s; b < len; b += 8) o[b] = in[b];
-    for (u32 b = len + s; b < seq_room(len); b += 8) o[b] = 0;  // up to the next record's boundary
 }
 
 __global__ __launch_bounds__(256) void k_split_cigar(u64 n, const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
@@ -180,7 +219,7 @@ struct HostUnits {
 void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_total) {
     pp_aln_batch &v = P->view;
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
-    v.seq4 = nullptr;  // a part carries no 4-bit mirror
+    v.seq4 = P->mem == PP_MEM_DEVICE ? (const u8 *)P->d[10] : nullptr;  // a device part brings the 4-bit mirror of its seq array
     if (P->mem == PP_MEM_DEVICE) {
         v.contig = (const u32 *)P->d[0]; v.ref_start = (const u32 *)P->d[1]; v.k = (const u32 *)P->d[2];
         v.seq_off = (const uint64_t *)P->d[3]; v.seq_len = (const u32 *)P->d[4]; v.cig_off = (const uint64_t *)P->d[5];
@@ -216,15 +255,33 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
     P->h_contig.reserve(cnt); P->h_ref_start.reserve(cnt); P->h_k.reserve(cnt); P->h_seq_len.reserve(cnt); P->h_n_cig.reserve(cnt);
     P->h_orig.reserve(cnt); P->h_seq_off.reserve(cnt); P->h_cig_off.reserve(cnt);
     P->h_seq.resize(seq_total + 64); P->h_cigar.resize(cig_total + 1);
-    uint64_t so = 0, co = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        if (!sel[i]) continue;
+    // where the part's SEQ bytes go: in the order of the SOURCE's seq array (a window-grouped batch gives window-grouped
+    // parts), which for a batch in file order is the order of the records
+    std::vector<uint64_t> picked;
+    picked.reserve(cnt);
+    bool sorted = true;
+    for (uint64_t i = 0; i < n; i++)
+        if (sel[i]) {
+            if (!picked.empty() && B->seq_off[i] < B->seq_off[picked.back()]) sorted = false;
+            picked.push_back(i);
+        }
+    std::vector<uint64_t> place(cnt);  // per part record: its offset in the part's seq array
+    {
+        std::vector<uint32_t> ord(cnt);
+        for (uint64_t j = 0; j < cnt; j++) ord[j] = (uint32_t)j;
+        if (!sorted) std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return B->seq_off[picked[a]] < B->seq_off[picked[b]]; });
+        uint64_t so = 0;
+        for (uint64_t j = 0; j < cnt; j++) { place[ord[j]] = so; so += seq_room(B->seq_len[picked[ord[j]]]); }
+    }
+    uint64_t co = 0;
+    for (uint64_t j = 0; j < cnt; j++) {
+        const uint64_t i = picked[j], so = place[j];
         P->h_contig.push_back(B->contig[i]); P->h_ref_start.push_back(B->ref_start[i]); P->h_k.push_back(B->k[i]);
         P->h_seq_len.push_back(B->seq_len[i]); P->h_n_cig.push_back(B->n_cig[i]); P->h_orig.push_back((u32)i);
         P->h_seq_off.push_back(so); P->h_cig_off.push_back(co);
         memcpy(P->h_seq.data() + so, B->seq + B->seq_off[i], B->seq_len[i]);
         memcpy(P->h_cigar.data() + co, B->cigar + B->cig_off[i], (size_t)B->n_cig[i] * 4);
-        so += seq_room(B->seq_len[i]); co += B->n_cig[i];  // (h_seq was zero-filled: so are the bytes up to the boundary)
+        co += B->n_cig[i];  // (h_seq was zero-filled: so are the bytes up to the boundary)
     }
     set_view(P, cnt, seq_total, cig_total);
     return PP_OK;
@@ -257,23 +314,38 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
         return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: uploading the plan failed"));
     const UnitTable T{(const u32 *)t_first.p, d_units, d_units + nu, d_units + 2 * nu, n_contigs, U.fallback};
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    // slots of the source's seq array (see k_split_flag): [0, n_slots) notes, [n_slots + 1 ...) their scan, one word "bad"
+    const u64 n_slots = (B->seq_bytes + (u64)PP_SEQ_ALIGN - 1) / (u64)PP_SEQ_ALIGN;
+    const bool by_slots = n_slots > 0 && n_slots < 0xFFFFFFF0ull;  // (the part's bytes / 32 fit 32 bits)
+    pp::DevBuf &slots = ctx->b_split[10], &slot_scan = ctx->b_split[11];
+    if (by_slots) {
+        if ((rc = pp::dev_ensure(ctx, slots, (n_slots + 2) * 4)) || (rc = pp::dev_ensure(ctx, slot_scan, (n_slots + 2) * 4))) return done(rc);
+        if (hipMemsetAsync(slots.p, 0, (n_slots + 2) * 4, st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: memset failed"));
+    }
+    u32 *d_bad = by_slots ? (u32 *)slots.p + n_slots + 1 : nullptr;
     hipLaunchKernelGGL(k_split_flag, dim3(blocks), dim3(256), 0, st, (u64)n, B->contig, B->ref_start, B->seq_len,
-                       (const u64 *)B->cig_off, B->n_cig, B->cigar, T, dest, (u32 *)flag.p, (u32 *)sel_seq.p, (u32 *)sel_cig.p);
+                       (const u64 *)B->cig_off, B->n_cig, B->cigar, T, dest, (u32 *)flag.p, (u32 *)sel_seq.p, (u32 *)sel_cig.p,
+                       (const u64 *)B->seq_off, by_slots ? (u32 *)slots.p : (u32 *)nullptr, n_slots, d_bad);
     if ((rc = scan_u32<u32>(ctx, sums, sums_off, (const u32 *)flag.p, (u64)n, (u32 *)out_idx.p)) ||
         (rc = scan_u32<u64>(ctx, sums, sums_off, (const u32 *)sel_seq.p, (u64)n, (u64 *)seq_scan.p)) ||
         (rc = scan_u32<u64>(ctx, sums, sums_off, (const u32 *)sel_cig.p, (u64)n, (u64 *)cig_scan.p)))
         return done(rc);
-    u32 cnt = 0;
+    u32 cnt = 0, bad = 1;
     u64 seq_total = 0, cig_total = 0;
     if ((rc = fetch(ctx, (const u32 *)out_idx.p + n, &cnt)) || (rc = fetch(ctx, (const u64 *)seq_scan.p + n, &seq_total)) ||
-        (rc = fetch(ctx, (const u64 *)cig_scan.p + n, &cig_total)))
+        (rc = fetch(ctx, (const u64 *)cig_scan.p + n, &cig_total)) || (by_slots && (rc = fetch(ctx, (const u32 *)d_bad, &bad))))
         return done(rc);
-    const size_t esz[10] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 4};
-    const uint64_t ecnt[10] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total, cnt};
-    size_t at[11] = {0};
-    for (int a = 0; a < 10; a++) at[a + 1] = (at[a] + (size_t)ecnt[a] * esz[a] + 255) / 256 * 256;
-    if ((rc = pp::dev_ensure(ctx, P->d_all, at[10]))) return done(rc);
-    for (int a = 0; a < 10; a++) P->d[a] = (char *)P->d_all.p + at[a];
+    if (by_slots && !bad && cnt) {  // the part's SEQ bytes in the order of the source's seq array
+        if ((rc = scan_u32<u32>(ctx, sums, sums_off, (const u32 *)slots.p, n_slots, (u32 *)slot_scan.p))) return done(rc);
+        hipLaunchKernelGGL(k_split_place, dim3(blocks), dim3(256), 0, st, (u64)n, (const u32 *)flag.p, (const u64 *)B->seq_off,
+                           (const u32 *)slot_scan.p, (u64 *)seq_scan.p);
+    }
+    const size_t esz[11] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 4, 1};
+    const uint64_t ecnt[11] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total, cnt, (seq_total + 1) / 2 + 96};
+    size_t at[12] = {0};
+    for (int a = 0; a < 11; a++) at[a + 1] = (at[a] + (size_t)ecnt[a] * esz[a] + 255) / 256 * 256;
+    if ((rc = pp::dev_ensure(ctx, P->d_all, at[11]))) return done(rc);
+    for (int a = 0; a < 11; a++) P->d[a] = (char *)P->d_all.p + at[a];
     SplitOut O{(u32 *)P->d[0], (u32 *)P->d[1], (u32 *)P->d[2], (u32 *)P->d[4], (u32 *)P->d[6], (u32 *)P->d[8],
                (u32 *)P->d[9], (u64 *)P->d[3], (u64 *)P->d[5], (u8 *)P->d[7]};
     if (cnt) {
@@ -281,7 +353,7 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
                            B->n_cig, (const u32 *)flag.p, (const u32 *)out_idx.p, (const u64 *)seq_scan.p,
                            (const u64 *)cig_scan.p, O);
         hipLaunchKernelGGL(k_split_seq, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, st, (u64)n, (const u64 *)B->seq_off,
-                           B->seq_len, B->seq, (const u32 *)flag.p, (const u64 *)seq_scan.p, O.seq);
+                           B->seq_len, B->seq, (const u32 *)flag.p, (const u64 *)seq_scan.p, O.seq, (u8 *)P->d[10]);
         hipLaunchKernelGGL(k_split_cigar, dim3(blocks), dim3(256), 0, st, (u64)n, (const u64 *)B->cig_off, B->n_cig, B->cigar,
                            (const u32 *)flag.p, (const u64 *)cig_scan.p, O.cigar);
         if (hipMemsetAsync(O.seq + seq_total, 0, 64, st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: memset failed"));

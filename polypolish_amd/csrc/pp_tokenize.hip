@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void k_tok_group_first(u32 n_aln, const u32 *_
     if (r == 0) group_first[n_groups] = n_aln;
 }
 
+constexpr u32 WIN_NONE = 0xFFFFFFFFu;  // win_of[] of a record that is not good
 // process_one_read (alignment.rs:275-322), one lane per read group
 __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
                                                    const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
@@ -209,12 +210,13 @@ __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, 
                                                    u32 *__restrict__ good,
                                                    u32 *__restrict__ kk, u32 *__restrict__ src_rec,
                                                    u32 *__restrict__ g_seq_len, u32 *__restrict__ g_ncig,
+                                                   const u64 *__restrict__ ctg_off, u32 n_win, u32 *__restrict__ win_of,
                                                    u64 *__restrict__ status) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const u32 r0 = group_first[g], r1 = group_first[g + 1];
     const u64 key = 2ull * (g + 1 < n_groups ? (u64)rec_line[r1] : n_lines) + 1ull;
-    for (u32 r = r0; r < r1; r++) { good[r] = 0; kk[r] = 0; src_rec[r] = r; g_seq_len[r] = 0; g_ncig[r] = 0; }
+    for (u32 r = r0; r < r1; r++) { good[r] = 0; kk[r] = 0; src_rec[r] = r; g_seq_len[r] = 0; g_ncig[r] = 0; win_of[r] = WIN_NONE; }
     if (careful && r1 - r0 > 1) return;
     u32 src = 0xFFFFFFFFu;
     for (u32 r = r0; r < r1; r++) {
@@ -242,6 +244,9 @@ __global__ __launch_bounds__(256) void k_tok_group(const u8 *__restrict__ text, 
         src_rec[r] = star ? src : r;
         g_seq_len[r] = star ? s.seq_len : a.seq_len;
         g_ncig[r] = a.n_runs;
+        // the 2048-position window of the assembly the record starts in (the window-grouped SEQ layout places it there)
+        const u64 w = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
+        win_of[r] = w < n_win ? (u32)w : n_win - 1u;
     }
 }
 
@@ -287,163 +292,150 @@ __device__ __forceinline__ u8 comp_upper(u8 c) {  // misc.rs:170-182 on the uppe
     }
 }
 
-// SEQ bytes: eight lanes per good record, 16 bytes per lane and trip; upper-cased; a "*" record takes the
-// group's sequence, reverse-complemented when the strands differ (alignment.rs:161-167, 288-296)
-__global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
-                                                 const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
-                                                 u32 n_aln, const u32 *__restrict__ good, const u32 *__restrict__ src_rec,
-                                                 const u64 *__restrict__ seq_scan, u8 *__restrict__ seq, u64 seq_base) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 3, s = t & 7u;
-    if (r >= n_aln || !good[r]) return;
-    const u32 sr = src_rec[r];
-    const LineRec &a = rec[rec_line[r]], &b = rec[rec_line[sr]];
-    const u8 *in = text + line_start(nl_pos, rec_line[sr]) + b.seq_off;
-    const u32 n = b.seq_len;
-    u8 *out = seq + seq_base + seq_scan[r];
-    const bool rc = sr != r && ((a.flag & 16u) == 0) != ((b.flag & 16u) == 0);
-    if (!rc) {
-        // 16 bytes per lane and trip (gfx950 global accesses need no alignment), upper-cased four at a time:
-        // bit 7 of every byte in 'a'..'z' (ASCII only), shifted down to the 0x20 that is taken off
-        const u32 whole = n & ~15u;
-        for (u32 i = 16u * s; i < whole; i += 128u) {
-            uint4 v;
-            __builtin_memcpy(&v, in + i, 16);
-            u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32 x = w[q] & 0x7F7F7F7Fu;
-                const u32 m = (x + 0x1F1F1F1Fu) & ~(x + 0x05050505u) & ~w[q] & 0x80808080u;
-                w[q] -= m >> 2;
-            }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-            __builtin_memcpy(out + i, &v, 16);
-        }
-        for (u32 i = whole + s; i < n; i += 8) {
-            u8 c = in[i];
-            if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
-            out[i] = c;
-        }
-        for (u32 i = n + s; i < seq_room(n); i += 8) out[i] = 0;  // up to the next record's boundary
-        return;
-    }
-    for (u32 i = s; i < n; i += 8) {  // a "*" record on the other strand (rare): byte-wise, reversed and complemented
-        u8 c = in[n - 1 - i];
-        if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
-        out[i] = comp_upper(c);
-    }
-    for (u32 i = n + s; i < seq_room(n); i += 8) out[i] = 0;
-}
-
-// ---- the 4-bit mirror of the seq array (pp_aln_batch.seq4) ---------------------------------------------
-// Base i of the ARRAY in bits 4*(i&1).. of byte i >> 1, whatever record it belongs to: a plain function of the bytes, so a
-// stretch may be packed again (a file's stretch starts wherever the one before ended; the 32 bytes around the joint are
-// done twice).  One thread: 32 bytes in, 16 out.  Costs 0.3 ms per GB of SEQ; k_tile then fetches 75 bytes for a 150-base
-// read instead of 150 -- 1.6 instead of 2.2 128-byte lines.
+// ---- SEQ bytes and their 4-bit mirror (pp_aln_batch.seq4), one pass ------------------------------------------------
+// Eight lanes per good record, one 16-byte chunk of its room (SEQ bytes up to the next PP_SEQ_ALIGN boundary) per lane and
+// trip: upper-cased (alignment.rs:94), zeros past the read, and -- the bytes being in registers anyway -- their 4-bit codes
+// packed into the mirror (base i of the ARRAY in bits 4*(i&1).. of seq4[i >> 1]: a room starts on a multiple of 32 bytes,
+// so a chunk's eight mirror bytes are its own).  A "*" record takes the group's sequence, reverse-complemented when the
+// strands differ (alignment.rs:161-167, 288-296).  Round 3 packed the mirror in a kernel of its own that read the seq
+// array back (0.4 ms per 2.4 GB of text); here it costs the stores.
 __device__ __forceinline__ u32 seq4_code(u32 c) {
     const u32 t = (c >> 1) & 3u;  // A->0 C->1 T->2 G->3: the counter rows
     const u32 expect = (0x47544341u >> (t * 8u)) & 0xFFu;
     return c == expect ? t : (c == (u32)'N' ? (u32)PP_SEQ4_N : (c == (u32)'-' ? (u32)PP_SEQ4_DASH : (u32)PP_SEQ4_OTHER));
 }
-__global__ __launch_bounds__(256) void k_tok_pack4(const u8 *__restrict__ seq, u8 *__restrict__ seq4, u64 lo, u64 hi) {
-    // [lo, hi): byte range of seq, lo a multiple of 32; bytes from hi on are not there yet (their codes are written when they are)
-    const u64 i0 = lo + ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 32u;
-    if (i0 >= hi) return;
-    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (i0 + 32u <= hi) {
-        uint4 a, b;
-        __builtin_memcpy(&a, seq + i0, 16);
-        __builtin_memcpy(&b, seq + i0 + 16, 16);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    } else {
-        for (u32 j = 0; i0 + j < hi; j++) w[j >> 2] |= (u32)seq[i0 + j] << (8u * (j & 3u));
-    }
-    u32 o[4];
+__device__ __forceinline__ uint2 pack4_16(const u32 w[4]) {  // 16 bytes -> 16 nibbles
+    u32 o[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 2; q++) {
         u32 v = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) v |= seq4_code((w[2 * q + (j >> 2)] >> (8 * (j & 3))) & 0xFFu) << (4 * j);
         o[q] = v;
     }
-    const uint4 out = make_uint4(o[0], o[1], o[2], o[3]);
-    __builtin_memcpy(seq4 + (i0 >> 1), &out, 16);
+    return make_uint2(o[0], o[1]);
+}
+__global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                 const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+                                                 u32 n_aln, const u32 *__restrict__ good, const u32 *__restrict__ src_rec,
+                                                 const u64 *__restrict__ seq_scan, u8 *__restrict__ seq, u8 *__restrict__ seq4,
+                                                 u64 seq_base) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x, r = t >> 3, s = t & 7u;
+    if (r >= n_aln || !good[r]) return;
+    const u32 sr = src_rec[r];
+    const LineRec &a = rec[rec_line[r]], &b = rec[rec_line[sr]];
+    const u8 *in = text + line_start(nl_pos, rec_line[sr]) + b.seq_off;
+    const u32 n = b.seq_len, room = seq_room(n);
+    const u64 at = seq_base + seq_scan[r];  // a multiple of PP_SEQ_ALIGN
+    u8 *out = seq + at;
+    u8 *out4 = seq4 ? seq4 + (at >> 1) : nullptr;
+    const bool rc = sr != r && ((a.flag & 16u) == 0) != ((b.flag & 16u) == 0);
+    for (u32 i = 16u * s; i < room; i += 128u) {
+        u32 w[4] = {0, 0, 0, 0};
+        if (!rc) {
+            if (i < n) {
+                // 16 bytes per lane and trip (gfx950 global accesses need no alignment; the text buffer is padded, the bytes
+                // past the read -- the next column -- are cut off), upper-cased four at a time: bit 7 of every byte in
+                // 'a'..'z' (ASCII only), shifted down to the 0x20 that is taken off
+                uint4 v;
+                __builtin_memcpy(&v, in + i, 16);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                const u32 live = n - i;  // bytes of this chunk that belong to the read (>= 1)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 have = live > 4u * q ? min(4u, live - 4u * q) : 0u;
+                    w[q] &= have == 4u ? 0xFFFFFFFFu : ((1u << (8u * have)) - 1u);
+                    const u32 x = w[q] & 0x7F7F7F7Fu;
+                    const u32 m = (x + 0x1F1F1F1Fu) & ~(x + 0x05050505u) & ~w[q] & 0x80808080u;
+                    w[q] -= m >> 2;
+                }
+            }
+        } else {  // a "*" record on the other strand (rare): byte-wise, reversed and complemented
+            for (u32 j = 0; j < 16u && i + j < n; j++) {
+                u8 c = in[n - 1 - (i + j)];
+                if (c >= (u8)'a' && c <= (u8)'z') c = (u8)(c - 32);
+                w[j >> 2] |= (u32)comp_upper(c) << (8u * (j & 3u));
+            }
+        }
+        const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+        __builtin_memcpy(out + i, &v, 16);
+        if (out4) {
+            const uint2 p4 = pack4_16(w);
+            __builtin_memcpy(out4 + (i >> 1), &p4, 8);
+        }
+    }
 }
 
-// ---- window-grouped SEQ layout (pp_dev_ingest_set_seq_layout) ----------------------------------------
-// Where a good record's SEQ bytes go when the reads of one 2048-position window are to be adjacent in the seq array: the
-// bytes per window are counted, scanned, and every record takes its stretch of its window's region with an atomic
-// (the order inside a window is whatever the atomics make it: seq_off goes with the record, nothing depends on it).
-__global__ __launch_bounds__(256) void k_tok_win_bytes(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
-                                                       const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
-                                                       const u64 *__restrict__ ctg_off, u32 n_win, u32 *__restrict__ wbytes) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_aln || !good[r]) return;
-    const LineRec &a = rec[rec_line[r]];
-    const u64 w = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
-    atomicAdd(&wbytes[w < n_win ? (u32)w : n_win - 1u], g_seq_len[r]);
-}
-__global__ __launch_bounds__(256) void k_tok_win_place(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
-                                                       const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
-                                                       const u64 *__restrict__ ctg_off, u32 n_win, const u64 *__restrict__ wbase,
-                                                       u32 *__restrict__ wcur, u64 *__restrict__ seq_pos) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_aln || !good[r]) return;
-    const LineRec &a = rec[rec_line[r]];
-    const u64 w0 = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
-    const u32 w = w0 < n_win ? (u32)w0 : n_win - 1u;
-    seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], g_seq_len[r]);
-}
-
-// The same two steps with the windows' counters in LDS (up to 16384 windows = 33.5 Mbp): a workgroup takes 16384 records,
-// adds them up per window in LDS and goes to the global counters once per window it met.  The kernels above send every
-// record to one of a few thousand global addresses (a device-scope atomic on one address is served every ~0.6 us on this
-// chip: the XCDs share no L2); with the counters in LDS the two steps are 0.2-0.4 ms per SAM file of 3.3 M records.
-constexpr u32 WIN_LDS_MAX = 16384, WIN_RPT = 16;  // windows in LDS; records per thread
-__global__ __launch_bounds__(1024) void k_tok_win_bytes_lds(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
-                                                            const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
-                                                            const u64 *__restrict__ ctg_off, u32 n_win, u32 *__restrict__ wbytes) {
+// ---- window-grouped SEQ layout (pp_dev_ingest_set_seq_layout; the default) -------------------------------------------
+// Where a good record's SEQ bytes go when the reads of one 2048-position window are to be adjacent in the seq array.  The
+// record's window comes from k_tok_group (win_of[]: it has the record in hand); what is left is a multisplit of the rooms
+// into the windows, done like the polish pipeline's own (pp_k_bucket.h), without global atomics: a workgroup adds its
+// records' rooms up per window in LDS and leaves its row of a blocks x windows matrix (k_tok_win_hist), one wave per
+// window scans its column (k_tok_win_cols: the window's bytes, and every block's offset inside the window's region), the
+// windows' bytes are scanned into the regions' starts, and the workgroups place their records with LDS cursors that
+// start at their offsets (k_tok_win_place).  Round 3 went to one global counter per window from every workgroup -- a
+// device-scope atomic on one address is served every ~0.6 us on this chip (the XCDs share no L2) -- and read the 48-byte
+// parse record of every line twice: 0.3 ms per SAM file of 3.3 M records, now 0.05.
+// Inside a window the order is that of the workgroups (file order) and, within one, whatever the LDS atomics make it:
+// seq_off goes with the record, nothing depends on it.
+constexpr u32 WIN_LDS_MAX = 16384;  // windows in LDS (33.5 Mbp); beyond: the global-atomic kernels below
+__global__ __launch_bounds__(1024) void k_tok_win_hist(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
+                                                       u32 per_block, u32 n_win, u32 *__restrict__ mat) {
     __shared__ u32 hist[WIN_LDS_MAX];
     for (u32 w = threadIdx.x; w < n_win; w += 1024u) hist[w] = 0;
     __syncthreads();
-    const u32 base = blockIdx.x * (1024u * WIN_RPT);
-    for (u32 i = 0; i < WIN_RPT; i++) {
-        const u32 r = base + i * 1024u + threadIdx.x;
-        if (r >= n_aln || !good[r]) continue;
-        const LineRec &a = rec[rec_line[r]];
-        const u64 w = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
-        atomicAdd(&hist[w < n_win ? (u32)w : n_win - 1u], g_seq_len[r]);
+    const u32 lo = blockIdx.x * per_block, hi = min(n_aln, lo + per_block);
+    for (u32 r = lo + threadIdx.x; r < hi; r += 1024u) {
+        const u32 w = win_of[r];
+        if (w != WIN_NONE) atomicAdd(&hist[w], seq_room(g_seq_len[r]));
     }
     __syncthreads();
-    for (u32 w = threadIdx.x; w < n_win; w += 1024u)
-        if (hist[w]) atomicAdd(&wbytes[w], hist[w]);
+    for (u32 w = threadIdx.x; w < n_win; w += 1024u) mat[(u64)blockIdx.x * n_win + w] = hist[w];
 }
-__global__ __launch_bounds__(1024) void k_tok_win_place_lds(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line, u32 n_aln,
-                                                            const u32 *__restrict__ good, const u32 *__restrict__ g_seq_len,
-                                                            const u64 *__restrict__ ctg_off, u32 n_win, const u64 *__restrict__ wbase,
-                                                            u32 *__restrict__ wcur, u64 *__restrict__ seq_pos) {
-    __shared__ u32 hist[WIN_LDS_MAX];
-    for (u32 w = threadIdx.x; w < n_win; w += 1024u) hist[w] = 0;
-    __syncthreads();
-    const u32 base = blockIdx.x * (1024u * WIN_RPT);
-    u32 win[WIN_RPT], local[WIN_RPT];
-#pragma unroll
-    for (u32 i = 0; i < WIN_RPT; i++) {
-        const u32 r = base + i * 1024u + threadIdx.x;
-        win[i] = 0xFFFFFFFFu;
-        local[i] = 0;
-        if (r >= n_aln || !good[r]) continue;
-        const LineRec &a = rec[rec_line[r]];
-        const u64 w0 = (ctg_off[a.contig] + a.ref_start) / (u64)pp::TILE;
-        win[i] = w0 < n_win ? (u32)w0 : n_win - 1u;
-        local[i] = atomicAdd(&hist[win[i]], g_seq_len[r]);  // its place among this workgroup's bytes of the window
+// one wave per window: exclusive scan of its column over the blocks (in place), the total to wbytes
+__global__ __launch_bounds__(256) void k_tok_win_cols(u32 n_win, u32 n_blocks, u32 *__restrict__ mat, u32 *__restrict__ wbytes) {
+    const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (w >= n_win) return;
+    u32 carry = 0;
+    for (u32 b0 = 0; b0 < n_blocks; b0 += 64u) {
+        const u32 b = b0 + lane;
+        const u32 v = b < n_blocks ? mat[(u64)b * n_win + w] : 0u;
+        u32 inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += t;
+        }
+        if (b < n_blocks) mat[(u64)b * n_win + w] = carry + inc - v;
+        carry += (u32)__shfl((int)inc, 63, 64);
     }
+    if (lane == 0) wbytes[w] = carry;
+}
+__global__ __launch_bounds__(1024) void k_tok_win_place(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
+                                                        u32 per_block, u32 n_win, const u32 *__restrict__ mat,
+                                                        const u64 *__restrict__ wbase, u64 *__restrict__ seq_pos) {
+    __shared__ u32 cur[WIN_LDS_MAX];
+    for (u32 w = threadIdx.x; w < n_win; w += 1024u) cur[w] = mat[(u64)blockIdx.x * n_win + w];
     __syncthreads();
-    for (u32 w = threadIdx.x; w < n_win; w += 1024u)
-        if (hist[w]) hist[w] = atomicAdd(&wcur[w], hist[w]);  // the workgroup's stretch of the window's region
-    __syncthreads();
-#pragma unroll
-    for (u32 i = 0; i < WIN_RPT; i++)
-        if (win[i] != 0xFFFFFFFFu) seq_pos[base + i * 1024u + threadIdx.x] = wbase[win[i]] + (u64)hist[win[i]] + (u64)local[i];
+    const u32 lo = blockIdx.x * per_block, hi = min(n_aln, lo + per_block);
+    for (u32 r = lo + threadIdx.x; r < hi; r += 1024u) {
+        const u32 w = win_of[r];
+        if (w != WIN_NONE) seq_pos[r] = wbase[w] + (u64)atomicAdd(&cur[w], seq_room(g_seq_len[r]));
+    }
+}
+// more windows than LDS holds (from 33.5 Mbp on): one global counter per window -- there are enough of them then
+__global__ __launch_bounds__(256) void k_tok_win_bytes_g(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
+                                                         u32 *__restrict__ wbytes) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln) return;
+    const u32 w = win_of[r];
+    if (w != WIN_NONE) atomicAdd(&wbytes[w], seq_room(g_seq_len[r]));
+}
+__global__ __launch_bounds__(256) void k_tok_win_place_g(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
+                                                         const u64 *__restrict__ wbase, u32 *__restrict__ wcur, u64 *__restrict__ seq_pos) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_aln) return;
+    const u32 w = win_of[r];
+    if (w != WIN_NONE) seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], seq_room(g_seq_len[r]));
 }
 
 __global__ __launch_bounds__(256) void k_tok_cigar(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
@@ -479,8 +471,8 @@ struct pp_dev_ingest {
     // contig table
     pp::DevBuf t_slots, t_off, t_names, t_ctgoff;
     u32 t_mask = 0;
-    int seq_layout = PP_SEQ_FILE_ORDER;
-    pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos;
+    int seq_layout = PP_SEQ_WINDOW_GROUPED;  // the default since round 4 (PP_SEQ_LAYOUT=file: in the order of the records)
+    pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos, d_win;
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
         d_good, d_k, d_src, d_gseq, d_groom, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
@@ -488,9 +480,8 @@ struct pp_dev_ingest {
     pp::DevBuf o_contig, o_ref_start, o_k, o_seq_len, o_n_cig, o_cigar, o_seq_off, o_cig_off, o_seq;
     pp::DevBuf o_seq4;   // the 4-bit mirror of o_seq (pp_aln_batch.seq4)
     u64 expect_total = 0;  // pp_dev_ingest_expect: text bytes of all the files to come (sizes the arrays once)
-    int seq4 = -1;       // 1 / 0: PP_SEQ4 says so; -1: with the window-grouped layout only (in file order the pileup kernel is
-                         // bound by the random line fetches themselves, one DRAM page per read, and gains nothing from half the bytes)
-    bool mirror() const { return seq4 >= 0 ? seq4 != 0 : seq_layout == PP_SEQ_WINDOW_GROUPED; }
+    int seq4 = 1;        // the mirror goes with every batch (PP_SEQ4=0: none)
+    bool mirror() const { return seq4 != 0; }
     u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
 };
 
@@ -508,7 +499,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
     D->ctx = ctx;
     D->asmb = a;
     D->max_errors = max_errors;
-    if (const char *e = getenv("PP_SEQ4")) D->seq4 = atoi(e) != 0;  // PP_SEQ4=1 / 0: the 4-bit mirror with every layout / never
+    if (const char *e = getenv("PP_SEQ4")) D->seq4 = atoi(e) != 0;  // PP_SEQ4=0: no 4-bit mirror
     D->careful = careful != 0;
     // RNAME table
     const u32 nc = pp_assembly_n_contigs(a);
@@ -535,7 +526,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
     if (!rc) rc = pp::dev_ensure(ctx, D->t_ctgoff, ((size_t)nc + 1) * 8);
     if (!rc && hipMemcpy(D->t_ctgoff.p, pp_assembly_offsets(a), ((size_t)nc + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
         rc = ctx->fail(PP_ERR_HIP, "uploading the contig offsets failed");
-    if (const char *e = getenv("PP_SEQ_LAYOUT")) D->seq_layout = !strcmp(e, "window") ? PP_SEQ_WINDOW_GROUPED : PP_SEQ_FILE_ORDER;
+    if (const char *e = getenv("PP_SEQ_LAYOUT")) D->seq_layout = !strcmp(e, "file") ? PP_SEQ_FILE_ORDER : PP_SEQ_WINDOW_GROUPED;
     if (!rc && (hipMemcpy(D->t_slots.p, slots.data(), cap * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(D->t_off.p, off.data(), (nc + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
                 (names.size() && hipMemcpy(D->t_names.p, names.data(), names.size(), hipMemcpyHostToDevice) != hipSuccess)))
@@ -548,7 +539,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
 extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     if (!D) return;
     (void)hipStreamSynchronize(D->ctx->stream);
-    pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
+    pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->d_win, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
                          &D->d_k, &D->d_src, &D->d_gseq, &D->d_groom, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
@@ -748,6 +739,10 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         }
     }
     const bool pass_mismatch = n_pass && !d_pass && n_aln;
+    const bool window_layout = D->seq_layout == PP_SEQ_WINDOW_GROUPED;
+    const u64 G_asm = pp_assembly_offsets(D->asmb)[pp_assembly_n_contigs(D->asmb)];
+    const u32 n_win = (u32)std::max<u64>(1, (G_asm + pp::TILE - 1) / pp::TILE);
+    const u64 *seq_place = nullptr, *seq_total_at = nullptr;
     if (n_aln) {
         ENS(d_recline, (u64)n_aln * 4);
         ENS(d_isstart, (u64)n_aln * 4);
@@ -760,22 +755,53 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         if ((rc = fetch(ctx, (const u32 *)D->d_grpofrec.p + n_aln, &n_groups))) return rc;
         ENS(d_gfirst, ((u64)n_groups + 1) * 4);
         ENS(d_good, (u64)n_aln * 4); ENS(d_k, (u64)n_aln * 4); ENS(d_src, (u64)n_aln * 4);
-        ENS(d_gseq, (u64)n_aln * 4); ENS(d_groom, (u64)n_aln * 4); ENS(d_gcig, (u64)n_aln * 4);
+        ENS(d_gseq, (u64)n_aln * 4); ENS(d_groom, (u64)n_aln * 4); ENS(d_gcig, (u64)n_aln * 4); ENS(d_win, (u64)n_aln * 4);
         ENS(d_outidx, ((u64)n_aln + 1) * 4); ENS(d_seqscan, ((u64)n_aln + 1) * 8); ENS(d_cigscan, ((u64)n_aln + 1) * 8);
         hipLaunchKernelGGL(k_tok_group_first, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_isstart.p,
                            (const u32 *)D->d_grpofrec.p, n_groups, (u32 *)D->d_gfirst.p);
         hipLaunchKernelGGL(k_tok_group, dim3((n_groups + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                            (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, (const u32 *)D->d_gfirst.p, n_groups,
                            n_lines, D->max_errors, D->careful, d_pass, (u32 *)D->d_good.p, (u32 *)D->d_k.p, (u32 *)D->d_src.p,
-                           (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, d_status);
+                           (u32 *)D->d_gseq.p, (u32 *)D->d_gcig.p, (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_win.p, d_status);
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p))) return rc;
-        hipLaunchKernelGGL(k_tok_room, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_gseq.p, (u32 *)D->d_groom.p);
-        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_groom.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
         if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p))) return rc;
+        if (timing) lap("groups + gates");
+        // where every good record's SEQ bytes go inside this file's stretch of the seq array
+        if (!window_layout) {  // in file order: a scan of the rooms
+            hipLaunchKernelGGL(k_tok_room, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_gseq.p, (u32 *)D->d_groom.p);
+            if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_groom.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
+            seq_place = (const u64 *)D->d_seqscan.p;
+            seq_total_at = (const u64 *)D->d_seqscan.p + n_aln;
+        } else {  // window-grouped: a multisplit of the rooms into the windows the records start in (see k_tok_win_hist)
+            ENS(d_wbytes, ((u64)n_win + 1) * 4); ENS(d_wbase, ((u64)n_win + 1) * 8); ENS(d_seqpos, (u64)n_aln * 8);
+            if (n_win <= WIN_LDS_MAX) {
+                // 16384 records per workgroup, more when the matrix would pass 1024 rows
+                const u32 per_block = std::max<u32>(16384u, (u32)((((u64)n_aln + 1023u) / 1024u + 1023u) & ~1023ull));
+                const u32 nb = (n_aln + per_block - 1u) / per_block;
+                ENS(d_wcur, (u64)nb * n_win * 4);
+                hipLaunchKernelGGL(k_tok_win_hist, dim3(nb), dim3(1024), 0, st, (const u32 *)D->d_win.p, (const u32 *)D->d_gseq.p, n_aln,
+                                   per_block, n_win, (u32 *)D->d_wcur.p);
+                hipLaunchKernelGGL(k_tok_win_cols, dim3((n_win + 3u) / 4u), dim3(256), 0, st, n_win, nb, (u32 *)D->d_wcur.p, (u32 *)D->d_wbytes.p);
+                hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p);
+                hipLaunchKernelGGL(k_tok_win_place, dim3(nb), dim3(1024), 0, st, (const u32 *)D->d_win.p, (const u32 *)D->d_gseq.p, n_aln,
+                                   per_block, n_win, (const u32 *)D->d_wcur.p, (const u64 *)D->d_wbase.p, (u64 *)D->d_seqpos.p);
+            } else {
+                ENS(d_wcur, (u64)n_win * 4);
+                PP_HIPCHK(ctx, hipMemsetAsync(D->d_wbytes.p, 0, ((size_t)n_win + 1) * 4, st));
+                PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 4, st));
+                hipLaunchKernelGGL(k_tok_win_bytes_g, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const u32 *)D->d_win.p,
+                                   (const u32 *)D->d_gseq.p, n_aln, (u32 *)D->d_wbytes.p);
+                if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
+                hipLaunchKernelGGL(k_tok_win_place_g, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const u32 *)D->d_win.p,
+                                   (const u32 *)D->d_gseq.p, n_aln, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
+            }
+            seq_place = (const u64 *)D->d_seqpos.p;
+            seq_total_at = (const u64 *)D->d_wbase.p + n_win;
+        }
+        if (timing) lap(window_layout ? "window layout" : "file-order layout");
     }
     u64 status = ~0ull;
     if ((rc = fetch(ctx, d_status, &status))) return rc;
-    lap("groups + gates");
     c.alignments = n_aln;
     if (status != ~0ull) {
         std::vector<u32> rec_line(n_aln), group_first((size_t)n_groups + 1);
@@ -795,7 +821,7 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
     u32 n_good = 0;
     u64 seq_total = 0, cig_total = 0;
     if ((rc = fetch(ctx, (const u32 *)D->d_outidx.p + n_aln, &n_good))) return rc;
-    if ((rc = fetch(ctx, (const u64 *)D->d_seqscan.p + n_aln, &seq_total))) return rc;
+    if ((rc = fetch(ctx, seq_total_at, &seq_total))) return rc;
     if ((rc = fetch(ctx, (const u64 *)D->d_cigscan.p + n_aln, &cig_total))) return rc;
     // ---- append to the batch ----
     const u64 no = D->n_out;
@@ -811,51 +837,16 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
 #undef GROW
     OutArrays O{(u32 *)D->o_contig.p, (u32 *)D->o_ref_start.p, (u32 *)D->o_k.p, (u32 *)D->o_seq_len.p, (u32 *)D->o_n_cig.p,
                 (u32 *)D->o_cigar.p, (u64 *)D->o_seq_off.p, (u64 *)D->o_cig_off.p, (u8 *)D->o_seq.p};
-    // where every good record's SEQ bytes go inside this file's stretch of the seq array: in file order (the scan), or
-    // window-grouped
-    const u64 *seq_place = (const u64 *)D->d_seqscan.p;
-    if (D->seq_layout == PP_SEQ_WINDOW_GROUPED) {
-        const u64 G = pp_assembly_offsets(D->asmb)[pp_assembly_n_contigs(D->asmb)];
-        const u32 n_win = (u32)((G + pp::TILE - 1) / pp::TILE);
-        ENS(d_wbytes, ((u64)n_win + 1) * 4); ENS(d_wbase, ((u64)n_win + 1) * 8); ENS(d_wcur, (u64)n_win * 4); ENS(d_seqpos, (u64)n_aln * 8);
-        PP_HIPCHK(ctx, hipMemsetAsync(D->d_wbytes.p, 0, ((size_t)n_win + 1) * 4, st));
-        PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 4, st));
-        const bool in_lds = n_win <= WIN_LDS_MAX;
-        const unsigned wg = (unsigned)((n_aln + 1024u * WIN_RPT - 1u) / (1024u * WIN_RPT));
-        if (in_lds)
-            hipLaunchKernelGGL(k_tok_win_bytes_lds, dim3(wg), dim3(1024), 0, st, (const LineRec *)D->d_rec.p,
-                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
-                               (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_wbytes.p);
-        else
-        hipLaunchKernelGGL(k_tok_win_bytes, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
-                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
-                           (const u64 *)D->t_ctgoff.p, n_win, (u32 *)D->d_wbytes.p);
-        if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
-        if (in_lds)
-            hipLaunchKernelGGL(k_tok_win_place_lds, dim3(wg), dim3(1024), 0, st, (const LineRec *)D->d_rec.p,
-                               (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
-                               (const u64 *)D->t_ctgoff.p, n_win, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
-        else
-        hipLaunchKernelGGL(k_tok_win_place, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
-                           (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_groom.p,
-                           (const u64 *)D->t_ctgoff.p, n_win, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
-        seq_place = (const u64 *)D->d_seqpos.p;
-        lap("window layout");
-    }
     hipLaunchKernelGGL(k_tok_meta, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
                        (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_k.p,
                        (const u32 *)D->d_gseq.p, (const u32 *)D->d_outidx.p, seq_place,
                        (const u64 *)D->d_cigscan.p, O, no, D->seq_bytes, D->n_cig_total);
+    // the SEQ bytes and, in the same pass, their 4-bit mirror (this file's stretch of the seq array starts on a multiple of
+    // PP_SEQ_ALIGN: every stretch so far was a sum of rooms)
     hipLaunchKernelGGL(k_tok_seq, dim3((unsigned)(((u64)n_aln * 8 + 255) / 256)), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
-                       (const u32 *)D->d_src.p, seq_place, O.seq, D->seq_bytes);
-    if (D->mirror() && seq_total) {  // the mirror of this file's stretch of the seq array (from the 32-byte boundary in front of it)
-        if (timing) lap("seq bytes");
-        const u64 lo = D->seq_bytes & ~31ull, hi = D->seq_bytes + seq_total;
-        hipLaunchKernelGGL(k_tok_pack4, dim3((unsigned)(((hi - lo + 31) / 32 + 255) / 256)), dim3(256), 0, st, (const u8 *)D->o_seq.p,
-                           (u8 *)D->o_seq4.p, lo, hi);
-        if (timing) lap("4-bit mirror");
-    }
+                       (const u32 *)D->d_src.p, seq_place, O.seq, D->mirror() ? (u8 *)D->o_seq4.p : (u8 *)nullptr, D->seq_bytes);
+    if (timing) lap("seq bytes + mirror");
     hipLaunchKernelGGL(k_tok_cigar, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
                        (const u64 *)D->d_cigscan.p, O.cigar, D->n_cig_total);

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import synth
+from layout_check import check_seq_layout, same_records
 
 pytestmark = pytest.mark.gpu
 C_u64 = ctypes.c_uint64
@@ -99,6 +100,15 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         for c in range(len(off) - 1):
             assert m["stats"][c]["changed"] == got["stats"][c]["changed"], ("seq4", c)
             assert m["stats"][c]["zero_depth"] == got["stats"][c]["zero_depth"], ("seq4", c)
+        # ... and WITHOUT the mirror (a foreign device batch polished in place: the lane-group plain class over the bytes;
+        # host batches -- ctx.polish_records above -- get a mirror packed on the device since round 4)
+        m = _polish_device_batch(ctx, pp, contig_off, bases, recs, False, positions=True, **kw)
+        for k in POS_KEYS:
+            bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
+            assert len(bad) == 0, ("bytes", k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
+        assert m["polished"] == want["polished"]
+        m = _polish_device_batch(ctx, pp, contig_off, bases, recs, False, positions=False, **kw)
+        assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
     return want, got
 
 
@@ -645,43 +655,41 @@ def test_compact_runs_of_sharded_jobs(ctx, pp, orc, long_read):
 
 
 def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
-    """pp_dev_ingest_set_seq_layout(PP_SEQ_WINDOW_GROUPED): the tokenizer writes the SEQ bytes of the reads that start in
-    one 2048-position window next to each other (per SAM file).  Every record array but seq_off equals the host ingest's,
-    every record's bytes are its bytes, the windows come in order inside a file's stretch of the seq array, and the
-    polish of that batch -- and the CLI with PP_SEQ_LAYOUT=window -- gives the oracle's bytes (repeats with SEQ '*'
-    records on both strands, indels, several contigs)."""
+    """PP_SEQ_WINDOW_GROUPED, the default layout of both ingests since round 4: the SEQ bytes of the reads that start in one
+    2048-position window are next to each other (per SAM file).  Every record array but seq_off equals the host ingest's,
+    every record's bytes are its bytes, the rooms tile the seq array, the windows come in order inside a file's stretch
+    (the host ingest keeps file order inside a window, the tokenizer leaves that to its atomics), the batch brings the
+    4-bit mirror of its seq array, and the polish of that batch -- and the CLI under every combination of PP_SEQ_LAYOUT /
+    PP_SEQ4 / ingest -- gives the oracle's bytes (repeats with SEQ '*' records on both strands, indels, several contigs).
+    PP_SEQ_FILE_ORDER on request: array-equal to the host ingest's."""
     ds = synth.rich_dataset(str(tmp_path), seed=97, contig_lens=(30_000, 2_500, 9_000), coverage=25, repeat_len=300,
                             repeat_copies=3, lowercase_frac=0.1)
     sams = [ds["sam1"], ds["sam2"]]
     _, _, off, bases, want, counts = pp.ingest(ds["fasta"], sams)
-    _, _, off2, bases2, got, counts2 = pp.ingest_device(ctx, ds["fasta"], sams, seq_layout=1)
-    assert counts == counts2 and np.array_equal(off, off2) and np.array_equal(bases, bases2)
-    for k in ("contig", "ref_start", "k", "seq_len", "cig_off", "n_cig", "cigar"):
-        assert np.array_equal(want[k], got[k]), k
-    assert len(got["seq"]) == len(want["seq"]) and not np.array_equal(got["seq_off"], want["seq_off"])
-    _check_mirror(pp, got, expect=True)   # the window-grouped batch brings the 4-bit mirror of its seq array
-    so_w, so_g, sl = want["seq_off"].astype(np.int64), got["seq_off"].astype(np.int64), want["seq_len"].astype(np.int64)
-    for i in list(range(0, len(sl), 37)) + [len(sl) - 1]:
-        assert bytes(got["seq"][so_g[i]:so_g[i] + sl[i]]) == bytes(want["seq"][so_w[i]:so_w[i] + sl[i]]), i
-    covered = np.zeros(len(got["seq"]) + 1, dtype=np.int64)   # the records' stretches (each up to its PP_SEQ_ALIGN boundary) tile the seq array exactly
-    np.add.at(covered, so_g, 1)
-    np.add.at(covered, so_g + ((sl + 31) & ~31), -1)
-    assert (np.cumsum(covered)[:-1] == 1).all() and (so_g % 32 == 0).all()
-    n1 = counts[0][1]                                        # good records of file 1: their stretch comes first
-    win = (off[got["contig"]].astype(np.int64) + got["ref_start"].astype(np.int64)) // 2048
-    for lo, hi in ((0, n1), (n1, len(sl))):
-        order = np.argsort(so_g[lo:hi], kind="stable")
-        assert (np.diff(win[lo:hi][order]) >= 0).all(), "inside a file's stretch the windows come in order"
-    assert so_g[:n1].max() < so_g[n1:].min()
+    _, _, off2, bases2, got, counts2 = pp.ingest_device(ctx, ds["fasta"], sams)      # the default: window-grouped
+    _, _, _, _, got1, counts3 = pp.ingest_device(ctx, ds["fasta"], sams, seq_layout=1)
+    assert counts == counts2 == counts3 and np.array_equal(off, off2) and np.array_equal(bases, bases2)
+    used = [c[1] for c in counts]
+    check_seq_layout(want, off, used, grouped=True, file_order_inside=True)
+    for g in (got, got1):
+        same_records(want, g)
+        check_seq_layout(g, off, used, grouped=True)
+        _check_mirror(pp, g, expect=True)   # the batch brings the 4-bit mirror of its seq array
+    _, _, _, _, flat_h, _ = pp.ingest(ds["fasta"], sams, seq_layout=0)
+    _, _, _, _, flat_d, _ = pp.ingest_device(ctx, ds["fasta"], sams, seq_layout=0)
+    check_seq_layout(flat_d, off, used, grouped=False)
+    _check_mirror(pp, flat_d, expect=True)
+    for k in flat_h:
+        assert np.array_equal(flat_h[k], flat_d[k]), k
+    same_records(want, flat_h)
     res = ctx.polish_records(off, bases, got)
     assert res["polished"] == orc.polish_records(off, bases, want)["polished"]
     exe = os.path.join(ROOT, "bin", "polypolish")
-    r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, PP_SEQ_LAYOUT="window"))
-    assert r.returncode == 0 and r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"], r.stderr[-400:]
-    # ... the mirror without the layout, and the layout without the mirror
-    for env in (dict(PP_SEQ4="1"), dict(PP_SEQ_LAYOUT="window", PP_SEQ4="0")):
+    oracle_fasta = orc.polish_files(ds["fasta"], sams)["fasta"]
+    for env in (dict(), dict(PP_SEQ_LAYOUT="window"), dict(PP_SEQ_LAYOUT="file"), dict(PP_SEQ4="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0"),
+                dict(PP_DEVICE_INGEST="0"), dict(PP_DEVICE_INGEST="0", PP_SEQ_LAYOUT="file"), dict(PP_DEVICE_INGEST="0", PP_SEQ4="0")):
         r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
-        assert r.returncode == 0 and r.stdout == orc.polish_files(ds["fasta"], sams)["fasta"], (env, r.stderr[-400:])
+        assert r.returncode == 0 and r.stdout == oracle_fasta, (env, r.stderr[-400:])
 
 
 def test_multi_process_driver_on_one_gpu(orc, tmp_path):
@@ -713,10 +721,17 @@ def _same_ingest(pp, ctx, fasta, sams, **kw):
     assert ge == we, (ge, we)
     if want is not None:
         assert got[5] == want[5], (got[5], want[5])
-        for k in want[4]:
-            assert np.array_equal(got[4][k], want[4][k]), k
+        grouped = kw.get("seq_layout", None) != 0 and os.environ.get("PP_SEQ_LAYOUT") != "file"
+        if grouped:  # window-grouped: the same records, the same layout up to the order inside a window
+            same_records(want[4], got[4])
+            used = [c[1] for c in want[5]]
+            check_seq_layout(want[4], want[2], used, grouped=True, file_order_inside=True)
+            check_seq_layout(got[4], want[2], used, grouped=True)
+        else:
+            for k in want[4]:
+                assert np.array_equal(got[4][k], want[4][k]), k
         # the 4-bit mirror the tokenizer hands over with its batch (pp_aln_batch.seq4): base i of the seq ARRAY in nibble i
-        _check_mirror(pp, got[4], expect=os.environ.get("PP_SEQ4") == "1")
+        _check_mirror(pp, got[4], expect=os.environ.get("PP_SEQ4") != "0")
     return want, we
 
 
@@ -735,12 +750,13 @@ def _check_mirror(pp, recs, expect):
 @pytest.mark.parametrize("case", FILE_CASES, ids=[f"seed{c['seed']}" for c in FILE_CASES])
 @pytest.mark.parametrize("careful", [False, True])
 def test_device_tokenizer_equals_host_ingest(pp, ctx, tmp_path, case, careful, monkeypatch):
-    """pp_dev_ingest_*: SAM text tokenized by kernels; the batch must equal the host ingest's array by array
-    (and therefore what the reference's process_one_read would feed the pileup).  With PP_SEQ4=1 (every other case) the
-    batch brings the 4-bit mirror of its seq array: checked nibble by nibble (secondaries' SEQ filled in from the other
-    strand, lower case, bytes other than A/C/G/T)."""
+    """pp_dev_ingest_*: SAM text tokenized by kernels; the batch must hold the host ingest's records (and therefore what the
+    reference's process_one_read would feed the pileup): in the default window-grouped layout the same records and the same
+    layout up to the order inside a window, with PP_SEQ_LAYOUT=file (every other case) array by array.  The batch brings
+    the 4-bit mirror of its seq array: checked nibble by nibble (secondaries' SEQ filled in from the other strand, lower
+    case, bytes other than A/C/G/T)."""
     if careful:
-        monkeypatch.setenv("PP_SEQ4", "1")
+        monkeypatch.setenv("PP_SEQ_LAYOUT", "file")
     ds = synth.rich_dataset(str(tmp_path), lowercase_frac=0.2, **case)
     want, err = _same_ingest(pp, ctx, ds["fasta"], [ds["sam1"], ds["sam2"]], max_errors=10, careful=careful)
     assert err is None and len(want[4]["contig"]) > 0
@@ -1285,9 +1301,9 @@ def test_device_split_equals_host_split(ctx, pp, orc, world):
     torch.cuda.synchronize()
     L = pp.lib()
     total = 0
-    for r in range(world):
-        want, want_orig = pp.shard_split_host(plan, r, odd)
-        part = pp.ShardPart(ctx, plan, r, n, {k: v.data_ptr() for k, v in keep.items()}, keep["seq"].numel(), keep["cigar"].numel(),
+    def parts_agree(src, keep_t, r):
+        want, want_orig = pp.shard_split_host(plan, r, src)
+        part = pp.ShardPart(ctx, plan, r, n, {k: v.data_ptr() for k, v in keep_t.items()}, keep_t["seq"].numel(), keep_t["cigar"].numel(),
                             pp.MEM_DEVICE)
         assert part.n_aln == len(want_orig) and part.seq_bytes == len(want["seq"]) and part.n_cig_total == len(want["cigar"]), r
         sizes = {"seq": part.seq_bytes, "cigar": part.n_cig_total}
@@ -1301,9 +1317,41 @@ def test_device_split_equals_host_split(ctx, pp, orc, world):
         if part.n_aln:
             assert L.pp_ctx_download(ctx._h, orig.ctypes.data, part.orig_ptr, orig.nbytes) == 0
         assert np.array_equal(orig, want_orig), r
-        total += part.n_aln
+        # a device part brings the 4-bit mirror of its seq array
+        assert "seq4" in part.ptrs
+        m = np.zeros((part.seq_bytes + 1) // 2, dtype=np.uint8)
+        if m.size:
+            assert L.pp_ctx_download(ctx._h, m.ctypes.data, part.ptrs["seq4"], m.nbytes) == 0
+            assert np.array_equal(m[:part.seq_bytes // 2], pp.pack_seq4(want["seq"])[:part.seq_bytes // 2]), r
+        cnt_part = part.n_aln
         part.close()
+        return want, cnt_part
+    for r in range(world):
+        total += parts_agree(odd, keep, r)[1]
     assert n <= total < 1.2 * n
+    # The same from a batch laid out as the library's ingests lay one out (rooms of PP_SEQ_ALIGN bytes, the SEQ bytes NOT in
+    # the order of the records: here shuffled, as window-grouping shuffles them): a part keeps the order of the source's seq
+    # array -- a window-grouped batch gives window-grouped parts -- on the device (a scan over the array's 32-byte slots)
+    # as on the host (a sort), and the two agree array by array.
+    rng = np.random.default_rng(5)
+    sl = odd["seq_len"].astype(np.int64)
+    room = (sl + 31) & ~31
+    perm = rng.permutation(n)
+    place = np.zeros(n, dtype=np.int64)
+    place[perm] = np.cumsum(room[perm]) - room[perm]
+    shuf = {k: v.copy() for k, v in odd.items()}
+    shuf["seq"] = np.zeros(int(room.sum()), dtype=np.uint8)
+    for i in range(n):
+        shuf["seq"][place[i]:place[i] + sl[i]] = odd["seq"][int(odd["seq_off"][i]):int(odd["seq_off"][i]) + sl[i]]
+    shuf["seq_off"] = place.astype(np.uint64)
+    keep2 = {k: torch.from_numpy(np.ascontiguousarray(shuf[k], dtype=dt).view(np.int64 if dt == np.uint64 else (np.int32 if dt == np.uint32 else np.uint8))).to(dev)
+             for k, dt in pp.REC_FIELDS}
+    torch.cuda.synchronize()
+    for r in range(world):
+        want, _ = parts_agree(shuf, keep2, r)
+        if len(want["contig"]) > 1:  # the part's SEQ bytes follow the source's seq array, not the records
+            src_order = np.argsort(shuf["seq_off"][pp.shard_split_host(plan, r, shuf)[1]], kind="stable")
+            assert (np.diff(want["seq_off"][src_order].astype(np.int64)) > 0).all(), r
     cnt = pp.shard_count(ctx, n, keep["contig"].data_ptr(), pp.MEM_DEVICE, 4, {k: v.data_ptr() for k, v in keep.items()})
     assert np.array_equal(cnt.astype(np.int64), np.bincount(odd["contig"][odd["contig"] < 4], minlength=4))
     for r in range(world):  # the property the partition exists for, on the device engine

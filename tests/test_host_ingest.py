@@ -12,6 +12,7 @@ import pytest
 
 import polypolish_amd as pp
 import synth
+from layout_check import check_seq_layout, same_records
 
 ROOT = pp.ROOT
 
@@ -93,15 +94,21 @@ def test_ingest_records_reproduce_the_text_path(orc, tmp_path, case, careful):
     if not careful and case.get("repeat_copies"):
         assert recs["k"].max() > 1, "no multi-mapped read survived: the 1/k path is not exercised"
     assert names == [c.name for c in ds["contigs"]] and descs[0] == "some description"
-    # the layout of the seq array (include/polypolish_hip.h: PP_SEQ_ALIGN): every record's SEQ on a 32-byte boundary, the
-    # bytes up to the next record zero, nothing else in the array
-    so, sl = recs["seq_off"].astype(np.int64), recs["seq_len"].astype(np.int64)
-    room = (sl + 31) & ~31
-    assert (so % 32 == 0).all() and np.array_equal(so, np.cumsum(room) - room) and len(recs["seq"]) == int(room.sum())
-    used = np.zeros(len(recs["seq"]) + 1, dtype=np.int64)
-    np.add.at(used, so, 1)
-    np.add.at(used, so + sl, -1)
-    assert (recs["seq"][np.cumsum(used)[:-1] == 0] == 0).all() and (recs["seq"][np.cumsum(used)[:-1] == 1] != 0).all()
+    # the layout of the seq array (include/polypolish_hip.h: PP_SEQ_ALIGN, PP_SEQ_WINDOW_GROUPED): every record's SEQ on a
+    # 32-byte boundary, the bytes up to the next record zero, nothing else in the array; window-grouped per file by default
+    # (file order inside a window, whatever the thread count), in the order of the records on request -- same records
+    used = [c[1] for c in counts]
+    check_seq_layout(recs, off, used, grouped=True, file_order_inside=True)
+    for layout, env in ((0, None), (None, "file")):
+        if env:
+            os.environ["PP_SEQ_LAYOUT"] = env
+        try:
+            _, _, _, _, flat, counts_f = pp.ingest(ds["fasta"], sams, max_errors=10, careful=careful, seq_layout=layout)
+        finally:
+            os.environ.pop("PP_SEQ_LAYOUT", None)
+        assert counts_f == counts
+        check_seq_layout(flat, off, used, grouped=False)
+        same_records(flat, recs)
 
 
 def _line(name, flag, ref, pos, cigar, seq, tags="NM:i:0"):
@@ -381,5 +388,8 @@ def test_slices_of_a_sam_file_start_on_read_group_boundaries(tmp_path):
         pth.write_bytes(text[a0:b0])
         paths.append(str(pth))
     _, _, _, _, got, _ = pp.ingest(str(fa), paths)
-    for k in want:
-        assert np.array_equal(want[k], got[k]), k
+    same_records(want, got)   # (the SEQ bytes are window-grouped per FILE: the slices' stretches differ from the whole file's)
+    _, _, _, _, want_f, _ = pp.ingest(str(fa), [str(whole)], seq_layout=0)
+    _, _, _, _, got_f, _ = pp.ingest(str(fa), paths, seq_layout=0)
+    for k in want_f:
+        assert np.array_equal(want_f[k], got_f[k]), k

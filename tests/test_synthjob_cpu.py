@@ -85,10 +85,18 @@ def test_cli_argument_grammar_is_claps():
                  ["polish", "-q", "x.fa"], ["polish", "--careful=1", "x.fa"], ["polish", "-d"], ["polish"],
                  ["polish", "-i", "abc", "x.fa"], ["filter", "--in1", "a", "--in2", "b", "--out1", "c"],
                  ["filter", "--in1", "a", "--in2", "b", "--out1", "c", "--out2", "d", "--low", "x"],
-                 ["filter", "--in1", "a", "--in2", "b", "--out1", "c", "--out2", "d", "extra"], ["bogus"]):
+                 ["filter", "--in1", "a", "--in2", "b", "--out1", "c", "--out2", "d", "extra"], ["bogus"],
+                 # an option's value is never taken from an argument that looks like an option (clap: "a value is required"):
+                 ["polish", "--debug", "--careful", "x.fa"], ["polish", "-m", "-5", "x.fa"], ["polish", "-d", "--", "x.fa"],
+                 ["filter", "--in1", "--in2", "b", "--out1", "c", "--out2", "d"]):
         code, err = rc(*args)
         assert code == 2 and err.startswith(b"error:"), (args, code, err)
+    for args, opt in ((["polish", "--debug", "--careful", "x.fa"], b"--debug <DEBUG>"), (["polish", "-m", "-5", "x.fa"], b"--max_errors <MAX_ERRORS>")):
+        code, err = rc(*args)
+        assert b"a value is required for '" + opt + b"' but none was supplied" in err, (args, err)
+        assert not os.path.exists("--careful")
     for args in (["polish", "-d4", "missing.fa"], ["polish", "-d=4", "missing.fa"], ["polish", "--min_depth=4", "--", "-odd-name.fa"],
+                 ["polish", "--debug", "-", "missing.fa"], ["polish", "--debug=-x.tsv", "missing.fa"],   # a lone "-" and an attached value are values
                  ["polish", "-m3", "-i0.1", "-v=0.6", "--careful", "missing.fa", "a.sam", "b.sam"]):
         code, err = rc(*args)
         assert code == 1, (args, code, err)

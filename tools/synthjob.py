@@ -43,7 +43,7 @@ def _excl_cumsum(x):
 
 
 def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=42, sub_rate=0.002, n_rate=1e-4,
-             seq_pitch=None,
+             seq_pitch=None, seq_layout="window",
              asm_err_rate=1e-4, recipe="survey", indel_read_frac=None, repeat=None, repeat_bp=0, repeat_k=5, pairs=False,
              unaligned_frac=0.0, G=None, end_margin=1000, asm_sub_rate=None):
     """One synthetic polish job (see the module docstring).  contig_lens are TRUTH lengths; the assembly's differ by
@@ -388,11 +388,20 @@ def make_job(device, contig_lens=(5_000_000,), coverage=200, read_len=150, seed=
     job = {"G": Ga, "contig_off": aoff.cpu().numpy().astype(np.uint64), "bases": bases, "recs": recs,
            "truth": lut[truth.long()], "truth_off": toff.cpu().numpy().astype(np.uint64), "read_len": L,
            "n_runs": int(r_ncig.sum().item()), "n_aln": ng, "n_records": n, "sam": sam, "planted": planted, "recipe": recipe,
-           "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi]}
-    # the resident records as the product's ingests lay them out: every record's SEQ on a PP_SEQ_ALIGN (32-byte) boundary of
-    # the seq array, zeros in between (seq_pitch=0: packed back to back, the layout of rounds 1-3's bench lines)
+           "repeat_loci": loci_asm, "repeat_loci_truth": loci, "repeat_seg": repeat[0] if repeat else 0, "gstart": gstart[gi],
+           "file_used": None}
+    # good records of SAM file 1 / 2 (without the text form, pairs=False: the two halves of the records, as two files would hold them)
+    n1 = int((gi < (half if pairs else n // 2)).sum().item())
+    job["file_used"] = [n1, ng - n1]
+    # the resident records as the product's ingests lay them out (include/polypolish_hip.h): every record's SEQ on a
+    # PP_SEQ_ALIGN (32-byte) boundary of the seq array, zeros in between, and -- the default since round 4 -- the SEQ bytes of
+    # a SAM file WINDOW-GROUPED (PP_SEQ_WINDOW_GROUPED; file order inside a window, as the host ingest writes them:
+    # tests/test_synthjob_cpu.py compares the arrays).  seq_layout="file": in the order of the records (rounds 1-3);
+    # seq_pitch=0: packed back to back as well (the layout of rounds 1-3's first bench lines)
     pitch = (L + 31) // 32 * 32 if seq_pitch is None else (seq_pitch or L)
-    return job if pitch == L else with_pitch(job, pitch)
+    if pitch != L:
+        job = with_pitch(job, pitch)
+    return window_grouped(job) if seq_layout == "window" and seq_pitch is None else job
 
 
 def seq4_of(seq, chunk=1 << 27):
@@ -432,7 +441,8 @@ def with_pitch(job, pitch):
     out.pop("_prepared", None)
     recs = dict(r)
     padded = torch.zeros((n, pitch), dtype=torch.uint8, device=dev)
-    padded[:, :L] = r["seq"].view(n, job.get("pitch", L))[:, :L]   # (file-order layout of constant pitch on the way in)
+    P0 = job.get("pitch", L)
+    padded[:, :L] = r["seq"].view(n, P0)[r["seq_off"] // P0][:, :L]   # (any layout of constant pitch on the way in; file order out)
     recs["seq"] = padded.reshape(-1).contiguous()
     recs["seq_off"] = (torch.arange(n, device=dev, dtype=torch.int64) * pitch).contiguous()
     out["recs"] = recs
@@ -442,26 +452,47 @@ def with_pitch(job, pitch):
 
 
 def window_grouped(job, window=2048):
-    """The same job with the SEQ bytes laid out WINDOW-GROUPED: the reads of one 2048-position window are adjacent in the
-    seq array (windows in order, file order inside a window); every other array -- and the order of the records -- is
-    unchanged, seq_off simply points there.  The C ABI allows any seq_off, so this is not a new batch format but a choice
-    the producer of a batch has (an ingest that knows the windows could write its SEQ bytes this way): the layout probe
-    of DESIGN.md section 9."""
+    """The same job with the SEQ bytes laid out WINDOW-GROUPED, as the product's ingests write them by default
+    (PP_SEQ_WINDOW_GROUPED): per SAM file, the reads that start in one 2048-position window are adjacent in the file's
+    stretch of the seq array (windows in order, file order inside a window -- the host ingest's order; the device tokenizer
+    leaves the order inside a window to its atomics); every other array -- and the order of the records -- is unchanged,
+    seq_off simply points there.  The C ABI allows any seq_off, so this is not a batch format but the producer's choice."""
     r = job["recs"]
     L = job["read_len"]
     n = job["n_aln"]
     dev = r["seq"].device
-    win = job["gstart"] // window
-    order = torch.argsort(win, stable=True)           # records by window, file order inside
+    n_win = max(1, (int(job["G"]) + window - 1) // window)
+    win = torch.clamp(job["gstart"] // window, max=n_win - 1)
+    n1 = job.get("file_used", [n, 0])[0]
+    file_of = (torch.arange(n, device=dev) >= n1).long()
+    order = torch.argsort(file_of * n_win + win, stable=True)   # records by (file, window), file order inside
     slot = torch.empty(n, dtype=torch.int64, device=dev)
     slot[order] = torch.arange(n, device=dev)
     out = dict(job)
     out.pop("_prepared", None)
     recs = dict(r)
     P = job.get("pitch", L)                            # bytes of the seq array per record (its SEQ up to the next boundary)
-    recs["seq"] = r["seq"].view(n, P)[order].reshape(-1).contiguous()
+    row = r["seq_off"] // P                            # (any layout of constant pitch on the way in)
+    recs["seq"] = r["seq"].view(n, P)[row[order]].reshape(-1).contiguous()
     recs["seq_off"] = (slot * P).contiguous()
     out["recs"] = recs
+    out["seq_layout"] = "window"
+    if job.get("seq4") is not None:
+        out["seq4"] = seq4_of(recs["seq"])
+    return out
+
+
+def file_ordered(job):
+    """The same job with the SEQ bytes in the order of the records (PP_SEQ_FILE_ORDER: the layout of rounds 1-3)."""
+    r = job["recs"]
+    n, P = job["n_aln"], job.get("pitch", job["read_len"])
+    out = dict(job)
+    out.pop("_prepared", None)
+    recs = dict(r)
+    recs["seq"] = r["seq"].view(n, P)[r["seq_off"] // P].reshape(-1).contiguous()
+    recs["seq_off"] = (torch.arange(n, device=r["seq"].device, dtype=torch.int64) * P).contiguous()
+    out["recs"] = recs
+    out["seq_layout"] = "file"
     if job.get("seq4") is not None:
         out["seq4"] = seq4_of(recs["seq"])
     return out
