@@ -771,7 +771,9 @@ class Context:
     def polish_records(self, contig_off, bases, recs, min_depth=5, fraction_valid=0.5, fraction_invalid=0.2,
                        positions=False, emit=None, cuts=None):
         """Host numpy SoA (field names of pp_aln_batch) -> polished bytes, offsets, stats.
-        cuts: optional record indices at which the records are cut into several pp_polish_add batches."""
+        cuts: optional record indices at which the records are cut into several pp_polish_add batches.
+        positions: True = the per-position records of --debug; 3 = the records of what the pileup kernel itself decides
+        (test hook: positions with inexact depth shares settled by its interval test are not replayed)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
         lib().pp_polish_set_debug(self._h, int(positions))

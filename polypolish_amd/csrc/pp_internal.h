@@ -21,7 +21,14 @@ constexpr int COARSE_WINDOWS = 8;     // windows per coarse bucket of the two-le
 constexpr int COARSE_WINDOWS_BIG = 64;  // ... and beyond COARSE_BIG_FROM windows (measured on 250 Mbp: 2.8 vs 3.1 ms)
 constexpr uint32_t COARSE_BIG_FROM = 65536;
 constexpr int COUNT_RANGE = 16384;   // windows histogrammed per LDS pass of the bucketing kernels
-constexpr int DEPTH_FX_BITS = 10;    // depth shares 1/2^j (j <= 10) are summed as 2^-10 units
+// Depth in fixed point.  A window tallies the depth shares 1/k of its reads as DEFICITS against 1 in units of 2^-b, b =
+// win_fx_bits(items of the window) <= DEPTH_FX_BITS: a share 1/2^j with j <= b is exact in any order (the reference's f64
+// sum of such shares is exact too), any other share is rounded to the nearest unit and marks the positions it covers as
+// INEXACT -- their depth is then known to within (reads there) * 2^-(b+1), and only the positions where that interval
+// leaves one of the vote's three tests open (pileup.rs:70-72,114) are replayed in file order (k_exact2).  b is chosen so
+// that a position's deficit cannot pass 2^31 however many of the window's items cover it.  The per-contig depth sums
+// (the log's mean read depth) are kept in 2^-DEPTH_FX_BITS units.
+constexpr int DEPTH_FX_BITS = 20;
 constexpr uint32_t MAX_BUCKET = 1u << 21;  // (alignment, window) items per window on the fast path
 constexpr uint32_t SORT_MAX = 16384;      // items per window the ordered-depth replay kernel sorts in LDS (128 KiB)
 constexpr uint32_t SORT_SMALL = 10112;    // ... its small instance (80 KiB of LDS: two workgroups per CU)
@@ -52,7 +59,11 @@ constexpr uint32_t ENT_POINT = 8u;
 constexpr uint32_t NKW_INDEL1 = 3u;    // class bits (30-31) of the nkeep word: span | a << 9 | is_deletion << 17 below them
 constexpr uint32_t INDEL1_MIN_SEG = 8; // both flanks at least this long (PLAIN_MIN_LEN), else the general walk
 constexpr uint32_t FAST_MAX_LEN = 252; // a read of <= 252 bases is one dword-per-lane wave load
-constexpr uint32_t KCLASS_NONDYADIC = 255u;
+// depth-share class of a work item (8 bits; kclass_of / k_of_class in pp_k_common.h): 0: k = 1 | 1..20: k = 2^class |
+// 21..254: k = class - 18 (3..236, the other small k: all-hits reads in a handful of copies) | 255: any other k (looked up)
+constexpr uint32_t KCLASS_DYADIC_MAX = 20u;
+constexpr uint32_t KCLASS_SMALL_BASE = 18u, KCLASS_SMALL_MAX_K = 236u;
+constexpr uint32_t KCLASS_OTHER = 255u;
 
 // device-side error codes, packed as (record index << 8 | code) and combined with atomicMin so
 // that the first offending record in file order wins, as in the reference's streaming loop
@@ -87,7 +98,7 @@ struct KernelTimer {
 struct ContigStatsDev {  // per contig, accumulated with atomics
     unsigned long long changed;
     unsigned long long zero_depth;
-    unsigned long long depth_fx;  // sum of depth in 2^-DEPTH_FX_BITS units
+    unsigned long long depth_fx;  // sum of depth in 2^-DEPTH_FX_BITS units (inexact shares as rounded, see DEPTH_FX_BITS)
 };
 
 }  // namespace pp
@@ -103,6 +114,7 @@ struct pp_ctx {
     bool timer_open = false;
     std::vector<hipEvent_t> event_pool;
     bool debug = false;
+    int debug_level = 0;  // what pp_polish_set_debug was given (3: see run_pipeline)
     std::vector<pp::KernelTimer> timers;
     pp_kernel_times last_times{};
 

@@ -83,13 +83,32 @@ __device__ __forceinline__ u32 d_bankers(double x) {
     return r + (r & 1u);
 }
 
+// depth-share class of k good alignments per read (pp_internal.h: KCLASS_*) and back
 __device__ __forceinline__ u32 kclass_of(u32 k) {
     if (k == 1) return 0;
     if ((k & (k - 1)) == 0) {
-        u32 j = 31u - (u32)__clz((int)k);
-        if (j <= (u32)DEPTH_FX_BITS) return j;
+        const u32 j = 31u - (u32)__clz((int)k);
+        if (j <= KCLASS_DYADIC_MAX) return j;
+        return KCLASS_OTHER;
     }
-    return KCLASS_NONDYADIC;
+    return k <= KCLASS_SMALL_MAX_K ? k + KCLASS_SMALL_BASE : KCLASS_OTHER;
+}
+__device__ __forceinline__ u32 k_of_class(u32 kc, const u32 *kk, u32 rec) {
+    return kc == 0 ? 1u : (kc <= KCLASS_DYADIC_MAX ? (1u << kc) : (kc != KCLASS_OTHER ? kc - KCLASS_SMALL_BASE : kk[rec]));
+}
+// fixed-point bits of a window with n_items work items: a position's deficit (< items covering it * 2^b) stays below 2^31
+__device__ __forceinline__ u32 win_fx_bits(u32 n_items) {
+    const u32 bits = 32u - (u32)__clz((int)(n_items | 1u));
+    return min((u32)DEPTH_FX_BITS, 31u - bits);
+}
+// The deficit (2^b - share) of a read of class kc in units of 2^-b, the share rounded to the nearest unit; *inexact = the
+// share is not a multiple of the unit (its positions' depths are then only bounded, see DEPTH_FX_BITS).
+__device__ __forceinline__ u32 share_deficit(u32 kc, u32 b, const u32 *kk, u32 rec, bool *inexact) {
+    if (kc <= KCLASS_DYADIC_MAX && kc <= b) { *inexact = false; return (1u << b) - (1u << (b - kc)); }
+    const u32 k = k_of_class(kc, kk, rec), one = 1u << b;
+    const u32 s = (one + (k >> 1)) / k;
+    *inexact = s * k != one;
+    return one - s;
 }
 
 // counter row of one read byte: exact "A"/"C"/"G"/"T" (pileup.rs:58-61), "-" shares the

@@ -229,7 +229,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, u32 cap, ulonglong2 *cov,
     for (u32 i = lane; i < n; i += 64) {
         const u32 kq = (u32)(cov[i].x & 0xFFFFFFFFull), kc = kclass_of(kq);
         rcp[i] = 1.0 / (double)kq;
-        if (kc == KCLASS_NONDYADIC) odd = true; else fx += (u64)(1u << DEPTH_FX_BITS) >> kc;
+        if (kc > KCLASS_DYADIC_MAX) odd = true; else fx += (u64)(1u << DEPTH_FX_BITS) >> kc;
         const u64 y = cov[i].y;
         const u32 len = (u32)((y >> 40) & 0x7FFFFFu);
         // the key's first (up to four) bytes: one load where four bytes lie inside the seq array, else byte by byte
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
             }
             lim = tf ? L - 4u + (u32)((31 - __clz((int)tf)) >> 3) : simple_nkeep(rp, L);
         }
-        const u32 k = kc == 0 ? 1u : (kc != KCLASS_NONDYADIC ? (1u << kc) : A.kk[ent.w]);
+        const u32 k = k_of_class(kc, A.kk, ent.w);
         ulonglong2 r;
         r.x = (u64)(u32)item_rel(ent.z) | ((u64)lim << 32);
         r.y = (u64)__double_as_longlong(1.0 / (double)k);

@@ -17,6 +17,7 @@ struct TileArgs {
     const u64 *cig_off;
     const u32 *n_cig;
     const u32 *cigar;
+    const u32 *kk;    // k per record (only for the rare share classes that do not carry their k: KCLASS_OTHER)
     const u8 *bases;
     u64 G;
     const u64 *contig_off;
@@ -55,13 +56,35 @@ struct TileArgs {
     int dbg;
 };
 
-__device__ __forceinline__ void tile_add(u32 *cnt, int row, int p, u32 kc) {
-    atomicAdd(&cnt[row * TILE + p], 1u);
-    if (kc) {
-        if (kc == KCLASS_NONDYADIC) atomicOr(&cnt[ROW_DEF * TILE + p], 0x80000000u);
-        else atomicAdd(&cnt[ROW_DEF * TILE + p], (1u << DEPTH_FX_BITS) - (1u << (DEPTH_FX_BITS - kc)));
+// the window's fixed-point bits and whether any item of it had a depth share other than 1 (then the deficit row is scanned)
+struct TileShare {
+    u32 b;            // win_fx_bits of the window
+    u32 *any_shared;  // LDS flag
+    const u32 *kk;
+};
+
+// The depth share of ONE work item of class kc != 0 over the window positions [p0, p1) it covers (every entry of an
+// alignment is one add_seq with the read's share, pileup.rs:56-65, and an item's entries are consecutive positions): its
+// deficit against 1 goes into the deficit row as a DIFFERENCE (+d at p0, -d at p1; prefix-summed before the vote, like
+// the coverage row), and an inexact share marks [p0, p1) in the window's bitmap of inexact positions.  Called by one lane
+// per item.
+__device__ __forceinline__ void share_range(u32 *cnt, u32 *ndbits, const TileShare &S, int p0, int p1, u32 kc, u32 rec) {
+    if (kc == 0 || p1 <= p0) return;
+    bool inexact;
+    const u32 d = share_deficit(kc, S.b, S.kk, rec, &inexact);
+    atomicAdd(&cnt[ROW_DEF * TILE + p0], d);
+    if (p1 < TILE) atomicAdd(&cnt[ROW_DEF * TILE + p1], 0u - d);
+    *S.any_shared = 1u;
+    if (inexact) {
+        const u32 a = (u32)p0, b = (u32)p1;
+        for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
+            const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
+            atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
+        }
     }
 }
+
+__device__ __forceinline__ void tile_add(u32 *cnt, int row, int p) { atomicAdd(&cnt[row * TILE + p], 1u); }
 
 __device__ __forceinline__ u32 find_contig(const u64 *contig_off, u32 n_contigs, u64 p) {
     u32 lo = 0, hi = n_contigs;  // contig_off[lo] <= p < contig_off[hi]
@@ -94,16 +117,14 @@ struct VoteOut {
 };
 
 // pileup.rs:67-134 restricted to the keys A,C,G,T and "-"; callers guarantee that no other key
-// can reach either threshold.
-__device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, double depth,
-                                         u8 orig, u32 min_depth, double fv, double fi) {
+// can reach either threshold.  vote5_thr: with the two thresholds and the depth test already evaluated.
+__device__ __forceinline__ VoteOut vote5_thr(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, u32 vthr, u32 ithr, bool low_depth, u8 orig) {
     VoteOut v;
-    u32 vt = d_bankers(__dmul_rn(depth, fv));
-    v.vthr = max(min_depth, vt);
-    v.ithr = d_bankers(__dmul_rn(depth, fi));
+    v.vthr = vthr;
+    v.ithr = ithr;
     v.out = orig;
     v.status = PP_ST_KEPT;
-    if (depth < (double)min_depth) {
+    if (low_depth) {
         v.status = PP_ST_LOW_DEPTH;
     } else {
         int nv = 0, ni = 0;
@@ -126,6 +147,11 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
     }
     if (v.out == (u8)'-') v.out = 0;  // polish.rs:188
     return v;
+}
+__device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, double depth,
+                                         u8 orig, u32 min_depth, double fv, double fi) {
+    const u32 vt = d_bankers(__dmul_rn(depth, fv));
+    return vote5_thr(nA, nC, nG, nT, nDel, max(min_depth, vt), d_bankers(__dmul_rn(depth, fi)), depth < (double)min_depth, orig);
 }
 
 // LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
@@ -175,13 +201,12 @@ struct PlainCfg {
     __device__ static __forceinline__ u32 group(u32 lane) {
         return GW == 8 ? lane >> 3 : (GW == 5 ? (lane * 52u) >> 8 : (lane * 43u) >> 8);
     }
-    // work-item words x, y: no flags, share class 0 (k = 1) or non-dyadic (depth replayed exactly anyway),
-    // length in range, and every 32-byte chunk of the read inside the seq array
+    // work-item words x, y: no flags (any depth share: it goes into the deficit row as a range, share_range), length in
+    // range, and every 32-byte chunk of the read inside the seq array
     __device__ static __forceinline__ bool ok(u32 ex, u32 ey, u64 seq_bytes) {
-        const u32 L = ey >> 24, kc = (ey >> 8) & 0xFFu;
+        const u32 L = ey >> 24;
         const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
-        return (ey & 0x00FF0000u) == 0 && (kc == 0 || kc == KCLASS_NONDYADIC) && L >= PLAIN_MIN_LEN && L <= MAXL &&
-               so + ((L + 31u) & ~31u) <= seq_bytes;
+        return (ey & 0x00FF0000u) == 0 && L >= PLAIN_MIN_LEN && L <= MAXL && so + ((L + 31u) & ~31u) <= seq_bytes;
     }
 };
 
@@ -194,7 +219,7 @@ struct PlainItem {  // per lane
     bool first;        // lane 0 of the group
     u32 L;
     bool plain, active;
-    bool nd;           // depth share is not a power of two: its positions are replayed by k_exact2
+    u32 kc, rec;       // depth-share class (0: share 1) and record index (the share of the rare class that looks its k up)
     bool notrim;       // the flank in front of a read's single indel: its end is not the read's end, nothing to trim
 };
 
@@ -212,7 +237,8 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, c
     it.rel = item_rel(ez);
     it.notrim = ((ez >> 30) & 1u) != 0;
     it.L = ey >> 24;
-    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.kc = (ey >> 8) & 0xFFu;
+    it.rec = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.w);
     it.plain = g < C::IPP && j < nb && (ez >> 31) == 0 && C::ok(ex, ey, seq_bytes);
     const u8 *rp = seq + ((u64)ex | ((u64)(ey & 0xFFu) << 32));
     const u32 mis = PP_PLAIN_ALIGNED ? (u32)((uintptr_t)rp & 31u) : 0u;
@@ -233,7 +259,7 @@ __device__ __forceinline__ PlainItem plain_fetch(const u8 *seq, u64 seq_bytes, c
     return it;
 }
 
-__device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *asm_w, const PlainItem &it, u32 lane) {
+__device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm_w, const PlainItem &it, u32 lane) {
     const int rel = it.rel;
     const u32 L = it.L;
 
@@ -256,13 +282,7 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const u32 *as
     if (live && it.first) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
-        if (it.nd) {  // mark [rel+lo, rel+hi) in the window's bitmap of order-dependent positions
-            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
-            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
-                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
-                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
-            }
-        }
+        share_range(cnt, ndbits, S, rel + lo, rel + hi, it.kc, it.rec);  // a depth share other than 1
     }
     // ---- compare this lane's 32 bases with the assembly; tally only the differing ones ----
     const int ib = it.ib;
@@ -353,8 +373,8 @@ struct PlainItem4 {  // per lane
     const u8 *rp;      // the read's bytes in seq (the rare trims that need them)
     int rel, ib;
     bool first;
-    u32 L;
-    bool plain, active, nd, notrim;
+    u32 L, kc, rec;
+    bool plain, active, notrim;
 };
 
 template <int GW>
@@ -371,7 +391,8 @@ __device__ __forceinline__ PlainItem4 plain_fetch4(const u8 *seq, const u8 *seq4
     it.rel = item_rel(ez);
     it.notrim = ((ez >> 30) & 1u) != 0;
     it.L = ey >> 24;
-    it.nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    it.kc = (ey >> 8) & 0xFFu;
+    it.rec = (u32)__builtin_amdgcn_ds_bpermute(src, (int)my.w);
     it.plain = g < C::IPP && j < nb && (ez >> 31) == 0 && C::ok(ex, ey, seq_bytes);
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
     it.rp = seq + so;
@@ -395,7 +416,7 @@ __device__ __forceinline__ PlainItem4 plain_fetch4(const u8 *seq, const u8 *seq4
     return it;
 }
 
-__device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const u32 *asm4, const PlainItem4 &it, u32 lane) {
+__device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const PlainItem4 &it, u32 lane) {
     const int rel = it.rel;
     const u32 L = it.L;
     int nkeep = trim4(it.tail, it.e, L);
@@ -406,13 +427,7 @@ __device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const u32 *a
     if (live && it.first) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
-        if (it.nd) {
-            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
-            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
-                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
-                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
-            }
-        }
+        share_range(cnt, ndbits, S, rel + lo, rel + hi, it.kc, it.rec);
     }
     const int ib = it.ib;
     const int b0 = min(max(lo - ib, 0), 32), b1 = min(max(hi - ib, 0), 32);
@@ -449,13 +464,13 @@ __device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const u32 *a
 // Lane l works on item l of the batch, straight from the batch registers (no ds_bpermute); its chunks are compared one
 // after the other against asm4 exactly as a lane of plain_apply4 compares its one.
 template <int NCH>
-__device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const u32 *asm4, const u8 *seq, const u8 *seq4, const uint4 &my,
-                                           bool mine) {
+__device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const u8 *seq, const u8 *seq4,
+                                           const uint4 &my, bool mine) {
     const u32 ex = my.x, ey = my.y, ez = my.z;
     const int rel = item_rel(ez);
     const bool notrim = ((ez >> 30) & 1u) != 0;
     const u32 L = ey >> 24;
-    const bool nd = ((ey >> 8) & 0xFFu) == KCLASS_NONDYADIC;
+    const u32 kc = (ey >> 8) & 0xFFu;
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
     const u8 *q = seq4 + (so >> 1);
     const bool odd = mine && ((u32)so & 1u) != 0;
@@ -492,13 +507,7 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const u32 *asm
     if (live) {
         atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
-        if (nd) {
-            const u32 a = (u32)(rel + lo), b = (u32)(rel + hi);
-            for (u32 wd = a >> 5; wd <= (b - 1u) >> 5; wd++) {
-                const u32 from = wd == (a >> 5) ? (a & 31u) : 0u, to = wd == ((b - 1u) >> 5) ? ((b - 1u) & 31u) : 31u;
-                atomicOr(&ndbits[wd], (0xFFFFFFFFu >> (31u - to)) & (0xFFFFFFFFu << from));
-            }
-        }
+        share_range(cnt, ndbits, S, rel + lo, rel + hi, kc, my.w);
     }
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -566,7 +575,8 @@ __device__ __forceinline__ u32 fast_load(const u8 *seq, const FastItem &f, u32 l
 // per kept base (reads whose depth share is not 1) or, for the bulk, two coverage-difference
 // atomics per read plus a 4-bases-at-a-time comparison against the assembly window in LDS, with
 // per-base atomics only where the read differs from the assembly.
-__device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const FastItem &f, u32 word, u32 lane) {
+__device__ __forceinline__ void fast_apply(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm_w, const FastItem &f, u32 rec,
+                                           u32 word, u32 lane) {
     if (!f.on) return;
     const u32 mis = f.mis;
     const int ib = (int)(4u * lane) - (int)mis;      // read index of this lane's byte 0
@@ -586,19 +596,10 @@ __device__ __forceinline__ void fast_apply(u32 *cnt, const u32 *asm_w, const Fas
     if (f.notrim) nkeep = (int)f.L;
     const int lo = max(0, -f.rel), hi = min(nkeep, TILE - f.rel);
     if (hi <= lo) return;
-    if (f.kc != 0) {
-        // byte order rotated by lane/8 so that the 32 lanes of an LDS group hit 32 different banks
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            const int b = (jj + (int)(lane >> 3)) & 3;
-            const int i = ib + b;
-            if (i >= lo && i < hi) tile_add(cnt, row_of((word >> (8 * b)) & 0xFFu), f.rel + i, f.kc);
-        }
-        return;
-    }
     if (lane == 0) {
         atomicAdd(&cnt[ROW_COV * TILE + f.rel + lo], 1u);
         if (f.rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + f.rel + hi], 0xFFFFFFFFu);
+        share_range(cnt, ndbits, S, f.rel + lo, f.rel + hi, f.kc, rec);
     }
     const int lowb = max(0, lo - ib), highb = min(4, hi - ib);
     if (lowb < highb) {
@@ -639,7 +640,7 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
 // item, where walking run by run with the runs in memory took eight or nine dependent ones (measured: 1 % of such
 // reads cost k_tile 0.09 of its 0.49 ms).
 __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int nkeep, u32 nc, u32 r0, u32 r1, u32 r2,
-                                           u32 r3, u32 kc, u32 lane) {
+                                           u32 r3, u32 lane) {
     constexpr int SRC_NONE = -1, SRC_DEL = -2, SRC_OTH = -3;
     int src[4] = {SRC_NONE, SRC_NONE, SRC_NONE, SRC_NONE};
     int ent0 = 0;
@@ -672,7 +673,7 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
     for (int t = 0; t < 4; t++) {
         if (src[t] == SRC_NONE) continue;
         const int row = src[t] >= 0 ? row_of(c[t]) : (src[t] == SRC_DEL ? ROW_DEL : ROW_OTH);
-        tile_add(cnt, row, rel + (int)lane + 64 * t, kc);
+        tile_add(cnt, row, rel + (int)lane + 64 * t);
     }
 }
 
@@ -681,8 +682,8 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
 // hidden by the other 7 waves of the SIMD, not by software pipelining of the passes (which measured slower).
 template <int GW, bool P4>
-__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const u32 *asm_w, const u32 *asm4, u32 e0,
-                                           u32 e1, u32 wave, u32 lane) {
+__device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const TileShare &S, const u32 *asm_w,
+                                           const u32 *asm4, u32 e0, u32 e1, u32 wave, u32 lane) {
     typedef PlainCfg<GW> C;
     // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
     constexpr bool WIDE = P4 && GW == 5;
@@ -709,17 +710,20 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         u32 sl_nc = 0;
         if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         if (WIDE) {
-            wide4_pass<GW>(cnt, s_ndbits, asm4, A.seq, A.seq4, my, my_plain);
+            wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain);
             if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
         } else for (u32 first = 0; first < nb; first += C::IPP) {
-            if (P4) plain_apply4(cnt, s_ndbits, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, my, nb, first, lane), lane);
-            else plain_apply(cnt, s_ndbits, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+            if (P4) plain_apply4(cnt, s_ndbits, S, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, my, nb, first, lane), lane);
+            else plain_apply(cnt, s_ndbits, S, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
         }
         // the entry AT a read's single indel (ENT_POINT): one tally, one item per lane -- the two-byte key of an
         // insertion is counted by string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
         if (my_point) {
             const int p = item_rel(my.z);
-            if (p >= 0 && p < TILE) tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, p, (my.y >> 8) & 0xFFu);
+            if (p >= 0 && p < TILE) {
+                tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, p);
+                share_range(cnt, s_ndbits, S, p, p + 1, (my.y >> 8) & 0xFFu, my.w);
+            }
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
         u64 rest = __ballot(lane < nb && !my_slow && !my_plain && !my_point);
@@ -727,7 +731,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             const u32 j = (u32)__ffsll((long long)rest) - 1u;
             rest &= rest - 1;
             const FastItem f = fast_fetch(my, j, nb, A.seq);
-            fast_apply(cnt, asm_w, f, fast_load(A.seq, f, lane), lane);
+            fast_apply(cnt, s_ndbits, S, asm_w, f, (u32)__builtin_amdgcn_readlane((int)my.w, (int)j), fast_load(A.seq, f, lane), lane);
         }
         u64 slow = __ballot(my_slow);
         if (slow) {
@@ -749,17 +753,22 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                 const u64 so = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)sl_so, j) |
                                ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(sl_so >> 32), j) << 32);
                 const u8 *s = A.seq + so;
+                {   // the item's depth share over the window positions its kept entries cover (entry q <-> position rel + q)
+                    const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
+                    const u32 recj = (u32)__builtin_amdgcn_readlane((int)my.w, j);
+                    if (lane == 0) share_range(cnt, s_ndbits, S, rel + lo, rel + hi, kc, recj);
+                }
                 if (!((ey >> 16) & ENT_COMPLEX)) {
                     // no indels, trim precomputed by k_prep (long read or contig overhang): entry i is base i
                     const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);
-                    for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i, kc);
+                    for (int i = lo + (int)lane; i < hi; i += 64) tile_add(cnt, row_of(s[i]), rel + i);
                     continue;
                 }
                 const u32 nc = (u32)__builtin_amdgcn_readlane((int)sl_nc, j);
                 if (nc <= 4u && nkeep <= 256) {
                     slow_short(cnt, s, rel, nkeep, nc, (u32)__builtin_amdgcn_readlane((int)rr0, j),
                                (u32)__builtin_amdgcn_readlane((int)rr1, j), (u32)__builtin_amdgcn_readlane((int)rr2, j),
-                               (u32)__builtin_amdgcn_readlane((int)rr3, j), kc, lane);
+                               (u32)__builtin_amdgcn_readlane((int)rr3, j), lane);
                     continue;
                 }
                 // many runs or a long read: run by run, with the runs read as they come
@@ -779,7 +788,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                         int row;
                         if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
                         else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
-                        tile_add(cnt, row, rel + q, kc);
+                        tile_add(cnt, row, rel + q);
                     }
                     ent0 += (int)len;
                     if (o != PP_OP_D) ro += len;
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty;
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty, s_shared;
     __shared__ unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below)
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         asm4[t] = v;
     }
-    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; }
+    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; }
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
         if (lane == 0) { if (wave == 0) s_c0 = cw; else s_c1 = cw; }
@@ -911,6 +920,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
 #endif
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk};  // (a heavy window's helpers: the same bits, their deficits add up)
     {
         u32 i0 = e0, i1 = e1;
         if (heavy) {  // this helper's share of the window's items
@@ -920,12 +930,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
         if (A.seq4) {
-            if (longest <= PlainCfg<5>::MAXL) tile_items<5, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
-            else if (longest <= PlainCfg<6>::MAXL) tile_items<6, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
-            else tile_items<8, true>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
-        } else if (longest <= PlainCfg<5>::MAXL) tile_items<5, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
-        else if (longest <= PlainCfg<6>::MAXL) tile_items<6, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
-        else tile_items<8, false>(A, cnt, s_ndbits, asm_w, asm4, i0, i1, wave, lane);
+            if (longest <= PlainCfg<5>::MAXL) tile_items<5, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+            else if (longest <= PlainCfg<6>::MAXL) tile_items<6, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+            else tile_items<8, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+        } else if (longest <= PlainCfg<5>::MAXL) tile_items<5, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+        else if (longest <= PlainCfg<6>::MAXL) tile_items<6, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+        else tile_items<8, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
     }
     if (e1 - e0 >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);
     __syncthreads();
@@ -970,14 +980,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
 #pragma unroll
             for (u32 q = 0; q < HEAVY_PARTS; q++)  // all parts' loads in flight (this part's own tallies are there as well)
                 o[q] = __hip_atomic_load(&base[(u64)q * HSLAB_WORDS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u32 sum = 0, top = 0;
-            const bool def_row = i / (u32)TILE == (u32)ROW_DEF;
+            u32 sum = 0;
 #pragma unroll
-            for (u32 q = 0; q < HEAVY_PARTS; q++) {
-                sum += def_row ? (o[q] & 0x7FFFFFFFu) : o[q];
-                top |= o[q];
-            }
-            cnt[i] = def_row ? ((sum & 0x7FFFFFFFu) | (top & 0x80000000u)) : sum;
+            for (u32 q = 0; q < HEAVY_PARTS; q++) sum += o[q];  // (the deficit row holds differences: they add up like counts)
+            cnt[i] = sum;
+            if (sum && i / (u32)TILE == (u32)ROW_DEF) s_shared = 1u;  // some part saw a depth share other than 1
         }
         if (tid < (u32)(TILE / 32)) {
             u32 bits = 0;
@@ -989,10 +996,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         __syncthreads();
     }
 
-    // ---- coverage of the fast class: prefix sum of the difference array, in place ----
-    {
-        u32 *cov = cnt + ROW_COV * TILE;
-        const u32 d0 = cov[2 * tid], d1 = cov[2 * tid + 1];
+    // ---- coverage of the fast class, and the depth deficits: prefix sums of the two difference arrays, in place ----
+    auto scan_row = [&](u32 *row) {
+        const u32 d0 = row[2 * tid], d1 = row[2 * tid + 1];
         const u32 sum = d0 + d1;
         u32 inc = sum;
         for (int o = 1; o < 64; o <<= 1) {
@@ -1004,10 +1010,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         u32 base = 0;
         for (u32 i = 0; i < wave; i++) base += s_wsum[i];
         const u32 ex = base + inc - sum;
-        cov[2 * tid] = ex + d0;
-        cov[2 * tid + 1] = ex + d0 + d1;
-    }
-    __syncthreads();
+        row[2 * tid] = ex + d0;
+        row[2 * tid + 1] = ex + d0 + d1;
+        __syncthreads();
+    };
+    scan_row(cnt + ROW_COV * TILE);
+    if (s_shared) scan_row(cnt + ROW_DEF * TILE);  // (uniform: written before the barrier in front of this)
 
     // ---- vote ----
     // Pass 1, one lane per position: a position where NOTHING was tallied explicitly -- every read that covers it shows
@@ -1065,37 +1073,58 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         const u32 p = s_dirty[di];
         const u64 gp = w0 + p;
         u32 nA, nC, nG, nT, nDel, nOth;
-        const u32 defw = cnt[ROW_DEF * TILE + p];
+        const u32 deficit = cnt[ROW_DEF * TILE + p];  // in units of 2^-S.b (prefix-summed above)
         const u8 orig = ((const u8 *)asm_w)[ASM_PAD + p];
         position_tallies(cnt, orig, p, nA, nC, nG, nT, nDel, nOth);
-        const bool nd = (defw >> 31) != 0 || ((s_ndbits[p >> 5] >> (p & 31u)) & 1u) != 0;
-        const u32 deficit = defw & 0x7FFFFFFFu;
+        const bool nd = ((s_ndbits[p >> 5] >> (p & 31u)) & 1u) != 0;  // some share here is not a multiple of the unit
         const u32 ntot = nA + nC + nG + nT + nDel + nOth;
         if (orig >= 0x80u) report(A.status, gp, DE_NON_ASCII);
-        const u64 dfx = ((u64)ntot << DEPTH_FX_BITS) - deficit;
-        const double depth = (double)dfx * (1.0 / (double)(1u << DEPTH_FX_BITS));  // exact
-        bool flag = false;
+        const u64 dfx_b = ((u64)ntot << S.b) - deficit;
+        const double depth = (double)dfx_b * (1.0 / (double)(1u << S.b));  // exact unless nd
+        const u64 dfx = dfx_b << ((u32)DEPTH_FX_BITS - S.b);               // the same in the statistics' unit
+        bool flag = false, for_keys = false, decided = true, low;
+        u32 vthr, ithr;
         VoteOut v;
         v.out = (orig == (u8)'-') ? 0 : orig;
         v.status = PP_ST_LOW_DEPTH;
         v.vthr = 0; v.ithr = 0;
         if (nd) {
-            // depth is an order-dependent f64 sum: exact only in the replay kernels.  depth <= ntot always, so
-            // ntot < min_depth already decides DepthTooLow -- but the depth itself feeds the contig's mean read
-            // depth (polish.rs:173-180), and the integer tallies would count every 1/k share as 1: replay those too.
-            if (ntot > 0 || A.dbg) flag = true;
+            // The depth is an order-dependent f64 sum (pileup.rs:64: depth += 1.0 / k, in file order) that the fixed-point
+            // tally only BOUNDS: every inexact share is off by at most half a unit, the f64 sum itself by < 1e-9.  The vote
+            // looks at the depth through three monotone step functions -- bankers_rounding(depth * fraction_valid),
+            // bankers_rounding(depth * fraction_invalid), depth < min_depth (pileup.rs:70-72,114) -- so where both ends of
+            // the interval give the same three values every depth inside it does, and the position is decided here with
+            // those.  Only where a step falls inside the interval (a few positions in 10^5), and wherever the depth itself
+            // is printed (--debug), is the position replayed in file order.
+            if (A.dbg == 1 || A.dbg == 2) decided = false;
+            else {
+                const double eps = (double)ntot * (0.5 / (double)(1u << S.b)) + 1e-9;
+                const double lo = fmax(depth - eps, 0.0), hi = depth + eps;
+                const u32 v0 = d_bankers(__dmul_rn(lo, A.fv)), v1 = d_bankers(__dmul_rn(hi, A.fv));
+                const u32 i0 = d_bankers(__dmul_rn(lo, A.fi)), i1 = d_bankers(__dmul_rn(hi, A.fi));
+                const bool l0 = lo < (double)A.min_depth, l1 = hi < (double)A.min_depth;
+                decided = v0 == v1 && i0 == i1 && l0 == l1;
+                vthr = max(A.min_depth, v0); ithr = i0; low = l0;
+            }
+            // (depth <= ntot always, so ntot < min_depth would decide DepthTooLow -- but the depth itself feeds the contig's
+            // mean read depth, polish.rs:173-180: an undecided position is replayed whenever anything covers it)
+            if (!decided && (ntot > 0 || A.dbg)) flag = true;
         } else {
-            const u32 ithr = d_bankers(__dmul_rn(depth, A.fi));
-            if (!(depth < (double)A.min_depth) && nOth > 0 && nOth >= ithr) flag = true;
-            else v = vote5(nA, nC, nG, nT, nDel, depth, orig, A.min_depth, A.fv, A.fi);
+            vthr = max(A.min_depth, d_bankers(__dmul_rn(depth, A.fv)));
+            ithr = d_bankers(__dmul_rn(depth, A.fi));
+            low = depth < (double)A.min_depth;
         }
-        if (A.dbg && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
+        if (decided) {
+            if (!low && nOth > 0 && nOth >= ithr) { flag = true; for_keys = true; }  // a string-keyed tally could reach a threshold
+            else v = vote5_thr(nA, nC, nG, nT, nDel, vthr, ithr, low, orig);
+        }
+        if ((A.dbg == 1 || A.dbg == 2) && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
             // dbg 2: test hook, see run_pipeline; a listed heavy window is replayed by k_exact2's sub-range instance.
             // A position that is only here for its string-keyed tallies (an insertion that may win: its depth is exact
             // already) goes straight to the list of k_exact's wave-per-position replay -- k_exact2 would sort the whole
             // window for the ordered depth it does not need, and then hand it over all the same.
-            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy) || !nd;
+            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy) || !nd || for_keys;
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);

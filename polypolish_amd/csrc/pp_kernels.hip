@@ -632,7 +632,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.seq = B.seq; T.seq_off = (const u64 *)B.seq_off; T.cig_off = (const u64 *)B.cig_off;
     static const bool no_seq4 = getenv("PP_SEQ4") && atoi(getenv("PP_SEQ4")) == 0;  // tuning / tests: ignore a batch's 4-bit mirror
     T.seq4 = no_seq4 ? nullptr : B.seq4;
-    T.n_cig = B.n_cig; T.cigar = B.cigar;
+    T.n_cig = B.n_cig; T.cigar = B.cigar; T.kk = B.k;
     T.bases = d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
     T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
@@ -653,7 +653,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // PP_DEBUG_REPLAY2=1 (tests): per-position records while order-dependent positions still go through k_exact2,
     // so that its f64 depths can be compared bit for bit (the key records of the TSV are then incomplete)
     static const bool dbg_replay2 = getenv("PP_DEBUG_REPLAY2") && atoi(getenv("PP_DEBUG_REPLAY2")) != 0;
-    T.dbg = ctx->debug ? (dbg_replay2 ? 2 : 1) : 0;
+    // debug_level 3 (tests: pp_polish_set_debug(ctx, 3)): per-position records of what k_tile itself decides -- positions with
+    // inexact depth shares that its interval test settles are NOT sent to the replay, their record holds the thresholds and
+    // the status as voted and the fixed-point depth (within the interval of the exact one)
+    T.dbg = ctx->debug ? (ctx->debug_level == 3 ? 3 : (dbg_replay2 ? 2 : 1)) : 0;
     const uint32_t per = (n_own_win + 7) / 8;  // windows to work on, dealt to the eight XCDs in stretches
     timer_begin(ctx, "tile");
 #ifdef PP_TILE_STAMPS
@@ -869,6 +872,7 @@ extern "C" const uint8_t *pp_polish_result_device(pp_ctx *ctx) {
 extern "C" int pp_polish_set_debug(pp_ctx *ctx, int enable) {
     if (!ctx) return PP_ERR_ARG;
     ctx->debug = enable != 0;
+    ctx->debug_level = enable;
     return PP_OK;
 }
 

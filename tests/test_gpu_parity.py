@@ -109,6 +109,23 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         assert m["polished"] == want["polished"]
         m = _polish_device_batch(ctx, pp, contig_off, bases, recs, False, positions=False, **kw)
         assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
+        # What the pileup kernel decides BY ITSELF (debug level 3): a position with depth shares that are not a multiple of
+        # the window's fixed-point unit is voted from the interval its depth is known to lie in, and only replayed in
+        # file order where a step of the vote (pileup.rs:70-72,114) falls inside it.  Tallies, both thresholds and the
+        # status must be the oracle's at EVERY position; the depth of the positions decided that way is the fixed-point
+        # one, within reads * 2^-11 of the exact sum (a window's unit is 2^-10 at the coarsest).
+        for mirror in (True, False):
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, mirror, positions=3, **kw)
+            for k in POS_KEYS:
+                if k == "depth":
+                    continue
+                bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
+                assert len(bad) == 0, ("interval", mirror, k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
+            p = want["positions"]
+            reads = (p["count_a"].astype(np.int64) + p["count_c"] + p["count_g"] + p["count_t"] + p["count_other"]).astype(np.float64)
+            err = np.abs(m["positions"]["depth"] - p["depth"])
+            assert (err <= reads * 2.0 ** -11 + 1e-9).all(), ("interval depth", mirror, float(err.max()))
+            assert m["polished"] == want["polished"]
     return want, got
 
 
@@ -142,6 +159,17 @@ def test_polish_records_parity(ctx, orc, name):
     if name in ("plain_k1", "indels"):
         assert (want["positions"]["status"] == 1).sum() > 0
     _compare_records(ctx, orc, contig_off, bases, recs, min_depth=1, fraction_valid=0.6, fraction_invalid=0.05)
+    if name in ("nondyadic_k", "all_k3", "big_k"):
+        # nearly every position of these jobs has an order-dependent depth: the interval test must settle almost all of
+        # them in k_tile (until round 4 every one of them was replayed in file order)
+        ctx.set_profiling(1)
+        try:
+            ctx.polish_records(contig_off, bases, recs)
+            replayed = ctx.kernel_times()["n_flagged"]
+        finally:
+            ctx.set_profiling(0)
+        odd = np.isin(recs["k"], (3, 5, 6, 7, 1000, 2048, 4096)).sum()
+        assert odd > 0 and replayed < 0.03 * int(contig_off[-1]), (name, replayed, int(contig_off[-1]))
 
 
 @pytest.mark.parametrize("read_len", [12, 31, 33, 160, 161, 192, 193, 250, 252, 253])
