@@ -159,6 +159,9 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
     }
 }
 
+#ifndef PP_FILL_NT
+#define PP_FILL_NT 0
+#endif
 template <int CW>
 __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
                                                const u32 *__restrict__ nkeep,
@@ -235,7 +238,14 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                           ((w % (u32)CW) << 18);
                     e.z = ((u32)(int)((long long)g - (long long)w * TILE) & 0x3FFFFFFFu) | (zf << 30);
                     e.w = (u32)a;
+#if PP_FILL_NT
+                    // (experiment) streaming store: the 16-byte items land all over the window buckets, a line is rarely
+                    // completed while it is in the L2
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((v4u){e.x, e.y, e.z, e.w}, (v4u *)&entB[slot]);
+#else
                     entB[slot] = e;
+#endif
                 }
             });
         }

@@ -28,6 +28,8 @@ struct TileArgs {
     u32 *win_len;
     u32 *counters;  // [0] positions on the global replay list, [1] n_multi, [2] all flagged positions
     u32 cap_flag;
+    MultiEnt *multi;  // positions whose polished string has two or more bytes (counters[1] of them; k_exact adds its own)
+    u32 cap_multi;
     u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
     u32 *win_nflag;   // per window: number of flagged positions
     u32 *win_slab;    // per window: index of its tally slab (6 x 2048 u32), or ~0
@@ -61,6 +63,7 @@ struct TileShare {
     u32 b;            // win_fx_bits of the window
     u32 *any_shared;  // LDS flag
     const u32 *kk;
+    u32 *pt, *pt_over;  // the window's table of two-byte keys (pt_insert) and its overflow flag
 };
 
 // The depth share of ONE work item of class kc != 0 over the window positions [p0, p1) it covers (every entry of an
@@ -85,6 +88,33 @@ __device__ __forceinline__ void share_range(u32 *cnt, u32 *ndbits, const TileSha
 }
 
 __device__ __forceinline__ void tile_add(u32 *cnt, int row, int p) { atomicAdd(&cnt[row * TILE + p], 1u); }
+
+// ---- the two-byte keys of the window, tallied by string ---------------------------------------------------------------
+// An assembly that lacks a base makes every read over that spot vote for a two-byte key there (alignment.rs:175-201: the I
+// run extends the entry before it; pileup.rs:56-63 counts it by string) -- the sites polishing is about, and all of their
+// ~200 items are ENT_POINT items.  Their keys are tallied in a small LDS hash table, (position, two bytes) -> count and
+// where the bytes stand in the seq array, so that such a position is voted right here like any other instead of being
+// listed for k_exact (a workgroup per position that scans the window's items again: 0.05 ms per job for 167 sites).
+// Whatever else lands in the position's string-keyed row -- N, longer insertions, the same key from a read that took the
+// slow class -- is not in the table: the vote notices (the table's counts do not add up to the row) and lists the position
+// as before.  Entry: tag = 1 << 31 | position << 16 | bytes; count in bits 0..23 of the second word, bits 32..39 of the
+// offset above them; the offset's low word.
+constexpr u32 PT_SLOTS = 20;
+__device__ __forceinline__ void pt_insert(u32 *pt, u32 *over, int p, const u8 *seq, u64 so) {
+    const u32 tag = 0x80000000u | ((u32)p << 16) | (u32)seq[so] | ((u32)seq[so + 1] << 8);
+    u32 h = ((tag * 2654435761u) >> 16) % PT_SLOTS;
+    for (u32 t = 0; t < PT_SLOTS; t++) {
+        const u32 old = atomicCAS(&pt[3 * h], 0u, tag);
+        if (old == 0u) {
+            pt[3 * h + 2] = (u32)so;
+            atomicAdd(&pt[3 * h + 1], 1u | ((u32)(so >> 32) << 24));
+            return;
+        }
+        if (old == tag) { atomicAdd(&pt[3 * h + 1], 1u); return; }
+        h = h + 1u == PT_SLOTS ? 0u : h + 1u;
+    }
+    *over = 1u;  // more distinct keys than the table holds: the window's string-keyed positions are listed as before
+}
 
 __device__ __forceinline__ u32 find_contig(const u64 *contig_off, u32 n_contigs, u64 p) {
     u32 lo = 0, hi = n_contigs;  // contig_off[lo] <= p < contig_off[hi]
@@ -723,6 +753,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             if (p >= 0 && p < TILE) {
                 tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, p);
                 share_range(cnt, s_ndbits, S, p, p + 1, (my.y >> 8) & 0xFFu, my.w);
+                if ((my.y >> 24) == 2u) pt_insert(S.pt, S.pt_over, p, A.seq, (u64)my.x | ((u64)(my.y & 0xFFu) << 32));
             }
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
@@ -810,6 +841,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     __shared__ unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below)
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
+    __shared__ u32 s_pt[PT_SLOTS * 3], s_ptover;
 
     // The first HEAVY_BLOCKS blocks are helpers: block HEAVY_PARTS * slot + part tallies one part of the items of the
     // heavy window in that slot of the list.  They are dispatched first, so the longest windows start at time zero, and
@@ -909,7 +941,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         }
         asm4[t] = v;
     }
-    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; }
+    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; }
+    if (tid >= 64u && tid < 64u + PT_SLOTS * 3u) s_pt[tid - 64u] = 0;  // (a heavy window's helpers would each have their own table: listed as before)
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
         if (lane == 0) { if (wave == 0) s_c0 = cw; else s_c1 = cw; }
@@ -920,7 +953,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
 #endif
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk};  // (a heavy window's helpers: the same bits, their deficits add up)
+    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk, s_pt, &s_ptover};  // (a heavy window's helpers: the same bits, their deficits add up)
     {
         u32 i0 = e0, i1 = e1;
         if (heavy) {  // this helper's share of the window's items
@@ -1094,8 +1127,12 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             // looks at the depth through three monotone step functions -- bankers_rounding(depth * fraction_valid),
             // bankers_rounding(depth * fraction_invalid), depth < min_depth (pileup.rs:70-72,114) -- so where both ends of
             // the interval give the same three values every depth inside it does, and the position is decided here with
-            // those.  Only where a step falls inside the interval (a few positions in 10^5), and wherever the depth itself
-            // is printed (--debug), is the position replayed in file order.
+            // those.  Where ONE of the three differs between the ends, by one step, the exact depth gives one of the two
+            // sets of values: if the vote comes out the same with both (no tally sits exactly on the threshold that
+            // moved -- shares like 1/3 put depth * fraction on an exact .5 at one position in six, where the order of the
+            // additions decides the rounding, but a tally on that very threshold is rare) it is decided as well.  Only
+            // the rest (a few positions in 10^4), and wherever the depth itself is printed (--debug), is replayed in file
+            // order.  (debug level 3 records the thresholds it voted with: there the strict rule only.)
             if (A.dbg == 1 || A.dbg == 2) decided = false;
             else {
                 const double eps = (double)ntot * (0.5 / (double)(1u << S.b)) + 1e-9;
@@ -1103,8 +1140,17 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
                 const u32 v0 = d_bankers(__dmul_rn(lo, A.fv)), v1 = d_bankers(__dmul_rn(hi, A.fv));
                 const u32 i0 = d_bankers(__dmul_rn(lo, A.fi)), i1 = d_bankers(__dmul_rn(hi, A.fi));
                 const bool l0 = lo < (double)A.min_depth, l1 = hi < (double)A.min_depth;
-                decided = v0 == v1 && i0 == i1 && l0 == l1;
+                const u32 ndiff = (u32)(v0 != v1) + (u32)(i0 != i1) + (u32)(l0 != l1);
                 vthr = max(A.min_depth, v0); ithr = i0; low = l0;
+                decided = ndiff == 0;
+                if (ndiff == 1 && A.dbg == 0 && v1 - v0 <= 1u && i1 - i0 <= 1u) {
+                    const bool keys0 = !l0 && nOth > 0 && nOth >= i0, keys1 = !l1 && nOth > 0 && nOth >= i1;
+                    if (!keys0 && !keys1) {
+                        const VoteOut va = vote5_thr(nA, nC, nG, nT, nDel, vthr, ithr, low, orig);
+                        const VoteOut vb = vote5_thr(nA, nC, nG, nT, nDel, max(A.min_depth, v1), i1, l1, orig);
+                        decided = va.out == vb.out && va.status == vb.status;
+                    }
+                }
             }
             // (depth <= ntot always, so ntot < min_depth would decide DepthTooLow -- but the depth itself feeds the contig's
             // mean read depth, polish.rs:173-180: an undecided position is replayed whenever anything covers it)
@@ -1114,9 +1160,67 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             ithr = d_bankers(__dmul_rn(depth, A.fi));
             low = depth < (double)A.min_depth;
         }
+        u32 multi_eff = 0;   // > 0: a two-byte key won and leaves this many bytes (polish.rs:188 drops '-')
+        u64 multi_off = 0;
         if (decided) {
-            if (!low && nOth > 0 && nOth >= ithr) { flag = true; for_keys = true; }  // a string-keyed tally could reach a threshold
-            else v = vote5_thr(nA, nC, nG, nT, nDel, vthr, ithr, low, orig);
+            if (!low && nOth > 0 && nOth >= ithr) {
+                // A string-keyed tally could reach a threshold.  If the window's table of two-byte keys accounts for the whole
+                // string-keyed row of this position, the vote of pileup.rs:77-134 runs here over A C G T, "-" and those keys
+                // (when exactly one key is valid it wins whatever the order of the keys, otherwise nothing changes);
+                // else the position is listed for k_exact.
+                u32 n_tab = 0;
+                const bool table_ok = !s_ptover && A.dbg != 1 && A.dbg != 2;
+                if (table_ok)
+                    for (u32 t = 0; t < PT_SLOTS; t++) {
+                        const u32 tag = s_pt[3 * t];
+                        if (tag && ((tag >> 16) & 0x7FFFu) == p) n_tab += s_pt[3 * t + 1] & 0xFFFFFFu;
+                    }
+                if (table_ok && n_tab == nOth) {
+                    int nv = 0, ni = 0;
+                    u8 win = 0;
+                    u32 win_t = 0xFFFFFFFFu;
+                    const u32 c5[5] = {nA, nC, nG, nT, nDel};
+                    const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        if (j == 4 && nDel == 0) break;
+                        if (c5[j] >= vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= ithr) ni++;
+                    }
+                    for (u32 t = 0; t < PT_SLOTS; t++) {
+                        const u32 tag = s_pt[3 * t];
+                        if (!tag || ((tag >> 16) & 0x7FFFu) != p) continue;
+                        const u32 c = s_pt[3 * t + 1] & 0xFFFFFFu;
+                        if (c >= vthr) { if (!nv) win_t = t; nv++; } else if (c >= ithr) ni++;
+                    }
+                    v.vthr = vthr; v.ithr = ithr;
+                    v.out = (orig == (u8)'-') ? 0 : orig;
+                    v.status = PP_ST_KEPT;
+                    if (nv == 1) {
+                        if (ni > 0) v.status = PP_ST_TOO_CLOSE;
+                        else if (win_t == 0xFFFFFFFFu) {
+                            v.out = (win == (u8)'-') ? 0 : win;
+                            if (win != orig) v.status = PP_ST_CHANGED;
+                        } else {
+                            v.status = PP_ST_CHANGED;  // a two-byte string is never the original base
+                            const u32 tag = s_pt[3 * win_t];
+                            const u8 b0 = (u8)(tag & 0xFFu), b1 = (u8)((tag >> 8) & 0xFFu);
+                            const u32 eff = (u32)(b0 != (u8)'-') + (u32)(b1 != (u8)'-');
+                            const u8 only = b1 != (u8)'-' ? b1 : b0;
+                            if (eff == 0) v.out = 0;
+                            else if (eff == 1 && only < 0x80u) v.out = only;
+                            else {
+                                multi_eff = eff;
+                                multi_off = (u64)s_pt[3 * win_t + 2] | ((u64)(s_pt[3 * win_t + 1] >> 24) << 32);
+                            }
+                        }
+                    } else {
+                        v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+                    }
+                } else {
+                    flag = true;
+                    for_keys = true;
+                }
+            } else v = vote5_thr(nA, nC, nG, nT, nDel, vthr, ithr, low, orig);
         }
         if ((A.dbg == 1 || A.dbg == 2) && nDel + nOth > 0) flag = true;  // --debug lists every key: k_exact writes the records
         if (flag) {
@@ -1146,8 +1250,20 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             A.code[gp] = 0;
             continue;
         }
-        A.code[gp] = v.out;
-        const u32 l = v.out ? 1u : 0u, ch = (v.status == PP_ST_CHANGED), z = (ntot == 0);
+        u32 l = v.out ? 1u : 0u;
+        if (multi_eff) {  // the winner has two bytes: k_emit takes them from the seq array (as for k_exact's multi-byte winners)
+            l = multi_eff;
+            A.code[gp] = (u8)(0x80u | multi_eff);
+            const u32 slot = atomicAdd(&A.counters[1], 1u);
+            if (slot < A.cap_multi) {
+                MultiEnt m;
+                m.off = multi_off; m.pos = (u32)gp; m.len = 2u; m.eff = multi_eff; m.pad = 0;
+                A.multi[slot] = m;
+            } else {
+                report(A.status, slot, DE_CAPACITY_LATE);
+            }
+        } else A.code[gp] = v.out;
+        const u32 ch = (v.status == PP_ST_CHANGED), z = (ntot == 0);
         if (one_contig) {
             my_len += l; my_changed += ch; my_zero += z; my_depth += dfx;
         } else {

@@ -637,6 +637,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
     T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
+    T.multi = (MultiEnt *)ctx->b_multi.p; T.cap_multi = (u32)ctx->cap_multi;
     T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
     T.win_slab = (u32 *)ctx->b_win_slab.p; T.slab_win = (u32 *)ctx->b_slab_win.p; T.slabs = (u32 *)ctx->b_slabs.p; T.cap_slabs = (u32)ctx->cap_slabs;

@@ -169,6 +169,8 @@ def test_polish_records_parity(ctx, orc, name):
         finally:
             ctx.set_profiling(0)
         odd = np.isin(recs["k"], (3, 5, 6, 7, 1000, 2048, 4096)).sum()
+        # (with k = 3 for every read depth * 0.5 = reads / 6 is an exact .5 at one position in six: there the order of the
+        # additions decides the rounding -- but the vote only depends on it where a tally sits exactly on that threshold)
         assert odd > 0 and replayed < 0.03 * int(contig_off[-1]), (name, replayed, int(contig_off[-1]))
 
 

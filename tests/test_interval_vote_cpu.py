@@ -53,6 +53,11 @@ def test_decided_positions_get_the_exact_thresholds():
             for k in ks[perm]:
                 depth += 1.0 / float(k)
             assert lo <= depth <= hi, (b, n, D, depth)
+            exact = (int(bankers(np.float64(depth) * fv)), int(bankers(np.float64(depth) * fi)), depth < min_depth)
             if decided:
-                assert (int(bankers(np.float64(depth) * fv)), int(bankers(np.float64(depth) * fi)), depth < min_depth) == t[0]
+                assert exact == t[0]
+            elif sum(a != c for a, c in zip(t[0], t[1])) == 1 and t[1][0] - t[0][0] <= 1 and t[1][1] - t[0][1] <= 1:
+                # one of the three moved by one step between the ends: the exact depth gives one end's values or the other's
+                # (the kernel then votes with both and only replays the position if the two votes differ)
+                assert exact in (t[0], t[1]), (exact, t)
     assert undecided < 0.25 * n_pos   # (b = 10 with hundreds of inexact reads leaves a wide interval; b >= 19 almost none)
