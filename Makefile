@@ -33,9 +33,9 @@ $(OUT)/pp_kernels.o: HIPFLAGS += $(KFLAGS)
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -lpthread -ldl
 
-bin/polypolish: $(CSRC)/pp_cli.cpp $(LIB)
+bin/polypolish: $(CSRC)/pp_cli.cpp $(CSRC)/pp_host.h $(LIB)
 	@mkdir -p bin
-	$(HIPCC) -O2 -std=c++17 -Iinclude -x c++ $(CSRC)/pp_cli.cpp -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
+	$(HIPCC) -O2 -std=c++17 -Iinclude -I$(CSRC) -x c++ $(CSRC)/pp_cli.cpp -o $@ -L$(OUT) -lpolypolish_hip -Wl,-rpath,'$$ORIGIN/../$(OUT)'
 
 # strict C99: the header is a C header, and nothing but the C ABI is needed on the caller's side
 bin/polish_min: examples/polish_min.c include/polypolish_hip.h $(LIB)

@@ -239,6 +239,12 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                                          "parity": sha(r_host.stdout) == want}
         out["oracle_polish"] = {"wall_s": round(t_cpu, 2), "mbp_per_s": round(genome / 1e6 / t_cpu, 4), "cores": 1,
                                 "sha256": want[:16]}
+        # where the default command's wall time goes: its own stage lines (PP_TIMING=1: seconds since the process started;
+        # the tokenizer's stages end in a stream synchronisation each, so this run is a little slower than the timed one)
+        t_st, r_st = _timed([exe, "polish", fa] + sams, dict(env, PP_DEVICE_INGEST="1", PP_TIMING="1"))
+        if t_st is not None:
+            out["polish_stages"] = {"wall_s": round(t_st, 3),
+                                    "lines": [l for l in r_st.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]")]}
         out["speedup_polish"] = round(t_cpu / min(t for t in (t_dev, t_host) if t is not None), 1)
         if not big:
             # What the default SEQ layout costs the tokenizer, read off its own stage timers (PP_TIMING=1: a synchronisation

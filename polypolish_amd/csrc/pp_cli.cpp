@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "polypolish_hip.h"
+#include "pp_host.h"
 
 static const char *HELP =
     "Polypolish (MI355X/gfx950 implementation, parity target v0.6.1)\n"
@@ -173,6 +174,7 @@ static int no_device(int device) {
 // runtime and unmapping gigabytes of parsed input page by page (the kernel reclaims both at exit).
 static int finish(int code) {
     fflush(stdout);
+    if (getenv("PP_TIMING")) fprintf(stderr, "[timing] %-36s %8s    (process %7.3f s)\n", "output written, leaving", "", pph::seconds_since_process_start());
     fflush(stderr);
     _exit(code);
 }

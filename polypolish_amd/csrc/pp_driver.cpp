@@ -327,10 +327,12 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     else log("  not logging debugging information\n\n");
 
     const bool timing = getenv("PP_TIMING") != nullptr;
+    // PP_TIMING=1: "[timing] <stage>  <seconds since the driver was entered>  (<seconds since the process started>)"
     auto lap = [&](const char *what) {
-        if (timing) fprintf(stderr, "[timing] %-28s %8.3f s\n", what,
-                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        if (timing) fprintf(stderr, "[timing] %-36s %8.3f s  (process %7.3f s)\n", what,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), pph::seconds_since_process_start());
     };
+    lap("driver entered");
     // load_assembly, polish.rs:93-106
     log("Loading assembly\n");
     pp_assembly *a = nullptr;
@@ -411,6 +413,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         if (largest) rc = pp_dev_ingest_reserve_text_(dg, largest);
         if (rc == PP_OK && n_sams > 1) rc = pp_dev_ingest_expect(dg, total);  // the batch's arrays sized once, for all the files
     }
+    if (dev_ingest) lap("device ready, tokenizer created");  // (pp_dev_ingest_create waits for the HIP runtime's start-up)
     uint64_t alignment_total = 0, used_total = 0;
     // sharded: the records of file i's slice on context s are records [slice_end[i-1][s], slice_end[i][s]) of its batch
     std::vector<std::vector<uint64_t>> slice_end;
@@ -526,6 +529,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             }
         }
         log("%s: %s alignments from %s reads\n", sams[i], commas(c.alignments).c_str(), commas(c.reads).c_str());
+        if (timing) { char what[64]; snprintf(what, sizeof what, "file %d ingested", i + 1); lap(what); }
         alignment_total += c.alignments;
         used_total += c.used;
     }
@@ -794,6 +798,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     }
     fasta->data = out;
     fasta->len = w;
+    lap("FASTA assembled");
 
     // finished_message, polish.rs:76-90
     log("Finished!\nPolished sequence (to stdout):\n");

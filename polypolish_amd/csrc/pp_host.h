@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <string>
@@ -70,6 +71,30 @@ void parallel_for(size_t n, unsigned threads, F f) {
         if (lo < hi) pool.emplace_back([=] { f(lo, hi, t); });
     }
     for (auto &th : pool) th.join();
+}
+
+// seconds since this process was started (its start time in /proc/self/stat against CLOCK_BOOTTIME; 10 ms resolution):
+// what a PP_TIMING line of a command driver counts from -- exec, dynamic linking and the HIP runtime's start-up included
+inline double seconds_since_process_start() {
+    static const double started = [] {
+        double st = -1.0;
+        if (FILE *f = fopen("/proc/self/stat", "r")) {
+            char buf[1024];
+            const size_t n = fread(buf, 1, sizeof buf - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            if (const char *p = strrchr(buf, ')')) {  // fields after the command name: state is the 3rd, starttime the 22nd
+                int field = 2;
+                for (p++; *p && field < 21; p++)
+                    if (*p == ' ') field++;
+                if (field == 21) st = strtod(p, nullptr) / (double)sysconf(_SC_CLK_TCK);
+            }
+        }
+        return st;
+    }();
+    struct timespec ts;
+    if (started < 0 || clock_gettime(CLOCK_BOOTTIME, &ts) != 0) return -1.0;
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec - started;
 }
 
 // PP_INGEST_THREADS, else one thread per 4 MiB of text up to min(cores, 64)

@@ -641,7 +641,10 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
     pp_sam_counts c{0, 0, 0};
     if (counts) *counts = c;
     pph::FileText F;
+    const auto t_open = std::chrono::steady_clock::now();
     if (!F.open_file(path)) return ctx->fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
+    if (getenv("PP_TIMING"))
+        fprintf(stderr, "[timing]   tokenizer: %-20s %.4f s  (%.2f GB)\n", "mapping ready", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(), 1e-9 * (double)F.size);
     return ingest_text(D, path, F.text, F.size, false, pass, n_pass, counts);
 }
 

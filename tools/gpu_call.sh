@@ -24,7 +24,7 @@ for s in "$@"; do
         @bench:*) cmd="python bench.py ${s#@bench:} > $out/bench_$n.json" ;;
         *) cmd="$s" ;;
     esac
-    script+=" ( timeout $step_timeout bash -c $(printf %q "$cmd") ) > $out/$n.log 2>&1; echo \"$n rc=\$? $(printf %q "$s" | cut -c1-120)\" >> $out/status.txt;"
+    script+=" ( timeout $step_timeout bash -c $(printf %q "$cmd") ) > $out/$n.log 2>&1; echo \"$n rc=\$? $(printf %s "$s" | tr -c 'A-Za-z0-9_.,:=@/+-' ' ' | cut -c1-110)\" >> $out/status.txt;"
 done
 script+=" cat $out/status.txt"
 exec /usr/local/graft/bin/gpurun --timeout "$total" -- "$script"
