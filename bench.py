@@ -319,6 +319,39 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
     return out
 
 
+def _error_line(world, args, msg):
+    """The contract's JSON line when the run cannot produce a value (a communicator that does not come up, a collective that
+    hangs): the driver gets a parseable record with an "error" field instead of a silent hang or a traceback."""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.config in (3, 4) and world > 1 else "weak",
+                       "vs_baseline": None, "dtype": "u8/u32 counts + f64 depth", "data": "synthetic",
+                       "config": {"workload": f"configs[{args.config}]"}, "error": msg})
+
+
+class _Watchdog:
+    """A collective that hangs (one rank gone, a fabric problem) cannot be caught: a timer thread prints the error line on
+    rank 0 and ends the process.  arm(seconds, what) before the risky stretch, disarm() after it."""
+
+    def __init__(self, world, rank, args):
+        import threading
+        self._t, self._threading, self.world, self.rank, self.args = None, threading, world, rank, args
+
+    def arm(self, seconds, what):
+        self.disarm()
+        def fire():
+            if self.rank == 0:
+                print(_error_line(self.world, self.args, f"{what} did not finish within {seconds} s (rank {self.rank} gave up)"), flush=True)
+            os._exit(3)
+        self._t = self._threading.Timer(seconds, fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def disarm(self):
+        if self._t is not None:
+            self._t.cancel()
+            self._t = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,6 +393,9 @@ def main():
     ap.add_argument("--repeat-bp", type=int, default=0,
                     help="experiments only: reads starting in a region of this many bp get depth share 1/5 "
                          "(order-dependent f64 depth -> exact replay kernel) without the extra records of config 2")
+    ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("PP_BENCH_COLLECTIVE_TIMEOUT", "180")),
+                    help="N > 1: seconds a communicator set-up or one step's gather may take before the run is given up with an "
+                         "\"error\" line (a hung collective cannot be caught any other way)")
     ap.add_argument("--nd-frac", type=float, default=0.0,
                     help="experiments only: this fraction of the reads gets depth share 1/3 (every window then has "
                          "order-dependent depths: the worst case of the exact replay)")
@@ -379,12 +415,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
+    dog = _Watchdog(world, rank, args)
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "1")
+        dog.arm(args.collective_timeout, "setting up the process group")
+        try:
+            if share:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.collective_timeout))
+            else:
+                dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=args.collective_timeout))
+        except Exception as e:  # noqa: BLE001 -- whatever it is, the driver gets a line
+            if rank == 0:
+                print(_error_line(world, args, f"init_process_group failed: {e}"), flush=True)
+            raise SystemExit(3)
+        dog.disarm()
 
     import polypolish_amd as pp
     ctx = pp.Context(dev_index)
@@ -443,20 +490,37 @@ def main():
     gbuf = None
     if world > 1 and not share:
         # the exchange of the path, inside the library: pp_polish_gather (RCCL over xGMI)
-        ident = [pp.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0, device=device)
-        ctx.comm_init(rank, world, ident[0])
+        dog.arm(args.collective_timeout, "pp_comm_init (ncclCommInitRank)")
+        try:
+            ident = [pp.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0, device=device)
+            ctx.comm_init(rank, world, ident[0])
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(_error_line(world, args, f"pp_comm_init failed: {e}"), flush=True)
+            os._exit(3)
+        dog.disarm()
         gbuf = torch.zeros(total_cap, dtype=torch.uint8, device=device) if rank == 0 else None
     elif world > 1:
         # one GPU shared by all ranks (tests): RCCL refuses that, the bytes travel over gloo
         sbuf = torch.zeros(cap, dtype=torch.uint8, device=device)
         gathered = [torch.empty(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
     last = {}
+    split_s = {"compute": 0.0, "gather": 0.0, "n": 0}   # host clock around the two halves of a step (both end in a stream synchronisation)
 
     def step():
+        ta = time.perf_counter()
         run_job(ctx, pp, job)
+        tb = time.perf_counter()
         if world > 1 and not share:
-            last["lens"], last["offs"] = ctx.gather(gbuf.data_ptr() if rank == 0 else None, total_cap if rank == 0 else 0)
+            dog.arm(args.collective_timeout, "pp_polish_gather")
+            try:
+                last["lens"], last["offs"] = ctx.gather(gbuf.data_ptr() if rank == 0 else None, total_cap if rank == 0 else 0)
+            except Exception as e:  # noqa: BLE001 -- (a rank that backed out alone would leave the others in ncclSend: everybody leaves)
+                if rank == 0:
+                    print(_error_line(world, args, f"pp_polish_gather failed: {e}"), flush=True)
+                os._exit(3)
+            dog.disarm()
         elif world > 1:
             pp.lib().pp_polish_result(ctx._h, sbuf.data_ptr(), pp.MEM_DEVICE, None, None)
             src = sbuf.cpu()
@@ -467,6 +531,9 @@ def main():
                 ops = [dist.P2POp(dist.isend, src, 0)]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        split_s["compute"] += tb - ta
+        split_s["gather"] += time.perf_counter() - tb
+        split_s["n"] += 1
 
     # Timed region: only the dominant kernel carries an event pair (on the library's stream), so that the
     # timers do not perturb what `value` measures.  The per-group breakdown (kernel_ms_per_step) comes from
@@ -477,6 +544,7 @@ def main():
     ctx.set_profiling(2)
     dom_ms = []
     dom_name = None
+    split_s.update(compute=0.0, gather=0.0, n=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -498,6 +566,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    timed_split = dict(split_s)   # the timed steps' compute / gather halves on this rank
     ctx.set_profiling(1)
     all_ms, n_break, work = {}, 5, {}
     for _ in range(n_break):
@@ -509,7 +578,17 @@ def main():
     ctx.set_profiling(0)
 
     gather_ok = None
+    per_rank = None
+    one_gpu_ms = None
     if world > 1:
+        # what every rank did, so that a multi-GPU record can be read: its kernels, and its steps split into compute (begin /
+        # add / finish: ends in a stream synchronisation) and the gather
+        mine_diag = {"rank": rank, "records": job["part"].n_aln if strong else job["n_aln"],
+                     "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
+                     "compute_ms_per_step": round(1e3 * timed_split["compute"] / max(timed_split["n"], 1), 4),
+                     "gather_ms_per_step": round(1e3 * timed_split["gather"] / max(timed_split["n"], 1), 4)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_diag)
         # every rank's polished bytes must have arrived on rank 0 unchanged, and -- strong scaling -- put back in
         # assembly order they must be the bytes ONE GPU produces for the whole job
         mine, my_offs, _ = ctx.result()
@@ -531,6 +610,12 @@ def main():
                 run_job(ctx, pp, full)
                 ref, _, _ = ctx.result()
                 gather_ok = bool(gather_ok and whole == ref)
+                # ... and what the whole job takes on this ONE GPU: the compute side of the scaling curve
+                run_job(ctx, pp, full)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    run_job(ctx, pp, full)
+                one_gpu_ms = 1e3 * (time.perf_counter() - t1) / 3
                 run_job(ctx, pp, job)  # leave the rank's own result in the context for the report below
     G_all_ranks = G_total
     if world > 1 and not strong:  # weak scaling: every rank's own contig (their lengths differ by the planted indels)
@@ -666,6 +751,14 @@ def main():
         "work": work,
         "planted_errors_recovered": recovered,
         "gather_verified": gather_ok,
+        "per_rank": per_rank,
+        "multi_gpu_split": None if per_rank is None else {
+            "compute_ms_per_step_max": max(r["compute_ms_per_step"] for r in per_rank),
+            "gather_ms_per_step_max": max(r["gather_ms_per_step"] for r in per_rank),
+            "whole_job_ms_on_one_gpu": None if one_gpu_ms is None else round(one_gpu_ms, 4),
+            "compute_only_speedup": None if one_gpu_ms is None else round(one_gpu_ms / max(max(r["compute_ms_per_step"] for r in per_rank), 1e-9), 3),
+            "note": "strong scaling: the whole job on rank 0's GPU alone (after the timed region) over the slowest rank's compute half of a "
+                    "step -- the curve without the gather; the driver computes the efficiency with the gather from `value`"},
         "changed_positions": int(sum(s["changed"] for s in stats)),
     }
 

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <algorithm>
@@ -146,6 +147,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                              const pp_polish_options *opt, pp_bytes *fasta, const uint8_t *const *pass,
                              const uint64_t *n_pass, int resume_log_at = -1);
 extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes);
+extern "C" void pp_dev_ingest_prefetch_(pp_dev_ingest *D, const char *path, uint64_t second_buffer_bytes);
 extern "C" int pp_ingest_fail_cut_(const pp_ingest *I, uint64_t *cut);
 extern "C" int pp_ingest_sam_prefix_(pp_ingest *I, const char *path, uint64_t cut, const uint8_t *pass, uint64_t n_pass,
                                      pp_sam_counts *counts, char *err, size_t errlen);
@@ -215,7 +217,7 @@ size_t group_cut(const char *text, size_t size, size_t from) {
     }
     // the aligned record before it (scan back over header / empty / unaligned lines; give up after a while: then the
     // first aligned line at or after p is compared with nothing and the search just moves on one group)
-    bool have_prev = false;
+    bool have_prev = false, unknown_prev = false;
     const char *pq = nullptr;
     size_t pql = 0;
     {
@@ -228,14 +230,20 @@ size_t group_cut(const char *text, size_t size, size_t from) {
             if (v.aligned) { have_prev = true; pq = v.q; pql = v.qlen; break; }
             e = ls;
         }
-        if (!have_prev && e > 0) return size;  // a long stretch without aligned records: do not cut in this neighbourhood
+        // A long stretch without aligned records (unmapped reads grouped together): the aligned record before it is out
+        // of sight, so the first aligned line from p on may still belong to ITS group.  It is then taken as the record to
+        // compare with, and the cut falls on the first QNAME change after it -- a boundary whatever came before.  (Until
+        // round 4 this gave up and returned `size`: every later cut then fell on `size` too and one GPU tokenized the rest
+        // of the file.)
+        unknown_prev = !have_prev && e > 0;
     }
     while (p < size) {
         const char *nl = (const char *)memchr(text + p, '\n', size - p);
         const size_t le = nl ? (size_t)(nl - text) : size;
         const LineView v = look_at_line(text, p, le);
         if (v.aligned) {
-            if (!have_prev || (pql != 0 && (pql != v.qlen || memcmp(pq, v.q, pql) != 0))) return p;
+            if (unknown_prev) unknown_prev = false;
+            else if (!have_prev || (pql != 0 && (pql != v.qlen || memcmp(pq, v.q, pql) != 0))) return p;
             have_prev = true; pq = v.q; pql = v.qlen;
         }
         p = le + 1;
@@ -344,6 +352,19 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     log("\n");
 
     lap("assembly loaded");
+    // The FASTA that will be returned: headers + polished bytes.  Its buffer is allocated for an upper bound NOW and touched
+    // by a helper thread while the alignments are loaded -- the polished bytes then come off the device straight into their
+    // place in it (a fresh 250 MB destination took 30 ms of page faults inside the copy, and assembling the FASTA from a
+    // second buffer another 40 ms of memcpy).
+    size_t fasta_cap = 0;
+    for (uint32_t c = 0; c < nc; c++) fasta_cap += strlen(pp_assembly_name(a, c)) + strlen(pp_assembly_description(a, c)) + 16;
+    const size_t header_bytes = fasta_cap;
+    fasta_cap += (size_t)(off[nc] + off[nc] / 8) + 2 * (size_t)nc + 65536;  // (every planted insertion adds a byte: far below 1/8)
+    uint8_t *out = (uint8_t *)malloc(fasta_cap);
+    std::thread out_toucher;
+    if (out) out_toucher = std::thread([out, fasta_cap] { for (size_t q = 0; q < fasta_cap; q += 4096) out[q] = 0; });
+    // (every way out of this function: the helper joined first, then the buffer released unless it went to the caller)
+    struct OutGuard { std::thread &t; uint8_t *&p; ~OutGuard() { if (t.joinable()) t.join(); free(p); } } out_guard{out_toucher, out};
     // load_alignments, polish.rs:109-134 -- by the device tokenizer (pp_tokenize.hip), or on the host (multi-threaded
     // parse) with PP_DEVICE_INGEST=0 and with --debug (the TSV needs the read bytes on the host)
     log("Loading alignments\n");
@@ -401,6 +422,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     if (sharded) rc = on_all([&](int d) { return pp_dev_ingest_create(ctxs[d], a, opt->max_errors, opt->careful, &dgs[(size_t)d]); });
     else rc = dev_ingest ? pp_dev_ingest_create(ctx, a, opt->max_errors, opt->careful, &dg)
                          : (per_file ? PP_OK : pp_ingest_create(a, opt->max_errors, opt->careful, &g));
+    uint64_t largest_sam = 0;
     if (rc == PP_OK && dev_ingest && !sharded) {
         uint64_t largest = 0, total = 0;
         for (int i = 0; i < n_sams; i++) {
@@ -410,6 +432,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                 total += (uint64_t)st.st_size;
             }
         }
+        largest_sam = largest;
         if (largest) rc = pp_dev_ingest_reserve_text_(dg, largest);
         if (rc == PP_OK && n_sams > 1) rc = pp_dev_ingest_expect(dg, total);  // the batch's arrays sized once, for all the files
     }
@@ -450,6 +473,8 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             }
             slice_end.push_back(ends);
         } else if (dev_ingest) {
+            // the text of the NEXT file goes up (second text buffer, upload stream) while this one is tokenized
+            if (i + 1 < n_sams) pp_dev_ingest_prefetch_(dg, sams[i + 1], largest_sam);
             rc = pass ? pp_dev_ingest_sam_filtered(dg, sams[i], pass[i], n_pass[i], &c) : pp_dev_ingest_sam(dg, sams[i], &c);
             if (rc == PP_ERR_QUIT || rc == PP_ERR_PANIC || rc == PP_ERR_NOT_ASCII) {
                 // A defect in the text.  Which defect the reference reports FIRST also depends on what its CIGAR walk
@@ -561,6 +586,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     }
     pp_polish_set_debug(ctx, dbg ? 1 : 0);
     uint64_t total = 0;
+    bool direct_fetch = false;
     std::vector<uint8_t> polished(1);
     std::vector<uint64_t> out_off(nc + 1);
     std::vector<pp_contig_stats> stats(nc);
@@ -575,8 +601,11 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         if (dbg) fclose(dbg);
         pp_polish_set_debug(ctx, 0);
         if (rc == PP_OK) rc = pp_polish_result_size(ctx, &total);
-        polished.resize(total ? total : 1);
-        if (rc == PP_OK) rc = pp_polish_result(ctx, polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
+        // offsets and statistics now; the bytes go straight into the FASTA buffer below (contig by contig) when that is a
+        // handful of copies, else through one copy of everything
+        direct_fetch = rc == PP_OK && out && nc <= 256 && header_bytes + total + nc <= fasta_cap;
+        if (!direct_fetch) polished.resize(total ? total : 1);
+        if (rc == PP_OK) rc = pp_polish_result(ctx, direct_fetch ? nullptr : polished.data(), PP_MEM_HOST, out_off.data(), stats.data());
     } else {
         // ---- the plan, from the alignment counts per contig ----
         // source batches in file order: sharded -> (file, slice) pieces living on the contexts' GPUs; host ingest -> files
@@ -768,12 +797,15 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         return rc;
     }
 
-    lap("result fetched");
+    lap(direct_fetch ? "result: offsets fetched" : "result fetched");
     // print_seq_to_stdout (polish.rs:196-203), one contig after the other in FASTA order
-    size_t need = total;
-    for (uint32_t c = 0; c < nc; c++)
-        need += strlen(pp_assembly_name(a, c)) + strlen(pp_assembly_description(a, c)) + 16;
-    uint8_t *out = (uint8_t *)malloc(need ? need : 1);
+    if (out_toucher.joinable()) out_toucher.join();
+    if (!out || header_bytes + total + nc > fasta_cap) {  // (a job whose polished bytes outgrow the bound: a buffer of the exact size)
+        free(out);
+        out = (uint8_t *)malloc(header_bytes + total + nc + 1);
+        if (!out) { free_all(); return set_err(ctx, PP_ERR_HIP, "out of host memory for the FASTA"); }
+    }
+    const uint8_t *d_polished = direct_fetch ? pp_polish_result_device(ctx) : nullptr;
     size_t w = 0;
     for (uint32_t c = 0; c < nc; c++) {
         const char *name = pp_assembly_name(a, c), *desc = pp_assembly_description(a, c);
@@ -784,7 +816,10 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             memcpy(out + w, desc, strlen(desc)); w += strlen(desc);
         }
         memcpy(out + w, " polypolish\n", 12); w += 12;
-        memcpy(out + w, polished.data() + out_off[c], out_off[c + 1] - out_off[c]); w += out_off[c + 1] - out_off[c];
+        if (direct_fetch) {
+            if (int rd = pp_ctx_download(ctx, out + w, d_polished + out_off[c], out_off[c + 1] - out_off[c])) { free_all(); return rd; }
+        } else memcpy(out + w, polished.data() + out_off[c], out_off[c + 1] - out_off[c]);
+        w += out_off[c + 1] - out_off[c];
         out[w++] = '\n';
         // print_polishing_info, polish.rs:206-227
         const double len = (double)(off[c + 1] - off[c]);
@@ -798,6 +833,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     }
     fasta->data = out;
     fasta->len = w;
+    out = nullptr;  // the caller's now (pp_bytes_free)
     lap("FASTA assembled");
 
     // finished_message, polish.rs:76-90
@@ -807,6 +843,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     log("\nTime to run: %s\n\n", format_duration(secs).c_str());
     free_all();
+    lap("device and host buffers released");
     return PP_OK;
 }
 

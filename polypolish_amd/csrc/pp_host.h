@@ -85,9 +85,9 @@ inline double seconds_since_process_start() {
             buf[n] = 0;
             if (const char *p = strrchr(buf, ')')) {  // fields after the command name: state is the 3rd, starttime the 22nd
                 int field = 2;
-                for (p++; *p && field < 21; p++)
+                for (p++; *p && field < 22; p++)  // (every space opens the next field: p ends up on the first digit of the 22nd)
                     if (*p == ' ') field++;
-                if (field == 21) st = strtod(p, nullptr) / (double)sysconf(_SC_CLK_TCK);
+                if (field == 22) st = strtod(p, nullptr) / (double)sysconf(_SC_CLK_TCK);
             }
         }
         return st;

@@ -100,9 +100,10 @@ __device__ __forceinline__ void tile_add(u32 *cnt, int row, int p) { atomicAdd(&
 // as before.  Entry: tag = 1 << 31 | position << 16 | bytes; count in bits 0..23 of the second word, bits 32..39 of the
 // offset above them; the offset's low word.
 constexpr u32 PT_SLOTS = 20;
-__device__ __forceinline__ void pt_insert(u32 *pt, u32 *over, int p, const u8 *seq, u64 so) {
+__device__ __noinline__ void pt_insert(u32 *pt, u32 *over, int p, const u8 *seq, u64 so) {  // (rare: kept out of the item loop's registers)
     const u32 tag = 0x80000000u | ((u32)p << 16) | (u32)seq[so] | ((u32)seq[so + 1] << 8);
     u32 h = ((tag * 2654435761u) >> 16) % PT_SLOTS;
+#pragma unroll 1
     for (u32 t = 0; t < PT_SLOTS; t++) {
         const u32 old = atomicCAS(&pt[3 * h], 0u, tag);
         if (old == 0u) {
@@ -182,6 +183,66 @@ __device__ __forceinline__ VoteOut vote5(u32 nA, u32 nC, u32 nG, u32 nT, u32 nDe
                                          u8 orig, u32 min_depth, double fv, double fi) {
     const u32 vt = d_bankers(__dmul_rn(depth, fv));
     return vote5_thr(nA, nC, nG, nT, nDel, max(min_depth, vt), d_bankers(__dmul_rn(depth, fi)), depth < (double)min_depth, orig);
+}
+
+// The vote of pileup.rs:77-134 over A C G T, "-" and the two-byte keys the window's table holds for position p -- for a
+// position whose string-keyed row the table accounts for entirely (its counts add up to n_oth; else handled = false and the
+// position is listed for k_exact).  When exactly one key is valid it wins whatever the order of the keys, otherwise
+// nothing changes.  multi_eff > 0: a two-byte key won and leaves that many bytes (polish.rs:188 drops '-'), at multi_off in
+// the seq array.  Rare (a few positions per window at most): not inlined, so that its registers are not the vote loop's.
+struct KeyVote {
+    u32 handled, out, status, multi_eff;
+    u64 multi_off;
+};
+__device__ __noinline__ KeyVote vote_with_keys(const u32 *pt, u32 p, u32 nA, u32 nC, u32 nG, u32 nT, u32 nDel, u32 n_oth,
+                                               u32 vthr, u32 ithr, u32 orig) {
+    KeyVote r{0u, orig == (u32)'-' ? 0u : orig, (u32)PP_ST_KEPT, 0u, 0ull};
+    u32 n_tab = 0;
+#pragma unroll 1
+    for (u32 t = 0; t < PT_SLOTS; t++) {
+        const u32 tag = pt[3 * t];
+        if (tag && ((tag >> 16) & 0x7FFFu) == p) n_tab += pt[3 * t + 1] & 0xFFFFFFu;
+    }
+    if (n_tab != n_oth) return r;
+    r.handled = 1u;
+    int nv = 0, ni = 0;
+    u32 win = 0, win_t = 0xFFFFFFFFu;
+    const u32 c5[5] = {nA, nC, nG, nT, nDel};
+    const u32 k5[5] = {'A', 'C', 'G', 'T', '-'};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        if (j == 4 && nDel == 0) break;
+        if (c5[j] >= vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= ithr) ni++;
+    }
+#pragma unroll 1
+    for (u32 t = 0; t < PT_SLOTS; t++) {
+        const u32 tag = pt[3 * t];
+        if (!tag || ((tag >> 16) & 0x7FFFu) != p) continue;
+        const u32 c = pt[3 * t + 1] & 0xFFFFFFu;
+        if (c >= vthr) { if (!nv) win_t = t; nv++; } else if (c >= ithr) ni++;
+    }
+    if (nv == 1) {
+        if (ni > 0) r.status = PP_ST_TOO_CLOSE;
+        else if (win_t == 0xFFFFFFFFu) {
+            r.out = (win == (u32)'-') ? 0u : win;
+            if (win != orig) r.status = PP_ST_CHANGED;
+        } else {
+            r.status = PP_ST_CHANGED;  // a two-byte string is never the original base
+            const u32 tag = pt[3 * win_t];
+            const u32 b0 = tag & 0xFFu, b1 = (tag >> 8) & 0xFFu;
+            const u32 eff = (u32)(b0 != (u32)'-') + (u32)(b1 != (u32)'-');
+            const u32 only = b1 != (u32)'-' ? b1 : b0;
+            if (eff == 0) r.out = 0;
+            else if (eff == 1 && only < 0x80u) r.out = only;
+            else {
+                r.multi_eff = eff;
+                r.multi_off = (u64)pt[3 * win_t + 2] | ((u64)(pt[3 * win_t + 1] >> 24) << 32);
+            }
+        }
+    } else {
+        r.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
+    }
+    return r;
 }
 
 // LDS copy of the window's assembly bytes: ASM_PAD bytes of slack in front, >= 20 behind, so that a
@@ -669,10 +730,12 @@ __device__ __forceinline__ void position_tallies(const u32 *cnt, u8 orig, u32 p,
 // read base (alignment.rs:175-201), ALL read bytes are then loaded together and tallied -- one memory round trip per
 // item, where walking run by run with the runs in memory took eight or nine dependent ones (measured: 1 % of such
 // reads cost k_tile 0.09 of its 0.49 ms).
-__device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int nkeep, u32 nc, u32 r0, u32 r1, u32 r2,
-                                           u32 r3, u32 lane) {
+__device__ __forceinline__ void slow_short(u32 *cnt, const TileShare &S, const u8 *seq, u64 so, int rel, int nkeep, u32 nc, u32 r0,
+                                           u32 r1, u32 r2, u32 r3, u32 lane) {
     constexpr int SRC_NONE = -1, SRC_DEL = -2, SRC_OTH = -3;
+    const u8 *s = seq + so;
     int src[4] = {SRC_NONE, SRC_NONE, SRC_NONE, SRC_NONE};
+    int key2[4] = {-1, -1, -1, -1};  // read offset of a TWO-byte key (an M entry extended by one inserted base): tallied in the window's table too
     int ent0 = 0;
     u32 ro = 0;
     for (u32 r = 0; r < nc && ent0 < nkeep; r++) {
@@ -691,7 +754,10 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
             if (q < a || q >= b) continue;
             const bool ext = (q == ent0 + (int)len - 1) && ins > 0;
             if (o == PP_OP_D) src[t] = ext ? (ins == 1 ? (int)ro : SRC_OTH) : SRC_DEL;
-            else src[t] = ext ? SRC_OTH : (int)ro + (q - ent0);
+            else {
+                src[t] = ext ? SRC_OTH : (int)ro + (q - ent0);
+                if (ext && ins == 1u) key2[t] = (int)ro + (q - ent0);
+            }
         }
         ent0 += (int)len;
         if (o != PP_OP_D) ro += len;
@@ -704,6 +770,7 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const u8 *s, int rel, int n
         if (src[t] == SRC_NONE) continue;
         const int row = src[t] >= 0 ? row_of(c[t]) : (src[t] == SRC_DEL ? ROW_DEL : ROW_OTH);
         tile_add(cnt, row, rel + (int)lane + 64 * t);
+        if (key2[t] >= 0) pt_insert(S.pt, S.pt_over, rel + (int)lane + 64 * t, seq, so + (u64)key2[t]);
     }
 }
 
@@ -797,7 +864,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                 }
                 const u32 nc = (u32)__builtin_amdgcn_readlane((int)sl_nc, j);
                 if (nc <= 4u && nkeep <= 256) {
-                    slow_short(cnt, s, rel, nkeep, nc, (u32)__builtin_amdgcn_readlane((int)rr0, j),
+                    slow_short(cnt, S, A.seq, so, rel, nkeep, nc, (u32)__builtin_amdgcn_readlane((int)rr0, j),
                                (u32)__builtin_amdgcn_readlane((int)rr1, j), (u32)__builtin_amdgcn_readlane((int)rr2, j),
                                (u32)__builtin_amdgcn_readlane((int)rr3, j), lane);
                     continue;
@@ -820,6 +887,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                         if (o == PP_OP_D) row = ext ? (ins == 1 ? row_of(s[ro]) : ROW_OTH) : ROW_DEL;
                         else row = ext ? ROW_OTH : row_of(s[ro + (u64)(q - ent0)]);
                         tile_add(cnt, row, rel + q);
+                        if (o != PP_OP_D && ext && ins == 1u) pt_insert(S.pt, S.pt_over, rel + q, A.seq, so + ro + (u64)(q - ent0));
                     }
                     ent0 += (int)len;
                     if (o != PP_OP_D) ro += len;
@@ -1168,54 +1236,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
                 // string-keyed row of this position, the vote of pileup.rs:77-134 runs here over A C G T, "-" and those keys
                 // (when exactly one key is valid it wins whatever the order of the keys, otherwise nothing changes);
                 // else the position is listed for k_exact.
-                u32 n_tab = 0;
-                const bool table_ok = !s_ptover && A.dbg != 1 && A.dbg != 2;
-                if (table_ok)
-                    for (u32 t = 0; t < PT_SLOTS; t++) {
-                        const u32 tag = s_pt[3 * t];
-                        if (tag && ((tag >> 16) & 0x7FFFu) == p) n_tab += s_pt[3 * t + 1] & 0xFFFFFFu;
-                    }
-                if (table_ok && n_tab == nOth) {
-                    int nv = 0, ni = 0;
-                    u8 win = 0;
-                    u32 win_t = 0xFFFFFFFFu;
-                    const u32 c5[5] = {nA, nC, nG, nT, nDel};
-                    const u8 k5[5] = {'A', 'C', 'G', 'T', '-'};
-#pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        if (j == 4 && nDel == 0) break;
-                        if (c5[j] >= vthr) { if (!nv) win = k5[j]; nv++; } else if (c5[j] >= ithr) ni++;
-                    }
-                    for (u32 t = 0; t < PT_SLOTS; t++) {
-                        const u32 tag = s_pt[3 * t];
-                        if (!tag || ((tag >> 16) & 0x7FFFu) != p) continue;
-                        const u32 c = s_pt[3 * t + 1] & 0xFFFFFFu;
-                        if (c >= vthr) { if (!nv) win_t = t; nv++; } else if (c >= ithr) ni++;
-                    }
+                KeyVote kv{0u, 0u, 0u, 0u, 0ull};
+                if (!s_ptover && A.dbg != 1 && A.dbg != 2) kv = vote_with_keys(s_pt, p, nA, nC, nG, nT, nDel, nOth, vthr, ithr, (u32)orig);
+                if (kv.handled) {
                     v.vthr = vthr; v.ithr = ithr;
-                    v.out = (orig == (u8)'-') ? 0 : orig;
-                    v.status = PP_ST_KEPT;
-                    if (nv == 1) {
-                        if (ni > 0) v.status = PP_ST_TOO_CLOSE;
-                        else if (win_t == 0xFFFFFFFFu) {
-                            v.out = (win == (u8)'-') ? 0 : win;
-                            if (win != orig) v.status = PP_ST_CHANGED;
-                        } else {
-                            v.status = PP_ST_CHANGED;  // a two-byte string is never the original base
-                            const u32 tag = s_pt[3 * win_t];
-                            const u8 b0 = (u8)(tag & 0xFFu), b1 = (u8)((tag >> 8) & 0xFFu);
-                            const u32 eff = (u32)(b0 != (u8)'-') + (u32)(b1 != (u8)'-');
-                            const u8 only = b1 != (u8)'-' ? b1 : b0;
-                            if (eff == 0) v.out = 0;
-                            else if (eff == 1 && only < 0x80u) v.out = only;
-                            else {
-                                multi_eff = eff;
-                                multi_off = (u64)s_pt[3 * win_t + 2] | ((u64)(s_pt[3 * win_t + 1] >> 24) << 32);
-                            }
-                        }
-                    } else {
-                        v.status = (nv == 0) ? PP_ST_NONE : PP_ST_MULTIPLE;
-                    }
+                    v.out = (u8)kv.out;
+                    v.status = (u8)kv.status;
+                    multi_eff = kv.multi_eff;
+                    multi_off = kv.multi_off;
                 } else {
                     flag = true;
                     for_keys = true;

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" int pp_ingest_text_(pp_ingest *I, const char *path, const char *text, size_t size, uint64_t line_base,
@@ -483,7 +484,28 @@ struct pp_dev_ingest {
     int seq4 = 1;        // the mirror goes with every batch (PP_SEQ4=0: none)
     bool mirror() const { return seq4 != 0; }
     u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
+    // The text of the NEXT file goes up while the current one is tokenized (pp_dev_ingest_prefetch_): two text buffers, an
+    // upload stream of its own, and a helper thread per upload (a copy out of pageable memory keeps its caller busy).
+    pp::DevBuf d_text2;
+    hipStream_t up_stream = nullptr;
+    int text_sel = 0;        // the buffer the last tokenized file's text went to (0: d_text, 1: d_text2)
+    int n_files_started = 0;
+    struct Prefetch {
+        std::string path;
+        pph::FileText *F = nullptr;
+        std::thread th;
+        int sel = 0;
+        bool ok = false;     // the text is in the device buffer (set by the thread)
+        double wait_s = 0, copy_s = 0;
+    } *pf = nullptr;
 };
+
+// the mapping of a file that has been tokenized goes away in the background: unmapping 15 GB of populated pages takes 0.14 s
+static void reap_mapping(pph::FileText *F) {
+    if (!F) return;
+    std::thread([F] { delete F; }).detach();
+}
+static pp::DevBuf &text_buf(pp_dev_ingest *D, int sel) { return sel ? D->d_text2 : D->d_text; }
 
 namespace {
 
@@ -538,6 +560,15 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
 
 extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     if (!D) return;
+    if (D->pf) {
+        if (D->pf->th.joinable()) D->pf->th.join();
+        reap_mapping(D->pf->F);
+        delete D->pf;
+        D->pf = nullptr;
+    }
+    (void)hipSetDevice(D->ctx->device);
+    if (D->up_stream) { (void)hipStreamSynchronize(D->up_stream); (void)hipStreamDestroy(D->up_stream); }
+    pp::dev_free(D->d_text2);
     (void)hipStreamSynchronize(D->ctx->stream);
     pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->d_win, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
@@ -627,12 +658,54 @@ extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes) {
     return pp::dev_ensure(D->ctx, D->d_text, (size_t)(padded + 64));
 }
 
+// Start the upload of `path` -- the file pp_dev_ingest_sam* will be given NEXT -- into the text buffer the current file does
+// not use, on the upload stream: it then overlaps the tokenizer kernels of the current file (and whatever the caller does
+// in between).  Internal (the file drivers call it); a prefetch that cannot be made is simply not there, the ingest then
+// uploads as usual.  second_buffer_bytes: room to make for the second text buffer (the largest file of the job).
+extern "C" void pp_dev_ingest_prefetch_(pp_dev_ingest *D, const char *path, uint64_t second_buffer_bytes) {
+    if (!D || !path || D->pf) return;
+    pp_ctx *ctx = D->ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) return;
+    if (!D->up_stream && hipStreamCreateWithFlags(&D->up_stream, hipStreamNonBlocking) != hipSuccess) { D->up_stream = nullptr; return; }
+    const int sel = D->n_files_started ? 1 - D->text_sel : D->text_sel;  // (before the first file: the buffer it would use anyway)
+    {
+        const u64 n_blk = (second_buffer_bytes + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
+        pp::DevBuf &b = text_buf(D, sel);
+        if (b.cap < padded + 64) {  // (made here, on the caller's thread: the helper only copies)
+            if (b.p) return;        // in use or too small: no prefetch rather than a reallocation under a running kernel
+            if (hipMalloc(&b.p, (size_t)(padded + 64)) != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return; }
+            b.cap = (size_t)(padded + 64);
+        }
+    }
+    auto *P = new pp_dev_ingest::Prefetch();
+    P->path = path;
+    P->sel = sel;
+    P->F = new pph::FileText();
+    D->pf = P;
+    const int device = ctx->device;
+    hipStream_t us = D->up_stream;
+    pp::DevBuf *buf = &text_buf(D, sel);
+    P->th = std::thread([P, device, us, buf] {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!P->F->open_file(P->path.c_str())) return;  // (waits for the pre-faulting of the mapping)
+        const auto t1 = std::chrono::steady_clock::now();
+        P->wait_s = std::chrono::duration<double>(t1 - t0).count();
+        const u64 size = P->F->size, n_blk = (size + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
+        if (buf->cap < padded + 64 || hipSetDevice(device) != hipSuccess) return;
+        if (size && hipMemcpyAsync(buf->p, P->F->text, size, hipMemcpyHostToDevice, us) != hipSuccess) return;
+        if (hipMemsetAsync((u8 *)buf->p + size, 0, padded + 64 - size, us) != hipSuccess) return;
+        if (hipStreamSynchronize(us) != hipSuccess) return;
+        P->copy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        P->ok = true;
+    });
+}
+
 extern "C" int pp_dev_ingest_sam(pp_dev_ingest *D, const char *path, pp_sam_counts *counts) {
     return pp_dev_ingest_sam_filtered(D, path, nullptr, 0, counts);
 }
 
 static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64 size, bool slice, const uint8_t *pass,
-                       uint64_t n_pass, pp_sam_counts *counts);
+                       uint64_t n_pass, pp_sam_counts *counts, const u8 *uploaded = nullptr);
 
 extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, const uint8_t *pass, uint64_t n_pass,
                                           pp_sam_counts *counts) {
@@ -640,12 +713,37 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
     pp_ctx *ctx = D->ctx;
     pp_sam_counts c{0, 0, 0};
     if (counts) *counts = c;
-    pph::FileText F;
+    const bool timing = getenv("PP_TIMING") != nullptr;
+    pph::FileText *F = nullptr;
+    const u8 *uploaded = nullptr;  // the text is on the device already (prefetched while the file before was tokenized)
     const auto t_open = std::chrono::steady_clock::now();
-    if (!F.open_file(path)) return ctx->fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path);
-    if (getenv("PP_TIMING"))
-        fprintf(stderr, "[timing]   tokenizer: %-20s %.4f s  (%.2f GB)\n", "mapping ready", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(), 1e-9 * (double)F.size);
-    return ingest_text(D, path, F.text, F.size, false, pass, n_pass, counts);
+    if (D->pf) {
+        pp_dev_ingest::Prefetch *P = D->pf;
+        D->pf = nullptr;
+        if (P->th.joinable()) P->th.join();
+        if (P->path == path && P->ok) {
+            F = P->F;
+            uploaded = (const u8 *)text_buf(D, P->sel).p;
+            D->text_sel = P->sel;
+            if (timing)
+                fprintf(stderr, "[timing]   tokenizer: %-20s %.4f s  (%.2f GB: mapping %.4f s + copy %.4f s on the upload stream, %.4f s of it still to wait for)\n",
+                        "text prefetched", P->wait_s + P->copy_s, 1e-9 * (double)F->size, P->wait_s, P->copy_s,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count());
+        } else {
+            reap_mapping(P->F);  // another file, or the prefetch did not come about: the usual way
+        }
+        delete P;
+    }
+    if (!F) {
+        F = new pph::FileText();
+        if (!F->open_file(path)) { delete F; return ctx->fail(PP_ERR_QUIT, "unable to load alignments from \"%s\"", path); }
+        if (timing)
+            fprintf(stderr, "[timing]   tokenizer: %-20s %.4f s  (%.2f GB)\n", "mapping ready", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(), 1e-9 * (double)F->size);
+    }
+    D->n_files_started++;
+    const int rc = ingest_text(D, path, F->text, F->size, false, pass, n_pass, counts, uploaded);
+    reap_mapping(F);
+    return rc;
 }
 
 // One SLICE of a SAM file -- a byte range that starts and ends on read-group boundaries (src/alignment.rs:255-263: a
@@ -662,7 +760,7 @@ extern "C" int pp_dev_ingest_slice_(pp_dev_ingest *D, const char *path, const ch
 }
 
 static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64 size, bool slice, const uint8_t *pass,
-                       uint64_t n_pass, pp_sam_counts *counts) {
+                       uint64_t n_pass, pp_sam_counts *counts, const u8 *uploaded) {
     pp_ctx *ctx = D->ctx;
     hipStream_t st = ctx->stream;
     pp_sam_counts c{0, 0, 0};
@@ -682,14 +780,18 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
 #define ENS(buf, bytes) if ((rc = pp::dev_ensure(ctx, D->buf, (size_t)(bytes)))) return rc
     // ---- text + newline index ----
     const u64 n_blk = (size + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
-    ENS(d_text, padded + 64);
     ENS(d_status, 8);
-    if (size) PP_HIPCHK(ctx, hipMemcpyAsync(D->d_text.p, F.text, size, hipMemcpyHostToDevice, st));
-    PP_HIPCHK(ctx, hipMemsetAsync((u8 *)D->d_text.p + size, 0, padded + 64 - size, st));
+    const u8 *d_text = uploaded;
+    if (!uploaded) {  // (else: it went up on the upload stream while the file before was tokenized, pp_dev_ingest_prefetch_)
+        pp::DevBuf &tb = text_buf(D, D->text_sel);
+        if ((rc = pp::dev_ensure(ctx, tb, (size_t)(padded + 64)))) return rc;
+        if (size) PP_HIPCHK(ctx, hipMemcpyAsync(tb.p, F.text, size, hipMemcpyHostToDevice, st));
+        PP_HIPCHK(ctx, hipMemsetAsync((u8 *)tb.p + size, 0, padded + 64 - size, st));
+        d_text = (const u8 *)tb.p;
+    }
     PP_HIPCHK(ctx, hipMemsetAsync(D->d_status.p, 0xFF, 8, st));
-    const u8 *d_text = (const u8 *)D->d_text.p;
     u64 *d_status = (u64 *)D->d_status.p;
-    lap("text uploaded");
+    if (!uploaded) lap("text uploaded");
     u64 n_nl = 0;
     if (n_blk) {
         ENS(d_blk, (n_blk + 1) * 4);

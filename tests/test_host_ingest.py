@@ -375,6 +375,16 @@ def test_slices_of_a_sam_file_start_on_read_group_boundaries(tmp_path):
         assert c == nxt, (frm, c, nxt)
         cuts.add(c)
     assert len(cuts) > 50
+    # A long run of unaligned records (unmapped reads grouped together) in front of the target: the aligned record before it
+    # is out of the cut search's sight, the first aligned line after it may still belong to that record's group (unaligned
+    # lines do not close a group) -- the cut then falls on the first QNAME change after it: a boundary whatever came
+    # before, and not the end of the file (which left one GPU with the rest of the text).
+    una = [f"u{i}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*" for i in range(5000)]
+    long_lines = ["@HD\tVN:1.6", rec("g1", 16, 10)] + una + [rec("g1", 256, 900), rec("g1", 256, 950), rec("g2", 0, 20), rec("g3", 0, 30)]
+    ltext = ("\n".join(long_lines) + "\n").encode()
+    after_una = ltext.index(b"g1\t256")
+    c = int(L.pp_sam_group_cut_(ltext, len(ltext), after_una - 200))
+    assert c == ltext.index(b"g2\t0"), (c, ltext.index(b"g2\t0"))
     # ingest of the slices == ingest of the file
     fa = tmp_path / "a.fasta"
     fa.write_text(">c1\n" + "ACGT" * 1250 + "\n")
