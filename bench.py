@@ -38,6 +38,7 @@ import ctypes
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -256,8 +257,9 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                 lines = [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("[timing]   tokenizer:")]
                 tot = {}
                 for l in lines:
-                    name = l.split("tokenizer:")[1].rsplit(None, 2)[0].strip()
-                    tot[name] = tot.get(name, 0.0) + float(l.split()[-2])
+                    m = re.match(r"\[timing\]\s+tokenizer:\s+(.*?)\s+([0-9.]+) s\b", l)
+                    if m:
+                        tot[m.group(1)] = tot.get(m.group(1), 0.0) + float(m.group(2))
                 return {k: round(1e3 * v, 3) for k, v in tot.items()}
             t_w, r_w = _timed([exe, "polish", fa] + sams, dict(env, PP_TIMING="1"), repeat=rep)
             t_f, r_f = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_TIMING="1"), repeat=rep)
@@ -396,6 +398,8 @@ def main():
     ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("PP_BENCH_COLLECTIVE_TIMEOUT", "180")),
                     help="N > 1: seconds a communicator set-up or one step's gather may take before the run is given up with an "
                          "\"error\" line (a hung collective cannot be caught any other way)")
+    ap.add_argument("--window-sorted-records", action="store_true",
+                    help="experiments only: the records themselves in window order (as a position-sorted SAM file would have them)")
     ap.add_argument("--nd-frac", type=float, default=0.0,
                     help="experiments only: this fraction of the reads gets depth share 1/3 (every window then has "
                          "order-dependent depths: the worst case of the exact replay)")
@@ -462,6 +466,14 @@ def main():
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
     if args.seq4 == "on":   # the mirror the device tokenizer hands over with its batch (and pp_polish_add packs for any other)
         job = synthjob.with_seq4(job)
+    if args.window_sorted_records:
+        # experiment: the RECORDS themselves in window order (a position-sorted SAM file): what the bucketing kernels cost
+        # when a block's records fall into a handful of windows and its work items are written next to each other
+        r = job["recs"]
+        order = torch.argsort(job["gstart"] // 2048, stable=True)
+        rr = {k: (v[order].contiguous() if k not in ("seq", "cigar") else v) for k, v in r.items()}
+        job = dict(job, recs=rr, gstart=job["gstart"][order])
+        job.pop("_prepared", None)
     if args.nd_frac > 0:
         gg = torch.Generator(device=device)
         gg.manual_seed(7)

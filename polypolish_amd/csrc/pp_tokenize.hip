@@ -489,7 +489,10 @@ struct pp_dev_ingest {
     pp::DevBuf d_text2;
     hipStream_t up_stream = nullptr;
     int text_sel = 0;        // the buffer the last tokenized file's text went to (0: d_text, 1: d_text2)
-    int n_files_started = 0;
+    hipEvent_t up_gate = nullptr;  // recorded behind the current file's own upload: the next file's copy waits for it
+    bool gate_set = false;
+    std::string next_path;   // the file the driver announced as the next one (pp_dev_ingest_prefetch_)
+    uint64_t next_bytes = 0;
     struct Prefetch {
         std::string path;
         pph::FileText *F = nullptr;
@@ -568,6 +571,7 @@ extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     }
     (void)hipSetDevice(D->ctx->device);
     if (D->up_stream) { (void)hipStreamSynchronize(D->up_stream); (void)hipStreamDestroy(D->up_stream); }
+    if (D->up_gate) (void)hipEventDestroy(D->up_gate);
     pp::dev_free(D->d_text2);
     (void)hipStreamSynchronize(D->ctx->stream);
     pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->d_win, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
@@ -663,11 +667,22 @@ extern "C" int pp_dev_ingest_reserve_text_(pp_dev_ingest *D, uint64_t bytes) {
 // in between).  Internal (the file drivers call it); a prefetch that cannot be made is simply not there, the ingest then
 // uploads as usual.  second_buffer_bytes: room to make for the second text buffer (the largest file of the job).
 extern "C" void pp_dev_ingest_prefetch_(pp_dev_ingest *D, const char *path, uint64_t second_buffer_bytes) {
-    if (!D || !path || D->pf) return;
+    if (!D || !path) return;
+    D->next_path = path;              // (started by the ingest of the current file, once ITS text has gone up: two uploads
+    D->next_bytes = second_buffer_bytes;  //  at a time would only share the link)
+}
+static void start_prefetch(pp_dev_ingest *D) {
+    if (D->next_path.empty() || D->pf) return;
+    const std::string path_s = D->next_path;
+    const char *path = path_s.c_str();
+    const uint64_t second_buffer_bytes = D->next_bytes;
+    D->next_path.clear();
     pp_ctx *ctx = D->ctx;
     if (hipSetDevice(ctx->device) != hipSuccess) return;
     if (!D->up_stream && hipStreamCreateWithFlags(&D->up_stream, hipStreamNonBlocking) != hipSuccess) { D->up_stream = nullptr; return; }
-    const int sel = D->n_files_started ? 1 - D->text_sel : D->text_sel;  // (before the first file: the buffer it would use anyway)
+    if (D->gate_set && hipStreamWaitEvent(D->up_stream, D->up_gate, 0) != hipSuccess) return;  // behind the current file's upload
+    D->gate_set = false;
+    const int sel = 1 - D->text_sel;  // the file that is tokenized meanwhile uses (or used) buffer text_sel
     {
         const u64 n_blk = (second_buffer_bytes + NL_BLOCK - 1) / NL_BLOCK, padded = std::max<u64>(1, n_blk) * NL_BLOCK;
         pp::DevBuf &b = text_buf(D, sel);
@@ -717,11 +732,11 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
     pph::FileText *F = nullptr;
     const u8 *uploaded = nullptr;  // the text is on the device already (prefetched while the file before was tokenized)
     const auto t_open = std::chrono::steady_clock::now();
-    if (D->pf) {
+    if (D->pf && D->pf->path == path) {  // (a prefetch for a LATER file stays pending: it is for the file after this one)
         pp_dev_ingest::Prefetch *P = D->pf;
         D->pf = nullptr;
         if (P->th.joinable()) P->th.join();
-        if (P->path == path && P->ok) {
+        if (P->ok) {
             F = P->F;
             uploaded = (const u8 *)text_buf(D, P->sel).p;
             D->text_sel = P->sel;
@@ -730,7 +745,8 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
                         "text prefetched", P->wait_s + P->copy_s, 1e-9 * (double)F->size, P->wait_s, P->copy_s,
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count());
         } else {
-            reap_mapping(P->F);  // another file, or the prefetch did not come about: the usual way
+            if (timing) fprintf(stderr, "[timing]   tokenizer: the prefetch of this file did not come about: uploading it now\n");
+            reap_mapping(P->F);
         }
         delete P;
     }
@@ -740,7 +756,6 @@ extern "C" int pp_dev_ingest_sam_filtered(pp_dev_ingest *D, const char *path, co
         if (timing)
             fprintf(stderr, "[timing]   tokenizer: %-20s %.4f s  (%.2f GB)\n", "mapping ready", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count(), 1e-9 * (double)F->size);
     }
-    D->n_files_started++;
     const int rc = ingest_text(D, path, F->text, F->size, false, pass, n_pass, counts, uploaded);
     reap_mapping(F);
     return rc;
@@ -788,10 +803,13 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         if (size) PP_HIPCHK(ctx, hipMemcpyAsync(tb.p, F.text, size, hipMemcpyHostToDevice, st));
         PP_HIPCHK(ctx, hipMemsetAsync((u8 *)tb.p + size, 0, padded + 64 - size, st));
         d_text = (const u8 *)tb.p;
+        if (!D->up_gate && hipEventCreateWithFlags(&D->up_gate, hipEventDisableTiming) != hipSuccess) D->up_gate = nullptr;
+        if (D->up_gate && hipEventRecord(D->up_gate, st) == hipSuccess) D->gate_set = true;
     }
     PP_HIPCHK(ctx, hipMemsetAsync(D->d_status.p, 0xFF, 8, st));
     u64 *d_status = (u64 *)D->d_status.p;
     if (!uploaded) lap("text uploaded");
+    if (!slice) start_prefetch(D);  // this file's text is on its way (a copy out of pageable memory returns when it is staged): the next file's may follow
     u64 n_nl = 0;
     if (n_blk) {
         ENS(d_blk, (n_blk + 1) * 4);

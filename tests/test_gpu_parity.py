@@ -1086,6 +1086,22 @@ def test_configs2_from_text_at_full_size(tmp_path):
     assert out["filter"]["records_failed_in_file_1"] > 1000, out["filter"]  # the filter had something to reject
 
 
+def test_configs3_from_sam_files_beyond_4_gib(tmp_path):
+    """BASELINE.json configs[3] (100-contig metagenome, 100x) END TO END FROM SAM TEXT at a reduced size whose two SAM files
+    are still larger than 4 GiB each: byte offsets into a file's text, newline positions and the tokenizer's scans pass
+    2^32 (pp_tokenize.hip indexes the text with 64-bit offsets; a 32-bit slip would scramble every record of the second half
+    of a file).  `polish` through the device tokenizer and through the host ingest against the oracle's CLI, sha256."""
+    import torch
+    import bench
+    lens, cov, repeat, _ = bench.config_shape(3, genome=38_000_000)
+    out = bench.end_to_end(torch.device("cuda", 0), 3, lens, cov, repeat, seed=4245, keep_dir=str(tmp_path))
+    assert out.get("parity") is True, out
+    assert out["text_bytes"] / 2 > 2 ** 32 + 2 ** 27, out["text_bytes"]   # each of the two files well past 4 GiB
+    assert out["polish"]["parity"] and out["polish_host_ingest"]["parity"], out
+    for p in os.listdir(tmp_path):   # 9 GB of text: gone before the next test
+        os.unlink(os.path.join(tmp_path, p))
+
+
 def test_assembly_of_4_gbp_is_refused_cleanly(ctx, pp):
     """Positions are 32-bit in this version: an assembly of 2^32-4096 bp or more is refused by pp_polish_begin with
     PP_ERR_LIMIT before anything is read or allocated (the reference's Vec<PileupBase>, src/pileup.rs:178-187, has no
