@@ -13,6 +13,7 @@
 
 #include "polypolish_hip.h"
 #include "pp_host.h"
+extern "C" void pp_process_leaving_soon_(int yes);
 
 static const char *HELP =
     "Polypolish (MI355X/gfx950 implementation, parity target v0.6.1)\n"
@@ -227,6 +228,7 @@ int main(int argc, char **argv) {
     if (cmd == "-h" || cmd == "--help") { fputs(HELP, stdout); return 0; }
     if (cmd == "-V" || cmd == "--version") { printf("Polypolish v0.6.1 (%s)\n", pp_version()); return 0; }
     int device = getenv("PP_DEVICE") ? atoi(getenv("PP_DEVICE")) : 0;
+    pp_process_leaving_soon_(1);  // every command ends in finish(): _exit without tearing the mappings and the runtime down
 
     if (cmd == "polish") {
         pp_polish_options opt{0.2, 0.5, 10, 5, 0, nullptr, 0};

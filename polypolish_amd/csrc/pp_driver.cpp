@@ -65,6 +65,9 @@ namespace {
 int set_err(pp_ctx *ctx, int code, const char *msg) { return pp_ctx_set_error_(ctx, code, msg); }
 }  // namespace
 
+// (internal, bin/polypolish only) the process exits right after the command: see pph::process_leaving_soon
+extern "C" void pp_process_leaving_soon_(int yes) { pph::process_leaving_soon() = yes != 0; }
+
 extern "C" void pp_bytes_free(pp_bytes *b) {
     if (!b) return;
     free(b->data);

@@ -73,6 +73,11 @@ void parallel_for(size_t n, unsigned threads, F f) {
     for (auto &th : pool) th.join();
 }
 
+// The command-line program leaves with _exit as soon as its output is written: unmapping tens of GB of input mappings
+// (0.14 s per 15 GB, and every mmap / hipMalloc of the process waits for the lock meanwhile) and releasing device buffers is
+// then the kernel's business at exit.  Library callers never set this: their mappings are unmapped on a background thread.
+inline bool &process_leaving_soon() { static bool v = false; return v; }
+
 // seconds since this process was started (its start time in /proc/self/stat against CLOCK_BOOTTIME; 10 ms resolution):
 // what a PP_TIMING line of a command driver counts from -- exec, dynamic linking and the HIP runtime's start-up included
 inline double seconds_since_process_start() {

@@ -280,7 +280,9 @@ struct pp_ingest {
     uint64_t fail_cut = 0;
     bool fail_has_cut = false;
     ~pp_ingest() {
-        for (auto &t : reapers) t.join();
+        for (auto &t : reapers) {
+            if (pph::process_leaving_soon()) t.detach(); else t.join();  // (the CLI exits without waiting for the unmapping)
+        }
     }
 };
 

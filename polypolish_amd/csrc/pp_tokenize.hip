@@ -506,6 +506,7 @@ struct pp_dev_ingest {
 // the mapping of a file that has been tokenized goes away in the background: unmapping 15 GB of populated pages takes 0.14 s
 static void reap_mapping(pph::FileText *F) {
     if (!F) return;
+    if (pph::process_leaving_soon()) return;  // the CLI: left to the exit (see pp_host.h)
     std::thread([F] { delete F; }).detach();
 }
 static pp::DevBuf &text_buf(pp_dev_ingest *D, int sel) { return sel ? D->d_text2 : D->d_text; }
