@@ -94,8 +94,9 @@ def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
     job's own record arrays."""
     part = job.get("part")
     seq4 = job.get("seq4")  # the 4-bit mirror of the seq array (pp_aln_batch.seq4), when the job has one
+    wo = job.get("wo")      # the window-order mirror of the records (pp_aln_batch.wo), when the job has one
     key = (id(ctx), params, None if job.get("emit") is None else id(job["emit"]), job["bases"].data_ptr(),
-           job["recs"]["seq"].data_ptr(), None if seq4 is None else seq4.data_ptr(), job["n_aln"], id(part),
+           job["recs"]["seq"].data_ptr(), None if seq4 is None else seq4.data_ptr(), None if wo is None else wo.data_ptr(), job["n_aln"], id(part),
            job["contig_off"].tobytes() if len(job["contig_off"]) < 64 else id(job["contig_off"]))
     run = job.setdefault("_prepared", {}).get(key)
     if run is None:
@@ -107,6 +108,8 @@ def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
             ptrs = {k: v.data_ptr() for k, v in r.items()}
             if seq4 is not None:
                 ptrs["seq4"] = seq4.data_ptr()
+            if wo is not None:
+                ptrs["wo"] = wo.data_ptr()
             run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, job["n_aln"],
                                    ptrs, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
                                    *params, emit=job.get("emit"))
@@ -262,16 +265,16 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                         tot[m.group(1)] = tot.get(m.group(1), 0.0) + float(m.group(2))
                 return {k: round(1e3 * v, 3) for k, v in tot.items()}
             t_w, r_w = _timed([exe, "polish", fa] + sams, dict(env, PP_TIMING="1"), repeat=rep)
-            t_f, r_f = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_TIMING="1"), repeat=rep)
-            t_file, r_file = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0"), repeat=rep)
+            t_f, r_f = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0", PP_TIMING="1"), repeat=rep)
+            t_file, r_file = _timed([exe, "polish", fa] + sams, dict(env, PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0"), repeat=rep)
             if t_w is not None and t_f is not None and t_file is not None:
                 sw, sf = stages(r_w), stages(r_f)
-                out["tokenizer_stages_ms"] = {"default (window-grouped + mirror)": sw, "PP_SEQ_LAYOUT=file PP_SEQ4=0": sf,
+                out["tokenizer_stages_ms"] = {"default (window-grouped + mirror)": sw, "PP_SEQ_LAYOUT=file PP_SEQ4=0 PP_WO=0": sf,
                                               "layout_extra_ms": round(sw.get("window layout", 0.0) - sf.get("file-order layout", 0.0), 3),
                                               "seq_and_mirror_extra_ms": round(sw.get("seq bytes + mirror", 0.0) - sf.get("seq bytes + mirror", 0.0), 3),
                                               "note": "sums over the two SAM files; every stage ends in a stream synchronisation under PP_TIMING"}
                 out["polish_file_order_seq"] = {"wall_s": round(t_file, 3), "parity": sha(r_file.stdout) == want,
-                                                "batch": "PP_SEQ_LAYOUT=file PP_SEQ4=0: SEQ bytes in the order of the records, no 4-bit mirror (rounds 1-3)"}
+                                                "batch": "PP_SEQ_LAYOUT=file PP_SEQ4=0 PP_WO=0: SEQ bytes in the order of the records, no mirrors (rounds 1-3)"}
             del r_w, r_f, r_file
         ok = out["polish"]["parity"] and out.get("polish_host_ingest", {}).get("parity", True)
         del r_dev, r_host, r_cpu
@@ -373,6 +376,9 @@ def main():
     ap.add_argument("--seq4", default="on", choices=["on", "off"],
                     help="hand the 4-bit mirror of the seq array over with the batch (pp_aln_batch.seq4), as the device tokenizer does "
                          "(default; 'off' = PP_SEQ4=0)")
+    ap.add_argument("--wo", default="on", choices=["on", "off"],
+                    help="hand the window-order mirror of the records over with the batch (pp_aln_batch.wo), as both ingests do "
+                         "(default; 'off' = PP_WO=0: the bucketing kernels read the records in file order)")
     ap.add_argument("--seq-layout", default="window", choices=["file", "window"],
                     help="'window' (default): the SEQ bytes of a SAM file window-grouped, as both ingests lay them out since round 4 "
                          "(PP_SEQ_WINDOW_GROUPED; tools/synthjob.py window_grouped); 'file' = in the order of the records "
@@ -398,8 +404,6 @@ def main():
     ap.add_argument("--collective-timeout", type=float, default=float(os.environ.get("PP_BENCH_COLLECTIVE_TIMEOUT", "180")),
                     help="N > 1: seconds a communicator set-up or one step's gather may take before the run is given up with an "
                          "\"error\" line (a hung collective cannot be caught any other way)")
-    ap.add_argument("--window-sorted-records", action="store_true",
-                    help="experiments only: the records themselves in window order (as a position-sorted SAM file would have them)")
     ap.add_argument("--nd-frac", type=float, default=0.0,
                     help="experiments only: this fraction of the reads gets depth share 1/3 (every window then has "
                          "order-dependent depths: the worst case of the exact replay)")
@@ -445,7 +449,7 @@ def main():
     strong = world > 1 and args.config in (3, 4)
     if args.indel_frac is None:
         args.indel_frac = synthjob.SURVEY_INDEL_READ_FRAC if args.recipe == "survey" else 0.01
-    default_shape = (args.seq_layout == "window" and args.seq_pitch == -1 and args.seq4 == "on" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
+    default_shape = (args.seq_layout == "window" and args.seq_pitch == -1 and args.seq4 == "on" and args.wo == "on" and args.recipe == "survey" and args.indel_frac == synthjob.SURVEY_INDEL_READ_FRAC and args.sub_rate == 0.002 and args.n_rate == 1e-4 and args.read_len == 150 and
                      args.repeat_bp == 0 and args.nd_frac == 0.0 and args.genome is None and args.coverage is None)
     # config 1: this rank's own 5 Mbp contig (seed differs per rank); configs 3 / 4 with N > 1: every rank builds
     # the same job and keeps its shard
@@ -466,14 +470,8 @@ def main():
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
     if args.seq4 == "on":   # the mirror the device tokenizer hands over with its batch (and pp_polish_add packs for any other)
         job = synthjob.with_seq4(job)
-    if args.window_sorted_records:
-        # experiment: the RECORDS themselves in window order (a position-sorted SAM file): what the bucketing kernels cost
-        # when a block's records fall into a handful of windows and its work items are written next to each other
-        r = job["recs"]
-        order = torch.argsort(job["gstart"] // 2048, stable=True)
-        rr = {k: (v[order].contiguous() if k not in ("seq", "cigar") else v) for k, v in r.items()}
-        job = dict(job, recs=rr, gstart=job["gstart"][order])
-        job.pop("_prepared", None)
+    if args.wo == "on":     # the window-order mirror of the records both ingests hand over with their batch (pp_aln_batch.wo)
+        job = synthjob.with_wo(job)
     if args.nd_frac > 0:
         gg = torch.Generator(device=device)
         gg.manual_seed(7)
@@ -658,7 +656,7 @@ def main():
     # command (N = 1); failing that, the committed figure of the same workload (profiles/traffic.json), else null.
     traffic = traffic_source = None
     if world == 1 and dom_name and not args.no_live_traffic:
-        tail = ["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--seq4", args.seq4, "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
+        tail = ["--config", str(args.config), "--seq-pitch", str(args.seq_pitch), "--seq4", args.seq4, "--wo", args.wo, "--seq-layout", args.seq_layout, "--recipe", args.recipe, "--indel-frac", repr(args.indel_frac), "--sub-rate", repr(args.sub_rate),
                 "--n-rate", repr(args.n_rate), "--read-len", str(args.read_len), "--repeat-bp", str(args.repeat_bp), "--nd-frac", repr(args.nd_frac)]
         if args.genome is not None:
             tail += ["--genome", str(args.genome)]
@@ -677,7 +675,7 @@ def main():
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
     second = None
-    if world == 1 and args.seq_layout == "window" and args.seq4 == "on" and args.seq_pitch < 0 and not args.no_second_layout:
+    if world == 1 and args.seq_layout == "window" and args.seq4 == "on" and args.wo == "on" and args.seq_pitch < 0 and not args.no_second_layout:
         # The same job as rounds 1-3 measured it (and as the ingests still deliver it with PP_SEQ_LAYOUT=file PP_SEQ4=0): SEQ bytes
         # in the order of the records, no 4-bit mirror -- the lane-group plain class over the bytes.  Measured like the headline.
         def other_layout(wj, what, tail):
@@ -709,9 +707,10 @@ def main():
                     "frac": round(b_alg / (w_kernel * 1e-3) / 1e9 / peak, 4) if w_kernel else 0.0, "traffic": w_traffic,
                     "ms_per_step": round(w_step, 4), "mbp_per_s": round(G_total / 1e6 / (w_step * 1e-3), 1) if w_step else None,
                     "same_polished_bytes": bool(w_polished == polished)}
-        wj = synthjob.with_seq4(synthjob.file_ordered(job), on=False)
-        second = other_layout(wj, "SEQ bytes in the order of the records, no 4-bit mirror (PP_SEQ_LAYOUT=file PP_SEQ4=0: the resident layout "
-                                  "of rounds 1-3; every other array and every result unchanged)", ["--seq-layout", "file", "--seq4", "off"])
+        wj = synthjob.with_wo(synthjob.with_seq4(synthjob.file_ordered(job), on=False), on=False)
+        second = other_layout(wj, "SEQ bytes in the order of the records, no 4-bit mirror of the seq array, no window-order mirror of the "
+                                  "records (PP_SEQ_LAYOUT=file PP_SEQ4=0 PP_WO=0: the resident batch of rounds 1-3; every result unchanged)",
+                              ["--seq-layout", "file", "--seq4", "off", "--wo", "off"])
         del wj
     # What the dominant kernel actually moves, as a rate: the algorithmic fraction above prices a 150-byte read at 150
     # bytes, the memory system fetches the 128-byte lines it touches (2.16 of them at an arbitrary byte offset).  6290 GB/s
@@ -749,7 +748,9 @@ def main():
                                           ("; SEQ bytes in the order of the records (PP_SEQ_LAYOUT=file: not the default layout)" if args.seq_pitch < 0
                                            else ("; SEQ packed back to back in file order" if args.seq_pitch == 0 else f"; SEQ pitch {args.seq_pitch} bytes, file order")))
                                        + ("; with the 4-bit mirror of the seq array the device tokenizer hands over (pp_aln_batch.seq4)" if args.seq4 == "on"
-                                          else "; WITHOUT the 4-bit mirror (PP_SEQ4=0: not the default batch)") + ")",
+                                          else "; WITHOUT the 4-bit mirror (PP_SEQ4=0: not the default batch)")
+                                       + ("; with the window-order mirror of the records both ingests hand over (pp_aln_batch.wo)" if args.wo == "on"
+                                          else "; WITHOUT the window-order mirror of the records (PP_WO=0: not the default batch)") + ")",
                    "parallelism": (("contig-shard" if len(lens) > 1 else "window-tile") if strong else "contig-shard") + f" x{world}"
                    if world > 1 else "single GPU",
                    "alignments_per_gpu": job["part"].n_aln if strong else job["n_aln"]},

@@ -136,7 +136,25 @@ typedef struct {
      * is the same with and without it.  seq must be there all the same: everything that needs a byte as it was delivered
      * (string-keyed tallies, trims through bytes other than A/C/G/T/N/-) reads seq. */
     const uint8_t *seq4;
+    /* Optional (NULL = none): the records once more, in WINDOW ORDER -- n_aln entries of 32 bytes, a permutation of the batch's
+     * records in which the records that start in one 2048-position window of the assembly are adjacent (per SAM file, as the
+     * SEQ bytes of PP_SEQ_WINDOW_GROUPED; inside a window in any order).  Like seq4 it is a mirror, a function of the arrays
+     * above, and a hint: every result is the same with and without it.  The polish reads the records through it when it
+     * is there: a workgroup's records then fall into a handful of windows and its work items are written next to each
+     * other, where the file order scatters them over the whole assembly (the bucketing kernels take 0.15 instead of 0.25 ms
+     * on the 5 Mbp / 200x job).  The library's ingests bring one; pp_polish_add carries it along while every batch of the
+     * job has one. */
+    const struct pp_wo_rec *wo;
 } pp_aln_batch;
+/* one record of pp_aln_batch.wo: the fields the bucketing reads, file_idx = the record's index in the batch's arrays (its
+ * place in file order), op0 = its only CIGAR run (packed as in `cigar`) or PP_WO_MULTI_RUN for a record of several runs
+ * (those are read from n_cig / cig_off / cigar by file_idx) */
+typedef struct pp_wo_rec {
+    uint32_t contig, ref_start, k, seq_len;
+    uint64_t seq_off;
+    uint32_t op0, file_idx;
+} pp_wo_rec;
+#define PP_WO_MULTI_RUN 0xFFFFFFFFu
 /* The library's own producers of batches (pp_ingest_*, pp_dev_ingest_*, pp_shard_split) start every record's SEQ on a multiple
  * of PP_SEQ_ALIGN bytes of the seq array, the bytes in between zero, and lay the SEQ bytes of a SAM file out WINDOW-GROUPED
  * (PP_SEQ_WINDOW_GROUPED below: the default since round 4): the pileup kernel waits for the 128-byte lines a read touches,

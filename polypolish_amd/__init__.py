@@ -42,7 +42,36 @@ class AlnBatch(C.Structure):
     _fields_ = [("n_aln", C.c_uint64), ("contig", C.c_void_p), ("ref_start", C.c_void_p), ("k", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seq_len", C.c_void_p), ("cig_off", C.c_void_p), ("n_cig", C.c_void_p),
                 ("seq", C.c_void_p), ("seq_bytes", C.c_uint64), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64),
-                ("seq4", C.c_void_p)]  # optional 4-bit mirror of seq (include/polypolish_hip.h); None = none
+                ("seq4", C.c_void_p),  # optional 4-bit mirror of seq (include/polypolish_hip.h); None = none
+                ("wo", C.c_void_p)]    # optional window-order mirror of the records (pp_wo_rec[n_aln]); None = none
+
+
+# one record of pp_aln_batch.wo (include/polypolish_hip.h: pp_wo_rec, 32 bytes)
+WO_DTYPE = np.dtype([("contig", np.uint32), ("ref_start", np.uint32), ("k", np.uint32), ("seq_len", np.uint32),
+                     ("seq_off", np.uint64), ("op0", np.uint32), ("file_idx", np.uint32)])
+WO_MULTI_RUN = 0xFFFFFFFF
+
+
+def window_order_mirror(recs, contig_off, used_per_file=None, window=2048):
+    """pp_aln_batch.wo for a batch given as numpy arrays: its records in window order -- per SAM file (used_per_file: good
+    records of every file; None = one file), the records that start in one 2048-position window adjacent, file order inside
+    a window -- as the host ingest writes it."""
+    n = len(recs["contig"])
+    off = np.asarray(contig_off).astype(np.int64)
+    n_win = max(1, (int(off[-1]) + window - 1) // window)
+    c = np.minimum(recs["contig"].astype(np.int64), len(off) - 2)
+    win = np.minimum((off[c] + recs["ref_start"].astype(np.int64)) // window, n_win - 1)
+    file_of = np.zeros(n, dtype=np.int64)
+    if used_per_file is not None:
+        file_of = np.repeat(np.arange(len(used_per_file)), used_per_file)
+    order = np.argsort(file_of * n_win + win, kind="stable")
+    wo = np.zeros(n, dtype=WO_DTYPE)
+    for k in ("contig", "ref_start", "k", "seq_len", "seq_off"):
+        wo[k] = recs[k][order]
+    first = recs["cigar"][np.minimum(recs["cig_off"][order].astype(np.int64), max(len(recs["cigar"]) - 1, 0))] if len(recs["cigar"]) else np.zeros(n, np.uint32)
+    wo["op0"] = np.where(recs["n_cig"][order] == 1, first, WO_MULTI_RUN)
+    wo["file_idx"] = order.astype(np.uint32)
+    return wo
 
 
 class ContigStats(C.Structure):
@@ -319,6 +348,8 @@ def ingest(assembly, sams, max_errors=10, careful=False, seq_layout=None):
             else:
                 arr = np.zeros(0, dtype=dt)
             recs[name] = arr
+        if b.wo and b.n_aln:  # the window-order mirror of the records (pp_aln_batch.wo)
+            recs["wo"] = np.ctypeslib.as_array(C.cast(b.wo, C.POINTER(C.c_uint8)), shape=(int(b.n_aln) * WO_DTYPE.itemsize,)).copy().view(WO_DTYPE)
         return names, descs, off, bases, recs, counts
     finally:
         if g:
@@ -384,6 +415,10 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=
             if m.size:
                 ctx._chk(L.pp_ctx_download(ctx._h, m.ctypes.data, b.seq4, m.nbytes))
             recs["seq4"] = m
+        if b.wo and b.n_aln:
+            w = np.zeros(int(b.n_aln), dtype=WO_DTYPE)
+            ctx._chk(L.pp_ctx_download(ctx._h, w.ctypes.data, b.wo, w.nbytes))
+            recs["wo"] = w
         return names, descs, off, bases, recs, counts
     finally:
         if g:
@@ -460,7 +495,8 @@ class ShardPart:
     def __init__(self, ctx, plan, dest, n_aln, ptrs, seq_bytes, n_cig_total, mem):
         L = lib()
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
+                     ptrs.get("wo") or None)
         self._p = C.c_void_p()
         self._ctx = ctx  # keeps the context (and with it the part's device memory) alive
         rc = L.pp_shard_split(ctx._h if ctx is not None else None, plan._p, dest, C.byref(b), mem, C.byref(self._p))
@@ -671,7 +707,8 @@ class Context:
 
     def polish_add_ptrs(self, n_aln, ptrs: dict, seq_bytes, n_cig_total, mem):
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
+                     ptrs.get("wo") or None)
         self._chk(lib().pp_polish_add(self._h, C.byref(b), mem))
 
     def polish_finish(self):
@@ -686,7 +723,8 @@ class Context:
         off = np.ascontiguousarray(contig_off, dtype=np.uint64)
         p = Params(min_depth, fraction_valid, fraction_invalid)
         b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None)
+                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
+                     ptrs.get("wo") or None)
         n_contigs, G = len(off) - 1, int(off[-1])
         h, off_p, p_ref, b_ref = self._h, off.ctypes.data, C.byref(p), C.byref(b)
         begin, add, finish, set_emit = L.pp_polish_begin, L.pp_polish_add, L.pp_polish_finish, L.pp_polish_set_emit

@@ -272,6 +272,8 @@ struct pp_ingest {
     HugeBuf<uint32_t> contig, ref_start, k, seq_len, n_cig, cigar;
     HugeBuf<uint64_t> seq_off, cig_off, name_off;
     HugeBuf<uint8_t> seq;
+    HugeBuf<pp_wo_rec> wo;  // the records once more, in window order (pp_aln_batch.wo); empty with PP_WO=0
+    bool wo_mirror = true;
     HugeBuf<char> names;  // NUL-separated QNAMEs, one per record
     std::vector<std::thread> reapers;  // parse-time memory of finished files being released in the background
     // After a failed pp_ingest_sam: the byte offset in that file of the first line of the read group that was pending
@@ -436,6 +438,7 @@ extern "C" int pp_ingest_create(const pp_assembly *a, uint32_t max_errors, int c
     g->max_errors = max_errors;
     g->careful = careful != 0;
     if (const char *e = getenv("PP_SEQ_LAYOUT")) g->seq_layout = !strcmp(e, "file") ? PP_SEQ_FILE_ORDER : PP_SEQ_WINDOW_GROUPED;
+    if (const char *e = getenv("PP_WO")) g->wo_mirror = atoi(e) != 0;
     *out = g;
     return PP_OK;
 }
@@ -727,42 +730,52 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
         const uint64_t G_asm = ctg_off[pp_assembly_n_contigs(I->asmb)];
         const size_t n_win = (size_t)std::max<uint64_t>(1, (G_asm + WINDOW - 1) / WINDOW);
         const bool grouped = I->seq_layout == PP_SEQ_WINDOW_GROUPED && n_out > 0;
+        const bool mirror = I->wo_mirror && n_out > 0;  // the window-order mirror of the records: the same multisplit, counting records
         auto window_of = [&](const Rec &a) {
             const uint64_t w = (ctg_off[a.contig] + a.ref_start) / WINDOW;
             return (size_t)std::min<uint64_t>(w, n_win - 1);
         };
         HugeBuf<uint64_t> wcur;  // [part][window]: first the bytes, then where the part's next record of the window goes
-        if (grouped) {
+        HugeBuf<uint64_t> wcnt;  // [part][window]: the same for the records themselves (slots of the window-order mirror)
+        if (grouped || mirror) {
             wcur.resize(threads * n_win);
+            wcnt.resize(threads * n_win);
             parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
                 for (size_t t = lo; t < hi; t++) {
-                    uint64_t *row = wcur.data() + t * n_win;
+                    uint64_t *row = wcur.data() + t * n_win, *crow = wcnt.data() + t * n_win;
                     memset(row, 0, n_win * sizeof(uint64_t));
+                    memset(crow, 0, n_win * sizeof(uint64_t));
                     for (size_t i = 0; i < parts[t].outs.size(); i++) {
                         const OutRec &o = parts[t].outs[i];
-                        row[window_of(*o.rec)] += seq_room(o.star ? o.src->seq_n : o.rec->seq_n);
+                        const size_t w = window_of(*o.rec);
+                        row[w] += seq_room(o.star ? o.src->seq_n : o.rec->seq_n);
+                        crow[w] += 1;
                     }
                 }
             });
-            std::vector<uint64_t> wtot(n_win + 1, 0);
+            std::vector<uint64_t> wtot(n_win + 1, 0), ctot(n_win + 1, 0);
             parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
                 for (size_t w = lo; w < hi; w++) {
-                    uint64_t sum = 0;
-                    for (size_t t = 0; t < threads; t++) sum += wcur[t * n_win + w];
+                    uint64_t sum = 0, cs = 0;
+                    for (size_t t = 0; t < threads; t++) { sum += wcur[t * n_win + w]; cs += wcnt[t * n_win + w]; }
                     wtot[w + 1] = sum;
+                    ctot[w + 1] = cs;
                 }
             });
-            for (size_t w = 0; w < n_win; w++) wtot[w + 1] += wtot[w];
+            for (size_t w = 0; w < n_win; w++) { wtot[w + 1] += wtot[w]; ctot[w + 1] += ctot[w]; }
             parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
                 for (size_t w = lo; w < hi; w++) {
-                    uint64_t run = seq0 + wtot[w];
+                    uint64_t run = seq0 + wtot[w], crun = base + ctot[w];
                     for (size_t t = 0; t < threads; t++) {
-                        const uint64_t v = wcur[t * n_win + w];
+                        const uint64_t v = wcur[t * n_win + w], c = wcnt[t * n_win + w];
                         wcur[t * n_win + w] = run;
+                        wcnt[t * n_win + w] = crun;
                         run += v;
+                        crun += c;
                     }
                 }
             });
+            if (mirror) I->wo.resize(base + n_out);
             lap("window layout");
         }
         parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
@@ -803,6 +816,14 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                     I->cig_off[d] = co;
                     I->n_cig[d] = a.run_n;
                     memcpy(I->cigar.data() + co, o.runs, (size_t)a.run_n * 4);
+                    if (mirror) {  // the record once more, at its place in window order (file order inside a window)
+                        pp_wo_rec w;
+                        w.contig = (uint32_t)a.contig; w.ref_start = (uint32_t)a.ref_start; w.k = o.k; w.seq_len = (uint32_t)sn;
+                        w.seq_off = I->seq_off[d];
+                        w.op0 = a.run_n == 1 ? o.runs[0] : PP_WO_MULTI_RUN;
+                        w.file_idx = (uint32_t)d;
+                        I->wo[wcnt[t * n_win + window_of(a)]++] = w;
+                    }
                     co += a.run_n;
                     I->name_off[d] = no;
                     memcpy(I->names.data() + no, a.name, a.name_n);
@@ -852,6 +873,7 @@ extern "C" void pp_ingest_batch(const pp_ingest *I, pp_aln_batch *out) {
     out->seq = I->seq.data();
     out->seq_bytes = I->seq.size();
     out->seq4 = nullptr;
+    out->wo = I->wo_mirror && I->wo.size() == I->contig.size() && I->contig.size() ? I->wo.data() : nullptr;
     out->cigar = I->cigar.data();
     out->n_cig_total = I->cigar.size();
 }

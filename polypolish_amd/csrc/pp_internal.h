@@ -136,7 +136,8 @@ struct pp_ctx {
 
     // owned device buffers (grow-only, reused across jobs)
     pp::DevBuf b_bases, b_contig_off, b_status;
-    pp::DevBuf b_in[10];  // the accumulated batch arrays (uploaded or gathered); [9] = the 4-bit mirror of [7], the seq array
+    pp::DevBuf b_in[11];  // the accumulated batch arrays (uploaded or gathered); [9] = the 4-bit mirror of [7], the seq array; [10] = the window-order mirror
+    bool acc_wo = false;  // every batch accumulated so far brought a window-order mirror (pp_aln_batch.wo)
     pp::DevBuf b_gstart, b_nkeep, b_aflag, b_hist, b_wincnt, b_winoff, b_entA, b_entB, b_ccnt, b_coff;
     pp::DevBuf b_code, b_winlen, b_winout, b_flag_pos, b_flag_cov, b_flag_scr, b_scratch;
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slab_win, b_slabs, b_ents, b_keys, b_own;

@@ -162,8 +162,11 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
 #ifndef PP_FILL_NT
 #define PP_FILL_NT 0
 #endif
-template <int CW>
-__global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__restrict__ gstart,
+// WO: the records come through the window-order mirror (gstart / nkeep are in mirror order, see k_prep): k, seq_off,
+// seq_len and the file index -- the item's `w` -- are read from it, and the slot of a record's FIRST item is taken once per
+// wave and column (ballot, one returning LDS atomic by the leader): a wave's records mostly go to one window.
+template <int CW, bool WO>
+__global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec *__restrict__ wo, const u32 *__restrict__ gstart,
                                                const u32 *__restrict__ nkeep,
                                                const u32 *__restrict__ kk,
                                                const u64 *__restrict__ seq_off,
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
     const u32 range_lo = crange_lo * (u32)CW;                       // the same range, in windows
     const u32 range_n = min(crange_n * (u32)CW, nwin - range_lo);
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u64 a0 = lo + threadIdx.x; a0 < hi; a0 += 4ull * blockDim.x) {
-        u32 nk4[4], g4[4], k4[4], sl4[4];
+    const u64 a_end = WO ? lo + (hi - lo + 4ull * blockDim.x - 1) / (4ull * blockDim.x) * (4ull * blockDim.x) : hi;  // (WO: whole waves, for the ballots)
+    for (u64 a0 = lo + threadIdx.x; a0 < a_end; a0 += 4ull * blockDim.x) {
+        u32 nk4[4], g4[4], k4[4], sl4[4], fi4[4];
         u64 so4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // four records per trip: their loads are in flight together
@@ -192,19 +196,56 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
             const bool ok = a < hi;
             nk4[u] = ok ? nkeep[a] : 0u;
             g4[u] = ok ? gstart[a] : 0u;
-            k4[u] = ok ? kk[a] : 1u;
-            so4[u] = ok ? seq_off[a] : 0ull;
-            sl4[u] = ok ? seq_len[a] : 0u;
+            if (WO) {
+                pp_wo_rec r{0, 0, 1, 0, 0, 0, 0};
+                if (ok) r = wo[a];
+                k4[u] = r.k; so4[u] = r.seq_off; sl4[u] = r.seq_len; fi4[u] = r.file_idx;
+            } else {
+                k4[u] = ok ? kk[a] : 1u;
+                so4[u] = ok ? seq_off[a] : 0ull;
+                sl4[u] = ok ? seq_len[a] : 0u;
+                fi4[u] = (u32)a;
+            }
             if (ok && blockIdx.y == 0) {  // checks that need k / seq_off (not read by k_prep's fast path)
-                if (k4[u] == 0) report(status, a, DE_BAD_K);
-                else if (so4[u] + sl4[u] > (1ull << 40)) report(status, a, DE_OVERFLOW);
+                if (k4[u] == 0) report(status, fi4[u], DE_BAD_K);
+                else if (so4[u] + sl4[u] > (1ull << 40)) report(status, fi4[u], DE_OVERFLOW);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const u32 word = nk4[u];
+            // WO: the slot of the record's first item (first piece, first window of this pass), one cursor update per wave and column
+            u32 first_slot = 0;
+            bool first_taken = false;
+            if (WO) {
+                u32 key = 0xFFFFFFFFu;
+                if (word) {
+                    const u32 sp0 = (word >> 30) == NKW_INDEL1 ? (((word >> 17) & 1u) ? ((word >> 9) & 0xFFu) : ((word >> 9) & 0xFFu) - 1u)
+                                                               : (word & 0x3FFFFFFFu);  // span of the first piece (for_each_piece)
+                    const u32 w0 = g4[u] / (u32)TILE, w1 = (g4[u] + sp0 - 1u) / (u32)TILE;
+                    const u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
+                    if (sp0 && wa <= wb) key = wa / (u32)CW - crange_lo;
+                }
+                const u32 lane = threadIdx.x & 63u;
+                u32 mine = key;
+                for (;;) {
+                    const u64 todo = __ballot(mine != 0xFFFFFFFFu);
+                    if (!todo) break;
+                    const int lead = __ffsll((long long)todo) - 1;
+                    const u32 kl = (u32)__builtin_amdgcn_readlane((int)mine, lead);
+                    const u64 same = __ballot(mine == kl);
+                    u32 base = 0;
+                    if ((int)lane == lead) base = atomicAdd(&cur[kl], (u32)__popcll(same));
+                    base = (u32)__builtin_amdgcn_readlane((int)base, lead);
+                    if (mine == kl) {
+                        first_slot = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+                        first_taken = true;
+                        mine = 0xFFFFFFFFu;
+                    }
+                }
+            }
             if (!word) continue;
-            const u64 a = a0 + (u64)u * blockDim.x;
+            const u64 a = fi4[u];  // the record's index in file order: the item's `w`
             const u32 kc = kclass_of(k4[u]);
             const u32 cls = word >> 30;
             const u32 ia = (word >> 9) & 0xFFu, idel = (word >> 17) & 1u;  // a one-indel read: run length in front, kind
@@ -231,7 +272,9 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const u32 *__re
                     else so += idel ? ia : ia + 1u;
                 } else fl = cls;
                 for (u32 w = wa; w <= wb && w >= wa; w++) {
-                    u32 slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
+                    u32 slot;
+                    if (WO && first_taken) { slot = first_slot; first_taken = false; }  // (the record's first item: taken with the wave)
+                    else slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
                     uint4 e;
                     e.x = fl ? sp : (u32)so;
                     e.y = (fl ? 0u : (((u32)(so >> 32) & 0xFFu) | (len << 24))) | (kc << 8) | (fl << 16) |

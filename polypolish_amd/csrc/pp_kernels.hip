@@ -223,6 +223,14 @@ __global__ void k_rebase(u64 *seq_off, u64 *cig_off, u64 n, u64 seq_base, u64 ci
     }
 }
 
+__global__ void k_rebase_wo(pp_wo_rec *wo, u64 n, u64 seq_base, u32 idx_base) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        wo[i].seq_off += seq_base;
+        wo[i].file_idx += idx_base;
+    }
+}
+
 // Optional, between pp_polish_begin and the first pp_polish_add: room for what all the batches of the job will hold
 // (a guess is fine: the arrays still grow when it was too small, at the price of a reallocation and a copy).
 extern "C" int pp_polish_reserve(pp_ctx *ctx, uint64_t n_aln, uint64_t seq_bytes, uint64_t n_cig_total) {
@@ -231,11 +239,12 @@ extern "C" int pp_polish_reserve(pp_ctx *ctx, uint64_t n_aln, uint64_t seq_bytes
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_reserve without pp_polish_begin");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     // (room for up to 31 unused bytes at every joint of the seq array, and for its 4-bit mirror)
-    const size_t esz[10] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 1};
-    const uint64_t cnt[10] = {n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, seq_bytes + 4096, n_cig_total, (seq_bytes + 4096) / 2 + 96};
-    const uint64_t used[10] = {ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_seq, ctx->acc_cig, (ctx->acc_seq + 1) / 2};
+    const size_t esz[11] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 1, sizeof(pp_wo_rec)};
+    const uint64_t cnt[11] = {n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, n_aln, seq_bytes + 4096, n_cig_total, (seq_bytes + 4096) / 2 + 96, n_aln};
+    const uint64_t used[11] = {ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_n, ctx->acc_seq, ctx->acc_cig, (ctx->acc_seq + 1) / 2,
+                               ctx->acc_wo ? ctx->acc_n : 0};
     const bool owned = ctx->have_batch && !ctx->batch_borrowed;
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 11; i++)
         if (int rc = dev_grow_keep(ctx, ctx->b_in[i], (size_t)cnt[i] * esz[i], owned ? (size_t)used[i] * esz[i] : 0)) return rc;
     return PP_OK;
 }
@@ -308,6 +317,18 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     if (n && (s0 || c0))
         hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64 *)ctx->b_in[3].p + n0,
                            (u64 *)ctx->b_in[5].p + n0, (u64)n, (u64)s0, (u64)c0);
+    // the window-order mirror of the records (pp_aln_batch.wo) goes along while every batch of the job brings one: a
+    // batch's entries follow those of the batches before it (the windows then come once per batch, like the SEQ bytes
+    // of the files), its seq offsets and file indices rebased like the arrays'
+    static const bool no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
+    ctx->acc_wo = !no_wo && (n0 == 0 || ctx->acc_wo) && (b->wo != nullptr || n == 0);
+    if (ctx->acc_wo && n) {
+        if (int rc = dev_grow_keep(ctx, ctx->b_in[10], (size_t)(n0 + n) * sizeof(pp_wo_rec), (size_t)n0 * sizeof(pp_wo_rec))) return rc;
+        PP_HIPCHK(ctx, hipMemcpyAsync((pp_wo_rec *)ctx->b_in[10].p + n0, b->wo, (size_t)n * sizeof(pp_wo_rec), kind, ctx->stream));
+        if (s0 || n0)
+            hipLaunchKernelGGL(k_rebase_wo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (pp_wo_rec *)ctx->b_in[10].p + n0,
+                               (u64)n, (u64)s0, (u32)n0);
+    }
     if (mem != PP_MEM_DEVICE) PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host / peer buffers are only borrowed for the call
     ctx->acc_n = n0 + n; ctx->acc_seq = s0 + b->seq_bytes; ctx->acc_cig = c0 + b->n_cig_total;
     pp_aln_batch &d = ctx->dbatch;
@@ -317,6 +338,7 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     d.cig_off = (const uint64_t *)ctx->b_in[5].p; d.n_cig = (const uint32_t *)ctx->b_in[6].p;
     d.seq = (const uint8_t *)ctx->b_in[7].p; d.cigar = (const uint32_t *)ctx->b_in[8].p;
     d.seq4 = no_seq4 ? nullptr : (const uint8_t *)ctx->b_in[9].p;
+    d.wo = ctx->acc_wo && ctx->acc_n ? (const pp_wo_rec *)ctx->b_in[10].p : nullptr;
     return PP_OK;
 }
 
@@ -569,19 +591,34 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
     // records of every block per window (two-level path: k_count, per range of windows)
     const bool fused_count = ncoarse <= (uint32_t)COUNT_RANGE;  // the columns (windows, or coarse buckets) fit one LDS range
+    // the records through the batch's window-order mirror when it brings one (pp_aln_batch.wo; PP_WO=0: tuning / tests)
+    static const bool no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
+    const pp_wo_rec *d_wo = no_wo ? nullptr : B.wo;
     timer_begin(ctx, "prep");
-    if (!fused_count)
-        hipLaunchKernelGGL(k_prep<false>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
-                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
-                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full,
-                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, (u32 *)nullptr, d_status);
-    else
-        hipLaunchKernelGGL(k_prep<true>, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, B.contig, B.ref_start,
-                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
-                           (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full,
-                           d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse, d_hist, d_status);
+#define PP_PREP_ARGS dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, B.contig, B.ref_start, (const u64 *)B.seq_off, B.seq_len, \
+                     (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full, \
+                     d_gstart, d_nkeep, (u32 *)(d_meta + 9), nwin, cw, ncoarse
+    if (!fused_count) {
+        if (d_wo) hipLaunchKernelGGL((k_prep<false, true>), PP_PREP_ARGS, (u32 *)nullptr, d_status);
+        else hipLaunchKernelGGL((k_prep<false, false>), PP_PREP_ARGS, (u32 *)nullptr, d_status);
+    } else {
+        if (d_wo) hipLaunchKernelGGL((k_prep<true, true>), PP_PREP_ARGS, d_hist, d_status);
+        else hipLaunchKernelGGL((k_prep<true, false>), PP_PREP_ARGS, d_hist, d_status);
+    }
+#undef PP_PREP_ARGS
     timer_end(ctx);
     timer_begin(ctx, "bucket");
+#define PP_FILL(CWV, ENT, OFF)                                                                                                  \
+    do {                                                                                                                        \
+        if (d_wo)                                                                                                               \
+            hipLaunchKernelGGL((k_fill<CWV, true>), dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, d_gstart,   \
+                               d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,            \
+                               (const u32 *)(OFF), ENT, frange, d_status);                                                     \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_fill<CWV, false>), dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, d_gstart,  \
+                               d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,            \
+                               (const u32 *)(OFF), ENT, frange, d_status);                                                     \
+    } while (0)
     if (two_level) {
         if (!fused_count) {  // more than 16384 coarse buckets (a 2 Gbp assembly): counted range by range
             if (cw == (uint32_t)COARSE_WINDOWS_BIG)
@@ -596,17 +633,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
                            d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
         if (cw == (uint32_t)COARSE_WINDOWS_BIG) {
-            if (n)
-                hipLaunchKernelGGL(k_fill<COARSE_WINDOWS_BIG>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk,
-                                   d_gstart, d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse,
-                                   (const u32 *)d_hist, (const u32 *)d_coff, d_entB, frange, d_status);
+            if (n) PP_FILL(COARSE_WINDOWS_BIG, d_entB, d_coff);
             hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS_BIG>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
                                (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         } else {
-            if (n)
-                hipLaunchKernelGGL(k_fill<COARSE_WINDOWS>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
-                                   d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,
-                                   (const u32 *)d_coff, d_entB, frange, d_status);
+            if (n) PP_FILL(COARSE_WINDOWS, d_entB, d_coff);
             hipLaunchKernelGGL(k_regroup<COARSE_WINDOWS>, dim3(ncoarse), dim3(1024), 0, st, nwin, ncoarse,
                                (const u32 *)d_coff, d_winoff, (const uint4 *)d_entB, d_entA, d_status);
         }
@@ -620,11 +651,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                            d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
                            d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
-        if (n)
-            hipLaunchKernelGGL(k_fill<1>, dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep,
-                               B.k, (const u64 *)B.seq_off, B.seq_len, nwin, nwin, (const u32 *)d_hist,
-                               (const u32 *)d_winoff, d_entA, frange, d_status);
+        if (n) PP_FILL(1, d_entA, d_winoff);
     }
+#undef PP_FILL
     timer_end(ctx);
 
     TileArgs T;

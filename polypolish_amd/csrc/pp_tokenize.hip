@@ -265,10 +265,12 @@ struct OutArrays {
     u8 *seq;
 };
 
-__global__ __launch_bounds__(256) void k_tok_meta(const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
+__global__ __launch_bounds__(256) void k_tok_meta(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
+                                                  const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
                                                   u32 n_aln, const u32 *__restrict__ good, const u32 *__restrict__ kk,
                                                   const u32 *__restrict__ g_seq_len, const u32 *__restrict__ out_idx,
                                                   const u64 *__restrict__ seq_scan, const u64 *__restrict__ cig_scan,
+                                                  const u32 *__restrict__ slot, pp_wo_rec *__restrict__ wo,
                                                   OutArrays O, u64 out_base, u64 seq_base, u64 cig_base) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_aln || !good[r]) return;
@@ -281,6 +283,28 @@ __global__ __launch_bounds__(256) void k_tok_meta(const LineRec *__restrict__ re
     O.n_cig[o] = a.n_runs;
     O.seq_off[o] = seq_base + seq_scan[r];
     O.cig_off[o] = cig_base + cig_scan[r];
+    if (wo) {
+        // the record once more, at its place in window order (pp_aln_batch.wo): one 32-byte store.  op0 = its only CIGAR
+        // run, parsed here from the text (validated by k_tok_parse), or the marker for a record of several runs
+        u32 op0 = PP_WO_MULTI_RUN;
+        if (a.n_runs == 1u) {
+            const u8 *cg = text + line_start(nl_pos, rec_line[r]) + a.cig_off;
+            u64 num = 0;
+            u32 i = 0;
+            for (;;) {  // runs of length zero vanish (get_expanded_cigar): the one run left is the one with a length
+                num = 0;
+                while (cg[i] >= (u8)'0' && cg[i] <= (u8)'9') num = num * 10 + (u64)(cg[i++] - (u8)'0');
+                if (num) break;
+                i++;
+            }
+            op0 = ((u32)num << 4) | (u32)op_code(cg[i]);
+        }
+        pp_wo_rec w;
+        w.contig = a.contig; w.ref_start = a.ref_start; w.k = kk[r]; w.seq_len = g_seq_len[r];
+        w.seq_off = seq_base + seq_scan[r];
+        w.op0 = op0; w.file_idx = (u32)o;
+        wo[out_base + slot[r]] = w;
+    }
 }
 
 __device__ __forceinline__ u8 comp_upper(u8 c) {  // misc.rs:170-182 on the upper-cased base
@@ -379,64 +403,76 @@ __global__ __launch_bounds__(256) void k_tok_seq(const u8 *__restrict__ text, co
 // parse record of every line twice: 0.3 ms per SAM file of 3.3 M records, now 0.05.
 // Inside a window the order is that of the workgroups (file order) and, within one, whatever the LDS atomics make it:
 // seq_off goes with the record, nothing depends on it.
-constexpr u32 WIN_LDS_MAX = 16384;  // windows in LDS (33.5 Mbp); beyond: the global-atomic kernels below
+// Two things are placed at once: a record's SEQ bytes in its window's region of the seq array, and the record itself in the
+// batch's window-order mirror (pp_aln_batch.wo: the records of a window adjacent) -- one 64-bit counter per window, the
+// records in bits 40.. and the bytes below (a file holds < 2^40 SEQ bytes and a window < 2^24 records: MAX_BUCKET).
+constexpr u32 WIN_LDS_MAX = 8192;   // windows in LDS (16.7 Mbp); beyond: the global-atomic kernels below
+constexpr u64 WIN_BYTES_MASK = (1ull << 40) - 1ull;
 __global__ __launch_bounds__(1024) void k_tok_win_hist(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
-                                                       u32 per_block, u32 n_win, u32 *__restrict__ mat) {
-    __shared__ u32 hist[WIN_LDS_MAX];
+                                                       u32 per_block, u32 n_win, u64 *__restrict__ mat) {
+    __shared__ u64 hist[WIN_LDS_MAX];
     for (u32 w = threadIdx.x; w < n_win; w += 1024u) hist[w] = 0;
     __syncthreads();
     const u32 lo = blockIdx.x * per_block, hi = min(n_aln, lo + per_block);
     for (u32 r = lo + threadIdx.x; r < hi; r += 1024u) {
         const u32 w = win_of[r];
-        if (w != WIN_NONE) atomicAdd(&hist[w], seq_room(g_seq_len[r]));
+        if (w != WIN_NONE) atomicAdd(&hist[w], (1ull << 40) | (u64)seq_room(g_seq_len[r]));
     }
     __syncthreads();
     for (u32 w = threadIdx.x; w < n_win; w += 1024u) mat[(u64)blockIdx.x * n_win + w] = hist[w];
 }
-// one wave per window: exclusive scan of its column over the blocks (in place), the total to wbytes
-__global__ __launch_bounds__(256) void k_tok_win_cols(u32 n_win, u32 n_blocks, u32 *__restrict__ mat, u32 *__restrict__ wbytes) {
+// one wave per window: exclusive scan of its column over the blocks (in place), the totals to wbytes / wcount
+__global__ __launch_bounds__(256) void k_tok_win_cols(u32 n_win, u32 n_blocks, u64 *__restrict__ mat, u32 *__restrict__ wbytes,
+                                                      u32 *__restrict__ wcount) {
     const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= n_win) return;
-    u32 carry = 0;
+    u64 carry = 0;
     for (u32 b0 = 0; b0 < n_blocks; b0 += 64u) {
         const u32 b = b0 + lane;
-        const u32 v = b < n_blocks ? mat[(u64)b * n_win + w] : 0u;
-        u32 inc = v;
+        const u64 v = b < n_blocks ? mat[(u64)b * n_win + w] : 0ull;
+        u64 inc = v;
         for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_up(inc, o, 64);
+            const u64 t = (u64)__shfl_up((long long)inc, o, 64);
             if ((int)lane >= o) inc += t;
         }
         if (b < n_blocks) mat[(u64)b * n_win + w] = carry + inc - v;
-        carry += (u32)__shfl((int)inc, 63, 64);
+        carry += (u64)__shfl((long long)inc, 63, 64);
     }
-    if (lane == 0) wbytes[w] = carry;
+    if (lane == 0) { wbytes[w] = (u32)(carry & WIN_BYTES_MASK); wcount[w] = (u32)(carry >> 40); }
 }
 __global__ __launch_bounds__(1024) void k_tok_win_place(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
-                                                        u32 per_block, u32 n_win, const u32 *__restrict__ mat,
-                                                        const u64 *__restrict__ wbase, u64 *__restrict__ seq_pos) {
-    __shared__ u32 cur[WIN_LDS_MAX];
+                                                        u32 per_block, u32 n_win, const u64 *__restrict__ mat,
+                                                        const u64 *__restrict__ wbase, const u32 *__restrict__ wcbase,
+                                                        u64 *__restrict__ seq_pos, u32 *__restrict__ slot) {
+    __shared__ u64 cur[WIN_LDS_MAX];
     for (u32 w = threadIdx.x; w < n_win; w += 1024u) cur[w] = mat[(u64)blockIdx.x * n_win + w];
     __syncthreads();
     const u32 lo = blockIdx.x * per_block, hi = min(n_aln, lo + per_block);
     for (u32 r = lo + threadIdx.x; r < hi; r += 1024u) {
         const u32 w = win_of[r];
-        if (w != WIN_NONE) seq_pos[r] = wbase[w] + (u64)atomicAdd(&cur[w], seq_room(g_seq_len[r]));
+        if (w == WIN_NONE) continue;
+        const u64 old = atomicAdd(&cur[w], (1ull << 40) | (u64)seq_room(g_seq_len[r]));
+        seq_pos[r] = wbase[w] + (old & WIN_BYTES_MASK);
+        slot[r] = wcbase[w] + (u32)(old >> 40);
     }
 }
-// more windows than LDS holds (from 33.5 Mbp on): one global counter per window -- there are enough of them then
+// more windows than LDS holds (from 16.7 Mbp on): global counters per window -- there are enough of them then
 __global__ __launch_bounds__(256) void k_tok_win_bytes_g(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
-                                                         u32 *__restrict__ wbytes) {
+                                                         u32 *__restrict__ wbytes, u32 *__restrict__ wcount) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_aln) return;
     const u32 w = win_of[r];
-    if (w != WIN_NONE) atomicAdd(&wbytes[w], seq_room(g_seq_len[r]));
+    if (w != WIN_NONE) { atomicAdd(&wbytes[w], seq_room(g_seq_len[r])); atomicAdd(&wcount[w], 1u); }
 }
 __global__ __launch_bounds__(256) void k_tok_win_place_g(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
-                                                         const u64 *__restrict__ wbase, u32 *__restrict__ wcur, u64 *__restrict__ seq_pos) {
+                                                         const u64 *__restrict__ wbase, const u32 *__restrict__ wcbase, u32 *__restrict__ wcur,
+                                                         u32 *__restrict__ wccur, u64 *__restrict__ seq_pos, u32 *__restrict__ slot) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_aln) return;
     const u32 w = win_of[r];
-    if (w != WIN_NONE) seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], seq_room(g_seq_len[r]));
+    if (w == WIN_NONE) return;
+    seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], seq_room(g_seq_len[r]));
+    slot[r] = wcbase[w] + atomicAdd(&wccur[w], 1u);
 }
 
 __global__ __launch_bounds__(256) void k_tok_cigar(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
@@ -473,7 +509,9 @@ struct pp_dev_ingest {
     pp::DevBuf t_slots, t_off, t_names, t_ctgoff;
     u32 t_mask = 0;
     int seq_layout = PP_SEQ_WINDOW_GROUPED;  // the default since round 4 (PP_SEQ_LAYOUT=file: in the order of the records)
-    pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos, d_win;
+    pp::DevBuf d_wbytes, d_wbase, d_wcur, d_seqpos, d_win, d_wcount, d_wcbase, d_slot;
+    pp::DevBuf o_wo;         // the batch's window-order mirror (pp_aln_batch.wo)
+    bool wo_mirror = true;   // PP_WO=0: none
     // per-file scratch
     pp::DevBuf d_text, d_blk, d_blkoff, d_nl, d_rec, d_isaln, d_recofline, d_recline, d_isstart, d_grpofrec, d_gfirst,
         d_good, d_k, d_src, d_gseq, d_groom, d_gcig, d_outidx, d_seqscan, d_cigscan, d_status, d_sums, d_sumsoff, d_pass;
@@ -526,6 +564,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
     D->asmb = a;
     D->max_errors = max_errors;
     if (const char *e = getenv("PP_SEQ4")) D->seq4 = atoi(e) != 0;  // PP_SEQ4=0: no 4-bit mirror
+    if (const char *e = getenv("PP_WO")) D->wo_mirror = atoi(e) != 0;  // PP_WO=0: no window-order mirror of the records
     D->careful = careful != 0;
     // RNAME table
     const u32 nc = pp_assembly_n_contigs(a);
@@ -575,7 +614,7 @@ extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     if (D->up_gate) (void)hipEventDestroy(D->up_gate);
     pp::dev_free(D->d_text2);
     (void)hipStreamSynchronize(D->ctx->stream);
-    pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->d_win, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
+    pp::DevBuf *all[] = {&D->t_ctgoff, &D->d_wbytes, &D->d_wbase, &D->d_wcur, &D->d_seqpos, &D->d_win, &D->d_wcount, &D->d_wcbase, &D->d_slot, &D->o_wo, &D->t_slots, &D->t_off, &D->t_names, &D->d_text, &D->d_blk, &D->d_blkoff, &D->d_nl, &D->d_rec,
                          &D->d_isaln, &D->d_recofline, &D->d_recline, &D->d_isstart, &D->d_grpofrec, &D->d_gfirst, &D->d_good,
                          &D->d_k, &D->d_src, &D->d_gseq, &D->d_groom, &D->d_gcig, &D->d_outidx, &D->d_seqscan, &D->d_cigscan, &D->d_status, &D->d_sums, &D->d_sumsoff, &D->d_pass,
                          &D->o_contig, &D->o_ref_start, &D->o_k, &D->o_seq_len, &D->o_n_cig, &D->o_cigar, &D->o_seq_off,
@@ -609,6 +648,7 @@ extern "C" void pp_dev_ingest_batch(const pp_dev_ingest *D, pp_aln_batch *out) {
     out->seq = (const u8 *)D->o_seq.p;
     out->seq_bytes = D->seq_bytes;
     out->seq4 = D->mirror() && D->seq_bytes ? (const u8 *)D->o_seq4.p : nullptr;
+    out->wo = D->wo_mirror && D->n_out ? (const pp_wo_rec *)D->o_wo.p : nullptr;
     out->cigar = (const u32 *)D->o_cigar.p;
     out->n_cig_total = D->n_cig_total;
 }
@@ -890,37 +930,49 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
         if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_good.p, (u64)n_aln, (u32 *)D->d_outidx.p))) return rc;
         if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_gcig.p, (u64)n_aln, (u64 *)D->d_cigscan.p))) return rc;
         if (timing) lap("groups + gates");
-        // where every good record's SEQ bytes go inside this file's stretch of the seq array
-        if (!window_layout) {  // in file order: a scan of the rooms
+        // where every good record's SEQ bytes go inside this file's stretch of the seq array, and -- for the batch's
+        // window-order mirror -- where the record itself goes among the file's records in window order
+        if (!window_layout) {  // SEQ bytes in file order: a scan of the rooms
             hipLaunchKernelGGL(k_tok_room, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, (const u32 *)D->d_gseq.p, (u32 *)D->d_groom.p);
             if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_groom.p, (u64)n_aln, (u64 *)D->d_seqscan.p))) return rc;
-            seq_place = (const u64 *)D->d_seqscan.p;
-            seq_total_at = (const u64 *)D->d_seqscan.p + n_aln;
-        } else {  // window-grouped: a multisplit of the rooms into the windows the records start in (see k_tok_win_hist)
+        }
+        if (window_layout || D->wo_mirror) {  // the multisplit into the windows the records start in (see k_tok_win_hist)
             ENS(d_wbytes, ((u64)n_win + 1) * 4); ENS(d_wbase, ((u64)n_win + 1) * 8); ENS(d_seqpos, (u64)n_aln * 8);
+            ENS(d_wcount, ((u64)n_win + 1) * 4); ENS(d_wcbase, ((u64)n_win + 1) * 4); ENS(d_slot, (u64)n_aln * 4);
             if (n_win <= WIN_LDS_MAX) {
                 // 16384 records per workgroup, more when the matrix would pass 1024 rows
                 const u32 per_block = std::max<u32>(16384u, (u32)((((u64)n_aln + 1023u) / 1024u + 1023u) & ~1023ull));
                 const u32 nb = (n_aln + per_block - 1u) / per_block;
-                ENS(d_wcur, (u64)nb * n_win * 4);
+                ENS(d_wcur, (u64)nb * n_win * 8);
                 hipLaunchKernelGGL(k_tok_win_hist, dim3(nb), dim3(1024), 0, st, (const u32 *)D->d_win.p, (const u32 *)D->d_gseq.p, n_aln,
-                                   per_block, n_win, (u32 *)D->d_wcur.p);
-                hipLaunchKernelGGL(k_tok_win_cols, dim3((n_win + 3u) / 4u), dim3(256), 0, st, n_win, nb, (u32 *)D->d_wcur.p, (u32 *)D->d_wbytes.p);
+                                   per_block, n_win, (u64 *)D->d_wcur.p);
+                hipLaunchKernelGGL(k_tok_win_cols, dim3((n_win + 3u) / 4u), dim3(256), 0, st, n_win, nb, (u64 *)D->d_wcur.p, (u32 *)D->d_wbytes.p,
+                                   (u32 *)D->d_wcount.p);
                 hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p);
+                hipLaunchKernelGGL(k_tscan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_wcount.p, (u64)n_win, (u32 *)D->d_wcbase.p);
                 hipLaunchKernelGGL(k_tok_win_place, dim3(nb), dim3(1024), 0, st, (const u32 *)D->d_win.p, (const u32 *)D->d_gseq.p, n_aln,
-                                   per_block, n_win, (const u32 *)D->d_wcur.p, (const u64 *)D->d_wbase.p, (u64 *)D->d_seqpos.p);
+                                   per_block, n_win, (const u64 *)D->d_wcur.p, (const u64 *)D->d_wbase.p, (const u32 *)D->d_wcbase.p,
+                                   (u64 *)D->d_seqpos.p, (u32 *)D->d_slot.p);
             } else {
-                ENS(d_wcur, (u64)n_win * 4);
+                ENS(d_wcur, (u64)n_win * 8);  // two u32 cursors per window
                 PP_HIPCHK(ctx, hipMemsetAsync(D->d_wbytes.p, 0, ((size_t)n_win + 1) * 4, st));
-                PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 4, st));
+                PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcount.p, 0, ((size_t)n_win + 1) * 4, st));
+                PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 8, st));
                 hipLaunchKernelGGL(k_tok_win_bytes_g, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const u32 *)D->d_win.p,
-                                   (const u32 *)D->d_gseq.p, n_aln, (u32 *)D->d_wbytes.p);
+                                   (const u32 *)D->d_gseq.p, n_aln, (u32 *)D->d_wbytes.p, (u32 *)D->d_wcount.p);
                 if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
+                if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wcount.p, (u64)n_win, (u32 *)D->d_wcbase.p))) return rc;
                 hipLaunchKernelGGL(k_tok_win_place_g, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const u32 *)D->d_win.p,
-                                   (const u32 *)D->d_gseq.p, n_aln, (const u64 *)D->d_wbase.p, (u32 *)D->d_wcur.p, (u64 *)D->d_seqpos.p);
+                                   (const u32 *)D->d_gseq.p, n_aln, (const u64 *)D->d_wbase.p, (const u32 *)D->d_wcbase.p, (u32 *)D->d_wcur.p,
+                                   (u32 *)D->d_wcur.p + n_win, (u64 *)D->d_seqpos.p, (u32 *)D->d_slot.p);
             }
+        }
+        if (window_layout) {
             seq_place = (const u64 *)D->d_seqpos.p;
             seq_total_at = (const u64 *)D->d_wbase.p + n_win;
+        } else {
+            seq_place = (const u64 *)D->d_seqscan.p;
+            seq_total_at = (const u64 *)D->d_seqscan.p + n_aln;
         }
         if (timing) lap(window_layout ? "window layout" : "file-order layout");
     }
@@ -958,13 +1010,15 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
     GROW(o_seq_off, 8, no + r_good, no); GROW(o_cig_off, 8, no + r_good, no);
     GROW(o_seq, 1, D->seq_bytes + r_seq + 64, D->seq_bytes); GROW(o_cigar, 4, D->n_cig_total + r_cig, D->n_cig_total);
     if (D->mirror()) GROW(o_seq4, 1, (D->seq_bytes + r_seq) / 2 + 96, (D->seq_bytes + 1) / 2);
+    if (D->wo_mirror) GROW(o_wo, sizeof(pp_wo_rec), no + r_good, no);
 #undef GROW
     OutArrays O{(u32 *)D->o_contig.p, (u32 *)D->o_ref_start.p, (u32 *)D->o_k.p, (u32 *)D->o_seq_len.p, (u32 *)D->o_n_cig.p,
                 (u32 *)D->o_cigar.p, (u64 *)D->o_seq_off.p, (u64 *)D->o_cig_off.p, (u8 *)D->o_seq.p};
-    hipLaunchKernelGGL(k_tok_meta, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const LineRec *)D->d_rec.p,
+    hipLaunchKernelGGL(k_tok_meta, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p, (const LineRec *)D->d_rec.p,
                        (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p, (const u32 *)D->d_k.p,
                        (const u32 *)D->d_gseq.p, (const u32 *)D->d_outidx.p, seq_place,
-                       (const u64 *)D->d_cigscan.p, O, no, D->seq_bytes, D->n_cig_total);
+                       (const u64 *)D->d_cigscan.p, D->wo_mirror ? (const u32 *)D->d_slot.p : (const u32 *)nullptr,
+                       D->wo_mirror ? (pp_wo_rec *)D->o_wo.p : (pp_wo_rec *)nullptr, O, no, D->seq_bytes, D->n_cig_total);
     // the SEQ bytes and, in the same pass, their 4-bit mirror (this file's stretch of the seq array starts on a multiple of
     // PP_SEQ_ALIGN: every stretch so far was a sum of rooms)
     hipLaunchKernelGGL(k_tok_seq, dim3((unsigned)(((u64)n_aln * 8 + 255) / 256)), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,

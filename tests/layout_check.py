@@ -66,3 +66,33 @@ def check_seq_layout(recs, contig_off, used_per_file, grouped=True, file_order_i
                 assert (np.diff(o)[same] > 0).all(), "inside a window the records come in file order"
         lo = hi
     assert end_prev == len(recs["seq"])
+
+
+def check_window_order_mirror(recs, contig_off, used_per_file, file_order_inside=False):
+    """pp_aln_batch.wo (include/polypolish_hip.h): a permutation of the batch's records, every entry a copy of its record's
+    fields (op0 = the only CIGAR run, or the marker for a record of several), a file's records in one stretch, inside it the
+    windows the records start in in order (file_order_inside: and inside a window the records in file order -- the host
+    ingest; the device tokenizer leaves that to its atomics)."""
+    wo = recs["wo"]
+    n = len(recs["contig"])
+    assert len(wo) == n
+    fi = wo["file_idx"].astype(np.int64)
+    assert np.array_equal(np.sort(fi), np.arange(n)), "not a permutation of the records"
+    for k in ("contig", "ref_start", "k", "seq_len", "seq_off"):
+        assert np.array_equal(wo[k], recs[k][fi]), k
+    one = recs["n_cig"][fi] == 1
+    assert (wo["op0"][~one] == 0xFFFFFFFF).all()
+    assert np.array_equal(wo["op0"][one], recs["cigar"][recs["cig_off"][fi][one].astype(np.int64)])
+    off = np.asarray(contig_off).astype(np.int64)
+    n_win = max(1, (int(off[-1]) + WINDOW - 1) // WINDOW)
+    win = np.minimum((off[wo["contig"]] + wo["ref_start"].astype(np.int64)) // WINDOW, n_win - 1)
+    lo = 0
+    for cnt in used_per_file:
+        hi = lo + cnt
+        assert ((fi[lo:hi] >= lo) & (fi[lo:hi] < hi)).all(), "a file's records take one stretch of the mirror"
+        assert (np.diff(win[lo:hi]) >= 0).all(), "inside a file's stretch the windows come in order"
+        if file_order_inside:
+            same = np.diff(win[lo:hi]) == 0
+            assert (np.diff(fi[lo:hi])[same] > 0).all(), "inside a window the records come in file order"
+        lo = hi
+    assert lo == n

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import synth
-from layout_check import check_seq_layout, same_records
+from layout_check import check_seq_layout, check_window_order_mirror, same_records
 
 pytestmark = pytest.mark.gpu
 C_u64 = ctypes.c_uint64
@@ -36,9 +36,11 @@ def _seqs(fasta_bytes):
 
 
 def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False, min_depth=5, fraction_valid=0.5,
-                         fraction_invalid=0.2):
+                         fraction_invalid=0.2, wo=None):
     """The records as ONE device-resident batch that is polished in place (what the device tokenizer hands over), with or
-    without the 4-bit mirror of the seq array (pp_aln_batch.seq4)."""
+    without the 4-bit mirror of the seq array (pp_aln_batch.seq4) and the window-order mirror of the records
+    (pp_aln_batch.wo; wo = True: as the host ingest orders it, "shuffled": the same entries in a random order -- the mirror
+    is a hint, any permutation of the records must give the same results)."""
     import torch
     dev = torch.device("cuda:0")
     t = {k: torch.from_numpy(np.ascontiguousarray(recs[k], dtype=dt)).to(dev) for k, dt in pp.REC_FIELDS}
@@ -47,6 +49,12 @@ def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False
     if seq4:
         mirror = torch.from_numpy(pp.pack_seq4(recs["seq"])).to(dev)
         ptrs["seq4"] = mirror.data_ptr()
+    if wo:
+        w = pp.window_order_mirror(recs, contig_off)
+        if wo == "shuffled":
+            w = w[np.random.default_rng(len(w)).permutation(len(w))]
+        wt = torch.from_numpy(np.ascontiguousarray(w).view(np.uint8)).to(dev)
+        ptrs["wo"] = wt.data_ptr()
     torch.cuda.synchronize()
     pp.lib().pp_polish_set_debug(ctx._h, int(positions))
     try:
@@ -109,6 +117,19 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         assert m["polished"] == want["polished"]
         m = _polish_device_batch(ctx, pp, contig_off, bases, recs, False, positions=False, **kw)
         assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
+        # ... and with the window-order mirror of the records (pp_aln_batch.wo): k_prep and k_fill then walk the records
+        # through it (gstart / nkeep in mirror order, items numbered by file index, one histogram / cursor update per wave and
+        # window), per position with the debug planes and bytes without -- as the ingests order it, and in a random order
+        for order in (True, "shuffled"):
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, order is True, positions=True, wo=order, **kw)
+            for k in POS_KEYS:
+                bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
+                assert len(bad) == 0, ("wo", order, k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
+            assert m["polished"] == want["polished"]
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, order is True, positions=False, wo=order, **kw)
+            assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
+            for c in range(len(off) - 1):
+                assert m["stats"][c]["changed"] == got["stats"][c]["changed"], ("wo", order, c)
         # What the pileup kernel decides BY ITSELF (debug level 3): a position with depth shares that are not a multiple of
         # the window's fixed-point unit is voted from the interval its depth is known to lie in, and only replayed in
         # file order where a step of the vote (pileup.rs:70-72,114) falls inside it.  Tallies, both thresholds and the
@@ -715,14 +736,18 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     check_seq_layout(flat_d, off, used, grouped=False)
     _check_mirror(pp, flat_d, expect=True)
     for k in flat_h:
-        assert np.array_equal(flat_h[k], flat_d[k]), k
+        if k != "wo":
+            assert np.array_equal(flat_h[k], flat_d[k]), k
     same_records(want, flat_h)
+    for g, inside in ((want, True), (got, False), (flat_h, True), (flat_d, False)):
+        check_window_order_mirror(g, off, used, file_order_inside=inside)   # pp_aln_batch.wo of every batch
     res = ctx.polish_records(off, bases, got)
     assert res["polished"] == orc.polish_records(off, bases, want)["polished"]
     exe = os.path.join(ROOT, "bin", "polypolish")
     oracle_fasta = orc.polish_files(ds["fasta"], sams)["fasta"]
     for env in (dict(), dict(PP_SEQ_LAYOUT="window"), dict(PP_SEQ_LAYOUT="file"), dict(PP_SEQ4="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0"),
-                dict(PP_DEVICE_INGEST="0"), dict(PP_DEVICE_INGEST="0", PP_SEQ_LAYOUT="file"), dict(PP_DEVICE_INGEST="0", PP_SEQ4="0")):
+                dict(PP_DEVICE_INGEST="0"), dict(PP_DEVICE_INGEST="0", PP_SEQ_LAYOUT="file"), dict(PP_DEVICE_INGEST="0", PP_SEQ4="0"),
+                dict(PP_WO="0"), dict(PP_DEVICE_INGEST="0", PP_WO="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0")):
         r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout == oracle_fasta, (env, r.stderr[-400:])
 
@@ -764,9 +789,14 @@ def _same_ingest(pp, ctx, fasta, sams, **kw):
             check_seq_layout(got[4], want[2], used, grouped=True)
         else:
             for k in want[4]:
-                assert np.array_equal(got[4][k], want[4][k]), k
+                if k != "wo":  # (inside a window the tokenizer's mirror is in the order of its atomics)
+                    assert np.array_equal(got[4][k], want[4][k]), k
         # the 4-bit mirror the tokenizer hands over with its batch (pp_aln_batch.seq4): base i of the seq ARRAY in nibble i
         _check_mirror(pp, got[4], expect=os.environ.get("PP_SEQ4") != "0")
+        # the window-order mirror of the records (pp_aln_batch.wo) of both ingests
+        if len(want[4]["contig"]):
+            check_window_order_mirror(want[4], want[2], [c[1] for c in want[5]], file_order_inside=True)
+            check_window_order_mirror(got[4], want[2], [c[1] for c in want[5]])
     return want, we
 
 

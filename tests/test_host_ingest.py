@@ -12,7 +12,7 @@ import pytest
 
 import polypolish_amd as pp
 import synth
-from layout_check import check_seq_layout, same_records
+from layout_check import check_seq_layout, check_window_order_mirror, same_records
 
 ROOT = pp.ROOT
 
@@ -99,6 +99,7 @@ def test_ingest_records_reproduce_the_text_path(orc, tmp_path, case, careful):
     # (file order inside a window, whatever the thread count), in the order of the records on request -- same records
     used = [c[1] for c in counts]
     check_seq_layout(recs, off, used, grouped=True, file_order_inside=True)
+    check_window_order_mirror(recs, off, used, file_order_inside=True)   # pp_aln_batch.wo: the records once more, in window order
     for layout, env in ((0, None), (None, "file")):
         if env:
             os.environ["PP_SEQ_LAYOUT"] = env
@@ -108,6 +109,7 @@ def test_ingest_records_reproduce_the_text_path(orc, tmp_path, case, careful):
             os.environ.pop("PP_SEQ_LAYOUT", None)
         assert counts_f == counts
         check_seq_layout(flat, off, used, grouped=False)
+        check_window_order_mirror(flat, off, used, file_order_inside=True)   # (the mirror does not depend on where the SEQ bytes go)
         same_records(flat, recs)
 
 
@@ -402,4 +404,5 @@ def test_slices_of_a_sam_file_start_on_read_group_boundaries(tmp_path):
     _, _, _, _, want_f, _ = pp.ingest(str(fa), [str(whole)], seq_layout=0)
     _, _, _, _, got_f, _ = pp.ingest(str(fa), paths, seq_layout=0)
     for k in want_f:
-        assert np.array_equal(want_f[k], got_f[k]), k
+        if k != "wo":  # (the window-order mirror is per FILE, like the window-grouped SEQ bytes)
+            assert np.array_equal(want_f[k], got_f[k]), k

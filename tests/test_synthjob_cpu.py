@@ -67,6 +67,13 @@ def test_text_and_records_describe_the_same_job(orc, tmp_path):
     assert sum(c[1] for c in counts) == job["n_aln"]
     for k in h:
         assert np.array_equal(h[k], recs[k]), k
+    # ... and the window-order mirror of the records the ingest hands over with them (pp_aln_batch.wo) is the one the bench
+    # keeps resident (tools/synthjob.py wo_of) -- and the one the binding's numpy definition gives
+    wo = synthjob.wo_of(job).numpy().view(np.uint8).reshape(-1).view(pp.WO_DTYPE)
+    for k in pp.WO_DTYPE.names:
+        assert np.array_equal(wo[k], recs["wo"][k]), k
+    ref = pp.window_order_mirror(recs, off, [c[1] for c in counts])
+    assert all(np.array_equal(ref[k], recs["wo"][k]) for k in pp.WO_DTYPE.names)
     assert int((h["k"] == 5).sum()) > 1000
 
 

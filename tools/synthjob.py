@@ -430,6 +430,40 @@ def with_seq4(job, on=True):
     return out
 
 
+def wo_of(job, window=2048):
+    """The window-order mirror of the job's records (pp_aln_batch.wo: 32 bytes per record -- contig, ref_start, k, seq_len,
+    seq_off (8), op0, file_idx), as the host ingest writes it: per SAM file, the records that start in one 2048-position
+    window adjacent, file order inside a window.  An int32 tensor [n, 8] on the records' device."""
+    r = job["recs"]
+    n = job["n_aln"]
+    dev = r["seq"].device
+    n_win = max(1, (int(job["G"]) + window - 1) // window)
+    win = torch.clamp(job["gstart"] // window, max=n_win - 1)
+    n1 = job.get("file_used", [n, 0])[0]
+    file_of = (torch.arange(n, device=dev) >= n1).long()
+    order = torch.argsort(file_of * n_win + win, stable=True)
+    wo = torch.empty((n, 8), dtype=torch.int32, device=dev)
+    wo[:, 0] = r["contig"][order]
+    wo[:, 1] = r["ref_start"][order]
+    wo[:, 2] = r["k"][order]
+    wo[:, 3] = r["seq_len"][order]
+    so = r["seq_off"][order]
+    wo[:, 4] = (so & 0xFFFFFFFF).to(torch.int64).where((so & 0xFFFFFFFF) < 2 ** 31, (so & 0xFFFFFFFF) - 2 ** 32).int()
+    wo[:, 5] = (so >> 32).int()
+    first = r["cigar"][r["cig_off"][order]]
+    wo[:, 6] = torch.where(r["n_cig"][order] == 1, first, torch.full_like(first, -1))
+    wo[:, 7] = order.int()
+    return wo.contiguous()
+
+
+def with_wo(job, on=True):
+    """The job with (or without) the window-order mirror of its records: job["wo"], handed to the library as pp_aln_batch.wo."""
+    out = dict(job)
+    out.pop("_prepared", None)
+    out["wo"] = wo_of(job) if on else None
+    return out
+
+
 def with_pitch(job, pitch):
     """The same job with every read's SEQ bytes starting on a multiple of `pitch` bytes (an experiment of DESIGN.md section
     9: 150-byte reads at pitch 160 start on 32-byte boundaries and touch 2.0 instead of 2.16 lines of 128 bytes)."""
