@@ -223,7 +223,7 @@ def end_to_end(device, config, lens, coverage, repeat, seed, keep_dir=None, reci
                     f"{n_rec} records ({n_secondary} secondary with SEQ '*'), {text_bytes / 1e9:.2f} GB of text "
                     f"(QUAL strings included), recipe {recipe} {planted}, generated in {gen_s:.1f} s",
            "host_cores": os.cpu_count(), "text_bytes": text_bytes}
-    rep = 1 if big else 2
+    rep = 2
     try:
         env = dict(os.environ)
         env["PP_DEVICE_INGEST"] = "1"

@@ -242,3 +242,9 @@ extern "C" int pp_filter_kernel_times(pp_ctx *ctx, pp_kernel_times *out) {
     *out = ctx->last_times;
     return PP_OK;
 }
+
+// (see pp_tokenize_warm_: the code object of this translation unit is loaded by its first launch)
+__global__ void k_filter_warm(uint32_t *p) {
+    if (p) p[threadIdx.x] = 0;
+}
+extern "C" void pp_filter_warm_(hipStream_t st) { hipLaunchKernelGGL(k_filter_warm, dim3(1), dim3(64), 0, st, (uint32_t *)nullptr); }

@@ -196,10 +196,10 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
             const bool ok = a < hi;
             nk4[u] = ok ? nkeep[a] : 0u;
             g4[u] = ok ? gstart[a] : 0u;
-            if (WO) {
-                pp_wo_rec r{0, 0, 1, 0, 0, 0, 0};
-                if (ok) r = wo[a];
-                k4[u] = r.k; so4[u] = r.seq_off; sl4[u] = r.seq_len; fi4[u] = r.file_idx;
+            if (WO) {  // the mirror's 32-byte record as two 16-byte loads
+                uint4 qa = make_uint4(0, 0, 1, 0), qb = make_uint4(0, 0, 0, 0);
+                if (ok) { qa = ((const uint4 *)wo)[2 * a]; qb = ((const uint4 *)wo)[2 * a + 1]; }
+                k4[u] = qa.z; sl4[u] = qa.w; so4[u] = (u64)qb.x | ((u64)qb.y << 32); fi4[u] = qb.w;
             } else {
                 k4[u] = ok ? kk[a] : 1u;
                 so4[u] = ok ? seq_off[a] : 0ull;

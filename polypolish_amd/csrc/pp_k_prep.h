@@ -201,35 +201,51 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     };
     u32 fast_len = 0;  // the longest fast-class read this thread saw: picks the lane-group width of k_tile's plain class
     if (WO) {
-        // the mirror: one 32-byte record per lane (two 16-byte loads), nothing dependent but the contig table
-        const u64 span = (hi - lo + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves: the ballots below need every lane
-        for (u64 a = lo + threadIdx.x; a < lo + span; a += blockDim.x) {
-            const bool in = a < hi;
-            pp_wo_rec r{0, 0, 0, 0, 0, 0, 0};
-            if (in) r = wo[a];
-            const u32 cc = min(r.contig, n_contigs - 1u);
-            const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1], gb = g_base[cc];
-            bool bulk = in && r.contig < n_contigs && r.op0 != PP_WO_MULTI_RUN && (r.op0 & 15u) == PP_OP_M && (r.op0 >> 4) == r.seq_len &&
-                        r.seq_len > 0 && r.seq_len <= FAST_MAX_LEN && (u64)r.ref_start + r.seq_len <= c_hi - c_lo;
-            // what finish() will make of a bulk record, as far as the histogram's first entry goes (the same tests)
-            u32 g_out = (u32)(gb + r.ref_start);
-            bool kept = bulk;
-            if (bulk) {
-                if (own && ((u64)r.ref_start + r.seq_len <= own[2 * r.contig] || r.ref_start >= own[2 * r.contig + 1])) kept = false;
-                if (gb == ~0ull) kept = false;
-                if (slice && kept && ((u64)r.ref_start < slice[2 * r.contig] || (u64)r.ref_start + r.seq_len > slice[2 * r.contig + 1])) kept = false;  // (finish reports DE_HALO)
+        // the mirror: one 32-byte record per lane as two 16-byte loads, two records per trip in flight; nothing dependent
+        // but the contig table
+        constexpr int WU = 2;
+        const uint4 *wq = (const uint4 *)wo;
+        const u64 trip = (u64)WU * blockDim.x;
+        const u64 span = (hi - lo + trip - 1) / trip * trip;  // whole waves and whole trips: the ballots below need every lane
+        for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
+            uint4 qa[WU], qb[WU];
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);  // clamped: the loads are unconditional
+                qa[u] = wq[2 * a];
+                qb[u] = wq[2 * a + 1];
             }
-            if (COUNT) count_first_by_wave(kept, min(g_out / (u32)TILE, nwin - 1u) / cw);
-            if (bulk) {
-                fast_len = max(fast_len, r.seq_len);
-                finish(a, r.file_idx, r.contig, r.ref_start, g_out, r.seq_len, 0u, !kept || !COUNT);
-            } else if (in) {
-                const u32 slot = atomicAdd(&n_later, 1u);
-                if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
-                else {
-                    const u32 fi = r.file_idx;
-                    const bool multi = r.op0 == PP_WO_MULTI_RUN;
-                    general(a, fi, r.contig, multi ? n_cig[fi] : 1u, r.seq_len, r.ref_start, r.seq_off, cig_off[fi], c_lo, c_hi);
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const u64 a = a0 + (u64)u * blockDim.x;
+                const bool in = a < hi;
+                pp_wo_rec r;
+                r.contig = qa[u].x; r.ref_start = qa[u].y; r.k = qa[u].z; r.seq_len = qa[u].w;
+                r.seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32); r.op0 = qb[u].z; r.file_idx = qb[u].w;
+                const u32 cc = min(r.contig, n_contigs - 1u);
+                const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1], gb = g_base[cc];
+                bool bulk = in && r.contig < n_contigs && r.op0 != PP_WO_MULTI_RUN && (r.op0 & 15u) == PP_OP_M && (r.op0 >> 4) == r.seq_len &&
+                            r.seq_len > 0 && r.seq_len <= FAST_MAX_LEN && (u64)r.ref_start + r.seq_len <= c_hi - c_lo;
+                // what finish() will make of a bulk record, as far as the histogram's first entry goes (the same tests)
+                u32 g_out = (u32)(gb + r.ref_start);
+                bool kept = bulk;
+                if (bulk) {
+                    if (own && ((u64)r.ref_start + r.seq_len <= own[2 * r.contig] || r.ref_start >= own[2 * r.contig + 1])) kept = false;
+                    if (gb == ~0ull) kept = false;
+                    if (slice && kept && ((u64)r.ref_start < slice[2 * r.contig] || (u64)r.ref_start + r.seq_len > slice[2 * r.contig + 1])) kept = false;  // (finish reports DE_HALO)
+                }
+                if (COUNT) count_first_by_wave(kept, min(g_out / (u32)TILE, nwin - 1u) / cw);
+                if (bulk) {
+                    fast_len = max(fast_len, r.seq_len);
+                    finish(a, r.file_idx, r.contig, r.ref_start, g_out, r.seq_len, 0u, !kept || !COUNT);
+                } else if (in) {
+                    const u32 slot = atomicAdd(&n_later, 1u);
+                    if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
+                    else {
+                        const u32 fi = r.file_idx;
+                        const bool multi = r.op0 == PP_WO_MULTI_RUN;
+                        general(a, fi, r.contig, multi ? n_cig[fi] : 1u, r.seq_len, r.ref_start, r.seq_off, cig_off[fi], c_lo, c_hi);
+                    }
                 }
             }
         }

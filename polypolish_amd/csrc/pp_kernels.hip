@@ -973,6 +973,8 @@ extern "C" int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out) {
 }
 
 // ---- context -----------------------------------------------------------------------------------
+extern "C" void pp_tokenize_warm_(hipStream_t st);
+extern "C" void pp_filter_warm_(hipStream_t st);
 __global__ void k_warm(uint32_t *p) {
     if (p) p[threadIdx.x] = 0;
 }
@@ -1012,8 +1014,10 @@ extern "C" int pp_ctx_create_async(int device, pp_ctx **out) {
     ctx->init_pending = true;
     ctx->init_thread = std::thread([ctx] {
         ctx->init_rc = device_init(ctx);
-        if (ctx->init_rc == PP_OK) {  // load the code object and spin up the queue while the host parses
+        if (ctx->init_rc == PP_OK) {  // load the code objects (one per translation unit) and spin up the queue while the host parses
             hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, ctx->stream, (uint32_t *)nullptr);
+            pp_tokenize_warm_(ctx->stream);
+            pp_filter_warm_(ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
         }
     });

@@ -1039,3 +1039,11 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
 #undef ENS
     return PP_OK;
 }
+
+// The HIP runtime loads a translation unit's code object when one of its kernels is launched for the first time (~10 ms for
+// this one: it showed up as the first file's "newline index" stage).  pp_ctx_create_async launches this on its helper
+// thread, while the host still loads the assembly.
+__global__ void k_tok_warm(u32 *p) {
+    if (p) p[threadIdx.x] = 0;
+}
+extern "C" void pp_tokenize_warm_(hipStream_t st) { hipLaunchKernelGGL(k_tok_warm, dim3(1), dim3(64), 0, st, (u32 *)nullptr); }
