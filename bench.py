@@ -121,8 +121,10 @@ def shard_of(ctx, pp, job, plan, rank):
     """The job as rank `rank` of the plan sees it: the records that reach its units (pp_shard_split, on the device) and
     its emit ranges; everything else is shared with `job`."""
     r = job["recs"]
-    part = pp.ShardPart(ctx, plan, rank, job["n_aln"], {k: v.data_ptr() for k, v in r.items()}, r["seq"].numel(),
-                        r["cigar"].numel(), pp.MEM_DEVICE)
+    ptrs = {k: v.data_ptr() for k, v in r.items()}
+    if job.get("wo") is not None:   # the window-order mirror goes along into the part (restricted to its records)
+        ptrs["wo"] = job["wo"].data_ptr()
+    part = pp.ShardPart(ctx, plan, rank, job["n_aln"], ptrs, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE)
     mine = dict(job)
     mine.pop("_prepared", None)
     mine["part"] = part

@@ -509,6 +509,8 @@ class ShardPart:
         self.ptrs = {name: (C.cast(getattr(out, name), C.c_void_p).value or 0) for name, _ in REC_FIELDS}
         if out.seq4:  # a device part brings the 4-bit mirror of its seq array
             self.ptrs["seq4"] = out.seq4
+        if out.wo:    # ... and every part the window-order mirror of its records, when the source batch has one
+            self.ptrs["wo"] = out.wo
         self.orig_ptr = orig.value or 0
 
     def host(self):
@@ -521,6 +523,8 @@ class ShardPart:
                           if cnt and self.ptrs[name] else np.zeros(0, dtype=dt))
         orig = (np.ctypeslib.as_array(C.cast(self.orig_ptr, C.POINTER(C.c_uint32)), shape=(self.n_aln,)).copy()
                 if self.n_aln else np.zeros(0, np.uint32))
+        if self.ptrs.get("wo") and self.n_aln:
+            recs["wo"] = np.ctypeslib.as_array(C.cast(self.ptrs["wo"], C.POINTER(C.c_uint8)), shape=(self.n_aln * WO_DTYPE.itemsize,)).copy().view(WO_DTYPE)
         return recs, orig
 
     def close(self):
@@ -536,9 +540,13 @@ class ShardPart:
 
 
 def shard_split_host(plan, dest, recs):
-    """Host numpy SoA -> (recs of the part, orig)."""
+    """Host numpy SoA -> (recs of the part, orig).  recs["wo"] (the window-order mirror, WO_DTYPE) goes along when it is there."""
     keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
-    part = ShardPart(None, plan, dest, len(keep["contig"]), {k: v.ctypes.data for k, v in keep.items()}, len(keep["seq"]),
+    ptrs = {k: v.ctypes.data for k, v in keep.items()}
+    if "wo" in recs and len(recs["wo"]):
+        keep["wo"] = np.ascontiguousarray(recs["wo"])
+        ptrs["wo"] = keep["wo"].ctypes.data
+    part = ShardPart(None, plan, dest, len(keep["contig"]), ptrs, len(keep["seq"]),
                      len(keep["cigar"]), MEM_HOST)
     out = part.host()
     part.close()

@@ -183,6 +183,8 @@ extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char 
 
 extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n);
 extern "C" int pp_ctx_device_(const pp_ctx *ctx);
+extern "C" int pp_shard_split_view_(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
+                                    uint32_t wo_idx_base, pp_shard_part **out);
 extern "C" int pp_polish_gather_to_host_(pp_ctx *ctx, uint8_t *host_out, uint64_t cap, uint64_t *rank_len, uint64_t *rank_contig_off);
 extern "C" int pp_dev_ingest_slice_(pp_dev_ingest *D, const char *path, const char *text, uint64_t size, pp_sam_counts *counts);
 
@@ -612,7 +614,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     } else {
         // ---- the plan, from the alignment counts per contig ----
         // source batches in file order: sharded -> (file, slice) pieces living on the contexts' GPUs; host ingest -> files
-        struct Src { pp_aln_batch view; int mem; int owner; uint64_t base; };
+        struct Src { pp_aln_batch view; int mem; int owner; uint64_t base; uint32_t wo_base; };
         std::vector<Src> srcs;
         uint64_t base = 0;
         if (sharded) {
@@ -624,7 +626,8 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     pp_aln_batch v = whole[(size_t)sidx];  // seq / cigar: the whole arrays (seq_off / cig_off are absolute)
                     v.n_aln = hi - lo;
                     v.contig += lo; v.ref_start += lo; v.k += lo; v.seq_off += lo; v.seq_len += lo; v.cig_off += lo; v.n_cig += lo;
-                    srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base});
+                    if (v.wo) v.wo += lo;  // (a slice's entries of the window-order mirror are its own stretch; they count from lo)
+                    srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base, (uint32_t)lo});
                     base += hi - lo;
                 }
             // (one context after the other: a histogram kernel each, they add into the same host array)
@@ -636,7 +639,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             for (pp_ingest *gi : gs) {
                 pp_aln_batch v;
                 pp_ingest_batch(gi, &v);
-                srcs.push_back(Src{v, PP_MEM_HOST, -1, base});
+                srcs.push_back(Src{v, PP_MEM_HOST, -1, base, 0u});
                 base += v.n_aln;
                 pp_shard_count(nullptr, &v, PP_MEM_HOST, nc, per_contig.data());
             }
@@ -651,7 +654,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     for (size_t q = 0; q < srcs.size(); q++) {
                         if (srcs[q].owner != sidx) continue;
                         for (int d = 0; d < n_ctx; d++)
-                            if (int r = pp_shard_split(ctxs[sidx], plan, (uint32_t)d, &srcs[q].view, PP_MEM_DEVICE, &parts[q][(size_t)d])) return r;
+                            if (int r = pp_shard_split_view_(ctxs[sidx], plan, (uint32_t)d, &srcs[q].view, PP_MEM_DEVICE, srcs[q].wo_base, &parts[q][(size_t)d])) return r;
                     }
                     return (int)PP_OK;
                 });

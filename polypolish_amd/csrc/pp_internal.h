@@ -158,7 +158,7 @@ struct pp_ctx {
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 1;
     pp::DevBuf b_comm, b_gather;  // the gather's size exchange | rank 0's receive buffer (pp_polish_gather_to_host_)
-    pp::DevBuf b_split[12];  // pp_shard_split's scratch (pp_shard_dev.hip)
+    pp::DevBuf b_split[13];  // pp_shard_split's scratch (pp_shard_dev.hip)
 
     // ---- filter job ----
     pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert, f_poisoned;

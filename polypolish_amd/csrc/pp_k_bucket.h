@@ -214,33 +214,39 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const u32 word = nk4[u];
-            // WO: the slot of the record's first item (first piece, first window of this pass), one cursor update per wave and column
-            u32 first_slot = 0;
-            bool first_taken = false;
+            // WO: the slots of the first two items of the record's first piece (its windows in this pass: one, or two for
+            // a read across a window boundary), one cursor update per wave and column each
+            u32 pre_slot[2] = {0, 0}, pre_n = 0, pre_used = 0;
             if (WO) {
-                u32 key = 0xFFFFFFFFu;
+                u32 key[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (word) {
                     const u32 sp0 = (word >> 30) == NKW_INDEL1 ? (((word >> 17) & 1u) ? ((word >> 9) & 0xFFu) : ((word >> 9) & 0xFFu) - 1u)
                                                                : (word & 0x3FFFFFFFu);  // span of the first piece (for_each_piece)
                     const u32 w0 = g4[u] / (u32)TILE, w1 = (g4[u] + sp0 - 1u) / (u32)TILE;
                     const u32 wa = max(w0, range_lo), wb = min(w1, range_lo + range_n - 1u);
-                    if (sp0 && wa <= wb) key = wa / (u32)CW - crange_lo;
+                    if (sp0 && wa <= wb) {
+                        key[0] = wa / (u32)CW - crange_lo;
+                        if (wa < wb) key[1] = (wa + 1u) / (u32)CW - crange_lo;
+                    }
                 }
                 const u32 lane = threadIdx.x & 63u;
-                u32 mine = key;
-                for (;;) {
-                    const u64 todo = __ballot(mine != 0xFFFFFFFFu);
-                    if (!todo) break;
-                    const int lead = __ffsll((long long)todo) - 1;
-                    const u32 kl = (u32)__builtin_amdgcn_readlane((int)mine, lead);
-                    const u64 same = __ballot(mine == kl);
-                    u32 base = 0;
-                    if ((int)lane == lead) base = atomicAdd(&cur[kl], (u32)__popcll(same));
-                    base = (u32)__builtin_amdgcn_readlane((int)base, lead);
-                    if (mine == kl) {
-                        first_slot = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
-                        first_taken = true;
-                        mine = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    u32 mine = key[q];
+                    for (;;) {
+                        const u64 todo = __ballot(mine != 0xFFFFFFFFu);
+                        if (!todo) break;
+                        const int lead = __ffsll((long long)todo) - 1;
+                        const u32 kl = (u32)__builtin_amdgcn_readlane((int)mine, lead);
+                        const u64 same = __ballot(mine == kl);
+                        u32 base = 0;
+                        if ((int)lane == lead) base = atomicAdd(&cur[kl], (u32)__popcll(same));
+                        base = (u32)__builtin_amdgcn_readlane((int)base, lead);
+                        if (mine == kl) {
+                            pre_slot[q] = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+                            pre_n = (u32)q + 1u;
+                            mine = 0xFFFFFFFFu;
+                        }
                     }
                 }
             }
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
                 } else fl = cls;
                 for (u32 w = wa; w <= wb && w >= wa; w++) {
                     u32 slot;
-                    if (WO && first_taken) { slot = first_slot; first_taken = false; }  // (the record's first item: taken with the wave)
+                    if (WO && piece == 0u && pre_used < pre_n) slot = pre_slot[pre_used++];  // (taken with the wave, above)
                     else slot = atomicAdd(&cur[w / (u32)CW - crange_lo], 1u);
                     uint4 e;
                     e.x = fl ? sp : (u32)so;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     // contig_off / n_contigs / own are the JOB's (a record names its contig by the job's index); g_base[c] is where contig
     // c starts in the coordinates of this RUN -- the same table, or a compact one over the contigs this context owns
     // (run_pipeline), with ~0 for the others: their records are validated like any record, then dropped.
-    auto finish = [&](u64 a, u64 idx, u32 c, u32 rs, u32 g_out, u32 nk_out, u32 fl_out, bool count_first) {  // a: where the result goes; idx: the record's file index
+    auto finish = [&](u64 a, u64 idx, u32 c, u32 rs, u32 g_out, u32 nk_out, u32 fl_out, u32 n_counted) {  // a: where the result goes; idx: the record's file index; n_counted: leading histogram entries the wave has counted already (WO)
         // Sharded job (pp_polish_set_emit): a record that does not reach the range of its contig this context emits
         // is somebody else's -- validated like every record (all ranks report the same first bad record), then
         // dropped.  The untrimmed span of the fast class errs on the side of keeping.
@@ -167,12 +167,12 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         gstart[a] = g_out;
         nkeep[a] = word;
         if (COUNT && word) {
-            bool skip = !count_first;  // (WO: the first window of the first piece was counted by the wave, see below)
+            u32 skip = n_counted;  // (WO: the first windows of the first piece were counted by the wave, see below)
             for_each_piece(g_out, word, [&](u32, u32 g, u32 sp) {
                 if (!sp) return;
                 const u32 w0 = g / (u32)TILE, w1 = min((g + sp - 1u) / (u32)TILE, nwin - 1u);
                 for (u32 w = w0; w <= w1; w++) {
-                    if (skip) { skip = false; continue; }
+                    if (skip) { skip--; continue; }
                     atomicAdd(&h[w / cw], 1u);  // per window, or per coarse bucket of cw windows
                 }
             });
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         if (c >= n_contigs) report(status, idx, DE_BAD_CONTIG);
         else if (nc == 0) report(status, idx, DE_BAD_RUN);
         else prep_general(idx, rs, sl, so, cigar + co, nc, seq, g_base[c], c_hi - c_lo, &g_out, &nk_out, &fl_out, status);
-        finish(a, idx, c, rs, g_out, nk_out, fl_out, true);
+        finish(a, idx, c, rs, g_out, nk_out, fl_out, 0u);
     };
     u32 fast_len = 0;  // the longest fast-class read this thread saw: picks the lane-group width of k_tile's plain class
     if (WO) {
@@ -234,10 +234,17 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                     if (gb == ~0ull) kept = false;
                     if (slice && kept && ((u64)r.ref_start < slice[2 * r.contig] || (u64)r.ref_start + r.seq_len > slice[2 * r.contig + 1])) kept = false;  // (finish reports DE_HALO)
                 }
-                if (COUNT) count_first_by_wave(kept, min(g_out / (u32)TILE, nwin - 1u) / cw);
+                // a bulk record is one piece of at most 252 positions: one window, or two -- both counted by the wave (with
+                // the records in window order the second one is the same window for a whole wave as well: left to plain
+                // atomics, those 7 % of the records serialised on one address)
+                const u32 w0 = g_out / (u32)TILE, w1 = min((g_out + r.seq_len - 1u) / (u32)TILE, nwin - 1u);
+                if (COUNT) {
+                    count_first_by_wave(kept, w0 / cw);
+                    count_first_by_wave(kept && w1 > w0, w1 / cw);
+                }
                 if (bulk) {
                     fast_len = max(fast_len, r.seq_len);
-                    finish(a, r.file_idx, r.contig, r.ref_start, g_out, r.seq_len, 0u, !kept || !COUNT);
+                    finish(a, r.file_idx, r.contig, r.ref_start, g_out, r.seq_len, 0u, kept && COUNT ? (w1 > w0 ? 2u : 1u) : 0u);
                 } else if (in) {
                     const u32 slot = atomicAdd(&n_later, 1u);
                     if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                 sl[u] <= FAST_MAX_LEN && (u64)rs[u] + sl[u] <= c_hi[u] - c_lo[u]) {
                 // the bulk: one M run, short, inside its contig -> fast class, trimmed later by k_tile
                 fast_len = max(fast_len, sl[u]);
-                finish(a, a, c[u], rs[u], (u32)(gb[u] + rs[u]), sl[u], 0u, true);
+                finish(a, a, c[u], rs[u], (u32)(gb[u] + rs[u]), sl[u], 0u, 0u);
             } else {
                 const u32 slot = atomicAdd(&n_later, 1u);
                 if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);

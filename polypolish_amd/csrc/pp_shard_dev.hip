@@ -25,8 +25,10 @@
 struct pp_shard_part {
     pp_ctx *ctx = nullptr;
     int mem = PP_MEM_HOST;
-    pp::DevBuf d_all;   // one allocation, carved into: contig ref_start k seq_off seq_len cig_off n_cig seq cigar orig seq4
-    void *d[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pp::DevBuf d_all;   // one allocation, carved into: contig ref_start k seq_off seq_len cig_off n_cig seq cigar orig seq4 wo
+    void *d[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool has_wo = false;
+    std::vector<pp_wo_rec> h_wo;
     std::vector<uint32_t> h_contig, h_ref_start, h_k, h_seq_len, h_n_cig, h_cigar, h_orig;
     std::vector<uint64_t> h_seq_off, h_cig_off;
     std::vector<uint8_t> h_seq;
@@ -164,6 +166,30 @@ __global__ __launch_bounds__(256) void k_split_seq(u64 n, const u64 *__restrict_
     }
 }
 
+// The part's window-order mirror (pp_aln_batch.wo): the source's mirror restricted to the selected records, in the source's
+// order -- entry j of the source goes along if its record does (mflag, scanned into mpos by the caller), with the record's
+// new place in the part's seq array and its new index among the part's records.  idx_base: what the source mirror's
+// file_idx count from (a view on records [lo, hi) of a batch keeps the batch's numbering).
+__global__ __launch_bounds__(256) void k_split_wo_flag(u64 n, const pp_wo_rec *__restrict__ wo, u32 idx_base, const u32 *__restrict__ flag,
+                                                       u32 *__restrict__ mflag, u32 *__restrict__ bad) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 fi = wo[j].file_idx - idx_base;
+    if (fi >= n) { atomicOr(bad, 2u); mflag[j] = 0; return; }  // not this view's mirror: the part goes without one
+    mflag[j] = flag[fi];
+}
+__global__ __launch_bounds__(256) void k_split_wo(u64 n, const pp_wo_rec *__restrict__ wo, u32 idx_base, const u32 *__restrict__ mflag,
+                                                  const u32 *__restrict__ mpos, const u32 *__restrict__ out_idx,
+                                                  const u64 *__restrict__ seq_scan, pp_wo_rec *__restrict__ out) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !mflag[j]) return;
+    pp_wo_rec w = wo[j];
+    const u32 fi = w.file_idx - idx_base;
+    w.seq_off = seq_scan[fi];
+    w.file_idx = out_idx[fi];
+    out[mpos[j]] = w;
+}
+
 __global__ __launch_bounds__(256) void k_split_cigar(u64 n, const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
                                                      const u32 *__restrict__ cigar, const u32 *__restrict__ flag,
                                                      const u64 *__restrict__ cig_scan, u32 *__restrict__ out) {
@@ -220,6 +246,7 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
     pp_aln_batch &v = P->view;
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
     v.seq4 = P->mem == PP_MEM_DEVICE ? (const u8 *)P->d[10] : nullptr;  // a device part brings the 4-bit mirror of its seq array
+    v.wo = !P->has_wo || n == 0 ? nullptr : (P->mem == PP_MEM_DEVICE ? (const pp_wo_rec *)P->d[11] : P->h_wo.data());  // ... and both kinds the window-order mirror, when the source has one
     if (P->mem == PP_MEM_DEVICE) {
         v.contig = (const u32 *)P->d[0]; v.ref_start = (const u32 *)P->d[1]; v.k = (const u32 *)P->d[2];
         v.seq_off = (const uint64_t *)P->d[3]; v.seq_len = (const u32 *)P->d[4]; v.cig_off = (const uint64_t *)P->d[5];
@@ -238,7 +265,7 @@ bool batch_ok(const pp_aln_batch *b) {
                                   b->seq && b->cigar));
 }
 
-int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B) {
+int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B, u32 wo_base) {
     const UnitTable T = U.table(n_contigs);
     const uint64_t n = B->n_aln;
     uint64_t seq_total = 0, cig_total = 0, cnt = 0;
@@ -283,11 +310,27 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
         memcpy(P->h_cigar.data() + co, B->cigar + B->cig_off[i], (size_t)B->n_cig[i] * 4);
         co += B->n_cig[i];  // (h_seq was zero-filled: so are the bytes up to the boundary)
     }
+    if (B->wo && cnt) {  // the source's window-order mirror, restricted to the part (see k_split_wo)
+        std::vector<uint32_t> new_idx((size_t)n, 0xFFFFFFFFu);
+        for (uint64_t j = 0; j < cnt; j++) new_idx[picked[j]] = (uint32_t)j;
+        P->h_wo.reserve(cnt);
+        bool ok = true;
+        for (uint64_t j = 0; j < n && ok; j++) {
+            pp_wo_rec w = B->wo[j];
+            const uint32_t fi = w.file_idx - wo_base;
+            if (fi >= n) { ok = false; break; }
+            if (new_idx[fi] == 0xFFFFFFFFu) continue;
+            w.seq_off = place[new_idx[fi]];
+            w.file_idx = new_idx[fi];
+            P->h_wo.push_back(w);
+        }
+        P->has_wo = ok && P->h_wo.size() == cnt;
+    }
     set_view(P, cnt, seq_total, cig_total);
     return PP_OK;
 }
 
-int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B) {
+int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, const pp_aln_batch *B, u32 wo_base) {
     pp_ctx *ctx = P->ctx;
     hipStream_t st = ctx->stream;
     const uint64_t n = B->n_aln;
@@ -340,12 +383,12 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
         hipLaunchKernelGGL(k_split_place, dim3(blocks), dim3(256), 0, st, (u64)n, (const u32 *)flag.p, (const u64 *)B->seq_off,
                            (const u32 *)slot_scan.p, (u64 *)seq_scan.p);
     }
-    const size_t esz[11] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 4, 1};
-    const uint64_t ecnt[11] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total, cnt, (seq_total + 1) / 2 + 96};
-    size_t at[12] = {0};
-    for (int a = 0; a < 11; a++) at[a + 1] = (at[a] + (size_t)ecnt[a] * esz[a] + 255) / 256 * 256;
-    if ((rc = pp::dev_ensure(ctx, P->d_all, at[11]))) return done(rc);
-    for (int a = 0; a < 11; a++) P->d[a] = (char *)P->d_all.p + at[a];
+    const size_t esz[12] = {4, 4, 4, 8, 4, 8, 4, 1, 4, 4, 1, sizeof(pp_wo_rec)};
+    const uint64_t ecnt[12] = {cnt, cnt, cnt, cnt, cnt, cnt, cnt, seq_total + 64, cig_total, cnt, (seq_total + 1) / 2 + 96, B->wo ? cnt : 0};
+    size_t at[13] = {0};
+    for (int a = 0; a < 12; a++) at[a + 1] = (at[a] + (size_t)ecnt[a] * esz[a] + 255) / 256 * 256;
+    if ((rc = pp::dev_ensure(ctx, P->d_all, at[12]))) return done(rc);
+    for (int a = 0; a < 12; a++) P->d[a] = (char *)P->d_all.p + at[a];
     SplitOut O{(u32 *)P->d[0], (u32 *)P->d[1], (u32 *)P->d[2], (u32 *)P->d[4], (u32 *)P->d[6], (u32 *)P->d[8],
                (u32 *)P->d[9], (u64 *)P->d[3], (u64 *)P->d[5], (u8 *)P->d[7]};
     if (cnt) {
@@ -357,6 +400,21 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
         hipLaunchKernelGGL(k_split_cigar, dim3(blocks), dim3(256), 0, st, (u64)n, (const u64 *)B->cig_off, B->n_cig, B->cigar,
                            (const u32 *)flag.p, (const u64 *)cig_scan.p, O.cigar);
         if (hipMemsetAsync(O.seq + seq_total, 0, 64, st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: memset failed"));
+        if (B->wo) {  // the part's window-order mirror: the source's, restricted (sel_seq / sel_cig are free again: mflag / mpos)
+            u32 *mflag = (u32 *)sel_seq.p, *wbad = (u32 *)sel_cig.p;
+            pp::DevBuf &mpos = ctx->b_split[12];
+            if ((rc = pp::dev_ensure(ctx, mpos, (n + 1) * 4))) return done(rc);
+            if (hipMemsetAsync(wbad, 0, 4, st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: memset failed"));
+            hipLaunchKernelGGL(k_split_wo_flag, dim3(blocks), dim3(256), 0, st, (u64)n, B->wo, wo_base, (const u32 *)flag.p, mflag, wbad);
+            if ((rc = scan_u32<u32>(ctx, sums, sums_off, (const u32 *)mflag, (u64)n, (u32 *)mpos.p))) return done(rc);
+            u32 wb = 0, mcnt = 0;
+            if ((rc = fetch(ctx, (const u32 *)wbad, &wb)) || (rc = fetch(ctx, (const u32 *)mpos.p + n, &mcnt))) return done(rc);
+            if (!wb && mcnt == cnt) {
+                hipLaunchKernelGGL(k_split_wo, dim3(blocks), dim3(256), 0, st, (u64)n, B->wo, wo_base, (const u32 *)mflag, (const u32 *)mpos.p,
+                                   (const u32 *)out_idx.p, (const u64 *)seq_scan.p, (pp_wo_rec *)P->d[11]);
+                P->has_wo = true;
+            }
+        }
     }
     if (hipGetLastError() != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: a kernel launch failed"));
     set_view(P, cnt, seq_total, cig_total);
@@ -365,8 +423,16 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
 
 }  // namespace
 
+// (internal) wo_idx_base: what the file_idx of batch->wo count from -- a view on records [lo, hi) of a larger batch (the
+// multi-GPU driver's (file, slice) pieces: batch->wo = the larger batch's mirror + lo) keeps that batch's numbering
+extern "C" int pp_shard_split_view_(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
+                                    uint32_t wo_idx_base, pp_shard_part **out);
 extern "C" int pp_shard_split(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
                               pp_shard_part **out) {
+    return pp_shard_split_view_(ctx, plan, dest, batch, mem, 0, out);
+}
+extern "C" int pp_shard_split_view_(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t dest, const pp_aln_batch *batch, int mem,
+                                    uint32_t wo_idx_base, pp_shard_part **out) {
     if (!out) return PP_ERR_ARG;
     *out = nullptr;
     if (!plan || dest >= plan->world || !batch_ok(batch) || (mem != PP_MEM_HOST && mem != PP_MEM_DEVICE)) return PP_ERR_ARG;
@@ -380,7 +446,8 @@ extern "C" int pp_shard_split(pp_ctx *ctx, const pp_shard_plan *plan, uint32_t d
     pp_shard_part *P = new pp_shard_part();
     P->ctx = ctx;
     P->mem = mem;
-    const int rc = mem == PP_MEM_DEVICE ? split_device(P, U, plan->n_contigs, dest, batch) : split_host(P, U, plan->n_contigs, dest, batch);
+    const int rc = mem == PP_MEM_DEVICE ? split_device(P, U, plan->n_contigs, dest, batch, wo_idx_base)
+                                        : split_host(P, U, plan->n_contigs, dest, batch, wo_idx_base);
     if (rc) { pp_shard_part_free(P); return rc; }
     *out = P;
     return PP_OK;

@@ -1390,8 +1390,18 @@ def test_device_split_equals_host_split(ctx, pp, orc, world):
     total = 0
     def parts_agree(src, keep_t, r):
         want, want_orig = pp.shard_split_host(plan, r, src)
-        part = pp.ShardPart(ctx, plan, r, n, {k: v.data_ptr() for k, v in keep_t.items()}, keep_t["seq"].numel(), keep_t["cigar"].numel(),
-                            pp.MEM_DEVICE)
+        ptrs_t = {k: v.data_ptr() for k, v in keep_t.items() if k != "wo"}
+        if "wo" in keep_t:
+            ptrs_t["wo"] = keep_t["wo"].data_ptr()
+        part = pp.ShardPart(ctx, plan, r, n, ptrs_t, keep_t["seq"].numel(), keep_t["cigar"].numel(), pp.MEM_DEVICE)
+        # the window-order mirror goes along into the part: the source's entries of the part's records, in the source's order,
+        # renumbered -- on the device as on the host
+        assert ("wo" in part.ptrs) == ("wo" in want) == ("wo" in src and len(want_orig) > 0), r
+        if "wo" in want:
+            w = np.zeros(part.n_aln, dtype=pp.WO_DTYPE)
+            assert L.pp_ctx_download(ctx._h, w.ctypes.data, part.ptrs["wo"], w.nbytes) == 0
+            assert all(np.array_equal(w[k], want["wo"][k]) for k in pp.WO_DTYPE.names), r
+            check_window_order_mirror(want, contig_off, [len(want_orig)])
         assert part.n_aln == len(want_orig) and part.seq_bytes == len(want["seq"]) and part.n_cig_total == len(want["cigar"]), r
         sizes = {"seq": part.seq_bytes, "cigar": part.n_cig_total}
         for name, dt in pp.REC_FIELDS:
@@ -1433,6 +1443,9 @@ def test_device_split_equals_host_split(ctx, pp, orc, world):
     shuf["seq_off"] = place.astype(np.uint64)
     keep2 = {k: torch.from_numpy(np.ascontiguousarray(shuf[k], dtype=dt).view(np.int64 if dt == np.uint64 else (np.int32 if dt == np.uint32 else np.uint8))).to(dev)
              for k, dt in pp.REC_FIELDS}
+    torch.cuda.synchronize()
+    shuf["wo"] = pp.window_order_mirror(shuf, contig_off)   # (the odd records 5 and 9 included: a mirror holds every record)
+    keep2["wo"] = torch.from_numpy(np.ascontiguousarray(shuf["wo"]).view(np.uint8)).to(dev)
     torch.cuda.synchronize()
     for r in range(world):
         want, _ = parts_agree(shuf, keep2, r)
