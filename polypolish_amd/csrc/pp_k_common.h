@@ -31,9 +31,19 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
 
 // the job's metadata block: word 0 is the status ("no error" = all ones: errors are combined with atomicMin), the
 // counters and sizes behind it start at zero -- one launch where two memsets left a gap between them
-__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 n_zero) {
+// ... and the job's table of the vote's two thresholds for every INTEGER depth below VOTE_TAB_N (d_bankers is defined below):
+// thr[2n] = bankers_rounding(n * fraction_valid), thr[2n + 1] = bankers_rounding(n * fraction_invalid) (pileup.rs:70-72),
+// computed with the very operations the vote uses on an f64 depth, so that a position whose depth is an integer -- every
+// position no shared read touches -- reads its thresholds instead of multiplying and rounding twice.
+constexpr u32 VOTE_TAB_N = 4096;
+__device__ __forceinline__ u32 d_bankers(double x);
+__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 n_zero, u32 *thr, double fv, double fi) {
     if (blockIdx.x == 0) {
         for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
+        for (u32 n = threadIdx.x; n < VOTE_TAB_N; n += blockDim.x) {
+            thr[2 * n] = d_bankers(__dmul_rn((double)n, fv));
+            thr[2 * n + 1] = d_bankers(__dmul_rn((double)n, fi));
+        }
         return;
     }
     // blocks 1..: 4096 elements of the two arrays each (a sharded job's win_len / win_nflag)

@@ -28,6 +28,7 @@ struct TileArgs {
     u32 *win_len;
     u32 *counters;  // [0] positions on the global replay list, [1] n_multi, [2] all flagged positions
     u32 cap_flag;
+    const u32 *vote_tab;  // (valid, invalid) thresholds per integer depth below VOTE_TAB_N (k_meta_init)
     MultiEnt *multi;  // positions whose polished string has two or more bytes (counters[1] of them; k_exact adds its own)
     u32 cap_multi;
     u32 *flag_bits;   // per window: 2048-bit map of flagged positions (64 words)
@@ -1223,6 +1224,13 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
             // (depth <= ntot always, so ntot < min_depth would decide DepthTooLow -- but the depth itself feeds the contig's
             // mean read depth, polish.rs:173-180: an undecided position is replayed whenever anything covers it)
             if (!decided && (ntot > 0 || A.dbg)) flag = true;
+        } else if (deficit == 0 && ntot < VOTE_TAB_N) {
+            // an integer depth (no shared read here): both thresholds from the job's table -- the same two multiplications
+            // and roundings, done once per depth instead of once per position
+            const uint2 th = ((const uint2 *)A.vote_tab)[ntot];
+            vthr = max(A.min_depth, th.x);
+            ithr = th.y;
+            low = ntot < A.min_depth;
         } else {
             vthr = max(A.min_depth, d_bankers(__dmul_rn(depth, A.fv)));
             ithr = d_bankers(__dmul_rn(depth, A.fi));

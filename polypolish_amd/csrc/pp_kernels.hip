@@ -472,6 +472,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const size_t heavy_at = 16 + (size_t)nc + 1 + 3 * (size_t)nc;
     const size_t meta_words = heavy_at + (HEAVY_WORDS + 1) / 2;
     ENS(b_meta, meta_words * 8);
+    ENS(b_vote_tab, (size_t)VOTE_TAB_N * 8);
     ENS(b_win_heavy, nwin);
     ENS(b_hslab, (size_t)HEAVY_SLOTS * HEAVY_PARTS * HSLAB_WORDS * 4);
     ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
@@ -509,7 +510,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     {
         const bool sharded = !ctx->emit.empty();
         hipLaunchKernelGGL(k_meta_init, dim3(sharded ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
-                           sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr, nwin);
+                           sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr, nwin,
+                           (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
     }
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
     u8 *d_win_heavy = (u8 *)ctx->b_win_heavy.p;
@@ -666,6 +668,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
     T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
+    T.vote_tab = (const u32 *)ctx->b_vote_tab.p;
     T.multi = (MultiEnt *)ctx->b_multi.p; T.cap_multi = (u32)ctx->cap_multi;
     T.flag_pos = (u32 *)ctx->b_flag_pos.p; T.flag_cov = (u32 *)ctx->b_flag_cov.p;
     T.flag_bits = (u32 *)ctx->b_flag_bits.p; T.win_nflag = (u32 *)ctx->b_win_nflag.p;
@@ -1051,7 +1054,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
     DevBuf *all[] = {&ctx->b_comm, &ctx->b_gather, &ctx->b_bases, &ctx->b_contig_off, &ctx->b_status, &ctx->b_gstart, &ctx->b_nkeep,
                      &ctx->b_aflag, &ctx->b_hist, &ctx->b_wincnt, &ctx->b_winoff, &ctx->b_entA, &ctx->b_entB, &ctx->b_ccnt, &ctx->b_coff,
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
-                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
+                     &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_vote_tab, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_win_heavy, &ctx->b_hslab, &ctx->b_sub_bases,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,

@@ -85,7 +85,8 @@ def check_window_order_mirror(recs, contig_off, used_per_file, file_order_inside
     assert np.array_equal(wo["op0"][one], recs["cigar"][recs["cig_off"][fi][one].astype(np.int64)])
     off = np.asarray(contig_off).astype(np.int64)
     n_win = max(1, (int(off[-1]) + WINDOW - 1) // WINDOW)
-    win = np.minimum((off[wo["contig"]] + wo["ref_start"].astype(np.int64)) // WINDOW, n_win - 1)
+    ctg = np.minimum(wo["contig"].astype(np.int64), len(off) - 2)   # (a record that names no contig of the assembly is still a record)
+    win = np.minimum((off[ctg] + wo["ref_start"].astype(np.int64)) // WINDOW, n_win - 1)
     lo = 0
     for cnt in used_per_file:
         hi = lo + cnt
