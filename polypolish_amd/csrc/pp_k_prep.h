@@ -203,7 +203,10 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     if (WO) {
         // the mirror: one 32-byte record per lane as two 16-byte loads, two records per trip in flight; nothing dependent
         // but the contig table
-        constexpr int WU = 2;
+#ifndef PP_WO_UNROLL
+#define PP_WO_UNROLL 2
+#endif
+        constexpr int WU = PP_WO_UNROLL;
         const uint4 *wq = (const uint4 *)wo;
         const u64 trip = (u64)WU * blockDim.x;
         const u64 span = (hi - lo + trip - 1) / trip * trip;  // whole waves and whole trips: the ballots below need every lane
