@@ -470,15 +470,15 @@ def main():
                    repeat_bp=args.repeat_bp, recipe=args.recipe, seq_pitch=None if args.seq_pitch < 0 else args.seq_pitch,
                    seq_layout=args.seq_layout)
     G_total = job["G"]  # the assembly's length (the truth's +- the planted indels)
-    if args.seq4 == "on":   # the mirror the device tokenizer hands over with its batch (and pp_polish_add packs for any other)
-        job = synthjob.with_seq4(job)
-    if args.wo == "on":     # the window-order mirror of the records both ingests hand over with their batch (pp_aln_batch.wo)
-        job = synthjob.with_wo(job)
     if args.nd_frac > 0:
         gg = torch.Generator(device=device)
         gg.manual_seed(7)
         nd = torch.rand(job["n_aln"], device=device, generator=gg) < args.nd_frac
         job["recs"]["k"] = torch.where(nd, 3, job["recs"]["k"]).int().contiguous()
+    if args.seq4 == "on":   # the mirror the device tokenizer hands over with its batch (and pp_polish_add packs for any other)
+        job = synthjob.with_seq4(job)
+    if args.wo == "on":     # the window-order mirror of the records both ingests hand over with their batch (pp_aln_batch.wo)
+        job = synthjob.with_wo(job)
     plan = None
     if strong:
         # ONE job; a rank keeps the records that reach its units (pp_shard_plan_create: whole contigs by longest-

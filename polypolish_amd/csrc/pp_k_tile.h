@@ -101,6 +101,7 @@ __device__ __forceinline__ void tile_add(u32 *cnt, int row, int p) { atomicAdd(&
 // as before.  Entry: tag = 1 << 31 | position << 16 | bytes; count in bits 0..23 of the second word, bits 32..39 of the
 // offset above them; the offset's low word.
 constexpr u32 PT_SLOTS = 20;
+constexpr u32 FEW_FLAGGED = 4;  // windows with at most this many positions left for the ordered replay hand them to k_exact
 __device__ __noinline__ void pt_insert(u32 *pt, u32 *over, int p, const u8 *seq, u64 so) {  // (rare: kept out of the item loop's registers)
     const u32 tag = 0x80000000u | ((u32)p << 16) | (u32)seq[so] | ((u32)seq[so + 1] << 8);
     u32 h = ((tag * 2654435761u) >> 16) % PT_SLOTS;
@@ -1332,6 +1333,34 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         if (my_depth) atomicAdd(&s_depth, my_depth);
     }
     __syncthreads();
+    // A handful of flagged positions (since the interval vote settles nearly everything, a window rarely has more than one
+    // or two left) is not worth the window's ordered replay -- k_exact2 sorts ALL of the window's items for them: they go
+    // to the global list instead, where k_exact replays each with a workgroup of its own (its depth in file order too).
+    if (s_nflag && s_nflag <= FEW_FLAGGED && A.dbg != 2 && !heavy) {
+        if (tid < (u32)(TILE / 32)) {
+            u32 bits = s_fbits[tid];
+            while (bits) {
+                const u32 p = 32u * tid + (u32)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                u32 nA, nC, nG, nT, nDel, nOth;
+                position_tallies(cnt, ((const u8 *)asm_w)[ASM_PAD + p], p, nA, nC, nG, nT, nDel, nOth);
+                const u32 ntot = nA + nC + nG + nT + nDel + nOth;
+                const u32 slot = atomicAdd(&A.counters[0], 1u);
+                const u64 scr_at = atomicAdd(A.scr_need, (u64)ntot);
+                if (slot < A.cap_flag) {
+                    A.flag_pos[slot] = (u32)(w0 + p);
+                    A.flag_cov[slot] = ntot;
+                    A.flag_scr[slot] = scr_at;
+                } else {
+                    report(A.status, slot, DE_CAPACITY_LATE);
+                }
+            }
+            s_fbits[tid] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) { atomicAdd(&A.counters[2], s_nflag); s_nflag = 0; }
+        __syncthreads();
+    }
     if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
     if (s_nflag && (e1 - e0 <= SORT_MAX || heavy)) {
         // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)

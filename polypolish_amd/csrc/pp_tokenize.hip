@@ -283,26 +283,30 @@ __global__ __launch_bounds__(256) void k_tok_meta(const u8 *__restrict__ text, c
     O.n_cig[o] = a.n_runs;
     O.seq_off[o] = seq_base + seq_scan[r];
     O.cig_off[o] = cig_base + cig_scan[r];
+    // the CIGAR as packed runs (validated by k_tok_parse; zero-length runs vanish, long runs split: get_expanded_cigar) --
+    // the one pass over the record's CIGAR text also yields the mirror's op0
+    const u8 *cg = text + line_start(nl_pos, rec_line[r]) + a.cig_off;
+    u32 *runs = O.cigar + cig_base + cig_scan[r];
+    u32 i = 0, nw = 0, first_run = PP_WO_MULTI_RUN;
+    while (i < a.cig_len) {
+        u64 num = 0;
+        while (cg[i] >= (u8)'0' && cg[i] <= (u8)'9') num = num * 10 + (u64)(cg[i++] - (u8)'0');
+        const u32 op = (u32)op_code(cg[i++]);
+        while (num > 0) {
+            const u32 piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (u32)num;
+            const u32 run = (piece << 4) | op;
+            if (nw == 0) first_run = run;
+            runs[nw++] = run;
+            num -= piece;
+        }
+    }
     if (wo) {
         // the record once more, at its place in window order (pp_aln_batch.wo): one 32-byte store.  op0 = its only CIGAR
-        // run, parsed here from the text (validated by k_tok_parse), or the marker for a record of several runs
-        u32 op0 = PP_WO_MULTI_RUN;
-        if (a.n_runs == 1u) {
-            const u8 *cg = text + line_start(nl_pos, rec_line[r]) + a.cig_off;
-            u64 num = 0;
-            u32 i = 0;
-            for (;;) {  // runs of length zero vanish (get_expanded_cigar): the one run left is the one with a length
-                num = 0;
-                while (cg[i] >= (u8)'0' && cg[i] <= (u8)'9') num = num * 10 + (u64)(cg[i++] - (u8)'0');
-                if (num) break;
-                i++;
-            }
-            op0 = ((u32)num << 4) | (u32)op_code(cg[i]);
-        }
+        // run, or the marker for a record of several runs
         pp_wo_rec w;
         w.contig = a.contig; w.ref_start = a.ref_start; w.k = kk[r]; w.seq_len = g_seq_len[r];
         w.seq_off = seq_base + seq_scan[r];
-        w.op0 = op0; w.file_idx = (u32)o;
+        w.op0 = a.n_runs == 1u ? first_run : PP_WO_MULTI_RUN; w.file_idx = (u32)o;
         wo[out_base + slot[r]] = w;
     }
 }
@@ -473,28 +477,6 @@ __global__ __launch_bounds__(256) void k_tok_win_place_g(const u32 *__restrict__
     if (w == WIN_NONE) return;
     seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], seq_room(g_seq_len[r]));
     slot[r] = wcbase[w] + atomicAdd(&wccur[w], 1u);
-}
-
-__global__ __launch_bounds__(256) void k_tok_cigar(const u8 *__restrict__ text, const u64 *__restrict__ nl_pos,
-                                                   const LineRec *__restrict__ rec, const u32 *__restrict__ rec_line,
-                                                   u32 n_aln, const u32 *__restrict__ good,
-                                                   const u64 *__restrict__ cig_scan, u32 *__restrict__ cigar, u64 cig_base) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_aln || !good[r]) return;
-    const LineRec &a = rec[rec_line[r]];
-    const u8 *cg = text + line_start(nl_pos, rec_line[r]) + a.cig_off;
-    u32 *out = cigar + cig_base + cig_scan[r];
-    u32 i = 0, w = 0;
-    while (i < a.cig_len) {  // validated by k_tok_parse
-        u64 num = 0;
-        while (cg[i] >= (u8)'0' && cg[i] <= (u8)'9') num = num * 10 + (u64)(cg[i++] - (u8)'0');
-        const u32 op = (u32)op_code(cg[i++]);
-        while (num > 0) {
-            const u32 piece = num > 0x0FFFFFFFull ? 0x0FFFFFFFu : (u32)num;
-            out[w++] = (piece << 4) | op;
-            num -= piece;
-        }
-    }
 }
 
 }  // namespace
@@ -1025,9 +1007,6 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
                        (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
                        (const u32 *)D->d_src.p, seq_place, O.seq, D->mirror() ? (u8 *)D->o_seq4.p : (u8 *)nullptr, D->seq_bytes);
     if (timing) lap("seq bytes + mirror");
-    hipLaunchKernelGGL(k_tok_cigar, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_text, (const u64 *)D->d_nl.p,
-                       (const LineRec *)D->d_rec.p, (const u32 *)D->d_recline.p, n_aln, (const u32 *)D->d_good.p,
-                       (const u64 *)D->d_cigscan.p, O.cigar, D->n_cig_total);
     PP_HIPCHK(ctx, hipStreamSynchronize(st));  // the text mapping goes away with F
     lap("batch filled");
     D->n_out += n_good;
