@@ -525,14 +525,12 @@ def main():
         run_job(ctx, pp, job)
         tb = time.perf_counter()
         if world > 1 and not share:
-            dog.arm(args.collective_timeout, "pp_polish_gather")
             try:
                 last["lens"], last["offs"] = ctx.gather(gbuf.data_ptr() if rank == 0 else None, total_cap if rank == 0 else 0)
             except Exception as e:  # noqa: BLE001 -- (a rank that backed out alone would leave the others in ncclSend: everybody leaves)
                 if rank == 0:
                     print(_error_line(world, args, f"pp_polish_gather failed: {e}"), flush=True)
                 os._exit(3)
-            dog.disarm()
         elif world > 1:
             pp.lib().pp_polish_result(ctx._h, sbuf.data_ptr(), pp.MEM_DEVICE, None, None)
             src = sbuf.cpu()
@@ -551,6 +549,9 @@ def main():
     # timers do not perturb what `value` measures.  The per-group breakdown (kernel_ms_per_step) comes from
     # a few extra, untimed steps afterwards with every kernel group under HIP events.
     ctx.set_profiling(0)
+    # (one watchdog over all the steps, not one per step: a timer thread per step would sit inside the timed region)
+    if world > 1:
+        dog.arm(args.collective_timeout + 2.0 * (args.warmup + args.steps + 8), "the steps' gathers (pp_polish_gather)")
     for _ in range(args.warmup):
         step()
     ctx.set_profiling(2)
@@ -579,6 +580,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timed_split = dict(split_s)   # the timed steps' compute / gather halves on this rank
+    dog.disarm()
+    if world > 1:
+        dog.arm(args.collective_timeout + 60.0, "the untimed steps and the verification of the gathered bytes")
     ctx.set_profiling(1)
     all_ms, n_break, work = {}, 5, {}
     for _ in range(n_break):
@@ -634,6 +638,7 @@ def main():
         t = torch.tensor([G_total], dtype=torch.int64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         G_all_ranks = int(t.item())
+    dog.disarm()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -73,40 +73,37 @@ __global__ __launch_bounds__(256) void k_heavy(u32 nwin, const u32 *__restrict__
 }
 
 // win_heavy != nullptr (single-level path, the columns ARE the windows): also lists the heavy windows.
-// Exclusive scan of every column of the blocks x columns matrix over the blocks, in place, and the columns' totals.  A
-// workgroup takes 64 adjacent columns, its four waves a quarter of the rows each: a wave's lanes read 64 ADJACENT words of
-// one row per load (round 3 had a lane walk down its own column: every 4-byte read pulled a whole line, 40 MB fetched for a
-// 5 MB matrix, 18 us), add their quarter up, meet in LDS, and write the prefixes on a second pass over the same rows.
+// One wave per column, eight rows per lane (<= 512 rows: PP_NB_MAX), all of a lane's loads in flight at once.  (Round 4 tried
+// the row-wise variant -- a wave reads 64 adjacent words of a row, the rows in sequence: 5 MB fetched instead of 40, but 32
+// dependent trips per wave: 26 us instead of 18.)
 __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *__restrict__ hist,
                                                    u32 *__restrict__ win_cnt, u32 heavy_min, u32 *__restrict__ heavy,
                                                    u8 *__restrict__ win_heavy) {
-    __shared__ u32 part[4][64];
-    const u32 lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
-    const u32 w = blockIdx.x * 64u + lane;
-    const u32 per = (nblocks + 3u) / 4u, b0 = min(nblocks, q * per), b1 = min(nblocks, b0 + per);
-    u32 sum = 0;
-    if (w < nwin) {
-        u32 b = b0;
-        for (; b + 4u <= b1; b += 4u) {  // four rows in flight
-            const u32 v0 = hist[(u64)b * nwin + w], v1 = hist[(u64)(b + 1u) * nwin + w], v2 = hist[(u64)(b + 2u) * nwin + w],
-                      v3 = hist[(u64)(b + 3u) * nwin + w];
-            sum += v0 + v1 + v2 + v3;
-        }
-        for (; b < b1; b++) sum += hist[(u64)b * nwin + w];
-    }
-    part[q][lane] = sum;
-    __syncthreads();
+    const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (w >= nwin) return;
-    u32 run = 0;
-    for (u32 i = 0; i < q; i++) run += part[i][lane];
-    for (u32 b = b0; b < b1; b++) {
-        const u32 v = hist[(u64)b * nwin + w];
-        hist[(u64)b * nwin + w] = run;
-        run += v;
+    u32 v[8];
+    u32 sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
+        v[i] = (b < nblocks) ? hist[(u64)b * nwin + w] : 0u;
+        sum += v[i];
     }
-    if (q == 3u) {
-        win_cnt[w] = run;  // (the last quarter ends on the column's total)
-        if (win_heavy) note_heavy(w, run, heavy_min, heavy, win_heavy);
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    u32 run = inc - sum;
+#pragma unroll
+    for (u32 i = 0; i < 8; i++) {
+        const u32 b = 8u * lane + i;
+        if (b < nblocks) hist[(u64)b * nwin + w] = run;
+        run += v[i];
+    }
+    if (lane == 63) {
+        win_cnt[w] = inc;
+        if (win_heavy) note_heavy(w, inc, heavy_min, heavy, win_heavy);
     }
 }
 

@@ -460,7 +460,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ctx->run_nc = nc;
     const uint32_t nwin = (uint32_t)((G + TILE - 1) / TILE);
 #ifndef PP_NB_MAX
-#define PP_NB_MAX 512  // one resident wave of k_prep / k_fill workgroups (two per CU); more rows only lengthen the matrix
+#define PP_NB_MAX 512  // one resident wave of k_prep / k_fill workgroups (two per CU), and what k_scan_cols takes; 1024 measured slower (bucket 0.10 -> 0.13 ms), 256 the same
 #endif
     const uint32_t NB = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(PP_NB_MAX, (n + 4095) / 4096));
     const uint64_t chunk = (n + NB - 1) / NB;
@@ -633,7 +633,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                 hipLaunchKernelGGL(k_count<COARSE_WINDOWS>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart,
                                    d_nkeep, nwin, ncoarse, d_hist);
         }
-        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 63) / 64), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt, 0u,
+        hipLaunchKernelGGL(k_scan_cols, dim3((ncoarse + 3) / 4), dim3(256), 0, st, ncoarse, NB, d_hist, d_ccnt, 0u,
                            (u32 *)nullptr, (u8 *)nullptr);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_ccnt, (u64)ncoarse, (const u32 *)nullptr,
                            d_coff, d_meta + 3, (u64)ctx->cap_ent, d_status);
@@ -652,7 +652,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         if (!fused_count)  // one level forced beyond one LDS range of windows (tuning): counted range by range
             hipLaunchKernelGGL(k_count<1>, dim3(NB, nranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_gstart, d_nkeep, nwin,
                                nwin, d_hist);
-        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 63) / 64), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, heavy_min,
+        hipLaunchKernelGGL(k_scan_cols, dim3((nwin + 3) / 4), dim3(256), 0, st, nwin, NB, d_hist, d_wincnt, heavy_min,
                            d_heavy, d_win_heavy);
         hipLaunchKernelGGL(k_scan<u32>, dim3(1), dim3(1024), 0, st, (const u32 *)d_wincnt, (u64)nwin, (const u32 *)nullptr,
                            d_winoff, d_meta + 3, (u64)ctx->cap_ent, d_status);
