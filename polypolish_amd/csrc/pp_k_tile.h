@@ -65,6 +65,7 @@ struct TileShare {
     u32 *any_shared;  // LDS flag
     const u32 *kk;
     u32 *pt, *pt_over;  // the window's table of two-byte keys (pt_insert) and its overflow flag
+    const u32 *pmask;   // LDS table of 33 words: pmask4(b) (see nz_perm)
 };
 
 // The depth share of ONE work item of class kc != 0 over the window positions [p0, p1) it covers (every entry of an
@@ -271,10 +272,12 @@ __device__ __forceinline__ u32 splat8(u32 n) {  // n * 0x01010101 for n < 256 (o
 __device__ __forceinline__ u32 nz_mask4(u32 x) {
     return __builtin_amdgcn_udot4(nz_flags(x) >> 7, 0x08040201u, 0u, false);
 }
+// (a vector type of alignment 1: ONE global_load_dwordx4 -- a 16-byte memcpy from a byte pointer is lowered to an
+// overlapping dwordx3 + dwordx2 and moves that have to wait for the first of them)
+typedef u32 u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 __device__ __forceinline__ uint4 load16_unaligned(const u8 *p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
+    const u32x4_unaligned v = *(const u32x4_unaligned *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ u32 load4_unaligned(const u8 *p) {
     u32 v;
@@ -434,6 +437,38 @@ __device__ __forceinline__ u32 nz_nibbles(u32 x) {
     const u32 z = (y | (y >> 3)) & 0x03030303u;        // two flags per byte: bits 0, 1 of byte b <=> nibbles 2b, 2b + 1
     return __builtin_amdgcn_udot4(z, 0x40100401u, 0u, false);
 }
+// The same for the four dwords of a 32-base chunk at once, WITHOUT moving the flags together: bit 4k + d of the result
+// <=> nibble k of x_d is not zero, i.e. base 8d + k of the chunk differs -- a permutation of the chunk's bitmap, which is
+// all the loop over the differing bases needs (19 instructions for 32 bases where four nz_nibbles and their three shifts are
+// 39; the chunk compare is what k_tile's item loop spends its VALU issue on).  (n & 7) + 7 carries into bit 3 of its own
+// nibble exactly when n & 7 is not zero and never beyond it.
+#ifndef PP_NZ_PERM
+#define PP_NZ_PERM 1
+#endif
+#ifndef PP_WIDE_LOADS_TOGETHER
+#define PP_WIDE_LOADS_TOGETHER 1
+#endif
+#ifndef PP_WIDE_PREFETCH_LATE
+#define PP_WIDE_PREFETCH_LATE 1
+#endif
+__device__ __forceinline__ u32 nz_perm(u32 x0, u32 x1, u32 x2, u32 x3) {
+    constexpr u32 m7 = 0x77777777u;
+    const u32 u0 = ((x0 & m7) + m7) | x0, u1 = ((x1 & m7) + m7) | x1, u2 = ((x2 & m7) + m7) | x2, u3 = ((x3 & m7) + m7) | x3;
+    u32 f = (u0 >> 3) & 0x11111111u;
+    f = ((u1 >> 2) & 0x22222222u) | (f & ~0x22222222u);
+    f = ((u2 >> 1) & 0x44444444u) | (f & ~0x44444444u);
+    return (u3 & 0x88888888u) | (f & ~0x88888888u);
+}
+// the bases [0, b) of a chunk in nz_perm's bit order, b = 0 .. 32 (k_tile keeps the 33 words in LDS: TileShare::pmask)
+__device__ __forceinline__ u32 pmask4(u32 b) {
+    u32 m = 0;
+#pragma unroll
+    for (u32 d = 0; d < 4u; d++) {
+        const u32 n = (u32)min(max((int)b - 8 * (int)d, 0), 8);
+        m |= (n == 8u ? 0x11111111u : (0x11111111u & ((1u << (4u * n)) - 1u))) << d;
+    }
+    return m;
+}
 __device__ __forceinline__ int row_of_code(u32 code) {
     return code < 4u ? (int)code : (code == (u32)PP_SEQ4_DASH ? ROW_DEL : ROW_OTH);
 }
@@ -558,7 +593,7 @@ __device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const TileSh
 // after the other against asm4 exactly as a lane of plain_apply4 compares its one.
 template <int NCH>
 __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const u8 *seq, const u8 *seq4,
-                                           const uint4 &my, bool mine) {
+                                           const uint4 &my, bool mine, const uint4 *ent, u32 nxt_at, uint4 &nxt) {
     const u32 ex = my.x, ey = my.y, ez = my.z;
     const int rel = item_rel(ez);
     const bool notrim = ((ez >> 30) & 1u) != 0;
@@ -567,16 +602,42 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
     const u8 *q = seq4 + (so >> 1);
     const bool odd = mine && ((u32)so & 1u) != 0;
+#if PP_WIDE_PREFETCH_LATE
+    {
+        // The next batch's items are asked for HERE, next to the pass's own loads, not at the top of tile_items' loop: a
+        // request that is out before the item's fields are unpacked is waited for on the spot (the fields' registers may
+        // be the target of a load from the slow classes' code further down the loop, and the wait the compiler puts in
+        // front of the first write to them drains everything in flight).  The empty asm ties the index to the unpacked
+        // offset, which keeps the scheduler from moving the load back up.
+        u32 at = nxt_at;
+        asm volatile("" : "+v"(at) : "v"((u32)(so >> 32)));
+        nxt = ent[at];
+    }
+#endif
     uint4 W[NCH];
     u32 tail = 0, xb = 0;
+    const u32 nch = (L + 31u) >> 5;  // chunks of this lane's read
+#pragma unroll
+    for (int c = 0; c < NCH; c++) W[c] = make_uint4(0, 0, 0, 0);
+#if PP_WIDE_LOADS_TOGETHER
+    if (mine) {
+        // ALL loads of the pass in one basic block, so that they are in flight together: with a condition per chunk every
+        // load sat in a block of its own, followed by the wait for it -- five dependent round trips per pass, which is what
+        // a wave's time consisted of.  A chunk past the read's last one repeats the last one's address (C::ok vouches for
+        // the room up to there) and is never looked at (b1 = 0 below); the byte behind the last chunk is what an odd start
+        // needs (inside the room then: so + 32 nch <= seq_bytes with so odd), any other read takes the byte in front of it.
+        tail = load4_unaligned(seq4 + ((so + (L - 1u)) >> 1) - 3);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) W[c] = load16_unaligned(q + 16u * min((u32)c, nch - 1u));
+        xb = q[16u * nch - (odd ? 0u : 1u)];
+    }
+#else
     if (mine) tail = load4_unaligned(seq4 + ((so + (L - 1u)) >> 1) - 3);
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        W[c] = make_uint4(0, 0, 0, 0);
+    for (int c = 0; c < NCH; c++)
         if (mine && 32u * (u32)c < L) W[c] = load16_unaligned(q + 16 * c);
-    }
-    const u32 nch = (L + 31u) >> 5;  // chunks of this lane's read
     if (odd) xb = q[16u * nch];
+#endif
     if (__ballot(odd)) {
         // some read of the pass starts on an odd base of the array (the flank behind an indel, a read after one of odd
         // length): its nibbles move down by one, the byte behind its last chunk fills the top
@@ -611,6 +672,21 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
             const u32 *ap = asm4 + (ai >> 3);
             const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
             const u32 sh = 4u * (ai & 7u);
+#if PP_NZ_PERM
+            u32 F = nz_perm(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh), W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
+                            W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh), W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh));
+            F &= S.pmask[b1] & ~S.pmask[b0];  // bases [b0, b1) only
+            while (F) {  // one trip per differing base: bit t = 4k + d <=> nibble k of dword d
+                const u32 t = (u32)__ffs((int)F) - 1u;
+                F &= F - 1u;
+                const u32 md0 = 0u - (t & 1u), md1 = 0u - ((t >> 1) & 1u);
+                const u32 wlo = (md0 & W[c].y) | (~md0 & W[c].x), whi = (md0 & W[c].w) | (~md0 & W[c].z);
+                const u32 code = (((md1 & whi) | (~md1 & wlo)) >> (t & 28u)) & 15u;
+                const int p = P0 + (int)(((t & 3u) << 3) | (t >> 2));
+                atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
+                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+            }
+#else
             u32 D = nz_nibbles(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh)) |
                     (nz_nibbles(W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh)) << 8) |
                     (nz_nibbles(W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh)) << 16) |
@@ -626,6 +702,7 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
                 atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
                 atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
             }
+#endif
         }
     }
 }
@@ -799,7 +876,10 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
         const u32 nb = min(BATCH, hi_w - eb);
         const uint4 my = nxt;
-        if (eb + BATCH < hi_w) nxt = A.entA[eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u)];
+        constexpr bool LATE = WIDE && PP_WIDE_PREFETCH_LATE;  // (then wide4_pass asks for them)
+        const bool more = eb + BATCH < hi_w;
+        const u32 nxt_at = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
+        if (!LATE && more) nxt = A.entA[nxt_at];
         const u32 my_flags = item_flags(my.y, my.z);
         const bool my_slow = lane < nb && (my_flags & 3u) != 0;
         const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
@@ -809,7 +889,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         u32 sl_nc = 0;
         if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         if (WIDE) {
-            wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain);
+            wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, A.entA, nxt_at, nxt);
             if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
         } else for (u32 first = 0; first < nb; first += C::IPP) {
             if (P4) plain_apply4(cnt, s_ndbits, S, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, my, nb, first, lane), lane);
@@ -903,12 +983,23 @@ constexpr u32 HSLAB_WORDS = (u32)(N_ROWS * TILE + TILE / 32);  // the nine count
 static_assert(HSLAB_WORDS % 4 == 0 && (N_ROWS * TILE) % 4 == 0 && TILE % 128 == 0, "the partial tallies move as 16-byte words");
 constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at the front of k_tile's grid (a multiple of 8)
 
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
+#ifndef PP_TILE_LAZY_ARGS
+#define PP_TILE_LAZY_ARGS 1
+#endif
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg) {
+    // The arguments are read where they are used, from the kernel-argument segment itself (scalar loads): taken by value
+    // the ~45 fields are all loaded at entry, as 16-dword tuples that the register allocator can only spill whole -- 222
+    // SGPR spills, and a v_readlane per spilled dword in front of every use: a fifth of the item loop's VALU issue.
+#if PP_TILE_LAZY_ARGS
+    const TileArgs &A = *(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const TileArgs &A = A_in_kernarg;
+#endif
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty, s_shared;
-    __shared__ unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below)
+    __shared__ __attribute__((aligned(16))) unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below); while the items are tallied its first 33 words hold pmask4()
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
     __shared__ u32 s_pt[PT_SLOTS * 3], s_ptover;
@@ -1012,6 +1103,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
         asm4[t] = v;
     }
     if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; }
+    if (tid >= 128u && tid < 128u + 33u) ((u32 *)s_dirty)[tid - 128u] = pmask4(tid - 128u);
     if (tid >= 64u && tid < 64u + PT_SLOTS * 3u) s_pt[tid - 64u] = 0;  // (a heavy window's helpers would each have their own table: listed as before)
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
@@ -1023,7 +1115,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A) {
     if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
 #endif
     const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk, s_pt, &s_ptover};  // (a heavy window's helpers: the same bits, their deficits add up)
+    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk, s_pt, &s_ptover, (const u32 *)s_dirty};  // (a heavy window's helpers: the same bits, their deficits add up)
     {
         u32 i0 = e0, i1 = e1;
         if (heavy) {  // this helper's share of the window's items

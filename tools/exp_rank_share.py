@@ -13,6 +13,7 @@ config, world = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
 lens, cov, repeat, label = bench.config_shape(config)
 job = bench.make_job(dev, contig_lens=lens, coverage=cov, repeat=repeat)
+job = bench.synthjob.with_wo(bench.synthjob.with_seq4(job))   # the two mirrors, as bench.py's default job carries them
 ctx = pp.Context(0)
 ctx.set_profiling(1)
 counts = np.bincount(job["recs"]["contig"].cpu().numpy().astype(np.int64), minlength=len(lens))
