@@ -178,6 +178,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
                                                const u32 *__restrict__ coarse_off,
                                                uint4 *__restrict__ entB, u32 frange, u64 *__restrict__ status) {
     __shared__ u32 cur[COUNT_RANGE];  // cursors of the coarse buckets of this pass
+    PP_STAMP(1, 0);
     if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
     // blockIdx.y: the pass -- frange (<= COUNT_RANGE) columns each.  The blocks of one pass are dispatched together (x runs
     // fastest), so the lines a pass writes to are few enough to stay in the L2s until they are full (see run_pipeline).
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
     for (u32 i = threadIdx.x; i < crange_n; i += blockDim.x)
         cur[i] = coarse_off[crange_lo + i] + hist_c[(u64)blockIdx.x * ncoarse + crange_lo + i];
     __syncthreads();
+    PP_STAMP(1, 1);
     const u32 range_lo = crange_lo * (u32)CW;                       // the same range, in windows
     const u32 range_n = min(crange_n * (u32)CW, nwin - range_lo);
     u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
             });
         }
     }
+    PP_STAMP(1, 2);
 }
 
 // Level 2 of the multisplit: one workgroup per coarse bucket counts its items per window, turns the counts into the

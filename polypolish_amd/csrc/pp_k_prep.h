@@ -4,6 +4,18 @@
 
 namespace pp {
 
+// Profiling build only (-DPP_PREP_STAMPS; tools/exp_prep_stamps.py): thread 0 of every block of k_prep (kernel 0) and
+// k_fill (kernel 1) leaves 100 MHz ticks at a few points, 8 words per block and kernel.
+#ifdef PP_PREP_STAMPS
+__device__ u64 *g_prep_stamps;
+#define PP_STAMP(kern, slot)                                                                                  \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.y == 0) g_prep_stamps[((u64)(kern) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define PP_STAMP(kern, slot) do { } while (0)
+#endif
+
 // =============================================================================================
 // k_prep
 // =============================================================================================
@@ -141,10 +153,12 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                                                u32 *__restrict__ hist, u64 *status) {
     __shared__ u32 h[COUNT ? COUNT_RANGE : 1];
     __shared__ u32 later[PREP_LATER_MAX], n_later;
+    PP_STAMP(0, 0);
     if (threadIdx.x == 0) n_later = 0;
     if (COUNT)
         for (u32 i = threadIdx.x; i < (u32)COUNT_RANGE; i += blockDim.x) h[i] = 0;
     __syncthreads();
+    PP_STAMP(0, 1);
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     // a record's result: stored, and (COUNT) tallied in the windows it reaches
     // contig_off / n_contigs / own are the JOB's (a record names its contig by the job's index); g_base[c] is where contig
@@ -259,7 +273,9 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                 }
             }
         }
+        PP_STAMP(0, 2);
         __syncthreads();
+        PP_STAMP(0, 3);
         for (u32 i = threadIdx.x; i < min(n_later, PREP_LATER_MAX); i += blockDim.x) {
             const u64 a = lo + later[i];
             const pp_wo_rec r = wo[a];
@@ -307,6 +323,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         general(a, a, c, n_cig[a], seq_len[a], ref_start[a], seq_off[a], cig_off[a], contig_off[cc], contig_off[cc + 1]);
     }
     }
+    PP_STAMP(0, 4);
     // the job's longest fast-class read, once per wave and only beyond the narrowest lane group (<= 160 bases); the
     // word is read from L2, not from a possibly stale CU-local copy
     if (__ballot(fast_len > PLAIN_NARROW_MAX)) {
@@ -316,8 +333,10 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
     }
     if (COUNT) {
         __syncthreads();
+        PP_STAMP(0, 5);
         for (u32 i = threadIdx.x; i < ncols; i += blockDim.x) hist[(u64)blockIdx.x * ncols + i] = h[i];
     }
+    PP_STAMP(0, 6);
 }
 
 }  // namespace pp

@@ -65,7 +65,7 @@ struct TileShare {
     u32 *any_shared;  // LDS flag
     const u32 *kk;
     u32 *pt, *pt_over;  // the window's table of two-byte keys (pt_insert) and its overflow flag
-    const u32 *pmask;   // LDS table of 33 words: pmask4(b) (see nz_perm)
+    const u32 *pmask;   // LDS table: pmask[PMASK_BASE + b] = pmask4(clamp(b, 0, 32)) (see wide4_pass)
 };
 
 // The depth share of ONE work item of class kc != 0 over the window positions [p0, p1) it covers (every entry of an
@@ -442,15 +442,6 @@ __device__ __forceinline__ u32 nz_nibbles(u32 x) {
 // all the loop over the differing bases needs (19 instructions for 32 bases where four nz_nibbles and their three shifts are
 // 39; the chunk compare is what k_tile's item loop spends its VALU issue on).  (n & 7) + 7 carries into bit 3 of its own
 // nibble exactly when n & 7 is not zero and never beyond it.
-#ifndef PP_NZ_PERM
-#define PP_NZ_PERM 1
-#endif
-#ifndef PP_WIDE_LOADS_TOGETHER
-#define PP_WIDE_LOADS_TOGETHER 1
-#endif
-#ifndef PP_WIDE_PREFETCH_LATE
-#define PP_WIDE_PREFETCH_LATE 1
-#endif
 __device__ __forceinline__ u32 nz_perm(u32 x0, u32 x1, u32 x2, u32 x3) {
     constexpr u32 m7 = 0x77777777u;
     const u32 u0 = ((x0 & m7) + m7) | x0, u1 = ((x1 & m7) + m7) | x1, u2 = ((x2 & m7) + m7) | x2, u3 = ((x3 & m7) + m7) | x3;
@@ -459,7 +450,7 @@ __device__ __forceinline__ u32 nz_perm(u32 x0, u32 x1, u32 x2, u32 x3) {
     f = ((u2 >> 1) & 0x44444444u) | (f & ~0x44444444u);
     return (u3 & 0x88888888u) | (f & ~0x88888888u);
 }
-// the bases [0, b) of a chunk in nz_perm's bit order, b = 0 .. 32 (k_tile keeps the 33 words in LDS: TileShare::pmask)
+// the bases [0, b) of a chunk in nz_perm's bit order, b = 0 .. 32 (k_tile keeps a table of them in LDS: TileShare::pmask)
 __device__ __forceinline__ u32 pmask4(u32 b) {
     u32 m = 0;
 #pragma unroll
@@ -583,17 +574,37 @@ __device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const TileSh
     }
 }
 
-// ---- the plain class, ONE LANE PER READ (4-bit mirror, reads up to 192 bases) ------------------------------------------
-// What the item loop costs is VALU issue: a CDNA SIMD is 16 lanes wide, a wave instruction takes four cycles, and a pass of
-// the lane-group scheme above is ~350 of them for 12 reads -- the fields of the item, the trim, the coverage atomics are
-// worked out by all five lanes of a group, once per read (measured: 159 M wave instructions per configs[1] job = 0.26 ms of
-// issue on 256 CUs; halving the bytes with the mirror moved k_tile by 4 %).  With 75 bytes per read a lane can hold a whole
-// read: NCH 16-byte loads (20 VGPRs at 160 bases), and the same ~450 instructions then serve 64 reads instead of 12.
+// ---- the plain class, ONE LANE PER READ (4-bit mirror, reads up to 160 bases) ------------------------------------------
+// What the item loop costs is VALU issue and the round trips of a pass.  A CDNA SIMD is 16 lanes wide, a wave instruction
+// takes four cycles, and a pass of the lane-group scheme above is ~350 of them for 12 reads -- the fields of the item, the
+// trim, the coverage atomics are worked out by all five lanes of a group, once per read.  With 75 bytes per read a lane can
+// hold a whole read: NCH 16-byte loads (20 VGPRs at 160 bases), and ~450 instructions then serve 64 reads instead of 12.
 // Lane l works on item l of the batch, straight from the batch registers (no ds_bpermute); its chunks are compared one
-// after the other against asm4 exactly as a lane of plain_apply4 compares its one.
+// after the other against asm4.  Round 4, from the ISA listing of this function:
+//  * ALL loads of a pass -- the read's chunks, the four bytes the trim looks at, the next batch of items -- go out in one
+//    basic block, one after the other: with a condition per chunk every load sat in a block of its own, followed by the
+//    wait for it (five dependent round trips per pass; k_tile 0.244 -> 0.221 ms on configs[1]);
+//  * a read that starts on an odd base of the array (the flank behind an indel, a read after one of odd length) is NOT moved
+//    down by a nibble any more (twenty funnel shifts and the byte behind the last chunk, for the whole wave whenever one
+//    lane had such a read): its window coordinates move instead -- it is compared as if it started one base earlier, with
+//    that base outside [lo, hi);
+//  * which bases of a chunk count -- [lo, hi) cut to the chunk -- is a pair of LDS table reads at constant offsets
+//    (TileShare::pmask) instead of four clamps and a branch per chunk; a chunk with no base in range is compared like any
+//    other and masked to nothing.
+constexpr int PMASK_BASE = 128;                   // TileShare::pmask[PMASK_BASE + b] = pmask4(clamp(b, 0, 32)), b = -128 .. 161
+constexpr int PMASK_WORDS = PMASK_BASE + 162;
+
+// A read the pass cannot take although PlainCfg<5>::ok says plain: an odd start whose LAST base counts (the flank in front
+// of an indel is not trimmed) when the length fills its last chunk -- one base too many for NCH chunks.  (A trimmed read
+// never looks at its last base.)  Such an item goes the way of the other fast classes.
+__device__ __forceinline__ bool wide4_takes(u32 ex, u32 ey, u32 ez) {
+    return !((ex & 1u) && ((ez >> 30) & 1u) && ((ey >> 24) & 31u) == 0);
+}
+
 template <int NCH>
 __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const u8 *seq, const u8 *seq4,
                                            const uint4 &my, bool mine, const uint4 *ent, u32 nxt_at, uint4 &nxt) {
+    static_assert(32 * (NCH - 1) <= PMASK_BASE && 32 * NCH + 1 < PMASK_WORDS - PMASK_BASE, "the range table");
     const u32 ex = my.x, ey = my.y, ez = my.z;
     const int rel = item_rel(ez);
     const bool notrim = ((ez >> 30) & 1u) != 0;
@@ -601,8 +612,7 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
     const u32 kc = (ey >> 8) & 0xFFu;
     const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);  // index of the piece's first base: a byte of seq, a nibble of seq4
     const u8 *q = seq4 + (so >> 1);
-    const bool odd = mine && ((u32)so & 1u) != 0;
-#if PP_WIDE_PREFETCH_LATE
+    const u32 adj = ex & 1u;  // an odd start: base i of the read is nibble i + 1 of what is loaded
     {
         // The next batch's items are asked for HERE, next to the pass's own loads, not at the top of tile_items' loop: a
         // request that is out before the item's fields are unpacked is waited for on the spot (the fields' registers may
@@ -613,45 +623,17 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
         asm volatile("" : "+v"(at) : "v"((u32)(so >> 32)));
         nxt = ent[at];
     }
-#endif
     uint4 W[NCH];
-    u32 tail = 0, xb = 0;
+    u32 tail = 0;
     const u32 nch = (L + 31u) >> 5;  // chunks of this lane's read
 #pragma unroll
     for (int c = 0; c < NCH; c++) W[c] = make_uint4(0, 0, 0, 0);
-#if PP_WIDE_LOADS_TOGETHER
     if (mine) {
-        // ALL loads of the pass in one basic block, so that they are in flight together: with a condition per chunk every
-        // load sat in a block of its own, followed by the wait for it -- five dependent round trips per pass, which is what
-        // a wave's time consisted of.  A chunk past the read's last one repeats the last one's address (C::ok vouches for
-        // the room up to there) and is never looked at (b1 = 0 below); the byte behind the last chunk is what an odd start
-        // needs (inside the room then: so + 32 nch <= seq_bytes with so odd), any other read takes the byte in front of it.
+        // A chunk past the read's last one repeats the last one's address (PlainCfg::ok vouches for the room up to there)
+        // and is never looked at: no base of it is in range.
         tail = load4_unaligned(seq4 + ((so + (L - 1u)) >> 1) - 3);
 #pragma unroll
         for (int c = 0; c < NCH; c++) W[c] = load16_unaligned(q + 16u * min((u32)c, nch - 1u));
-        xb = q[16u * nch - (odd ? 0u : 1u)];
-    }
-#else
-    if (mine) tail = load4_unaligned(seq4 + ((so + (L - 1u)) >> 1) - 3);
-#pragma unroll
-    for (int c = 0; c < NCH; c++)
-        if (mine && 32u * (u32)c < L) W[c] = load16_unaligned(q + 16 * c);
-    if (odd) xb = q[16u * nch];
-#endif
-    if (__ballot(odd)) {
-        // some read of the pass starts on an odd base of the array (the flank behind an indel, a read after one of odd
-        // length): its nibbles move down by one, the byte behind its last chunk fills the top
-        const u32 sh = odd ? 4u : 0u;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {  // in place, upwards: every dword takes its top nibble from the one after it
-            u32 nx = 0;                  // (chunks past the read's last one are zero)
-            if (c + 1 < NCH) nx = W[c + 1].x;
-            if ((u32)(c + 1) == nch) nx = xb;
-            W[c].x = __builtin_amdgcn_alignbit(W[c].y, W[c].x, sh);
-            W[c].y = __builtin_amdgcn_alignbit(W[c].z, W[c].y, sh);
-            W[c].z = __builtin_amdgcn_alignbit(W[c].w, W[c].z, sh);
-            W[c].w = __builtin_amdgcn_alignbit(nx, W[c].w, sh);
-        }
     }
     int nkeep = trim4(tail, so + (L - 1u), L);
     if (notrim) nkeep = (int)L;
@@ -663,46 +645,30 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
         if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
         share_range(cnt, ndbits, S, rel + lo, rel + hi, kc, my.w);
     }
+    if (!__ballot(live)) return;
+    // nibble x of the loaded chunks <-> window position relc + x; the nibbles [xlo, xhi) count (none of a lane that is not live)
+    const int relc = rel - (int)adj;
+    const u32 xlo = live ? (u32)lo + adj : 0u, xhi = live ? (u32)hi + adj : 0u;
+    const u32 *mlo = S.pmask + xlo, *mhi = S.pmask + xhi;
+    const u32 sh = (u32)(relc + ASM4_PAD) << 2;  // (v_alignbit takes it modulo 32: 4 * (the position's nibble in its dword), the same for all chunks)
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        const int b0 = min(max(lo - 32 * c, 0), 32), b1 = min(max(hi - 32 * c, 0), 32);
-        if (live && b1 > b0) {
-            const int P0 = rel + 32 * c;  // window position of the chunk's base 0 (> -32 here)
-            const u32 ai = (u32)(P0 + ASM4_PAD);
-            const u32 *ap = asm4 + (ai >> 3);
-            const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
-            const u32 sh = 4u * (ai & 7u);
-#if PP_NZ_PERM
-            u32 F = nz_perm(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh), W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
-                            W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh), W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh));
-            F &= S.pmask[b1] & ~S.pmask[b0];  // bases [b0, b1) only
-            while (F) {  // one trip per differing base: bit t = 4k + d <=> nibble k of dword d
-                const u32 t = (u32)__ffs((int)F) - 1u;
-                F &= F - 1u;
-                const u32 md0 = 0u - (t & 1u), md1 = 0u - ((t >> 1) & 1u);
-                const u32 wlo = (md0 & W[c].y) | (~md0 & W[c].x), whi = (md0 & W[c].w) | (~md0 & W[c].z);
-                const u32 code = (((md1 & whi) | (~md1 & wlo)) >> (t & 28u)) & 15u;
-                const int p = P0 + (int)(((t & 3u) << 3) | (t >> 2));
-                atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
-                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-            }
-#else
-            u32 D = nz_nibbles(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh)) |
-                    (nz_nibbles(W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh)) << 8) |
-                    (nz_nibbles(W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh)) << 16) |
-                    (nz_nibbles(W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh)) << 24);
-            D &= (0xFFFFFFFFu << b0) & (0xFFFFFFFFu >> (32 - b1));
-            while (D) {  // one trip per differing base
-                const int i = __ffs((int)D) - 1;
-                D &= D - 1u;
-                const u32 m8 = (u32)(((int)((u32)i << 28)) >> 31), m16 = (u32)(((int)((u32)i << 27)) >> 31);
-                const u32 wlo = (m8 & W[c].y) | (~m8 & W[c].x), whi = (m8 & W[c].w) | (~m8 & W[c].z);
-                const u32 code = (((m16 & whi) | (~m16 & wlo)) >> (4 * (i & 7))) & 15u;
-                const int p = P0 + i;
-                atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
-                atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
-            }
-#endif
+        const int P0 = relc + 32 * c;  // window position of the chunk's nibble 0
+        const u32 ai = (u32)min(max(P0 + ASM4_PAD, 0), 8 * (ASM4_WORDS - 5));  // (clamped only for a chunk with nothing in range)
+        const u32 *ap = asm4 + (ai >> 3);
+        const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+        u32 F = nz_perm(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh), W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
+                        W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh), W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh));
+        F &= mhi[PMASK_BASE - 32 * c] & ~mlo[PMASK_BASE - 32 * c];
+        while (F) {  // one trip per differing base: bit t = 4k + d <=> nibble k of dword d
+            const u32 t = (u32)__ffs((int)F) - 1u;
+            F &= F - 1u;
+            const u32 md0 = 0u - (t & 1u), md1 = 0u - ((t >> 1) & 1u);
+            const u32 wlo = (md0 & W[c].y) | (~md0 & W[c].x), whi = (md0 & W[c].w) | (~md0 & W[c].z);
+            const u32 code = (((md1 & whi) | (~md1 & wlo)) >> (t & 28u)) & 15u;
+            const int p = P0 + (int)(((t & 3u) << 3) | (t >> 2));
+            atomicAdd(&cnt[row_of_code(code) * TILE + p], 1u);
+            atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
         }
     }
 }
@@ -876,19 +842,18 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
         const u32 nb = min(BATCH, hi_w - eb);
         const uint4 my = nxt;
-        constexpr bool LATE = WIDE && PP_WIDE_PREFETCH_LATE;  // (then wide4_pass asks for them)
         const bool more = eb + BATCH < hi_w;
         const u32 nxt_at = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
-        if (!LATE && more) nxt = A.entA[nxt_at];
+        if (!WIDE && more) nxt = A.entA[nxt_at];  // (WIDE: wide4_pass asks for them, together with its own loads)
         const u32 my_flags = item_flags(my.y, my.z);
         const bool my_slow = lane < nb && (my_flags & 3u) != 0;
         const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
-        const bool my_plain = lane < nb && !my_point && C::ok(my.x, my.y, A.seq_bytes);
+        const bool my_plain = lane < nb && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
         if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
-        if (WIDE) {
+        if constexpr (WIDE) {
             wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, A.entA, nxt_at, nxt);
             if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
         } else for (u32 first = 0; first < nb; first += C::IPP) {
@@ -999,7 +964,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
     __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty, s_shared;
-    __shared__ __attribute__((aligned(16))) unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below); while the items are tallied its first 33 words hold pmask4()
+    __shared__ __attribute__((aligned(16))) unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below); while the items are tallied its first PMASK_WORDS words hold TileShare::pmask
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
     __shared__ u32 s_pt[PT_SLOTS * 3], s_ptover;
@@ -1103,7 +1068,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
         asm4[t] = v;
     }
     if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; }
-    if (tid >= 128u && tid < 128u + 33u) ((u32 *)s_dirty)[tid - 128u] = pmask4(tid - 128u);
+    if (tid >= 128u && tid < 128u + (u32)PMASK_WORDS)
+        ((u32 *)s_dirty)[tid - 128u] = pmask4((u32)min(max((int)tid - 128 - PMASK_BASE, 0), 32));
     if (tid >= 64u && tid < 64u + PT_SLOTS * 3u) s_pt[tid - 64u] = 0;  // (a heavy window's helpers would each have their own table: listed as before)
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);

@@ -599,6 +599,16 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // the records through the batch's window-order mirror when it brings one (pp_aln_batch.wo; PP_WO=0: tuning / tests)
     static const bool no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
     const pp_wo_rec *d_wo = no_wo ? nullptr : B.wo;
+#ifdef PP_PREP_STAMPS
+    static DevBuf b_pstamps;
+    const size_t pstamp_bytes = (size_t)2 * NB * 64;
+    if (int rc2 = dev_ensure(ctx, b_pstamps, pstamp_bytes)) return rc2;
+    PP_HIPCHK(ctx, hipMemsetAsync(b_pstamps.p, 0, pstamp_bytes, st));
+    {
+        u64 *sp = (u64 *)b_pstamps.p;
+        PP_HIPCHK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(pp::g_prep_stamps), &sp, sizeof sp, 0, hipMemcpyHostToDevice, st));
+    }
+#endif
     timer_begin(ctx, "prep");
 #define PP_PREP_ARGS dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, B.contig, B.ref_start, (const u64 *)B.seq_off, B.seq_len, \
                      (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full, \
@@ -660,6 +670,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     }
 #undef PP_FILL
     timer_end(ctx);
+#ifdef PP_PREP_STAMPS
+    if (const char *path = getenv("PP_PREP_STAMPS_FILE")) {
+        std::vector<uint64_t> hs(pstamp_bytes / 8);
+        PP_HIPCHK(ctx, hipMemcpyAsync(hs.data(), b_pstamps.p, pstamp_bytes, hipMemcpyDeviceToHost, st));
+        PP_HIPCHK(ctx, hipStreamSynchronize(st));
+        if (FILE *f = fopen(path, "wb")) { fwrite(hs.data(), 1, pstamp_bytes, f); fclose(f); }
+    }
+#endif
 
     TileArgs T;
     T.entA = d_entA; T.win_off = d_winoff; T.nwin = nwin;
