@@ -206,6 +206,41 @@ def test_read_lengths_across_the_lane_group_widths(ctx, orc, read_len):
     _compare_records(ctx, orc, contig_off, bases, recs)
 
 
+def _repitch(recs, pitch, lead=0):
+    """The same records with every read's bases at lead + i * pitch of a new seq array (the gaps hold a base that differs
+    from its neighbours, so that a compare that looks one base too far is seen)."""
+    n, L = len(recs["contig"]), int(recs["seq_len"][0])
+    assert (recs["seq_len"] == L).all() and pitch >= L
+    old = recs["seq"].reshape(n, L)
+    seq = np.full(lead + n * pitch + 64, ord("T"), dtype=np.uint8)
+    view = seq[lead:lead + n * pitch].reshape(n, pitch)
+    view[:, :L] = old
+    view[:, L:] = np.where(old[:, -1:] == ord("G"), ord("C"), ord("G"))
+    out = dict(recs)
+    out["seq"] = seq
+    out["seq_off"] = (np.uint64(lead) + np.arange(n, dtype=np.uint64) * np.uint64(pitch))
+    return out
+
+
+@pytest.mark.parametrize("read_len,pitch", [(160, 161), (128, 129), (64, 65), (96, 97), (150, 151), (99, 99), (151, 151), (159, 159)])
+def test_reads_that_start_on_odd_bases_of_the_seq_array(ctx, orc, read_len, pitch):
+    """With the 4-bit mirror a read that starts on an odd base of the seq array is compared through shifted window
+    coordinates (wide4_pass); a length that fills its last 32-base chunk leaves no room for the shift -- fine for a trimmed
+    read, whose last base never counts, and handed to the other fast classes for the untrimmed flank in front of an indel
+    (wide4_takes).  Odd pitches give every other read an odd start; with a third of the reads carrying an indel, flanks of
+    32, 64 and 96 bases in front of one are there."""
+    contig_off, bases, recs = synth.fast_records(seed=300 + read_len, contig_lens=(14_000, 2_600), coverage=60, read_len=read_len,
+                                                 indel_read_frac=0.35, n_rate=0.002, k_choices=(1, 1, 1, 2, 3))
+    recs = _repitch(recs, pitch, lead=1 if pitch % 2 == 0 else 0)
+    odd = (recs["seq_off"] & np.uint64(1)) == 1
+    assert odd.any() and (~odd).any()
+    if read_len >= 99:
+        three = recs["n_cig"] == 3
+        front = recs["cigar"][recs["cig_off"][three].astype(np.int64)] >> 4
+        assert ((front % 32 == 0) & odd[three]).any(), "no untrimmed flank that fills its last chunk from an odd start"
+    _compare_records(ctx, orc, contig_off, bases, recs)
+
+
 def test_mixed_read_lengths_in_one_job(ctx, orc):
     """The longest read picks the group width for everyone: 150-base and 250-base reads together (8 lanes),
     and 150 + 180 (6 lanes)."""
