@@ -175,11 +175,20 @@ extern "C" int pp_polish_gather_to_host_(pp_ctx *ctx, uint8_t *host_out, uint64_
     if (!ctx->comm) return ctx->fail(PP_ERR_ARG, "pp_polish_gather without pp_comm_init");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool root = ctx->comm_rank == 0;
-    if (root && !host_out) return ctx->fail(PP_ERR_ARG, "pp_polish_gather_to_host_: rank 0 needs a buffer");
-    if (root)
-        if (int rc = pp::dev_ensure(ctx, ctx->b_gather, (size_t)cap + 16)) return rc;
+    // A rank 0 that cannot take the bytes (no host buffer, no room on its device) still JOINS the collective, with a buffer
+    // of zero bytes: every rank then learns from the gathered figures that nothing fits and returns the same error, where a
+    // rank 0 that backed out here would leave the others waiting in the AllGather for good.
+    int root_rc = PP_OK;
+    if (root && !host_out) root_rc = ctx->fail(PP_ERR_ARG, "pp_polish_gather_to_host_: rank 0 needs a buffer");
+    if (root && root_rc == PP_OK) root_rc = pp::dev_ensure(ctx, ctx->b_gather, (size_t)cap + 16);
+    const std::string root_err = root_rc ? ctx->err : std::string();
+    const bool have = root && root_rc == PP_OK;
     std::vector<uint64_t> lens((size_t)ctx->comm_world, 0);
-    if (int rc = pp_polish_gather(ctx, root ? (uint8_t *)ctx->b_gather.p : nullptr, root ? cap : 0, lens.data(), rank_contig_off)) return rc;
+    if (int rc = pp_polish_gather(ctx, have ? (uint8_t *)ctx->b_gather.p : nullptr, have ? cap : 0, lens.data(), rank_contig_off)) {
+        if (root_rc) { ctx->err = root_err; return root_rc; }
+        return rc;
+    }
+    if (root_rc) { ctx->err = root_err; return root_rc; }  // (only when there was nothing to gather at all)
     if (rank_len) memcpy(rank_len, lens.data(), lens.size() * 8);
     if (root) {
         uint64_t total = 0;

@@ -169,10 +169,11 @@ extern "C" int pp_polish_files(pp_ctx *ctx, const char *assembly, const char *co
 // One process, several GPUs (polish::polish has no counterpart: src/polish.rs:137-154 is one thread): every context
 // uploads and tokenizes its own slice of every SAM file (or the host ingest parses once), the records are partitioned --
 // a context is sent the records that reach its units (pp_shard_split) -- the contexts polish side by side on their own
-// threads, and the polished bytes meet on the first context's GPU in ONE RCCL gather over xGMI (pp_polish_gather: the
-// north star's "single RCCL gather for the final FASTA") followed by one device-to-host copy.  Where RCCL cannot run --
-// librccl not loadable, two contexts on one device (PP_SHARE_GPU, tests), PP_GATHER=host -- every device copies its own
-// share out and the host puts them together; PP_TIMING prints the route that was taken.
+// threads, and every device copies its own share of the polished bytes out for the host to put together -- or, with
+// PP_GATHER=rccl, the bytes meet on the first context's GPU in ONE RCCL gather over xGMI (pp_polish_gather: the north
+// star's "single RCCL gather for the final FASTA") followed by one device-to-host copy.  The RCCL route of THIS driver is
+// opt-in until it has run on a multi-GPU node (see below); it cannot run without librccl or with two contexts on one
+// device (PP_SHARE_GPU, tests).  PP_TIMING prints the route that was taken.
 extern "C" int pp_polish_files_multi(pp_ctx *const *ctxs, int n_ctx, const char *assembly, const char *const *sams,
                                      int n_sams, const pp_polish_options *opt, pp_bytes *fasta) {
     if (!ctxs || n_ctx < 1) return PP_ERR_ARG;
@@ -680,7 +681,12 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
         lap("records split");
         // every context: its records, the ranges of its units, finish, its own bytes to the host -- side by side
         // ---- how the polished bytes will reach the host: one RCCL gather to the first context's GPU, or every device by itself ----
-        bool use_rccl = !(getenv("PP_GATHER") && !strcmp(getenv("PP_GATHER"), "host"));
+        // The RCCL route is OPT-IN (PP_GATHER=rccl) in this one-process driver: it has only ever run with world = 1 -- the boxes
+        // this was built on have one GPU, and RCCL refuses two ranks on one device -- and a rank that fails inside
+        // ncclCommInitRank leaves the other threads waiting there.  The default is the route every test runs: each device
+        // copies its share out and the FASTA is assembled on the host.  (One process per GPU -- python -m
+        // polypolish_amd.distributed, bench.py --gpus N -- gathers over RCCL, behind a watchdog.)
+        bool use_rccl = getenv("PP_GATHER") && !strcmp(getenv("PP_GATHER"), "rccl");
         for (int d = 0; d < n_ctx && use_rccl; d++)
             for (int e = 0; e < d; e++)
                 if (pp_ctx_device_(ctxs[d]) == pp_ctx_device_(ctxs[e])) use_rccl = false;  // RCCL refuses two ranks on one device
@@ -693,7 +699,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             }
         }
         if (timing) fprintf(stderr, "[timing] polished bytes -> host: %s\n", use_rccl ? "ONE RCCL gather (ncclSend/ncclRecv over xGMI) to the first GPU + one D2H"
-                                                                                    : "every device copies its share out, assembled on the host (no RCCL: PP_GATHER=host, shared device, or librccl missing)");
+                                                                                    : "every device copies its share out, assembled on the host (the default; PP_GATHER=rccl asks for the RCCL gather -- not with two contexts on one device or without librccl)");
         std::vector<uint8_t> gathered;
         std::vector<uint64_t> r_total((size_t)n_ctx, 0);
         std::vector<std::vector<uint8_t>> r_bytes((size_t)n_ctx);

@@ -1068,7 +1068,8 @@ def test_device_filter_load_details_and_errors(pp, ctx, orc, tmp_path):
 
 
 def test_reference_orientation_vectors_on_device(ctx, pp):
-    """T4 (src/filter.rs:384-424) and T3 (src/alignment.rs:402-422) through the filter kernels."""
+    """T4 (src/filter.rs:384-424) through the filter kernels: orientation and insert size of the eight pairs (all `150M`).
+    T3's four CIGARs (src/alignment.rs:402-422) go through k_ref_end in tests/test_reference_vectors_gpu.py."""
     import ctypes as C
     import json
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_unit_vectors.json")))
