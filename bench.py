@@ -110,6 +110,8 @@ def run_job(ctx, pp, job, params=(5, 0.5, 0.2)):
                 ptrs["seq4"] = seq4.data_ptr()
             if wo is not None:
                 ptrs["wo"] = wo.data_ptr()
+                if job.get("wo_runs") and not os.environ.get("PP_BENCH_NO_RUNS"):  # the mirror's runs: the direct path
+                    ptrs["wo_runs"] = job["wo_runs"]
             run = ctx.prepared_job(job["contig_off"], job["bases"].data_ptr(), pp.MEM_DEVICE, job["n_aln"],
                                    ptrs, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE,
                                    *params, emit=job.get("emit"))

@@ -145,7 +145,20 @@ typedef struct {
      * on the 5 Mbp / 200x job).  The library's ingests bring one; pp_polish_add carries it along while every batch of the
      * job has one. */
     const struct pp_wo_rec *wo;
+    /* Optional with wo (0 / NULL = not known): the mirror as RUNS.  wo_n_runs stretches of entries, one behind the other
+     * (one per SAM file, as the library's ingests write it), each of them window-grouped IN ASCENDING WINDOW ORDER;
+     * wo_run_end[r] = the index one past the last entry of run r (ascending; the last one = n_aln).  HOST memory whatever
+     * the batch's `mem` (a handful of numbers; copied by pp_polish_add).  With it -- and in a job that is not sharded
+     * (pp_polish_set_emit) -- the pileup kernel takes the records that are one short M run inside their contig STRAIGHT from
+     * the mirror, window by window (round 5: no bucketing pass, no work items for them); one streaming pass over the
+     * mirror validates every record as before, finds where each window's entries start in every run and cuts work items
+     * only for the others (indels, long reads) and for the reads that reach into the next window.  A hint like the
+     * mirror itself: where the entries turn out not to be in that order (any permutation is still a valid mirror) the
+     * job silently takes the bucketing path; every result is the same. */
+    uint32_t wo_n_runs;
+    const uint64_t *wo_run_end;
 } pp_aln_batch;
+#define PP_WO_MAX_RUNS 16  /* more runs than this: the bucketing path */
 /* one record of pp_aln_batch.wo: the fields the bucketing reads, file_idx = the record's index in the batch's arrays (its
  * place in file order), op0 = its only CIGAR run (packed as in `cigar`) or PP_WO_MULTI_RUN for a record of several runs
  * (those are read from n_cig / cig_off / cigar by file_idx) */

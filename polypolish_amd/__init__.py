@@ -43,7 +43,29 @@ class AlnBatch(C.Structure):
                 ("seq_off", C.c_void_p), ("seq_len", C.c_void_p), ("cig_off", C.c_void_p), ("n_cig", C.c_void_p),
                 ("seq", C.c_void_p), ("seq_bytes", C.c_uint64), ("cigar", C.c_void_p), ("n_cig_total", C.c_uint64),
                 ("seq4", C.c_void_p),  # optional 4-bit mirror of seq (include/polypolish_hip.h); None = none
-                ("wo", C.c_void_p)]    # optional window-order mirror of the records (pp_wo_rec[n_aln]); None = none
+                ("wo", C.c_void_p),    # optional window-order mirror of the records (pp_wo_rec[n_aln]); None = none
+                ("wo_n_runs", C.c_uint32), ("wo_run_end", C.c_void_p)]  # optional: the mirror's runs (HOST array of u64 ends)
+
+
+def _runs_of(b):
+    """the run table of a batch's window-order mirror (pp_aln_batch.wo_run_end: HOST memory) as a numpy array"""
+    if not b.wo_n_runs or not b.wo_run_end:
+        return np.zeros(0, dtype=np.uint64)
+    return np.ctypeslib.as_array(C.cast(b.wo_run_end, C.POINTER(C.c_uint64)), shape=(int(b.wo_n_runs),)).copy()
+
+
+def aln_batch(n_aln, ptrs: dict, seq_bytes, n_cig_total):
+    """pp_aln_batch from addresses (field name -> address; "seq4", "wo" optional) plus, optionally, ptrs["wo_runs"]: the ends
+    of the mirror's runs (a sequence of integers, HOST: pp_aln_batch.wo_run_end)."""
+    runs = ptrs.get("wo_runs")
+    if runs is not None:
+        runs = np.ascontiguousarray(runs, dtype=np.uint64)
+    b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
+                 ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
+                 ptrs.get("wo") or None, len(runs) if runs is not None and ptrs.get("wo") else 0,
+                 runs.ctypes.data if runs is not None and len(runs) and ptrs.get("wo") else None)
+    b._runs = runs  # (the C side reads it during pp_polish_add)
+    return b
 
 
 # one record of pp_aln_batch.wo (include/polypolish_hip.h: pp_wo_rec, 32 bytes)
@@ -350,6 +372,7 @@ def ingest(assembly, sams, max_errors=10, careful=False, seq_layout=None):
             recs[name] = arr
         if b.wo and b.n_aln:  # the window-order mirror of the records (pp_aln_batch.wo)
             recs["wo"] = np.ctypeslib.as_array(C.cast(b.wo, C.POINTER(C.c_uint8)), shape=(int(b.n_aln) * WO_DTYPE.itemsize,)).copy().view(WO_DTYPE)
+            recs["wo_runs"] = _runs_of(b)
         return names, descs, off, bases, recs, counts
     finally:
         if g:
@@ -419,6 +442,7 @@ def ingest_device(ctx, assembly, sams, max_errors=10, careful=False, seq_layout=
             w = np.zeros(int(b.n_aln), dtype=WO_DTYPE)
             ctx._chk(L.pp_ctx_download(ctx._h, w.ctypes.data, b.wo, w.nbytes))
             recs["wo"] = w
+            recs["wo_runs"] = _runs_of(b)
         return names, descs, off, bases, recs, counts
     finally:
         if g:
@@ -714,9 +738,7 @@ class Context:
         self._chk(lib().pp_polish_begin(self._h, self._n_contigs, off.ctypes.data, bases_ptr, bases_mem, C.byref(p)))
 
     def polish_add_ptrs(self, n_aln, ptrs: dict, seq_bytes, n_cig_total, mem):
-        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
-                     ptrs.get("wo") or None)
+        b = aln_batch(n_aln, ptrs, seq_bytes, n_cig_total)
         self._chk(lib().pp_polish_add(self._h, C.byref(b), mem))
 
     def polish_finish(self):
@@ -730,9 +752,7 @@ class Context:
         L = lib()
         off = np.ascontiguousarray(contig_off, dtype=np.uint64)
         p = Params(min_depth, fraction_valid, fraction_invalid)
-        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
-                     ptrs.get("wo") or None)
+        b = aln_batch(n_aln, ptrs, seq_bytes, n_cig_total)
         n_contigs, G = len(off) - 1, int(off[-1])
         h, off_p, p_ref, b_ref = self._h, off.ctypes.data, C.byref(p), C.byref(b)
         begin, add, finish, set_emit = L.pp_polish_begin, L.pp_polish_add, L.pp_polish_finish, L.pp_polish_set_emit

@@ -628,6 +628,8 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     v.n_aln = hi - lo;
                     v.contig += lo; v.ref_start += lo; v.k += lo; v.seq_off += lo; v.seq_len += lo; v.cig_off += lo; v.n_cig += lo;
                     if (v.wo) v.wo += lo;  // (a slice's entries of the window-order mirror are its own stretch; they count from lo)
+                    v.wo_n_runs = 0;       // (the run table is the whole batch's)
+                    v.wo_run_end = nullptr;
                     srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base, (uint32_t)lo});
                     base += hi - lo;
                 }

@@ -273,6 +273,7 @@ struct pp_ingest {
     HugeBuf<uint64_t> seq_off, cig_off, name_off;
     HugeBuf<uint8_t> seq;
     HugeBuf<pp_wo_rec> wo;  // the records once more, in window order (pp_aln_batch.wo); empty with PP_WO=0
+    std::vector<uint64_t> wo_run_end;  // ... one run per SAM file, in ascending window order: where each ends (pp_aln_batch.wo_run_end)
     bool wo_mirror = true;
     HugeBuf<char> names;  // NUL-separated QNAMEs, one per record
     std::vector<std::thread> reapers;  // parse-time memory of finished files being released in the background
@@ -775,7 +776,10 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                     }
                 }
             });
-            if (mirror) I->wo.resize(base + n_out);
+            if (mirror) {
+                I->wo.resize(base + n_out);
+                I->wo_run_end.push_back(base + n_out);  // this file's entries: one run
+            }
             lap("window layout");
         }
         parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
@@ -874,6 +878,9 @@ extern "C" void pp_ingest_batch(const pp_ingest *I, pp_aln_batch *out) {
     out->seq_bytes = I->seq.size();
     out->seq4 = nullptr;
     out->wo = I->wo_mirror && I->wo.size() == I->contig.size() && I->contig.size() ? I->wo.data() : nullptr;
+    const bool runs = out->wo && !I->wo_run_end.empty() && I->wo_run_end.back() == I->contig.size();
+    out->wo_n_runs = runs ? (uint32_t)I->wo_run_end.size() : 0;
+    out->wo_run_end = runs ? I->wo_run_end.data() : nullptr;
     out->cigar = I->cigar.data();
     out->n_cig_total = I->cigar.size();
 }

@@ -83,6 +83,10 @@ enum DevErr : uint32_t {
     DE_HALO = 14,           // compact run (run_pipeline): a record reaches an owned stretch from outside its slice -> rerun uncompacted
     DE_CAPACITY_LATE = 13,  // the same, raised from k_tile on: the work items are valid, so k_tile and k_exact2 keep
                             // COUNTING what they would need (guarded writes) and one rerun is enough
+    DE_BAD_MIRROR = 15,     // an entry of the window-order mirror names a record the batch does not have (pp_aln_batch.wo)
+    DE_MIRROR_ORDER = 16,   // direct path (pp_k_direct.h): the mirror's entries are not in the order its run table promises
+                            // -> the host runs the job over the bucketing path (always reported at the largest index, so
+                            // that the error of any record wins)
 };
 
 struct DevBuf {
@@ -143,6 +147,13 @@ struct pp_ctx {
     pp::DevBuf b_vote_tab;  // the job's vote thresholds per integer depth (k_meta_init)
     pp::DevBuf b_multi, b_meta, b_out, b_flag_bits, b_win_nflag, b_win_slab, b_slab_win, b_slabs, b_ents, b_keys, b_own;
     pp::DevBuf b_win_heavy, b_hslab;  // heavy windows: slot + 1 per window (u8) | the helpers' partial tallies
+    // ---- the direct path (pp_k_direct.h) ----
+    std::vector<uint64_t> wo_runs;      // ends of the runs of the job's window-order mirror (pp_aln_batch.wo_run_end, rebased); empty = not known
+    pp::DevBuf b_runs, b_first, b_xcnt, b_xent, b_need_win, b_win_lo, b_win_hi;
+    std::vector<uint32_t> runs_on_dev;  // what b_runs holds (identical tables are not uploaded again)
+    size_t xcap = 0;                    // room for extras per window (grow-only)
+    bool no_direct = false;             // this job is being rerun over the bucketing path (DE_MIRROR_ORDER)
+    bool last_direct = false;           // the last pass over the pipeline took the direct path
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run

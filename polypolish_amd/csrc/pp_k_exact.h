@@ -74,7 +74,7 @@ struct ExactArgs {
     const u32 *flag_cov;
     const u64 *flag_scr;
     const uint4 *entA;
-    const u32 *win_off;
+    const u32 *win_lo, *win_hi;  // the items of window w: entA[win_lo[w] .. win_hi[w]) -- the bucketing's offsets of w and w + 1, or (direct path) what k_xmat wrote out for the windows k_tile listed
     const u8 *seq;
     const u64 *seq_off;
     const u64 *cig_off;
@@ -154,7 +154,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, u32 cap, ulonglong2 *cov,
     const u32 gp = A.flag_pos[f];
     const u32 w = gp / (u32)TILE;
     const int pr = (int)(gp - w * (u32)TILE);
-    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
+    const u32 e0 = A.win_lo[w], e1 = A.win_hi[w];
     const u8 orig = A.bases[gp];
     const u32 c = find_contig_wave(A.contig_off, A.n_contigs, gp, lane);
     // ---- the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40); any order, sorted below ----
@@ -395,7 +395,7 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
 
     // collect the covering alignments: x = (file index << 32 | k), y = slice (offset | len << 40)
     u32 n = 0;
-    for (u32 e = A.win_off[w]; e < A.win_off[w + 1]; e++) {
+    for (u32 e = A.win_lo[w]; e < A.win_hi[w]; e++) {
         const uint4 ent = A.entA[e];
         const int q = pr - item_rel(ent.z);
         const u32 fl = (ent.y >> 16) & 0xFFu, idx = ent.w;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
             if (tid == 0)
                 for (u32 ww = blockIdx.x; ww < nwin; ww += gridDim.x) {
                     if (!A.win_nflag[ww] || A.win_heavy[ww]) continue;
-                    const u32 nn = A.win_off[ww + 1] - A.win_off[ww];
+                    const u32 nn = A.win_hi[ww] - A.win_lo[ww];
                     if (nn <= SMAX && nn > NLOW && nn > LDS_LIST_MAX) atomicAdd(A.ents_cursor, (u64)nn);  // smaller lists stay in LDS
                 }
             return;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
         plo = (int)(blockIdx.x % SUB) * PSPAN;
     }
     if (A.win_nflag[w] == 0) return;
-    const u32 e0 = A.win_off[w], n_all = A.win_off[w + 1] - e0;
+    const u32 e0 = A.win_lo[w], n_all = A.win_hi[w] - e0;
     if (SUB == 1) {
         if (A.win_heavy[w]) return;                  // the sub-range instance's
         if (n_all > SMAX || n_all <= NLOW) return;  // the other instance's window, or (n > SORT_MAX) replayed by k_exact

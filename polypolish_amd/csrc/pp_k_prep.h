@@ -241,6 +241,9 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
                 r.seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32); r.op0 = qb[u].z; r.file_idx = qb[u].w;
                 const u32 cc = min(r.contig, n_contigs - 1u);
                 const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1], gb = g_base[cc];
+                // the mirror is a hint, but its file index is what the arrays are read by (here for the records with several
+                // runs, in k_tile for every slow item): an entry that names no record of the batch is the caller's error
+                if (in && r.file_idx >= n) { report(status, a, DE_BAD_MIRROR); r.file_idx = 0; }
                 bool bulk = in && r.contig < n_contigs && r.op0 != PP_WO_MULTI_RUN && (r.op0 & 15u) == PP_OP_M && (r.op0 >> 4) == r.seq_len &&
                             r.seq_len > 0 && r.seq_len <= FAST_MAX_LEN && (u64)r.ref_start + r.seq_len <= c_hi - c_lo;
                 // what finish() will make of a bulk record, as far as the histogram's first entry goes (the same tests)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prep(u64 n, u64 chunk, 
         for (u32 i = threadIdx.x; i < min(n_later, PREP_LATER_MAX); i += blockDim.x) {
             const u64 a = lo + later[i];
             const pp_wo_rec r = wo[a];
-            const u32 cc = min(r.contig, n_contigs - 1u), fi = r.file_idx;
+            const u32 cc = min(r.contig, n_contigs - 1u), fi = r.file_idx < n ? r.file_idx : 0u;  // (out of range: reported in the loop)
             general(a, fi, r.contig, r.op0 == PP_WO_MULTI_RUN ? n_cig[fi] : 1u, r.seq_len, r.ref_start, r.seq_off, cig_off[fi], contig_off[cc],
                     contig_off[cc + 1]);
         }

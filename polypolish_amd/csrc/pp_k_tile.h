@@ -57,6 +57,26 @@ struct TileArgs {
     u8 *dbg_status;
     u64 *status;
     int dbg;
+    // ---- the direct path (pp_k_direct.h): the window's bulk comes straight from the window-order mirror ----
+    const uint4 *wo;      // the mirror, two 16-byte words per record
+    const u32 *first;     // [n_runs][nwin + 1]: where the entries of window w begin in run r
+    u32 n_runs;
+    u32 xcap;             // room for extras per window
+    const u32 *x_cnt;     // extras of each window ...
+    const uint4 *xent;    // ... at xent[w * xcap ..]
+    u32 *need_win;        // the windows the exact replays will read items of (k_xmat writes them out) ...
+    u64 *n_need;          // ... and how many
+};
+
+// direct path: how a window's virtual item index maps to mirror entries (LDS), and the window's contig when it has only one
+struct RecMap {
+    const u32 *pre;    // [R + 1] entries of the runs before run r in this window (prefix sums of the stretches)
+    const u32 *first;  // [R] first entry of the window in run r
+    u32 R;
+    u32 w;             // the window
+    bool one_contig;
+    u32 c0;            // its contig (one_contig) ...
+    u64 c_lo, clen;    // ... where that starts, how long it is
 };
 
 // the window's fixed-point bits and whether any item of it had a depth share other than 1 (then the deficit row is scanned)
@@ -601,9 +621,9 @@ __device__ __forceinline__ bool wide4_takes(u32 ex, u32 ey, u32 ez) {
     return !((ex & 1u) && ((ez >> 30) & 1u) && ((ey >> 24) & 31u) == 0);
 }
 
-template <int NCH>
+template <int NCH, bool REC>
 __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const u8 *seq, const u8 *seq4,
-                                           const uint4 &my, bool mine, const uint4 *ent, u32 nxt_at, uint4 &nxt) {
+                                           const uint4 &my, bool mine, const uint4 *ent, u32 nxt_at, uint4 &nxt, uint4 &nxt2) {
     static_assert(32 * (NCH - 1) <= PMASK_BASE && 32 * NCH + 1 < PMASK_WORDS - PMASK_BASE, "the range table");
     const u32 ex = my.x, ey = my.y, ez = my.z;
     const int rel = item_rel(ez);
@@ -621,7 +641,10 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
         // offset, which keeps the scheduler from moving the load back up.
         u32 at = nxt_at;
         asm volatile("" : "+v"(at) : "v"((u32)(so >> 32)));
-        nxt = ent[at];
+        if (REC) {  // (direct path: the next batch are mirror entries, two 16-byte words each)
+            nxt = ent[2ull * at];
+            nxt2 = ent[2ull * at + 1];
+        } else nxt = ent[at];
     }
     uint4 W[NCH];
     u32 tail = 0;
@@ -823,9 +846,9 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const TileShare &S, const u
 // The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
 // hidden by the other 7 waves of the SIMD, not by software pipelining of the passes (which measured slower).
-template <int GW, bool P4>
+template <int GW, bool P4, bool REC>
 __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const TileShare &S, const u32 *asm_w,
-                                           const u32 *asm4, u32 e0, u32 e1, u32 wave, u32 lane) {
+                                           const u32 *asm4, const uint4 *ent, const RecMap &M, u32 e0, u32 e1, u32 wave, u32 lane) {
     typedef PlainCfg<GW> C;
     // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
     constexpr bool WIDE = P4 && GW == 5;
@@ -836,29 +859,69 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
     const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
     if (lo_w >= hi_w) return;
+    // REC (direct path): [e0, e1) are the window's mirror entries numbered run after run; entry v is record rec_at(v) of the
+    // mirror `ent` (two 16-byte words), and its work item is made up here, in registers (wo_item: what k_fill would have
+    // written for it).  A record that is not bulk (its pieces are among the window's extras) is passed over.
+    auto rec_at = [&](u32 v) -> u32 {
+        u32 a = M.first[0] + v;
+        for (u32 r = 1; r < M.R; r++)
+            if (v >= M.pre[r]) a = M.first[r] + (v - M.pre[r]);
+        return a;
+    };
     // the records of the batch after the current one are asked for before the current one is worked on (2-5 % of the
     // kernel: a wave's chain of dependent round trips is what its time consists of)
-    uint4 nxt = A.entA[lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u)];
+    uint4 nxt, nxt2 = make_uint4(0, 0, 0, 0);
+    {
+        const u32 at = lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u);
+        if (REC) {
+            const u32 a = rec_at(at);
+            nxt = ent[2ull * a];
+            nxt2 = ent[2ull * a + 1];
+        } else nxt = ent[at];
+    }
     for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
         const u32 nb = min(BATCH, hi_w - eb);
-        const uint4 my = nxt;
+        uint4 my = nxt;
+        bool rec_ok = true;
+        if (REC) {
+            const uint4 qa = nxt, qb = nxt2;  // contig, ref_start, k, seq_len | seq_off (two words), op0, file index
+            u64 c_lo = M.c_lo, clen = M.clen;
+            bool c_ok = qa.x == M.c0;
+            if (!M.one_contig) {  // (a window with a contig boundary in it)
+                const u32 cc = min(qa.x, A.n_contigs - 1u);
+                c_lo = A.contig_off[cc];
+                clen = A.contig_off[cc + 1] - c_lo;
+                c_ok = qa.x < A.n_contigs;
+            }
+            rec_ok = wo_bulk(c_ok, qa.y, qa.w, qb.z, clen);
+            my = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), c_lo + qa.y, M.w, qb.w);
+        }
         const bool more = eb + BATCH < hi_w;
-        const u32 nxt_at = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
-        if (!WIDE && more) nxt = A.entA[nxt_at];  // (WIDE: wide4_pass asks for them, together with its own loads)
-        const u32 my_flags = item_flags(my.y, my.z);
-        const bool my_slow = lane < nb && (my_flags & 3u) != 0;
-        const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
-        const bool my_plain = lane < nb && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
+        u32 nxt_at = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
+        if (REC) nxt_at = rec_at(nxt_at);
+        if (!WIDE && more) {  // (WIDE: wide4_pass asks for them, together with its own loads)
+            if (REC) {
+                nxt = ent[2ull * nxt_at];
+                nxt2 = ent[2ull * nxt_at + 1];
+            } else nxt = ent[nxt_at];
+        }
+        const u32 my_flags = REC ? 0u : item_flags(my.y, my.z);
+        const bool my_slow = !REC && lane < nb && (my_flags & 3u) != 0;
+        const bool my_point = !REC && lane < nb && (my_flags & ENT_POINT) != 0;
+        const bool my_plain = lane < nb && rec_ok && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
         if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         if constexpr (WIDE) {
-            wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, A.entA, nxt_at, nxt);
+            wide4_pass<GW, REC>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, ent, nxt_at, nxt, nxt2);
             if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
         } else for (u32 first = 0; first < nb; first += C::IPP) {
-            if (P4) plain_apply4(cnt, s_ndbits, S, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, my, nb, first, lane), lane);
-            else plain_apply(cnt, s_ndbits, S, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, my, nb, first, lane), lane);
+            // (REC: a group picks its item out of the batch registers; a record that is not bulk shows as an item of length 0)
+            uint4 mine = my;
+            if (REC && !rec_ok) mine = make_uint4(0, 0, 0, 0);
+            if (P4) plain_apply4(cnt, s_ndbits, S, asm4, plain_fetch4<GW>(A.seq, A.seq4, A.seq_bytes, mine, nb, first, lane), lane);
+            else plain_apply(cnt, s_ndbits, S, asm_w, plain_fetch<GW>(A.seq, A.seq_bytes, mine, nb, first, lane), lane);
         }
         // the entry AT a read's single indel (ENT_POINT): one tally, one item per lane -- the two-byte key of an
         // insertion is counted by string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
@@ -871,7 +934,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             }
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
-        u64 rest = __ballot(lane < nb && !my_slow && !my_plain && !my_point);
+        u64 rest = __ballot(lane < nb && rec_ok && !my_slow && !my_plain && !my_point);
         while (rest) {
             const u32 j = (u32)__ffsll((long long)rest) - 1u;
             rest &= rest - 1;
@@ -951,15 +1014,11 @@ constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at
 #ifndef PP_TILE_LAZY_ARGS
 #define PP_TILE_LAZY_ARGS 1
 #endif
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg) {
-    // The arguments are read where they are used, from the kernel-argument segment itself (scalar loads): taken by value
-    // the ~45 fields are all loaded at entry, as 16-dword tuples that the register allocator can only spill whole -- 222
-    // SGPR spills, and a v_readlane per spilled dword in front of every use: a fifth of the item loop's VALU issue.
-#if PP_TILE_LAZY_ARGS
-    const TileArgs &A = *(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    const TileArgs &A = A_in_kernarg;
-#endif
+// DIRECT (pp_k_direct.h): the window's bulk comes straight from the window-order mirror -- its entries in every run, run
+// after run, through the plain class with their work items made up in registers -- and only its extras (the reads that
+// reach in from the window before, the pieces of records with indels) are items in memory.
+template <bool DIRECT>
+__device__ __forceinline__ void tile_window(const TileArgs &A) {
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
@@ -968,6 +1027,11 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
     __shared__ u32 s_pt[PT_SLOTS * 3], s_ptover;
+    __shared__ u32 s_need;  // DIRECT: a position of this window goes to an exact replay (its items have to be written out)
+    // DIRECT: the window's stretches of the mirror, in s_dirty's space behind the range table (both are only needed while the
+    // items are tallied): [0, R] prefix sums of the stretches' lengths, [32, 32 + R) where each begins
+    u32 *const s_run = (u32 *)s_dirty + 512;
+    static_assert(PMASK_WORDS <= 512 && 512 + 32 + PP_WO_MAX_RUNS <= TILE / 2 && PP_WO_MAX_RUNS < 32, "the run table shares s_dirty with the range table");
 
     // The first HEAVY_BLOCKS blocks are helpers: block HEAVY_PARTS * slot + part tallies one part of the items of the
     // heavy window in that slot of the list.  They are dispatched first, so the longest windows start at time zero, and
@@ -1067,7 +1131,22 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
         }
         asm4[t] = v;
     }
-    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; }
+    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; s_need = 0; }
+    if (DIRECT && tid >= 192u && tid < 192u + 64u) {  // one wave: the window's stretch of every run, and their prefix sums
+        const u32 r = tid - 192u, R = A.n_runs;
+        u32 len = 0, f0 = 0;
+        if (r < R) {
+            f0 = A.first[(u64)r * (A.nwin + 1u) + w];
+            len = A.first[(u64)r * (A.nwin + 1u) + w + 1u] - f0;
+        }
+        u32 inc = len;
+        for (int o = 1; o < 32; o <<= 1) {
+            const u32 t = (u32)__shfl_up((int)inc, o, 64);
+            if ((int)r >= o) inc += t;
+        }
+        if (r <= R && r < 32u) s_run[r] = inc - len;  // (lane R holds the total)
+        if (r < R) s_run[32u + r] = f0;
+    }
     if (tid >= 128u && tid < 128u + (u32)PMASK_WORDS)
         ((u32 *)s_dirty)[tid - 128u] = pmask4((u32)min(max((int)tid - 128 - PMASK_BASE, 0), 32));
     if (tid >= 64u && tid < 64u + PT_SLOTS * 3u) s_pt[tid - 64u] = 0;  // (a heavy window's helpers would each have their own table: listed as before)
@@ -1080,25 +1159,53 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
 #ifdef PP_TILE_STAMPS
     if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
 #endif
-    const u32 e0 = A.win_off[w], e1 = A.win_off[w + 1];
-    const TileShare S{win_fx_bits(e1 - e0), &s_shared, A.kk, s_pt, &s_ptover, (const u32 *)s_dirty};  // (a heavy window's helpers: the same bits, their deficits add up)
+    // The window's items: [e0, e1) of the work items in memory -- the bucketing's (k_fill), or (DIRECT) the window's extras --
+    // and, DIRECT, its n_rec mirror entries in front of them.
+    u32 e0, e1, n_rec = 0;
+    const uint4 *items;
+    if (DIRECT) {
+        e0 = 0;
+        e1 = min(A.x_cnt[w], A.xcap);
+        items = A.xent + (u64)w * A.xcap;
+        n_rec = s_run[A.n_runs];
+    } else {
+        e0 = A.win_off[w];
+        e1 = A.win_off[w + 1];
+        items = A.entA;
+    }
+    const TileShare S{win_fx_bits(e1 - e0 + n_rec), &s_shared, A.kk, s_pt, &s_ptover, (const u32 *)s_dirty};  // (a heavy window's helpers: the same bits, their deficits add up)
     {
-        u32 i0 = e0, i1 = e1;
+        u32 i0 = e0, i1 = e1, v0 = 0, v1 = n_rec;
         if (heavy) {  // this helper's share of the window's items
             const u32 chunk = ((e1 - e0 + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
             i0 = min(e1, e0 + part * chunk);
             i1 = min(e1, i0 + chunk);
+            const u32 vchunk = ((n_rec + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
+            v0 = min(n_rec, part * vchunk);
+            v1 = min(n_rec, v0 + vchunk);
         }
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
+        RecMap M{s_run, s_run + 32, A.n_runs, w, s_c0 == s_c1, s_c0, 0, 0};
+        if (DIRECT) {
+            M.c_lo = A.contig_off[s_c0];
+            M.clen = A.contig_off[s_c0 + 1] - M.c_lo;
+        }
+#define PP_TILE_ITEMS(GWV, P4V)                                                                                               \
+    do {                                                                                                                      \
+        if (DIRECT) tile_items<GWV, P4V, true>(A, cnt, s_ndbits, S, asm_w, asm4, A.wo, M, v0, v1, wave, lane);               \
+        tile_items<GWV, P4V, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave, lane);                         \
+    } while (0)
         if (A.seq4) {
-            if (longest <= PlainCfg<5>::MAXL) tile_items<5, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
-            else if (longest <= PlainCfg<6>::MAXL) tile_items<6, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
-            else tile_items<8, true>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
-        } else if (longest <= PlainCfg<5>::MAXL) tile_items<5, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
-        else if (longest <= PlainCfg<6>::MAXL) tile_items<6, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
-        else tile_items<8, false>(A, cnt, s_ndbits, S, asm_w, asm4, i0, i1, wave, lane);
+            if (longest <= PlainCfg<5>::MAXL) PP_TILE_ITEMS(5, true);
+            else if (longest <= PlainCfg<6>::MAXL) PP_TILE_ITEMS(6, true);
+            else PP_TILE_ITEMS(8, true);
+        } else if (longest <= PlainCfg<5>::MAXL) PP_TILE_ITEMS(5, false);
+        else if (longest <= PlainCfg<6>::MAXL) PP_TILE_ITEMS(6, false);
+        else PP_TILE_ITEMS(8, false);
+#undef PP_TILE_ITEMS
     }
-    if (e1 - e0 >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);
+    const u32 n_items = e1 - e0 + n_rec;
+    if (!DIRECT && n_items >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);  // (DIRECT: k_winplan)
     __syncthreads();
 #ifdef PP_TILE_STAMPS
     if (tid == 0) A.stamps[8ull * blockIdx.x + 1] = wall_clock64();
@@ -1323,7 +1430,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
             // A position that is only here for its string-keyed tallies (an insertion that may win: its depth is exact
             // already) goes straight to the list of k_exact's wave-per-position replay -- k_exact2 would sort the whole
             // window for the ordered depth it does not need, and then hand it over all the same.
-            const bool to_list = A.dbg == 1 || (e1 - e0 > SORT_MAX && !heavy) || !nd || for_keys;
+            const bool to_list = A.dbg == 1 || (n_items > SORT_MAX && !heavy) || !nd || for_keys;
+            if (DIRECT) s_need = 1u;
             if (!to_list) {
                 atomicOr(&s_fbits[p >> 5], 1u << (p & 31u));
                 atomicAdd(&s_nflag, 1u);
@@ -1420,7 +1528,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
         __syncthreads();
     }
     if (tid < (u32)(TILE / 32)) A.flag_bits[(u64)w * (TILE / 32) + tid] = s_fbits[tid];
-    if (s_nflag && (e1 - e0 <= SORT_MAX || heavy)) {
+    if (s_nflag && (n_items <= SORT_MAX || heavy)) {
         // the ordered-depth replay needs this window's integer tallies: save them (rare windows only)
         if (tid == 0) {
             const u32 slab = atomicAdd(&A.counters[3], 1u);
@@ -1445,6 +1553,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
     if (tid == 0) A.stamps[8ull * blockIdx.x + 2] = wall_clock64();
 #endif
     if (tid == 0) {
+        if (DIRECT && s_need) A.need_win[atomicAdd(A.n_need, 1ull)] = w;  // (every window at most once: room for all of them)
         A.win_nflag[w] = s_nflag;
         if (s_nflag) atomicAdd(&A.counters[2], s_nflag);
         A.win_len[w] = s_len;
@@ -1452,6 +1561,24 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg)
         if (s_zero) atomicAdd(&A.stats[s_c0].zero_depth, (u64)s_zero);
         if (s_depth) atomicAdd(&A.stats[s_c0].depth_fx, s_depth);
     }
+}
+
+// The arguments are read where they are used, from the kernel-argument segment itself (scalar loads): taken by value
+// the ~45 fields are all loaded at entry, as 16-dword tuples that the register allocator can only spill whole -- 222
+// SGPR spills, and a v_readlane per spilled dword in front of every use: a fifth of the item loop's VALU issue.
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg) {
+#if PP_TILE_LAZY_ARGS
+    tile_window<false>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
+#else
+    tile_window<false>(A_in_kernarg);
+#endif
+}
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_tile_direct(TileArgs A_in_kernarg) {
+#if PP_TILE_LAZY_ARGS
+    tile_window<true>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
+#else
+    tile_window<true>(A_in_kernarg);
+#endif
 }
 
 }  // namespace pp

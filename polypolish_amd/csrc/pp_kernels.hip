@@ -34,6 +34,7 @@
 #include "pp_k_common.h"
 #include "pp_k_prep.h"
 #include "pp_k_bucket.h"
+#include "pp_k_direct.h"
 #include "pp_k_tile.h"
 #include "pp_k_exact.h"
 #include "pp_k_emit.h"
@@ -192,6 +193,7 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
     ctx->batch_borrowed = false;
     ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
     ctx->emit.clear();
+    ctx->wo_runs.clear();
     memset(&ctx->dbatch, 0, sizeof ctx->dbatch);
     return PP_OK;
 }
@@ -280,6 +282,25 @@ __global__ __launch_bounds__(256) void k_pack4(const u8 *__restrict__ seq, u8 *_
     __builtin_memcpy(seq4 + (i0 >> 1), &out, 16);
 }
 
+// The run table of a batch's window-order mirror (pp_aln_batch.wo_run_end, HOST memory) joins the job's: ends rebased by
+// the records in front (n0), empty runs dropped.  The job's table stays known only while every batch so far brought a
+// mirror AND its runs; anything odd (descending ends, a last end that is not n_aln, too many runs) makes it unknown -- the
+// job then takes the bucketing path, which needs no order.
+static void runs_join(pp_ctx *ctx, const pp_aln_batch *b, uint64_t n0) {
+    const bool known_so_far = n0 == 0 || !ctx->wo_runs.empty();
+    if (n0 == 0) ctx->wo_runs.clear();
+    if (b->n_aln == 0) return;
+    bool ok = known_so_far && b->wo && b->wo_n_runs && b->wo_run_end && b->wo_run_end[b->wo_n_runs - 1] == b->n_aln;
+    uint64_t prev = 0;
+    for (uint32_t r = 0; ok && r < b->wo_n_runs; r++) {
+        const uint64_t e = b->wo_run_end[r];
+        if (e < prev || e > b->n_aln) ok = false;
+        else if (e > prev) ctx->wo_runs.push_back(n0 + e);
+        prev = e;
+    }
+    if (!ok || ctx->wo_runs.size() > PP_WO_MAX_RUNS) ctx->wo_runs.clear();
+}
+
 // Append one batch (host or device memory) to the library-owned accumulated arrays.  Every batch's SEQ bytes start on a
 // multiple of PP_SEQ_ALIGN of the accumulated seq array (up to 31 unused bytes at a joint), so that the 4-bit mirror of the
 // batch lands on whole bytes of the accumulated mirror: it is copied when the batch brings one (the library's ingests and
@@ -330,6 +351,7 @@ static int append_batch(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
                                (u64)n, (u64)s0, (u32)n0);
     }
     if (mem != PP_MEM_DEVICE) PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host / peer buffers are only borrowed for the call
+    if (ctx->acc_wo) runs_join(ctx, b, n0); else ctx->wo_runs.clear();
     ctx->acc_n = n0 + n; ctx->acc_seq = s0 + b->seq_bytes; ctx->acc_cig = c0 + b->n_cig_total;
     pp_aln_batch &d = ctx->dbatch;
     d.n_aln = ctx->acc_n; d.seq_bytes = ctx->acc_seq; d.n_cig_total = ctx->acc_cig;
@@ -359,12 +381,18 @@ extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_batch && mem == PP_MEM_DEVICE) {
         ctx->dbatch = *b;
+        runs_join(ctx, b, 0);  // (copied: the caller's table is only borrowed for the call)
+        ctx->dbatch.wo_n_runs = 0;
+        ctx->dbatch.wo_run_end = nullptr;
         ctx->batch_borrowed = true;
         ctx->have_batch = true;
         return PP_OK;
     }
     if (ctx->have_batch && ctx->batch_borrowed) {  // a second batch: the borrowed one moves into the accumulated arrays
-        const pp_aln_batch first = ctx->dbatch;
+        pp_aln_batch first = ctx->dbatch;
+        const std::vector<uint64_t> first_runs = ctx->wo_runs;  // (its run table as it was taken when the batch was added)
+        first.wo_n_runs = (uint32_t)first_runs.size();
+        first.wo_run_end = first_runs.empty() ? nullptr : first_runs.data();
         ctx->batch_borrowed = false;
         ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
         if (int rc = append_batch(ctx, &first, PP_MEM_DEVICE)) return rc;
@@ -394,6 +422,7 @@ static int map_device_error(pp_ctx *ctx, uint64_t key) {
     case DE_BAD_ENDS: return ctx->fail(PP_ERR_ARG, "alignment record %llu does not start and end with M/= (gate of alignment.rs:155-159 not applied)", idx);
     case DE_NON_ASCII: return ctx->fail(PP_ERR_LIMIT, "assembly position %llu holds a non-ASCII byte", idx);
     case DE_TOO_DEEP: return ctx->fail(PP_ERR_LIMIT, "window %llu has more than 2^21 overlapping alignments", idx);
+    case DE_BAD_MIRROR: return ctx->fail(PP_ERR_ARG, "entry %llu of the window-order mirror (pp_aln_batch.wo) names a record the batch does not have", idx);
     case DE_OVERFLOW: return ctx->fail(PP_ERR_LIMIT, "32-bit work-item count or reference span overflow (record/window %llu)", idx);
     default: return ctx->fail(PP_ERR_HIP, "internal device inconsistency %u at %llu", code, idx);
     }
@@ -466,6 +495,23 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const uint64_t chunk = (n + NB - 1) / NB;
     const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
+    // ---- the direct path (pp_k_direct.h): a mirror whose runs are known, a job that is not sharded ----
+    static const bool env_no_direct = getenv("PP_DIRECT") && atoi(getenv("PP_DIRECT")) == 0;  // tuning / tests
+    static const bool env_no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
+    const uint32_t n_runs = (uint32_t)ctx->wo_runs.size();
+    const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && n > 0 && B.wo && ctx->emit.empty() && n_runs > 0 &&
+                        n_runs <= PP_WO_MAX_RUNS && ctx->wo_runs.back() == n;
+    ctx->last_direct = direct;
+    if (direct) {
+        // room for a window's extras: a quarter of the average window's records (7 % reach in from the window before, a few per
+        // cent have indels) and then some; a window that needs more says so (DE_CAPACITY, meta word 12) and the job is rerun
+        uint64_t want = 128;
+        while (want < n / nwin / 4 + 64) want <<= 1;
+        ctx->xcap = std::max<size_t>(ctx->xcap, (size_t)want);
+        ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)1 << 18);  // (work items in memory: only what k_xmat writes out)
+    } else {
+        ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
+    }
 #define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
     // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements (10: the same, counted
     // as the positions are listed) |
@@ -478,7 +524,19 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_vote_tab, (size_t)VOTE_TAB_N * 8);
     ENS(b_win_heavy, nwin);
     ENS(b_hslab, (size_t)HEAVY_SLOTS * HEAVY_PARTS * HSLAB_WORDS * 4);
-    ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4);
+    if (!direct) { ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); }
+    if (direct) {
+        ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 4); ENS(b_xent, (uint64_t)nwin * ctx->xcap * 16);
+        ENS(b_need_win, (uint64_t)nwin * 4); ENS(b_win_lo, (uint64_t)nwin * 4); ENS(b_win_hi, (uint64_t)nwin * 4);
+        std::vector<uint32_t> ends(ctx->wo_runs.begin(), ctx->wo_runs.end());
+        if (!(ends == ctx->runs_on_dev && ctx->b_runs.p)) {  // (the same table as the job before: already there)
+            const void *dummy;
+            ctx->runs_on_dev.clear();
+            if ((rc = upload(ctx, ctx->b_runs, ends.data(), ends.size() * 4, &dummy))) return rc;
+            PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`ends` is a local)
+            ctx->runs_on_dev = ends;
+        }
+    }
     // One level (items straight into their windows) while all windows fit one LDS pass of k_fill; two levels
     // (coarse buckets of COARSE_WINDOWS windows, then k_regroup) beyond that: there the single-level k_fill
     // would re-read its records once per range of 16384 windows.  Measured on MI355X: 5 Mbp: one level 0.19 ms
@@ -491,9 +549,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     static const long forced_frange = getenv("PP_FILL_RANGE") ? atol(getenv("PP_FILL_RANGE")) : 0;
     const uint32_t frange = forced_frange > 0 ? (uint32_t)std::min<long>(forced_frange, COUNT_RANGE) : (uint32_t)COUNT_RANGE;
     const uint32_t ncranges = (ncoarse + frange - 1) / frange;
-    ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
-    ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
-    if (two_level) ENS(b_entB, ctx->cap_ent * 16);
+    if (!direct) {
+        ENS(b_hist, (uint64_t)NB * ncoarse * 4); ENS(b_wincnt, (uint64_t)nwin * 4); ENS(b_winoff, ((uint64_t)nwin + 1) * 4);
+        ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
+        if (two_level) ENS(b_entB, ctx->cap_ent * 16);
+    }
     ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
@@ -511,9 +571,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // zeros, status word = "no error"; a sharded job also gets its per-window output lengths and flag counts zeroed (the
     // windows nobody works on emit nothing and have nothing flagged) -- one launch instead of a kernel and two memsets
     {
+        // (the direct path is never sharded: the same blocks zero its per-window counts of extras)
         const bool sharded = !ctx->emit.empty();
-        hipLaunchKernelGGL(k_meta_init, dim3(sharded ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
-                           sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr, nwin,
+        hipLaunchKernelGGL(k_meta_init, dim3(sharded || direct ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
+                           direct ? (u32 *)ctx->b_xcnt.p : (sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr),
+                           direct ? (u32 *)ctx->b_xcnt.p : (sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr), nwin,
                            (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
     }
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
@@ -609,6 +671,18 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         PP_HIPCHK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(pp::g_prep_stamps), &sp, sizeof sp, 0, hipMemcpyHostToDevice, st));
     }
 #endif
+    if (direct) {
+        // one pass over the mirror: validation, where the windows begin in every run, extras; then what each window holds
+        timer_begin(ctx, "prep");
+        hipLaunchKernelGGL(k_prepd, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
+                           (const u64 *)ctx->b_contig_off.p, nc_full, nwin, (const u32 *)ctx->b_runs.p, n_runs, (u32 *)ctx->b_first.p,
+                           (u32 *)ctx->b_xcnt.p, (uint4 *)ctx->b_xent.p, (u32)ctx->xcap, (u32 *)(d_meta + 9), d_meta + 12, d_status);
+        timer_end(ctx);
+        timer_begin(ctx, "bucket");
+        hipLaunchKernelGGL(k_winplan, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, n_runs, (const u32 *)ctx->b_first.p,
+                           (const u32 *)ctx->b_xcnt.p, (u32)ctx->xcap, heavy_min, d_heavy, d_win_heavy, d_meta + 3, d_status);
+        timer_end(ctx);
+    } else {
     timer_begin(ctx, "prep");
 #define PP_PREP_ARGS dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, B.contig, B.ref_start, (const u64 *)B.seq_off, B.seq_len, \
                      (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq, (const u64 *)ctx->b_contig_off.p, nc_full, d_gbase, d_slice, d_own_full, \
@@ -670,6 +744,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     }
 #undef PP_FILL
     timer_end(ctx);
+    }
 #ifdef PP_PREP_STAMPS
     if (const char *path = getenv("PP_PREP_STAMPS_FILE")) {
         std::vector<uint64_t> hs(pstamp_bytes / 8);
@@ -711,6 +786,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // inexact depth shares that its interval test settles are NOT sent to the replay, their record holds the thresholds and
     // the status as voted and the fixed-point depth (within the interval of the exact one)
     T.dbg = ctx->debug ? (ctx->debug_level == 3 ? 3 : (dbg_replay2 ? 2 : 1)) : 0;
+    T.wo = (const uint4 *)d_wo; T.first = (const u32 *)ctx->b_first.p; T.n_runs = n_runs; T.xcap = (u32)ctx->xcap;
+    T.x_cnt = (const u32 *)ctx->b_xcnt.p; T.xent = (const uint4 *)ctx->b_xent.p; T.need_win = (u32 *)ctx->b_need_win.p; T.n_need = d_meta + 13;
     const uint32_t per = (n_own_win + 7) / 8;  // windows to work on, dealt to the eight XCDs in stretches
     timer_begin(ctx, "tile");
 #ifdef PP_TILE_STAMPS
@@ -720,7 +797,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     PP_HIPCHK(ctx, hipMemsetAsync(b_stamps.p, 0, stamp_bytes, st));
     T.stamps = (u64 *)b_stamps.p;
 #endif
-    hipLaunchKernelGGL(k_tile, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
+    if (direct) hipLaunchKernelGGL(k_tile_direct, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
+    else hipLaunchKernelGGL(k_tile, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
 #ifdef PP_TILE_STAMPS
     if (const char *path = getenv("PP_TILE_STAMPS_FILE")) {
         std::vector<uint64_t> hs(stamp_bytes / 8);
@@ -741,7 +819,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.scr_need = d_meta + 10; E.cap_scr = (u64)ctx->cap_scr; E.flag_scr_w = d_scr;
     E.keys = (KeyRec *)ctx->b_keys.p; E.cap_keys = ctx->debug ? ctx->cap_keys : 0; E.n_keys = d_meta + 8;
     E.flag_pos = T.flag_pos; E.flag_cov = T.flag_cov; E.flag_scr = d_scr;
-    E.entA = d_entA; E.win_off = d_winoff; E.seq = B.seq; E.seq_off = (const u64 *)B.seq_off;
+    E.entA = d_entA; E.seq = B.seq;
+    E.win_lo = direct ? (const u32 *)ctx->b_win_lo.p : d_winoff;
+    E.win_hi = direct ? (const u32 *)ctx->b_win_hi.p : d_winoff + 1; E.seq_off = (const u64 *)B.seq_off;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
     E.bases = d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc; E.seq_bytes = B.seq_bytes;
     E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
@@ -752,6 +832,11 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.heavy = d_heavy; E.win_heavy = d_win_heavy;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
+    if (direct)  // the windows k_tile listed for a replay get their work items written out: the replays read items
+        hipLaunchKernelGGL(k_xmat, dim3((unsigned)std::min<uint32_t>(nwin, 512)), dim3(1024), 0, st, (const u32 *)ctx->b_need_win.p,
+                           (const u64 *)(d_meta + 13), nwin, d_wo, n_runs, (const u32 *)ctx->b_first.p, (const u32 *)ctx->b_xcnt.p,
+                           (const uint4 *)ctx->b_xent.p, (u32)ctx->xcap, d_ctg, nc, d_entA, (u64)ctx->cap_ent, d_meta + 14,
+                           (u32 *)ctx->b_win_lo.p, (u32 *)ctx->b_win_hi.p, d_status);
     const unsigned n_replay = (unsigned)std::min<uint64_t>(nwin, ctx->cap_slabs);  // one block per window with a tally slab
     hipLaunchKernelGGL((k_exact2<SORT_SMALL, 0u, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
     hipLaunchKernelGGL((k_exact2<SORT_MAX, SORT_SMALL, 1u>), dim3(n_replay), dim3(1024), 0, st, E, nwin);
@@ -813,11 +898,9 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     if (!ctx->job_open) return ctx->fail(PP_ERR_ARG, "pp_polish_finish without pp_polish_begin");
     ctx->last_dev_error = ~0ull;
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
-    const uint64_t n = ctx->have_batch ? ctx->dbatch.n_aln : 0;
     const uint64_t G = ctx->G;
     const uint32_t nc = ctx->n_contigs;
-    // optimistic capacities (grow-only across jobs)
-    ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
+    // optimistic capacities (grow-only across jobs; the work items' is set by run_pipeline: it depends on the path)
     ctx->cap_flag = std::max<size_t>(ctx->cap_flag, std::min<size_t>((size_t)G, std::max<size_t>(65536, (size_t)(G / 64))));
     ctx->cap_scr = std::max<size_t>(ctx->cap_scr, (size_t)1 << 20);
     ctx->cap_multi = std::max<size_t>(ctx->cap_multi, 65536);
@@ -830,6 +913,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     uint32_t n_entries = 0;
     int attempt = 0;
     ctx->no_compact = false;
+    ctx->no_direct = false;
     for (;; attempt++) {
         timers_release(ctx);
         int rc = run_pipeline(ctx, meta, &n_entries);
@@ -838,6 +922,12 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         if (key == ~0ull) break;
         if ((key & 0xFF) == DE_HALO && !ctx->no_compact) {  // a read longer than the halo of a compact run: run over the whole assembly
             ctx->no_compact = true;
+            continue;
+        }
+        if ((key & 0xFF) == DE_MIRROR_ORDER && !ctx->no_direct) {  // the mirror is not in the order its run table promises: the bucketing path
+            static const bool trace_d = getenv("PP_TIMING") != nullptr;
+            if (trace_d) fprintf(stderr, "[timing] pass %d: the window-order mirror is not in run order -> bucketing path\n", attempt + 1);
+            ctx->no_direct = true;
             continue;
         }
         if ((key & 0xFF) != DE_CAPACITY && (key & 0xFF) != DE_CAPACITY_LATE) return map_device_error(ctx, key);
@@ -852,7 +942,8 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
             cap = (size_t)(need + need / 8 + 1024);
             grew = true;
         };
-        grow(ctx->cap_ent, meta[3], "work items");
+        grow(ctx->cap_ent, ctx->last_direct ? meta[14] : meta[3], "work items");
+        if (ctx->last_direct) grow(ctx->xcap, meta[12], "extras per window");
         grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G), "listed positions");
         grow(ctx->cap_scr, meta[10], "replay scratch");
         grow(ctx->cap_multi, cnt[1], "multi-byte winners");

@@ -504,6 +504,7 @@ struct pp_dev_ingest {
     int seq4 = 1;        // the mirror goes with every batch (PP_SEQ4=0: none)
     bool mirror() const { return seq4 != 0; }
     u64 n_out = 0, seq_bytes = 0, n_cig_total = 0;
+    std::vector<uint64_t> wo_run_end;  // the mirror's runs -- one per file (or slice of a file) -- as pp_aln_batch.wo_run_end
     // The text of the NEXT file goes up while the current one is tokenized (pp_dev_ingest_prefetch_): two text buffers, an
     // upload stream of its own, and a helper thread per upload (a copy out of pageable memory keeps its caller busy).
     pp::DevBuf d_text2;
@@ -631,6 +632,9 @@ extern "C" void pp_dev_ingest_batch(const pp_dev_ingest *D, pp_aln_batch *out) {
     out->seq_bytes = D->seq_bytes;
     out->seq4 = D->mirror() && D->seq_bytes ? (const u8 *)D->o_seq4.p : nullptr;
     out->wo = D->wo_mirror && D->n_out ? (const pp_wo_rec *)D->o_wo.p : nullptr;
+    const bool runs = out->wo && !D->wo_run_end.empty() && D->wo_run_end.back() == D->n_out;
+    out->wo_n_runs = runs ? (uint32_t)D->wo_run_end.size() : 0;  // (HOST memory, whatever the batch's)
+    out->wo_run_end = runs ? D->wo_run_end.data() : nullptr;
     out->cigar = (const u32 *)D->o_cigar.p;
     out->n_cig_total = D->n_cig_total;
 }
@@ -1010,6 +1014,7 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
     PP_HIPCHK(ctx, hipStreamSynchronize(st));  // the text mapping goes away with F
     lap("batch filled");
     D->n_out += n_good;
+    if (D->wo_mirror && n_good) D->wo_run_end.push_back(D->n_out);  // this file's entries of the mirror: one run, in ascending window order
     D->seq_bytes += seq_total;
     D->n_cig_total += cig_total;
     c.used = n_good;

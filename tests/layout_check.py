@@ -97,3 +97,7 @@ def check_window_order_mirror(recs, contig_off, used_per_file, file_order_inside
             assert (np.diff(fi[lo:hi])[same] > 0).all(), "inside a window the records come in file order"
         lo = hi
     assert lo == n
+    # the mirror's run table (pp_aln_batch.wo_run_end): one run per file that yielded records, ends ascending, the last one n
+    if "wo_runs" in recs:
+        want = [int(e) for e, c in zip(np.cumsum(used_per_file), used_per_file) if c]
+        assert [int(e) for e in recs["wo_runs"]] == want, (recs["wo_runs"], want)

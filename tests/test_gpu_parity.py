@@ -55,6 +55,11 @@ def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False
             w = w[np.random.default_rng(len(w)).permutation(len(w))]
         wt = torch.from_numpy(np.ascontiguousarray(w).view(np.uint8)).to(dev)
         ptrs["wo"] = wt.data_ptr()
+        # the mirror's run table (pp_aln_batch.wo_run_end): with it the job takes the DIRECT path (k_tile reads the bulk of
+        # the records straight from the mirror, pp_k_direct.h); "shuffled" claims one run and is none -- the device notices
+        # and the job falls back to the bucketing path; "no_runs": the mirror alone (rounds 4's path through k_prep / k_fill)
+        if wo != "no_runs" and len(w):
+            ptrs["wo_runs"] = [len(w)]
     torch.cuda.synchronize()
     pp.lib().pp_polish_set_debug(ctx._h, int(positions))
     try:
@@ -120,13 +125,17 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         # ... and with the window-order mirror of the records (pp_aln_batch.wo): k_prep and k_fill then walk the records
         # through it (gstart / nkeep in mirror order, items numbered by file index, one histogram / cursor update per wave and
         # window), per position with the debug planes and bytes without -- as the ingests order it, and in a random order
-        for order in (True, "shuffled"):
-            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, order is True, positions=True, wo=order, **kw)
+        # ... with its run table (the DIRECT path of round 5: k_tile takes the bulk of the records straight from the mirror, the
+        # others and the reads that reach into the next window as extras), with the 4-bit mirror (one lane per read) and without
+        # (lane groups); in a random order under a run table that is then wrong (the device notices, the job falls back to
+        # the bucketing path); and without a run table (round 4's path)
+        for order, s4 in ((True, True), (True, False), ("shuffled", False), ("no_runs", True)):
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, s4, positions=True, wo=order, **kw)
             for k in POS_KEYS:
                 bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
                 assert len(bad) == 0, ("wo", order, k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
             assert m["polished"] == want["polished"]
-            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, order is True, positions=False, wo=order, **kw)
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, s4, positions=False, wo=order, **kw)
             assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
             for c in range(len(off) - 1):
                 assert m["stats"][c]["changed"] == got["stats"][c]["changed"], ("wo", order, c)
@@ -135,13 +144,13 @@ def _compare_records(ctx, orc, contig_off, bases, recs, **kw):
         # file order where a step of the vote (pileup.rs:70-72,114) falls inside it.  Tallies, both thresholds and the
         # status must be the oracle's at EVERY position; the depth of the positions decided that way is the fixed-point
         # one, within reads * 2^-11 of the exact sum (a window's unit is 2^-10 at the coarsest).
-        for mirror in (True, False):
-            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, mirror, positions=3, **kw)
+        for mirror, order in ((True, None), (False, None), (True, True)):   # (the last one: the direct path)
+            m = _polish_device_batch(ctx, pp, contig_off, bases, recs, mirror, positions=3, wo=order, **kw)
             for k in POS_KEYS:
                 if k == "depth":
                     continue
                 bad = np.nonzero(want["positions"][k] != m["positions"][k])[0]
-                assert len(bad) == 0, ("interval", mirror, k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
+                assert len(bad) == 0, ("interval", mirror, order, k, len(bad), bad[:8], want["positions"][k][bad[:8]], m["positions"][k][bad[:8]])
             p = want["positions"]
             reads = (p["count_a"].astype(np.int64) + p["count_c"] + p["count_g"] + p["count_t"] + p["count_other"]).astype(np.float64)
             err = np.abs(m["positions"]["depth"] - p["depth"])

@@ -74,6 +74,7 @@ def test_text_and_records_describe_the_same_job(orc, tmp_path):
         assert np.array_equal(wo[k], recs["wo"][k]), k
     ref = pp.window_order_mirror(recs, off, [c[1] for c in counts])
     assert all(np.array_equal(ref[k], recs["wo"][k]) for k in pp.WO_DTYPE.names)
+    assert [int(e) for e in recs["wo_runs"]] == synthjob.with_wo(job)["wo_runs"]   # ... with the same run table (pp_aln_batch.wo_run_end)
     assert int((h["k"] == 5).sum()) > 1000
 
 

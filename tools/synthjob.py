@@ -461,6 +461,11 @@ def with_wo(job, on=True):
     out = dict(job)
     out.pop("_prepared", None)
     out["wo"] = wo_of(job) if on else None
+    # ... and its runs (pp_aln_batch.wo_run_end): one per SAM file, in ascending window order -- what both ingests hand over
+    n1 = job.get("file_used", [job["n_aln"], 0])[0]
+    out["wo_runs"] = [e for e in (n1, job["n_aln"]) if e > 0] if on else None
+    if out["wo_runs"] and len(out["wo_runs"]) == 2 and out["wo_runs"][0] == out["wo_runs"][1]:
+        out["wo_runs"] = out["wo_runs"][:1]
     return out
 
 
