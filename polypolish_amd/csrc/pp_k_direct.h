@@ -11,7 +11,7 @@
 //              and cuts 16-byte work items ("extras", the format of k_fill) only for what k_tile cannot take from the
 //              mirror: the part of a bulk read that reaches into the next window (7 % of the reads at 150 bases), and
 //              every piece of the other records (indels, long reads, overhangs -- prep_general as before).  Extras go to a
-//              fixed room of `xcap` items per window (one returning atomic per wave and window).
+//              fixed room of `xcap` items per window (staged in LDS; one returning atomic per block and window).
 //   k_winplan  per window: items = mirror entries + extras -> the heavy-window list, the depth limit, the job's item count
 //   k_tile     (pp_k_tile.h, DIRECT) the window's mirror entries through the plain class, then its extras like any items
 //   k_xmat     the few windows with positions left for the exact replays get their items written out (k_exact / k_exact2
@@ -54,18 +54,51 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
                                                                uint4 *__restrict__ xent, u32 xcap, u32 *__restrict__ maxlen,
                                                                u64 *__restrict__ x_need, u64 *status) {
     __shared__ u32 later[PREP_LATER_MAX], n_later;
-    if (threadIdx.x == 0) n_later = 0;
-    __syncthreads();
+    // The block's extras are STAGED in LDS and get their slots in the windows' rooms at the end, one returning global atomic
+    // per window of the block instead of one per wave, window and trip through the loop (a wave waited out thirteen of
+    // those round trips, one after the other: k_prepd 0.16 ms where k_prep + k_fill took 0.19).  A block's entries lie in
+    // a handful of consecutive windows (the mirror is in window order): XLOCAL counters from the window of its first entry
+    // on; an extra for a window outside that range (a block across the end of a run, a long read), or one more than the
+    // stage holds, takes its slot from the global counter on the spot.
+    constexpr u32 XSTAGE = 2048, XLOCAL = 64;
+    __shared__ uint4 st_item[XSTAGE];
+    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], n_st, s_wbase;
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    if (threadIdx.x == 0) {
+        n_later = 0;
+        n_st = 0;
+        u32 wb = 0;
+        if (lo < hi) {
+            const pp_wo_rec r0 = wo[lo];
+            if (r0.contig < n_contigs) wb = wo_home(contig_off[r0.contig], r0.ref_start, nwin);
+        }
+        s_wbase = wb;
+    }
+    if (threadIdx.x < XLOCAL) l_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 wbase = s_wbase;
     const u32 lane = threadIdx.x & 63u;
     const u32 stride = nwin + 1u;
-    // one extra: slot in its window's room, or a capacity overflow (the host gives the windows more room and reruns)
+    // one extra into its slot of its window's room, or a capacity overflow (the host gives the windows more room and reruns)
     auto put = [&](u32 w, u32 slot, const uint4 &e) {
         if (slot < xcap) xent[(u64)w * xcap + slot] = e;
         else {
             atomicMax(x_need, (u64)slot + 1ull);
             report(status, slot, DE_CAPACITY);
         }
+    };
+    // one extra of window w: staged, or straight to its window
+    auto emit = [&](u32 w, const uint4 &e) {
+        const u32 wl = w - wbase;
+        if (wl < XLOCAL) {
+            const u32 pos = atomicAdd(&n_st, 1u);
+            if (pos < XSTAGE) {
+                st_key[pos] = (wl << 16) | atomicAdd(&l_cnt[wl], 1u);
+                st_item[pos] = e;
+                return;
+            }
+        }
+        put(w, atomicAdd(&x_cnt[w], 1u), e);
     };
     // the pieces of a record that is NOT bulk (prep_general's verdict), window by window
     auto cut = [&](u32 g_out, u32 word, u64 so, u32 kc, u32 fi) {
@@ -87,7 +120,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
                 e.y = (fl ? 0u : (((u32)(pso >> 32) & 0xFFu) | (len << 24))) | (kc << 8) | (fl << 16);
                 e.z = ((u32)(int)((long long)g - (long long)w * TILE) & 0x3FFFFFFFu) | (zf << 30);
                 e.w = fi;
-                put(w, atomicAdd(&x_cnt[w], 1u), e);
+                emit(w, e);
             }
         });
     };
@@ -164,27 +197,10 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
             const bool begins = h != NOHOME && (starts || (hp != NOHOME && h > hp));
             fill(begins, run, starts ? 0u : hp + 1u, h, (u32)a);
             fill(h != NOHOME && (u32)a + 1u == run_hi, run, h + 1u, nwin, (u32)a + 1u);
-            // ---- a bulk read that reaches into the next window: one extra there (its slot taken once per wave and window) ----
+            // ---- a bulk read that reaches into the next window: one extra there ----
             const u64 g = c_lo + r.ref_start;
             const u32 w1 = bulk ? (u32)((g + r.seq_len - 1u) / (u64)TILE) : 0u;
-            {
-                u32 key = bulk && w1 > h ? w1 : 0xFFFFFFFFu, slot = 0;
-                for (;;) {
-                    const u64 todo = __ballot(key != 0xFFFFFFFFu);
-                    if (!todo) break;
-                    const int lead = __ffsll((long long)todo) - 1;
-                    const u32 kl = (u32)__builtin_amdgcn_readlane((int)key, lead);
-                    const u64 same = __ballot(key == kl);
-                    u32 base = 0;
-                    if ((int)lane == lead) base = atomicAdd(&x_cnt[kl], (u32)__popcll(same));
-                    base = (u32)__builtin_amdgcn_readlane((int)base, lead);
-                    if (key == kl) {
-                        slot = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
-                        key = 0xFFFFFFFFu;
-                        put(kl, slot, wo_item(r.seq_off, r.seq_len, kclass_of(r.k), g, kl, r.file_idx));
-                    }
-                }
-            }
+            if (bulk && w1 > h) emit(w1, wo_item(r.seq_off, r.seq_len, kclass_of(r.k), g, w1, r.file_idx));
             if (bulk) fast_len = max(fast_len, r.seq_len);
             else if (in) {
                 const u32 slot = atomicAdd(&n_later, 1u);
@@ -198,6 +214,17 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
         const pp_wo_rec r = wo[lo + later[i]];
         const u32 cc = min(r.contig, n_contigs - 1u);
         general(r, contig_off[cc], contig_off[cc + 1]);
+    }
+    // ---- the staged extras: a stretch of slots per window of the block, then every item to its slot ----
+    __syncthreads();
+    if (threadIdx.x < XLOCAL) {
+        const u32 c = l_cnt[threadIdx.x];
+        l_base[threadIdx.x] = c ? atomicAdd(&x_cnt[wbase + threadIdx.x], c) : 0u;  // (c > 0: a window of the assembly)
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < min(n_st, XSTAGE); i += blockDim.x) {
+        const u32 key = st_key[i], wl = key >> 16;
+        put(wbase + wl, l_base[wl] + (key & 0xFFFFu), st_item[i]);
     }
     // the job's longest fast-class read (as k_prep)
     if (__ballot(fast_len > PLAIN_NARROW_MAX)) {

@@ -73,6 +73,7 @@ struct RecMap {
     const u32 *pre;    // [R + 1] entries of the runs before run r in this window (prefix sums of the stretches)
     const u32 *first;  // [R] first entry of the window in run r
     u32 R;
+    u32 v0, nv;        // the entries this workgroup takes: [v0, v0 + nv) of the window's (all of them, or a heavy window's helper's share)
     u32 w;             // the window
     bool one_contig;
     u32 c0;            // its contig (one_contig) ...
@@ -621,9 +622,9 @@ __device__ __forceinline__ bool wide4_takes(u32 ex, u32 ey, u32 ez) {
     return !((ex & 1u) && ((ez >> 30) & 1u) && ((ey >> 24) & 31u) == 0);
 }
 
-template <int NCH, bool REC>
+template <int NCH, typename ASK>
 __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm4, const u8 *seq, const u8 *seq4,
-                                           const uint4 &my, bool mine, const uint4 *ent, u32 nxt_at, uint4 &nxt, uint4 &nxt2) {
+                                           const uint4 &my, bool mine, ASK &&ask_for_next) {
     static_assert(32 * (NCH - 1) <= PMASK_BASE && 32 * NCH + 1 < PMASK_WORDS - PMASK_BASE, "the range table");
     const u32 ex = my.x, ey = my.y, ez = my.z;
     const int rel = item_rel(ez);
@@ -637,14 +638,9 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
         // The next batch's items are asked for HERE, next to the pass's own loads, not at the top of tile_items' loop: a
         // request that is out before the item's fields are unpacked is waited for on the spot (the fields' registers may
         // be the target of a load from the slow classes' code further down the loop, and the wait the compiler puts in
-        // front of the first write to them drains everything in flight).  The empty asm ties the index to the unpacked
-        // offset, which keeps the scheduler from moving the load back up.
-        u32 at = nxt_at;
-        asm volatile("" : "+v"(at) : "v"((u32)(so >> 32)));
-        if (REC) {  // (direct path: the next batch are mirror entries, two 16-byte words each)
-            nxt = ent[2ull * at];
-            nxt2 = ent[2ull * at + 1];
-        } else nxt = ent[at];
+        // front of the first write to them drains everything in flight).  The empty asm (in the caller's ask_for_next) ties
+        // the index to the unpacked offset, which keeps the scheduler from moving the load back up.
+        ask_for_next((u32)(so >> 32));
     }
     uint4 W[NCH];
     u32 tail = 0;
@@ -853,37 +849,56 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
     constexpr bool WIDE = P4 && GW == 5;
     constexpr u32 IPP = WIDE ? 1u : C::IPP, BATCH = WIDE ? 64u : C::BATCH;
+    // REC (direct path): the window's work is ONE list -- its M.nv mirror entries [M.v0, M.v0 + nv), numbered run after
+    // run, and behind them its items in memory [e0, e1) (the extras) -- so that a pass is as full of the one kind as of the
+    // other (a pass costs what it costs, however many of its lanes have work: the ~300 extras of a window of 2,700
+    // records as a list of their own were a fourth pass for every wave).  Entry v is record rec_at(v) of the mirror
+    // (two 16-byte words), and its work item is made up here, in registers (wo_item: what k_fill would have written for
+    // it); a record that is not bulk (its pieces are among the extras) is passed over.
+    const u32 nv = REC ? M.nv : 0u;
+    const u32 nv_last = (u32)__builtin_amdgcn_readfirstlane((int)(nv ? nv - 1u : 0u));  // (uniform: kept in a scalar register)
+    const u32 u1 = nv + (e1 - e0);  // the list is [0, u1): u < nv a mirror entry, else item e0 + (u - nv)
     // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
     // of the items does not matter: the counters are integers)
     constexpr u32 WAVES = TILE_THREADS / 64;
-    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
-    const u32 lo_w = min(e1, e0 + wave * per_wave), hi_w = min(e1, lo_w + per_wave);
+    const u32 per_wave = ((u1 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
+    const u32 lo_w = min(u1, wave * per_wave), hi_w = min(u1, lo_w + per_wave);
     if (lo_w >= hi_w) return;
-    // REC (direct path): [e0, e1) are the window's mirror entries numbered run after run; entry v is record rec_at(v) of the
-    // mirror `ent` (two 16-byte words), and its work item is made up here, in registers (wo_item: what k_fill would have
-    // written for it).  A record that is not bulk (its pieces are among the window's extras) is passed over.
     auto rec_at = [&](u32 v) -> u32 {
         u32 a = M.first[0] + v;
         for (u32 r = 1; r < M.R; r++)
             if (v >= M.pre[r]) a = M.first[r] + (v - M.pre[r]);
         return a;
     };
+    // where entry u of the list lies: both 16-byte words of a mirror entry, or an item (its one word twice: no branch)
+    const uint4 *const wq = A.wo;
+    auto word_of = [&](u32 u, const uint4 *&p1, const uint4 *&p2) {
+        if (REC) {
+            const bool rec = u < nv;
+            const u32 a = rec_at(M.v0 + min(u, nv_last));
+            const uint4 *const it = ent + e0 + (u - min(u, nv));
+            p1 = rec ? wq + 2ull * a : it;
+            p2 = rec ? wq + 2ull * a + 1 : it;
+        } else {
+            p1 = ent + e0 + u;
+            p2 = p1;
+        }
+    };
     // the records of the batch after the current one are asked for before the current one is worked on (2-5 % of the
     // kernel: a wave's chain of dependent round trips is what its time consists of)
     uint4 nxt, nxt2 = make_uint4(0, 0, 0, 0);
     {
-        const u32 at = lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u);
-        if (REC) {
-            const u32 a = rec_at(at);
-            nxt = ent[2ull * a];
-            nxt2 = ent[2ull * a + 1];
-        } else nxt = ent[at];
+        const uint4 *p1, *p2;
+        word_of(lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u), p1, p2);
+        nxt = *p1;
+        if (REC) nxt2 = *p2;
     }
     for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
         const u32 nb = min(BATCH, hi_w - eb);
         uint4 my = nxt;
-        bool rec_ok = true;
+        bool rec_ok = true, is_rec = false;
         if (REC) {
+            is_rec = eb + min(lane, nb - 1u) < nv;
             const uint4 qa = nxt, qb = nxt2;  // contig, ref_start, k, seq_len | seq_off (two words), op0, file index
             u64 c_lo = M.c_lo, clen = M.clen;
             bool c_ok = qa.x == M.c0;
@@ -893,28 +908,31 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                 clen = A.contig_off[cc + 1] - c_lo;
                 c_ok = qa.x < A.n_contigs;
             }
-            rec_ok = wo_bulk(c_ok, qa.y, qa.w, qb.z, clen);
-            my = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), c_lo + qa.y, M.w, qb.w);
+            rec_ok = !is_rec || wo_bulk(c_ok, qa.y, qa.w, qb.z, clen);
+            const uint4 made = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), c_lo + qa.y, M.w, qb.w);
+            if (is_rec) my = made;
         }
         const bool more = eb + BATCH < hi_w;
-        u32 nxt_at = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
-        if (REC) nxt_at = rec_at(nxt_at);
-        if (!WIDE && more) {  // (WIDE: wide4_pass asks for them, together with its own loads)
-            if (REC) {
-                nxt = ent[2ull * nxt_at];
-                nxt2 = ent[2ull * nxt_at + 1];
-            } else nxt = ent[nxt_at];
-        }
-        const u32 my_flags = REC ? 0u : item_flags(my.y, my.z);
-        const bool my_slow = !REC && lane < nb && (my_flags & 3u) != 0;
-        const bool my_point = !REC && lane < nb && (my_flags & ENT_POINT) != 0;
+        const u32 nxt_u = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
+        auto ask_for_next = [&](u32 tie) {
+            u32 u = nxt_u;
+            asm volatile("" : "+v"(u) : "v"(tie));
+            const uint4 *np1, *np2;
+            word_of(u, np1, np2);
+            nxt = *np1;
+            if (REC) nxt2 = *np2;
+        };
+        if (!WIDE && more) ask_for_next(0u);  // (WIDE: wide4_pass asks for them, together with its own loads)
+        const u32 my_flags = is_rec ? 0u : item_flags(my.y, my.z);
+        const bool my_slow = lane < nb && (my_flags & 3u) != 0;
+        const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
         const bool my_plain = lane < nb && rec_ok && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
         if (!WIDE && my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }
         if constexpr (WIDE) {
-            wide4_pass<GW, REC>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, ent, nxt_at, nxt, nxt2);
+            wide4_pass<GW>(cnt, s_ndbits, S, asm4, A.seq, A.seq4, my, my_plain, ask_for_next);
             if (my_slow) { sl_so = A.seq_off[my.w]; sl_co = A.cig_off[my.w]; sl_nc = A.n_cig[my.w]; }  // (a whole read per lane: no registers to spare across the pass)
         } else for (u32 first = 0; first < nb; first += C::IPP) {
             // (REC: a group picks its item out of the batch registers; a record that is not bulk shows as an item of length 0)
@@ -1185,16 +1203,16 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             v1 = min(n_rec, v0 + vchunk);
         }
         const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
-        RecMap M{s_run, s_run + 32, A.n_runs, w, s_c0 == s_c1, s_c0, 0, 0};
+        // (wave-uniform values out of LDS and memory: moved to scalar registers by hand, the compiler cannot know)
+        const u32 c0 = (u32)__builtin_amdgcn_readfirstlane((int)s_c0);
+        RecMap M{s_run, s_run + 32, A.n_runs, (u32)__builtin_amdgcn_readfirstlane((int)v0),
+                 (u32)__builtin_amdgcn_readfirstlane((int)(v1 - v0)), w, s_c0 == s_c1, c0, 0, 0};
         if (DIRECT) {
-            M.c_lo = A.contig_off[s_c0];
-            M.clen = A.contig_off[s_c0 + 1] - M.c_lo;
+            const u64 lo64 = A.contig_off[c0], len64 = A.contig_off[c0 + 1] - lo64;
+            M.c_lo = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)lo64) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(lo64 >> 32)) << 32);
+            M.clen = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)len64) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(len64 >> 32)) << 32);
         }
-#define PP_TILE_ITEMS(GWV, P4V)                                                                                               \
-    do {                                                                                                                      \
-        if (DIRECT) tile_items<GWV, P4V, true>(A, cnt, s_ndbits, S, asm_w, asm4, A.wo, M, v0, v1, wave, lane);               \
-        tile_items<GWV, P4V, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave, lane);                         \
-    } while (0)
+#define PP_TILE_ITEMS(GWV, P4V) tile_items<GWV, P4V, DIRECT>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave, lane)
         if (A.seq4) {
             if (longest <= PlainCfg<5>::MAXL) PP_TILE_ITEMS(5, true);
             else if (longest <= PlainCfg<6>::MAXL) PP_TILE_ITEMS(6, true);

@@ -875,6 +875,19 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
     meta.assign(ctx->h_meta, ctx->h_meta + meta_words);
     *n_entries_out = (uint32_t)meta[3];
+    if (getenv("PP_TRACE_FLAGGED")) {  // tuning: the positions this pass listed for k_exact
+        const uint32_t *c = (const uint32_t *)&meta[1];
+        const uint32_t nl = std::min<uint32_t>(c[0], 64);
+        std::vector<uint32_t> pos(nl ? nl : 1), cov(nl ? nl : 1);
+        if (nl) {
+            PP_HIPCHK(ctx, hipMemcpy(pos.data(), ctx->b_flag_pos.p, nl * 4, hipMemcpyDeviceToHost));
+            PP_HIPCHK(ctx, hipMemcpy(cov.data(), ctx->b_flag_cov.p, nl * 4, hipMemcpyDeviceToHost));
+        }
+        fprintf(stderr, "[flagged] %s path: listed %u, flagged in all %u, windows written out %llu:", direct ? "direct" : "bucketing", c[0], c[2],
+                (unsigned long long)meta[13]);
+        for (uint32_t i = 0; i < nl; i++) fprintf(stderr, " %u(cov %u)", pos[i], cov[i]);
+        fprintf(stderr, "\n");
+    }
     return PP_OK;
 }
 
