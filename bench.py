@@ -481,6 +481,7 @@ def main():
         job = synthjob.with_seq4(job)
     if args.wo == "on":     # the window-order mirror of the records both ingests hand over with their batch (pp_aln_batch.wo)
         job = synthjob.with_wo(job)
+    torch.cuda.synchronize()   # (the library runs on a stream of its own: the job's arrays have to be written by now)
     plan = None
     if strong:
         # ONE job; a rank keeps the records that reach its units (pp_shard_plan_create: whole contigs by longest-

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
                                                                const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
                                                                const u64 *__restrict__ contig_off, u32 n_contigs, u32 nwin,
                                                                const u32 *__restrict__ run_end, u32 n_runs,  // ends of the mirror's runs (ascending, the last one = n)
-                                                               u32 *__restrict__ first, u32 *__restrict__ x_cnt,
+                                                               u32 *__restrict__ first, u32 *__restrict__ x_cnt, u32 *__restrict__ x_nb,
                                                                uint4 *__restrict__ xent, u32 xcap, u32 *__restrict__ maxlen,
                                                                u64 *__restrict__ x_need, u64 *status) {
     __shared__ u32 later[PREP_LATER_MAX], n_later;
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
     // stage holds, takes its slot from the global counter on the spot.
     constexpr u32 XSTAGE = 2048, XLOCAL = 64;
     __shared__ uint4 st_item[XSTAGE];
-    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], n_st, s_wbase;
+    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
+    PP_STAMP(0, 0);
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     if (threadIdx.x == 0) {
         n_later = 0;
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
         }
         s_wbase = wb;
     }
-    if (threadIdx.x < XLOCAL) l_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < XLOCAL) { l_cnt[threadIdx.x] = 0; l_nb[threadIdx.x] = 0; }
     __syncthreads();
+    PP_STAMP(0, 1);
     const u32 wbase = s_wbase;
     const u32 lane = threadIdx.x & 63u;
     const u32 stride = nwin + 1u;
@@ -203,29 +205,38 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
             if (bulk && w1 > h) emit(w1, wo_item(r.seq_off, r.seq_len, kclass_of(r.k), g, w1, r.file_idx));
             if (bulk) fast_len = max(fast_len, r.seq_len);
             else if (in) {
+                // (a record that is not bulk: the window it starts in holds its entry AND, among the extras, its pieces --
+                // counted, so that k_winplan can tell what the window's work amounts to)
+                if (h != NOHOME) { if (h - wbase < XLOCAL) atomicAdd(&l_nb[h - wbase], 1u); else atomicAdd(&x_nb[h], 1u); }
                 const u32 slot = atomicAdd(&n_later, 1u);
                 if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
                 else general(r, c_lo, c_hi);
             }
         }
     }
+    PP_STAMP(0, 2);
     __syncthreads();
+    PP_STAMP(0, 3);
     for (u32 i = threadIdx.x; i < min(n_later, PREP_LATER_MAX); i += blockDim.x) {
         const pp_wo_rec r = wo[lo + later[i]];
         const u32 cc = min(r.contig, n_contigs - 1u);
         general(r, contig_off[cc], contig_off[cc + 1]);
     }
+    PP_STAMP(0, 4);
     // ---- the staged extras: a stretch of slots per window of the block, then every item to its slot ----
     __syncthreads();
     if (threadIdx.x < XLOCAL) {
-        const u32 c = l_cnt[threadIdx.x];
+        const u32 c = l_cnt[threadIdx.x], nb = l_nb[threadIdx.x];
         l_base[threadIdx.x] = c ? atomicAdd(&x_cnt[wbase + threadIdx.x], c) : 0u;  // (c > 0: a window of the assembly)
+        if (nb) atomicAdd(&x_nb[wbase + threadIdx.x], nb);
     }
     __syncthreads();
+    PP_STAMP(0, 5);
     for (u32 i = threadIdx.x; i < min(n_st, XSTAGE); i += blockDim.x) {
         const u32 key = st_key[i], wl = key >> 16;
         put(wbase + wl, l_base[wl] + (key & 0xFFFFu), st_item[i]);
     }
+    PP_STAMP(0, 6);
     // the job's longest fast-class read (as k_prep)
     if (__ballot(fast_len > PLAIN_NARROW_MAX)) {
         for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
 // k_winplan: what a window holds -> heavy-window list, depth limit, the job's item count; the run tables must ascend
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_winplan(u32 nwin, u32 n_runs, const u32 *__restrict__ first, const u32 *__restrict__ x_cnt,
-                                                 u32 xcap, u32 heavy_min, u32 *__restrict__ heavy, u8 *__restrict__ win_heavy,
+                                                 const u32 *__restrict__ x_nb, u32 xcap, u32 heavy_min, u32 *__restrict__ heavy, u8 *__restrict__ win_heavy,
                                                  u64 *__restrict__ n_items, u64 *status) {
     const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = w < nwin && *status == ~0ull;
@@ -249,6 +260,9 @@ __global__ __launch_bounds__(256) void k_winplan(u32 nwin, u32 n_runs, const u32
             const u32 a = first[(u64)r * (nwin + 1u) + w], b = first[(u64)r * (nwin + 1u) + w + 1u];
             if (b < a) bad = true; else cnt += b - a;
         }
+        // (an entry that is not bulk is passed over by k_tile -- its pieces are among the extras: what is left is what the
+        // bucketing would have counted for the window)
+        if (!bad) cnt -= min(cnt, x_nb[w]);
         if (bad) report(status, (1ull << 40) - 1ull, DE_MIRROR_ORDER);
         else {
             if (cnt >= MAX_BUCKET) report(status, w, DE_TOO_DEEP);

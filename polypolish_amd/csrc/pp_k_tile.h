@@ -849,20 +849,31 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
     constexpr bool WIDE = P4 && GW == 5;
     constexpr u32 IPP = WIDE ? 1u : C::IPP, BATCH = WIDE ? 64u : C::BATCH;
-    // REC (direct path): the window's work is ONE list -- its M.nv mirror entries [M.v0, M.v0 + nv), numbered run after
-    // run, and behind them its items in memory [e0, e1) (the extras) -- so that a pass is as full of the one kind as of the
-    // other (a pass costs what it costs, however many of its lanes have work: the ~300 extras of a window of 2,700
-    // records as a list of their own were a fourth pass for every wave).  Entry v is record rec_at(v) of the mirror
+    // REC (direct path): a wave's work is ONE list -- its share of the window's mirror entries (M.nv of them from M.v0 on,
+    // numbered run after run) and, behind them, its share of the window's items in memory [e0, e1) (the extras) -- so that a
+    // pass is as full of the one kind as of the other: a pass costs what it costs however many of its lanes have work, and
+    // the ~300 extras of a window of 2,700 records as a list of their own were a fourth pass for every wave.  Every wave
+    // takes a sixteenth of BOTH: the extras hold all of the window's slow items (one round trip each, one after the other),
+    // which two waves at the tail of one long list would have had to themselves.  Entry v is record rec_at(v) of the mirror
     // (two 16-byte words), and its work item is made up here, in registers (wo_item: what k_fill would have written for
     // it); a record that is not bulk (its pieces are among the extras) is passed over.
-    const u32 nv = REC ? M.nv : 0u;
-    const u32 nv_last = (u32)__builtin_amdgcn_readfirstlane((int)(nv ? nv - 1u : 0u));  // (uniform: kept in a scalar register)
-    const u32 u1 = nv + (e1 - e0);  // the list is [0, u1): u < nv a mirror entry, else item e0 + (u - nv)
-    // every wave takes one contiguous slice of the window's items, equal to within one pass (the order
-    // of the items does not matter: the counters are integers)
+    // Every wave takes one contiguous slice, equal to within one pass (the order of the items does not matter: the
+    // counters are integers).
     constexpr u32 WAVES = TILE_THREADS / 64;
-    const u32 per_wave = ((u1 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
-    const u32 lo_w = min(u1, wave * per_wave), hi_w = min(u1, lo_w + per_wave);
+    const u32 nv_all = REC ? M.nv : 0u;
+    const u32 per_wave_r = (nv_all + WAVES - 1u) / WAVES;
+    const u32 r_lo = min(nv_all, wave * per_wave_r);
+    const u32 nv = min(nv_all, r_lo + per_wave_r) - r_lo;   // this wave's mirror entries: [M.v0 + r_lo, ... + nv)
+    // ... and its items: a contiguous slice [x_lo, x_lo + nx) of the bucketing's items; every sixteenth of the extras, x_lo +
+    // 16 j (k_prepd writes a block's extras for the records with indels behind those for its bulk reads: in contiguous
+    // slices two waves would get all of a window's slow items -- one window with two planted indels 100 bases apart, whose
+    // reads have five runs, kept its workgroup for 190 us where the others take 25)
+    constexpr u32 XS = REC ? WAVES : 1u;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
+    const u32 x_lo = REC ? e0 + wave : min(e1, e0 + wave * per_wave);
+    const u32 nx = REC ? (e1 - e0 > wave ? (e1 - e0 - wave - 1u) / WAVES + 1u : 0u) : min(e1, x_lo + per_wave) - x_lo;
+    const u32 nv_last = (u32)__builtin_amdgcn_readfirstlane((int)(nv ? nv - 1u : 0u));  // (uniform: kept in a scalar register)
+    const u32 lo_w = 0u, hi_w = nv + nx;  // the list: u < nv a mirror entry, else item x_lo + XS * (u - nv)
     if (lo_w >= hi_w) return;
     auto rec_at = [&](u32 v) -> u32 {
         u32 a = M.first[0] + v;
@@ -870,28 +881,23 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             if (v >= M.pre[r]) a = M.first[r] + (v - M.pre[r]);
         return a;
     };
-    // where entry u of the list lies: both 16-byte words of a mirror entry, or an item (its one word twice: no branch)
+    // where entry u of the list lies: index of a mirror entry (two 16-byte words), or of an item
     const uint4 *const wq = A.wo;
-    auto word_of = [&](u32 u, const uint4 *&p1, const uint4 *&p2) {
+    auto index_of = [&](u32 u) -> u32 { return REC && u < nv ? rec_at(M.v0 + r_lo + min(u, nv_last)) : x_lo + XS * (u - min(u, nv)); };
+    // ... and its words: both words of the mirror entry, or the item's one word twice (no branch)
+    auto words_at = [&](bool rec, u32 idx, uint4 &a, uint4 &b) {
         if (REC) {
-            const bool rec = u < nv;
-            const u32 a = rec_at(M.v0 + min(u, nv_last));
-            const uint4 *const it = ent + e0 + (u - min(u, nv));
-            p1 = rec ? wq + 2ull * a : it;
-            p2 = rec ? wq + 2ull * a + 1 : it;
-        } else {
-            p1 = ent + e0 + u;
-            p2 = p1;
-        }
+            const uint4 *const p1 = rec ? wq + 2ull * idx : ent + idx, *const p2 = rec ? wq + 2ull * idx + 1 : ent + idx;
+            a = *p1;
+            b = *p2;
+        } else a = ent[idx];
     };
     // the records of the batch after the current one are asked for before the current one is worked on (2-5 % of the
     // kernel: a wave's chain of dependent round trips is what its time consists of)
     uint4 nxt, nxt2 = make_uint4(0, 0, 0, 0);
     {
-        const uint4 *p1, *p2;
-        word_of(lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u), p1, p2);
-        nxt = *p1;
-        if (REC) nxt2 = *p2;
+        const u32 u = lo_w + min(lane, min(BATCH, hi_w - lo_w) - 1u);
+        words_at(u < nv, index_of(u), nxt, nxt2);
     }
     for (u32 eb = lo_w; eb < hi_w; eb += BATCH) {
         const u32 nb = min(BATCH, hi_w - eb);
@@ -914,13 +920,12 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         }
         const bool more = eb + BATCH < hi_w;
         const u32 nxt_u = more ? eb + BATCH + min(lane, min(BATCH, hi_w - eb - BATCH) - 1u) : eb + min(lane, nb - 1u);
+        const u32 nxt_idx = index_of(nxt_u);  // (out of LDS: worked out here, not among the pass's loads)
+        const bool nxt_rec = nxt_u < nv;
         auto ask_for_next = [&](u32 tie) {
-            u32 u = nxt_u;
-            asm volatile("" : "+v"(u) : "v"(tie));
-            const uint4 *np1, *np2;
-            word_of(u, np1, np2);
-            nxt = *np1;
-            if (REC) nxt2 = *np2;
+            u32 idx = nxt_idx;
+            asm volatile("" : "+v"(idx) : "v"(tie));
+            words_at(nxt_rec, idx, nxt, nxt2);
         };
         if (!WIDE && more) ask_for_next(0u);  // (WIDE: wide4_pass asks for them, together with its own loads)
         const u32 my_flags = is_rec ? 0u : item_flags(my.y, my.z);

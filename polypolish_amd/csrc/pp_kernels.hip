@@ -526,7 +526,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_hslab, (size_t)HEAVY_SLOTS * HEAVY_PARTS * HSLAB_WORDS * 4);
     if (!direct) { ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); }
     if (direct) {
-        ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 4); ENS(b_xent, (uint64_t)nwin * ctx->xcap * 16);
+        ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 8);  /* extras per window | entries that are not bulk per window */ ENS(b_xent, (uint64_t)nwin * ctx->xcap * 16);
         ENS(b_need_win, (uint64_t)nwin * 4); ENS(b_win_lo, (uint64_t)nwin * 4); ENS(b_win_hi, (uint64_t)nwin * 4);
         std::vector<uint32_t> ends(ctx->wo_runs.begin(), ctx->wo_runs.end());
         if (!(ends == ctx->runs_on_dev && ctx->b_runs.p)) {  // (the same table as the job before: already there)
@@ -575,7 +575,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         const bool sharded = !ctx->emit.empty();
         hipLaunchKernelGGL(k_meta_init, dim3(sharded || direct ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
                            direct ? (u32 *)ctx->b_xcnt.p : (sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr),
-                           direct ? (u32 *)ctx->b_xcnt.p : (sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr), nwin,
+                           direct ? (u32 *)ctx->b_xcnt.p + nwin : (sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr), nwin,
                            (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
     }
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
@@ -676,11 +676,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         timer_begin(ctx, "prep");
         hipLaunchKernelGGL(k_prepd, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
                            (const u64 *)ctx->b_contig_off.p, nc_full, nwin, (const u32 *)ctx->b_runs.p, n_runs, (u32 *)ctx->b_first.p,
-                           (u32 *)ctx->b_xcnt.p, (uint4 *)ctx->b_xent.p, (u32)ctx->xcap, (u32 *)(d_meta + 9), d_meta + 12, d_status);
+                           (u32 *)ctx->b_xcnt.p, (u32 *)ctx->b_xcnt.p + nwin, (uint4 *)ctx->b_xent.p, (u32)ctx->xcap, (u32 *)(d_meta + 9), d_meta + 12, d_status);
         timer_end(ctx);
         timer_begin(ctx, "bucket");
         hipLaunchKernelGGL(k_winplan, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, n_runs, (const u32 *)ctx->b_first.p,
-                           (const u32 *)ctx->b_xcnt.p, (u32)ctx->xcap, heavy_min, d_heavy, d_win_heavy, d_meta + 3, d_status);
+                           (const u32 *)ctx->b_xcnt.p, (const u32 *)ctx->b_xcnt.p + nwin, (u32)ctx->xcap, heavy_min, d_heavy, d_win_heavy,
+                           d_meta + 3, d_status);
         timer_end(ctx);
     } else {
     timer_begin(ctx, "prep");

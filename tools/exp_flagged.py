@@ -12,16 +12,27 @@ dev = torch.device("cuda", 0)
 lens, cov, repeat, _ = bench.config_shape(int(os.environ.get("CONFIG", "1")))
 job = synthjob.make_job(dev, contig_lens=lens, coverage=cov, seed=42 + int(os.environ.get("CONFIG", "1")) + 1 + 1000 * 0, repeat=repeat)
 job = synthjob.with_wo(synthjob.with_seq4(job))
+torch.cuda.synchronize()   # (the library runs on a stream of its own: the job's arrays have to be there)
 ctx = pp.Context(0)
-ctx.set_profiling(1)
-for label, env in (("direct", None), ("bucketing", "1")):
-    if env:
-        os.environ["PP_BENCH_NO_RUNS"] = env
+ctx.set_profiling(int(os.environ.get("PROFILING", "1")))
+r = job["recs"]
+wo = job["wo"].cpu().numpy().view(np.uint8).reshape(-1).view(pp.WO_DTYPE)
+i0 = int(np.nonzero(wo["file_idx"] == 0)[0][0])
+print("record 0:", {k: int(r[k][0]) for k in ("contig", "ref_start", "k", "seq_off", "seq_len", "cig_off", "n_cig")},
+      "its mirror entry", i0, wo[i0], "runs", job["wo_runs"], flush=True)
+for label in os.environ.get("ORDER", "direct,bucketing,direct").split(","):
+    os.environ.pop("PP_BENCH_NO_RUNS", None)
+    if label == "bucketing":
+        os.environ["PP_BENCH_NO_RUNS"] = "1"
     job.pop("_prepared", None)
     print(f"== {label}", flush=True)
-    bench.run_job(ctx, pp, job)
-    ctx.sync()
-    print(label, ctx.kernel_times(), flush=True)
+    try:
+        bench.run_job(ctx, pp, job)
+        ctx.sync()
+        print(label, ctx.kernel_times(), flush=True)
+    except pp.PolypolishError as e:
+        print(label, "FAILED:", e, flush=True)
+os.environ.pop("PP_BENCH_NO_RUNS", None)
 # the per-position records (--debug planes) of the same job
 pp.lib().pp_polish_set_debug(ctx._h, 1)
 job.pop("_prepared", None)
