@@ -149,11 +149,12 @@ struct pp_ctx {
     pp::DevBuf b_win_heavy, b_hslab;  // heavy windows: slot + 1 per window (u8) | the helpers' partial tallies
     // ---- the direct path (pp_k_direct.h) ----
     std::vector<uint64_t> wo_runs;      // ends of the runs of the job's window-order mirror (pp_aln_batch.wo_run_end, rebased); empty = not known
-    pp::DevBuf b_runs, b_first, b_xcnt, b_xent, b_need_win, b_win_lo, b_win_hi;
+    pp::DevBuf b_runs, b_first, b_xcnt, b_xent, b_need_win, b_win_lo, b_win_hi, b_later;
     std::vector<uint32_t> runs_on_dev;  // what b_runs holds (identical tables are not uploaded again)
     size_t xcap = 0;                    // room for extras per window (grow-only)
     bool no_direct = false;             // this job is being rerun over the bucketing path (DE_MIRROR_ORDER)
     bool last_direct = false;           // the last pass over the pipeline took the direct path
+    bool nothing_flagged_last = false;  // the job before had no position flagged for the exact replays (run_pipeline: their launches are then left out until this job's metadata say otherwise)
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run

@@ -43,102 +43,200 @@ __device__ __forceinline__ uint4 wo_item(u64 so, u32 len, u32 kc, u64 g, u32 w, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_prepd
+// k_prepd / k_prepg
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk, const pp_wo_rec *__restrict__ wo,
-                                                               const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
-                                                               const u32 *__restrict__ cigar, const u8 *__restrict__ seq,
-                                                               const u64 *__restrict__ contig_off, u32 n_contigs, u32 nwin,
-                                                               const u32 *__restrict__ run_end, u32 n_runs,  // ends of the mirror's runs (ascending, the last one = n)
-                                                               u32 *__restrict__ first, u32 *__restrict__ x_cnt, u32 *__restrict__ x_nb,
-                                                               uint4 *__restrict__ xent, u32 xcap, u32 *__restrict__ maxlen,
-                                                               u64 *__restrict__ x_need, u64 *status) {
-    __shared__ u32 later[PREP_LATER_MAX], n_later;
-    // The block's extras are STAGED in LDS and get their slots in the windows' rooms at the end, one returning global atomic
-    // per window of the block instead of one per wave, window and trip through the loop (a wave waited out thirteen of
-    // those round trips, one after the other: k_prepd 0.16 ms where k_prep + k_fill took 0.19).  A block's entries lie in
-    // a handful of consecutive windows (the mirror is in window order): XLOCAL counters from the window of its first entry
-    // on; an extra for a window outside that range (a block across the end of a run, a long read), or one more than the
-    // stage holds, takes its slot from the global counter on the spot.
-    constexpr u32 XSTAGE = 2048, XLOCAL = 64;
-    __shared__ uint4 st_item[XSTAGE];
-    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
-    PP_STAMP(0, 0);
-    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    if (threadIdx.x == 0) {
-        n_later = 0;
-        n_st = 0;
-        u32 wb = 0;
-        if (lo < hi) {
-            const pp_wo_rec r0 = wo[lo];
-            if (r0.contig < n_contigs) wb = wo_home(contig_off[r0.contig], r0.ref_start, nwin);
-        }
-        s_wbase = wb;
-    }
-    if (threadIdx.x < XLOCAL) { l_cnt[threadIdx.x] = 0; l_nb[threadIdx.x] = 0; }
-    __syncthreads();
-    PP_STAMP(0, 1);
-    const u32 wbase = s_wbase;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 stride = nwin + 1u;
+// A workgroup's extras are STAGED in LDS and get their slots in the windows' rooms at the end, one returning global atomic
+// per window of the workgroup instead of one per wave, window and trip through the loop (a wave waited out thirteen of
+// those round trips, one after the other: k_prepd 0.16 ms where k_prep + k_fill took 0.19).  A workgroup's entries lie in
+// a handful of consecutive windows (the mirror is in window order): XLOCAL counters from the window of its first entry
+// on; an extra for a window outside that range (a workgroup across the end of a run, a long read), or one more than the
+// stage holds, takes its slot from the global counter on the spot.
+constexpr u32 XLOCAL = 64, CTG_LDS = 1024;
+struct XSink {
+    uint4 *st_item;  // LDS: [xstage] staged items ...
+    u32 *st_key;     //      ... their (local window << 16 | rank among the workgroup's extras of that window)
+    u32 *l_cnt, *l_base, *l_nb;  // LDS [XLOCAL]: extras / their first slot / entries that are not bulk, per local window
+    u32 *n_st;
+    u32 xstage, wbase, xcap;
+    u32 *x_cnt, *x_nb;
+    uint4 *xent;
+    u64 *x_need, *status;
     // one extra into its slot of its window's room, or a capacity overflow (the host gives the windows more room and reruns)
-    auto put = [&](u32 w, u32 slot, const uint4 &e) {
+    __device__ __forceinline__ void put(u32 w, u32 slot, const uint4 &e) const {
         if (slot < xcap) xent[(u64)w * xcap + slot] = e;
         else {
             atomicMax(x_need, (u64)slot + 1ull);
             report(status, slot, DE_CAPACITY);
         }
-    };
+    }
     // one extra of window w: staged, or straight to its window
-    auto emit = [&](u32 w, const uint4 &e) {
+    __device__ __forceinline__ void emit(u32 w, const uint4 &e) const {
         const u32 wl = w - wbase;
         if (wl < XLOCAL) {
-            const u32 pos = atomicAdd(&n_st, 1u);
-            if (pos < XSTAGE) {
+            const u32 pos = atomicAdd(n_st, 1u);
+            if (pos < xstage) {
                 st_key[pos] = (wl << 16) | atomicAdd(&l_cnt[wl], 1u);
                 st_item[pos] = e;
                 return;
             }
         }
         put(w, atomicAdd(&x_cnt[w], 1u), e);
-    };
-    // the pieces of a record that is NOT bulk (prep_general's verdict), window by window
-    auto cut = [&](u32 g_out, u32 word, u64 so, u32 kc, u32 fi) {
-        if (!word) return;
-        const u32 cls = word >> 30, ia = (word >> 9) & 0xFFu, idel = (word >> 17) & 1u;
-        for_each_piece(g_out, word, [&](u32 piece, u32 g, u32 sp) {
-            if (!sp) return;
-            const u32 wa = g / (u32)TILE, wb = min((g + sp - 1u) / (u32)TILE, nwin - 1u);
-            u64 pso = so;
-            u32 len = sp, fl = 0, zf = 0;
-            if (cls == NKW_INDEL1) {
-                if (piece == 0u) zf = 1u;
-                else if (piece == 1u) { zf = 2u; pso += ia - 1u + idel; len = idel ? 0u : 2u; }
-                else pso += idel ? ia : ia + 1u;
-            } else fl = cls;
-            for (u32 w = wa; w <= wb && w >= wa; w++) {
-                uint4 e;
-                e.x = fl ? sp : (u32)pso;
-                e.y = (fl ? 0u : (((u32)(pso >> 32) & 0xFFu) | (len << 24))) | (kc << 8) | (fl << 16);
-                e.z = ((u32)(int)((long long)g - (long long)w * TILE) & 0x3FFFFFFFu) | (zf << 30);
-                e.w = fi;
-                emit(w, e);
-            }
-        });
-    };
-    auto general = [&](const pp_wo_rec &r, u64 c_lo, u64 c_hi) {
-        u32 g_out = 0, nk_out = 0;
-        u8 fl_out = 0;
-        const u32 fi = r.file_idx;
-        if (fi >= n) return;  // (reported in the loop: the arrays cannot be read for it)
-        if (r.contig >= n_contigs) report(status, fi, DE_BAD_CONTIG);
-        else {
-            const u32 nc = r.op0 == PP_WO_MULTI_RUN ? n_cig[fi] : 1u;
-            if (nc == 0) report(status, fi, DE_BAD_RUN);
-            else prep_general(fi, r.ref_start, r.seq_len, r.seq_off, cigar + cig_off[fi], nc, seq, c_lo, c_hi - c_lo, &g_out, &nk_out, &fl_out, status);
+    }
+    // an entry of window h that is not bulk (k_tile passes it over: k_winplan takes it off the window's count)
+    __device__ __forceinline__ void not_bulk(u32 h) const {
+        if (h - wbase < XLOCAL) atomicAdd(&l_nb[h - wbase], 1u); else atomicAdd(&x_nb[h], 1u);
+    }
+    __device__ __forceinline__ void clear() const {  // (before a barrier)
+        if (threadIdx.x < XLOCAL) { l_cnt[threadIdx.x] = 0; l_nb[threadIdx.x] = 0; }
+        if (threadIdx.x == 0) *n_st = 0;
+    }
+    // every thread of the workgroup, when all extras are in: a stretch of slots per window, then every item to its slot
+    __device__ __forceinline__ void flush() const {
+        __syncthreads();
+        if (threadIdx.x < XLOCAL) {
+            const u32 c = l_cnt[threadIdx.x], nb = l_nb[threadIdx.x];
+            l_base[threadIdx.x] = c ? atomicAdd(&x_cnt[wbase + threadIdx.x], c) : 0u;  // (c > 0: a window of the assembly)
+            if (nb) atomicAdd(&x_nb[wbase + threadIdx.x], nb);
         }
-        cut(g_out, nk_out | ((u32)fl_out << 30), r.seq_off, kclass_of(r.k), fi);
-    };
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < min(*n_st, xstage); i += blockDim.x) {
+            const u32 key = st_key[i], wl = key >> 16;
+            put(wbase + wl, l_base[wl] + (key & 0xFFFFu), st_item[i]);
+        }
+    }
+};
+
+struct PrepdArgs {
+    u64 n;
+    const pp_wo_rec *wo;
+    const u64 *cig_off;
+    const u32 *n_cig, *cigar;
+    const u8 *seq;
+    const u64 *contig_off;
+    u32 n_contigs, nwin;
+    const u32 *run_end;  // ends of the mirror's runs (ascending, the last one = n)
+    u32 n_runs;
+    u32 *first, *x_cnt, *x_nb;
+    uint4 *xent;
+    u32 xcap;
+    u32 *maxlen;
+    u64 *x_need;
+    uint4 *g_later;      // the entries that are not bulk, for k_prepg: copies of them, two 16-byte words each (file index NOIDX: none) ...
+    u64 *g_nlater;       // ... how many (counted past the capacity too) ...
+    u64 cap_later;       // ... and the room
+    u64 *status;
+};
+
+// A record that is NOT bulk: prep_general's verdict (CIGAR validity, spans, the trim of the slow classes), its pieces window
+// by window as extras, and one more entry of its home window that k_tile will pass over.  One lane per record.
+// Two round trips: (1) the run count and where the runs are, and the read's last eight bytes (the trims look at the read
+// from its end and rarely further); (2) the first eight runs.  (A record of one run has it in its mirror entry.)  Anything
+// beyond is read where it is needed, as in k_prep.
+template <typename CTG>
+__device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdArgs &P, CTG ctg, const XSink &X) {
+    u32 g_out = 0, nk_out = 0;
+    u8 fl_out = 0;
+    const u32 fi = r.file_idx;
+    if (fi >= P.n) return;  // (reported by k_prepd's loop: the arrays cannot be read for it)
+    if (r.contig >= P.n_contigs) { report(P.status, fi, DE_BAD_CONTIG); return; }
+    const u64 c_lo = ctg(r.contig), c_hi = ctg(r.contig + 1u);
+    X.not_bulk(wo_home(c_lo, r.ref_start, P.nwin));
+    {
+        const bool multi = r.op0 == PP_WO_MULTI_RUN;
+        const u32 sl = r.seq_len;
+        const u8 *const sq = P.seq + r.seq_off;
+        u64 tail8 = 0;
+        if (sl >= 8u) __builtin_memcpy(&tail8, sq + (sl - 8u), 8);
+        u32 nc = 1;
+        u64 co = 0;
+        if (multi) { nc = P.n_cig[fi]; co = P.cig_off[fi]; }
+        if (nc == 0) report(P.status, fi, DE_BAD_RUN);
+        else {
+            const u32 *const cg = P.cigar + co;
+            u32 rr[8] = {r.op0, 0, 0, 0, 0, 0, 0, 0};
+            if (multi) {
+#pragma unroll
+                for (u32 j = 0; j < 8u; j++) rr[j] = cg[min(j, nc - 1u)];
+            }
+            prep_general_t(fi, r.ref_start, sl, nc,
+                           [&](u32 i) -> u32 {
+                               if (i >= 8u) return cg[i];
+                               u32 v = rr[0];
+#pragma unroll
+                               for (u32 j = 1; j < 8u; j++) v = i == j ? rr[j] : v;
+                               return v;
+                           },
+                           [&](u32 i) -> u8 { return sl >= 8u && i + 8u >= sl ? (u8)(tail8 >> (8u * (i + 8u - sl))) : sq[i]; },
+                           c_lo, c_hi - c_lo, &g_out, &nk_out, &fl_out, P.status);
+        }
+    }
+    const u32 word = nk_out | ((u32)fl_out << 30);
+    if (!word) return;
+    const u32 kc = kclass_of(r.k);
+    const u32 cls = word >> 30, ia = (word >> 9) & 0xFFu, idel = (word >> 17) & 1u;
+    for_each_piece(g_out, word, [&](u32 piece, u32 g, u32 sp) {
+        if (!sp) return;
+        const u32 wa = g / (u32)TILE, wb = min((g + sp - 1u) / (u32)TILE, P.nwin - 1u);
+        u64 pso = r.seq_off;
+        u32 len = sp, fl = 0, zf = 0;
+        if (cls == NKW_INDEL1) {
+            if (piece == 0u) zf = 1u;
+            else if (piece == 1u) { zf = 2u; pso += ia - 1u + idel; len = idel ? 0u : 2u; }
+            else pso += idel ? ia : ia + 1u;
+        } else fl = cls;
+        for (u32 w = wa; w <= wb && w >= wa; w++) {
+            uint4 e;
+            e.x = fl ? sp : (u32)pso;
+            e.y = (fl ? 0u : (((u32)(pso >> 32) & 0xFFu) | (len << 24))) | (kc << 8) | (fl << 16);
+            e.z = ((u32)(int)((long long)g - (long long)w * TILE) & 0x3FFFFFFFu) | (zf << 30);
+            e.w = fi;
+            X.emit(w, e);
+        }
+    });
+}
+
+constexpr u32 NOIDX = 0xFFFFFFFFu;
+
+// k_prepd: the streaming pass.  The records that are not bulk are only NOTED -- first in LDS, then, one stretch per
+// workgroup, in a list in memory that k_prepg works off with a lane per record: here, between the loop and the end of a
+// workgroup, their chain of round trips kept the chip from streaming (a workgroup: 21 us of loop, 15 us of waiting).
+// A workgroup whose records do not fit the lists (a job of reads with indels throughout) handles them itself.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, PrepdArgs P) {
+    constexpr u32 LATER_MAX = THREADS >= 1024 ? 768 : 320, XSTAGE = 2 * THREADS;  // (73 KB / 40 KB of LDS in all: two / four workgroups per CU)
+    __shared__ uint4 later[2 * LATER_MAX];  // the noted entries themselves (k_prepg then starts from the entry, not from its index)
+    __shared__ u32 n_later, s_later_at;
+    __shared__ uint4 st_item[XSTAGE];
+    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
+    __shared__ u64 s_ctg[CTG_LDS + 1];  // the contig table when it has up to CTG_LDS contigs: a record's two offsets are then LDS reads, not a dependent trip to memory
+    PP_STAMP(0, 0);
+    const u64 n = P.n;
+    const pp_wo_rec *const wo = P.wo;
+    const u32 n_contigs = P.n_contigs, nwin = P.nwin, n_runs = P.n_runs;
+    const u32 *const run_end = P.run_end;
+    u64 *const status = P.status;
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const bool ctg_lds = n_contigs <= CTG_LDS;
+    if (ctg_lds)
+        for (u32 i = threadIdx.x; i <= n_contigs; i += blockDim.x) s_ctg[i] = P.contig_off[i];
+    if (threadIdx.x == 0) {
+        n_later = 0;
+        u32 wb = 0;
+        if (lo < hi) {
+            const pp_wo_rec r0 = wo[lo];
+            if (r0.contig < n_contigs) wb = wo_home(P.contig_off[r0.contig], r0.ref_start, nwin);
+        }
+        s_wbase = wb;
+    }
+    XSink X{st_item, st_key, l_cnt, l_base, l_nb, &n_st, XSTAGE, 0u, P.xcap, P.x_cnt, P.x_nb, P.xent, P.x_need, status};
+    X.clear();
+    __syncthreads();
+    PP_STAMP(0, 1);
+    X.wbase = s_wbase;
+    auto ctg = [&](u32 i) -> u64 { return ctg_lds ? s_ctg[i] : P.contig_off[i]; };
+    const u32 lane = threadIdx.x & 63u;
+    const u32 stride = nwin + 1u;
+    u32 *const first = P.first;
     // first[run][from .. to] = val; short ranges by the lane itself (one entry when a window begins: the usual case), long
     // ones (windows without a record: an uncovered contig) by the whole wave -- every lane of the wave calls this
     auto fill = [&](bool want, u32 run, u32 from, u32 to, u32 val) {
@@ -155,93 +253,140 @@ __global__ __launch_bounds__(1024, PP_PREP_WAVES) void k_prepd(u64 n, u64 chunk,
             for (u64 w = (u64)ff + lane; w <= tt; w += 64) first[(u64)rr * stride + w] = vv;
         }
     };
-    u32 run0 = 0, run0_lo = 0;  // the run of the block's first entry
-    while (run0 + 1u < n_runs && lo >= run_end[run0]) { run0_lo = run_end[run0]; run0++; }
+    // The loop is what the kernel's time consists of, and with eight waves to a SIMD its instruction count more than its
+    // 32 bytes per record (its first version: ~300 instructions per record, 59 us per block for 213 MB): everything that
+    // is rare -- a window begins, a run ends, an entry out of order, a record the checks refuse -- sits behind ONE ballot; the
+    // window of the entry in front comes from the neighbouring lane (the wave's first lane: one look at the mirror).
+    u32 runw = 0, runw_lo = 0;  // the run of the current wave's first entry (wave-uniform, only ever moves on)
     u32 fast_len = 0;
     constexpr int WU = PP_WO_UNROLL;
     const uint4 *wq = (const uint4 *)wo;
     const u64 trip = (u64)WU * blockDim.x;
     const u64 span = (hi - lo + trip - 1) / trip * trip;  // whole waves and whole trips: the ballots below need every lane
     for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
-        uint4 qa[WU], qb[WU], pa[WU];
+        uint4 qa[WU], qb[WU];
+        u32 pc[WU], pr[WU];
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);  // clamped: the loads are unconditional
             qa[u] = wq[2 * a];
             qb[u] = wq[2 * a + 1];
-            pa[u] = wq[2 * (a ? a - 1 : 0)];  // the entry in front (its first half: contig, ref_start): where a window begins
+            // (contig, ref_start) of the entry in front of the wave's first one
+            const u64 wf = a0 - lane + (u64)u * blockDim.x;  // (the same for the whole wave)
+            const u64 pf = min(wf ? wf - 1 : 0, n - 1);
+            pc[u] = wo[pf].contig;
+            pr[u] = wo[pf].ref_start;
         }
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const u64 a = a0 + (u64)u * blockDim.x;
             const bool in = a < hi;
-            pp_wo_rec r;
-            r.contig = qa[u].x; r.ref_start = qa[u].y; r.k = qa[u].z; r.seq_len = qa[u].w;
-            r.seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32); r.op0 = qb[u].z; r.file_idx = qb[u].w;
-            const bool c_ok = r.contig < n_contigs, p_ok = pa[u].x < n_contigs;
-            const u32 cc = min(r.contig, n_contigs - 1u), pc = min(pa[u].x, n_contigs - 1u);
-            const u64 c_lo = contig_off[cc], c_hi = contig_off[cc + 1], p_lo = contig_off[pc];
-            const bool bulk = in && wo_bulk(c_ok, r.ref_start, r.seq_len, r.op0, c_hi - c_lo);
-            // ---- checks every record gets (k_fill's, and the mirror's own) ----
-            if (in) {
-                if (r.file_idx >= n) report(status, a, DE_BAD_MIRROR);
-                else if (r.k == 0) report(status, r.file_idx, DE_BAD_K);
-                else if (r.seq_off + r.seq_len > (1ull << 40)) report(status, r.file_idx, DE_OVERFLOW);
+            const u32 contig = qa[u].x, ref_start = qa[u].y, k = qa[u].z, seq_len = qa[u].w, op0 = qb[u].z, file_idx = qb[u].w;
+            const u64 seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32);
+            const bool c_ok = contig < n_contigs;
+            const u32 cc = min(contig, n_contigs - 1u);
+            const u64 c_lo = ctg(cc), c_hi = ctg(cc + 1u);
+            const bool bulk = in && wo_bulk(c_ok, ref_start, seq_len, op0, c_hi - c_lo);
+            const u64 g = c_lo + ref_start;
+            const u32 h = in && c_ok ? (u32)min(g / (u64)TILE, (u64)(nwin - 1u)) : NOHOME;
+            // the window of the entry in front
+            u32 hp = (u32)__shfl_up((int)h, 1, 64);
+            if (lane == 0) hp = pc[u] < n_contigs ? wo_home(ctg(pc[u]), pr[u], nwin) : NOHOME;
+            // the wave's run (uniform); a lane behind its end (a wave across the end of a run) finds its own
+            const u32 wf32 = (u32)(a - lane);
+            while (runw + 1u < n_runs && wf32 >= run_end[runw]) { runw_lo = run_end[runw]; runw++; }
+            u32 run = runw, run_lo = runw_lo, run_hi = run_end[runw];
+            if ((u32)a >= run_hi && runw + 1u < n_runs)
+                while (run + 1u < n_runs && (u32)a >= run_end[run]) { run_lo = run_end[run]; run++; run_hi = run_end[run]; }
+            const bool valid = h != NOHOME, starts = (u32)a == run_lo;
+            const bool begins = valid && (starts || (hp != NOHOME && h > hp));
+            const bool descent = valid && !starts && hp != NOHOME && h < hp;
+            const bool ends = valid && (u32)a + 1u == run_hi;
+            const bool bad = in && (file_idx >= n || k == 0 || seq_off + seq_len > (1ull << 40));
+            if (__ballot(begins || descent || ends || bad)) {
+                if (bad) {  // the checks every record gets (k_fill's, and the mirror's own)
+                    if (file_idx >= n) report(status, a, DE_BAD_MIRROR);
+                    else if (k == 0) report(status, file_idx, DE_BAD_K);
+                    else report(status, file_idx, DE_OVERFLOW);
+                }
+                if (descent) report(status, (1ull << 40) - 1ull, DE_MIRROR_ORDER);
+                fill(begins, run, starts ? 0u : hp + 1u, h, (u32)a);
+                fill(ends, run, h + 1u, nwin, (u32)a + 1u);
             }
-            // ---- where the windows begin in this entry's run ----
-            u32 run = run0, run_lo = run0_lo;  // (the block's entries lie in one run, or in a few)
-            while (run + 1u < n_runs && a >= run_end[run]) { run_lo = run_end[run]; run++; }
-            const u32 run_hi = run_end[run];
-            const u32 h = in && c_ok ? wo_home(c_lo, r.ref_start, nwin) : NOHOME;
-            const u32 hp = p_ok ? wo_home(p_lo, pa[u].y, nwin) : NOHOME;
-            const bool starts = (u32)a == run_lo;
-            if (h != NOHOME && !starts && hp != NOHOME && h < hp) report(status, (1ull << 40) - 1ull, DE_MIRROR_ORDER);
-            const bool begins = h != NOHOME && (starts || (hp != NOHOME && h > hp));
-            fill(begins, run, starts ? 0u : hp + 1u, h, (u32)a);
-            fill(h != NOHOME && (u32)a + 1u == run_hi, run, h + 1u, nwin, (u32)a + 1u);
-            // ---- a bulk read that reaches into the next window: one extra there ----
-            const u64 g = c_lo + r.ref_start;
-            const u32 w1 = bulk ? (u32)((g + r.seq_len - 1u) / (u64)TILE) : 0u;
-            if (bulk && w1 > h) emit(w1, wo_item(r.seq_off, r.seq_len, kclass_of(r.k), g, w1, r.file_idx));
-            if (bulk) fast_len = max(fast_len, r.seq_len);
+            // a bulk read that reaches into the next window: one extra there
+            const u32 w1 = bulk ? (u32)((g + seq_len - 1u) / (u64)TILE) : 0u;
+            if (bulk && w1 > h) X.emit(w1, wo_item(seq_off, seq_len, kclass_of(k), g, w1, file_idx));
+            if (bulk) fast_len = max(fast_len, seq_len);
             else if (in) {
-                // (a record that is not bulk: the window it starts in holds its entry AND, among the extras, its pieces --
-                // counted, so that k_winplan can tell what the window's work amounts to)
-                if (h != NOHOME) { if (h - wbase < XLOCAL) atomicAdd(&l_nb[h - wbase], 1u); else atomicAdd(&x_nb[h], 1u); }
                 const u32 slot = atomicAdd(&n_later, 1u);
-                if (slot < PREP_LATER_MAX) later[slot] = (u32)(a - lo);
-                else general(r, c_lo, c_hi);
+                if (slot < LATER_MAX) { later[2u * slot] = qa[u]; later[2u * slot + 1u] = qb[u]; }
             }
         }
     }
     PP_STAMP(0, 2);
     __syncthreads();
     PP_STAMP(0, 3);
-    for (u32 i = threadIdx.x; i < min(n_later, PREP_LATER_MAX); i += blockDim.x) {
-        const pp_wo_rec r = wo[lo + later[i]];
-        const u32 cc = min(r.contig, n_contigs - 1u);
-        general(r, contig_off[cc], contig_off[cc + 1]);
+    // the noted records: a stretch of the list in memory -- or, when there are more of them than either list holds, worked
+    // off here, from the block's entries once more (then the stretch, as far as it lies inside the list, is marked empty)
+    const u32 n_noted = n_later;
+    if (threadIdx.x == 0) s_later_at = n_noted ? (u32)min(atomicAdd(P.g_nlater, (u64)n_noted), (u64)NOIDX) : 0u;
+    __syncthreads();
+    const u64 at = s_later_at;
+    const bool listed = n_noted <= LATER_MAX && at + n_noted <= P.cap_later;
+    for (u32 i = threadIdx.x; i < 2u * n_noted; i += blockDim.x)
+        if (at + (i >> 1) < P.cap_later) P.g_later[2ull * at + i] = listed ? later[i] : make_uint4(NOIDX, NOIDX, NOIDX, NOIDX);
+    if (!listed && n_noted) {
+        for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
+            const pp_wo_rec r = wo[a];
+            const u32 cc = min(r.contig, n_contigs - 1u);
+            if (!wo_bulk(r.contig < n_contigs, r.ref_start, r.seq_len, r.op0, ctg(cc + 1u) - ctg(cc))) general_record(r, P, ctg, X);
+        }
     }
     PP_STAMP(0, 4);
-    // ---- the staged extras: a stretch of slots per window of the block, then every item to its slot ----
-    __syncthreads();
-    if (threadIdx.x < XLOCAL) {
-        const u32 c = l_cnt[threadIdx.x], nb = l_nb[threadIdx.x];
-        l_base[threadIdx.x] = c ? atomicAdd(&x_cnt[wbase + threadIdx.x], c) : 0u;  // (c > 0: a window of the assembly)
-        if (nb) atomicAdd(&x_nb[wbase + threadIdx.x], nb);
-    }
-    __syncthreads();
+    X.flush();
     PP_STAMP(0, 5);
-    for (u32 i = threadIdx.x; i < min(n_st, XSTAGE); i += blockDim.x) {
-        const u32 key = st_key[i], wl = key >> 16;
-        put(wbase + wl, l_base[wl] + (key & 0xFFFFu), st_item[i]);
-    }
-    PP_STAMP(0, 6);
     // the job's longest fast-class read (as k_prep)
     if (__ballot(fast_len > PLAIN_NARROW_MAX)) {
         for (int o = 32; o > 0; o >>= 1) fast_len = max(fast_len, (u32)__shfl_xor((int)fast_len, o, 64));
-        if (lane == 0 && fast_len > __hip_atomic_load(maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxlen, fast_len);
+        if (lane == 0 && fast_len > __hip_atomic_load(P.maxlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(P.maxlen, fast_len);
     }
+    PP_STAMP(0, 6);
+}
+
+// k_prepg: the records k_prepd noted, one lane each (a few per cent of a short-read job: all of their round trips at once)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
+    constexpr u32 XSTAGE = 4 * THREADS;
+    __shared__ uint4 st_item[XSTAGE];
+    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
+    __shared__ u64 s_ctg[CTG_LDS + 1];
+    if (*P.status != ~0ull) return;
+    const u64 total = min(*P.g_nlater, P.cap_later);
+    const u64 per = (total + gridDim.x - 1) / gridDim.x;
+    const u64 i0 = min(total, (u64)blockIdx.x * per), i1 = min(total, i0 + per);
+    if (i0 >= i1) return;
+    const bool ctg_lds = P.n_contigs <= CTG_LDS;
+    if (ctg_lds)
+        for (u32 i = threadIdx.x; i <= P.n_contigs; i += blockDim.x) s_ctg[i] = P.contig_off[i];
+    if (threadIdx.x == 0) {  // the window of the stretch's first record: where the local counters start
+        u32 wb = 0;
+        const uint4 q0 = P.g_later[2ull * i0];
+        if (q0.x < P.n_contigs) wb = wo_home(P.contig_off[q0.x], q0.y, P.nwin);
+        s_wbase = wb;
+    }
+    XSink X{st_item, st_key, l_cnt, l_base, l_nb, &n_st, XSTAGE, 0u, P.xcap, P.x_cnt, P.x_nb, P.xent, P.x_need, P.status};
+    X.clear();
+    __syncthreads();
+    X.wbase = s_wbase;
+    auto ctg = [&](u32 i) -> u64 { return ctg_lds ? s_ctg[i] : P.contig_off[i]; };
+    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const uint4 qa = P.g_later[2ull * i], qb = P.g_later[2ull * i + 1];
+        pp_wo_rec r;
+        r.contig = qa.x; r.ref_start = qa.y; r.k = qa.z; r.seq_len = qa.w;
+        r.seq_off = (u64)qb.x | ((u64)qb.y << 32); r.op0 = qb.z; r.file_idx = qb.w;
+        if (!(qa.x == NOIDX && qb.w == NOIDX)) general_record(r, P, ctg, X);
+    }
+    X.flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -21,20 +21,23 @@ __device__ u64 *g_prep_stamps;
 // =============================================================================================
 // every record that is not a single short M run inside its contig
 // g0: where the record's contig starts in the run's coordinates (k_prep's g_base); clen: the contig's length
-__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
-                                               u64 g0, u64 clen, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
+// RUN run(i): the record's i-th CIGAR run; BYTE sb(i): byte i of its SEQ -- straight from memory (k_prep), or out of registers
+// that were loaded together (k_prepd: the first four runs, the read's last eight bytes: two round trips instead of five)
+template <typename RUN, typename BYTE>
+__device__ __forceinline__ void prep_general_t(u64 a, u32 rs, u32 sl, u32 nc, RUN run, BYTE sb, u64 g0, u64 clen,
+                                               u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
     // walk the runs (alignment.rs:178-194): spans and validity
     u64 ref_span = 0, read_span = 0;
     bool indel = false;
     for (u32 r = 0; r < nc; r++) {
-        u32 op = cg[r], len = op >> 4, o = op & 15u;
+        u32 op = run(r), len = op >> 4, o = op & 15u;
         if (len == 0 || o > 8u) { report(status, a, DE_BAD_RUN); return; }
         if (o == PP_OP_M || o == PP_OP_EQ || o == PP_OP_X) { ref_span += len; read_span += len; }
         else if (o == PP_OP_I) { read_span += len; indel = true; }
         else if (o == PP_OP_D) { ref_span += len; indel = true; }
         else { report(status, a, DE_UNEXPECTED_OP); return; }
     }
-    u32 o_first = cg[0] & 15u, o_last = cg[nc - 1] & 15u;
+    u32 o_first = run(0) & 15u, o_last = run(nc - 1) & 15u;
     if (!((o_first == PP_OP_M || o_first == PP_OP_EQ) && (o_last == PP_OP_M || o_last == PP_OP_EQ))) {
         report(status, a, DE_BAD_ENDS);
         return;
@@ -42,18 +45,26 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     if (read_span != (u64)sl) { report(status, a, DE_LEN_MISMATCH); return; }
     if (ref_span >= 0x3FFFFFFFull) { report(status, a, DE_OVERFLOW); return; }
 
-    const u8 *s = seq + so;
+    // simple_trim_start over the bytes [from, from + len) of the read: index (relative to `from`) of the first base of the
+    // trailing homopolymer
+    auto trim_start = [&](u32 from, u32 len) -> u32 {
+        const u8 last = sb(from + len - 1u);
+        u32 i = len - 1u;
+        while (i > 0 && sb(from + i - 1u) == last) i--;
+        return i;
+    };
     u32 n_entries = (u32)ref_span;
     if (indel && nc == 3u && sl <= FAST_MAX_LEN && (u64)rs + ref_span <= clen) {
         // ONE 1-base indel between two M/= runs (a read over a planted assembly indel, or a sequencing indel): no walk.
         // k_fill cuts it into the flank in front, the entry at the indel and the flank behind (pp_internal.h, ENT_NOTRIM /
         // ENT_POINT); the trim has to stay inside the flank behind, which is what the reads of k_tile's plain class assume.
-        const u32 o0 = cg[0] & 15u, o1 = cg[1] & 15u, o2 = cg[2] & 15u, a = cg[0] >> 4, b = cg[2] >> 4;
+        const u32 c0 = run(0), c1 = run(1), c2 = run(2);
+        const u32 o0 = c0 & 15u, o1 = c1 & 15u, o2 = c2 & 15u, a = c0 >> 4, b = c2 >> 4;
         if ((o0 == PP_OP_M || o0 == PP_OP_EQ) && (o2 == PP_OP_M || o2 == PP_OP_EQ) && (o1 == PP_OP_I || o1 == PP_OP_D) &&
-            (cg[1] >> 4) == 1u) {
+            (c1 >> 4) == 1u) {
             const bool del = o1 == PP_OP_D;
             const u32 l1 = del ? a : a - 1u;
-            if (l1 >= INDEL1_MIN_SEG && b >= INDEL1_MIN_SEG && simple_trim_start(s + (del ? a : a + 1u), b) >= 1u) {
+            if (l1 >= INDEL1_MIN_SEG && b >= INDEL1_MIN_SEG && trim_start(del ? a : a + 1u, b) >= 1u) {
                 *g_out = (u32)(g0 + rs);
                 *nk_out = n_entries | (a << 9) | ((del ? 1u : 0u) << 17);
                 *fl_out = (u8)NKW_INDEL1;
@@ -70,10 +81,10 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     }
     // trim_bases_for_homopolymers (alignment.rs:364-378).  The last entry is the single base
     // seq[sl-1] (the last run is M/=).  `run` = number of trailing entries equal to it.
-    u8 last = s[sl - 1];
-    u32 run = 0;
+    u8 last = sb(sl - 1u);
+    u32 trun = 0;
     if (!indel) {
-        run = sl - simple_trim_start(s, sl);
+        trun = sl - trim_start(0u, sl);
     } else {
         // walk the entries from the right end and stop at the first one that differs from the
         // last base (typically after 2-3 steps): runs in reverse; `pend` = bases inserted right
@@ -82,28 +93,35 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
         u32 pend = 0;
         bool stop = false;
         for (u32 r = nc; r-- > 0 && !stop;) {
-            const u32 op = cg[r], len = op >> 4, o = op & 15u;
+            const u32 op = run(r), len = op >> 4, o = op & 15u;
             if (o == PP_OP_I) { ro -= len; pend += len; continue; }
             if (o == PP_OP_D) {
                 // last slot of the run: empty, or rewritten to the inserted bases; the others are empty
-                if (pend == 1 && s[ro] == last) { run += 1; if (len > 1) stop = true; }
+                if (pend == 1 && sb((u32)ro) == last) { trun += 1; if (len > 1) stop = true; }
                 else stop = true;
             } else {
                 for (u32 t = 0; t < len; t++) {
                     const bool extended = (t == 0) && pend > 0;
-                    if (!extended && s[ro - 1 - t] == last) run += 1; else { stop = true; break; }
+                    if (!extended && sb((u32)(ro - 1 - t)) == last) trun += 1; else { stop = true; break; }
                 }
                 ro -= len;
             }
             pend = 0;
         }
     }
-    u32 nk = (n_entries > run) ? n_entries - run - 1u : 0u;
+    u32 nk = (n_entries > trun) ? n_entries - trun - 1u : 0u;
     if (nk == 0) return;  // contributes nothing; the reference never indexes the pileup for it
     if ((u64)rs + nk > clen) { report(status, a, DE_OUT_OF_BOUNDS); return; }
     *g_out = (u32)(g0 + rs);
     *nk_out = nk;
     *fl_out = indel ? (u8)ENT_COMPLEX : (u8)ENT_PRETRIM;
+}
+
+// k_prep's: everything read where it is needed
+__device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u32 *cg, u32 nc, const u8 *seq,
+                                               u64 g0, u64 clen, u32 *g_out, u32 *nk_out, u8 *fl_out, u64 *status) {
+    const u8 *s = seq + so;
+    prep_general_t(a, rs, sl, nc, [&](u32 i) -> u32 { return cg[i]; }, [&](u32 i) -> u8 { return s[i]; }, g0, clen, g_out, nk_out, fl_out, status);
 }
 
 #ifndef PP_PLAIN_ALIGNED

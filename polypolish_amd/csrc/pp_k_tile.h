@@ -1054,7 +1054,8 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     // DIRECT: the window's stretches of the mirror, in s_dirty's space behind the range table (both are only needed while the
     // items are tallied): [0, R] prefix sums of the stretches' lengths, [32, 32 + R) where each begins
     u32 *const s_run = (u32 *)s_dirty + 512;
-    static_assert(PMASK_WORDS <= 512 && 512 + 32 + PP_WO_MAX_RUNS <= TILE / 2 && PP_WO_MAX_RUNS < 32, "the run table shares s_dirty with the range table");
+    // ... [48, 52) where the window's first contig starts and its length, [52] the window's extras
+    static_assert(PMASK_WORDS <= 512 && 512 + 53 <= TILE / 2 && PP_WO_MAX_RUNS <= 16, "the run table shares s_dirty with the range table");
 
     // The first HEAVY_BLOCKS blocks are helpers: block HEAVY_PARTS * slot + part tallies one part of the items of the
     // heavy window in that slot of the list.  They are dispatched first, so the longest windows start at time zero, and
@@ -1169,6 +1170,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
         if (r <= R && r < 32u) s_run[r] = inc - len;  // (lane R holds the total)
         if (r < R) s_run[32u + r] = f0;
+        if (r == 63u) s_run[52] = min(A.x_cnt[w], A.xcap);  // the window's extras (asked for here, with everything else of the prologue)
     }
     if (tid >= 128u && tid < 128u + (u32)PMASK_WORDS)
         ((u32 *)s_dirty)[tid - 128u] = pmask4((u32)min(max((int)tid - 128 - PMASK_BASE, 0), 32));
@@ -1176,6 +1178,10 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
         if (lane == 0) { if (wave == 0) s_c0 = cw; else s_c1 = cw; }
+        if (DIRECT && wave == 0 && lane == 0) {  // where the window's (first) contig starts and how long it is: for its mirror entries
+            const u64 lo64 = A.contig_off[cw], len64 = A.contig_off[cw + 1] - lo64;
+            s_run[48] = (u32)lo64; s_run[49] = (u32)(lo64 >> 32); s_run[50] = (u32)len64; s_run[51] = (u32)(len64 >> 32);
+        }
     }
     __syncthreads();
 
@@ -1188,7 +1194,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     const uint4 *items;
     if (DIRECT) {
         e0 = 0;
-        e1 = min(A.x_cnt[w], A.xcap);
+        e1 = s_run[52];
         items = A.xent + (u64)w * A.xcap;
         n_rec = s_run[A.n_runs];
     } else {
@@ -1213,9 +1219,8 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         RecMap M{s_run, s_run + 32, A.n_runs, (u32)__builtin_amdgcn_readfirstlane((int)v0),
                  (u32)__builtin_amdgcn_readfirstlane((int)(v1 - v0)), w, s_c0 == s_c1, c0, 0, 0};
         if (DIRECT) {
-            const u64 lo64 = A.contig_off[c0], len64 = A.contig_off[c0 + 1] - lo64;
-            M.c_lo = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)lo64) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(lo64 >> 32)) << 32);
-            M.clen = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)len64) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(len64 >> 32)) << 32);
+            M.c_lo = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[48]) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[49]) << 32);
+            M.clen = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[50]) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[51]) << 32);
         }
 #define PP_TILE_ITEMS(GWV, P4V) tile_items<GWV, P4V, DIRECT>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave, lane)
         if (A.seq4) {

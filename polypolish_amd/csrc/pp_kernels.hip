@@ -499,6 +499,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     static const bool env_no_direct = getenv("PP_DIRECT") && atoi(getenv("PP_DIRECT")) == 0;  // tuning / tests
     static const bool env_no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
     const uint32_t n_runs = (uint32_t)ctx->wo_runs.size();
+    // (room for the mirror indices of the records that are not bulk -- k_prepd notes them for k_prepg: an eighth of the
+    // records; a job with more of them has its workgroups handle what does not fit themselves)
+    const uint64_t cap_later = std::max<uint64_t>(65536, n / 8);
     const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && n > 0 && B.wo && ctx->emit.empty() && n_runs > 0 &&
                         n_runs <= PP_WO_MAX_RUNS && ctx->wo_runs.back() == n;
     ctx->last_direct = direct;
@@ -528,6 +531,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     if (direct) {
         ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 8);  /* extras per window | entries that are not bulk per window */ ENS(b_xent, (uint64_t)nwin * ctx->xcap * 16);
         ENS(b_need_win, (uint64_t)nwin * 4); ENS(b_win_lo, (uint64_t)nwin * 4); ENS(b_win_hi, (uint64_t)nwin * 4);
+        ENS(b_later, cap_later * 32);
         std::vector<uint32_t> ends(ctx->wo_runs.begin(), ctx->wo_runs.end());
         if (!(ends == ctx->runs_on_dev && ctx->b_runs.p)) {  // (the same table as the job before: already there)
             const void *dummy;
@@ -672,11 +676,28 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     }
 #endif
     if (direct) {
-        // one pass over the mirror: validation, where the windows begin in every run, extras; then what each window holds
+        // one pass over the mirror: validation, where the windows begin in every run, extras; then what each window holds.
+        // (Geometry measured on configs[1]: one resident wave of 1024-thread workgroups, as k_prep / k_fill; more, smaller
+        // ones only add their fixed round trips.)
+        static const long forced_nbd = getenv("PP_PREPD_BLOCKS") ? atol(getenv("PP_PREPD_BLOCKS")) : 0;  // tuning
+        static const long nbd_threads = getenv("PP_PREPD_THREADS") ? atol(getenv("PP_PREPD_THREADS")) : 1024;
+        // (one resident wave of workgroups for the 5 Mbp job -- 13,000 entries each: a workgroup's list of noted entries holds
+        // 768 of them, 6 % -- and as many more of that size as a larger job needs)
+        const uint32_t NBD = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(forced_nbd > 0 ? (uint64_t)forced_nbd : std::max<uint64_t>(512, n / 13000), (n + 2047) / 2048));
+        const uint64_t chunk_d = (n + NBD - 1) / NBD;
         timer_begin(ctx, "prep");
-        hipLaunchKernelGGL(k_prepd, dim3(NB), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, (const u64 *)B.cig_off, B.n_cig, B.cigar, B.seq,
-                           (const u64 *)ctx->b_contig_off.p, nc_full, nwin, (const u32 *)ctx->b_runs.p, n_runs, (u32 *)ctx->b_first.p,
-                           (u32 *)ctx->b_xcnt.p, (u32 *)ctx->b_xcnt.p + nwin, (uint4 *)ctx->b_xent.p, (u32)ctx->xcap, (u32 *)(d_meta + 9), d_meta + 12, d_status);
+PrepdArgs PA;
+        PA.n = n; PA.wo = d_wo; PA.cig_off = (const u64 *)B.cig_off; PA.n_cig = B.n_cig; PA.cigar = B.cigar; PA.seq = B.seq;
+        PA.contig_off = (const u64 *)ctx->b_contig_off.p; PA.n_contigs = nc_full; PA.nwin = nwin;
+        PA.run_end = (const u32 *)ctx->b_runs.p; PA.n_runs = n_runs; PA.first = (u32 *)ctx->b_first.p;
+        PA.x_cnt = (u32 *)ctx->b_xcnt.p; PA.x_nb = (u32 *)ctx->b_xcnt.p + nwin; PA.xent = (uint4 *)ctx->b_xent.p; PA.xcap = (u32)ctx->xcap;
+        PA.maxlen = (u32 *)(d_meta + 9); PA.x_need = d_meta + 12;
+        PA.g_later = (uint4 *)ctx->b_later.p; PA.g_nlater = d_meta + 15; PA.cap_later = cap_later;
+        PA.status = d_status;
+        if (nbd_threads == 1024) hipLaunchKernelGGL(k_prepd<1024>, dim3(NBD), dim3(1024), 0, st, (u64)chunk_d, PA);
+        else hipLaunchKernelGGL(k_prepd<512>, dim3(NBD), dim3(512), 0, st, (u64)chunk_d, PA);
+        // ... and the records it only noted (indels, long reads: a few per cent), a lane each
+        hipLaunchKernelGGL(k_prepg<256>, dim3((unsigned)std::max<uint64_t>(64, std::min<uint64_t>(16384, n / 8192 + 1))), dim3(256), 0, st, PA);
         timer_end(ctx);
         timer_begin(ctx, "bucket");
         hipLaunchKernelGGL(k_winplan, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, n_runs, (const u32 *)ctx->b_first.p,
@@ -811,7 +832,6 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     timer_end(ctx);
 
     u64 *d_scr = (u64 *)ctx->b_flag_scr.p;
-    timer_begin(ctx, "exact");
     ExactArgs E;
     E.cap_multi = (u32)ctx->cap_multi; E.cap_flag = (u32)ctx->cap_flag;
     E.flag_pos_w = T.flag_pos; E.flag_cov_w = T.flag_cov; E.flag_bits = T.flag_bits; E.win_nflag = T.win_nflag;
@@ -833,6 +853,8 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     E.heavy = d_heavy; E.win_heavy = d_win_heavy;
     // windows of up to SORT_MAX items: wave-per-position replay; the rest (and key-table overflows)
     // go through the global list to the thread-serial k_exact
+    auto launch_exact = [&]() {
+    timer_begin(ctx, "exact");
     if (direct)  // the windows k_tile listed for a replay get their work items written out: the replays read items
         hipLaunchKernelGGL(k_xmat, dim3((unsigned)std::min<uint32_t>(nwin, 512)), dim3(1024), 0, st, (const u32 *)ctx->b_need_win.p,
                            (const u64 *)(d_meta + 13), nwin, d_wo, n_runs, (const u32 *)ctx->b_first.p, (const u32 *)ctx->b_xcnt.p,
@@ -850,8 +872,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         hipLaunchKernelGGL(k_exact, dim3(ctx->last_listed == ~0u ? EXW_BLOCKS / 4 : blocks), dim3(EXW_THREADS), 0, st, E);
     }
     timer_end(ctx);
+    };
 
     u64 *d_winout = (u64 *)ctx->b_winout.p;
+    auto launch_emit = [&]() {
     timer_begin(ctx, "emit");
     hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
                        d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
@@ -861,6 +885,16 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
                        (const u64 *)d_winout, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc,
                        (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
     timer_end(ctx);
+    };
+    // The replays' five launches cost 23 us even when k_tile flagged nothing for them (4.5 us apiece: rocprofv3, round 5) --
+    // a tenth of a 5 Mbp job's kernels.  A context whose job before had nothing flagged leaves them out, looks at what THIS
+    // job flagged when its metadata are back, and only then -- anything flagged -- runs them and the emission once more
+    // (a second synchronisation: ~35 us; the polished bytes are the same either way -- a flagged position emits nothing
+    // until its replay has decided it).  Not with per-position records (they are the replays' to write).
+    static const bool env_no_spec = getenv("PP_SPECULATE") && atoi(getenv("PP_SPECULATE")) == 0;  // tuning / tests
+    const bool speculate = ctx->nothing_flagged_last && !ctx->debug && !env_no_spec;
+    if (!speculate) launch_exact();
+    launch_emit();
     PP_HIPCHK(ctx, hipGetLastError());
 
     // the job's one read-back, into pinned memory (a copy into pageable memory goes through the runtime's staging buffer
@@ -874,6 +908,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     }
     PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
     PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    if (speculate && ctx->h_meta[0] == ~0ull && (((const uint32_t *)&ctx->h_meta[1])[0] || ((const uint32_t *)&ctx->h_meta[1])[2])) {
+        launch_exact();  // something was flagged after all
+        launch_emit();
+        PP_HIPCHK(ctx, hipGetLastError());
+        PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
+        PP_HIPCHK(ctx, hipStreamSynchronize(st));
+    }
     meta.assign(ctx->h_meta, ctx->h_meta + meta_words);
     *n_entries_out = (uint32_t)meta[3];
     if (getenv("PP_TRACE_FLAGGED")) {  // tuning: the positions this pass listed for k_exact
@@ -970,6 +1011,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     const uint32_t *cnt = (const uint32_t *)&meta[1];
     ctx->total_out = meta[5];
     ctx->last_listed = cnt[0];
+    ctx->nothing_flagged_last = cnt[0] == 0 && cnt[2] == 0;
     ctx->n_multi = cnt[1];
     ctx->n_keys = meta[8];
     // per-contig results: the run's contigs are the job's, or (compact run) the ones this context owns -- the others
@@ -1182,6 +1224,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_code, &ctx->b_winlen, &ctx->b_winout, &ctx->b_flag_pos, &ctx->b_flag_cov,
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_vote_tab, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_win_heavy, &ctx->b_hslab, &ctx->b_sub_bases,
+                     &ctx->b_runs, &ctx->b_first, &ctx->b_xcnt, &ctx->b_xent, &ctx->b_need_win, &ctx->b_win_lo, &ctx->b_win_hi, &ctx->b_later,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
                      &ctx->f_insert};

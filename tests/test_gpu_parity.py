@@ -1714,3 +1714,20 @@ def test_device_front_ends_hand_non_ascii_text_to_the_host_parsers(orc, tmp_path
             assert (r.returncode == 0) == ok, (name, who, r.stderr[-500:])
             outs[who] = (o1.read_bytes(), o2.read_bytes()) if ok else r.returncode
         assert outs["host"] == outs["oracle"] == outs["device"], name
+
+
+def test_replays_are_left_out_after_a_clean_job_and_come_back_when_needed(ctx, orc):
+    """A context whose job before flagged nothing for the exact replays (k_exact2 / k_exact) leaves their launches out, and
+    runs them -- and the emission once more -- when this job's metadata say something was flagged after all
+    (run_pipeline, round 5).  A clean job, then one with order-dependent depths and insertions, then a clean one again:
+    every one of them bit-identical to the oracle, whichever way it went."""
+    clean = synth.fast_records(seed=71, contig_lens=(30_000,), coverage=40, indel_read_frac=0.0, n_rate=0.0)
+    odd = synth.fast_records(seed=72, contig_lens=(30_000, 2_500), coverage=50, k_choices=(1, 2, 3, 5, 6, 7),
+                             k_probs=(0.5, 0.1, 0.1, 0.1, 0.1, 0.1), indel_read_frac=0.2, n_rate=0.01)
+    import polypolish_amd as pp
+    for contig_off, bases, recs in (clean, clean, odd, odd, clean, odd):
+        want = orc.polish_records(contig_off, bases, recs)
+        got = ctx.polish_records(contig_off, bases, recs)
+        assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"])
+        m = _polish_device_batch(ctx, pp, contig_off, bases, recs, True, wo=True)   # ... and over the direct path
+        assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
