@@ -186,6 +186,69 @@ def live_traffic(argv_tail, kernel):
             "write_raw_bytes": int(got["WRITE_SIZE"])}
 
 
+def filter_roofline(ctx, pp, device, n_pairs, G, read_len=150, reps=5):
+    """The filter kernels (seam A: k_ref_end, k_samples, k_pairs -- src/alignment.rs:138-149, src/filter.rs:155-167,189-218,
+    352-377) on a resident input of BASELINE.json configs[1]'s shape: n_pairs read pairs, one alignment per mate and file
+    (2 n_pairs alignments), forward/reverse at ~350 bp.  SURVEY 8d's algorithmic bytes: 17 B per alignment (ref_id, ref_start,
+    ref_end, flags in, one pass byte out) + 8 B per pair (the two group offsets).  Kernel times: HIP events on the library's
+    stream (pp_filter_kernel_times), mean of `reps` runs; the copies of the verdicts to the host are outside them."""
+    import ctypes as C
+    g = torch.Generator(device=device)
+    g.manual_seed(4711)
+    n = n_pairs
+    i32, i64 = torch.int32, torch.int64
+    keep = []
+
+    def ffile(start, flags):
+        t = dict(ref_id=torch.zeros(n, dtype=i32, device=device), ref_start=start.to(i32), flags=flags.to(i32),
+                 cig_off=torch.arange(n, dtype=i64, device=device), n_cig=torch.ones(n, dtype=i32, device=device),
+                 cigar=torch.full((n,), (read_len << 4) | 0, dtype=i32, device=device), read=torch.arange(n, dtype=i32, device=device),
+                 grp_off=torch.arange(n + 1, dtype=i32, device=device), grp_idx=torch.arange(n, dtype=i32, device=device))
+        keep.append(t)
+        return pp.FilterFile(n, t["ref_id"].data_ptr(), t["ref_start"].data_ptr(), t["flags"].data_ptr(), t["cig_off"].data_ptr(),
+                             t["n_cig"].data_ptr(), t["cigar"].data_ptr(), n, t["read"].data_ptr(), t["grp_off"].data_ptr(),
+                             t["grp_idx"].data_ptr(), None)
+    s1 = torch.randint(0, max(G - 1000, 1), (n,), device=device, generator=g)
+    ins = torch.clamp((350 + 35 * torch.randn(n, device=device, generator=g)).round().long(), 160, 700)
+    s2 = s1 + ins - read_len
+    fwd_first = torch.rand(n, device=device, generator=g) < 0.5           # which mate is the forward one
+    f1 = ffile(torch.where(fwd_first, s1, s2), torch.where(fwd_first, 0, 16))
+    f2 = ffile(torch.where(fwd_first, s2, s1), torch.where(fwd_first, 16, 0))
+    inp = pp.FilterInput(n, (pp.FilterFile * 2)(f1, f2))
+    orient, insert = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
+    p1, p2 = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    torch.cuda.synchronize()
+    L = pp.lib()
+    ctx.set_profiling(1)
+    tot = {}
+    try:
+        for rep in range(reps + 1):
+            ctx._chk(L.pp_filter_begin(ctx._h, C.byref(inp), pp.MEM_DEVICE))
+            ctx._chk(L.pp_filter_samples(ctx._h, orient.ctypes.data, insert.ctypes.data))
+            lo, hi = int(np.percentile(insert, 0.1)), int(np.percentile(insert, 99.9))
+            ctx._chk(L.pp_filter_pairs(ctx._h, lo, hi, 0, p1.ctypes.data, p2.ctypes.data))
+            kt = pp.KernelTimes()
+            L.pp_filter_kernel_times(ctx._h, C.byref(kt))
+            if rep:  # (the first run allocates)
+                for k, v in kt.as_dict()["ms"].items():
+                    tot[k] = tot.get(k, 0.0) + v
+    finally:
+        ctx.set_profiling(0)
+    ms = {k: v / reps for k, v in tot.items()}
+    total_ms = sum(ms.values())
+    b_alg = 17 * 2 * n + 8 * n
+    # what the three kernels read and write as the ABI hands the input over (include/polypolish_hip.h, pp_filter_file: CIGAR
+    # runs instead of ref_end, a read number and a group index per alignment): k_ref_end 20 B in + 8 out per alignment,
+    # k_samples 16 B of offsets + 2 x (4 + 4 + 4 + 4 + 8) + 5 out per read, k_pairs 4 + 8 + 8 in + 1 out per alignment
+    b_abi = 2 * n * (28 + 21) + n * (16 + 48 + 5)
+    return {"bound": "hbm", "kernels": "k_ref_end (x2) + k_samples + k_pairs (x2)", "kernel_ms": {k: round(v, 4) for k, v in sorted(ms.items())},
+            "total_ms": round(total_ms, 4), "algorithmic_bytes": b_alg, "achieved": round(b_alg / (total_ms * 1e-3) / 1e9, 1) if total_ms else 0.0,
+            "peak": 8000.0, "unit": "GB/s", "frac": round(b_alg / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,
+            "bytes_the_abi_makes_them_move": b_abi, "frac_of_peak_on_those": round(b_abi / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,
+            "workload": f"{n} read pairs, one {read_len}M alignment per mate and file ({2 * n} alignments), all pairs unique: configs[1]'s shape",
+            "all_pass": bool(p1.all() and p2.all()), "orientation_fr": int((orient == 0).sum())}
+
+
 def _file_sha(path):
     h = hashlib.sha256()
     with open(path, "rb") as fh:
@@ -583,6 +646,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timed_split = dict(split_s)   # the timed steps' compute / gather halves on this rank
+    # the kernel the timed steps ran: k_tile_direct when the job took its bulk straight from the window-order mirror (round 5)
+    direct_path = ctx.took_direct_path()
+    dom_kernel = None if dom_name is None else ("k_" + dom_name + ("_direct" if direct_path and dom_name == "tile" else ""))
     dog.disarm()
     if world > 1:
         dog.arm(args.collective_timeout + 60.0, "the untimed steps and the verification of the gathered bytes")
@@ -672,7 +738,7 @@ def main():
             tail += ["--genome", str(args.genome)]
         if args.coverage is not None:
             tail += ["--coverage", str(args.coverage)]
-        lt = live_traffic(tail, "k_" + dom_name)
+        lt = live_traffic(tail, dom_kernel)
         if lt is not None:
             traffic = lt["hbm_bytes"]
             traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command (3 steps "
@@ -680,7 +746,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if traffic is None and default_shape and args.config == 1 and dom_name and os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("kernels", {}).get("k_" + dom_name, {}).get("hbm_bytes")
+            traffic = json.load(f).get("kernels", {}).get(dom_kernel, {}).get("hbm_bytes")
         if traffic is not None:
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 
@@ -767,7 +833,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "hbm_actual": moved(traffic, dom_avg_ms),
-                     "kernel": "k_" + (dom_name or "?"), "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
+                     "kernel": dom_kernel or "?", "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
+                     "path": ("direct: k_prepd + k_prepg (one pass over the window-order mirror: validation, where the windows begin, extras) -> "
+                              "k_tile_direct (a window's bulk straight from the mirror) -- no bucketing pass, no work items for 93 % of the records"
+                              if direct_path else "bucketing: k_prep -> k_scan_cols / k_scan / k_fill (16-byte work items) -> k_tile"),
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},
         "roofline_file_order_seq": second,
         "kernel_ms_per_step": {k: round(v / max(n_break, 1), 4) for k, v in sorted(all_ms.items())},
@@ -812,6 +881,11 @@ def main():
         }
         if got != want["polished"]:
             out["cpu_baseline"]["parity_note"] = "MISMATCH between device and oracle on the sample"
+    if world == 1 and not args.no_second_layout:
+        try:
+            out["roofline_filter"] = filter_roofline(ctx, pp, device, int(sum(lens)) * coverage // (2 * args.read_len), int(sum(lens)))
+        except Exception as e:  # noqa: BLE001 -- (a report, not the metric)
+            out["roofline_filter"] = {"error": str(e)}
     if world == 1 and not args.no_e2e:
         del job
         torch.cuda.empty_cache()

@@ -271,6 +271,10 @@ typedef struct {
 } pp_kernel_times;
 int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel group, 2 only the dominant kernel ("tile") */
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
+/* Which way the last pp_polish_finish of this context went: 1 = the direct path (the window-order mirror and its run table:
+ * pp_aln_batch.wo_run_end), 0 = the bucketing path (no mirror, no run table, a sharded job, or a mirror that turned out not
+ * to be in run order).  The results are the same either way; for reports (bench.py names the kernel it timed). */
+int pp_polish_took_direct_path(const pp_ctx *ctx);
 
 /* ---- multi-GPU: contigs (and windows of a large contig) shard across ranks -----------------------------------------
  * The reference is one thread on one CPU; the partition is SURVEY.md 8(e) / BASELINE.json configs[3], [4].

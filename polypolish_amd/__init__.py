@@ -166,7 +166,7 @@ EXPORTS = [
     "pp_polish_begin", "pp_polish_add", "pp_polish_reserve", "pp_polish_finish", "pp_polish_result_size", "pp_polish_result",
     "pp_polish_result_device", "pp_polish_set_emit", "pp_polish_set_debug", "pp_polish_positions", "pp_polish_debug_extra",
     "pp_debug_extra_free", "pp_ctx_set_profiling",
-    "pp_polish_kernel_times", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
+    "pp_polish_kernel_times", "pp_polish_took_direct_path", "pp_filter_begin", "pp_filter_samples", "pp_filter_pairs",
     "pp_filter_kernel_times", "pp_filter_load", "pp_filter_loaded_input", "pp_filter_write", "pp_filter_loaded_free",
     "pp_filter_load_device", "pp_filter_dev_input", "pp_filter_dev_text", "pp_filter_dev_free", "pp_filter_write_text",
     "pp_assembly_load", "pp_assembly_free", "pp_assembly_n_contigs",
@@ -218,6 +218,7 @@ def lib():
         L.pp_polish_positions.argtypes = [vp, C.POINTER(PositionsOut)]
         L.pp_ctx_set_profiling.argtypes = [vp, C.c_int]
         L.pp_polish_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.pp_polish_took_direct_path.argtypes = [vp]
         L.pp_filter_begin.argtypes = [vp, C.POINTER(FilterInput), C.c_int]
         L.pp_filter_samples.argtypes = [vp, vp, vp]
         L.pp_filter_pairs.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint8, vp, vp]
@@ -793,6 +794,10 @@ class Context:
         st = [dict(polished_len=s.polished_len, changed=s.changed, zero_depth=s.zero_depth, depth_sum=s.depth_sum)
               for s in stats]
         return out[:n].tobytes(), offs, st
+
+    def took_direct_path(self):
+        """True when the last pp_polish_finish took its bulk straight from the window-order mirror (pp_aln_batch.wo_run_end)."""
+        return bool(lib().pp_polish_took_direct_path(self._h))
 
     def kernel_times(self):
         kt = KernelTimes()

@@ -1137,6 +1137,8 @@ extern "C" int pp_ctx_set_profiling(pp_ctx *ctx, int enable) {
     return PP_OK;
 }
 
+extern "C" int pp_polish_took_direct_path(const pp_ctx *ctx) { return ctx && ctx->last_direct ? 1 : 0; }
+
 extern "C" int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out) {
     if (!ctx || !out) return PP_ERR_ARG;
     *out = ctx->last_times;
