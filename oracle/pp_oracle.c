@@ -872,8 +872,24 @@ static int valid_utf8(const char *s, size_t n) {
 /* ------------------------------------------------------------------------ */
 /* misc.rs:38-167 FASTA loader                                               */
 /* ------------------------------------------------------------------------ */
-static int rust_is_whitespace_ascii(char c) {
-    return c == ' ' || (c >= 0x09 && c <= 0x0D);
+/* char::is_whitespace (Unicode White_Space, misc.rs:118-120) at the start of the valid UTF-8 text p[0 .. left): the
+   number of bytes of that character, 0 if the character there is not whitespace.  U+0009-000D, 0020, 0085, 00A0, 1680,
+   2000-200A, 2028, 2029, 202F, 205F, 3000. */
+static size_t rust_whitespace_len(const char *p, size_t left) {
+    const unsigned char c = (unsigned char)p[0];
+    if (c == ' ' || (c >= 0x09 && c <= 0x0D)) return 1;
+    if (c == 0xC2 && left >= 2) {
+        const unsigned char d = (unsigned char)p[1];
+        return d == 0x85 || d == 0xA0 ? 2 : 0;
+    }
+    if (left >= 3) {
+        const unsigned char d = (unsigned char)p[1], e = (unsigned char)p[2];
+        if (c == 0xE1 && d == 0x9A && e == 0x80) return 3;                               /* U+1680 */
+        if (c == 0xE2 && d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) return 3; /* U+2000-200A, 2028, 2029, 202F */
+        if (c == 0xE2 && d == 0x81 && e == 0x9F) return 3;                               /* U+205F */
+        if (c == 0xE3 && d == 0x80 && e == 0x80) return 3;                               /* U+3000 */
+    }
+    return 0;
 }
 
 void orc_fasta_free(orc_fasta *f) {
@@ -966,11 +982,11 @@ static void load_fasta_inner(const char *path, orc_fasta *out) {
                 free(desc);
             }
             /* text[1..].splitn(2, char::is_whitespace), misc.rs:118-120 */
-            size_t i = 1;
-            while (i < n && !rust_is_whitespace_ascii(line[i])) i++;
+            size_t i = 1, wl = 0;
+            while (i < n && !(wl = rust_whitespace_len(line + i, n - i))) i++;
             name = xstrndup(line + 1, i - 1);
             name_len = i - 1;
-            desc = i < n ? xstrndup(line + i + 1, n - i - 1) : xstrndup("", 0);
+            desc = i < n ? xstrndup(line + i + wl, n - i - wl) : xstrndup("", 0);
         } else {
             if (name_len == 0) quit_with_error("\"%s\" is not correctly formatted", path);
             if (seq_len + n + 1 > seq_cap) {

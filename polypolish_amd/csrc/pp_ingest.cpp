@@ -92,7 +92,25 @@ struct LineReader {
     }
 };
 
-inline bool rust_ws(char c) { return c == ' ' || (c >= 0x09 && c <= 0x0D); }
+// char::is_whitespace (Unicode White_Space: what `splitn(2, char::is_whitespace)` splits a FASTA header at, misc.rs:118-120)
+// at the start of the valid UTF-8 text p[0 .. left): the bytes of that character, 0 if it is not whitespace.
+// U+0009-000D, 0020, 0085, 00A0, 1680, 2000-200A, 2028, 2029, 202F, 205F, 3000.
+inline size_t rust_ws_len(const char *p, size_t left) {
+    const unsigned char c = (unsigned char)p[0];
+    if (c == ' ' || (c >= 0x09 && c <= 0x0D)) return 1;
+    if (c == 0xC2 && left >= 2) {
+        const unsigned char d = (unsigned char)p[1];
+        return d == 0x85 || d == 0xA0 ? 2 : 0;
+    }
+    if (left >= 3) {
+        const unsigned char d = (unsigned char)p[1], e = (unsigned char)p[2];
+        if (c == 0xE1 && d == 0x9A && e == 0x80) return 3;
+        if (c == 0xE2 && d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) return 3;
+        if (c == 0xE2 && d == 0x81 && e == 0x9F) return 3;
+        if (c == 0xE3 && d == 0x80 && e == 0x80) return 3;
+    }
+    return 0;
+}
 
 // str::parse::<uN>(): optional '+', ASCII digits, overflow is an error
 bool parse_unsigned(const char *s, size_t n, uint64_t max, uint64_t &out) {
@@ -211,10 +229,10 @@ static void load_fasta(const char *path, pp_assembly &a) {
         if (header && !pph::valid_utf8(line, n)) fail(PP_ERR_QUIT, "unable to load \"%s\"", path);
         if (header) {
             if (have) push();
-            size_t i = 1;
-            while (i < n && !rust_ws(line[i])) i++;
+            size_t i = 1, wl = 0;
+            while (i < n && !(wl = rust_ws_len(line + i, n - i))) i++;
             name.assign(line + 1, i - 1);
-            desc = i < n ? std::string(line + i + 1, n - i - 1) : std::string();
+            desc = i < n ? std::string(line + i + wl, n - i - wl) : std::string();
             have = !name.empty();
         } else {
             if (!have) {

@@ -61,3 +61,31 @@ def test_decided_positions_get_the_exact_thresholds():
                 # (the kernel then votes with both and only replays the position if the two votes differ)
                 assert exact in (t[0], t[1]), (exact, t)
     assert undecided < 0.25 * n_pos   # (b = 10 with hundreds of inexact reads leaves a wide interval; b >= 19 almost none)
+
+
+def win_fx_bits(n_items):  # pp_k_common.h: the unit 2^-b of a window with n_items work items
+    return min(20, 31 - max(int(n_items), 1).bit_length())
+
+
+def test_interval_holds_the_ordered_sum_of_a_deep_window_of_odd_shares():
+    """The systematic case: EVERY read with the same inexact share, 10^5 and more of them on one position --
+    the share's rounding error has one sign and adds up (k = 3: each unit a third too small at b = 14), and the ordered
+    f64 sum drifts on its own.  The kernel's interval, n * 2^-(b+1) + 1e-9 either side of the fixed-point depth with b as
+    it picks it for a window of n items, must still hold the reference's sum, in file order and in any other."""
+    rng = np.random.default_rng(5)
+    for n, k in ((100_000, 3), (250_000, 3), (131_071, 7), (200_000, 6), (1_000_000, 3)):
+        b = win_fx_bits(n)
+        deficit = n * ((1 << b) - share_units(np.int64(k), b))
+        D = ((n << b) - int(deficit)) / float(1 << b)
+        eps = n * (0.5 / (1 << b)) + 1e-9
+        depth = float(np.add.accumulate(np.full(n, 1.0 / k))[-1])   # (sequential f64 additions, as src/pileup.rs:64)
+        assert D - eps <= depth <= D + eps, (n, k, b, D, depth, eps)
+        assert abs(depth - n / k) < 1e-4 < eps   # (the f64 sum's own drift -- 1e-6 at 10^6 reads -- is far inside the interval's half-width)
+    # ... and mixed with exact shares in a random order
+    n = 150_000
+    ks = rng.choice([1, 2, 3, 3, 3, 5], size=n).astype(np.int64)
+    b = win_fx_bits(n)
+    D = ((n << b) - int(((1 << b) - share_units(ks, b)).sum())) / float(1 << b)
+    eps = n * (0.5 / (1 << b)) + 1e-9
+    depth = float(np.add.accumulate(1.0 / ks.astype(np.float64))[-1])
+    assert D - eps <= depth <= D + eps
