@@ -124,6 +124,29 @@ __device__ __noinline__ void prep_general(u64 a, u32 rs, u32 sl, u64 so, const u
     prep_general_t(a, rs, sl, nc, [&](u32 i) -> u32 { return cg[i]; }, [&](u32 i) -> u8 { return s[i]; }, g0, clen, g_out, nk_out, fl_out, status);
 }
 
+// PP_CHECK_WO=1 (opt-in): the window-order mirror against the arrays it mirrors -- every entry names a record of the batch,
+// no record twice (n entries: a permutation then), and carries that record's fields.  The mirror is a hint the kernels
+// TRUST (include/polypolish_hip.h): its producers are the library's own; a caller that builds one itself can have it
+// checked here, at the price of one scattered read of the arrays (a few times k_prep's own time).
+__global__ __launch_bounds__(256) void k_check_wo(u64 n, const pp_wo_rec *__restrict__ wo, const u32 *__restrict__ contig,
+                                                  const u32 *__restrict__ ref_start, const u32 *__restrict__ kk,
+                                                  const u64 *__restrict__ seq_off, const u32 *__restrict__ seq_len,
+                                                  const u64 *__restrict__ cig_off, const u32 *__restrict__ n_cig,
+                                                  const u32 *__restrict__ cigar, u32 *__restrict__ seen, u64 *status) {
+    const u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const pp_wo_rec r = wo[a];
+    const u32 fi = r.file_idx;
+    bool ok = fi < n;
+    if (ok) {
+        ok = (atomicOr(&seen[fi >> 5], 1u << (fi & 31u)) & (1u << (fi & 31u))) == 0;   // (a second entry for the same record)
+        const u32 nc = n_cig[fi];
+        ok = ok && r.contig == contig[fi] && r.ref_start == ref_start[fi] && r.k == kk[fi] && r.seq_off == seq_off[fi] &&
+             r.seq_len == seq_len[fi] && r.op0 == (nc == 1u ? cigar[cig_off[fi]] : (u32)PP_WO_MULTI_RUN);
+    }
+    if (!ok) report(status, a, DE_BAD_MIRROR);
+}
+
 #ifndef PP_PLAIN_ALIGNED
 #define PP_PLAIN_ALIGNED 0
 #endif

@@ -422,7 +422,8 @@ static int map_device_error(pp_ctx *ctx, uint64_t key) {
     case DE_BAD_ENDS: return ctx->fail(PP_ERR_ARG, "alignment record %llu does not start and end with M/= (gate of alignment.rs:155-159 not applied)", idx);
     case DE_NON_ASCII: return ctx->fail(PP_ERR_LIMIT, "assembly position %llu holds a non-ASCII byte", idx);
     case DE_TOO_DEEP: return ctx->fail(PP_ERR_LIMIT, "window %llu has more than 2^21 overlapping alignments", idx);
-    case DE_BAD_MIRROR: return ctx->fail(PP_ERR_ARG, "entry %llu of the window-order mirror (pp_aln_batch.wo) names a record the batch does not have", idx);
+    case DE_BAD_MIRROR: return ctx->fail(PP_ERR_ARG, "entry %llu of the window-order mirror (pp_aln_batch.wo) names a record the batch does not have, "
+                                                     "or (PP_CHECK_WO=1) one that another entry names too, or does not carry that record's fields", idx);
     case DE_OVERFLOW: return ctx->fail(PP_ERR_LIMIT, "32-bit work-item count or reference span overflow (record/window %llu)", idx);
     default: return ctx->fail(PP_ERR_HIP, "internal device inconsistency %u at %llu", code, idx);
     }
@@ -658,6 +659,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
             d_bases = (const u8 *)ctx->b_sub_bases.p;
         }
         // (the windows nobody works on emit nothing and have nothing flagged: k_meta_init zeroes win_len / win_nflag)
+    }
+    // PP_CHECK_WO=1: the mirror checked against the arrays before anything reads the records through it
+    static const bool check_wo = getenv("PP_CHECK_WO") && atoi(getenv("PP_CHECK_WO")) != 0;
+    if (check_wo && B.wo && !env_no_wo && n) {
+        if ((rc = dev_ensure(ctx, ctx->b_aflag, (size_t)((n + 31) / 32) * 4))) return rc;
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_aflag.p, 0, (size_t)((n + 31) / 32) * 4, st));
+        hipLaunchKernelGGL(k_check_wo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.wo, B.contig, B.ref_start, B.k,
+                           (const u64 *)B.seq_off, B.seq_len, (const u64 *)B.cig_off, B.n_cig, B.cigar, (u32 *)ctx->b_aflag.p, d_status);
     }
     // records -> (global start, kept entries, class); with all windows in one LDS range the same pass counts the
     // records of every block per window (two-level path: k_count, per range of windows)

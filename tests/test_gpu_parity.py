@@ -1731,3 +1731,48 @@ def test_replays_are_left_out_after_a_clean_job_and_come_back_when_needed(ctx, o
         assert got["polished"] == want["polished"] and np.array_equal(got["offsets"], want["offsets"])
         m = _polish_device_batch(ctx, pp, contig_off, bases, recs, True, wo=True)   # ... and over the direct path
         assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
+
+
+def test_window_order_mirror_is_checked_on_request(orc, tmp_path):
+    """pp_aln_batch.wo is a hint the kernels trust (its producers are the library's own); PP_CHECK_WO=1 has it checked against
+    the arrays it mirrors before anything reads the records through it: every entry a record of the batch, none twice,
+    every field the record's.  A faithful mirror passes (in run order and shuffled); an entry that names a
+    record twice, one out of range, and one with a wrong field are the caller's error -- on the direct path and on the
+    bucketing path -- and without the check an entry out of range still is."""
+    code = """
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, synth, polypolish_amd as pp
+import test_gpu_parity as tg
+from oracle import orc
+ctx = pp.Context(0)
+o, b, r = synth.fast_records(seed=2, contig_lens=(40_000, 7_000), coverage=40, indel_read_frac=0.2)
+want = orc.polish_records(o, b, r)["polished"]
+real = pp.window_order_mirror
+for order in (True, "shuffled", "no_runs"):
+    assert tg._polish_device_batch(ctx, pp, o, b, r, True, wo=order)["polished"] == want
+def broken(kind):
+    def make(recs, off):
+        w = real(recs, off)
+        if kind == "twice": w["file_idx"][7] = w["file_idx"][8]
+        if kind == "range": w["file_idx"][5] = len(w) + 3
+        if kind == "field": w["ref_start"][11] += 1
+        if kind == "k": w["k"][3] += 1
+        return w
+    return make
+checked = os.environ.get("PP_CHECK_WO") == "1"
+for kind in ("twice", "range", "field", "k"):
+    pp.window_order_mirror = broken(kind)
+    for order in (True, "no_runs"):
+        try:
+            tg._polish_device_batch(ctx, pp, o, b, r, True, wo=order)
+            failed = None
+        except pp.PolypolishError as e:
+            failed = e
+        if checked or kind == "range":
+            assert failed is not None and failed.code == pp.ERR_ARG and "window-order mirror" in failed.msg, (kind, order, failed)
+print("mirror check ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for env in ({"PP_CHECK_WO": "1"}, {}):
+        r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0 and b"mirror check ok" in r.stdout, (env, r.stderr.decode()[-2000:])
