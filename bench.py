@@ -187,7 +187,8 @@ def live_traffic(argv_tail, kernel):
 
 
 def filter_roofline(ctx, pp, device, n_pairs, G, read_len=150, reps=5):
-    """The filter kernels (seam A: k_ref_end, k_samples, k_pairs -- src/alignment.rs:138-149, src/filter.rs:155-167,189-218,
+    """The filter kernels (seam A: k_filter_reads -- one pass over the reads: ends from the runs, samples, verdicts -- and
+    k_filter_listed for the reads whose verdicts need the thresholds; src/alignment.rs:138-149, src/filter.rs:155-167,189-218,
     352-377) on a resident input of BASELINE.json configs[1]'s shape: n_pairs read pairs, one alignment per mate and file
     (2 n_pairs alignments), forward/reverse at ~350 bp.  SURVEY 8d's algorithmic bytes: 17 B per alignment (ref_id, ref_start,
     ref_end, flags in, one pass byte out) + 8 B per pair (the two group offsets).  Kernel times: HIP events on the library's
@@ -237,11 +238,11 @@ def filter_roofline(ctx, pp, device, n_pairs, G, read_len=150, reps=5):
     ms = {k: v / reps for k, v in tot.items()}
     total_ms = sum(ms.values())
     b_alg = 17 * 2 * n + 8 * n
-    # what the three kernels read and write as the ABI hands the input over (include/polypolish_hip.h, pp_filter_file: CIGAR
-    # runs instead of ref_end, a read number and a group index per alignment): k_ref_end 20 B in + 8 out per alignment,
-    # k_samples 16 B of offsets + 2 x (4 + 4 + 4 + 4 + 8) + 5 out per read, k_pairs 4 + 8 + 8 in + 1 out per alignment
-    b_abi = 2 * n * (28 + 21) + n * (16 + 48 + 5)
-    return {"bound": "hbm", "kernels": "k_ref_end (x2) + k_samples + k_pairs (x2)", "kernel_ms": {k: round(v, 4) for k, v in sorted(ms.items())},
+    # what the pass reads and writes as the ABI hands the input over (include/polypolish_hip.h, pp_filter_file: CIGAR runs
+    # instead of ref_end, a group index per alignment): per read 8 B of group offsets, per alignment grp_idx, ref_id, ref_start,
+    # flags, n_cig and one run (4 B each) and cig_off (8 B) in, one verdict byte out; the sample (1 + 4 B) out per read
+    b_abi = n * 8 + 2 * n * (6 * 4 + 8 + 1) + n * 5
+    return {"bound": "hbm", "kernels": "k_filter_reads ('samples') + k_filter_listed ('pairs': the reads with several alignments; none here)", "kernel_ms": {k: round(v, 4) for k, v in sorted(ms.items())},
             "total_ms": round(total_ms, 4), "algorithmic_bytes": b_alg, "achieved": round(b_alg / (total_ms * 1e-3) / 1e9, 1) if total_ms else 0.0,
             "peak": 8000.0, "unit": "GB/s", "frac": round(b_alg / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,
             "bytes_the_abi_makes_them_move": b_abi, "frac_of_peak_on_those": round(b_abi / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,

@@ -1,7 +1,8 @@
 // pp_filter.hip -- gfx950 kernels of the paired-read insert-size filter (seam A of
 // include/polypolish_hip.h): ref_end from the CIGAR runs, orientation + insert size of the
 // uniquely-aligned pairs, and the per-alignment pass/fail rule.  Pure integer work, one lane per
-// alignment (or per read), structure-of-arrays loads; HBM-bound at ~17 B per alignment.
+// read, structure-of-arrays loads; HBM-bound.  Since round 5 ONE pass over the reads (k_filter_reads) and a pass over
+// the few reads whose verdicts need the thresholds (k_filter_listed).
 #include "pp_internal.h"
 
 #include <cstring>
@@ -11,24 +12,6 @@ namespace pp {
 typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
-
-// Alignment::get_ref_end, alignment.rs:138-149: ref_start + sum of M, D, N, =, X run lengths
-__global__ __launch_bounds__(256) void k_ref_end(u64 n, const u32 *__restrict__ ref_start,
-                                                 const u64 *__restrict__ cig_off,
-                                                 const u32 *__restrict__ n_cig,
-                                                 const u32 *__restrict__ cigar,
-                                                 u64 *__restrict__ ref_end) {
-    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
-    u64 end = ref_start[a];
-    const u32 *cg = cigar + cig_off[a];
-    for (u32 r = 0; r < n_cig[a]; r++) {
-        u32 op = cg[r], o = op & 15u;
-        if (o == PP_OP_M || o == PP_OP_D || o == PP_OP_N || o == PP_OP_EQ || o == PP_OP_X) end += op >> 4;
-        else if (o == (u32)PP_OP_UNPARSEABLE) { end = PP_REF_END_UNPARSEABLE; break; }
-    }
-    ref_end[a] = end;
-}
 
 // get_orientation, filter.rs:189-209 -> 0 fr, 1 rf, 2 ff, 3 rr.  Argument order matters.
 __device__ __forceinline__ u32 orientation_of(u32 flags1, u64 start1, u64 end1, u32 flags2,
@@ -51,58 +34,99 @@ __device__ __forceinline__ u32 insert_of(u64 s1, u64 e1, u64 s2, u64 e2) {
 
 struct FileDev {
     const u32 *ref_id, *ref_start, *flags, *grp_off, *grp_idx, *read;
-    const u64 *ref_end;
+    const u64 *ref_end;   // precomputed (the device loader), or NULL: from the runs below
+    const u64 *cig_off;
+    const u32 *n_cig, *cigar;
     u64 n_aln;
 };
 
-// sampling loop of get_insert_size_thresholds, filter.rs:155-167: one lane per read
-// `poisoned`: set when an end is needed that the reference could not have parsed (PP_REF_END_UNPARSEABLE)
-__global__ __launch_bounds__(256) void k_samples(u32 n_reads, FileDev f1, FileDev f2,
-                                                 u8 *__restrict__ orient, u32 *__restrict__ insert,
-                                                 u32 *__restrict__ poisoned) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+// Alignment::get_ref_end, alignment.rs:138-149: ref_start + sum of M, D, N, =, X run lengths -- where it is needed, from
+// the runs (rounds 1-4 had a kernel of its own write it to memory for the other two to read back: 28 bytes per alignment
+// in, 8 out, 8 in again)
+__device__ __forceinline__ u64 ref_end_of(const FileDev &F, u32 a, u64 start) {
+    if (F.ref_end) return F.ref_end[a];
+    u64 end = start;
+    const u32 *cg = F.cigar + F.cig_off[a];
+    const u32 nr = F.n_cig[a];
+    for (u32 r = 0; r < nr; r++) {
+        const u32 op = cg[r], o = op & 15u;
+        if (o == PP_OP_M || o == PP_OP_D || o == PP_OP_N || o == PP_OP_EQ || o == PP_OP_X) end += op >> 4;
+        else if (o == (u32)PP_OP_UNPARSEABLE) return PP_REF_END_UNPARSEABLE;
+    }
+    return end;
+}
+
+// alignment_pass_qc, filter.rs:352-377, for alignment a of `self` (n_this of its read there), mates [p0, p1) in `other`
+__device__ __forceinline__ u8 pass_qc(const FileDev &self, u32 a, u32 n_this, const FileDev &other, u32 p0, u32 p1, u32 low, u32 high,
+                                      u32 correct, u32 *poisoned) {
+    if (p1 == p0 || n_this == 1u) return 1;
+    const u32 fl = self.flags[a], ref = self.ref_id[a];
+    const u64 s = self.ref_start[a], e = ref_end_of(self, a, s);
+    for (u32 j = p0; j < p1; j++) {
+        const u32 b = other.grp_idx[j];
+        const u64 s2 = other.ref_start[b], e2 = ref_end_of(other, b, s2);
+        // get_insert_size comes first in the loop and parses both ends (filter.rs:367-368); a mate that is never
+        // reached -- an earlier one made a good pair -- is never parsed
+        if (e == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
+        const u32 ins = insert_of(s, e, s2, e2);
+        if (ref == other.ref_id[b] && low <= ins && ins <= high && orientation_of(fl, s, e, other.flags[b], s2, e2) == correct) return 1;
+    }
+    return 0;
+}
+
+// ONE pass over the reads (round 5; rounds 1-4: k_ref_end, k_samples and k_pairs -- three passes, 557 MB for the 140 MB
+// SURVEY 8d prices).  One lane per read: the sampling loop of get_insert_size_thresholds (filter.rs:155-167) for a read
+// with one alignment in each file, both ends out of the runs in registers; and the verdict of alignment_pass_qc for every
+// alignment that needs no thresholds for it -- its read has one alignment in this file, or none in the other: all of them
+// in a job without multi-mapped reads.  The reads whose verdicts need the thresholds (several alignments here, at least one
+// there) are only listed, for k_filter_listed.  `poisoned`: an end is needed that the reference could not have parsed.
+__global__ __launch_bounds__(256) void k_filter_reads(u32 n_reads, FileDev f1, FileDev f2, u8 *__restrict__ orient,
+                                                      u32 *__restrict__ insert, u8 *__restrict__ pass1, u8 *__restrict__ pass2,
+                                                      u32 *__restrict__ list, u32 *__restrict__ n_list, u32 *__restrict__ poisoned) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
+    const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
+    const u32 n1 = g1e - g1, n2 = g2e - g2;
     u8 o = 255;
     u32 ins = 0;
-    if (f1.grp_off[r + 1] - f1.grp_off[r] == 1u && f2.grp_off[r + 1] - f2.grp_off[r] == 1u) {
-        const u32 a = f1.grp_idx[f1.grp_off[r]], b = f2.grp_idx[f2.grp_off[r]];
+    if (n1 == 1u && n2 == 1u) {
+        const u32 a = f1.grp_idx[g1], b = f2.grp_idx[g2];
+        pass1[a] = 1;
+        pass2[b] = 1;
         if (f1.ref_id[a] == f2.ref_id[b]) {
-            if (f1.ref_end[a] == PP_REF_END_UNPARSEABLE || f2.ref_end[b] == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
-            o = (u8)orientation_of(f1.flags[a], f1.ref_start[a], f1.ref_end[a], f2.flags[b], f2.ref_start[b], f2.ref_end[b]);
-            ins = insert_of(f1.ref_start[a], f1.ref_end[a], f2.ref_start[b], f2.ref_end[b]);
+            const u64 s1 = f1.ref_start[a], s2 = f2.ref_start[b];
+            const u64 e1 = ref_end_of(f1, a, s1), e2 = ref_end_of(f2, b, s2);
+            if (e1 == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
+            o = (u8)orientation_of(f1.flags[a], s1, e1, f2.flags[b], s2, e2);
+            ins = insert_of(s1, e1, s2, e2);
         }
+    } else if ((n1 > 1u && n2 > 0u) || (n2 > 1u && n1 > 0u)) {
+        list[atomicAdd(n_list, 1u)] = r;
+    } else {  // (one alignment here and none there, several here and none there, none at all: everything passes)
+        for (u32 j = g1; j < g1e; j++) pass1[f1.grp_idx[j]] = 1;
+        for (u32 j = g2; j < g2e; j++) pass2[f2.grp_idx[j]] = 1;
     }
     orient[r] = o;
     insert[r] = ins;
 }
 
-// alignment_pass_qc, filter.rs:352-377: one lane per alignment of `self`, mates in `other`
-__global__ __launch_bounds__(256) void k_pairs(FileDev self, FileDev other, u32 low, u32 high,
-                                               u32 correct, u8 *__restrict__ pass, u32 *__restrict__ poisoned) {
-    u64 a = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= self.n_aln) return;
-    const u32 r = self.read[a];
-    const u32 n_this = self.grp_off[r + 1] - self.grp_off[r];
-    const u32 p0 = other.grp_off[r], p1 = other.grp_off[r + 1];
-    u8 ok = 0;
-    if (p1 == p0 || n_this == 1u) {
-        ok = 1;
-    } else {
-        const u32 fl = self.flags[a], ref = self.ref_id[a];
-        const u64 s = self.ref_start[a], e = self.ref_end[a];
-        for (u32 j = p0; j < p1 && !ok; j++) {
-            const u32 b = other.grp_idx[j];
-            const u64 s2 = other.ref_start[b], e2 = other.ref_end[b];
-            // get_insert_size comes first in the loop and parses both ends (filter.rs:367-368); a mate that is never
-            // reached -- an earlier one made a good pair -- is never parsed
-            if (e == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
-            const u32 ins = insert_of(s, e, s2, e2);
-            if (ref == other.ref_id[b] && low <= ins && ins <= high &&
-                orientation_of(fl, s, e, other.flags[b], s2, e2) == correct)
-                ok = 1;
+// the listed reads: alignment_pass_qc with the thresholds, one lane per read, every alignment of it in either file
+__global__ __launch_bounds__(256) void k_filter_listed(const u32 *__restrict__ list, const u32 *__restrict__ n_list, FileDev f1, FileDev f2,
+                                                       u32 low, u32 high, u32 correct, u8 *__restrict__ pass1, u8 *__restrict__ pass2,
+                                                       u32 *__restrict__ poisoned) {
+    const u32 n = *n_list;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u32 r = list[i];
+        const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
+        for (u32 j = g1; j < g1e; j++) {
+            const u32 a = f1.grp_idx[j];
+            pass1[a] = pass_qc(f1, a, g1e - g1, f2, g2, g2e, low, high, correct, poisoned);
+        }
+        for (u32 j = g2; j < g2e; j++) {
+            const u32 a = f2.grp_idx[j];
+            pass2[a] = pass_qc(f2, a, g2e - g2, f1, g1, g1e, low, high, correct, poisoned);
         }
     }
-    pass[a] = ok;
 }
 
 }  // namespace pp
@@ -125,7 +149,8 @@ static FileDev file_dev(const pp_ctx *ctx, int f) {
     const pp_filter_file &d = ctx->fdev.file[f];
     FileDev r;
     r.ref_id = d.ref_id; r.ref_start = d.ref_start; r.flags = d.flags; r.grp_off = d.grp_off;
-    r.grp_idx = d.grp_idx; r.read = d.read; r.ref_end = (const u64 *)ctx->f_refend_ptr[f]; r.n_aln = d.n_aln;
+    r.grp_idx = d.grp_idx; r.read = d.read; r.ref_end = (const u64 *)ctx->f_refend_ptr[f];
+    r.cig_off = (const u64 *)d.cig_off; r.n_cig = d.n_cig; r.cigar = d.cigar; r.n_aln = d.n_aln;
     return r;
 }
 
@@ -136,6 +161,8 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     timers_release(ctx);
     ctx->fdev = *in;
+    ctx->filter_reads_done = false;
+    ctx->filter_n_listed = -1;
     for (int f = 0; f < 2; f++) {
         const pp_filter_file &s = in->file[f];
         pp_filter_file &d = ctx->fdev.file[f];
@@ -160,25 +187,16 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
         UPF(7, grp_idx, uint32_t, n)
         UPF(8, grp_off, uint32_t, (size_t)in->n_reads + 1)
 #undef UPF
-        if (s.ref_end) {  // precomputed (the device loader): adopt or upload, no k_ref_end
+        ctx->f_refend_ptr[f] = nullptr;  // (the ends are worked out from the runs where they are needed: no pass of its own since round 5)
+        if (s.ref_end) {  // precomputed (the device loader): adopt or upload
             rc = up(ctx, ctx->f_refend[f], s.ref_end, n * 8, mem, &p);
             if (rc) return rc;
             ctx->f_refend_ptr[f] = (const uint64_t *)p;
-            continue;
-        }
-        rc = dev_ensure(ctx, ctx->f_refend[f], n * 8);
-        if (rc) return rc;
-        ctx->f_refend_ptr[f] = (const uint64_t *)ctx->f_refend[f].p;
-        if (n) {
-            timer_begin(ctx, "ref_end");
-            hipLaunchKernelGGL(k_ref_end, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (u64)n,
-                               d.ref_start, (const u64 *)d.cig_off, d.n_cig, d.cigar, (u64 *)ctx->f_refend[f].p);
-            timer_end(ctx);
         }
     }
-    int rcf = dev_ensure(ctx, ctx->f_poisoned, 4);
+    int rcf = dev_ensure(ctx, ctx->f_poisoned, 8);  // [0] poisoned, [1] number of listed reads
     if (rcf) return rcf;
-    PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_poisoned.p, 0, 4, ctx->stream));
+    PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_poisoned.p, 0, 8, ctx->stream));
     PP_HIPCHK(ctx, hipGetLastError());
     ctx->filter_open = true;
     return PP_OK;
@@ -186,10 +204,37 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
 
 // the reference's unwrap() on a run length that does not fit usize (alignment.rs:141)
 static int check_poisoned(pp_ctx *ctx) {
-    uint32_t flag = 0;
-    PP_HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->f_poisoned.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t w[2] = {0, 0};  // [1]: the number of listed reads (final once k_filter_reads has run)
+    PP_HIPCHK(ctx, hipMemcpyAsync(w, ctx->f_poisoned.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t flag = w[0];
+    if (ctx->filter_reads_done) ctx->filter_n_listed = (int64_t)w[1];
     if (flag) return ctx->fail(PP_ERR_PANIC, "a CIGAR run length that does not fit 64 bits belongs to an alignment whose end a pair comparison needs");
+    return PP_OK;
+}
+
+// the pass over the reads: samples, the verdicts that need no thresholds, the list of the reads whose verdicts do
+static int filter_reads(pp_ctx *ctx) {
+    const uint32_t n = ctx->fdev.n_reads;
+    int rc;
+    if ((rc = dev_ensure(ctx, ctx->f_orient, n))) return rc;
+    if ((rc = dev_ensure(ctx, ctx->f_insert, (size_t)n * 4))) return rc;
+    if ((rc = dev_ensure(ctx, ctx->f_list, (size_t)n * 4))) return rc;
+    for (int f = 0; f < 2; f++) {
+        const uint64_t na = ctx->fdev.file[f].n_aln;
+        if ((rc = dev_ensure(ctx, ctx->f_pass[f], na))) return rc;
+        // (an alignment that is in no read's group -- the input's contract has none -- passes, as an alignment without mates does)
+        if (na) PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_pass[f].p, 1, na, ctx->stream));
+    }
+    if (n) {
+        timer_begin(ctx, "samples");
+        hipLaunchKernelGGL(k_filter_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0), file_dev(ctx, 1),
+                           (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u8 *)ctx->f_pass[0].p, (u8 *)ctx->f_pass[1].p,
+                           (u32 *)ctx->f_list.p, (u32 *)ctx->f_poisoned.p + 1, (u32 *)ctx->f_poisoned.p);
+        timer_end(ctx);
+        PP_HIPCHK(ctx, hipGetLastError());
+    }
+    ctx->filter_reads_done = true;
     return PP_OK;
 }
 
@@ -198,15 +243,9 @@ extern "C" int pp_filter_samples(pp_ctx *ctx, uint8_t *orient, uint32_t *insert)
     if (!ctx->filter_open) return ctx->fail(PP_ERR_ARG, "pp_filter_samples without pp_filter_begin");
     if (!orient || !insert) return ctx->fail(PP_ERR_ARG, "pp_filter_samples: null output");
     const uint32_t n = ctx->fdev.n_reads;
-    int rc;
-    if ((rc = dev_ensure(ctx, ctx->f_orient, n))) return rc;
-    if ((rc = dev_ensure(ctx, ctx->f_insert, (size_t)n * 4))) return rc;
+    if (!ctx->filter_reads_done)
+        if (int rc = filter_reads(ctx)) return rc;
     if (n) {
-        timer_begin(ctx, "samples");
-        hipLaunchKernelGGL(k_samples, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0),
-                           file_dev(ctx, 1), (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u32 *)ctx->f_poisoned.p);
-        timer_end(ctx);
-        PP_HIPCHK(ctx, hipGetLastError());
         PP_HIPCHK(ctx, hipMemcpyAsync(orient, ctx->f_orient.p, n, hipMemcpyDeviceToHost, ctx->stream));
         PP_HIPCHK(ctx, hipMemcpyAsync(insert, ctx->f_insert.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -218,19 +257,21 @@ extern "C" int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t
     if (!ctx) return PP_ERR_ARG;
     if (!ctx->filter_open) return ctx->fail(PP_ERR_ARG, "pp_filter_pairs without pp_filter_begin");
     uint8_t *outs[2] = {pass1, pass2};
-    DevBuf *pb[2] = {&ctx->f_pass[0], &ctx->f_pass[1]};
-    for (int f = 0; f < 2; f++) {
-        const uint64_t n = ctx->fdev.file[f].n_aln;
-        if (n && !outs[f]) return ctx->fail(PP_ERR_ARG, "pp_filter_pairs: null output");
-        int rc = dev_ensure(ctx, *pb[f], n);
-        if (rc) return rc;
-        if (!n) continue;
+    for (int f = 0; f < 2; f++)
+        if (ctx->fdev.file[f].n_aln && !outs[f]) return ctx->fail(PP_ERR_ARG, "pp_filter_pairs: null output");
+    if (!ctx->filter_reads_done)  // (pairs without samples: the pass over the reads has not run yet)
+        if (int rc = filter_reads(ctx)) return rc;
+    if (ctx->fdev.n_reads && ctx->filter_n_listed != 0) {  // (0: pp_filter_samples read the count back -- a job without multi-mapped reads)
         timer_begin(ctx, "pairs");
-        hipLaunchKernelGGL(k_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, file_dev(ctx, f),
-                           file_dev(ctx, 1 - f), low, high, (u32)orientation, (u8 *)pb[f]->p, (u32 *)ctx->f_poisoned.p);
+        hipLaunchKernelGGL(k_filter_listed, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)ctx->f_list.p, (const u32 *)ctx->f_poisoned.p + 1,
+                           file_dev(ctx, 0), file_dev(ctx, 1), low, high, (u32)orientation, (u8 *)ctx->f_pass[0].p, (u8 *)ctx->f_pass[1].p,
+                           (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
-        PP_HIPCHK(ctx, hipMemcpyAsync(outs[f], pb[f]->p, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int f = 0; f < 2; f++) {
+        const uint64_t n = ctx->fdev.file[f].n_aln;
+        if (n) PP_HIPCHK(ctx, hipMemcpyAsync(outs[f], ctx->f_pass[f].p, n, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (int rcp = check_poisoned(ctx)) return rcp;
     if (ctx->profiling) timers_collect(ctx, &ctx->last_times);

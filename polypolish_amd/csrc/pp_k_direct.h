@@ -360,6 +360,7 @@ __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
     __shared__ uint4 st_item[XSTAGE];
     __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
     __shared__ u64 s_ctg[CTG_LDS + 1];
+    PP_STAMP(1, 0);
     if (*P.status != ~0ull) return;
     const u64 total = min(*P.g_nlater, P.cap_later);
     const u64 per = (total + gridDim.x - 1) / gridDim.x;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
     XSink X{st_item, st_key, l_cnt, l_base, l_nb, &n_st, XSTAGE, 0u, P.xcap, P.x_cnt, P.x_nb, P.xent, P.x_need, P.status};
     X.clear();
     __syncthreads();
+    PP_STAMP(1, 1);
     X.wbase = s_wbase;
     auto ctg = [&](u32 i) -> u64 { return ctg_lds ? s_ctg[i] : P.contig_off[i]; };
     for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
@@ -386,7 +388,11 @@ __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
         r.seq_off = (u64)qb.x | ((u64)qb.y << 32); r.op0 = qb.z; r.file_idx = qb.w;
         if (!(qa.x == NOIDX && qb.w == NOIDX)) general_record(r, P, ctg, X);
     }
+    PP_STAMP(1, 2);
+    __syncthreads();
+    PP_STAMP(1, 3);
     X.flush();
+    PP_STAMP(1, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

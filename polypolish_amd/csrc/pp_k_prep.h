@@ -10,7 +10,7 @@ namespace pp {
 __device__ u64 *g_prep_stamps;
 #define PP_STAMP(kern, slot)                                                                                  \
     do {                                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.y == 0) g_prep_stamps[((u64)(kern) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 16384u) g_prep_stamps[((u64)(kern) * 16384u + blockIdx.x) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define PP_STAMP(kern, slot) do { } while (0)

@@ -676,7 +676,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const pp_wo_rec *d_wo = no_wo ? nullptr : B.wo;
 #ifdef PP_PREP_STAMPS
     static DevBuf b_pstamps;
-    const size_t pstamp_bytes = (size_t)2 * NB * 64;
+    const size_t pstamp_bytes = (size_t)2 * 16384 * 64;  // (8 ticks per workgroup, 16384 workgroups per kernel, two kernels)
     if (int rc2 = dev_ensure(ctx, b_pstamps, pstamp_bytes)) return rc2;
     PP_HIPCHK(ctx, hipMemsetAsync(b_pstamps.p, 0, pstamp_bytes, st));
     {
@@ -1238,7 +1238,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_runs, &ctx->b_first, &ctx->b_xcnt, &ctx->b_xent, &ctx->b_need_win, &ctx->b_win_lo, &ctx->b_win_hi, &ctx->b_later,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
-                     &ctx->f_insert};
+                     &ctx->f_insert, &ctx->f_list};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &b : ctx->b_in) dev_free(b);
     for (auto &b : ctx->b_split) dev_free(b);

@@ -1776,3 +1776,83 @@ print("mirror check ok")
     for env in ({"PP_CHECK_WO": "1"}, {}):
         r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ, **env), timeout=600)
         assert r.returncode == 0 and b"mirror check ok" in r.stdout, (env, r.stderr.decode()[-2000:])
+
+
+def test_filter_seam_verdicts_with_and_without_the_sampling_call(ctx, pp):
+    """Seam A at the ABI: pp_filter_pairs right after pp_filter_begin (the pass over the reads has not run yet) gives the
+    verdicts pp_filter_begin -> pp_filter_samples -> pp_filter_pairs gives, and both are alignment_pass_qc
+    (src/filter.rs:352-377) restated here in plain loops -- reads with 0..3 alignments per file, two contigs, I/D/S runs."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    n_reads = 3000
+
+    def make_file():
+        cnt = rng.choice([0, 1, 1, 1, 2, 3], n_reads)
+        grp_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        n = int(grp_off[-1])
+        perm = rng.permutation(n).astype(np.uint32)          # file order differs from group order
+        read = np.empty(n, np.uint32)
+        read[perm] = np.repeat(np.arange(n_reads, dtype=np.uint32), cnt)
+        runs, off = [], []
+        for _ in range(n):
+            off.append(len(runs))
+            m = int(rng.integers(1, 4))
+            for j in range(m):
+                runs.append((int(rng.integers(1, 120)) << 4) | int(rng.choice([0, 0, 1, 2, 4, 7, 8])))
+        arr = dict(ref_id=rng.integers(0, 2, n).astype(np.uint32), ref_start=rng.integers(0, 5000, n).astype(np.uint32),
+                   flags=rng.choice([0, 16], n).astype(np.uint32), cig_off=np.array(off, np.uint64),
+                   n_cig=np.diff(np.array(off + [len(runs)])).astype(np.uint32), cigar=np.array(runs, np.uint32), read=read,
+                   grp_off=grp_off, grp_idx=perm)
+        f = pp.FilterFile(n, arr["ref_id"].ctypes.data, arr["ref_start"].ctypes.data, arr["flags"].ctypes.data,
+                          arr["cig_off"].ctypes.data, arr["n_cig"].ctypes.data, arr["cigar"].ctypes.data, len(runs),
+                          arr["read"].ctypes.data, arr["grp_off"].ctypes.data, arr["grp_idx"].ctypes.data)
+        end = arr["ref_start"].astype(np.int64).copy()
+        for a in range(n):
+            for op in arr["cigar"][off[a]:off[a] + arr["n_cig"][a]]:
+                if (op & 15) in (0, 2, 3, 7, 8):
+                    end[a] += op >> 4
+        arr["end"] = end
+        return f, arr
+    f1, a1 = make_file()
+    f2, a2 = make_file()
+    inp = pp.FilterInput(n_reads, (pp.FilterFile * 2)(f1, f2))
+    low, high, correct = 100, 900, 0
+
+    def orientation(fl1, s1, e1, fl2, s2, e2):               # filter.rs:189-209
+        fw1, fw2 = not fl1 & 16, not fl2 & 16
+        p1, p2 = (s1 if fw1 else e1), (s2 if fw2 else e2)
+        if fw1 != fw2:
+            return 0 if ((fw1 if p1 < p2 else fw2)) else 1
+        return (2 if p1 < p2 else 3) if fw1 else (2 if p2 < p1 else 3)
+
+    def verdicts(me, other):
+        out = np.ones(len(me["read"]), np.uint8)
+        for r in range(n_reads):
+            mine = me["grp_idx"][me["grp_off"][r]:me["grp_off"][r + 1]]
+            mates = other["grp_idx"][other["grp_off"][r]:other["grp_off"][r + 1]]
+            if len(mine) <= 1 or len(mates) == 0:
+                continue
+            for a in mine:
+                ok = 0
+                for b in mates:
+                    s1, e1, s2, e2 = int(me["ref_start"][a]), int(me["end"][a]), int(other["ref_start"][b]), int(other["end"][b])
+                    ins = max(s1, e1, s2, e2) - min(s1, e1, s2, e2)
+                    if me["ref_id"][a] == other["ref_id"][b] and low <= ins <= high and \
+                            orientation(int(me["flags"][a]), s1, e1, int(other["flags"][b]), s2, e2) == correct:
+                        ok = 1
+                        break
+                out[a] = ok
+        return out
+    want = verdicts(a1, a2), verdicts(a2, a1)
+    assert 0 < want[0].sum() < len(want[0])
+    L = pp.lib()
+    for with_samples in (False, True, False):
+        got = np.full(f1.n_aln, 7, np.uint8), np.full(f2.n_aln, 7, np.uint8)
+        assert L.pp_filter_begin(ctx._h, C.byref(inp), pp.MEM_HOST) == 0, L.pp_last_error(ctx._h)
+        if with_samples:
+            orient, insert = np.zeros(n_reads, np.uint8), np.zeros(n_reads, np.uint32)
+            assert L.pp_filter_samples(ctx._h, orient.ctypes.data, insert.ctypes.data) == 0
+            uniq = (np.diff(a1["grp_off"]) == 1) & (np.diff(a2["grp_off"]) == 1)
+            assert ((orient != 255) <= uniq).all() and (orient != 255).sum() > 100
+        assert L.pp_filter_pairs(ctx._h, low, high, correct, got[0].ctypes.data, got[1].ctypes.data) == 0
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()

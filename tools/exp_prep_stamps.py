@@ -6,12 +6,13 @@ their time, from the ticks thread 0 of every block leaves in PP_PREP_STAMPS_FILE
 import sys
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2, -1, 8).astype(np.int64)
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2, 16384, 8).astype(np.int64)
 names = {0: ("k_prep", ["start", "counters cleared", "stream loop done (thread 0)", "... whole block", "noted records done", "longest read noted, barrier", "histogram row written"]),
          1: ("k_fill", ["start", "cursors set", "items written (thread 0)"])}
 if "--direct" in sys.argv:  # the direct path's one pass over the mirror (pp_k_direct.h)
     names = {0: ("k_prepd", ["start", "stage cleared, first window known", "stream loop done (thread 0)", "... whole block", "noted records done (thread 0)",
-                             "slots taken for the staged extras", "extras written (thread 0)"])}
+                             "slots taken for the staged extras", "extras written (thread 0)"]),
+             1: ("k_prepg", ["start", "stage cleared, first window known", "noted records done (thread 0)", "... whole block", "extras written (thread 0)"])}
 t0 = a[0][:, 0][a[0][:, 0] > 0].min()
 for k in sorted(names):
     nm, pts = names[k]
