@@ -124,8 +124,10 @@ def shard_of(ctx, pp, job, plan, rank):
     its emit ranges; everything else is shared with `job`."""
     r = job["recs"]
     ptrs = {k: v.data_ptr() for k, v in r.items()}
-    if job.get("wo") is not None:   # the window-order mirror goes along into the part (restricted to its records)
+    if job.get("wo") is not None:   # the window-order mirror goes along into the part (restricted to its records), and its runs
         ptrs["wo"] = job["wo"].data_ptr()
+        if job.get("wo_runs") and not os.environ.get("PP_BENCH_NO_RUNS"):
+            ptrs["wo_runs"] = job["wo_runs"]
     part = pp.ShardPart(ctx, plan, rank, job["n_aln"], ptrs, r["seq"].numel(), r["cigar"].numel(), pp.MEM_DEVICE)
     mine = dict(job)
     mine.pop("_prepared", None)

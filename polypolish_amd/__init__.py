@@ -519,9 +519,7 @@ class ShardPart:
 
     def __init__(self, ctx, plan, dest, n_aln, ptrs, seq_bytes, n_cig_total, mem):
         L = lib()
-        b = AlnBatch(n_aln, ptrs["contig"], ptrs["ref_start"], ptrs["k"], ptrs["seq_off"], ptrs["seq_len"],
-                     ptrs["cig_off"], ptrs["n_cig"], ptrs["seq"], seq_bytes, ptrs["cigar"], n_cig_total, ptrs.get("seq4") or None,
-                     ptrs.get("wo") or None)
+        b = aln_batch(n_aln, ptrs, seq_bytes, n_cig_total)  # (ptrs["wo_runs"]: the mirror's runs go along, restricted)
         self._p = C.c_void_p()
         self._ctx = ctx  # keeps the context (and with it the part's device memory) alive
         rc = L.pp_shard_split(ctx._h if ctx is not None else None, plan._p, dest, C.byref(b), mem, C.byref(self._p))
@@ -536,6 +534,9 @@ class ShardPart:
             self.ptrs["seq4"] = out.seq4
         if out.wo:    # ... and every part the window-order mirror of its records, when the source batch has one
             self.ptrs["wo"] = out.wo
+            runs = _runs_of(out)
+            if len(runs):  # ... with its runs, when the source's are known: the part takes the direct path too
+                self.ptrs["wo_runs"] = runs
         self.orig_ptr = orig.value or 0
 
     def host(self):
@@ -565,15 +566,20 @@ class ShardPart:
 
 
 def shard_split_host(plan, dest, recs):
-    """Host numpy SoA -> (recs of the part, orig).  recs["wo"] (the window-order mirror, WO_DTYPE) goes along when it is there."""
+    """Host numpy SoA -> (recs of the part, orig).  recs["wo"] (the window-order mirror, WO_DTYPE) goes along when it is there,
+    and recs["wo_runs"] (the ends of its runs) with it."""
     keep = {k: np.ascontiguousarray(recs[k], dtype=dt) for k, dt in REC_FIELDS}
     ptrs = {k: v.ctypes.data for k, v in keep.items()}
     if "wo" in recs and len(recs["wo"]):
         keep["wo"] = np.ascontiguousarray(recs["wo"])
         ptrs["wo"] = keep["wo"].ctypes.data
+        if recs.get("wo_runs") is not None and len(recs["wo_runs"]):  # the mirror's runs: restricted along with it
+            ptrs["wo_runs"] = recs["wo_runs"]
     part = ShardPart(None, plan, dest, len(keep["contig"]), ptrs, len(keep["seq"]),
                      len(keep["cigar"]), MEM_HOST)
     out = part.host()
+    if "wo_runs" in part.ptrs and "wo" in out[0]:
+        out[0]["wo_runs"] = part.ptrs["wo_runs"]
     part.close()
     return out
 
@@ -852,8 +858,14 @@ class Context:
         if emit is not None:
             self.set_emit(emit)
         for part in split_records(keep, cuts):
-            self.polish_add_ptrs(len(part["contig"]), {k: v.ctypes.data for k, v in part.items()}, len(part["seq"]),
-                                 len(part["cigar"]), MEM_HOST)
+            ptrs = {k: v.ctypes.data for k, v in part.items()}
+            if cuts is None and recs.get("wo") is not None and len(recs["wo"]) == len(keep["contig"]) and len(recs["wo"]):
+                # the window-order mirror of the records (WO_DTYPE) and, optionally, the ends of its runs
+                keep["wo"] = np.ascontiguousarray(recs["wo"])
+                ptrs["wo"] = keep["wo"].ctypes.data
+                if recs.get("wo_runs") is not None and len(recs["wo_runs"]):
+                    ptrs["wo_runs"] = recs["wo_runs"]
+            self.polish_add_ptrs(len(part["contig"]), ptrs, len(part["seq"]), len(part["cigar"]), MEM_HOST)
         self.polish_finish()
         polished, offs, stats = self.result()
         res = {"polished": polished, "offsets": offs, "stats": stats, "positions": None}

@@ -300,19 +300,11 @@ extern "C" int pp_filter_load_device(pp_ctx *ctx, const char *in1, const char *i
         PP_HIPCHK(ctx, hipMemsetAsync((u8 *)X.d_text.p + size, 0, padded + 64 - size, st));
         PP_HIPCHK(ctx, hipMemsetAsync(d_status, 0xFF, 8, st));
         const u8 *d_text = (const u8 *)X.d_text.p;
-        if (n_blk) {
-            ENS(D->d_blk, (n_blk + 1) * 4);
-            ENS(D->d_blkoff, (n_blk + 1) * 8);
-            PP_HIPCHK(ctx, hipMemsetAsync((u32 *)D->d_blk.p + n_blk, 0, 4, st));
-            hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)D->d_blk.p);
-            hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_blk.p, n_blk, (u64 *)D->d_blkoff.p);
-            if ((rc = fetch(ctx, (const u64 *)D->d_blkoff.p + n_blk, &X.n_nl))) return rc;
+        {
             u32 not_ascii = 0;
-            if ((rc = fetch(ctx, (const u32 *)D->d_blk.p + n_blk, &not_ascii))) return rc;
+            if ((rc = newline_index(ctx, d_text, size, D->d_blk, D->d_blkoff, X.d_nl, &X.n_nl, &not_ascii))) return rc;
             if (not_ascii)  // the host loader knows which lines are valid UTF-8
                 return ctx->fail(PP_ERR_NOT_ASCII, "\"%s\" holds bytes outside ASCII: left to the host loader", ins[f]);
-            ENS(X.d_nl, std::max<u64>(1, X.n_nl) * 8);
-            hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)D->d_blkoff.p, (u64 *)X.d_nl.p);
         }
         X.n_lines = X.n_nl + ((size > 0 && X.text.text[size - 1] != '\n') ? 1 : 0);
         if (X.n_lines >= 0x7FFFFFFFull) return ctx->fail(PP_ERR_LIMIT, "\"%s\" has more than 2^31-1 lines", ins[f]);

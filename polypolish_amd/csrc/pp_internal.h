@@ -161,6 +161,15 @@ struct pp_ctx {
     uint32_t last_listed = ~0u;         // positions the last job listed for k_exact (sizes its grid for the next one)
     bool no_compact = false;            // this job is being rerun over the whole assembly (DE_HALO)
     uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block
+    // what k_meta_init has already set up, on the stream, for the next job (run_pipeline): valid while nothing else touched it
+    struct MetaReady {
+        const void *meta; uint32_t words; const void *za, *zb, *zc; uint32_t nwin; const void *tab; double fv, fi;
+        bool operator==(const MetaReady &o) const {
+            return meta == o.meta && words == o.words && za == o.za && zb == o.zb && zc == o.zc && nwin == o.nwin && tab == o.tab && fv == o.fv && fi == o.fi;
+        }
+    };
+    MetaReady meta_ready{};
+    bool meta_ready_valid = false;
     size_t h_meta_words = 0;
     std::vector<uint8_t> own_blob;      // what b_own holds (emit ranges, window ranges, compact tables), to skip identical uploads
     pp::DevBuf b_sub_bases;             // ... and its assembly bytes

@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void k_scan_cols(u32 nwin, u32 nblocks, u32 *_
 // single-block exclusive scan: out[i] = sum(in[0..i)), out[n] = total
 // n_ptr (optional) overrides n with a count held on the device; the total is also stored to *total_out;
 // a total above `limit` (capacity of the buffer the offsets index into) aborts the job with DE_CAPACITY.
-// Tiles of 4096 values, four per thread in one 16-byte load: coalesced, and 30 trips for the 122 K windows of a 250 Mbp
-// job where a thread walking its own 120-value stretch took 114 us.
+// Tiles of 16384 values, sixteen per thread in four 16-byte loads that are all out before the first is used: coalesced,
+// and 8 trips for the 122 K windows of a 250 Mbp job (a trip is a round trip to memory, the wave scans and two barriers:
+// ~2 us; with four values per thread the same job took 30 of them, and a thread walking its own 120-value stretch 114 us).
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n, const u32 *__restrict__ n_ptr,
                                                T *__restrict__ out, u64 *__restrict__ total_out, u64 limit,
@@ -120,18 +121,25 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
     if (*status != ~0ull) return;
     if (n_ptr) n = *n_ptr;
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    constexpr int Q = 4;  // 16-byte loads per thread and trip
     u64 carry = 0;
-    for (u64 base = 0; base < n; base += 4096) {
-        const u64 i0 = base + 4ull * t;
-        u32 v[4] = {0, 0, 0, 0};
-        if (i0 + 4 <= n) {
-            const uint4 q = *(const uint4 *)(in + i0);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
+    for (u64 base = 0; base < n; base += 4096ull * Q) {
+        const u64 i0 = base + 4ull * Q * t;
+        u32 v[4 * Q];
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (i0 + k < n) v[k] = in[i0 + k];
+        for (int q = 0; q < Q; q++) {
+            const u64 i = i0 + 4ull * q;
+            if (i + 4 <= n) {
+                const uint4 x = *(const uint4 *)(in + i);
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[4 * q + k] = i + k < n ? in[i + k] : 0u;
+            }
         }
-        const u64 s = (u64)v[0] + v[1] + v[2] + v[3];
+        u64 s = 0;
+#pragma unroll
+        for (int k = 0; k < 4 * Q; k++) s += v[k];
         u64 inc = s;
         for (int o = 1; o < 64; o <<= 1) {
             const u64 x = (u64)__shfl_up((long long)inc, o, 64);
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_scan(const u32 *__restrict__ in, u64 n
             tile += ws;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 4 * Q; k++) {
             if (i0 + k < n) out[i0 + k] = (T)before;
             before += v[k];
         }

@@ -37,7 +37,8 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
 // position no shared read touches -- reads its thresholds instead of multiplying and rounding twice.
 constexpr u32 VOTE_TAB_N = 4096;
 __device__ __forceinline__ u32 d_bankers(double x);
-__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 n_zero, u32 *thr, double fv, double fi) {
+__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 *zero_c, u32 *zero_d, u32 n_zero, u32 *thr, double fv,
+                            double fi) {
     if (blockIdx.x == 0) {
         for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
         for (u32 n = threadIdx.x; n < VOTE_TAB_N; n += blockDim.x) {
@@ -46,9 +47,12 @@ __global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 
         }
         return;
     }
-    // blocks 1..: 4096 elements of the two arrays each (a sharded job's win_len / win_nflag)
+    // blocks 1..: 4096 elements of the arrays each (a sharded job's win_len / win_nflag; the direct path's counts of extras)
     const u32 lo = (blockIdx.x - 1u) * 4096u, hi = min(n_zero, lo + 4096u);
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) { zero_a[i] = 0; zero_b[i] = 0; }
+    if (zero_a)
+        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) { zero_a[i] = 0; zero_b[i] = 0; }
+    if (zero_c)
+        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) { zero_c[i] = 0; zero_d[i] = 0; }
 }
 
 __device__ __forceinline__ void report(u64 *status, u64 idx, u32 code) {

@@ -671,11 +671,18 @@ __device__ __forceinline__ void wide4_pass(u32 *cnt, u32 *ndbits, const TileShar
     const u32 xlo = live ? (u32)lo + adj : 0u, xhi = live ? (u32)hi + adj : 0u;
     const u32 *mlo = S.pmask + xlo, *mhi = S.pmask + xhi;
     const u32 sh = (u32)(relc + ASM4_PAD) << 2;  // (v_alignbit takes it modulo 32: 4 * (the position's nibble in its dword), the same for all chunks)
+    const int dw0 = (relc + ASM4_PAD) >> 3;      // the dword of asm4 that holds chunk 0's nibble 0 (below zero: a read that starts well before the window)
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int P0 = relc + 32 * c;  // window position of the chunk's nibble 0
-        const u32 ai = (u32)min(max(P0 + ASM4_PAD, 0), 8 * (ASM4_WORDS - 5));  // (clamped only for a chunk with nothing in range)
+        // (clamped only for a chunk with nothing in range; one add and one v_med3 on the dword index -- the clamp on the
+        // nibble index was seven instructions per chunk)
+#ifndef PP_WIDE4_OLD_CLAMP
+        const u32 *ap = asm4 + min(max(dw0 + 4 * c, 0), ASM4_WORDS - 5);
+#else
+        const u32 ai = (u32)min(max(P0 + ASM4_PAD, 0), 8 * (ASM4_WORDS - 5));
         const u32 *ap = asm4 + (ai >> 3);
+#endif
         const u32 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
         u32 F = nz_perm(W[c].x ^ __builtin_amdgcn_alignbit(a1, a0, sh), W[c].y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
                         W[c].z ^ __builtin_amdgcn_alignbit(a3, a2, sh), W[c].w ^ __builtin_amdgcn_alignbit(a4, a3, sh));

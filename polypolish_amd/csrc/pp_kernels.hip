@@ -456,7 +456,18 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     std::vector<uint64_t> src_start;                 // per contig of the RUN: where its bytes start in the job's assembly
     std::vector<uint32_t> slice;                     // per contig of the JOB: [lo, hi) of it that the run holds
     ctx->run_full_of.clear();
-    if (!ctx->emit.empty() && !ctx->debug && !ctx->no_compact) {
+    // ---- the direct path (pp_k_direct.h): a mirror whose runs are known ----
+    // A sharded job takes it over the job's own coordinates (the mirror's window order is the job's: a compact run has
+    // other window boundaries), with the grids of k_tile / k_emit over the windows it works on as in any uncompacted
+    // sharded run; what is proportional to ALL windows of the job is a few words per window in k_meta_init, k_prepd's
+    // table, k_winplan and k_scan.
+    static const bool env_no_direct = getenv("PP_DIRECT") && atoi(getenv("PP_DIRECT")) == 0;  // tuning / tests
+    static const bool env_no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
+    const uint32_t n_runs = (uint32_t)ctx->wo_runs.size();
+    const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && n > 0 && B.wo && n_runs > 0 &&
+                        n_runs <= PP_WO_MAX_RUNS && ctx->wo_runs.back() == n;
+    ctx->last_direct = direct;
+    if (!ctx->emit.empty() && !ctx->debug && !ctx->no_compact && !direct) {
         uint64_t g_sub = 0;
         std::vector<uint32_t> owned;
         slice.assign(2 * (size_t)nc_full, 0);
@@ -496,21 +507,21 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const uint64_t chunk = (n + NB - 1) / NB;
     const uint32_t nranges = (nwin + COUNT_RANGE - 1) / COUNT_RANGE;
     int rc;
-    // ---- the direct path (pp_k_direct.h): a mirror whose runs are known, a job that is not sharded ----
-    static const bool env_no_direct = getenv("PP_DIRECT") && atoi(getenv("PP_DIRECT")) == 0;  // tuning / tests
-    static const bool env_no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
-    const uint32_t n_runs = (uint32_t)ctx->wo_runs.size();
     // (room for the mirror indices of the records that are not bulk -- k_prepd notes them for k_prepg: an eighth of the
     // records; a job with more of them has its workgroups handle what does not fit themselves)
     const uint64_t cap_later = std::max<uint64_t>(65536, n / 8);
-    const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && n > 0 && B.wo && ctx->emit.empty() && n_runs > 0 &&
-                        n_runs <= PP_WO_MAX_RUNS && ctx->wo_runs.back() == n;
-    ctx->last_direct = direct;
     if (direct) {
         // room for a window's extras: a quarter of the average window's records (7 % reach in from the window before, a few per
         // cent have indels) and then some; a window that needs more says so (DE_CAPACITY, meta word 12) and the job is rerun
-        uint64_t want = 128;
-        while (want < n / nwin / 4 + 64) want <<= 1;
+        // (a sharded job's records lie in the windows it works on)
+        uint64_t want = 128, own_est = nwin;
+        if (!ctx->emit.empty()) {
+            own_est = 0;
+            for (uint32_t c = 0; c < nc_full; c++)
+                if (ctx->emit[2 * c + 1] > ctx->emit[2 * c]) own_est += (ctx->emit[2 * c + 1] - ctx->emit[2 * c]) / TILE + 1;
+            own_est = std::max<uint64_t>(1, std::min<uint64_t>(own_est, nwin));
+        }
+        while (want < n / own_est / 4 + 64) want <<= 1;
         ctx->xcap = std::max<size_t>(ctx->xcap, (size_t)want);
         ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)1 << 18);  // (work items in memory: only what k_xmat writes out)
     } else {
@@ -575,14 +586,22 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ContigStatsDev *d_stats = (ContigStatsDev *)(d_meta + 17 + nc);
     // zeros, status word = "no error"; a sharded job also gets its per-window output lengths and flag counts zeroed (the
     // windows nobody works on emit nothing and have nothing flagged) -- one launch instead of a kernel and two memsets
-    {
-        // (the direct path is never sharded: the same blocks zero its per-window counts of extras)
-        const bool sharded = !ctx->emit.empty();
-        hipLaunchKernelGGL(k_meta_init, dim3(sharded || direct ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
-                           direct ? (u32 *)ctx->b_xcnt.p : (sharded ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr),
-                           direct ? (u32 *)ctx->b_xcnt.p + nwin : (sharded ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr), nwin,
+    // (the direct path: the same blocks zero its per-window counts of extras)
+    // A job that went through leaves this done for the NEXT one (see the end of this function): a context that polishes
+    // job after job of one shape -- a rank's share, a service -- starts with its first real kernel, and the 6 us of this one
+    // run while the host is busy with the results of the job before.
+    const bool sharded_job = !ctx->emit.empty();
+    const pp_ctx::MetaReady meta_key{d_meta, (u32)meta_words, sharded_job ? ctx->b_winlen.p : nullptr, sharded_job ? ctx->b_win_nflag.p : nullptr,
+                                     direct ? ctx->b_xcnt.p : nullptr, nwin, ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid};
+    auto launch_meta_init = [&]() {
+        hipLaunchKernelGGL(k_meta_init, dim3(sharded_job || direct ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
+                           sharded_job ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded_job ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr,
+                           direct ? (u32 *)ctx->b_xcnt.p : (u32 *)nullptr, direct ? (u32 *)ctx->b_xcnt.p + nwin : (u32 *)nullptr, nwin,
                            (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
-    }
+    };
+    static const bool env_no_ahead = getenv("PP_INIT_AHEAD") && atoi(getenv("PP_INIT_AHEAD")) == 0;  // tuning / tests
+    if (!(ctx->meta_ready_valid && ctx->meta_ready == meta_key)) launch_meta_init();
+    ctx->meta_ready_valid = false;
     u32 *d_heavy = (u32 *)(d_meta + heavy_at);
     u8 *d_win_heavy = (u8 *)ctx->b_win_heavy.p;
     // A window is heavy from 1.5x the average number of records per window on (a few per cent below the items).  In a job
@@ -590,8 +609,6 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // the ~200 reads over it are three items each.  (At 1.25x those windows took the 32 slots of the list in a job with
     // planted indels, and the collapsed repeats the list is for went the ordinary way: configs[2] 0.98 -> 1.55 ms.)
     static const long forced_heavy = getenv("PP_HEAVY_MIN") ? atol(getenv("PP_HEAVY_MIN")) : 0;  // tuning / tests
-    const u32 heavy_min = forced_heavy > 0 ? (u32)forced_heavy
-                                           : (u32)std::min<uint64_t>(MAX_BUCKET, std::max<uint64_t>(HEAVY_MIN_ITEMS, 3 * n / 2 / nwin));
 
     u32 *d_gstart = (u32 *)ctx->b_gstart.p, *d_nkeep = (u32 *)ctx->b_nkeep.p;
     u32 *d_hist = (u32 *)ctx->b_hist.p, *d_wincnt = (u32 *)ctx->b_wincnt.p, *d_winoff = (u32 *)ctx->b_winoff.p;
@@ -660,6 +677,9 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         }
         // (the windows nobody works on emit nothing and have nothing flagged: k_meta_init zeroes win_len / win_nflag)
     }
+    // (the average over the windows the context works on: a sharded job that is not compacted has its records there)
+    const u32 heavy_min = forced_heavy > 0 ? (u32)forced_heavy
+                                           : (u32)std::min<uint64_t>(MAX_BUCKET, std::max<uint64_t>(HEAVY_MIN_ITEMS, 3 * n / 2 / std::max<uint32_t>(1, n_own_win)));
     // PP_CHECK_WO=1: the mirror checked against the arrays before anything reads the records through it
     static const bool check_wo = getenv("PP_CHECK_WO") && atoi(getenv("PP_CHECK_WO")) != 0;
     if (check_wo && B.wo && !env_no_wo && n) {
@@ -926,6 +946,12 @@ PrepdArgs PA;
     }
     meta.assign(ctx->h_meta, ctx->h_meta + meta_words);
     *n_entries_out = (uint32_t)meta[3];
+    if (meta[0] == ~0ull && !env_no_ahead) {  // the job is through: the metadata block (and the per-window zeros) of the next one
+        launch_meta_init();
+        PP_HIPCHK(ctx, hipGetLastError());
+        ctx->meta_ready = meta_key;
+        ctx->meta_ready_valid = true;
+    }
     if (getenv("PP_TRACE_FLAGGED")) {  // tuning: the positions this pass listed for k_exact
         const uint32_t *c = (const uint32_t *)&meta[1];
         const uint32_t nl = std::min<uint32_t>(c[0], 64);

@@ -29,6 +29,7 @@ struct pp_shard_part {
     void *d[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool has_wo = false;
     std::vector<pp_wo_rec> h_wo;
+    std::vector<uint64_t> wo_runs;  // the ends of the part's mirror's runs (the source's runs, restricted), or empty: not known
     std::vector<uint32_t> h_contig, h_ref_start, h_k, h_seq_len, h_n_cig, h_cigar, h_orig;
     std::vector<uint64_t> h_seq_off, h_cig_off;
     std::vector<uint8_t> h_seq;
@@ -247,6 +248,8 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
     v.seq4 = P->mem == PP_MEM_DEVICE ? (const u8 *)P->d[10] : nullptr;  // a device part brings the 4-bit mirror of its seq array
     v.wo = !P->has_wo || n == 0 ? nullptr : (P->mem == PP_MEM_DEVICE ? (const pp_wo_rec *)P->d[11] : P->h_wo.data());  // ... and both kinds the window-order mirror, when the source has one
+    v.wo_n_runs = v.wo ? (uint32_t)P->wo_runs.size() : 0;  // ... with its runs (a restriction of an ascending run is one)
+    v.wo_run_end = v.wo_n_runs ? P->wo_runs.data() : nullptr;
     if (P->mem == PP_MEM_DEVICE) {
         v.contig = (const u32 *)P->d[0]; v.ref_start = (const u32 *)P->d[1]; v.k = (const u32 *)P->d[2];
         v.seq_off = (const uint64_t *)P->d[3]; v.seq_len = (const u32 *)P->d[4]; v.cig_off = (const uint64_t *)P->d[5];
@@ -258,6 +261,17 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
         v.cigar = P->h_cigar.data();
         P->orig = P->h_orig.data();
     }
+}
+
+// the source's run table is usable: the whole batch's mirror (not a view's), ends ascending, the last one the record count
+bool src_runs_ok(const pp_aln_batch *b, u32 wo_base) {
+    if (!b->wo || wo_base || !b->wo_n_runs || b->wo_n_runs > PP_WO_MAX_RUNS || !b->wo_run_end) return false;
+    uint64_t prev = 0;
+    for (u32 r = 0; r < b->wo_n_runs; r++) {
+        if (b->wo_run_end[r] < prev) return false;
+        prev = b->wo_run_end[r];
+    }
+    return prev == b->n_aln;
 }
 
 bool batch_ok(const pp_aln_batch *b) {
@@ -315,7 +329,10 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
         for (uint64_t j = 0; j < cnt; j++) new_idx[picked[j]] = (uint32_t)j;
         P->h_wo.reserve(cnt);
         bool ok = true;
+        const bool runs = src_runs_ok(B, wo_base);
+        uint32_t run = 0;
         for (uint64_t j = 0; j < n && ok; j++) {
+            while (runs && run < B->wo_n_runs && j == B->wo_run_end[run]) { P->wo_runs.push_back(P->h_wo.size()); run++; }
             pp_wo_rec w = B->wo[j];
             const uint32_t fi = w.file_idx - wo_base;
             if (fi >= n) { ok = false; break; }
@@ -324,7 +341,9 @@ int split_host(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, co
             w.file_idx = new_idx[fi];
             P->h_wo.push_back(w);
         }
+        while (runs && run < B->wo_n_runs) { P->wo_runs.push_back(P->h_wo.size()); run++; }
         P->has_wo = ok && P->h_wo.size() == cnt;
+        if (!P->has_wo) P->wo_runs.clear();
     }
     set_view(P, cnt, seq_total, cig_total);
     return PP_OK;
@@ -413,6 +432,14 @@ int split_device(pp_shard_part *P, const HostUnits &U, u32 n_contigs, u32 dest, 
                 hipLaunchKernelGGL(k_split_wo, dim3(blocks), dim3(256), 0, st, (u64)n, B->wo, wo_base, (const u32 *)mflag, (const u32 *)mpos.p,
                                    (const u32 *)out_idx.p, (const u64 *)seq_scan.p, (pp_wo_rec *)P->d[11]);
                 P->has_wo = true;
+                if (src_runs_ok(B, wo_base)) {  // where the source's runs end in the part's mirror: the scan at their ends
+                    u32 ends[PP_WO_MAX_RUNS];
+                    for (u32 r = 0; r < B->wo_n_runs; r++)
+                        if (hipMemcpyAsync(&ends[r], (const u32 *)mpos.p + B->wo_run_end[r], 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                            return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: copy failed"));
+                    if (hipStreamSynchronize(st) != hipSuccess) return done(ctx->fail(PP_ERR_HIP, "pp_shard_split: synchronize failed"));
+                    for (u32 r = 0; r < B->wo_n_runs; r++) P->wo_runs.push_back(ends[r]);
+                }
             }
         }
     }

@@ -838,19 +838,11 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
     if (!uploaded) lap("text uploaded");
     if (!slice) start_prefetch(D);  // this file's text is on its way (a copy out of pageable memory returns when it is staged): the next file's may follow
     u64 n_nl = 0;
-    if (n_blk) {
-        ENS(d_blk, (n_blk + 1) * 4);
-        ENS(d_blkoff, (n_blk + 1) * 8);
-        PP_HIPCHK(ctx, hipMemsetAsync((u32 *)D->d_blk.p + n_blk, 0, 4, st));
-        hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)D->d_blk.p);
-        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)D->d_blk.p, n_blk, (u64 *)D->d_blkoff.p);
-        if ((rc = fetch(ctx, (const u64 *)D->d_blkoff.p + n_blk, &n_nl))) return rc;
+    {
         u32 not_ascii = 0;
-        if ((rc = fetch(ctx, (const u32 *)D->d_blk.p + n_blk, &not_ascii))) return rc;
+        if ((rc = newline_index(ctx, d_text, size, D->d_blk, D->d_blkoff, D->d_nl, &n_nl, &not_ascii))) return rc;
         if (not_ascii)  // the host ingest knows which lines are valid UTF-8 (the driver reruns with it, as for any defect)
             return ctx->fail(PP_ERR_NOT_ASCII, "\"%s\" holds bytes outside ASCII: left to the host ingest", path);
-        ENS(d_nl, std::max<u64>(1, n_nl) * 8);
-        hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)D->d_blkoff.p, (u64 *)D->d_nl.p);
     }
     lap("newline index");
     const u64 n_lines = n_nl + ((size > 0 && F.text[size - 1] != '\n') ? 1 : 0);

@@ -182,3 +182,33 @@ def test_split_hands_every_rank_the_records_that_reach_its_units(orc, world):
         assert eng(contig_off, bases, part, emit=e)["polished"] == eng(contig_off, bases, recs, emit=e)["polished"], r
     cnt = pp.shard_count(None, n, recs["contig"].ctypes.data, pp.MEM_HOST, 4, {k: v.ctypes.data for k, v in recs.items()})
     assert np.array_equal(cnt.astype(np.int64), np.bincount(recs["contig"], minlength=4))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_a_parts_mirror_keeps_its_runs(world):
+    """pp_shard_split restricts the window-order mirror of a batch to a part's records AND the table of the mirror's runs
+    (pp_aln_batch.wo_run_end): the part's runs are the source's, entry for entry, every run ascending in the records'
+    home windows -- what lets a rank of a sharded job take the direct path.  Two SAM files, an empty run in front and one
+    between them (a file without usable records)."""
+    contig_off, bases, recs = synth.fast_records(seed=15, contig_lens=(30000, 400, 5000, 2600), coverage=25, read_len=100,
+                                                 k_choices=(1, 2), indel_read_frac=0.2)
+    n = len(recs["contig"])
+    per_file = [0, n // 3, 0, n - n // 3]
+    recs = dict(recs)
+    recs["wo"] = pp.window_order_mirror(recs, contig_off, used_per_file=per_file)
+    recs["wo_runs"] = np.cumsum(per_file).astype(np.uint64)
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=4), world, 2048)
+    off = np.asarray(contig_off, dtype=np.int64)
+    for r in range(world):
+        part, orig = pp.shard_split_host(plan, r, recs)
+        runs = [int(x) for x in part["wo_runs"]]
+        assert len(runs) == 4 and runs[0] == 0 and runs[1] == runs[2] and runs[-1] == len(part["contig"])
+        wo = part["wo"]
+        src_file = np.searchsorted(recs["wo_runs"], orig[wo["file_idx"]].astype(np.uint64), side="right")
+        home = (off[wo["contig"].astype(np.int64)] + wo["ref_start"].astype(np.int64)) // 2048
+        for i, (a, b) in enumerate(zip([0] + runs[:-1], runs)):
+            assert (src_file[a:b] == i).all(), (r, i)          # a run holds the records of its SAM file ...
+            assert (np.diff(home[a:b]) >= 0).all(), (r, i)     # ... in window order
+    # a mirror without a run table: the part has none either
+    plain = {k: v for k, v in recs.items() if k != "wo_runs"}
+    assert "wo_runs" not in pp.shard_split_host(plan, 0, plain)[0]

@@ -36,7 +36,7 @@ def _seqs(fasta_bytes):
 
 
 def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False, min_depth=5, fraction_valid=0.5,
-                         fraction_invalid=0.2, wo=None):
+                         fraction_invalid=0.2, wo=None, emit=None):
     """The records as ONE device-resident batch that is polished in place (what the device tokenizer hands over), with or
     without the 4-bit mirror of the seq array (pp_aln_batch.seq4) and the window-order mirror of the records
     (pp_aln_batch.wo; wo = True: as the host ingest orders it, "shuffled": the same entries in a random order -- the mirror
@@ -64,6 +64,8 @@ def _polish_device_batch(ctx, pp, contig_off, bases, recs, seq4, positions=False
     pp.lib().pp_polish_set_debug(ctx._h, int(positions))
     try:
         ctx.polish_begin(contig_off, tb.data_ptr(), pp.MEM_DEVICE, min_depth, fraction_valid, fraction_invalid)
+        if emit is not None:
+            ctx.set_emit(emit)
         ctx.polish_add_ptrs(len(recs["contig"]), ptrs, len(recs["seq"]), len(recs["cigar"]), pp.MEM_DEVICE)
         ctx.polish_finish()
         polished, offs, stats = ctx.result()
@@ -791,7 +793,8 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     oracle_fasta = orc.polish_files(ds["fasta"], sams)["fasta"]
     for env in (dict(), dict(PP_SEQ_LAYOUT="window"), dict(PP_SEQ_LAYOUT="file"), dict(PP_SEQ4="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0"),
                 dict(PP_DEVICE_INGEST="0"), dict(PP_DEVICE_INGEST="0", PP_SEQ_LAYOUT="file"), dict(PP_DEVICE_INGEST="0", PP_SEQ4="0"),
-                dict(PP_WO="0"), dict(PP_DEVICE_INGEST="0", PP_WO="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0")):
+                dict(PP_WO="0"), dict(PP_DEVICE_INGEST="0", PP_WO="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0"),
+                dict(PP_NL_ONE_PASS="1")):   # (the newline index in one pass over the text: k_nl_index)
         r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout == oracle_fasta, (env, r.stderr[-400:])
 
@@ -1856,3 +1859,96 @@ def test_filter_seam_verdicts_with_and_without_the_sampling_call(ctx, pp):
             assert ((orient != 255) <= uniq).all() and (orient != 255).sum() > 100
         assert L.pp_filter_pairs(ctx._h, low, high, correct, got[0].ctypes.data, got[1].ctypes.data) == 0
         assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+
+
+@pytest.mark.parametrize("long_read", [False, True])
+def test_sharded_jobs_take_the_direct_path(ctx, pp, orc, long_read):
+    """A rank of a sharded job whose batch brings the window-order mirror AND its runs takes the direct path too (over the
+    job's own coordinates: k_tile / k_emit only over the windows it works on): three ranks over a 400 kbp contig in three
+    windows and two small contigs, (a) every rank's host part -- pp_shard_split restricts the mirror and its run table --
+    (b) all records with the rank's emit ranges, (c) the part split on the device from a resident batch; the ranks' bytes
+    assemble to the oracle's unsharded polish, and every run says it took the direct path.  long_read: a 20,000-base
+    alignment across the first cut (no compact run, so no halo to outgrow).  Two runs (two SAM files) in the mirror."""
+    import torch
+    contig_off, bases, recs = synth.fast_records(seed=68, contig_lens=(400_000, 3_000, 60_000), coverage=12, read_len=100,
+                                                 k_choices=(1, 1, 2, 3), indel_read_frac=0.2, n_rate=0.003)
+    plan = pp.Plan(contig_off, np.bincount(recs["contig"], minlength=3), 3, 65536)
+    if long_read:
+        cut = int(plan.unit_hi[0])
+        rng = np.random.default_rng(2)
+        n_long = 20_000
+        extra = {"contig": np.array([0], np.uint32), "ref_start": np.array([cut - 18_000], np.uint32), "k": np.array([1], np.uint32),
+                 "seq_off": np.array([0], np.uint64), "seq_len": np.array([n_long], np.uint32), "cig_off": np.array([0], np.uint64),
+                 "n_cig": np.array([1], np.uint32), "seq": np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_long)].copy(),
+                 "cigar": np.array([(n_long << 4) | 0], np.uint32)}
+        recs = synth.merge_records(recs, extra, seed=4)
+    n = len(recs["contig"])
+    per_file = [n // 2, n - n // 2]
+    recs = dict(recs)
+    recs["wo"] = pp.window_order_mirror(recs, contig_off, used_per_file=per_file)
+    recs["wo_runs"] = np.cumsum(per_file).astype(np.uint64)
+    want = orc.polish_records(contig_off, bases, recs)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(recs[k], dtype=dt)).to(dev) for k, dt in pp.REC_FIELDS}
+    t["wo"] = torch.from_numpy(np.ascontiguousarray(recs["wo"]).view(np.uint8)).to(dev)
+    tb = torch.from_numpy(np.ascontiguousarray(bases, dtype=np.uint8)).to(dev)
+    torch.cuda.synchronize()
+    dptrs = {k: v.data_ptr() for k, v in t.items()}
+    dptrs["wo_runs"] = recs["wo_runs"]
+    for how in ("host part", "all records", "device part"):
+        rank_bytes, rank_offs = [], []
+        for rank in range(3):
+            emit = plan.emit_ranges(rank)
+            if how == "host part":
+                mine = pp.shard_split_host(plan, rank, recs)[0]
+                assert len(mine["wo"]) == len(mine["contig"]) and len(mine["wo_runs"]) == 2 and int(mine["wo_runs"][-1]) == len(mine["contig"])
+                got = ctx.polish_records(contig_off, bases, mine, emit=emit)
+            elif how == "all records":
+                got = ctx.polish_records(contig_off, bases, recs, emit=emit)
+            else:
+                part = pp.ShardPart(ctx, plan, rank, n, dptrs, len(recs["seq"]), len(recs["cigar"]), pp.MEM_DEVICE)
+                assert list(part.ptrs["wo_runs"]) == list(pp.shard_split_host(plan, rank, recs)[0]["wo_runs"])
+                ctx.polish_begin(contig_off, tb.data_ptr(), pp.MEM_DEVICE, 5, 0.5, 0.2)
+                ctx.set_emit(emit)
+                ctx.polish_add_ptrs(part.n_aln, part.ptrs, part.seq_bytes, part.n_cig_total, pp.MEM_DEVICE)
+                ctx.polish_finish()
+                polished, offs, stats = ctx.result()
+                got = {"polished": polished, "offsets": offs}
+                part.close()
+            assert ctx.took_direct_path(), (how, rank)
+            rank_bytes.append(got["polished"])
+            rank_offs.append(got["offsets"])
+        data, out_off = plan.assemble(rank_bytes, rank_offs)
+        assert data == want["polished"] and np.array_equal(out_off, want["offsets"]), how
+
+
+def test_newline_index_of_a_text_of_very_short_lines(orc, tmp_path):
+    """PP_NL_ONE_PASS=1: the device front ends index the newlines of a SAM text in one pass (k_nl_index, a chained scan),
+    into room for one newline per 64 bytes; a text with more of them (here: 300,000 four-byte header lines in front of the
+    records) is counted, given the room it needs and indexed once more -- polish and filter through the CLI, both text front
+    ends, against the oracle's bytes (and the default two-pass index on the same text)."""
+    ds = synth.rich_dataset(str(tmp_path), seed=131, contig_lens=(20_000, 3_000), coverage=20, repeat_len=200, repeat_copies=2)
+    sams = []
+    for i, src in enumerate((ds["sam1"], ds["sam2"])):
+        dst = str(tmp_path / f"short_{i + 1}.sam")
+        with open(src, "rb") as f:
+            body = f.read()
+        head_end = 0
+        while body[head_end:head_end + 1] == b"@":
+            head_end = body.index(b"\n", head_end) + 1
+        with open(dst, "wb") as f:
+            f.write(body[:head_end] + b"@CO\n" * 300_000 + body[head_end:])
+        sams.append(dst)
+    assert os.path.getsize(sams[0]) // 64 + 1024 < 300_000
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    want = orc.polish_files(ds["fasta"], sams)["fasta"]
+    for env in (dict(), dict(PP_NL_ONE_PASS="1")):
+        r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == want, (env, r.stderr[-400:])
+    o1, o2 = str(tmp_path / "f1.sam"), str(tmp_path / "f2.sam")
+    w1, w2 = str(tmp_path / "w1.sam"), str(tmp_path / "w2.sam")
+    orc.filter_files(sams[0], sams[1], w1, w2)
+    r = subprocess.run([exe, "filter", "--in1", sams[0], "--in2", sams[1], "--out1", o1, "--out2", o2], capture_output=True,
+                       env=dict(os.environ, PP_DEVICE_FILTER="1", PP_NL_ONE_PASS="1"))
+    assert r.returncode == 0, r.stderr[-400:]
+    assert open(o1, "rb").read() == open(w1, "rb").read() and open(o2, "rb").read() == open(w2, "rb").read()

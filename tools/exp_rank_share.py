@@ -39,5 +39,5 @@ for r in range(world):
         print("   records of rank %d: %d of %d" % (r, j["part"].n_aln, job["n_aln"]))
         j["part"].close()
     tot = max(tot, ms_r)
-    print("rank %d of %d: %.3f ms" % (r, world, ms_r), kt)
+    print("rank %d of %d: %.3f ms%s" % (r, world, ms_r, " (direct path)" if ctx.took_direct_path() else ""), kt)
 print("slowest rank %.3f ms -> speedup %.2f of %d" % (tot, ms / tot, world))
