@@ -84,84 +84,6 @@ __global__ __launch_bounds__(1024) void k_nl_write(const u8 *__restrict__ text, 
     }
 }
 
-// The two in ONE pass over the text (round 5): a workgroup counts the newlines of its 64 KB, learns how many lie in front of
-// it from the workgroups before it -- a chained scan: every workgroup publishes its count (state 1) and, once it knows what
-// is in front of it, its inclusive prefix (state 2); a workgroup looks back over its predecessors' words until it meets a
-// state-2 one -- and writes the positions out of the registers it counted them in.  Which 64 KB a workgroup takes is a
-// ticket drawn when it starts: the workgroups it waits for are then running or done, whatever order the dispatcher chose.
-// ctl: [0] ticket, [1] a byte outside ASCII was seen; state: one word per workgroup (zeroed by the caller: state in bits 62-63)
-// and, behind them, the total.  Positions beyond `cap` (the room the caller guessed) are counted, not written: the caller
-// looks at the total and comes back with more room.
-__global__ __launch_bounds__(1024) void k_nl_index(const u8 *__restrict__ text, u32 *__restrict__ ctl, u64 *__restrict__ state, u32 n_blk,
-                                                   u64 *__restrict__ nl_pos, u64 cap) {
-    __shared__ u32 s_w[16], s_b;
-    __shared__ u64 s_base;
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_b = atomicAdd(&ctl[0], 1u);
-    __syncthreads();
-    const u32 b = s_b;
-    const u64 base = (u64)b * NL_BLOCK + (u64)threadIdx.x * 64u;
-    const uint4 *p = (const uint4 *)(text + base);
-    const uint4 q[4] = {p[0], p[1], p[2], p[3]};
-    const u32 high = (q[0].x | q[0].y | q[0].z | q[0].w | q[1].x | q[1].y | q[1].z | q[1].w | q[2].x | q[2].y | q[2].z | q[2].w | q[3].x | q[3].y |
-                      q[3].z | q[3].w) & 0x80808080u;
-    if (__ballot(high != 0) && lane == 0) atomicOr(&ctl[1], 1u);
-    const u32 n = count_nl16(q[0]) + count_nl16(q[1]) + count_nl16(q[2]) + count_nl16(q[3]);
-    u32 inc = n;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 t = __shfl_up(inc, o, 64);
-        if ((int)lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    u32 before = inc - n;
-    for (u32 i = 0; i < wave; i++) before += s_w[i];
-    if (wave == 0) {  // the look-back, 64 predecessors at a time
-        u64 mine = 0;
-        for (u32 i = 0; i < 16u; i++) mine += s_w[i];
-        constexpr u64 VAL = (1ull << 62) - 1ull;
-        if (b > 0 && lane == 0) __hip_atomic_store(&state[b], (1ull << 62) | mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        u64 excl = 0;
-        for (long long top = (long long)b - 1; top >= 0;) {  // lane l looks at workgroup top - l
-            const long long idx = top - (long long)lane;
-            u64 v = 2ull << 62;  // (in front of the first workgroup: nothing, and known)
-            if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 known = __ballot((v >> 62) == 2u), blank = __ballot((v >> 62) == 0u);
-            const u32 upto = known ? (u32)__ffsll((long long)known) : 64u;  // lanes [0, upto) count: up to the nearest known prefix
-            const u64 need = upto >= 64u ? ~0ull : ((1ull << upto) - 1ull);
-            if (blank & need) continue;  // one of them has not published yet: look again
-            u64 part = lane < upto ? (v & VAL) : 0ull;
-            for (int o = 32; o > 0; o >>= 1) part += (u64)__shfl_xor((long long)part, o, 64);
-            excl += part;
-            if (known) break;
-            top -= 64;
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&state[b], (2ull << 62) | (excl + mine), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (b == n_blk - 1u) state[n_blk] = excl + mine;
-            s_base = excl;
-        }
-    }
-    __syncthreads();
-    if (!n) return;
-    u64 out = s_base + before;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        const u32 w[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const u32 x = w[i] ^ 0x0A0A0A0Au;
-            u32 m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-            while (m) {
-                const u32 bb = ((u32)__ffs((int)m) - 1u) >> 3;  // byte index inside the dword
-                m &= m - 1u;
-                if (out < cap) nl_pos[out] = base + (u64)(16 * v + 4 * i) + bb;
-                out++;
-            }
-        }
-    }
-}
-
 // ---- exclusive scan: u32 in -> T out (n + 1 entries) -- block sums, a single-block scan of the sums,
 // then every block scans its own 8192 elements on top of its base ------------------------------------
 constexpr u32 SCAN_PER_BLOCK = 1024 * 8;
@@ -291,7 +213,18 @@ __device__ __forceinline__ bool stage_wave_lines(const u8 *__restrict__ text, u6
     // the copy runs 16 bytes past the last line: find_tab looks at eight bytes at a time
     const u64 want = e1 - a0 + 16;
     const u32 span = (u32)min((u64)TOK_STAGE + 16u, (want + 15ull) & ~15ull);
-    for (u32 off = lane * 16u; off < span; off += 64u * 16u) *(uint4 *)(stage + off) = *(const uint4 *)(text + a0 + off);
+    // Eight 1 KB rows of the stretch per trip, their loads all out before the first is stored: with one row per trip the
+    // compiler waits for every load before its store, and a wave -- alone in its workgroup -- spent twenty-two memory round
+    // trips on its ~22 KB (k_tok_parse: 1.3 TB/s of text).  A lane past the end of the stretch copies the stretch's last 16
+    // bytes once more, unconditionally: a store under a condition takes its load along into the branch, one wait each.
+    const u32 n_rows = (span + 1023u) >> 10;  // (wave-uniform; span is a multiple of 16 and at least 16)
+    for (u32 row = 0; row < n_rows; row += 8u) {
+        uint4 v[8];
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) v[j] = *(const uint4 *)(text + a0 + min(((row + j) << 10) + lane * 16u, span - 16u));
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) *(uint4 *)(stage + min(((row + j) << 10) + lane * 16u, span - 16u)) = v[j];
+    }
     __syncthreads();
     *li = l0 + lane;
     if (*li >= n_lines) return false;
@@ -350,9 +283,10 @@ int fetch(pp_ctx *ctx, const void *dev, T *host, size_t n = 1) {
 }
 
 // The newline index of `size` bytes of text on the device (padded with zeros to a multiple of NL_BLOCK): *n_nl positions in
-// d_nl, *not_ascii when a byte outside ASCII was seen (the positions are then not to be used).  One pass (k_nl_index) with
-// room for a newline every 64 bytes -- or whatever d_nl already holds -- and a second one if the text has more.
-// Default: the count / scan / write kernels of rounds 1-4; PP_NL_ONE_PASS=1: k_nl_index (tuning / tests).
+// d_nl, *not_ascii when a byte outside ASCII was seen (there is no index then).  Count, scan, write: two passes over the
+// text.  (Round 5 tried ONE pass -- a chained scan over the workgroups, each publishing its count and then its prefix, the
+// look-back a wave wide: 0.89 ms per 680 MB file against the 0.33 ms of the two passes.  Every hop of the chain is a
+// device-scope load that another XCD's store has to reach through memory.)
 int newline_index(pp_ctx *ctx, const u8 *d_text, u64 size, pp::DevBuf &d_blk, pp::DevBuf &d_blkoff, pp::DevBuf &d_nl, u64 *n_nl,
                   u32 *not_ascii) {
     hipStream_t st = ctx->stream;
@@ -362,32 +296,15 @@ int newline_index(pp_ctx *ctx, const u8 *d_text, u64 size, pp::DevBuf &d_blk, pp
     if (!n_blk) return PP_OK;
     int rc;
     if ((rc = pp::dev_ensure(ctx, d_blk, (n_blk + 1) * 4)) || (rc = pp::dev_ensure(ctx, d_blkoff, (n_blk + 1) * 8))) return rc;
-    static const bool two_pass = !(getenv("PP_NL_ONE_PASS") && atoi(getenv("PP_NL_ONE_PASS")) != 0);
-    if (two_pass) {
-        PP_HIPCHK(ctx, hipMemsetAsync((u32 *)d_blk.p + n_blk, 0, 4, st));
-        hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)d_blk.p);
-        hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)d_blk.p, n_blk, (u64 *)d_blkoff.p);
-        if ((rc = fetch(ctx, (const u64 *)d_blkoff.p + n_blk, n_nl))) return rc;
-        if ((rc = fetch(ctx, (const u32 *)d_blk.p + n_blk, not_ascii))) return rc;
-        if (*not_ascii) return PP_OK;
-        if ((rc = pp::dev_ensure(ctx, d_nl, std::max<u64>(1, *n_nl) * 8))) return rc;
-        hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)d_blkoff.p, (u64 *)d_nl.p);
-        return PP_OK;
-    }
-    if ((rc = pp::dev_ensure(ctx, d_nl, std::max<u64>(d_nl.cap, (size / 64 + 1024) * 8)))) return rc;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const u64 cap = d_nl.cap / 8;
-        PP_HIPCHK(ctx, hipMemsetAsync(d_blk.p, 0, 8, st));
-        PP_HIPCHK(ctx, hipMemsetAsync(d_blkoff.p, 0, (n_blk + 1) * 8, st));
-        hipLaunchKernelGGL(k_nl_index, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)d_blk.p, (u64 *)d_blkoff.p, (u32)n_blk,
-                           (u64 *)d_nl.p, cap);
-        u32 ctl[2] = {0, 0};
-        if ((rc = fetch(ctx, (const u64 *)d_blkoff.p + n_blk, n_nl)) || (rc = fetch(ctx, (const u32 *)d_blk.p, ctl, 2))) return rc;
-        *not_ascii = ctl[1];
-        if (*not_ascii || *n_nl <= cap) return PP_OK;
-        if ((rc = pp::dev_ensure(ctx, d_nl, *n_nl * 8))) return rc;  // (a text of very short lines: once more, with the room it needs)
-    }
-    return ctx->fail(PP_ERR_HIP, "the newline index came out larger than its own count");
+    PP_HIPCHK(ctx, hipMemsetAsync((u32 *)d_blk.p + n_blk, 0, 4, st));
+    hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (u32 *)d_blk.p);
+    hipLaunchKernelGGL(k_tscan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)d_blk.p, n_blk, (u64 *)d_blkoff.p);
+    if ((rc = fetch(ctx, (const u64 *)d_blkoff.p + n_blk, n_nl))) return rc;
+    if ((rc = fetch(ctx, (const u32 *)d_blk.p + n_blk, not_ascii))) return rc;
+    if (*not_ascii) return PP_OK;
+    if ((rc = pp::dev_ensure(ctx, d_nl, std::max<u64>(1, *n_nl) * 8))) return rc;
+    hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_blk), dim3(1024), 0, st, d_text, (const u64 *)d_blkoff.p, (u64 *)d_nl.p);
+    return PP_OK;
 }
 
 }  // namespace

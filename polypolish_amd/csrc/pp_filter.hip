@@ -76,56 +76,74 @@ __device__ __forceinline__ u8 pass_qc(const FileDev &self, u32 a, u32 n_this, co
 
 // ONE pass over the reads (round 5; rounds 1-4: k_ref_end, k_samples and k_pairs -- three passes, 557 MB for the 140 MB
 // SURVEY 8d prices).  One lane per read: the sampling loop of get_insert_size_thresholds (filter.rs:155-167) for a read
-// with one alignment in each file, both ends out of the runs in registers; and the verdict of alignment_pass_qc for every
+// with one alignment in each file, both ends out of the runs in registers.  The verdict of alignment_pass_qc for every
 // alignment that needs no thresholds for it -- its read has one alignment in this file, or none in the other: all of them
-// in a job without multi-mapped reads.  The reads whose verdicts need the thresholds (several alignments here, at least one
+// in a job without multi-mapped reads -- is "pass": the host fills both verdict arrays with it before the launch.  The reads whose verdicts need the thresholds (several alignments here, at least one
 // there) are only listed, for k_filter_listed.  `poisoned`: an end is needed that the reference could not have parsed.
 __global__ __launch_bounds__(256) void k_filter_reads(u32 n_reads, FileDev f1, FileDev f2, u8 *__restrict__ orient,
-                                                      u32 *__restrict__ insert, u8 *__restrict__ pass1, u8 *__restrict__ pass2,
-                                                      u32 *__restrict__ list, u32 *__restrict__ n_list, u32 *__restrict__ poisoned) {
+                                                      u32 *__restrict__ insert,
+                                                      u32 *__restrict__ list, u32 *__restrict__ blk_cnt, u32 *__restrict__ any_listed,
+                                                      u32 *__restrict__ poisoned) {
+    __shared__ u32 s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
-    const u32 n1 = g1e - g1, n2 = g2e - g2;
-    u8 o = 255;
-    u32 ins = 0;
-    if (n1 == 1u && n2 == 1u) {
-        const u32 a = f1.grp_idx[g1], b = f2.grp_idx[g2];
-        pass1[a] = 1;
-        pass2[b] = 1;
-        if (f1.ref_id[a] == f2.ref_id[b]) {
-            const u64 s1 = f1.ref_start[a], s2 = f2.ref_start[b];
-            const u64 e1 = ref_end_of(f1, a, s1), e2 = ref_end_of(f2, b, s2);
-            if (e1 == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
-            o = (u8)orientation_of(f1.flags[a], s1, e1, f2.flags[b], s2, e2);
-            ins = insert_of(s1, e1, s2, e2);
-        }
-    } else if ((n1 > 1u && n2 > 0u) || (n2 > 1u && n1 > 0u)) {
-        list[atomicAdd(n_list, 1u)] = r;
-    } else {  // (one alignment here and none there, several here and none there, none at all: everything passes)
-        for (u32 j = g1; j < g1e; j++) pass1[f1.grp_idx[j]] = 1;
-        for (u32 j = g2; j < g2e; j++) pass2[f2.grp_idx[j]] = 1;
+    bool listed = false;
+    if (r < n_reads) {
+        const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
+        const u32 n1 = g1e - g1, n2 = g2e - g2;
+        u8 o = 255;
+        u32 ins = 0;
+        if (n1 == 1u && n2 == 1u) {
+            const u32 a = f1.grp_idx[g1], b = f2.grp_idx[g2];
+            if (f1.ref_id[a] == f2.ref_id[b]) {
+                const u64 s1 = f1.ref_start[a], s2 = f2.ref_start[b];
+                const u64 e1 = ref_end_of(f1, a, s1), e2 = ref_end_of(f2, b, s2);
+                if (e1 == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
+                o = (u8)orientation_of(f1.flags[a], s1, e1, f2.flags[b], s2, e2);
+                ins = insert_of(s1, e1, s2, e2);
+            }
+        } else if ((n1 > 1u && n2 > 0u) || (n2 > 1u && n1 > 0u)) {
+            listed = true;
+        }  // (else: one alignment here and none there, several here and none there, none at all -- everything passes)
+        // A verdict that needs no thresholds is "pass", and the verdict arrays were filled with it before the launch: nothing
+        // to store here (a byte per alignment at its place in FILE order -- the reads come in whatever order the loader
+        // grouped them -- would be millions of scattered read-modify-writes).
+        orient[r] = o;
+        insert[r] = ins;
     }
-    orient[r] = o;
-    insert[r] = ins;
+    // The list, in the workgroup's own stretch of it: [256 * block, + blk_cnt[block]).  (One counter for all of it -- a
+    // returning atomic per wave on ONE address -- is served every ~5 ns however few lanes ask: 0.25 ms for the 52,000 waves
+    // of a 3.3 M read job, five times the rest of the kernel.)
+    const u64 m = __ballot(listed);
+    if (m) {
+        const u32 lane = threadIdx.x & 63u, leader = (u32)__ffsll((long long)m) - 1u;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&s_cnt, (u32)__popcll(m));
+        base = (u32)__shfl((int)base, (int)leader, 64);
+        if (listed) list[blockIdx.x * blockDim.x + base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_cnt[blockIdx.x] = s_cnt;
+        if (s_cnt) *any_listed = 1u;  // (every writer writes the same)
+    }
 }
 
 // the listed reads: alignment_pass_qc with the thresholds, one lane per read, every alignment of it in either file
-__global__ __launch_bounds__(256) void k_filter_listed(const u32 *__restrict__ list, const u32 *__restrict__ n_list, FileDev f1, FileDev f2,
+__global__ __launch_bounds__(256) void k_filter_listed(const u32 *__restrict__ list, const u32 *__restrict__ blk_cnt, FileDev f1, FileDev f2,
                                                        u32 low, u32 high, u32 correct, u8 *__restrict__ pass1, u8 *__restrict__ pass2,
                                                        u32 *__restrict__ poisoned) {
-    const u32 n = *n_list;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const u32 r = list[i];
-        const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
-        for (u32 j = g1; j < g1e; j++) {
-            const u32 a = f1.grp_idx[j];
-            pass1[a] = pass_qc(f1, a, g1e - g1, f2, g2, g2e, low, high, correct, poisoned);
-        }
-        for (u32 j = g2; j < g2e; j++) {
-            const u32 a = f2.grp_idx[j];
-            pass2[a] = pass_qc(f2, a, g2e - g2, f1, g1, g1e, low, high, correct, poisoned);
-        }
+    if (threadIdx.x >= blk_cnt[blockIdx.x]) return;  // (the grid and the workgroups are k_filter_reads')
+    const u32 r = list[blockIdx.x * blockDim.x + threadIdx.x];
+    const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
+    for (u32 j = g1; j < g1e; j++) {
+        const u32 a = f1.grp_idx[j];
+        pass1[a] = pass_qc(f1, a, g1e - g1, f2, g2, g2e, low, high, correct, poisoned);
+    }
+    for (u32 j = g2; j < g2e; j++) {
+        const u32 a = f2.grp_idx[j];
+        pass2[a] = pass_qc(f2, a, g2e - g2, f1, g1, g1e, low, high, correct, poisoned);
     }
 }
 
@@ -194,7 +212,7 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
             ctx->f_refend_ptr[f] = (const uint64_t *)p;
         }
     }
-    int rcf = dev_ensure(ctx, ctx->f_poisoned, 8);  // [0] poisoned, [1] number of listed reads
+    int rcf = dev_ensure(ctx, ctx->f_poisoned, 8);  // [0] poisoned, [1] some read is listed for k_filter_listed
     if (rcf) return rcf;
     PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_poisoned.p, 0, 8, ctx->stream));
     PP_HIPCHK(ctx, hipGetLastError());
@@ -204,7 +222,7 @@ extern "C" int pp_filter_begin(pp_ctx *ctx, const pp_filter_input *in, int mem) 
 
 // the reference's unwrap() on a run length that does not fit usize (alignment.rs:141)
 static int check_poisoned(pp_ctx *ctx) {
-    uint32_t w[2] = {0, 0};  // [1]: the number of listed reads (final once k_filter_reads has run)
+    uint32_t w[2] = {0, 0};  // [1]: some read is listed (final once k_filter_reads has run)
     PP_HIPCHK(ctx, hipMemcpyAsync(w, ctx->f_poisoned.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PP_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t flag = w[0];
@@ -219,7 +237,9 @@ static int filter_reads(pp_ctx *ctx) {
     int rc;
     if ((rc = dev_ensure(ctx, ctx->f_orient, n))) return rc;
     if ((rc = dev_ensure(ctx, ctx->f_insert, (size_t)n * 4))) return rc;
-    if ((rc = dev_ensure(ctx, ctx->f_list, (size_t)n * 4))) return rc;
+    const uint32_t n_blocks = (n + 255u) / 256u;
+    if ((rc = dev_ensure(ctx, ctx->f_list, (size_t)n_blocks * 256 * 4))) return rc;
+    if ((rc = dev_ensure(ctx, ctx->f_blkcnt, (size_t)n_blocks * 4))) return rc;
     for (int f = 0; f < 2; f++) {
         const uint64_t na = ctx->fdev.file[f].n_aln;
         if ((rc = dev_ensure(ctx, ctx->f_pass[f], na))) return rc;
@@ -228,9 +248,9 @@ static int filter_reads(pp_ctx *ctx) {
     }
     if (n) {
         timer_begin(ctx, "samples");
-        hipLaunchKernelGGL(k_filter_reads, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0), file_dev(ctx, 1),
-                           (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u8 *)ctx->f_pass[0].p, (u8 *)ctx->f_pass[1].p,
-                           (u32 *)ctx->f_list.p, (u32 *)ctx->f_poisoned.p + 1, (u32 *)ctx->f_poisoned.p);
+        hipLaunchKernelGGL(k_filter_reads, dim3(n_blocks), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0), file_dev(ctx, 1),
+                           (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u32 *)ctx->f_list.p, (u32 *)ctx->f_blkcnt.p,
+                           (u32 *)ctx->f_poisoned.p + 1, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
     }
@@ -263,9 +283,9 @@ extern "C" int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t
         if (int rc = filter_reads(ctx)) return rc;
     if (ctx->fdev.n_reads && ctx->filter_n_listed != 0) {  // (0: pp_filter_samples read the count back -- a job without multi-mapped reads)
         timer_begin(ctx, "pairs");
-        hipLaunchKernelGGL(k_filter_listed, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)ctx->f_list.p, (const u32 *)ctx->f_poisoned.p + 1,
-                           file_dev(ctx, 0), file_dev(ctx, 1), low, high, (u32)orientation, (u8 *)ctx->f_pass[0].p, (u8 *)ctx->f_pass[1].p,
-                           (u32 *)ctx->f_poisoned.p);
+        hipLaunchKernelGGL(k_filter_listed, dim3((ctx->fdev.n_reads + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32 *)ctx->f_list.p,
+                           (const u32 *)ctx->f_blkcnt.p, file_dev(ctx, 0), file_dev(ctx, 1), low, high, (u32)orientation, (u8 *)ctx->f_pass[0].p,
+                           (u8 *)ctx->f_pass[1].p, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
     }

@@ -183,12 +183,12 @@ struct pp_ctx {
     pp::DevBuf b_split[13];  // pp_shard_split's scratch (pp_shard_dev.hip)
 
     // ---- filter job ----
-    pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert, f_poisoned, f_list;
+    pp::DevBuf f_in[2][9], f_refend[2], f_pass[2], f_orient, f_insert, f_poisoned, f_list, f_blkcnt;
     pp_filter_input fdev{};
     const uint64_t *f_refend_ptr[2] = {nullptr, nullptr};
     bool filter_open = false;
     bool filter_reads_done = false;  // the pass over the reads (k_filter_reads) of the open filter job has run
-    int64_t filter_n_listed = -1;    // the reads it listed for k_filter_listed, once read back (-1: not known on the host)
+    int64_t filter_n_listed = -1;    // whether it listed any read for k_filter_listed, once read back (-1: not known on the host)
 
     int fail(int code, const char *fmt, ...) {
         char buf[1024];

@@ -1264,7 +1264,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_runs, &ctx->b_first, &ctx->b_xcnt, &ctx->b_xent, &ctx->b_need_win, &ctx->b_win_lo, &ctx->b_win_hi, &ctx->b_later,
                      &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
-                     &ctx->f_insert, &ctx->f_list};
+                     &ctx->f_insert, &ctx->f_list, &ctx->f_blkcnt};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &b : ctx->b_in) dev_free(b);
     for (auto &b : ctx->b_split) dev_free(b);

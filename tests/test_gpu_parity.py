@@ -793,8 +793,7 @@ def test_window_grouped_seq_layout_of_the_tokenizer(ctx, pp, orc, tmp_path):
     oracle_fasta = orc.polish_files(ds["fasta"], sams)["fasta"]
     for env in (dict(), dict(PP_SEQ_LAYOUT="window"), dict(PP_SEQ_LAYOUT="file"), dict(PP_SEQ4="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0"),
                 dict(PP_DEVICE_INGEST="0"), dict(PP_DEVICE_INGEST="0", PP_SEQ_LAYOUT="file"), dict(PP_DEVICE_INGEST="0", PP_SEQ4="0"),
-                dict(PP_WO="0"), dict(PP_DEVICE_INGEST="0", PP_WO="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0"),
-                dict(PP_NL_ONE_PASS="1")):   # (the newline index in one pass over the text: k_nl_index)
+                dict(PP_WO="0"), dict(PP_DEVICE_INGEST="0", PP_WO="0"), dict(PP_SEQ_LAYOUT="file", PP_SEQ4="0", PP_WO="0")):
         r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout == oracle_fasta, (env, r.stderr[-400:])
 
@@ -1923,10 +1922,9 @@ def test_sharded_jobs_take_the_direct_path(ctx, pp, orc, long_read):
 
 
 def test_newline_index_of_a_text_of_very_short_lines(orc, tmp_path):
-    """PP_NL_ONE_PASS=1: the device front ends index the newlines of a SAM text in one pass (k_nl_index, a chained scan),
-    into room for one newline per 64 bytes; a text with more of them (here: 300,000 four-byte header lines in front of the
-    records) is counted, given the room it needs and indexed once more -- polish and filter through the CLI, both text front
-    ends, against the oracle's bytes (and the default two-pass index on the same text)."""
+    """A SAM text with far more lines than records -- 300,000 four-byte header lines in front of them, more newlines than one
+    per 64 bytes of text -- through both device text front ends (polish: the tokenizer; filter: the device loader), against
+    the oracle's bytes."""
     ds = synth.rich_dataset(str(tmp_path), seed=131, contig_lens=(20_000, 3_000), coverage=20, repeat_len=200, repeat_copies=2)
     sams = []
     for i, src in enumerate((ds["sam1"], ds["sam2"])):
@@ -1942,13 +1940,12 @@ def test_newline_index_of_a_text_of_very_short_lines(orc, tmp_path):
     assert os.path.getsize(sams[0]) // 64 + 1024 < 300_000
     exe = os.path.join(ROOT, "bin", "polypolish")
     want = orc.polish_files(ds["fasta"], sams)["fasta"]
-    for env in (dict(), dict(PP_NL_ONE_PASS="1")):
-        r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, env=dict(os.environ, **env))
-        assert r.returncode == 0 and r.stdout == want, (env, r.stderr[-400:])
+    r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True)
+    assert r.returncode == 0 and r.stdout == want, r.stderr[-400:]
     o1, o2 = str(tmp_path / "f1.sam"), str(tmp_path / "f2.sam")
     w1, w2 = str(tmp_path / "w1.sam"), str(tmp_path / "w2.sam")
     orc.filter_files(sams[0], sams[1], w1, w2)
     r = subprocess.run([exe, "filter", "--in1", sams[0], "--in2", sams[1], "--out1", o1, "--out2", o2], capture_output=True,
-                       env=dict(os.environ, PP_DEVICE_FILTER="1", PP_NL_ONE_PASS="1"))
+                       env=dict(os.environ, PP_DEVICE_FILTER="1"))
     assert r.returncode == 0, r.stderr[-400:]
     assert open(o1, "rb").read() == open(w1, "rb").read() and open(o2, "rb").read() == open(w2, "rb").read()

@@ -13,4 +13,4 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp
 PP_DEVICE_FILTER=1 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tk_filter -- python -c "import sys; sys.path.insert(0, '$ROOT'); import torch, polypolish_amd as pp; pp.filter('/tmp/flt_1.sam', '/tmp/flt_2.sam', '/tmp/o1.sam', '/tmp/o2.sam')" > /dev/null 2> "$OUT/filter.log"
 cd "$ROOT"
 python tools/prof_summary.py /tmp/tk_polish /tmp/tk_filter > "$OUT/tokenizers_kernel_trace.txt"
-cat "$OUT/tokenizers_kernel_trace.txt" | head -70
+cat "$OUT/tokenizers_kernel_trace.txt" | head -100
