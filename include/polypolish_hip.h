@@ -187,7 +187,12 @@ typedef struct {
     uint64_t polished_len;     /* bytes of the polished sequence                      */
     uint64_t changed;          /* positions with status Changed                       */
     uint64_t zero_depth;       /* positions with depth == 0.0                         */
-    double depth_sum;          /* sum of per-position depth (cosmetic: mean depth)    */
+    double depth_sum;          /* sum of per-position depth (cosmetic: the "mean read depth" line of the log, polish.rs:206-227).
+                                * Exact where every depth share 1/k is a power of two; a position with other shares adds its depth
+                                * rounded to 2^-10 (its VOTE is exact -- interval test or ordered replay -- its contribution to this
+                                * sum is not replayed): |depth_sum - reference| <= polished_len * 2^-11 + 1e-6 * depth_sum, i.e. the
+                                * mean depth printed to one decimal can differ in that digit only when it lies within 0.0005 of a
+                                * rounding boundary (tests/test_gpu_parity.py compares the sums under this bound). */
 } pp_contig_stats;
 
 /* Optional, between pp_polish_begin and pp_polish_finish: restrict what contig c EMITS to its positions

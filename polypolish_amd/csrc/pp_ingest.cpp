@@ -754,29 +754,38 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             const uint64_t w = (ctg_off[a.contig] + a.ref_start) / WINDOW;
             return (size_t)std::min<uint64_t>(w, n_win - 1);
         };
-        HugeBuf<uint64_t> wcur;  // [part][window]: first the bytes, then where the part's next record of the window goes
-        HugeBuf<uint64_t> wcnt;  // [part][window]: the same for the records themselves (slots of the window-order mirror)
+        // One row of the two tables for several parts in a row (file order) when a row per part would be large: the tables
+        // are [rows][windows] of 8 bytes -- 64 threads over a 3 Gbp assembly would be 1.5 GB of them per SAM file, cleared and
+        // scanned whatever the file holds -- so beyond 32 M entries a table the parts share rows, and the parts of one row are
+        // filled by one thread, one after the other.  (PP_INGEST_ROWS: tuning / tests.)
+        const long forced_rows = getenv("PP_INGEST_ROWS") ? atol(getenv("PP_INGEST_ROWS")) : 0;
+        const size_t rows = forced_rows > 0 ? std::min<size_t>(threads, (size_t)forced_rows)
+                                            : std::min<size_t>(threads, std::max<size_t>(1, ((size_t)32 << 20) / n_win));
+        auto row_first = [&](size_t r) { return (r * threads + rows - 1) / rows; };  // the parts of row r: [row_first(r), row_first(r + 1))
+        HugeBuf<uint64_t> wcur;  // [row][window]: first the bytes, then where the row's next record of the window goes
+        HugeBuf<uint64_t> wcnt;  // [row][window]: the same for the records themselves (slots of the window-order mirror)
         if (grouped || mirror) {
-            wcur.resize(threads * n_win);
-            wcnt.resize(threads * n_win);
-            parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
-                for (size_t t = lo; t < hi; t++) {
-                    uint64_t *row = wcur.data() + t * n_win, *crow = wcnt.data() + t * n_win;
+            wcur.resize(rows * n_win);
+            wcnt.resize(rows * n_win);
+            parallel_for(rows, threads, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t r = lo; r < hi; r++) {
+                    uint64_t *row = wcur.data() + r * n_win, *crow = wcnt.data() + r * n_win;
                     memset(row, 0, n_win * sizeof(uint64_t));
                     memset(crow, 0, n_win * sizeof(uint64_t));
-                    for (size_t i = 0; i < parts[t].outs.size(); i++) {
-                        const OutRec &o = parts[t].outs[i];
-                        const size_t w = window_of(*o.rec);
-                        row[w] += seq_room(o.star ? o.src->seq_n : o.rec->seq_n);
-                        crow[w] += 1;
-                    }
+                    for (size_t t = row_first(r); t < row_first(r + 1); t++)
+                        for (size_t i = 0; i < parts[t].outs.size(); i++) {
+                            const OutRec &o = parts[t].outs[i];
+                            const size_t w = window_of(*o.rec);
+                            row[w] += seq_room(o.star ? o.src->seq_n : o.rec->seq_n);
+                            crow[w] += 1;
+                        }
                 }
             });
             std::vector<uint64_t> wtot(n_win + 1, 0), ctot(n_win + 1, 0);
             parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
                 for (size_t w = lo; w < hi; w++) {
                     uint64_t sum = 0, cs = 0;
-                    for (size_t t = 0; t < threads; t++) { sum += wcur[t * n_win + w]; cs += wcnt[t * n_win + w]; }
+                    for (size_t t = 0; t < rows; t++) { sum += wcur[t * n_win + w]; cs += wcnt[t * n_win + w]; }
                     wtot[w + 1] = sum;
                     ctot[w + 1] = cs;
                 }
@@ -785,7 +794,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             parallel_for(n_win, threads, [&](size_t lo, size_t hi, unsigned) {
                 for (size_t w = lo; w < hi; w++) {
                     uint64_t run = seq0 + wtot[w], crun = base + ctot[w];
-                    for (size_t t = 0; t < threads; t++) {
+                    for (size_t t = 0; t < rows; t++) {
                         const uint64_t v = wcur[t * n_win + w], c = wcnt[t * n_win + w];
                         wcur[t * n_win + w] = run;
                         wcnt[t * n_win + w] = crun;
@@ -800,8 +809,9 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
             }
             lap("window layout");
         }
-        parallel_for(threads, threads, [&](size_t lo, size_t hi, unsigned) {
-            for (size_t t = lo; t < hi; t++) {
+        parallel_for(rows, threads, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t row = lo; row < hi; row++)
+            for (size_t t = row_first(row); t < row_first(row + 1); t++) {
                 const Part &P = parts[t];
                 uint64_t so = seq0 + p_seq[t], co = cig0 + p_cig[t], no = nam0 + p_nam[t];
                 for (size_t i = 0; i < P.outs.size(); i++) {
@@ -814,7 +824,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                     const char *s = o.star ? o.src->seq : a.seq;
                     const size_t sn = o.star ? o.src->seq_n : a.seq_n;
                     if (grouped) {  // its place in its window's region
-                        uint64_t &cur = wcur[t * n_win + window_of(a)];
+                        uint64_t &cur = wcur[row * n_win + window_of(a)];
                         so = cur;
                         cur += seq_room(sn);
                     }
@@ -844,7 +854,7 @@ static int ingest_impl(pp_ingest *I, const char *path, const char *ext_text, siz
                         w.seq_off = I->seq_off[d];
                         w.op0 = a.run_n == 1 ? o.runs[0] : PP_WO_MULTI_RUN;
                         w.file_idx = (uint32_t)d;
-                        I->wo[wcnt[t * n_win + window_of(a)]++] = w;
+                        I->wo[wcnt[row * n_win + window_of(a)]++] = w;
                     }
                     co += a.run_n;
                     I->name_off[d] = no;

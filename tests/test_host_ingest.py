@@ -211,6 +211,14 @@ def test_ingest_is_independent_of_the_thread_count(orc, tmp_path, monkeypatch):
         if ref is None:
             ref = cur
         assert cur == ref, f"thread count {t} changed the ingest"
+    # ... nor on how many rows the window multisplit's tables have (parts that share a row are placed one after the other,
+    # in file order: a large assembly's tables are bounded this way)
+    monkeypatch.setenv("PP_INGEST_THREADS", "7")
+    for rows in ("1", "3", "7"):
+        monkeypatch.setenv("PP_INGEST_ROWS", rows)
+        names, descs, off, bases, recs, counts = pp.ingest(ds["fasta"], sams, max_errors=10)
+        assert (counts, {k: v.tobytes() for k, v in recs.items()}) == ref, f"{rows} rows changed the ingest"
+    monkeypatch.delenv("PP_INGEST_ROWS")
     # an error deep in the file: same message and line number whatever the slicing
     lines = open(ds["sam1"]).read().split("\n")
     n = len(lines)
