@@ -148,8 +148,8 @@ typedef struct {
     /* Optional with wo (0 / NULL = not known): the mirror as RUNS.  wo_n_runs stretches of entries, one behind the other
      * (one per SAM file, as the library's ingests write it), each of them window-grouped IN ASCENDING WINDOW ORDER;
      * wo_run_end[r] = the index one past the last entry of run r (ascending; the last one = n_aln).  HOST memory whatever
-     * the batch's `mem` (a handful of numbers; copied by pp_polish_add).  With it -- and in a job that is not sharded
-     * (pp_polish_set_emit) -- the pileup kernel takes the records that are one short M run inside their contig STRAIGHT from
+     * the batch's `mem` (a handful of numbers; copied by pp_polish_add).  With it -- a sharded job (pp_polish_set_emit)
+     * included: pp_shard_split restricts the table along with the mirror -- the pileup kernel takes the records that are one short M run inside their contig STRAIGHT from
      * the mirror, window by window (round 5: no bucketing pass, no work items for them); one streaming pass over the
      * mirror validates every record as before, finds where each window's entries start in every run and cuts work items
      * only for the others (indels, long reads) and for the reads that reach into the next window.  A hint like the
