@@ -16,6 +16,8 @@
 //   k_tile     (pp_k_tile.h, DIRECT) the window's mirror entries through the plain class, then its extras like any items
 //   k_xmat     the few windows with positions left for the exact replays get their items written out (k_exact / k_exact2
 //              read items, as before)
+// A rank of a sharded job (pp_polish_set_emit) takes this path as well, over the job's own coordinates: k_prepd / k_prepg /
+// k_winplan see all windows (a few words each), k_tile works on the rank's.
 // An entry order that is not what the run table promises (any permutation is a valid mirror) makes k_prepd raise
 // DE_MIRROR_ORDER: every later kernel returns at once and the host runs the job over the bucketing path.
 #pragma once

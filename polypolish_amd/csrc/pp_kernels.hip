@@ -1,5 +1,10 @@
 // pp_kernels.hip -- gfx950 kernels of the polish hot path (seam B of include/polypolish_hip.h).
 //
+// Two pipelines, the same results.  A batch that brings its window-order mirror AND the mirror's run table -- what the
+// library's own ingests hand over, and what pp_shard_split leaves a rank of a sharded job -- takes the DIRECT path (round 5,
+// pp_k_direct.h): k_meta_init (done ahead, at the end of the job before) -> k_prepd -> k_prepg -> k_winplan ->
+// k_tile_direct -> [k_xmat, k_exact2 x 3, k_exact: only when something was flagged for them] -> k_scan -> k_emit; no work
+// items for the bulk of the records.  Everything else takes the BUCKETING path of rounds 1-4:
 // Pipeline (one pp_polish_finish, 13 stream operations):
 //   k_meta_init  the job's metadata block (status, counters, heavy-window list)
 //   k_prep     persistent blocks stream the alignment records: the bulk (one short M run inside its contig) on the
