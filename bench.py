@@ -175,7 +175,8 @@ def live_traffic(argv_tail, kernel):
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if row["Counter_Name"] == counter and kernel + "(" in row["Kernel_Name"].replace("pp::", ""):
+                        kn = row["Kernel_Name"].replace("pp::", "")  # (k_tile's instances are templates: "k_tile_direct<5, true>(...)")
+                        if row["Counter_Name"] == counter and (kernel + "(" in kn or kernel + "<" in kn):
                             vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None
@@ -749,7 +750,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if traffic is None and default_shape and args.config == 1 and dom_name and os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("kernels", {}).get(dom_kernel, {}).get("hbm_bytes")
+            kk = json.load(f).get("kernels", {})
+            traffic = next((v.get("hbm_bytes") for k, v in kk.items() if k == dom_kernel or k.startswith(str(dom_kernel) + "<")), None)
         if traffic is not None:
             traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes of this command, not this run)"
 

@@ -87,6 +87,8 @@ enum DevErr : uint32_t {
     DE_MIRROR_ORDER = 16,   // direct path (pp_k_direct.h): the mirror's entries are not in the order its run table promises
                             // -> the host runs the job over the bucketing path (always reported at the largest index, so
                             // that the error of any record wins)
+    DE_GW_HINT = 17,        // k_tile: the instance the host launched does not take the job's longest fast-class read (meta
+                            // word 9) -> the host reruns with the one that does (same index as DE_MIRROR_ORDER)
 };
 
 struct DevBuf {
@@ -153,6 +155,7 @@ struct pp_ctx {
     std::vector<uint32_t> runs_on_dev;  // what b_runs holds (identical tables are not uploaded again)
     size_t xcap = 0;                    // room for extras per window (grow-only)
     bool no_direct = false;             // this job is being rerun over the bucketing path (DE_MIRROR_ORDER)
+    uint32_t maxlen_hint = 0;           // the longest fast-class read of the context's last job (meta word 9): picks k_tile's instance for the next one (DE_GW_HINT)
     bool last_direct = false;           // the last pass over the pipeline took the direct path
     bool nothing_flagged_last = false;  // the job before had no position flagged for the exact replays (run_pipeline: their launches are then left out until this job's metadata say otherwise)
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything

@@ -13,8 +13,10 @@ typedef uint8_t u8;
 // class (+1 at the first kept position of a read, -1 one past the last; prefix-summed before the
 // vote) and MIS the number of fast-class bases that differ from the assembly, so that the tally of
 // the assembly's own base is  explicit + COV - MIS  without touching LDS once per matching base.
-enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_DEF = 6, ROW_COV = 7,
-       ROW_MIS = 8, N_ROWS = 9 };
+// (MIS and COV before DEF: their rows start below 64 KiB, so a tally's second atomic and a read's two coverage atomics take
+// the row as the instruction's 16-bit offset; the deficit row is touched by the rare jobs with shared reads only)
+enum { ROW_A = 0, ROW_C = 1, ROW_T = 2, ROW_G = 3, ROW_DEL = 4, ROW_OTH = 5, ROW_MIS = 6, ROW_COV = 7,
+       ROW_DEF = 8, N_ROWS = 9 };
 
 struct KeyRec {    // debug only: one distinct non-ACGT key of a position (len 0 = the deletion key "-")
     u64 off;

@@ -448,7 +448,8 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const TileSha
 // What needs a byte as it was delivered reads seq as before: the walk over a long homopolymer tail, and the whole trim
 // when the read ends in a byte that has no code of its own (two different bytes may share code 15).
 constexpr int ASM4_PAD = 32;                     // nibbles in front of the window's first position (as ASM_PAD)
-constexpr int ASM4_WORDS = TILE / 8 + 12;        // 8 positions per dword; a lane reads five dwords from (P0 + ASM4_PAD) / 8 on
+constexpr int ASM4_WORDS = TILE / 8 + 24;        // 8 positions per dword; a lane reads five dwords from (P0 + ASM4_PAD) / 8 on -- and
+                                                 // (direct_bulk) the 21 dwords under a 160-base read that starts at the window's last position
 constexpr u32 SEQ4_ASM_OTHER = 14;
 
 // bit k of the result <=> nibble k of x is not zero
@@ -484,6 +485,13 @@ __device__ __forceinline__ u32 pmask4(u32 b) {
 }
 __device__ __forceinline__ int row_of_code(u32 code) {
     return code < 4u ? (int)code : (code == (u32)PP_SEQ4_DASH ? ROW_DEL : ROW_OTH);
+}
+// the same in two instructions: a byte table in a register pair (v_perm_b32 with the selector min(code, 7): selector bytes
+// 0..7 pick that byte of the table; every code from 6 on lands on a ROW_OTH entry)
+__device__ __forceinline__ int row_of_code8(u32 code) {
+    static_assert(ROW_A == 0 && ROW_C == 1 && ROW_T == 2 && ROW_G == 3 && ROW_DEL == 4 && ROW_OTH == 5 && PP_SEQ4_N == 4 && PP_SEQ4_DASH == 5 &&
+                  PP_SEQ4_OTHER == 15, "the table");
+    return (int)__builtin_amdgcn_perm(0x05050405u, 0x03020100u, min(code, 7u));
 }
 
 // The trim (alignment.rs:364-378) off the codes of the read's last EIGHT bases: `t` = the four bytes of the mirror that end
@@ -615,6 +623,23 @@ __device__ __forceinline__ void plain_apply4(u32 *cnt, u32 *ndbits, const TileSh
 //    other and masked to nothing.
 constexpr int PMASK_BASE = 128;                   // TileShare::pmask[PMASK_BASE + b] = pmask4(clamp(b, 0, 32)), b = -128 .. 161
 constexpr int PMASK_WORDS = PMASK_BASE + 162;
+// ... the table, worked out by the compiler (k_tile's workgroups copy it into LDS)
+constexpr u32 pmask4_c(u32 b) {
+    u32 m = 0;
+    for (u32 d = 0; d < 4u; d++) {
+        const int n0 = (int)b - 8 * (int)d;
+        const u32 n = (u32)(n0 < 0 ? 0 : (n0 > 8 ? 8 : n0));
+        m |= (n == 8u ? 0x11111111u : (0x11111111u & ((1u << (4u * n)) - 1u))) << d;
+    }
+    return m;
+}
+struct PmaskTab {
+    u32 v[PMASK_WORDS];
+    constexpr PmaskTab() : v{} {
+        for (int i = 0; i < PMASK_WORDS; i++) v[i] = pmask4_c((u32)(i - PMASK_BASE < 0 ? 0 : (i - PMASK_BASE > 32 ? 32 : i - PMASK_BASE)));
+    }
+};
+__device__ const PmaskTab g_pmask_tab{};
 
 // A read the pass cannot take although PlainCfg<5>::ok says plain: an odd start whose LAST base counts (the flank in front
 // of an indel is not trimmed) when the length fills its last chunk -- one base too many for NCH chunks.  (A trimmed read
@@ -846,17 +871,38 @@ __device__ __forceinline__ void slow_short(u32 *cnt, const TileShare &S, const u
     }
 }
 
+// the items a wave takes when they are not the window's mirror entries (tile_items, !REC)
+struct ItemList {
+    u32 lo, n, stride;
+    const u32 *indirect;  // (LDS) the items are ent[indirect[lo + stride * u]] instead of ent[lo + stride * u], or null
+    // With `defer` a SLOW item (indels in several runs, a long read: one memory round trip each, one after the other) is
+    // not tallied: its index goes into the list (LDS, `defer_cap` entries, `*defer_n` counts them) for a later call in which
+    // all waves take a share (tile_window) -- a window whose reads cross two planted indels has hundreds of them, and a pass
+    // worth of extras holds a sixteenth or a fifth of the window's, not a two-hundredth.  An item the list has no room for is
+    // tallied on the spot.
+    u32 *defer, *defer_n;
+    u32 defer_cap;
+};
+// ... a wave's contiguous slice of [e0, e1), whole passes of IPP items (the bucketing path)
+template <u32 IPP>
+__device__ __forceinline__ ItemList wave_slice(u32 e0, u32 e1, u32 wave) {
+    constexpr u32 WAVES = TILE_THREADS / 64;
+    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
+    const u32 lo = min(e1, e0 + wave * per_wave);
+    return ItemList{lo, min(e1, lo + per_wave) - lo, 1u, nullptr, nullptr, nullptr, 0u};
+}
+
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
 // The work items of one window, one batch per wave at a time: one coalesced load of the batch's 16-byte
 // records, then the plain class IPP items per pass, then the other classes one item per pass.  Latency is
 // hidden by the other 7 waves of the SIMD, not by software pipelining of the passes (which measured slower).
 template <int GW, bool P4, bool REC>
 __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_ndbits, const TileShare &S, const u32 *asm_w,
-                                           const u32 *asm4, const uint4 *ent, const RecMap &M, u32 e0, u32 e1, u32 wave, u32 lane) {
+                                           const u32 *asm4, const uint4 *ent, const RecMap &M, u32 e0, u32 e1, const ItemList &X, u32 wave, u32 lane) {
     typedef PlainCfg<GW> C;
     // with the 4-bit mirror and reads of up to 192 bases: one lane per read, 64 items per batch and pass (wide4_pass)
     constexpr bool WIDE = P4 && GW == 5;
-    constexpr u32 IPP = WIDE ? 1u : C::IPP, BATCH = WIDE ? 64u : C::BATCH;
+    constexpr u32 BATCH = WIDE ? 64u : C::BATCH;
     // REC (direct path): a wave's work is ONE list -- its share of the window's mirror entries (M.nv of them from M.v0 on,
     // numbered run after run) and, behind them, its share of the window's items in memory [e0, e1) (the extras) -- so that a
     // pass is as full of the one kind as of the other: a pass costs what it costs however many of its lanes have work, and
@@ -876,10 +922,11 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     // 16 j (k_prepd writes a block's extras for the records with indels behind those for its bulk reads: in contiguous
     // slices two waves would get all of a window's slow items -- one window with two planted indels 100 bases apart, whose
     // reads have five runs, kept its workgroup for 190 us where the others take 25)
-    constexpr u32 XS = REC ? WAVES : 1u;
-    const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
-    const u32 x_lo = REC ? e0 + wave : min(e1, e0 + wave * per_wave);
-    const u32 nx = REC ? (e1 - e0 > wave ? (e1 - e0 - wave - 1u) / WAVES + 1u : 0u) : min(e1, x_lo + per_wave) - x_lo;
+    // (!REC: the caller names the wave's items -- X.lo, X.lo + X.stride, ... X.n of them: a contiguous slice of the bucketing's
+    // items, or one pass worth of a window's extras, see tile_window)
+    const u32 XS = REC ? WAVES : X.stride;
+    const u32 x_lo = REC ? e0 + wave : X.lo;
+    const u32 nx = REC ? (e1 - e0 > wave ? (e1 - e0 - wave - 1u) / WAVES + 1u : 0u) : X.n;
     const u32 nv_last = (u32)__builtin_amdgcn_readfirstlane((int)(nv ? nv - 1u : 0u));  // (uniform: kept in a scalar register)
     const u32 lo_w = 0u, hi_w = nv + nx;  // the list: u < nv a mirror entry, else item x_lo + XS * (u - nv)
     if (lo_w >= hi_w) return;
@@ -892,7 +939,11 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     // where entry u of the list lies: index of a mirror entry (two 16-byte words), or of an item
     const uint4 *const wq = A.wo;
     // (a lookup with scalar operands for a wave whose entries lie in one run or two -- base + u -- measured the same: 0.2196 vs 0.2185 ms)
-    auto index_of = [&](u32 u) -> u32 { return REC && u < nv ? rec_at(M.v0 + r_lo + min(u, nv_last)) : x_lo + XS * (u - min(u, nv)); };
+    auto index_of = [&](u32 u) -> u32 {
+        if (REC && u < nv) return rec_at(M.v0 + r_lo + min(u, nv_last));
+        const u32 x = x_lo + XS * (u - min(u, nv));
+        return !REC && X.indirect ? X.indirect[x] : x;
+    };
     // ... and its words: both words of the mirror entry, or the item's one word twice (no branch)
     auto words_at = [&](bool rec, u32 idx, uint4 &a, uint4 &b) {
         if (REC) {
@@ -943,7 +994,18 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
         };
         if (!WIDE && more) ask_for_next(0u);  // (WIDE: wide4_pass asks for them, together with its own loads)
         const u32 my_flags = is_rec ? 0u : item_flags(my.y, my.z);
-        const bool my_slow = lane < nb && (my_flags & 3u) != 0;
+        bool my_slow = lane < nb && (my_flags & 3u) != 0;
+        bool deferred = false;
+        if (!REC && X.defer && __ballot(my_slow)) {  // (rare)
+            if (my_slow) {
+                const u32 slot = atomicAdd(X.defer_n, 1u);
+                if (slot < X.defer_cap) {
+                    X.defer[slot] = index_of(eb + lane);
+                    deferred = true;
+                    my_slow = false;
+                }
+            }
+        }
         const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
         const bool my_plain = lane < nb && rec_ok && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
@@ -971,7 +1033,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             }
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
-        u64 rest = __ballot(lane < nb && rec_ok && !my_slow && !my_plain && !my_point);
+        u64 rest = __ballot(lane < nb && rec_ok && !my_slow && !deferred && !my_plain && !my_point);
         while (rest) {
             const u32 j = (u32)__ffsll((long long)rest) - 1u;
             rest &= rest - 1;
@@ -1044,6 +1106,242 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
     }
 }
 
+
+// ---- the direct path's bulk, one lane per MIRROR ENTRY (round 6) --------------------------------------------------------
+// Until round 6 a window's mirror entries went through tile_items as work items made up in registers (wo_item, unpacked
+// again by wide4_pass) in ONE list with the window's extras, a sixteenth of it per wave: ~610 vector instructions per pass
+// of 64 entries (rocprofv3 SQ_INSTS_VALU over the phase builds, profiles/r6_phases_*.txt) -- three quarters of the
+// kernel's instructions on the 200x job -- and, at 50x, sixteen passes two thirds full where eleven full ones would do.
+// A mirror entry of window w STARTS in w: no part of it lies in front of the window (lo = 0, no clamp of the assembly index:
+// asm4 has room for a read's 160 bases behind the window), its five chunks are loaded at constant offsets from one
+// address, the assembly's 21 dwords at constant offsets from another, its fields are used as they come: ~330 instructions
+// a pass.  Passes are dealt to the waves one by one (pass p, p + 16, ... of the window's entries; the window's extras
+// follow as passes of their own, tile_window): every pass but the window's last is full.  What a pass cannot take -- a bulk
+// read of fewer than 8 bases, one at the very end of the seq array -- goes the way of the other fast classes, an entry that
+// is not bulk is passed over (its pieces are among the extras).
+//
+// With the instructions down, what a wave's time consists of is its chain of memory round trips -- entries, then the
+// reads they name, pass after pass: 24 us of items per workgroup on the 200x job whatever the pass costs (the block
+// timeline of the first version of this function: as before it).  So the loads run AHEAD of the work:
+//  * a pass's entries are asked for two passes before it (begin / the top of the pass before the pass before), reduced
+//    to three registers (where the read lies, and rel | length | flags) one pass before it;
+//  * its chunks are asked for DURING the pass before it, chunk c into the registers chunk c of the current pass has
+//    just left (no second set of 20 registers: the workgroup's two-per-CU residency allows 64);
+//  * the first pass's entries and chunks are asked for before the workgroup's prologue has zeroed its counters (begin /
+//    stage between the prologue's own loads and its barrier): they need nothing the prologue writes.
+struct BulkRuns {  // the window's stretches of the mirror in two registers: lane r holds pre[r] (its entries in the runs before r; lane R: all of them) and first[r]
+    u32 pre_v, first_v, R;
+};
+__device__ __forceinline__ BulkRuns bulk_runs(const TileArgs &A, u32 w, u32 lane) {
+    BulkRuns B;
+    const u32 R = A.n_runs;
+    u32 len = 0, f0 = 0;
+    if (lane < R) {
+        f0 = A.first[(u64)lane * (A.nwin + 1u) + w];
+        len = A.first[(u64)lane * (A.nwin + 1u) + w + 1u] - f0;
+    }
+    u32 inc = len;
+    for (int o = 1; o < (int)PP_WO_MAX_RUNS; o <<= 1) {
+        const u32 t = (u32)__shfl_up((int)inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, (int)(R - 1u));
+    B.pre_v = lane < R ? inc - len : total;
+    B.first_v = f0;
+    B.R = R;
+    return B;
+}
+// (experiment builds, tools/exp_variants.sh: -DPP_EXP_NOLOAD = the chunks are not loaded, the pass works on a constant;
+// -DPP_EXP_NOCOMPARE = they are loaded and waited for, nothing is compared)
+#ifdef PP_EXP_NOLOAD
+#define PP_EXP_LOAD16(p) make_uint4((u32)(uintptr_t)(p), 0x01230123u, 0x32103210u, 0x11112222u)
+#else
+#define PP_EXP_LOAD16(p) load16_unaligned(p)
+#endif
+template <int NCH>
+struct DirectBulk {
+    BulkRuns B;
+    u32 v0, nv, n_pass;   // the entries this workgroup takes: [v0, v0 + nv) of the window's (v0: a multiple of 64), in n_pass passes
+    u32 pass;             // this wave's next pass (uniform)
+    uint4 ea, eb;         // its entries: contig, ref_start, k, seq_len | seq_off (two words), op0, file index
+    uint4 na, nb;         // ... and those of the pass after it
+    uint4 W[NCH];         // its chunks
+    u32 tail;             // the four bytes of the mirror that end with the read's last base (trim4)
+    static constexpr u32 WAVES = TILE_THREADS / 64;
+
+    __device__ __forceinline__ u32 entry_of(u32 p, u32 lane) const {  // the mirror entry this lane takes in pass p (past the end: the last one again)
+        const u32 vs = v0 + 64u * p;  // the pass's first entry (uniform)
+        const u32 v = min(vs + lane, v0 + nv - 1u);
+        u32 r = 0;
+        for (u32 j = 1; j < B.R; j++)  // (scalar: the run of the pass's first entry)
+            if (vs >= (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)j)) r = j;
+        u32 pr = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)r), nx = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
+        u32 a = (u32)__builtin_amdgcn_readlane((int)B.first_v, (int)r) + (v - pr);
+        while (__ballot(v >= nx)) {  // a pass across the end of a run (one pass per run and window)
+            r++;
+            pr = nx;
+            nx = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
+            if (v >= pr) a = (u32)__builtin_amdgcn_readlane((int)B.first_v, (int)r) + (v - pr);
+        }
+        return a;
+    }
+    // where a read's chunks are loaded from: its place in the mirror when all NCH chunk loads stay inside it (8 .. 32 NCH bases,
+    // 32 NCH nibbles from its start on inside the array: seq4 has 32 bytes of slack behind it), else the mirror's first bytes
+    // (nothing of them counts: such a read is not plain)
+    __device__ static __forceinline__ bool loadable(const TileArgs &A, const uint4 &qa, const uint4 &qb) {
+        const u64 so = (u64)qb.x | ((u64)qb.y << 32);
+        return qa.w - PLAIN_MIN_LEN <= 32u * NCH - PLAIN_MIN_LEN && so + 32u * NCH <= A.seq_bytes;
+    }
+    // (1) as soon as the window's stretches are known: the entries of this wave's first pass
+    __device__ __forceinline__ void begin(const TileArgs &A, const BulkRuns &runs, u32 v0_, u32 nv_, u32 wave, u32 lane) {
+        B = runs;
+        v0 = v0_;
+        nv = nv_;
+        n_pass = (nv + 63u) >> 6;
+        pass = wave;
+        ea = eb = na = nb = make_uint4(0, 0, 0, 0);
+        if (pass < n_pass) {
+            const u32 a = entry_of(pass, lane);
+            ea = A.wo[2ull * a];
+            eb = A.wo[2ull * a + 1];
+        }
+    }
+    // (2) when those entries are there (still in the prologue): the first pass's chunks -- from where the entry says its read
+    // lies when that is inside the mirror, whatever else the entry turns out to be --, and the entries of the pass after it
+    __device__ __forceinline__ void stage(const TileArgs &A, u32 lane) {
+        if (pass >= n_pass) return;
+        const bool more = pass + WAVES < n_pass;
+        {
+            const u32 a = entry_of(more ? pass + WAVES : pass, lane);
+            na = A.wo[2ull * a];
+            nb = A.wo[2ull * a + 1];
+        }
+        const bool ld = loadable(A, ea, eb);
+        const u64 so = (u64)eb.x | ((u64)eb.y << 32);
+        tail = load4_unaligned(A.seq4 + ((ld ? so + (ea.w - 1u) : 7ull) >> 1) - 3);
+        const u8 *const q = A.seq4 + ((ld ? so : 0ull) >> 1);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) W[c] = PP_EXP_LOAD16(q + 16 * c);
+    }
+    // What a pass needs of an entry, in three registers: where the read's chunks are loaded from (its place in the mirror, or 0
+    // when the pass does not take it) and rel | seq_len << 12 | flags.  Everything else (k, the file index, an offset that is
+    // not loadable) is fetched again by the rare paths that need it.
+    struct Lean {
+        u64 so_l;
+        u32 pack;
+    };
+    static constexpr u32 LN_BULK = 1u << 20, LN_PLAIN = 1u << 21, LN_SHARED = 1u << 22;
+    __device__ __forceinline__ Lean distill(const TileArgs &A, const RecMap &M, const uint4 &qa, const uint4 &qb, bool in_list) const {
+        const u32 ref_start = qa.y, L = qa.w;
+        u32 c_lo32 = (u32)M.c_lo, clen32 = (u32)M.clen;  // (a contig's length fits 32 bits: G < 2^32 - 4096)
+        bool c_ok = qa.x == M.c0;
+        if (!M.one_contig) {  // (a window with a contig boundary in it)
+            const u32 cc = min(qa.x, A.n_contigs - 1u);
+            const u64 lo64 = A.contig_off[cc];
+            c_lo32 = (u32)lo64;
+            clen32 = (u32)(A.contig_off[cc + 1] - lo64);
+            c_ok = qa.x < A.n_contigs;
+        }
+        const u32 rel = c_lo32 + ref_start - (u32)((u64)M.w * TILE);  // where the read starts in the window
+        // wo_bulk, in 32 bits (ref_start + L <= clen without the sum), and the entry's place in THIS window
+        const bool bulk = in_list && c_ok && qb.z == ((L << 4) | (u32)PP_OP_M) && L - 1u < FAST_MAX_LEN && L <= clen32 && ref_start <= clen32 - L &&
+                          rel < (u32)TILE;
+        const bool plain = bulk && loadable(A, qa, qb);  // the pass takes it (else: the other fast classes)
+        Lean n;
+        n.so_l = plain ? ((u64)qb.x | ((u64)qb.y << 32)) : 0ull;
+        n.pack = bulk ? (rel | (L << 12) | LN_BULK | (plain ? LN_PLAIN : 0u) | (qa.z != 1u ? LN_SHARED : 0u)) : 0u;
+        return n;
+    }
+    // (3) behind the prologue's barrier: the passes
+    __device__ __forceinline__ void run(const TileArgs &A, u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm_w, const u32 *asm4, const RecMap &M, u32 lane) {
+        if (pass >= n_pass) return;
+        Lean cur = distill(A, M, ea, eb, 64u * pass + lane < nv);
+        for (; pass < n_pass; pass += WAVES) {
+            const bool more = pass + WAVES < n_pass;
+            // the pass after this one: its entries are here (asked for a pass ago) and are reduced to what it needs; the entries
+            // of the pass after THAT are asked for now, then its tail bytes -- and its chunks one by one below, as this pass's
+            // chunks leave their registers
+            const Lean nxt = distill(A, M, na, nb, more && 64u * (pass + WAVES) + lane < nv);
+            if (pass + 2u * WAVES < n_pass) {
+                const u32 a = entry_of(pass + 2u * WAVES, lane);
+                na = A.wo[2ull * a];
+                nb = A.wo[2ull * a + 1];
+            }
+            const u32 tail_now = tail;
+            tail = load4_unaligned(A.seq4 + (((nxt.pack & LN_PLAIN) ? nxt.so_l + (((nxt.pack >> 12) & 0xFFu) - 1u) : 7ull) >> 1) - 3);
+            const u8 *const q_next = A.seq4 + (nxt.so_l >> 1);
+
+            const u32 rel = cur.pack & 0xFFFu, L = (cur.pack >> 12) & 0xFFu;
+            const bool plain = (cur.pack & LN_PLAIN) != 0;
+            const u64 so = cur.so_l;
+            // a bulk read the pass does not take (fewer than 8 bases; the last reads of the seq array): one item per pass, as the
+            // fast class that is not plain in tile_items; its entry is fetched again (rare)
+            u64 rest = __ballot((cur.pack & (LN_BULK | LN_PLAIN)) == LN_BULK);
+            if (rest) {
+                const u32 a = entry_of(pass, lane);
+                const uint4 qa = A.wo[2ull * a], qb = A.wo[2ull * a + 1];
+                const uint4 my = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), (u64)M.w * TILE + rel, M.w, qb.w);
+                while (rest) {
+                    const u32 j = (u32)__ffsll((long long)rest) - 1u;
+                    rest &= rest - 1;
+                    const FastItem f = fast_fetch(my, j, 64u, A.seq);
+                    fast_apply(cnt, ndbits, S, asm_w, f, (u32)__builtin_amdgcn_readlane((int)my.w, (int)j), fast_load(A.seq, f, lane), lane);
+                }
+            }
+            const u32 adj = (u32)so & 1u;  // an odd start: base i of the read is nibble i + 1 of what is loaded
+            int nkeep = trim4(tail_now, so + (L - 1u), L);
+            if (plain && nkeep < 0) nkeep = trim_bytes(A.seq + so, L);  // rare: see trim4
+            const u32 hi = min((u32)max(nkeep, 0), (u32)TILE - rel);    // the kept entries in the window: [0, hi) of the read
+            const bool live = plain && hi > 0;
+            if (live) {
+                atomicAdd(&cnt[ROW_COV * TILE + rel], 1u);
+                if (rel + hi < (u32)TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+            }
+            if (__ballot(live && (cur.pack & LN_SHARED))) {  // a depth share other than 1 (rare jobs: all-hits reads): k and the file index from the entry
+                if (live && (cur.pack & LN_SHARED)) {
+                    const u32 a = entry_of(pass, lane);
+                    share_range(cnt, ndbits, S, (int)rel, (int)(rel + hi), kclass_of(A.wo[2ull * a].z), A.wo[2ull * a + 1].w);
+                }
+            }
+            // nibble x of the loaded chunks <-> window position relc + x; the nibbles [adj, xhi) count (none of a lane that is not live)
+            const int relc = live ? (int)rel - (int)adj : 0;  // >= -1
+            const u32 xhi = live ? hi + adj : 0u;
+            const u32 *const mhi = S.pmask + xhi;
+            const u32 sh = (u32)(relc + ASM4_PAD) << 2;  // (v_alignbit takes it modulo 32)
+            const u32 *const ap = asm4 + ((relc + ASM4_PAD) >> 3);  // the dword of asm4 with chunk 0's nibble 0; 4 NCH + 1 dwords from here
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int P0 = relc + 32 * c;  // window position of the chunk's nibble 0
+                const u32 a0 = ap[4 * c], a1 = ap[4 * c + 1], a2 = ap[4 * c + 2], a3 = ap[4 * c + 3], a4 = ap[4 * c + 4];
+                const uint4 Wc = W[c];
+                u32 F = nz_perm(Wc.x ^ __builtin_amdgcn_alignbit(a1, a0, sh), Wc.y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
+                                Wc.z ^ __builtin_amdgcn_alignbit(a3, a2, sh), Wc.w ^ __builtin_amdgcn_alignbit(a4, a3, sh));
+                F &= mhi[PMASK_BASE - 32 * c];
+                if (c == 0) F &= ~adj;  // (nibble 0 of an odd start is the base in front of the read)
+#ifdef PP_EXP_NOCOMPARE
+                F = (Wc.x + Wc.y + Wc.z + Wc.w == 0x12345u && F) ? 1u : 0u;  // (experiment: the loads are waited for, nothing is tallied)
+#endif
+#ifdef PP_EXP_NOLOAD
+                F = (lane == 13u * c && live) ? 1u : (F & 0u);  // (experiment: one trip of the loop below per chunk, as the real data make it)
+#endif
+                while (F) {  // one trip per differing base: bit t = 4k + d <=> nibble k of dword d
+                    const u32 t = (u32)__ffs((int)F) - 1u;
+                    F &= F - 1u;
+                    // (selects, not masks: two compares and three v_cndmask where the mask form was ten instructions)
+                    const bool b0 = (t & 1u) != 0, b1 = (t & 2u) != 0;
+                    const u32 wlo = b0 ? Wc.y : Wc.x, whi = b0 ? Wc.w : Wc.z;
+                    const u32 code = __builtin_amdgcn_ubfe(b1 ? whi : wlo, t & 28u, 4u);
+                    const int p = P0 + (int)(((t & 3u) << 3) | (t >> 2));
+                    atomicAdd(&cnt[row_of_code8(code) * TILE + p], 1u);
+                    atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
+                }
+                W[c] = PP_EXP_LOAD16(q_next + 16 * c);  // the next pass's chunk c, into the registers this pass's has just left
+            }
+            cur = nxt;
+        }
+    }
+};
+
 constexpr u32 HSLAB_WORDS = (u32)(N_ROWS * TILE + TILE / 32);  // the nine counter rows + the bitmap of order-dependent positions
 static_assert(HSLAB_WORDS % 4 == 0 && (N_ROWS * TILE) % 4 == 0 && TILE % 128 == 0, "the partial tallies move as 16-byte words");
 constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at the front of k_tile's grid (a multiple of 8)
@@ -1051,25 +1349,48 @@ constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at
 #ifndef PP_TILE_LAZY_ARGS
 #define PP_TILE_LAZY_ARGS 1
 #endif
+// Profiling builds only (make variant NAME=stopK DEFS=-DPP_TILE_STOP=K, tools/exp_tile_phases.sh): an ordinary window's
+// workgroup ends behind phase K -- 1 prologue, 2 items, 3 prefix sums, 4 vote pass 1, 5 vote pass 2 -- so that the counters
+// and the duration of the truncated kernels give every phase's instructions and its share of the time (the window then
+// emits nothing: the results are wrong by design).
+#ifndef PP_TILE_STOP
+#define PP_TILE_STOP 0
+#endif
+#define PP_STOP_AFTER(K)                                                          \
+    if (PP_TILE_STOP == (K) && !heavy) {                                          \
+        if (tid == 0) { A.win_len[w] = 0; A.win_nflag[w] = 0; }                   \
+        return;                                                                   \
+    }
 // DIRECT (pp_k_direct.h): the window's bulk comes straight from the window-order mirror -- its entries in every run, run
 // after run, through the plain class with their work items made up in registers -- and only its extras (the reads that
 // reach in from the window before, the pieces of records with indels) are items in memory.
-template <bool DIRECT>
+// One instance per lane-group width GW of the plain class and per kind of read fetch P4 (the 4-bit mirror or the bytes): the
+// host launches the one that fits the job (run_pipeline; a job whose longest fast-class read the instance does not take
+// raises DE_GW_HINT and is rerun with the one that does).  As ONE kernel that picked its item loop at run time -- six loops
+// in a 22,000-line kernel -- k_tile_direct had 206 SGPR spills, a v_readlane / v_writelane each.
+template <bool DIRECT, int GW, bool P4>
 __device__ __forceinline__ void tile_window(const TileArgs &A) {
     __shared__ __attribute__((aligned(16))) u32 cnt[N_ROWS * TILE];
     __shared__ __attribute__((aligned(16))) u32 asm_w[ASM_WORDS];  // the window's assembly bytes at byte offset ASM_PAD
     __shared__ u32 asm4[ASM4_WORDS];  // the same as 4-bit codes, position p in nibble p + ASM4_PAD (only with TileArgs::seq4)
-    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_wsum[TILE_THREADS / 64], s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty, s_shared;
+    __shared__ u32 s_len, s_changed, s_zero, s_c0, s_c1, s_fbits[TILE / 32], s_nflag, s_ticket, s_ndirty, s_shared;
     __shared__ __attribute__((aligned(16))) unsigned short s_dirty[TILE];  // the positions that need the vote proper (see below); while the items are tallied its first PMASK_WORDS words hold TileShare::pmask
     __shared__ __attribute__((aligned(16))) u32 s_ndbits[TILE / 32];
     __shared__ u64 s_depth;
     __shared__ u32 s_pt[PT_SLOTS * 3], s_ptover;
     __shared__ u32 s_need;  // DIRECT: a position of this window goes to an exact replay (its items have to be written out)
+    __shared__ u32 s_nslow;  // BULK: the extras left for the slow round (ItemList::defer)
     // DIRECT: the window's stretches of the mirror, in s_dirty's space behind the range table (both are only needed while the
     // items are tallied): [0, R] prefix sums of the stretches' lengths, [32, 32 + R) where each begins
     u32 *const s_run = (u32 *)s_dirty + 512;
-    // ... [48, 52) where the window's first contig starts and its length, [52] the window's extras
-    static_assert(PMASK_WORDS <= 512 && 512 + 53 <= TILE / 2 && PP_WO_MAX_RUNS <= 16, "the run table shares s_dirty with the range table");
+    // ... [48, 52) where the window's first contig starts and its length, [52] the window's extras, [53] its entries that are not bulk
+    // ... and the prefix sums' per-wave totals (between the items and the vote: neither table is needed then, the list not yet)
+    u32 *const s_wsum = (u32 *)s_dirty + 640;
+    // ... and (BULK) the list of the window's slow extras (ItemList::defer), while the items are tallied
+    u32 *const s_slow = (u32 *)s_dirty + 704;
+    constexpr u32 SLOW_CAP = TILE / 2 - 704;
+    static_assert(640 + TILE_THREADS / 64 <= 704 && SLOW_CAP <= 64 * (TILE_THREADS / 64), "the slow list");
+    static_assert(PMASK_WORDS <= 512 && 512 + 54 <= 640 && 640 + TILE_THREADS / 64 <= TILE / 2 && PP_WO_MAX_RUNS <= 16, "the run table shares s_dirty with the range table");
 
     // The first HEAVY_BLOCKS blocks are helpers: block HEAVY_PARTS * slot + part tallies one part of the items of the
     // heavy window in that slot of the list.  They are dispatched first, so the longest windows start at time zero, and
@@ -1080,6 +1401,10 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     // Then the windows in XCD-aware order: consecutive windows (which share boundary-crossing reads) stay on one XCD.
     u32 w, part = 0, hslot = 0;
     const bool heavy = blockIdx.x < HEAVY_BLOCKS;
+    // (asked for before anything is waited for: with a branch between them every one of these was a round trip of its own
+    // at the start of every workgroup)
+    const u64 status_word = *A.status;
+    const u32 longest = *A.maxlen;
     if (heavy) {
         hslot = blockIdx.x / HEAVY_PARTS;
         part = blockIdx.x % HEAVY_PARTS;
@@ -1104,9 +1429,14 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             }
             w = first[lo] + (w - before[lo]);
         }
-        if (w >= A.nwin || A.win_heavy[w]) return;  // listed windows belong to the helpers
+        if (w >= A.nwin) return;
+        if (A.win_heavy[w]) return;  // listed windows belong to the helpers
     }
-    if (job_state(A.status) == 2) return;
+    if (status_word != ~0ull && (status_word & 0xFFu) != DE_CAPACITY_LATE) return;  // (job_state == 2: aborted)
+    if (longest > PlainCfg<GW>::MAXL) {  // not this instance's job (the host's hint was off: it reruns with the right one)
+        if (threadIdx.x == 0) report(A.status, (1ull << 40) - 1ull, DE_GW_HINT);
+        return;
+    }
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 w0 = (u64)w * TILE;
 #ifdef PP_TILE_STAMPS
@@ -1134,7 +1464,23 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             return;
         }
     }
-    for (u32 i = tid; i < (u32)(N_ROWS * TILE); i += TILE_THREADS) cnt[i] = 0;
+    // The bulk of a direct window, one lane per mirror entry (DirectBulk): every wave works the window's stretches out for
+    // itself (2 n_runs loads) and asks for its first pass's entries right away -- the rest of the prologue (zeroing the
+    // counters, the assembly's bytes and codes, the tables) runs while they are on their way.
+    constexpr bool BULK = DIRECT && P4 && GW == 5;
+    DirectBulk<5> D;
+    if constexpr (BULK) {
+        const BulkRuns runs = bulk_runs(A, w, lane);
+        const u32 n_all = (u32)__builtin_amdgcn_readlane((int)runs.pre_v, (int)runs.R);  // the window's mirror entries
+        u32 v0 = 0, v1 = n_all;
+        if (heavy) {  // this helper's share (as below)
+            const u32 vchunk = ((n_all + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
+            v0 = min(n_all, part * vchunk);
+            v1 = min(n_all, v0 + vchunk);
+        }
+        D.begin(A, runs, v0, v1 - v0, (u32)__builtin_amdgcn_readfirstlane((int)wave), lane);
+    }
+    for (u32 i = tid; i < (u32)(N_ROWS * TILE / 4); i += TILE_THREADS) ((uint4 *)cnt)[i] = make_uint4(0, 0, 0, 0);  // (16 bytes a store)
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
     {
         u8 *ab = (u8 *)asm_w;
@@ -1142,7 +1488,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         if (tid < (u32)ASM_PAD) ab[tid] = 0;
         if (tid < (u32)(ASM_WORDS * 4 - ASM_PAD - TILE)) ab[ASM_PAD + TILE + tid] = 0;
     }
-    if (A.seq4 && tid >= TILE_THREADS - (u32)ASM4_WORDS) {  // (the last waves: the first two search the contig table)
+    if (P4 && tid >= TILE_THREADS - (u32)ASM4_WORDS) {  // (the last waves: the first two search the contig table)
         const u32 t = tid - (TILE_THREADS - (u32)ASM4_WORDS);
         const int p0 = 8 * (int)t - ASM4_PAD;  // dword t holds positions p0 .. p0 + 7
         u32 lo8 = 0, hi8 = 0;                  // their bytes; 0 where there is no position (code "other": never compared)
@@ -1169,7 +1515,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
         asm4[t] = v;
     }
-    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; s_need = 0; }
+    if (tid == 0) { s_len = 0; s_changed = 0; s_zero = 0; s_depth = 0; s_nflag = 0; s_ndirty = 0; s_shared = 0; s_ptover = heavy ? 1u : 0u; s_need = 0; s_nslow = 0; }
     if (DIRECT && tid >= 192u && tid < 192u + 64u) {  // one wave: the window's stretch of every run, and their prefix sums
         const u32 r = tid - 192u, R = A.n_runs;
         u32 len = 0, f0 = 0;
@@ -1185,9 +1531,9 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         if (r <= R && r < 32u) s_run[r] = inc - len;  // (lane R holds the total)
         if (r < R) s_run[32u + r] = f0;
         if (r == 63u) s_run[52] = min(A.x_cnt[w], A.xcap);  // the window's extras (asked for here, with everything else of the prologue)
+        if (r == 62u) s_run[53] = A.x_cnt[A.nwin + w];       // ... and its entries that are not bulk (x_nb: k_tile passes them over)
     }
-    if (tid >= 128u && tid < 128u + (u32)PMASK_WORDS)
-        ((u32 *)s_dirty)[tid - 128u] = pmask4((u32)min(max((int)tid - 128 - PMASK_BASE, 0), 32));
+    if (tid >= 128u && tid < 128u + (u32)PMASK_WORDS) ((u32 *)s_dirty)[tid - 128u] = g_pmask_tab.v[tid - 128u];  // (one load: ~40 instructions to work it out)
     if (tid >= 64u && tid < 64u + PT_SLOTS * 3u) s_pt[tid - 64u] = 0;  // (a heavy window's helpers would each have their own table: listed as before)
     if (wave < 2u) {  // the contigs of the window's first and last position, one wave each
         const u32 cw = find_contig_wave(A.contig_off, A.n_contigs, wave == 0 ? w0 : min(w0 + TILE, A.G) - 1, lane);
@@ -1197,26 +1543,29 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             s_run[48] = (u32)lo64; s_run[49] = (u32)(lo64 >> 32); s_run[50] = (u32)len64; s_run[51] = (u32)(len64 >> 32);
         }
     }
+    if constexpr (BULK) D.stage(A, lane);  // the first pass's chunks and the second's entries: asked for in front of the barrier
     __syncthreads();
+    PP_STOP_AFTER(1)
 
 #ifdef PP_TILE_STAMPS
     if (tid == 0) A.stamps[8ull * blockIdx.x + 6] = wall_clock64();
 #endif
     // The window's items: [e0, e1) of the work items in memory -- the bucketing's (k_fill), or (DIRECT) the window's extras --
     // and, DIRECT, its n_rec mirror entries in front of them.
-    u32 e0, e1, n_rec = 0;
+    u32 e0, e1, n_rec = 0, n_notbulk = 0;
     const uint4 *items;
     if (DIRECT) {
         e0 = 0;
         e1 = s_run[52];
         items = A.xent + (u64)w * A.xcap;
         n_rec = s_run[A.n_runs];
+        n_notbulk = min(s_run[53], n_rec);  // (their pieces are among the extras: what is left is what the bucketing counts, as in k_winplan)
     } else {
         e0 = A.win_off[w];
         e1 = A.win_off[w + 1];
         items = A.entA;
     }
-    const TileShare S{win_fx_bits(e1 - e0 + n_rec), &s_shared, A.kk, s_pt, &s_ptover, (const u32 *)s_dirty};  // (a heavy window's helpers: the same bits, their deficits add up)
+    const TileShare S{win_fx_bits(e1 - e0 + n_rec - n_notbulk), &s_shared, A.kk, s_pt, &s_ptover, (const u32 *)s_dirty};  // (a heavy window's helpers: the same bits, their deficits add up)
     {
         u32 i0 = e0, i1 = e1, v0 = 0, v1 = n_rec;
         if (heavy) {  // this helper's share of the window's items
@@ -1227,7 +1576,6 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             v0 = min(n_rec, part * vchunk);
             v1 = min(n_rec, v0 + vchunk);
         }
-        const u32 longest = *A.maxlen;  // longest fast-class read of the job (k_prep)
         // (wave-uniform values out of LDS and memory: moved to scalar registers by hand, the compiler cannot know)
         const u32 c0 = (u32)__builtin_amdgcn_readfirstlane((int)s_c0);
         RecMap M{s_run, s_run + 32, A.n_runs, (u32)__builtin_amdgcn_readfirstlane((int)v0),
@@ -1237,19 +1585,36 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             M.clen = (u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[50]) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)s_run[51]) << 32);
             M.w_in_contig = (u32)(w0 - M.c_lo);
         }
-#define PP_TILE_ITEMS(GWV, P4V) tile_items<GWV, P4V, DIRECT>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave, lane)
-        if (A.seq4) {
-            if (longest <= PlainCfg<5>::MAXL) PP_TILE_ITEMS(5, true);
-            else if (longest <= PlainCfg<6>::MAXL) PP_TILE_ITEMS(6, true);
-            else PP_TILE_ITEMS(8, true);
-        } else if (longest <= PlainCfg<5>::MAXL) PP_TILE_ITEMS(5, false);
-        else if (longest <= PlainCfg<6>::MAXL) PP_TILE_ITEMS(6, false);
-        else PP_TILE_ITEMS(8, false);
-#undef PP_TILE_ITEMS
+        constexpr u32 WAVES = TILE_THREADS / 64;
+        if constexpr (BULK) {
+            // The window's work as PASSES of 64, dealt to the waves one by one: the passes over its mirror entries (DirectBulk)
+            // first, then its extras [i0, i1) as passes of their own -- pass j of them takes every n-th extra from j on --
+            // through tile_items.  Every pass but the last of either kind is full: at 50x a window is 11 + 1 passes where a
+            // sixteenth of one list per wave made 16 of them, two thirds full.  The extras' SLOW items are only listed here
+            // (ItemList::defer; the list lives behind the tables in s_dirty's space) and tallied in a round of their own below,
+            // a sixteenth per wave: k_prepg's pieces sit at the tail of a window's extras, hundreds of them in a window whose
+            // reads cross two planted indels, a memory round trip each.
+            D.run(A, cnt, s_ndbits, S, asm_w, asm4, M, lane);
+            const u32 pm = (M.nv + 63u) >> 6, px = (i1 - i0 + 63u) >> 6;
+            for (u32 g = pm + ((wave + WAVES - pm % WAVES) % WAVES); g < pm + px; g += WAVES) {
+                const u32 j = g - pm;  // (the first global pass >= pm that is this wave's: g = wave modulo WAVES)
+                tile_items<GW, P4, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1,
+                                          ItemList{i0 + j, (i1 - i0 - j - 1u) / px + 1u, px, nullptr, s_slow, &s_nslow, SLOW_CAP}, wave, lane);
+            }
+            __syncthreads();
+            const u32 n_slow = min(s_nslow, SLOW_CAP);
+            if (wave < n_slow)  // (every sixteenth of the list, one batch of at most SLOW_CAP / 16 <= 64 items per wave)
+                tile_items<GW, P4, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1,
+                                          ItemList{wave, (n_slow - wave - 1u) / WAVES + 1u, WAVES, s_slow, nullptr, nullptr, 0u}, wave, lane);
+        } else {
+            constexpr u32 IPP = (P4 && GW == 5) ? 1u : PlainCfg<GW>::IPP;  // (as tile_items: whole passes of the plain class)
+            tile_items<GW, P4, DIRECT>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave_slice<IPP>(i0, i1, wave), wave, lane);
+        }
     }
-    const u32 n_items = e1 - e0 + n_rec;
+    const u32 n_items = e1 - e0 + n_rec - n_notbulk;
     if (!DIRECT && n_items >= MAX_BUCKET && tid == 0 && part == 0) report(A.status, w, DE_TOO_DEEP);  // (DIRECT: k_winplan)
     __syncthreads();
+    PP_STOP_AFTER(2)
 #ifdef PP_TILE_STAMPS
     if (tid == 0) A.stamps[8ull * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -1327,6 +1692,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     };
     scan_row(cnt + ROW_COV * TILE);
     if (s_shared) scan_row(cnt + ROW_DEF * TILE);  // (uniform: written before the barrier in front of this)
+    PP_STOP_AFTER(3)
 
     // ---- vote ----
     // Pass 1, one lane per position: a position where NOTHING was tallied explicitly -- every read that covers it shows
@@ -1375,6 +1741,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
     }
     __syncthreads();
+    PP_STOP_AFTER(4)
 #ifdef PP_TILE_STAMPS
     if (tid == 0) A.stamps[8ull * blockIdx.x + 7] = wall_clock64();
 #endif
@@ -1531,6 +1898,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             A.dbg_status[gp] = v.status;
         }
     }
+    PP_STOP_AFTER(5)
     my_len = wave_sum(my_len);
     my_changed = wave_sum(my_changed);
     my_zero = wave_sum(my_zero);
@@ -1609,18 +1977,20 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
 // The arguments are read where they are used, from the kernel-argument segment itself (scalar loads): taken by value
 // the ~45 fields are all loaded at entry, as 16-dword tuples that the register allocator can only spill whole -- 222
 // SGPR spills, and a v_readlane per spilled dword in front of every use: a fifth of the item loop's VALU issue.
+template <int GW, bool P4>
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile(TileArgs A_in_kernarg) {
 #if PP_TILE_LAZY_ARGS
-    tile_window<false>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
+    tile_window<false, GW, P4>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
 #else
-    tile_window<false>(A_in_kernarg);
+    tile_window<false, GW, P4>(A_in_kernarg);
 #endif
 }
+template <int GW, bool P4>
 __global__ __launch_bounds__(TILE_THREADS, 8) void k_tile_direct(TileArgs A_in_kernarg) {
 #if PP_TILE_LAZY_ARGS
-    tile_window<true>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
+    tile_window<true, GW, P4>(*(const TileArgs *)__builtin_amdgcn_kernarg_segment_ptr());
 #else
-    tile_window<true>(A_in_kernarg);
+    tile_window<true, GW, P4>(A_in_kernarg);
 #endif
 }
 

@@ -878,11 +878,33 @@ PrepdArgs PA;
     PP_HIPCHK(ctx, hipMemsetAsync(b_stamps.p, 0, stamp_bytes, st));
     T.stamps = (u64 *)b_stamps.p;
 #endif
-    if (ev_launch) {
-        if (direct) hipExtLaunchKernelGGL(k_tile_direct, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, ev_start, ev_stop, 0, T);
-        else hipExtLaunchKernelGGL(k_tile, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, ev_start, ev_stop, 0, T);
-    } else if (direct) hipLaunchKernelGGL(k_tile_direct, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
-    else hipLaunchKernelGGL(k_tile, dim3(HEAVY_BLOCKS + per * 8), dim3(TILE_THREADS), 0, st, T);
+    // one kernel per (lane-group width of the plain class, read fetch): the instance for the longest fast-class read the
+    // context's job before had (a first job: short reads); an instance that does not take this job's raises DE_GW_HINT
+    // (pp_polish_finish reruns with the job's own figure)
+    {
+        const uint32_t hint = ctx->maxlen_hint;
+        const int gw = hint <= PlainCfg<5>::MAXL ? 5 : (hint <= PlainCfg<6>::MAXL ? 6 : 8);
+        const dim3 grid(HEAVY_BLOCKS + per * 8), block(TILE_THREADS);
+#define PP_TILE_LAUNCH(KERNEL)                                                                             \
+        do {                                                                                               \
+            if (ev_launch) hipExtLaunchKernelGGL(KERNEL, grid, block, 0, st, ev_start, ev_stop, 0, T);     \
+            else hipLaunchKernelGGL(KERNEL, grid, block, 0, st, T);                                        \
+        } while (0)
+#define PP_TILE_PICK(NAME)                                                                                 \
+        do {                                                                                               \
+            if (T.seq4) {                                                                                  \
+                if (gw == 5) PP_TILE_LAUNCH((NAME<5, true>));                                              \
+                else if (gw == 6) PP_TILE_LAUNCH((NAME<6, true>));                                         \
+                else PP_TILE_LAUNCH((NAME<8, true>));                                                      \
+            } else if (gw == 5) PP_TILE_LAUNCH((NAME<5, false>));                                          \
+            else if (gw == 6) PP_TILE_LAUNCH((NAME<6, false>));                                            \
+            else PP_TILE_LAUNCH((NAME<8, false>));                                                         \
+        } while (0)
+        if (direct) PP_TILE_PICK(k_tile_direct);
+        else PP_TILE_PICK(k_tile);
+#undef PP_TILE_PICK
+#undef PP_TILE_LAUNCH
+    }
 #ifdef PP_TILE_STAMPS
     if (const char *path = getenv("PP_TILE_STAMPS_FILE")) {
         std::vector<uint64_t> hs(stamp_bytes / 8);
@@ -1055,6 +1077,10 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
             ctx->no_compact = true;
             continue;
         }
+        if ((key & 0xFF) == DE_GW_HINT && ctx->maxlen_hint != (uint32_t)meta[9]) {  // k_tile's instance does not take this job's reads: the one that does
+            ctx->maxlen_hint = (uint32_t)meta[9];
+            continue;
+        }
         if ((key & 0xFF) == DE_MIRROR_ORDER && !ctx->no_direct) {  // the mirror is not in the order its run table promises: the bucketing path
             static const bool trace_d = getenv("PP_TIMING") != nullptr;
             if (trace_d) fprintf(stderr, "[timing] pass %d: the window-order mirror is not in run order -> bucketing path\n", attempt + 1);
@@ -1088,6 +1114,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     ctx->total_out = meta[5];
     ctx->last_listed = cnt[0];
     ctx->nothing_flagged_last = cnt[0] == 0 && cnt[2] == 0;
+    ctx->maxlen_hint = (uint32_t)meta[9];
     ctx->n_multi = cnt[1];
     ctx->n_keys = meta[8];
     // per-contig results: the run's contigs are the job's, or (compact run) the ones this context owns -- the others
