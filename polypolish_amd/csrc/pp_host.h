@@ -19,6 +19,17 @@
 #include <thread>
 #include <vector>
 
+#ifndef PP_MIRROR_REGISTRY_DECLARED
+#define PP_MIRROR_REGISTRY_DECLARED
+// The window-order mirrors the library's own producers hand out (pp_ingest_batch, pp_dev_ingest_batch, pp_shard_split's parts),
+// as address ranges keyed by their owner: a mirror inside one of them (a part of one: the multi-GPU driver's slice views) is
+// taken as it is, any other mirror is compared with the arrays it mirrors before the kernels read the records through it
+// (pp_polish_add, run_pipeline).  Implemented in pp_shard.cpp.
+void pp_mirror_register_(const void *owner, const void *p, size_t bytes);
+void pp_mirror_forget_(const void *owner);
+bool pp_mirror_trusted_(const void *p, size_t bytes);
+#endif
+
 namespace pph {
 
 // Growable array for the multi-GB buffers of a large job: anonymous mmap backed by transparent huge
@@ -113,6 +124,7 @@ inline unsigned host_threads(size_t text_bytes) {
 // the link delivers (measured on a 1.2 GB SAM file, tools/microbench/h2d2.hip: 89 ms against 3 + 21 ms).
 #ifndef MADV_POPULATE_READ
 #define MADV_POPULATE_READ 22
+
 #endif
 inline void populate_mapping(void *map, size_t size, unsigned threads = 8) {
     if (!map || !size) return;

@@ -906,6 +906,7 @@ extern "C" void pp_ingest_batch(const pp_ingest *I, pp_aln_batch *out) {
     out->seq_bytes = I->seq.size();
     out->seq4 = nullptr;
     out->wo = I->wo_mirror && I->wo.size() == I->contig.size() && I->contig.size() ? I->wo.data() : nullptr;
+    pp_mirror_register_(I, out->wo, out->wo ? I->wo.size() * sizeof(pp_wo_rec) : 0);  // (one of the library's own: pp_polish_add takes it unchecked)
     const bool runs = out->wo && !I->wo_run_end.empty() && I->wo_run_end.back() == I->contig.size();
     out->wo_n_runs = runs ? (uint32_t)I->wo_run_end.size() : 0;
     out->wo_run_end = runs ? I->wo_run_end.data() : nullptr;
@@ -918,4 +919,7 @@ extern "C" const char *pp_ingest_read_name(const pp_ingest *I, uint64_t i) {
     return I->names.data() + I->name_off[i];
 }
 
-extern "C" void pp_ingest_free(pp_ingest *I) { delete I; }
+extern "C" void pp_ingest_free(pp_ingest *I) {
+    pp_mirror_forget_(I);
+    delete I;
+}

@@ -12,6 +12,17 @@
 
 #include "polypolish_hip.h"
 
+#ifndef PP_MIRROR_REGISTRY_DECLARED
+#define PP_MIRROR_REGISTRY_DECLARED
+// The window-order mirrors the library's own producers hand out (pp_ingest_batch, pp_dev_ingest_batch, pp_shard_split's parts),
+// as address ranges keyed by their owner: a mirror inside one of them (a part of one: the multi-GPU driver's slice views) is
+// taken as it is, any other mirror is compared with the arrays it mirrors before the kernels read the records through it
+// (pp_polish_add, run_pipeline).  Implemented in pp_shard.cpp.
+void pp_mirror_register_(const void *owner, const void *p, size_t bytes);
+void pp_mirror_forget_(const void *owner);
+bool pp_mirror_trusted_(const void *p, size_t bytes);
+#endif
+
 namespace pp {
 
 // ---- geometry of the pileup tile kernel ----------------------------------------------------
@@ -87,9 +98,11 @@ enum DevErr : uint32_t {
     DE_MIRROR_ORDER = 16,   // direct path (pp_k_direct.h): the mirror's entries are not in the order its run table promises
                             // -> the host runs the job over the bucketing path (always reported at the largest index, so
                             // that the error of any record wins)
+    DE_SEQ_RANGE = 18,      // a record's SEQ bytes do not lie inside the batch's seq array (seq_off + seq_len > seq_bytes)
     DE_GW_HINT = 17,        // k_tile: the instance the host launched does not take the job's longest fast-class read (meta
                             // word 9) -> the host reruns with the one that does (same index as DE_MIRROR_ORDER)
 };
+
 
 struct DevBuf {
     void *p = nullptr;
@@ -155,6 +168,10 @@ struct pp_ctx {
     std::vector<uint32_t> runs_on_dev;  // what b_runs holds (identical tables are not uploaded again)
     size_t xcap = 0;                    // room for extras per window (grow-only)
     bool no_direct = false;             // this job is being rerun over the bucketing path (DE_MIRROR_ORDER)
+    bool wo_untrusted = false;          // a batch of this job brought a window-order mirror that is not one of the library's own (pp_mirror_trusted_): checked before it is used
+    bool trust_all = false;             // pp_ctx_trust_mirrors_: every mirror is taken as the library's own (bench / tests that lay a batch out as the ingests do)
+    bool no_wo = false;                 // this job is being rerun without its mirror (it did not stand the check)
+    size_t xcap_limit = ~(size_t)0;     // the most room for extras a window of this job can be given (run_pipeline): beyond it, the bucketing path
     uint32_t maxlen_hint = 0;           // the longest fast-class read of the context's last job (meta word 9): picks k_tile's instance for the next one (DE_GW_HINT)
     bool last_direct = false;           // the last pass over the pipeline took the direct path
     bool nothing_flagged_last = false;  // the job before had no position flagged for the exact replays (run_pipeline: their launches are then left out until this job's metadata say otherwise)

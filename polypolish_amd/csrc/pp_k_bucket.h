@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
                                                const u32 *__restrict__ seq_len, u32 nwin, u32 ncoarse,
                                                const u32 *__restrict__ hist_c,
                                                const u32 *__restrict__ coarse_off,
-                                               uint4 *__restrict__ entB, u32 frange, u64 *__restrict__ status) {
+                                               uint4 *__restrict__ entB, u32 frange, u64 seq_bytes, u64 *__restrict__ status) {
     __shared__ u32 cur[COUNT_RANGE];  // cursors of the coarse buckets of this pass
     PP_STAMP(1, 0);
     if (*status != ~0ull) return;  // a record error, or the work-item buffer is too small (host reruns)
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(1024) void k_fill(u64 n, u64 chunk, const pp_wo_rec
             if (ok && blockIdx.y == 0) {  // checks that need k / seq_off (not read by k_prep's fast path)
                 if (k4[u] == 0) report(status, fi4[u], DE_BAD_K);
                 else if (so4[u] + sl4[u] > (1ull << 40)) report(status, fi4[u], DE_OVERFLOW);
+                else if (so4[u] + sl4[u] > seq_bytes) report(status, fi4[u], DE_SEQ_RANGE);
             }
         }
 #pragma unroll

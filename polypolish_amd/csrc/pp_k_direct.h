@@ -126,6 +126,7 @@ struct PrepdArgs {
     uint4 *g_later;      // the entries that are not bulk, for k_prepg: copies of them, two 16-byte words each (file index NOIDX: none) ...
     u64 *g_nlater;       // ... how many (counted past the capacity too) ...
     u64 cap_later;       // ... and the room
+    u64 seq_bytes;       // bytes of the seq array: a record's SEQ has to lie inside it
     u64 *status;
 };
 
@@ -304,12 +305,13 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
             const bool begins = valid && (starts || (hp != NOHOME && h > hp));
             const bool descent = valid && !starts && hp != NOHOME && h < hp;
             const bool ends = valid && (u32)a + 1u == run_hi;
-            const bool bad = in && (file_idx >= n || k == 0 || seq_off + seq_len > (1ull << 40));
+            const bool bad = in && (file_idx >= n || k == 0 || seq_off + seq_len > (1ull << 40) || seq_off + seq_len > P.seq_bytes);
             if (__ballot(begins || descent || ends || bad)) {
                 if (bad) {  // the checks every record gets (k_fill's, and the mirror's own)
                     if (file_idx >= n) report(status, a, DE_BAD_MIRROR);
                     else if (k == 0) report(status, file_idx, DE_BAD_K);
-                    else report(status, file_idx, DE_OVERFLOW);
+                    else if (seq_off + seq_len > (1ull << 40)) report(status, file_idx, DE_OVERFLOW);
+                    else report(status, file_idx, DE_SEQ_RANGE);
                 }
                 if (descent) report(status, (1ull << 40) - 1ull, DE_MIRROR_ORDER);
                 fill(begins, run, starts ? 0u : hp + 1u, h, (u32)a);

@@ -123,7 +123,7 @@ __device__ __forceinline__ void tile_add(u32 *cnt, int row, int p) { atomicAdd(&
 // slow class -- is not in the table: the vote notices (the table's counts do not add up to the row) and lists the position
 // as before.  Entry: tag = 1 << 31 | position << 16 | bytes; count in bits 0..23 of the second word, bits 32..39 of the
 // offset above them; the offset's low word.
-constexpr u32 PT_SLOTS = 20;
+constexpr u32 PT_SLOTS = 10;  // (a window has a planted site or two; more distinct keys than slots: listed as before)
 constexpr u32 FEW_FLAGGED = 4;  // windows with at most this many positions left for the ordered replay hand them to k_exact
 __device__ __noinline__ void pt_insert(u32 *pt, u32 *over, int p, const u8 *seq, u64 so) {  // (rare: kept out of the item loop's registers)
     const u32 tag = 0x80000000u | ((u32)p << 16) | (u32)seq[so] | ((u32)seq[so + 1] << 8);
@@ -447,8 +447,9 @@ __device__ __forceinline__ void plain_apply(u32 *cnt, u32 *ndbits, const TileSha
 // the assembly's: the same integers come out (the explicit tally and the mismatch row go up together, position_tallies).
 // What needs a byte as it was delivered reads seq as before: the walk over a long homopolymer tail, and the whole trim
 // when the read ends in a byte that has no code of its own (two different bytes may share code 15).
-constexpr int ASM4_PAD = 32;                     // nibbles in front of the window's first position (as ASM_PAD)
-constexpr int ASM4_WORDS = TILE / 8 + 24;        // 8 positions per dword; a lane reads five dwords from (P0 + ASM4_PAD) / 8 on -- and
+constexpr int ASM4_PAD = 256;                    // nibbles in front of the window's first position: a fast-class read that reaches in from the
+                                                 // window before starts up to FAST_MAX_LEN - 1 positions in front of it (DirectBulk indexes without a clamp)
+constexpr int ASM4_WORDS = (ASM4_PAD + TILE) / 8 + 24;        // 8 positions per dword; a lane reads five dwords from (P0 + ASM4_PAD) / 8 on -- and
                                                  // (direct_bulk) the 21 dwords under a 160-base read that starts at the window's last position
 constexpr u32 SEQ4_ASM_OTHER = 14;
 
@@ -882,6 +883,7 @@ struct ItemList {
     // tallied on the spot.
     u32 *defer, *defer_n;
     u32 defer_cap;
+    bool only_slow;  // nothing but the slow items is tallied (the others have been: DirectBulk's round over extras it could not list)
 };
 // ... a wave's contiguous slice of [e0, e1), whole passes of IPP items (the bucketing path)
 template <u32 IPP>
@@ -889,7 +891,7 @@ __device__ __forceinline__ ItemList wave_slice(u32 e0, u32 e1, u32 wave) {
     constexpr u32 WAVES = TILE_THREADS / 64;
     const u32 per_wave = ((e1 - e0 + WAVES - 1u) / WAVES + IPP - 1u) / IPP * IPP;
     const u32 lo = min(e1, e0 + wave * per_wave);
-    return ItemList{lo, min(e1, lo + per_wave) - lo, 1u, nullptr, nullptr, nullptr, 0u};
+    return ItemList{lo, min(e1, lo + per_wave) - lo, 1u, nullptr, nullptr, nullptr, 0u, false};
 }
 
 // two 1024-thread workgroups per CU (8 waves per SIMD): at most 64 VGPRs
@@ -1006,8 +1008,9 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
                 }
             }
         }
-        const bool my_point = lane < nb && (my_flags & ENT_POINT) != 0;
-        const bool my_plain = lane < nb && rec_ok && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
+        const bool skip = !REC && X.only_slow;
+        const bool my_point = lane < nb && !skip && (my_flags & ENT_POINT) != 0;
+        const bool my_plain = lane < nb && !skip && rec_ok && !my_point && C::ok(my.x, my.y, A.seq_bytes) && (!WIDE || wide4_takes(my.x, my.y, my.z));
         // the slow items' record fields, one item per lane: asked for now, needed after the plain passes
         u64 sl_so = 0, sl_co = 0;
         u32 sl_nc = 0;
@@ -1033,7 +1036,7 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
             }
         }
         // fast class that is not plain (shared depth, or 242..252 bases): one item per pass
-        u64 rest = __ballot(lane < nb && rec_ok && !my_slow && !deferred && !my_plain && !my_point);
+        u64 rest = __ballot(lane < nb && !skip && rec_ok && !my_slow && !deferred && !my_plain && !my_point);
         while (rest) {
             const u32 j = (u32)__ffsll((long long)rest) - 1u;
             rest &= rest - 1;
@@ -1158,129 +1161,189 @@ __device__ __forceinline__ BulkRuns bulk_runs(const TileArgs &A, u32 w, u32 lane
 #else
 #define PP_EXP_LOAD16(p) load16_unaligned(p)
 #endif
+#ifndef PP_GROUP_SPLIT
+#define PP_GROUP_SPLIT 5
+#endif
+// -DPP_EXP_COALESCED: chunk c of a pass's 64 reads is loaded as ONE contiguous kilobyte (lane l: 16 bytes at 1024 c + 16 l from
+// where lane 0's read lies -- the same 5 KB the pass touches, wrong bytes in every lane but one: what a wave-interleaved
+// layout of the reads would cost the memory pipeline)
+#ifdef PP_EXP_COALESCED
+#define PP_EXP_CHUNK(q, c, lane) ((const u8 *)(((uintptr_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(uintptr_t)(q)) | ((uintptr_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)((uintptr_t)(q) >> 32)) << 32)) & ~(uintptr_t)15) + 1024 * (c) + 16 * (lane))
+#else
+#define PP_EXP_CHUNK(q, c, lane) ((q) + 16 * (c))
+#endif
 template <int NCH>
 struct DirectBulk {
     BulkRuns B;
-    u32 v0, nv, n_pass;   // the entries this workgroup takes: [v0, v0 + nv) of the window's (v0: a multiple of 64), in n_pass passes
-    u32 pass;             // this wave's next pass (uniform)
-    uint4 ea, eb;         // its entries: contig, ref_start, k, seq_len | seq_off (two words), op0, file index
+    u32 v0, nv, pm;       // the mirror entries this workgroup takes: [v0, v0 + nv) of the window's (v0: a multiple of 64), in pm passes
+    const uint4 *items;   // ... and its extras: items[x0 .. x0 + nx) (16-byte work items, k_prepd / k_prepg), in px passes behind them
+    u32 x0, nx, px;
+    u32 pass;             // this wave's next pass (uniform): < pm one over mirror entries, else one over extras
+    uint4 ea, eb;         // its sources: a mirror entry (contig, ref_start, k, seq_len | seq_off (two words), op0, file index) or an item (ea)
     uint4 na, nb;         // ... and those of the pass after it
     uint4 W[NCH];         // its chunks
     u32 tail;             // the four bytes of the mirror that end with the read's last base (trim4)
     static constexpr u32 WAVES = TILE_THREADS / 64;
 
-    __device__ __forceinline__ u32 entry_of(u32 p, u32 lane) const {  // the mirror entry this lane takes in pass p (past the end: the last one again)
+    __device__ __forceinline__ u32 n_pass() const { return pm + px; }
+    __device__ __forceinline__ u32 entry_of(u32 p, u32 lane) const {  // the mirror entry this lane takes in pass p < pm (past the end: the last one again)
         const u32 vs = v0 + 64u * p;  // the pass's first entry (uniform)
         const u32 v = min(vs + lane, v0 + nv - 1u);
         u32 r = 0;
         for (u32 j = 1; j < B.R; j++)  // (scalar: the run of the pass's first entry)
             if (vs >= (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)j)) r = j;
-        u32 pr = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)r), nx = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
+        u32 pr = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)r), nx_ = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
         u32 a = (u32)__builtin_amdgcn_readlane((int)B.first_v, (int)r) + (v - pr);
-        while (__ballot(v >= nx)) {  // a pass across the end of a run (one pass per run and window)
+        while (__ballot(v >= nx_)) {  // a pass across the end of a run (one pass per run and window)
             r++;
-            pr = nx;
-            nx = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
+            pr = nx_;
+            nx_ = (u32)__builtin_amdgcn_readlane((int)B.pre_v, (int)(r + 1u));
             if (v >= pr) a = (u32)__builtin_amdgcn_readlane((int)B.first_v, (int)r) + (v - pr);
         }
         return a;
     }
-    // where a read's chunks are loaded from: its place in the mirror when all NCH chunk loads stay inside it (8 .. 32 NCH bases,
-    // 32 NCH nibbles from its start on inside the array: seq4 has 32 bytes of slack behind it), else the mirror's first bytes
-    // (nothing of them counts: such a read is not plain)
-    __device__ static __forceinline__ bool loadable(const TileArgs &A, const uint4 &qa, const uint4 &qb) {
-        const u64 so = (u64)qb.x | ((u64)qb.y << 32);
-        return qa.w - PLAIN_MIN_LEN <= 32u * NCH - PLAIN_MIN_LEN && so + 32u * NCH <= A.seq_bytes;
-    }
-    // (1) as soon as the window's stretches are known: the entries of this wave's first pass
-    __device__ __forceinline__ void begin(const TileArgs &A, const BulkRuns &runs, u32 v0_, u32 nv_, u32 wave, u32 lane) {
-        B = runs;
-        v0 = v0_;
-        nv = nv_;
-        n_pass = (nv + 63u) >> 6;
-        pass = wave;
-        ea = eb = na = nb = make_uint4(0, 0, 0, 0);
-        if (pass < n_pass) {
-            const u32 a = entry_of(pass, lane);
-            ea = A.wo[2ull * a];
-            eb = A.wo[2ull * a + 1];
+    // the sources of pass p into (qa, qb): this lane's mirror entry, or its item (qb: the same again, not looked at)
+    __device__ __forceinline__ void ask_sources(const TileArgs &A, u32 p, u32 lane, uint4 &qa, uint4 &qb) const {
+        if (p < pm) {
+            const u32 a = entry_of(p, lane);
+            qa = A.wo[2ull * a];
+            qb = A.wo[2ull * a + 1];
+        } else {
+            const u32 i = x0 + min(64u * (p - pm) + lane, nx - 1u);
+            qa = items[i];
+            qb = qa;
         }
     }
-    // (2) when those entries are there (still in the prologue): the first pass's chunks -- from where the entry says its read
-    // lies when that is inside the mirror, whatever else the entry turns out to be --, and the entries of the pass after it
-    __device__ __forceinline__ void stage(const TileArgs &A, u32 lane) {
-        if (pass >= n_pass) return;
-        const bool more = pass + WAVES < n_pass;
-        {
-            const u32 a = entry_of(more ? pass + WAVES : pass, lane);
-            na = A.wo[2ull * a];
-            nb = A.wo[2ull * a + 1];
-        }
-        const bool ld = loadable(A, ea, eb);
-        const u64 so = (u64)eb.x | ((u64)eb.y << 32);
-        tail = load4_unaligned(A.seq4 + ((ld ? so + (ea.w - 1u) : 7ull) >> 1) - 3);
-        const u8 *const q = A.seq4 + ((ld ? so : 0ull) >> 1);
-#pragma unroll
-        for (int c = 0; c < NCH; c++) W[c] = PP_EXP_LOAD16(q + 16 * c);
-    }
-    // What a pass needs of an entry, in three registers: where the read's chunks are loaded from (its place in the mirror, or 0
-    // when the pass does not take it) and rel | seq_len << 12 | flags.  Everything else (k, the file index, an offset that is
-    // not loadable) is fetched again by the rare paths that need it.
+    __device__ __forceinline__ bool in_list(u32 p, u32 lane) const { return p < pm ? 64u * p + lane < nv : 64u * (p - pm) + lane < nx; }
+    // What a pass needs of a source, in three registers: where the read's chunks are loaded from (its place in the mirror, or 0
+    // when the pass does not take it) and (rel + LN_REL0) | length << 12 | flags.  Everything else (k, the file index, an
+    // offset that is not loadable) is fetched again by the rare paths that need it.
     struct Lean {
         u64 so_l;
         u32 pack;
     };
-    static constexpr u32 LN_BULK = 1u << 20, LN_PLAIN = 1u << 21, LN_SHARED = 1u << 22;
-    __device__ __forceinline__ Lean distill(const TileArgs &A, const RecMap &M, const uint4 &qa, const uint4 &qb, bool in_list) const {
-        const u32 ref_start = qa.y, L = qa.w;
-        u32 c_lo32 = (u32)M.c_lo, clen32 = (u32)M.clen;  // (a contig's length fits 32 bits: G < 2^32 - 4096)
-        bool c_ok = qa.x == M.c0;
-        if (!M.one_contig) {  // (a window with a contig boundary in it)
-            const u32 cc = min(qa.x, A.n_contigs - 1u);
-            const u64 lo64 = A.contig_off[cc];
-            c_lo32 = (u32)lo64;
-            clen32 = (u32)(A.contig_off[cc + 1] - lo64);
-            c_ok = qa.x < A.n_contigs;
+    static constexpr u32 LN_REL0 = 256;  // (rel > -256: a fast-class read has at most FAST_MAX_LEN bases)
+    static constexpr u32 LN_FAST = 1u << 20, LN_PLAIN = 1u << 21, LN_SHARED = 1u << 22, LN_NOTRIM = 1u << 23, LN_POINT = 1u << 24, LN_SLOW = 1u << 25;
+    // the read's chunks are loaded from its place in the mirror when all NCH chunk loads stay inside it: 8 .. 32 NCH bases, 32 NCH
+    // nibbles from its start on inside the array (seq4 has 32 bytes of slack behind it)
+    __device__ static __forceinline__ bool loadable(const TileArgs &A, u64 so, u32 L) {
+        return L - PLAIN_MIN_LEN <= 32u * NCH - PLAIN_MIN_LEN && so + 32u * NCH <= A.seq_bytes;
+    }
+    __device__ __forceinline__ Lean distill(const TileArgs &A, const RecMap &M, u32 p, const uint4 &qa, const uint4 &qb, bool listed) const {
+        Lean n{0ull, 0u};
+        if (p < pm) {  // a mirror entry (uniform branch)
+            const u32 ref_start = qa.y, L = qa.w;
+            u32 c_lo32 = (u32)M.c_lo, clen32 = (u32)M.clen;  // (a contig's length fits 32 bits: G < 2^32 - 4096)
+            bool c_ok = qa.x == M.c0;
+            if (!M.one_contig) {  // (a window with a contig boundary in it)
+                const u32 cc = min(qa.x, A.n_contigs - 1u);
+                const u64 lo64 = A.contig_off[cc];
+                c_lo32 = (u32)lo64;
+                clen32 = (u32)(A.contig_off[cc + 1] - lo64);
+                c_ok = qa.x < A.n_contigs;
+            }
+            const u32 rel = c_lo32 + ref_start - (u32)((u64)M.w * TILE);  // where the read starts in the window
+            // wo_bulk, in 32 bits (ref_start + L <= clen without the sum), and the entry's place in THIS window
+            const bool bulk = listed && c_ok && qb.z == ((L << 4) | (u32)PP_OP_M) && L - 1u < FAST_MAX_LEN && L <= clen32 && ref_start <= clen32 - L &&
+                              rel < (u32)TILE;
+            const u64 so = (u64)qb.x | ((u64)qb.y << 32);
+            const bool plain = bulk && loadable(A, so, L);  // the pass takes it (else: the other fast classes)
+            n.so_l = plain ? so : 0ull;
+            n.pack = bulk ? ((rel + LN_REL0) | (L << 12) | LN_FAST | (plain ? LN_PLAIN : 0u) | (qa.z != 1u ? LN_SHARED : 0u)) : 0u;
+        } else {       // a work item (k_fill's format, pp_k_bucket.h)
+            const u32 ex = qa.x, ey = qa.y, ez = qa.z;
+            const u32 flags = item_flags(ey, ez), L = ey >> 24;
+            const bool slow = (flags & 3u) != 0, point = (flags & ENT_POINT) != 0, notrim = (flags & ENT_NOTRIM) != 0;
+            const u64 so = (u64)ex | ((u64)(ey & 0xFFu) << 32);
+            const int rel = item_rel(ez);
+            const bool fast = listed && !slow && rel > -(int)LN_REL0 && rel < TILE;
+            const bool plain = fast && !point && loadable(A, so, L) && wide4_takes(ex, ey, ez);
+            n.so_l = plain ? so : 0ull;
+            n.pack = listed ? (slow ? LN_SLOW : (fast ? (((u32)(rel + (int)LN_REL0)) | (L << 12) | LN_FAST | (plain ? LN_PLAIN : 0u) |
+                                                         (((ey >> 8) & 0xFFu) ? LN_SHARED : 0u) | (notrim ? LN_NOTRIM : 0u) | (point ? LN_POINT : 0u))
+                                                       : 0u))
+                            : 0u;
         }
-        const u32 rel = c_lo32 + ref_start - (u32)((u64)M.w * TILE);  // where the read starts in the window
-        // wo_bulk, in 32 bits (ref_start + L <= clen without the sum), and the entry's place in THIS window
-        const bool bulk = in_list && c_ok && qb.z == ((L << 4) | (u32)PP_OP_M) && L - 1u < FAST_MAX_LEN && L <= clen32 && ref_start <= clen32 - L &&
-                          rel < (u32)TILE;
-        const bool plain = bulk && loadable(A, qa, qb);  // the pass takes it (else: the other fast classes)
-        Lean n;
-        n.so_l = plain ? ((u64)qb.x | ((u64)qb.y << 32)) : 0ull;
-        n.pack = bulk ? (rel | (L << 12) | LN_BULK | (plain ? LN_PLAIN : 0u) | (qa.z != 1u ? LN_SHARED : 0u)) : 0u;
         return n;
     }
-    // (3) behind the prologue's barrier: the passes
-    __device__ __forceinline__ void run(const TileArgs &A, u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm_w, const u32 *asm4, const RecMap &M, u32 lane) {
-        if (pass >= n_pass) return;
-        Lean cur = distill(A, M, ea, eb, 64u * pass + lane < nv);
-        for (; pass < n_pass; pass += WAVES) {
-            const bool more = pass + WAVES < n_pass;
-            // the pass after this one: its entries are here (asked for a pass ago) and are reduced to what it needs; the entries
-            // of the pass after THAT are asked for now, then its tail bytes -- and its chunks one by one below, as this pass's
-            // chunks leave their registers
-            const Lean nxt = distill(A, M, na, nb, more && 64u * (pass + WAVES) + lane < nv);
-            if (pass + 2u * WAVES < n_pass) {
-                const u32 a = entry_of(pass + 2u * WAVES, lane);
-                na = A.wo[2ull * a];
-                nb = A.wo[2ull * a + 1];
-            }
-            const u32 tail_now = tail;
-            tail = load4_unaligned(A.seq4 + (((nxt.pack & LN_PLAIN) ? nxt.so_l + (((nxt.pack >> 12) & 0xFFu) - 1u) : 7ull) >> 1) - 3);
-            const u8 *const q_next = A.seq4 + (nxt.so_l >> 1);
-
-            const u32 rel = cur.pack & 0xFFFu, L = (cur.pack >> 12) & 0xFFu;
-            const bool plain = (cur.pack & LN_PLAIN) != 0;
-            const u64 so = cur.so_l;
-            // a bulk read the pass does not take (fewer than 8 bases; the last reads of the seq array): one item per pass, as the
-            // fast class that is not plain in tile_items; its entry is fetched again (rare)
-            u64 rest = __ballot((cur.pack & (LN_BULK | LN_PLAIN)) == LN_BULK);
-            if (rest) {
-                const u32 a = entry_of(pass, lane);
-                const uint4 qa = A.wo[2ull * a], qb = A.wo[2ull * a + 1];
-                const uint4 my = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), (u64)M.w * TILE + rel, M.w, qb.w);
+    // (1) as soon as the window's stretches and the number of its extras are known: the sources of this wave's first pass
+    __device__ __forceinline__ void begin(const TileArgs &A, const BulkRuns &runs, u32 v0_, u32 nv_, const uint4 *items_, u32 x0_, u32 nx_, u32 wave, u32 lane) {
+        B = runs;
+        v0 = v0_;
+        nv = nv_;
+        pm = (nv + 63u) >> 6;
+        items = items_;
+        x0 = x0_;
+        nx = nx_;
+        px = (nx + 63u) >> 6;
+        pass = wave;
+        ea = eb = make_uint4(0, 0, 0, 0);
+        if (pass < n_pass()) ask_sources(A, pass, lane, ea, eb);
+    }
+    // where the chunks and the tail bytes of a source are loaded from, before anything else about it is known (stage)
+    __device__ __forceinline__ void raw_place(const TileArgs &A, u32 p, const uint4 &qa, const uint4 &qb, u64 &so, u32 &L) const {
+        if (p < pm) {
+            so = (u64)qb.x | ((u64)qb.y << 32);
+            L = qa.w;
+        } else {
+            so = (u64)qa.x | ((u64)(qa.y & 0xFFu) << 32);
+            L = (qa.y & 0x00030000u) ? 0u : qa.y >> 24;  // (a slow item's x is not an offset)
+        }
+    }
+    // (2) when those sources are there (still in the prologue): the first pass's chunks -- from where the source says its read
+    // lies when that is inside the mirror, whatever else it turns out to be --, and the sources of the pass after it
+    __device__ __forceinline__ void stage(const TileArgs &A, u32 lane) {
+        if (pass >= n_pass()) return;
+        const bool more = pass + WAVES < n_pass();
+        ask_sources(A, more ? pass + WAVES : pass, lane, na, nb);
+        u64 so;
+        u32 L;
+        raw_place(A, pass, ea, eb, so, L);
+        const bool ld = loadable(A, so, L);
+        tail = load4_unaligned(A.seq4 + ((ld ? so + (L - 1u) : 7ull) >> 1) - 3);
+        const u8 *const q = A.seq4 + ((ld ? so : 0ull) >> 1);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) W[c] = PP_EXP_LOAD16(PP_EXP_CHUNK(q, c, lane));
+    }
+    // (3) behind the prologue's barrier: the passes.  `defer`: the list for the extras' slow items (ItemList::defer)
+    __device__ __forceinline__ void run(const TileArgs &A, u32 *cnt, u32 *ndbits, const TileShare &S, const u32 *asm_w, const u32 *asm4, const RecMap &M,
+                                        u32 *defer, u32 *defer_n, u32 defer_cap, u32 lane) {
+        const u32 np = n_pass();
+        if (pass >= np) return;
+        Lean cur = distill(A, M, pass, ea, eb, in_list(pass, lane));
+        for (; pass < np; pass += WAVES) {
+            const bool more = pass + WAVES < np;
+            // ---- what the pass itself does not tally (all of it rare; the source is fetched again) -- in front of everything
+            // else of the pass, where the fewest registers are live (behind the next pass's loads the allocator spilled four
+            // of the chunk registers around it, on every pass)
+            if (__ballot((cur.pack & (LN_SLOW | LN_POINT)) != 0 || (cur.pack & (LN_FAST | LN_PLAIN)) == LN_FAST)) {
+                const int rel_r = (int)(cur.pack & 0xFFFu) - (int)LN_REL0;
+                uint4 my;  // the source as a work item
+                u32 src;
+                if (pass < pm) {
+                    src = entry_of(pass, lane);
+                    const uint4 qa = A.wo[2ull * src], qb = A.wo[2ull * src + 1];
+                    my = wo_item((u64)qb.x | ((u64)qb.y << 32), qa.w, kclass_of(qa.z), (u64)M.w * TILE + (u32)rel_r, M.w, qb.w);
+                } else {
+                    src = x0 + min(64u * (pass - pm) + lane, nx - 1u);
+                    my = items[src];
+                }
+                // a slow item (indels in several runs, a long read): listed for the slow round (tile_window), or -- no room --
+                // counted for a round over all of the window's extras
+                if (cur.pack & LN_SLOW) {
+                    const u32 slot = atomicAdd(defer_n, 1u);
+                    if (slot < defer_cap) defer[slot] = src;
+                }
+                // the entry AT a read's single indel (ENT_POINT): one tally -- the two-byte key of an insertion is counted by
+                // string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
+                if ((cur.pack & LN_POINT) && rel_r >= 0) {
+                    tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, rel_r);
+                    share_range(cnt, ndbits, S, rel_r, rel_r + 1, (my.y >> 8) & 0xFFu, my.w);
+                    if ((my.y >> 24) == 2u) pt_insert(S.pt, S.pt_over, rel_r, A.seq, (u64)my.x | ((u64)(my.y & 0xFFu) << 32));
+                }
+                // a fast-class read the pass does not take (fewer than 8 bases; the last reads of the seq array; an odd-start flank
+                // that fills its last chunk): one item per pass, as the fast class that is not plain in tile_items
+                u64 rest = __ballot((cur.pack & (LN_FAST | LN_PLAIN | LN_POINT)) == LN_FAST);
                 while (rest) {
                     const u32 j = (u32)__ffsll((long long)rest) - 1u;
                     rest &= rest - 1;
@@ -1288,25 +1351,49 @@ struct DirectBulk {
                     fast_apply(cnt, ndbits, S, asm_w, f, (u32)__builtin_amdgcn_readlane((int)my.w, (int)j), fast_load(A.seq, f, lane), lane);
                 }
             }
+            // the pass after this one: its sources are here (asked for a pass ago) and are reduced to what it needs; the sources
+            // of the pass after THAT are asked for now, then its tail bytes -- and its chunks one by one below, as this pass's
+            // chunks leave their registers
+            const Lean nxt = distill(A, M, pass + WAVES, na, nb, more && in_list(pass + WAVES, lane));
+            if (pass + 2u * WAVES < np) ask_sources(A, pass + 2u * WAVES, lane, na, nb);
+            const u32 tail_now = tail;
+            const u8 *const q_next = A.seq4 + (nxt.so_l >> 1);
+            const u8 *const t_next = A.seq4 + (((nxt.pack & LN_PLAIN) ? nxt.so_l + (((nxt.pack >> 12) & 0xFFu) - 1u) : 7ull) >> 1) - 3;
+
+            const int rel = (int)(cur.pack & 0xFFFu) - (int)LN_REL0;
+            const u32 L = (cur.pack >> 12) & 0xFFu;
+            const bool plain = (cur.pack & LN_PLAIN) != 0;
+            const u64 so = cur.so_l;
+            // ---- the plain reads ----
             const u32 adj = (u32)so & 1u;  // an odd start: base i of the read is nibble i + 1 of what is loaded
             int nkeep = trim4(tail_now, so + (L - 1u), L);
-            if (plain && nkeep < 0) nkeep = trim_bytes(A.seq + so, L);  // rare: see trim4
-            const u32 hi = min((u32)max(nkeep, 0), (u32)TILE - rel);    // the kept entries in the window: [0, hi) of the read
-            const bool live = plain && hi > 0;
+            if (cur.pack & LN_NOTRIM) nkeep = (int)L;  // (the flank in front of a read's single indel: its end is not the read's end)
+            else if (plain && nkeep < 0) nkeep = trim_bytes(A.seq + so, L);  // rare: see trim4
+            const int lo = max(0, -rel), hi = min(nkeep, TILE - rel);  // the kept entries in the window: [lo, hi) of the read
+            const bool live = plain && hi > lo;
             if (live) {
-                atomicAdd(&cnt[ROW_COV * TILE + rel], 1u);
-                if (rel + hi < (u32)TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
+                atomicAdd(&cnt[ROW_COV * TILE + rel + lo], 1u);
+                if (rel + hi < TILE) atomicAdd(&cnt[ROW_COV * TILE + rel + hi], 0xFFFFFFFFu);
             }
-            if (__ballot(live && (cur.pack & LN_SHARED))) {  // a depth share other than 1 (rare jobs: all-hits reads): k and the file index from the entry
+            if (__ballot(live && (cur.pack & LN_SHARED))) {  // a depth share other than 1 (rare jobs: all-hits reads): class and file index from the source
                 if (live && (cur.pack & LN_SHARED)) {
-                    const u32 a = entry_of(pass, lane);
-                    share_range(cnt, ndbits, S, (int)rel, (int)(rel + hi), kclass_of(A.wo[2ull * a].z), A.wo[2ull * a + 1].w);
+                    u32 kc, rec;
+                    if (pass < pm) {
+                        const u32 a = entry_of(pass, lane);
+                        kc = kclass_of(A.wo[2ull * a].z);
+                        rec = A.wo[2ull * a + 1].w;
+                    } else {
+                        const uint4 it = items[x0 + 64u * (pass - pm) + lane];
+                        kc = (it.y >> 8) & 0xFFu;
+                        rec = it.w;
+                    }
+                    share_range(cnt, ndbits, S, rel + lo, rel + hi, kc, rec);
                 }
             }
-            // nibble x of the loaded chunks <-> window position relc + x; the nibbles [adj, xhi) count (none of a lane that is not live)
-            const int relc = live ? (int)rel - (int)adj : 0;  // >= -1
-            const u32 xhi = live ? hi + adj : 0u;
-            const u32 *const mhi = S.pmask + xhi;
+            // nibble x of the loaded chunks <-> window position relc + x; the nibbles [xlo, xhi) count (none of a lane that is not live)
+            const int relc = live ? rel - (int)adj : 0;  // > -ASM4_PAD
+            const u32 xlo = live ? (u32)lo + adj : 0u, xhi = live ? (u32)hi + adj : 0u;
+            const u32 *const mlo = S.pmask + xlo, *const mhi = S.pmask + xhi;
             const u32 sh = (u32)(relc + ASM4_PAD) << 2;  // (v_alignbit takes it modulo 32)
             const u32 *const ap = asm4 + ((relc + ASM4_PAD) >> 3);  // the dword of asm4 with chunk 0's nibble 0; 4 NCH + 1 dwords from here
 #pragma unroll
@@ -1316,8 +1403,7 @@ struct DirectBulk {
                 const uint4 Wc = W[c];
                 u32 F = nz_perm(Wc.x ^ __builtin_amdgcn_alignbit(a1, a0, sh), Wc.y ^ __builtin_amdgcn_alignbit(a2, a1, sh),
                                 Wc.z ^ __builtin_amdgcn_alignbit(a3, a2, sh), Wc.w ^ __builtin_amdgcn_alignbit(a4, a3, sh));
-                F &= mhi[PMASK_BASE - 32 * c];
-                if (c == 0) F &= ~adj;  // (nibble 0 of an odd start is the base in front of the read)
+                F &= mhi[PMASK_BASE - 32 * c] & ~mlo[PMASK_BASE - 32 * c];
 #ifdef PP_EXP_NOCOMPARE
                 F = (Wc.x + Wc.y + Wc.z + Wc.w == 0x12345u && F) ? 1u : 0u;  // (experiment: the loads are waited for, nothing is tallied)
 #endif
@@ -1335,7 +1421,24 @@ struct DirectBulk {
                     atomicAdd(&cnt[row_of_code8(code) * TILE + p], 1u);
                     atomicAdd(&cnt[ROW_MIS * TILE + p], 1u);
                 }
-                W[c] = PP_EXP_LOAD16(q_next + 16 * c);  // the next pass's chunk c, into the registers this pass's has just left
+#if PP_GROUP_SPLIT > 0
+                // The next pass's chunks in two groups, each back to back -- chunks 0 .. PP_GROUP_SPLIT - 1 when this pass's chunk
+                // PP_GROUP_SPLIT - 1 is through, the others at the end: one by one (each into the registers its predecessor had just
+                // left) every load was an L1 miss of its own, the loads of a read's neighbouring 16 bytes far apart in time (17.8 M
+                // L1 -> L2 read requests per launch for 6.9 M L2 -> HBM ones, profiles/r6i_*; k_tile_direct 0.236 -> 0.217 ms).
+                if (c == PP_GROUP_SPLIT - 1) {
+#pragma unroll
+                    for (int cc = 0; cc < PP_GROUP_SPLIT; cc++) W[cc] = PP_EXP_LOAD16(PP_EXP_CHUNK(q_next, cc, lane));
+                }
+                if (c == NCH - 1 && PP_GROUP_SPLIT < NCH) {
+#pragma unroll
+                    for (int cc = PP_GROUP_SPLIT; cc < NCH; cc++) W[cc] = PP_EXP_LOAD16(PP_EXP_CHUNK(q_next, cc, lane));
+                }
+                if (c == NCH - 1) tail = load4_unaligned(t_next);  // (its tail bytes with them: the line its last chunk is in)
+#else
+                W[c] = PP_EXP_LOAD16(PP_EXP_CHUNK(q_next, c, lane));  // (experiment: the next pass's chunk c, into the registers this pass's has just left)
+                if (c == NCH - 1) tail = load4_unaligned(t_next);
+#endif
             }
             cur = nxt;
         }
@@ -1470,15 +1573,20 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     constexpr bool BULK = DIRECT && P4 && GW == 5;
     DirectBulk<5> D;
     if constexpr (BULK) {
+        const u32 n_x = min(A.x_cnt[w], A.xcap);  // the window's extras (asked for with the stretches)
         const BulkRuns runs = bulk_runs(A, w, lane);
         const u32 n_all = (u32)__builtin_amdgcn_readlane((int)runs.pre_v, (int)runs.R);  // the window's mirror entries
-        u32 v0 = 0, v1 = n_all;
+        u32 v0 = 0, v1 = n_all, x0 = 0, x1 = n_x;
         if (heavy) {  // this helper's share (as below)
             const u32 vchunk = ((n_all + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
             v0 = min(n_all, part * vchunk);
             v1 = min(n_all, v0 + vchunk);
+            const u32 chunk = ((n_x + HEAVY_PARTS - 1u) / HEAVY_PARTS + 63u) & ~63u;
+            x0 = min(n_x, part * chunk);
+            x1 = min(n_x, x0 + chunk);
         }
-        D.begin(A, runs, v0, v1 - v0, (u32)__builtin_amdgcn_readfirstlane((int)wave), lane);
+        D.begin(A, runs, v0, v1 - v0, A.xent + (u64)w * A.xcap, (u32)__builtin_amdgcn_readfirstlane((int)x0),
+                (u32)__builtin_amdgcn_readfirstlane((int)(x1 - x0)), (u32)__builtin_amdgcn_readfirstlane((int)wave), lane);
     }
     for (u32 i = tid; i < (u32)(N_ROWS * TILE / 4); i += TILE_THREADS) ((uint4 *)cnt)[i] = make_uint4(0, 0, 0, 0);  // (16 bytes a store)
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
@@ -1543,7 +1651,9 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             s_run[48] = (u32)lo64; s_run[49] = (u32)(lo64 >> 32); s_run[50] = (u32)len64; s_run[51] = (u32)(len64 >> 32);
         }
     }
+#ifndef PP_EXP_STAGE_LATE
     if constexpr (BULK) D.stage(A, lane);  // the first pass's chunks and the second's entries: asked for in front of the barrier
+#endif
     __syncthreads();
     PP_STOP_AFTER(1)
 
@@ -1587,25 +1697,26 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
         constexpr u32 WAVES = TILE_THREADS / 64;
         if constexpr (BULK) {
-            // The window's work as PASSES of 64, dealt to the waves one by one: the passes over its mirror entries (DirectBulk)
-            // first, then its extras [i0, i1) as passes of their own -- pass j of them takes every n-th extra from j on --
-            // through tile_items.  Every pass but the last of either kind is full: at 50x a window is 11 + 1 passes where a
-            // sixteenth of one list per wave made 16 of them, two thirds full.  The extras' SLOW items are only listed here
-            // (ItemList::defer; the list lives behind the tables in s_dirty's space) and tallied in a round of their own below,
-            // a sixteenth per wave: k_prepg's pieces sit at the tail of a window's extras, hundreds of them in a window whose
-            // reads cross two planted indels, a memory round trip each.
-            D.run(A, cnt, s_ndbits, S, asm_w, asm4, M, lane);
-            const u32 pm = (M.nv + 63u) >> 6, px = (i1 - i0 + 63u) >> 6;
-            for (u32 g = pm + ((wave + WAVES - pm % WAVES) % WAVES); g < pm + px; g += WAVES) {
-                const u32 j = g - pm;  // (the first global pass >= pm that is this wave's: g = wave modulo WAVES)
-                tile_items<GW, P4, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1,
-                                          ItemList{i0 + j, (i1 - i0 - j - 1u) / px + 1u, px, nullptr, s_slow, &s_nslow, SLOW_CAP}, wave, lane);
-            }
+            // The window's work as PASSES of 64, dealt to the waves one by one (DirectBulk): the passes over its mirror entries,
+            // then its extras [i0, i1) in the same pipeline.  Every pass but the last of either kind is full: at 50x a window
+            // is 11 + 1 passes where a sixteenth of one list per wave made 16 of them, two thirds full.  The extras' SLOW items
+            // are only listed there (the list lives behind the tables in s_dirty's space) and tallied in a round of their own
+            // below, a sixteenth per wave, through tile_items: k_prepg's pieces sit at the tail of a window's extras, hundreds
+            // of them in a window whose reads cross two planted indels, a memory round trip each.
+#ifdef PP_EXP_STAGE_LATE
+            D.stage(A, lane);  // (experiment: behind the barrier)
+#endif
+            D.run(A, cnt, s_ndbits, S, asm_w, asm4, M, s_slow, &s_nslow, SLOW_CAP, lane);
             __syncthreads();
-            const u32 n_slow = min(s_nslow, SLOW_CAP);
-            if (wave < n_slow)  // (every sixteenth of the list, one batch of at most SLOW_CAP / 16 <= 64 items per wave)
+            const u32 n_slow = s_nslow;
+            if (n_slow > SLOW_CAP) {  // more slow items than the list holds: every wave looks through a sixteenth of the extras for them
+                const u32 n = i1 - i0;
+                if (wave < n)
+                    tile_items<GW, P4, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1,
+                                              ItemList{i0 + wave, (n - wave - 1u) / WAVES + 1u, WAVES, nullptr, nullptr, nullptr, 0u, true}, wave, lane);
+            } else if (wave < n_slow)  // (every sixteenth of the list, one batch of at most SLOW_CAP / 16 <= 64 items per wave)
                 tile_items<GW, P4, false>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1,
-                                          ItemList{wave, (n_slow - wave - 1u) / WAVES + 1u, WAVES, s_slow, nullptr, nullptr, 0u}, wave, lane);
+                                          ItemList{wave, (n_slow - wave - 1u) / WAVES + 1u, WAVES, s_slow, nullptr, nullptr, 0u, true}, wave, lane);
         } else {
             constexpr u32 IPP = (P4 && GW == 5) ? 1u : PlainCfg<GW>::IPP;  // (as tile_items: whole passes of the plain class)
             tile_items<GW, P4, DIRECT>(A, cnt, s_ndbits, S, asm_w, asm4, items, M, i0, i1, wave_slice<IPP>(i0, i1, wave), wave, lane);

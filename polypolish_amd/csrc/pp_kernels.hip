@@ -222,6 +222,7 @@ extern "C" int pp_polish_begin(pp_ctx *ctx, uint32_t n_contigs, const uint64_t *
     ctx->acc_n = ctx->acc_seq = ctx->acc_cig = 0;
     ctx->emit.clear();
     ctx->wo_runs.clear();
+    ctx->wo_untrusted = false;
     memset(&ctx->dbatch, 0, sizeof ctx->dbatch);
     return PP_OK;
 }
@@ -407,6 +408,8 @@ extern "C" int pp_polish_add(pp_ctx *ctx, const pp_aln_batch *b, int mem) {
                      !b->cig_off || !b->n_cig || !b->seq || !b->cigar))
         return ctx->fail(PP_ERR_ARG, "pp_polish_add: null array in a non-empty batch");
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
+    // a mirror that is not one of the library's own (or part of one) is compared with the arrays before it is used (run_pipeline)
+    if (b->wo && b->n_aln && !pp_mirror_trusted_(b->wo, (size_t)b->n_aln * sizeof(pp_wo_rec))) ctx->wo_untrusted = true;
     if (!ctx->have_batch && mem == PP_MEM_DEVICE) {
         ctx->dbatch = *b;
         runs_join(ctx, b, 0);  // (copied: the caller's table is only borrowed for the call)
@@ -452,6 +455,7 @@ static int map_device_error(pp_ctx *ctx, uint64_t key) {
     case DE_TOO_DEEP: return ctx->fail(PP_ERR_LIMIT, "window %llu has more than 2^21 overlapping alignments", idx);
     case DE_BAD_MIRROR: return ctx->fail(PP_ERR_ARG, "entry %llu of the window-order mirror (pp_aln_batch.wo) names a record the batch does not have, "
                                                      "or (PP_CHECK_WO=1) one that another entry names too, or does not carry that record's fields", idx);
+    case DE_SEQ_RANGE: return ctx->fail(PP_ERR_ARG, "alignment record %llu: its SEQ bytes (seq_off + seq_len) lie outside the batch's seq array", idx);
     case DE_OVERFLOW: return ctx->fail(PP_ERR_LIMIT, "32-bit work-item count or reference span overflow (record/window %llu)", idx);
     default: return ctx->fail(PP_ERR_HIP, "internal device inconsistency %u at %llu", code, idx);
     }
@@ -492,7 +496,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     static const bool env_no_direct = getenv("PP_DIRECT") && atoi(getenv("PP_DIRECT")) == 0;  // tuning / tests
     static const bool env_no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
     const uint32_t n_runs = (uint32_t)ctx->wo_runs.size();
-    const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && n > 0 && B.wo && n_runs > 0 &&
+    const bool direct = !env_no_direct && !env_no_wo && !ctx->no_direct && !ctx->no_wo && n > 0 && B.wo && n_runs > 0 &&
                         n_runs <= PP_WO_MAX_RUNS && ctx->wo_runs.back() == n;
     ctx->last_direct = direct;
     if (!ctx->emit.empty() && !ctx->debug && !ctx->no_compact && !direct) {
@@ -550,7 +554,14 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
             own_est = std::max<uint64_t>(1, std::min<uint64_t>(own_est, nwin));
         }
         while (want < n / own_est / 4 + 64) want <<= 1;
-        ctx->xcap = std::max<size_t>(ctx->xcap, (size_t)want);
+        // Every window gets the same room, so ONE deep window (a collapsed repeat, a plasmid at 10,000x) sets it for all of them:
+        // the room is capped at what keeps the windows' rooms together under PP_XENT_BUDGET bytes (default 8 GiB, never less than
+        // the job's own estimate) -- a window that needs more sends the job over the bucketing path, which takes such a job with
+        // 20 bytes per record (pp_polish_finish).  The room is this job's: what an earlier, deeper job of the context grew it
+        // to is kept only while it stays under the cap.
+        static const uint64_t xent_budget = getenv("PP_XENT_BUDGET") ? strtoull(getenv("PP_XENT_BUDGET"), nullptr, 10) : (8ull << 30);
+        ctx->xcap_limit = (size_t)std::max<uint64_t>(want, xent_budget / ((uint64_t)nwin * 16));
+        ctx->xcap = std::min<size_t>(std::max<size_t>(ctx->xcap, (size_t)want), ctx->xcap_limit);
         ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)1 << 18);  // (work items in memory: only what k_xmat writes out)
     } else {
         ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
@@ -569,7 +580,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     ENS(b_hslab, (size_t)HEAVY_SLOTS * HEAVY_PARTS * HSLAB_WORDS * 4);
     if (!direct) { ENS(b_gstart, n * 4); ENS(b_nkeep, n * 4); }
     if (direct) {
-        ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 8);  /* extras per window | entries that are not bulk per window */ ENS(b_xent, (uint64_t)nwin * ctx->xcap * 16);
+        ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 8);  /* extras per window | entries that are not bulk per window */ if (dev_ensure(ctx, ctx->b_xent, (size_t)((uint64_t)nwin * ctx->xcap * 16))) { (void)hipGetLastError(); ctx->no_direct = true; return run_pipeline(ctx, meta, n_entries_out); }  /* (no room for the windows' extras: the bucketing path) */
         ENS(b_need_win, (uint64_t)nwin * 4); ENS(b_win_lo, (uint64_t)nwin * 4); ENS(b_win_hi, (uint64_t)nwin * 4);
         ENS(b_later, cap_later * 32);
         std::vector<uint32_t> ends(ctx->wo_runs.begin(), ctx->wo_runs.end());
@@ -708,9 +719,12 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // (the average over the windows the context works on: a sharded job that is not compacted has its records there)
     const u32 heavy_min = forced_heavy > 0 ? (u32)forced_heavy
                                            : (u32)std::min<uint64_t>(MAX_BUCKET, std::max<uint64_t>(HEAVY_MIN_ITEMS, 3 * n / 2 / std::max<uint32_t>(1, n_own_win)));
-    // PP_CHECK_WO=1: the mirror checked against the arrays before anything reads the records through it
-    static const bool check_wo = getenv("PP_CHECK_WO") && atoi(getenv("PP_CHECK_WO")) != 0;
-    if (check_wo && B.wo && !env_no_wo && n) {
+    // The mirror checked against the arrays before anything reads the records through it: every mirror that is not one of the
+    // library's own (pp_polish_add), and any with PP_CHECK_WO=1.  One that does not stand the check (DE_BAD_MIRROR) is left
+    // aside: pp_polish_finish runs the job again without it.
+    static const bool env_check_wo = getenv("PP_CHECK_WO") && atoi(getenv("PP_CHECK_WO")) != 0;
+    const bool check_wo = env_check_wo || (ctx->wo_untrusted && !ctx->trust_all);
+    if (check_wo && B.wo && !env_no_wo && !ctx->no_wo && n) {
         if ((rc = dev_ensure(ctx, ctx->b_aflag, (size_t)((n + 31) / 32) * 4))) return rc;
         PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_aflag.p, 0, (size_t)((n + 31) / 32) * 4, st));
         hipLaunchKernelGGL(k_check_wo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64)n, B.wo, B.contig, B.ref_start, B.k,
@@ -721,7 +735,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     const bool fused_count = ncoarse <= (uint32_t)COUNT_RANGE;  // the columns (windows, or coarse buckets) fit one LDS range
     // the records through the batch's window-order mirror when it brings one (pp_aln_batch.wo; PP_WO=0: tuning / tests)
     static const bool no_wo = getenv("PP_WO") && atoi(getenv("PP_WO")) == 0;
-    const pp_wo_rec *d_wo = no_wo ? nullptr : B.wo;
+    const pp_wo_rec *d_wo = no_wo || ctx->no_wo ? nullptr : B.wo;
 #ifdef PP_PREP_STAMPS
     static DevBuf b_pstamps;
     const size_t pstamp_bytes = (size_t)2 * 16384 * 64;  // (8 ticks per workgroup, 16384 workgroups per kernel, two kernels)
@@ -749,7 +763,7 @@ PrepdArgs PA;
         PA.run_end = (const u32 *)ctx->b_runs.p; PA.n_runs = n_runs; PA.first = (u32 *)ctx->b_first.p;
         PA.x_cnt = (u32 *)ctx->b_xcnt.p; PA.x_nb = (u32 *)ctx->b_xcnt.p + nwin; PA.xent = (uint4 *)ctx->b_xent.p; PA.xcap = (u32)ctx->xcap;
         PA.maxlen = (u32 *)(d_meta + 9); PA.x_need = d_meta + 12;
-        PA.g_later = (uint4 *)ctx->b_later.p; PA.g_nlater = d_meta + 15; PA.cap_later = cap_later;
+        PA.g_later = (uint4 *)ctx->b_later.p; PA.g_nlater = d_meta + 15; PA.cap_later = cap_later; PA.seq_bytes = B.seq_bytes;
         PA.status = d_status;
         if (nbd_threads == 1024) hipLaunchKernelGGL(k_prepd<1024>, dim3(NBD), dim3(1024), 0, st, (u64)chunk_d, PA);
         else hipLaunchKernelGGL(k_prepd<512>, dim3(NBD), dim3(512), 0, st, (u64)chunk_d, PA);
@@ -781,11 +795,11 @@ PrepdArgs PA;
         if (d_wo)                                                                                                               \
             hipLaunchKernelGGL((k_fill<CWV, true>), dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, d_gstart,   \
                                d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,            \
-                               (const u32 *)(OFF), ENT, frange, d_status);                                                     \
+                               (const u32 *)(OFF), ENT, frange, (u64)B.seq_bytes, d_status);                                   \
         else                                                                                                                    \
             hipLaunchKernelGGL((k_fill<CWV, false>), dim3(NB, ncranges), dim3(1024), 0, st, (u64)n, (u64)chunk, d_wo, d_gstart,  \
                                d_nkeep, B.k, (const u64 *)B.seq_off, B.seq_len, nwin, ncoarse, (const u32 *)d_hist,            \
-                               (const u32 *)(OFF), ENT, frange, d_status);                                                     \
+                               (const u32 *)(OFF), ENT, frange, (u64)B.seq_bytes, d_status);                                   \
     } while (0)
     if (two_level) {
         if (!fused_count) {  // more than 16384 coarse buckets (a 2 Gbp assembly): counted range by range
@@ -1067,6 +1081,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     int attempt = 0;
     ctx->no_compact = false;
     ctx->no_direct = false;
+    ctx->no_wo = false;
     for (;; attempt++) {
         timers_release(ctx);
         int rc = run_pipeline(ctx, meta, &n_entries);
@@ -1079,6 +1094,13 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
         }
         if ((key & 0xFF) == DE_GW_HINT && ctx->maxlen_hint != (uint32_t)meta[9]) {  // k_tile's instance does not take this job's reads: the one that does
             ctx->maxlen_hint = (uint32_t)meta[9];
+            continue;
+        }
+        if ((key & 0xFF) == DE_BAD_MIRROR && !ctx->no_wo) {  // the mirror is not what its name says (a hint: every result the same without it)
+            static const bool trace_m = getenv("PP_TIMING") != nullptr;
+            if (trace_m) fprintf(stderr, "[timing] pass %d: entry %llu of the window-order mirror does not mirror its record -> the job runs without the mirror\n",
+                                 attempt + 1, (unsigned long long)(key >> 8));
+            ctx->no_wo = true;
             continue;
         }
         if ((key & 0xFF) == DE_MIRROR_ORDER && !ctx->no_direct) {  // the mirror is not in the order its run table promises: the bucketing path
@@ -1100,7 +1122,14 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
             grew = true;
         };
         grow(ctx->cap_ent, ctx->last_direct ? meta[14] : meta[3], "work items");
-        if (ctx->last_direct) grow(ctx->xcap, meta[12], "extras per window");
+        if (ctx->last_direct && meta[12] > ctx->xcap) {
+            if (meta[12] + meta[12] / 8 + 1024 > ctx->xcap_limit) {  // one window needs more room than every window can be given: the bucketing path
+                if (trace) fprintf(stderr, "[timing] pass %d: a window needs %llu extras (room for %zu at most) -> bucketing path\n", attempt + 1,
+                                   (unsigned long long)meta[12], ctx->xcap_limit);
+                ctx->no_direct = true;
+                grew = true;
+            } else grow(ctx->xcap, meta[12], "extras per window");
+        }
         grow(ctx->cap_flag, std::min<uint64_t>(cnt[0], G), "listed positions");
         grow(ctx->cap_scr, meta[10], "replay scratch");
         grow(ctx->cap_multi, cnt[1], "multi-byte winners");
@@ -1362,6 +1391,13 @@ extern "C" void pp_ctx_enable_peers_(pp_ctx *const *ctxs, int n) {
 }
 
 extern "C" int pp_ctx_device_(const pp_ctx *ctx) { return ctx ? ctx->device : -1; }
+// (internal: bench / tests that lay their batches out as the library's ingests do) every window-order mirror this context is
+// given counts as one of the library's own: not compared with the arrays before it is used
+extern "C" int pp_ctx_trust_mirrors_(pp_ctx *ctx, int on) {
+    if (!ctx) return PP_ERR_ARG;
+    ctx->trust_all = on != 0;
+    return PP_OK;
+}
 extern "C" int pp_ctx_set_error_(pp_ctx *ctx, int code, const char *msg) {
     if (ctx) ctx->err = msg ? msg : "";
     return code;

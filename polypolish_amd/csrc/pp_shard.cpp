@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "polypolish_hip.h"
+#include "pp_host.h"
 
 namespace {
 constexpr uint64_t WINDOW_ALIGN = 2048;  // the device's tile width: windows start on tile boundaries
@@ -127,4 +128,28 @@ extern "C" int pp_shard_assemble(const pp_shard_plan *p, const uint8_t *const *r
     }
     contig_out_off[p->n_contigs] = w;
     return PP_OK;
+}
+
+// ---- the library's own window-order mirrors (pp_internal.h) ------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_mirror_mu;
+std::map<const void *, std::pair<const char *, const char *>> g_mirrors;  // owner -> [lo, hi)
+}  // namespace
+void pp_mirror_register_(const void *owner, const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    if (p && bytes) g_mirrors[owner] = {(const char *)p, (const char *)p + bytes};
+    else g_mirrors.erase(owner);
+}
+void pp_mirror_forget_(const void *owner) {
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    g_mirrors.erase(owner);
+}
+bool pp_mirror_trusted_(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mirror_mu);
+    const char *lo = (const char *)p, *hi = lo + bytes;
+    for (const auto &kv : g_mirrors)
+        if (lo >= kv.second.first && hi <= kv.second.second) return true;
+    return false;
 }

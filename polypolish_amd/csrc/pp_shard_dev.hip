@@ -248,6 +248,7 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
     v.n_aln = n; v.seq_bytes = seq_bytes; v.n_cig_total = n_cig_total;
     v.seq4 = P->mem == PP_MEM_DEVICE ? (const u8 *)P->d[10] : nullptr;  // a device part brings the 4-bit mirror of its seq array
     v.wo = !P->has_wo || n == 0 ? nullptr : (P->mem == PP_MEM_DEVICE ? (const pp_wo_rec *)P->d[11] : P->h_wo.data());  // ... and both kinds the window-order mirror, when the source has one
+    pp_mirror_register_(P, v.wo, v.wo ? (size_t)n * sizeof(pp_wo_rec) : 0);  // (one of the library's own: pp_polish_add takes it unchecked)
     v.wo_n_runs = v.wo ? (uint32_t)P->wo_runs.size() : 0;  // ... with its runs (a restriction of an ascending run is one)
     v.wo_run_end = v.wo_n_runs ? P->wo_runs.data() : nullptr;
     if (P->mem == PP_MEM_DEVICE) {
@@ -490,6 +491,7 @@ extern "C" void pp_shard_part_batch(const pp_shard_part *part, pp_aln_batch *out
 
 extern "C" void pp_shard_part_free(pp_shard_part *P) {
     if (!P) return;
+    pp_mirror_forget_(P);
     if (P->mem == PP_MEM_DEVICE && P->ctx) {
         (void)hipSetDevice(P->ctx->device);
         (void)hipStreamSynchronize(P->ctx->stream);

@@ -586,6 +586,7 @@ extern "C" int pp_dev_ingest_create(pp_ctx *ctx, const pp_assembly *a, uint32_t 
 
 extern "C" void pp_dev_ingest_free(pp_dev_ingest *D) {
     if (!D) return;
+    pp_mirror_forget_(D);
     if (D->pf) {
         if (D->pf->th.joinable()) D->pf->th.join();
         reap_mapping(D->pf->F);
@@ -632,6 +633,7 @@ extern "C" void pp_dev_ingest_batch(const pp_dev_ingest *D, pp_aln_batch *out) {
     out->seq_bytes = D->seq_bytes;
     out->seq4 = D->mirror() && D->seq_bytes ? (const u8 *)D->o_seq4.p : nullptr;
     out->wo = D->wo_mirror && D->n_out ? (const pp_wo_rec *)D->o_wo.p : nullptr;
+    pp_mirror_register_(D, out->wo, out->wo ? (size_t)D->n_out * sizeof(pp_wo_rec) : 0);  // (one of the library's own: pp_polish_add takes it unchecked)
     const bool runs = out->wo && !D->wo_run_end.empty() && D->wo_run_end.back() == D->n_out;
     out->wo_n_runs = runs ? (uint32_t)D->wo_run_end.size() : 0;  // (HOST memory, whatever the batch's)
     out->wo_run_end = runs ? D->wo_run_end.data() : nullptr;

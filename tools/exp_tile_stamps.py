@@ -67,3 +67,10 @@ for b in late:
 edges = np.arange(0, end[ran].max() + 25, 25)
 busy = [(int(((start[idx] < e + 25) & (end[idx] > e)).sum())) for e in edges]
 print("blocks in flight per 25 us:", busy)
+# the longest blocks, phase by phase
+dur = (end - start)
+longest = idx[np.argsort(-dur[idx])[:8]]
+print("longest blocks (window: start | prologue, items, prefix sums + pass 1, pass 2 + epilogue):")
+for b in longest:
+    print("  block %5d window %5d heavy %d: start %.1f | %.1f %.1f %.1f %.1f = %.1f us" %
+          (b, win[b], heavy[b], start[b], pro[b] - start[b], mid[b] - pro[b], p1[b] - mid[b], end[b] - p1[b], dur[b]))
