@@ -167,7 +167,7 @@ def live_traffic(argv_tail, kernel):
         d = tempfile.mkdtemp(prefix="pp_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-live-traffic", "--no-second-layout"] + argv_tail
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-live-traffic", "--no-second-layout", "--no-other-configs"] + argv_tail
             r = subprocess.run(cmd, capture_output=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
             if r.returncode != 0:
                 return None
@@ -456,6 +456,8 @@ def main():
                          "(PP_SEQ_LAYOUT=file: the layout of rounds 1-3)")
     ap.add_argument("--no-second-layout", action="store_true", help="skip the second roofline entry (SEQ bytes in file order, no mirror: rounds 1-3)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (one GPU)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact entries of configs[2], [3], [4] and the no-speculation step (child runs of this command)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes (the committed figure is used if the workload matches)")
     ap.add_argument("--e2e-only", action="store_true", help="only the end-to-end CLI leg of --config (no kernel bench)")
@@ -514,6 +516,10 @@ def main():
 
     import polypolish_amd as pp
     ctx = pp.Context(dev_index)
+    # The resident job is laid out exactly as the library's ingests lay a batch out (tests/test_synthjob_cpu.py), but its
+    # window-order mirror is built here, not by them: told so, the library takes it as one of its own instead of comparing
+    # it with the arrays on every step (what that comparison costs a foreign caller: "foreign_mirror_check_ms" below).
+    ctx.trust_mirrors(True)
 
     lens, coverage, repeat, label = config_shape(args.config, args.genome, args.coverage)
     G_total = int(sum(lens))
@@ -891,8 +897,70 @@ def main():
             out["roofline_filter"] = filter_roofline(ctx, pp, device, int(sum(lens)) * coverage // (2 * args.read_len), int(sum(lens)))
         except Exception as e:  # noqa: BLE001 -- (a report, not the metric)
             out["roofline_filter"] = {"error": str(e)}
-    if world == 1 and not args.no_e2e:
+    if world == 1:
+        # (1) a fresh context's FIRST job of this very batch: what the steady-state step does not pay -- buffer allocation, the
+        # contig table's upload, k_meta_init in front, the exact replays' launches not yet left out, a pass that only finds
+        # out how much room the windows' extras need.  Host clock around begin / add / finish.
+        torch.cuda.synchronize()
+        fresh = pp.Context(dev_index)
+        fresh.trust_mirrors(True)
+        fresh.sync()
+        t1 = time.perf_counter()
+        run_job(fresh, pp, job)
+        first_ms = (time.perf_counter() - t1) * 1e3
+        fresh.set_profiling(1)
+        t1 = time.perf_counter()
+        run_job(fresh, pp, job)
+        second_ms = (time.perf_counter() - t1) * 1e3
+        passes2 = fresh.kernel_times()["n_passes"]
+        fresh.set_profiling(0)
+        out["first_job_ms"] = round(first_ms, 3)
+        out["first_job_note"] = ("a fresh context's first begin / add / finish of this batch, host clock: device buffers allocated, contig table "
+                                 f"uploaded, capacities found (reruns); its second job {second_ms:.3f} ms in {passes2} pass(es), before the replays' "
+                                 "launches are left out and the next job's metadata are set up ahead (ms_per_step is the steady state)")
+        del fresh
+        # (2) what the check of a FOREIGN window-order mirror costs (the same batch, not taken on trust): per step
+        ctx.trust_mirrors(False)
+        for _ in range(3):
+            run_job(ctx, pp, job)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            run_job(ctx, pp, job)
+        ctx.sync()
+        out["foreign_mirror_check_ms"] = round((time.perf_counter() - t1) * 1e2 - ms_per_step, 4)
+        ctx.trust_mirrors(True)
+    if world == 1 and not args.no_other_configs and not args.no_live_traffic and default_shape and args.config == 1:
+        # (3) the other GPU configurations, compact and driver-timed: child runs of this command (their jobs do not fit next to
+        # this one's), and configs[1] once more without the two steady-state shortcuts (PP_SPECULATE=0 PP_INIT_AHEAD=0)
+        def child(extra, env=None):
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-e2e", "--no-cpu-baseline", "--no-live-traffic", "--no-second-layout",
+                   "--no-other-configs", "--steps", "10", "--warmup", "3"] + extra
+            try:
+                r = subprocess.run(cmd, capture_output=True, timeout=400, env=dict(os.environ, **(env or {})))
+                return json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001 -- (a report, not the metric)
+                return {"error": str(e)[:200]}
         del job
+        torch.cuda.empty_cache()
+        job = None
+        others = {}
+        for c in (2, 3, 4):
+            d = child(["--config", str(c)])
+            others[f"configs[{c}]"] = d if "error" in d else {
+                "workload": d["config"]["workload"][:80], "ms_per_step": d["ms_per_step"], "mbp_per_s": d["value"],
+                "kernel": d["roofline"]["kernel"], "kernel_ms": d["roofline"]["kernel_ms"], "frac": d["roofline"]["frac"],
+                "whole_path_frac": d["roofline"]["whole_path_frac"], "first_job_ms": d.get("first_job_ms"),
+                "parity": ("planted errors recovered: the polished contigs equal the truth" if d.get("planted_errors_recovered")
+                           else ("all-hits repeats: planted-error check does not apply" if d.get("planted_errors_recovered") is None else "MISMATCH")),
+                "positions_replayed_exactly": d["work"]["positions_replayed_exactly"]}
+        out["other_configs"] = others
+        d = child([], {"PP_SPECULATE": "0", "PP_INIT_AHEAD": "0"})
+        out["ms_per_step_without_steady_state_shortcuts"] = d if "error" in d else {
+            "ms_per_step": d["ms_per_step"], "env": "PP_SPECULATE=0 PP_INIT_AHEAD=0",
+            "note": "every step launches the exact replays (five kernels) and k_meta_init in front, as a context's first jobs do"}
+    if world == 1 and not args.no_e2e:
+        job = None
         torch.cuda.empty_cache()
         out["e2e"] = end_to_end(device, args.config, lens, coverage, repeat, seed=4242 + args.config, keep_dir=args.e2e_dir,
                                 recipe=args.recipe)

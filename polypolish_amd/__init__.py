@@ -801,6 +801,15 @@ class Context:
               for s in stats]
         return out[:n].tobytes(), offs, st
 
+    def trust_mirrors(self, on=True):
+        """(internal hook, pp_ctx_trust_mirrors_) every window-order mirror this context is given counts as one of the library's
+        own: it is not compared with the arrays before the kernels read the records through it.  For callers that lay their
+        batches out exactly as the library's ingests do (bench.py's resident job; tests/test_synthjob_cpu.py checks that it does)."""
+        f = lib().pp_ctx_trust_mirrors_
+        f.argtypes = [C.c_void_p, C.c_int]
+        f.restype = C.c_int
+        self._chk(f(self._h, int(bool(on))))
+
     def took_direct_path(self):
         """True when the last pp_polish_finish took its bulk straight from the window-order mirror (pp_aln_batch.wo_run_end)."""
         return bool(lib().pp_polish_took_direct_path(self._h))

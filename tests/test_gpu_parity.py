@@ -1735,12 +1735,14 @@ def test_replays_are_left_out_after_a_clean_job_and_come_back_when_needed(ctx, o
         assert m["polished"] == want["polished"] and np.array_equal(m["offsets"], want["offsets"])
 
 
-def test_window_order_mirror_is_checked_on_request(orc, tmp_path):
-    """pp_aln_batch.wo is a hint the kernels trust (its producers are the library's own); PP_CHECK_WO=1 has it checked against
-    the arrays it mirrors before anything reads the records through it: every entry a record of the batch, none twice,
-    every field the record's.  A faithful mirror passes (in run order and shuffled); an entry that names a
-    record twice, one out of range, and one with a wrong field are the caller's error -- on the direct path and on the
-    bucketing path -- and without the check an entry out of range still is."""
+def test_a_foreign_window_order_mirror_is_checked_before_it_is_used(orc, tmp_path):
+    """pp_aln_batch.wo is a hint: every result is the same with and without it (include/polypolish_hip.h).  A mirror that is not
+    one of the library's own (its ingests', pp_shard_split's -- a registry of their address ranges) is compared with the arrays
+    it mirrors before anything reads the records through it: every entry a record of the batch, none twice, every field the
+    record's.  A faithful mirror passes -- in run order (the direct path), shuffled, without a run
+    table --; one that names a record twice, one out of range, one with a wrong field (an altered ref_start, a wrong k) is
+    left aside and the job gives the oracle's bytes over the bucketing path, never other bytes, never an error
+    (/root/reference src/alignment.rs:297-303: every good alignment is applied exactly as parsed)."""
     code = """
 import sys, os, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -1753,6 +1755,7 @@ want = orc.polish_records(o, b, r)["polished"]
 real = pp.window_order_mirror
 for order in (True, "shuffled", "no_runs"):
     assert tg._polish_device_batch(ctx, pp, o, b, r, True, wo=order)["polished"] == want
+    assert ctx.took_direct_path() == (order is True), order
 def broken(kind):
     def make(recs, off):
         w = real(recs, off)
@@ -1760,24 +1763,55 @@ def broken(kind):
         if kind == "range": w["file_idx"][5] = len(w) + 3
         if kind == "field": w["ref_start"][11] += 1
         if kind == "k": w["k"][3] += 1
+        if kind == "seq_off": w["seq_off"][9] += 32
         return w
     return make
-checked = os.environ.get("PP_CHECK_WO") == "1"
-for kind in ("twice", "range", "field", "k"):
+for kind in ("twice", "range", "field", "k", "seq_off"):
     pp.window_order_mirror = broken(kind)
     for order in (True, "no_runs"):
-        try:
-            tg._polish_device_batch(ctx, pp, o, b, r, True, wo=order)
-            failed = None
-        except pp.PolypolishError as e:
-            failed = e
-        if checked or kind == "range":
-            assert failed is not None and failed.code == pp.ERR_ARG and "window-order mirror" in failed.msg, (kind, order, failed)
+        got = tg._polish_device_batch(ctx, pp, o, b, r, True, wo=order)
+        assert got["polished"] == want, (kind, order)
+        assert not ctx.took_direct_path(), (kind, order)
 print("mirror check ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
-    for env in ({"PP_CHECK_WO": "1"}, {}):
-        r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ, **env), timeout=600)
-        assert r.returncode == 0 and b"mirror check ok" in r.stdout, (env, r.stderr.decode()[-2000:])
+    r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ), timeout=600)
+    assert r.returncode == 0 and b"mirror check ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_extras_room_is_capped_and_a_deep_window_takes_the_bucketing_path(orc):
+    """the direct path gives every window the same room for extras, so one deep window would set it for all of
+    them.  The room is capped (PP_XENT_BUDGET bytes for all windows together, never below the job's own estimate); a window
+    that needs more sends the job over the bucketing path -- same bytes, no error.  Here the budget is one byte and most reads
+    carry an indel (every piece of such a read is an extra)."""
+    code = """
+import sys, os, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, synth, polypolish_amd as pp
+import test_gpu_parity as tg
+from oracle import orc
+ctx = pp.Context(0)
+o, b, r = synth.fast_records(seed=5, contig_lens=(30_000,), coverage=300, indel_read_frac=0.9)
+want = orc.polish_records(o, b, r)["polished"]
+got = tg._polish_device_batch(ctx, pp, o, b, r, True, wo=True)
+assert got["polished"] == want
+assert not ctx.took_direct_path()
+print("capped ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run(["python", "-c", code], capture_output=True, env=dict(os.environ, PP_XENT_BUDGET="1"), timeout=600)
+    assert r.returncode == 0 and b"capped ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_a_record_whose_seq_lies_outside_the_seq_array_is_refused(ctx, pp):
+    """seq_off + seq_len beyond seq_bytes was only caught where it passed 2^40.  Both paths refuse the record (the
+    caller broke the batch's contract: PP_ERR_ARG), naming it."""
+    o, b, r = synth.fast_records(seed=8, contig_lens=(20_000,), coverage=20)
+    r = dict(r)
+    r["seq_off"] = r["seq_off"].copy()
+    r["seq_off"][17] = len(r["seq"]) - 5
+    for wo in (True, None):
+        with pytest.raises(pp.PolypolishError) as e:
+            _polish_device_batch(ctx, pp, o, b, r, True, wo=wo)
+        assert e.value.code == pp.ERR_ARG and "record 17" in e.value.msg and "seq array" in e.value.msg, e.value.msg
 
 
 def test_filter_seam_verdicts_with_and_without_the_sampling_call(ctx, pp):
