@@ -143,7 +143,13 @@ typedef struct {
      * is there: a workgroup's records then fall into a handful of windows and its work items are written next to each
      * other, where the file order scatters them over the whole assembly (the bucketing kernels take 0.15 instead of 0.25 ms
      * on the 5 Mbp / 200x job).  The library's ingests bring one; pp_polish_add carries it along while every batch of the
-     * job has one. */
+     * job has one.
+     * The hint is ENFORCED (round 6): a mirror that is not one of the library's own (pp_ingest_batch, pp_dev_ingest_batch, the
+     * parts of pp_shard_split, or a part of one of those) is compared with the arrays on the device before anything reads the
+     * records through it -- every entry a record of the batch, none twice, contig / ref_start / k / seq_off / seq_len / first
+     * run the record's -- and one that does not stand the comparison is left aside: the job runs without it and gives the
+     * same bytes.  The comparison is a scattered read of the arrays (about 1 ms per 6.7 M records): a caller whose mirror is
+     * not worth that should not pass one. */
     const struct pp_wo_rec *wo;
     /* Optional with wo (0 / NULL = not known): the mirror as RUNS.  wo_n_runs stretches of entries, one behind the other
      * (one per SAM file, as the library's ingests write it), each of them window-grouped IN ASCENDING WINDOW ORDER;
@@ -277,8 +283,10 @@ typedef struct {
 int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel group, 2 only the dominant kernel ("tile") */
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
 /* Which way the last pp_polish_finish of this context went: 1 = the direct path (the window-order mirror and its run table:
- * pp_aln_batch.wo_run_end), 0 = the bucketing path (no mirror, no run table, a sharded job, or a mirror that turned out not
- * to be in run order).  The results are the same either way; for reports (bench.py names the kernel it timed). */
+ * pp_aln_batch.wo_run_end -- a rank of a sharded job included: pp_shard_split restricts the table with the mirror), 0 = the
+ * bucketing path (no mirror, no run table, more than PP_WO_MAX_RUNS runs, the one-process multi-GPU driver's slice views, a
+ * mirror that turned out not to be in run order or not to mirror its records, a window that needs more room for its extras
+ * than the windows can be given).  The results are the same either way; for reports (bench.py names the kernel it timed). */
 int pp_polish_took_direct_path(const pp_ctx *ctx);
 
 /* ---- multi-GPU: contigs (and windows of a large contig) shard across ranks -----------------------------------------

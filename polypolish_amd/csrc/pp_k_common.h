@@ -135,6 +135,23 @@ __device__ __forceinline__ int row_of(u32 c) {
     return (c == expect) ? (int)t : (c == (u32)'-' ? ROW_DEL : ROW_OTH);
 }
 
+// Inclusive prefix sum over the wave's 64 lanes with data-parallel primitives (gfx9 DPP: shifts inside a row of 16 lanes, then
+// lane 15 of a row to the next row, lane 31 to the upper half): six v_add with a DPP operand and no address registers, where
+// six __shfl_up are six ds_bpermute with an index register each -- indices the compiler kept alive from k_tile's prologue to
+// its prefix sums, in scratch memory across the item loop (round 6).
+__device__ __forceinline__ u32 wave_scan_incl(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// (every lane of the wave has to be active where these two are called: an inactive lane's register is what a DPP operand reads)
+__device__ __forceinline__ u32 wave_sum_dpp(u32 v) {  // (the same value in every lane)
+    return (u32)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
+}
 __device__ __forceinline__ u32 wave_sum(u32 v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;

@@ -135,7 +135,10 @@ struct PrepdArgs {
 // Two round trips: (1) the run count and where the runs are, and the read's last eight bytes (the trims look at the read
 // from its end and rarely further); (2) the first eight runs.  (A record of one run has it in its mirror entry.)  Anything
 // beyond is read where it is needed, as in k_prep.
-template <typename CTG>
+// RUNS_IN_REGS = false (k_prepd's own fallback, a workgroup whose noted records do not fit the lists): the runs are read where
+// they are needed -- the eight-run cache is an indexed array, and in k_prepd's loop it went to scratch memory (48 bytes a
+// lane reserved for every wave of the streaming kernel).
+template <bool RUNS_IN_REGS = true, typename CTG>
 __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdArgs &P, CTG ctg, const XSink &X) {
     u32 g_out = 0, nk_out = 0;
     u8 fl_out = 0;
@@ -156,18 +159,21 @@ __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdAr
         if (nc == 0) report(P.status, fi, DE_BAD_RUN);
         else {
             const u32 *const cg = P.cigar + co;
-            u32 rr[8] = {r.op0, 0, 0, 0, 0, 0, 0, 0};
-            if (multi) {
-#pragma unroll
-                for (u32 j = 0; j < 8u; j++) rr[j] = cg[min(j, nc - 1u)];
+            // (eight scalars, not an array: indexed, the array went to scratch memory -- a memory round trip per run in the
+            // kernel whose time is its chain of round trips)
+            u32 r0 = r.op0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+            if (RUNS_IN_REGS && multi) {
+                r0 = cg[0];
+                r1 = cg[min(1u, nc - 1u)]; r2 = cg[min(2u, nc - 1u)]; r3 = cg[min(3u, nc - 1u)]; r4 = cg[min(4u, nc - 1u)];
+                r5 = cg[min(5u, nc - 1u)]; r6 = cg[min(6u, nc - 1u)]; r7 = cg[min(7u, nc - 1u)];
             }
             prep_general_t(fi, r.ref_start, sl, nc,
                            [&](u32 i) -> u32 {
+                               if (!RUNS_IN_REGS) return multi ? cg[i] : r.op0;
                                if (i >= 8u) return cg[i];
-                               u32 v = rr[0];
-#pragma unroll
-                               for (u32 j = 1; j < 8u; j++) v = i == j ? rr[j] : v;
-                               return v;
+                               const u32 a = (i & 1u) ? r1 : r0, b = (i & 1u) ? r3 : r2, c = (i & 1u) ? r5 : r4, d = (i & 1u) ? r7 : r6;
+                               const u32 ab = (i & 2u) ? b : a, cd = (i & 2u) ? d : c;
+                               return (i & 4u) ? cd : ab;
                            },
                            [&](u32 i) -> u8 { return sl >= 8u && i + 8u >= sl ? (u8)(tail8 >> (8u * (i + 8u - sl))) : sq[i]; },
                            c_lo, c_hi - c_lo, &g_out, &nk_out, &fl_out, P.status);
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
         for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
             const pp_wo_rec r = wo[a];
             const u32 cc = min(r.contig, n_contigs - 1u);
-            if (!wo_bulk(r.contig < n_contigs, r.ref_start, r.seq_len, r.op0, ctg(cc + 1u) - ctg(cc))) general_record(r, P, ctg, X);
+            if (!wo_bulk(r.contig < n_contigs, r.ref_start, r.seq_len, r.op0, ctg(cc + 1u) - ctg(cc))) general_record<false>(r, P, ctg, X);
         }
     }
     PP_STAMP(0, 4);

@@ -1135,19 +1135,44 @@ __device__ __forceinline__ void tile_items(const TileArgs &A, u32 *cnt, u32 *s_n
 struct BulkRuns {  // the window's stretches of the mirror in two registers: lane r holds pre[r] (its entries in the runs before r; lane R: all of them) and first[r]
     u32 pre_v, first_v, R;
 };
-__device__ __forceinline__ BulkRuns bulk_runs(const TileArgs &A, u32 w, u32 lane) {
+// -DPP_TILE_SLOAD (measured, not the default: k_tile_direct 0.1925 vs 0.1952 ms on configs[1], nothing on configs[4] --
+// inside the noise, not worth inline assembly in the product): a handful of uniform words at the top of a workgroup -- the
+// window's stretch of every run, its extras' count -- come through the SCALAR cache (s_load_dword, inline: the compiler only uses scalar loads for memory it can prove nobody writes): as vector
+// loads they queue behind everything else the CU's vector memory pipeline has in flight (2 us of every workgroup's chain
+// entries -> chunks -> first pass).  What the words hold was written by the kernels before this one (the scalar cache is
+// invalidated at the start of a kernel).  All requests go out before the one wait.
+// (one asm statement: the requests and the wait together -- between two statements the compiler may copy a destination register
+// that the load has not written yet)
+constexpr u32 SLOAD_RUNS = 2;  // runs whose stretches are fetched this way (a job of more SAM files: vector loads, as before)
+__device__ __forceinline__ void sload5(const u32 *p0, const u32 *p1, const u32 *p2, u32 &a0, u32 &a1, u32 &b0, u32 &b1, u32 &c) {
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x4\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %6, 0x4\n\t"
+                 "s_load_dword %4, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a0), "=&s"(a1), "=&s"(b0), "=&s"(b1), "=&s"(c)
+                 : "s"(p0), "s"(p1), "s"(p2)
+                 : "memory");
+}
+__device__ __forceinline__ BulkRuns bulk_runs(const TileArgs &A, u32 w, u32 lane, u32 *n_extras) {
     BulkRuns B;
     const u32 R = A.n_runs;
     u32 len = 0, f0 = 0;
-    if (lane < R) {
-        f0 = A.first[(u64)lane * (A.nwin + 1u) + w];
-        len = A.first[(u64)lane * (A.nwin + 1u) + w + 1u] - f0;
+#ifdef PP_TILE_SLOAD
+    if (R <= SLOAD_RUNS) {
+        u32 a0, a1, b0, b1, xc;
+        const u32 *const row0 = A.first + w, *const row1 = A.first + (u64)(R - 1u) * (A.nwin + 1u) + w;  // (one run: its row twice)
+        sload5(row0, row1, A.x_cnt + w, a0, a1, b0, b1, xc);
+        *n_extras = xc;
+        if (lane == 0) { f0 = a0; len = a1 - a0; }
+        if (lane == 1 && R > 1u) { f0 = b0; len = b1 - b0; }
+    } else
+#endif
+    {
+        *n_extras = A.x_cnt[w];
+        if (lane < R) {
+            f0 = A.first[(u64)lane * (A.nwin + 1u) + w];
+            len = A.first[(u64)lane * (A.nwin + 1u) + w + 1u] - f0;
+        }
     }
-    u32 inc = len;
-    for (int o = 1; o < (int)PP_WO_MAX_RUNS; o <<= 1) {
-        const u32 t = (u32)__shfl_up((int)inc, o, 64);
-        if ((int)lane >= o) inc += t;
-    }
+    const u32 inc = wave_scan_incl(len);  // (the lanes from R on hold 0)
     const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, (int)(R - 1u));
     B.pre_v = lane < R ? inc - len : total;
     B.first_v = f0;
@@ -1540,7 +1565,12 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         if (threadIdx.x == 0) report(A.status, (1ull << 40) - 1ull, DE_GW_HINT);
         return;
     }
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (the wave's number in a scalar register, the lane's from v_mbcnt, the thread's from the two: three values that live across
+    // the whole kernel, none of them in a vector register that has to be kept -- or spilled: the item loop of the direct path
+    // left four registers of them in scratch memory, 80 MB of traffic per launch on configs[1])
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const u32 tid = (wave << 6) | lane;
     const u64 w0 = (u64)w * TILE;
 #ifdef PP_TILE_STAMPS
     if (tid == 0) {
@@ -1573,8 +1603,9 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     constexpr bool BULK = DIRECT && P4 && GW == 5;
     DirectBulk<5> D;
     if constexpr (BULK) {
-        const u32 n_x = min(A.x_cnt[w], A.xcap);  // the window's extras (asked for with the stretches)
-        const BulkRuns runs = bulk_runs(A, w, lane);
+        u32 n_x_raw;
+        const BulkRuns runs = bulk_runs(A, w, lane, &n_x_raw);
+        const u32 n_x = min(n_x_raw, A.xcap);  // the window's extras (asked for with the stretches)
         const u32 n_all = (u32)__builtin_amdgcn_readlane((int)runs.pre_v, (int)runs.R);  // the window's mirror entries
         u32 v0 = 0, v1 = n_all, x0 = 0, x1 = n_x;
         if (heavy) {  // this helper's share (as below)
@@ -1787,15 +1818,11 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     auto scan_row = [&](u32 *row) {
         const u32 d0 = row[2 * tid], d1 = row[2 * tid + 1];
         const u32 sum = d0 + d1;
-        u32 inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 v = __shfl_up(inc, o, 64);
-            if ((int)lane >= o) inc += v;
-        }
+        const u32 inc = wave_scan_incl(sum);
         if (lane == 63) s_wsum[wave] = inc;
         __syncthreads();
-        u32 base = 0;
-        for (u32 i = 0; i < wave; i++) base += s_wsum[i];
+        // the waves in front: their totals (one per lane), summed
+        const u32 base = wave_sum_dpp(lane < wave ? s_wsum[lane & 15u] : 0u);
         const u32 ex = base + inc - sum;
         row[2 * tid] = ex + d0;
         row[2 * tid + 1] = ex + d0 + d1;
@@ -2010,9 +2037,9 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
     }
     PP_STOP_AFTER(5)
-    my_len = wave_sum(my_len);
-    my_changed = wave_sum(my_changed);
-    my_zero = wave_sum(my_zero);
+    my_len = wave_sum_dpp(my_len);
+    my_changed = wave_sum_dpp(my_changed);
+    my_zero = wave_sum_dpp(my_zero);
     my_depth = wave_sum64(my_depth);
     if (lane == 0) {
         if (my_len) atomicAdd(&s_len, my_len);

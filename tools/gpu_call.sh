@@ -14,7 +14,7 @@ total=2400
 if [ "${1:-}" = "-t" ]; then total=$2; shift 2; fi
 step_timeout=${STEP_TIMEOUT:-900}
 out=gpurun_out/$name
-script="mkdir -p $out; cd /tmp; export TMPDIR=/tmp; cd \$GRAFT_REPO_ROOT; : > $out/status.txt;"
+script="ulimit -c 0; mkdir -p $out; cd /tmp; export TMPDIR=/tmp; cd \$GRAFT_REPO_ROOT; : > $out/status.txt;"
 i=0
 for s in "$@"; do
     i=$((i + 1)); n=$(printf %02d $i)
