@@ -1151,31 +1151,40 @@ __device__ __forceinline__ void sload5(const u32 *p0, const u32 *p1, const u32 *
                  : "s"(p0), "s"(p1), "s"(p2)
                  : "memory");
 }
-__device__ __forceinline__ BulkRuns bulk_runs(const TileArgs &A, u32 w, u32 lane, u32 *n_extras) {
-    BulkRuns B;
+struct BulkRunsRaw {  // as loaded: lane r's stretch of the window in run r, and the window's count of extras
+    u32 f0, len, n_extras;
+};
+__device__ __forceinline__ BulkRunsRaw bulk_runs_load(const TileArgs &A, u32 w, u32 lane) {
+    BulkRunsRaw raw{0u, 0u, 0u};
     const u32 R = A.n_runs;
-    u32 len = 0, f0 = 0;
 #ifdef PP_TILE_SLOAD
     if (R <= SLOAD_RUNS) {
         u32 a0, a1, b0, b1, xc;
         const u32 *const row0 = A.first + w, *const row1 = A.first + (u64)(R - 1u) * (A.nwin + 1u) + w;  // (one run: its row twice)
         sload5(row0, row1, A.x_cnt + w, a0, a1, b0, b1, xc);
-        *n_extras = xc;
-        if (lane == 0) { f0 = a0; len = a1 - a0; }
-        if (lane == 1 && R > 1u) { f0 = b0; len = b1 - b0; }
+        raw.n_extras = xc;
+        if (lane == 0) { raw.f0 = a0; raw.len = a1 - a0; }
+        if (lane == 1 && R > 1u) { raw.f0 = b0; raw.len = b1 - b0; }
     } else
 #endif
     {
-        *n_extras = A.x_cnt[w];
-        if (lane < R) {
-            f0 = A.first[(u64)lane * (A.nwin + 1u) + w];
-            len = A.first[(u64)lane * (A.nwin + 1u) + w + 1u] - f0;
-        }
+        // (no load under a condition -- a lane past the last run reads the last run's words and drops them: a conditional load
+        // is waited for where its branch ends, and the words asked for in front of it with it)
+        const u32 r = min(lane, R - 1u);
+        const u32 xc = A.x_cnt[w], a = A.first[(u64)r * (A.nwin + 1u) + w], b = A.first[(u64)r * (A.nwin + 1u) + w + 1u];
+        raw.n_extras = xc;
+        raw.f0 = lane < R ? a : 0u;
+        raw.len = lane < R ? b - a : 0u;
     }
-    const u32 inc = wave_scan_incl(len);  // (the lanes from R on hold 0)
+    return raw;
+}
+__device__ __forceinline__ BulkRuns bulk_runs_scan(const TileArgs &A, const BulkRunsRaw &raw, u32 lane) {
+    BulkRuns B;
+    const u32 R = A.n_runs;
+    const u32 inc = wave_scan_incl(raw.len);  // (the lanes from R on hold 0)
     const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, (int)(R - 1u));
-    B.pre_v = lane < R ? inc - len : total;
-    B.first_v = f0;
+    B.pre_v = lane < R ? inc - raw.len : total;
+    B.first_v = raw.f0;
     B.R = R;
     return B;
 }
@@ -1558,8 +1567,20 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
             w = first[lo] + (w - before[lo]);
         }
         if (w >= A.nwin) return;
-        if (A.win_heavy[w]) return;  // listed windows belong to the helpers
     }
+    constexpr bool BULK = DIRECT && P4 && GW == 5;
+    // (BULK: where the window's entries lie in every run and how many extras it has -- asked for HERE, with the three words the
+    // next lines wait for: behind them it was a round trip of its own at the start of every workgroup)
+    const u32 lane_early = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const u32 listed = (u32)A.win_heavy[w];  // (read by a helper too: a load under a condition is waited for where the branches meet)
+    BulkRunsRaw raw_runs{0u, 0u, 0u};
+    BulkRuns runs_early{0u, 0u, 0u};
+    if constexpr (BULK) {
+        // (... and scanned here, in front of the early returns: loads nobody uses on the returning path are moved behind the branch)
+        raw_runs = bulk_runs_load(A, w, lane_early);
+        runs_early = bulk_runs_scan(A, raw_runs, lane_early);
+    }
+    if (listed && !heavy) return;  // listed windows belong to the helpers
     if (status_word != ~0ull && (status_word & 0xFFu) != DE_CAPACITY_LATE) return;  // (job_state == 2: aborted)
     if (longest > PlainCfg<GW>::MAXL) {  // not this instance's job (the host's hint was off: it reruns with the right one)
         if (threadIdx.x == 0) report(A.status, (1ull << 40) - 1ull, DE_GW_HINT);
@@ -1600,12 +1621,10 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     // The bulk of a direct window, one lane per mirror entry (DirectBulk): every wave works the window's stretches out for
     // itself (2 n_runs loads) and asks for its first pass's entries right away -- the rest of the prologue (zeroing the
     // counters, the assembly's bytes and codes, the tables) runs while they are on their way.
-    constexpr bool BULK = DIRECT && P4 && GW == 5;
     DirectBulk<5> D;
     if constexpr (BULK) {
-        u32 n_x_raw;
-        const BulkRuns runs = bulk_runs(A, w, lane, &n_x_raw);
-        const u32 n_x = min(n_x_raw, A.xcap);  // the window's extras (asked for with the stretches)
+        const BulkRuns runs = runs_early;
+        const u32 n_x = min(raw_runs.n_extras, A.xcap);  // the window's extras (asked for with the stretches)
         const u32 n_all = (u32)__builtin_amdgcn_readlane((int)runs.pre_v, (int)runs.R);  // the window's mirror entries
         u32 v0 = 0, v1 = n_all, x0 = 0, x1 = n_x;
         if (heavy) {  // this helper's share (as below)
