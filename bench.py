@@ -203,49 +203,60 @@ def filter_roofline(ctx, pp, device, n_pairs, G, read_len=150, reps=5):
     i32, i64 = torch.int32, torch.int64
     keep = []
 
-    def ffile(start, flags):
+    def ffile(start, flags, with_ref_end):
         t = dict(ref_id=torch.zeros(n, dtype=i32, device=device), ref_start=start.to(i32), flags=flags.to(i32),
                  cig_off=torch.arange(n, dtype=i64, device=device), n_cig=torch.ones(n, dtype=i32, device=device),
                  cigar=torch.full((n,), (read_len << 4) | 0, dtype=i32, device=device), read=torch.arange(n, dtype=i32, device=device),
-                 grp_off=torch.arange(n + 1, dtype=i32, device=device), grp_idx=torch.arange(n, dtype=i32, device=device))
+                 grp_off=torch.arange(n + 1, dtype=i32, device=device), grp_idx=torch.arange(n, dtype=i32, device=device),
+                 ref_end=(start + read_len).to(i64))
         keep.append(t)
         return pp.FilterFile(n, t["ref_id"].data_ptr(), t["ref_start"].data_ptr(), t["flags"].data_ptr(), t["cig_off"].data_ptr(),
                              t["n_cig"].data_ptr(), t["cigar"].data_ptr(), n, t["read"].data_ptr(), t["grp_off"].data_ptr(),
-                             t["grp_idx"].data_ptr(), None)
+                             t["grp_idx"].data_ptr(), t["ref_end"].data_ptr() if with_ref_end else None)
     s1 = torch.randint(0, max(G - 1000, 1), (n,), device=device, generator=g)
     ins = torch.clamp((350 + 35 * torch.randn(n, device=device, generator=g)).round().long(), 160, 700)
     s2 = s1 + ins - read_len
     fwd_first = torch.rand(n, device=device, generator=g) < 0.5           # which mate is the forward one
-    f1 = ffile(torch.where(fwd_first, s1, s2), torch.where(fwd_first, 0, 16))
-    f2 = ffile(torch.where(fwd_first, s2, s1), torch.where(fwd_first, 16, 0))
-    inp = pp.FilterInput(n, (pp.FilterFile * 2)(f1, f2))
     orient, insert = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
     p1, p2 = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
-    torch.cuda.synchronize()
     L = pp.lib()
-    ctx.set_profiling(1)
-    tot = {}
-    try:
-        for rep in range(reps + 1):
-            ctx._chk(L.pp_filter_begin(ctx._h, C.byref(inp), pp.MEM_DEVICE))
-            ctx._chk(L.pp_filter_samples(ctx._h, orient.ctypes.data, insert.ctypes.data))
-            lo, hi = int(np.percentile(insert, 0.1)), int(np.percentile(insert, 99.9))
-            ctx._chk(L.pp_filter_pairs(ctx._h, lo, hi, 0, p1.ctypes.data, p2.ctypes.data))
-            kt = pp.KernelTimes()
-            L.pp_filter_kernel_times(ctx._h, C.byref(kt))
-            if rep:  # (the first run allocates)
-                for k, v in kt.as_dict()["ms"].items():
-                    tot[k] = tot.get(k, 0.0) + v
-    finally:
-        ctx.set_profiling(0)
+
+    def run(with_ref_end):
+        f1 = ffile(torch.where(fwd_first, s1, s2), torch.where(fwd_first, 0, 16), with_ref_end)
+        f2 = ffile(torch.where(fwd_first, s2, s1), torch.where(fwd_first, 16, 0), with_ref_end)
+        inp = pp.FilterInput(n, (pp.FilterFile * 2)(f1, f2))
+        torch.cuda.synchronize()
+        ctx.set_profiling(1)
+        tot = {}
+        try:
+            for rep in range(reps + 1):
+                ctx._chk(L.pp_filter_begin(ctx._h, C.byref(inp), pp.MEM_DEVICE))
+                ctx._chk(L.pp_filter_samples(ctx._h, orient.ctypes.data, insert.ctypes.data))
+                lo, hi = int(np.percentile(insert, 0.1)), int(np.percentile(insert, 99.9))
+                ctx._chk(L.pp_filter_pairs(ctx._h, lo, hi, 0, p1.ctypes.data, p2.ctypes.data))
+                kt = pp.KernelTimes()
+                L.pp_filter_kernel_times(ctx._h, C.byref(kt))
+                if rep:  # (the first run allocates)
+                    for k, v in kt.as_dict()["ms"].items():
+                        tot[k] = tot.get(k, 0.0) + v
+        finally:
+            ctx.set_profiling(0)
+        return tot
+    # the input as the ABI's general form hands it over (CIGAR runs: the kernel works the ends out), and with the ends
+    # precomputed (pp_filter_file.ref_end: what the device loader, pp_filter_dev_input, hands over -- no CIGAR array is read)
+    tot_cigar = run(False)
+    tot = run(True)
+    ms_cigar = sum(tot_cigar.values()) / reps
     ms = {k: v / reps for k, v in tot.items()}
     total_ms = sum(ms.values())
     b_alg = 17 * 2 * n + 8 * n
-    # what the pass reads and writes as the ABI hands the input over (include/polypolish_hip.h, pp_filter_file: CIGAR runs
-    # instead of ref_end, a group index per alignment): per read 8 B of group offsets, per alignment grp_idx, ref_id, ref_start,
-    # flags, n_cig and one run (4 B each) and cig_off (8 B) in, one verdict byte out; the sample (1 + 4 B) out per read
-    b_abi = n * 8 + 2 * n * (6 * 4 + 8 + 1) + n * 5
+    # what the pass reads and writes as the ABI hands the input over (include/polypolish_hip.h, pp_filter_file: 32-bit fields, a
+    # group index per alignment): per read 8 B of group offsets, per alignment grp_idx, ref_id, ref_start, flags (4 B each) and
+    # ref_end (8 B) in, one verdict byte out; the sample (1 + 4 B) out per read
+    b_abi = n * 8 + 2 * n * (4 * 4 + 8 + 1) + n * 5  # (with ref_end: grp_idx, ref_id, ref_start, flags (4 B each) and ref_end (8 B) per alignment)
     return {"bound": "hbm", "kernels": "k_filter_reads ('samples') + k_filter_listed ('pairs': the reads with several alignments; none here)", "kernel_ms": {k: round(v, 4) for k, v in sorted(ms.items())},
+            "input": "ends precomputed (pp_filter_file.ref_end, as pp_filter_dev_input hands the input over): no CIGAR array is read",
+            "with_cigar_runs_instead_of_ref_end": {"total_ms": round(ms_cigar, 4), "frac": round(b_alg / (ms_cigar * 1e-3) / 1e9 / 8000.0, 4) if ms_cigar else 0.0},
             "total_ms": round(total_ms, 4), "algorithmic_bytes": b_alg, "achieved": round(b_alg / (total_ms * 1e-3) / 1e9, 1) if total_ms else 0.0,
             "peak": 8000.0, "unit": "GB/s", "frac": round(b_alg / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,
             "bytes_the_abi_makes_them_move": b_abi, "frac_of_peak_on_those": round(b_abi / (total_ms * 1e-3) / 1e9 / 8000.0, 4) if total_ms else 0.0,

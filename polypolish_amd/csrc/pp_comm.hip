@@ -11,7 +11,12 @@
 // else in the library depends on it.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "pp_internal.h"
@@ -44,9 +49,13 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl R = [] {
         Rccl r;
+        // PP_RCCL_LIB: another library with the same nine entry points (tests/fake_rccl.cpp: a stand-in that runs several ranks
+        // on ONE device, so that the one-process driver's RCCL route and a rank that fails to join can be exercised on a
+        // one-GPU box)
+        if (const char *alt = getenv("PP_RCCL_LIB")) r.lib = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) return r;
 #define PP_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
@@ -95,8 +104,39 @@ extern "C" int pp_comm_init(pp_ctx *ctx, int rank, int world, const void *id) {
     PP_HIPCHK(ctx, hipSetDevice(ctx->device));
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
+    // ncclCommInitRank returns when EVERY rank has joined: a rank that failed before it got here (or was never started)
+    // would keep the others inside it for good.  The call runs on a helper thread and is waited for
+    // with a deadline (PP_COMM_TIMEOUT seconds, default 120); past it this rank returns an error -- the helper stays behind in
+    // the call (there is no communicator yet to abort), which costs a failing process one parked thread.
+    struct Join {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t c = nullptr;
+    };
+    auto join = std::make_shared<Join>();
+    const int device = ctx->device;
+    std::thread([join, world, u, rank, device]() {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = rccl().CommInitRank(&c, world, u, rank);
+        std::lock_guard<std::mutex> lk(join->m);
+        join->r = r;
+        join->c = c;
+        join->done = true;
+        join->cv.notify_all();
+    }).detach();
+    const long limit = getenv("PP_COMM_TIMEOUT") ? std::max(1L, atol(getenv("PP_COMM_TIMEOUT"))) : 120L;
     ncclComm_t c = nullptr;
-    PP_NCCLCHK(ctx, rccl().CommInitRank(&c, world, u, rank));
+    {
+        std::unique_lock<std::mutex> lk(join->m);
+        if (!join->cv.wait_for(lk, std::chrono::seconds(limit), [&] { return join->done; }))
+            return ctx->fail(PP_ERR_HIP, "ncclCommInitRank (rank %d of %d) did not return within %ld s: a rank of the job has not joined "
+                                         "(it failed before it got there, or was never started)", rank, world, limit);
+        if (join->r != ncclSuccess) return ctx->fail(PP_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(join->r));
+        c = join->c;
+    }
     ctx->comm = c;
     ctx->comm_rank = rank;
     ctx->comm_world = world;

@@ -1860,7 +1860,11 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     // proper is ~200 instructions with two f64 multiplies per position, and a wave runs it for all of its 64 lanes or
     // for none.
     u32 my_len = 0, my_changed = 0, my_zero = 0;
-    u64 my_depth = 0;
+    // (depths: whole reads are counted in 32 bits -- a lane sees two positions of at most 2^21 items each --, only the positions of
+    // a window with shared reads carry fractions: 64-bit sums, and their 64-bit wave total, only there)
+    u32 my_cov = 0;
+    u64 my_dfx = 0;
+    const bool win_shared = s_shared != 0;
     const bool one_contig = (s_c0 == s_c1);
     for (u32 p0 = tid; p0 < (u32)TILE; p0 += TILE_THREADS) {
         const u64 gp = w0 + p0;
@@ -1885,7 +1889,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
                     A.code[gp] = orig;
                     my_len += 1u;
                     my_zero += cov == 0;
-                    my_depth += (u64)cov << DEPTH_FX_BITS;
+                    my_cov += cov;
                 } else dirty = true;
             }
         }
@@ -2035,7 +2039,8 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         } else A.code[gp] = v.out;
         const u32 ch = (v.status == PP_ST_CHANGED), z = (ntot == 0);
         if (one_contig) {
-            my_len += l; my_changed += ch; my_zero += z; my_depth += dfx;
+            my_len += l; my_changed += ch; my_zero += z;
+            if (win_shared) my_dfx += dfx; else my_cov += ntot;  // (no shared read in the window: dfx = ntot << DEPTH_FX_BITS)
         } else {
             my_len += l;
             const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
@@ -2059,7 +2064,8 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     my_len = wave_sum_dpp(my_len);
     my_changed = wave_sum_dpp(my_changed);
     my_zero = wave_sum_dpp(my_zero);
-    my_depth = wave_sum64(my_depth);
+    u64 my_depth = (u64)wave_sum_dpp(my_cov) << DEPTH_FX_BITS;
+    if (win_shared) my_depth += wave_sum64(my_dfx);
     if (lane == 0) {
         if (my_len) atomicAdd(&s_len, my_len);
         if (my_changed) atomicAdd(&s_changed, my_changed);

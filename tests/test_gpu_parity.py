@@ -1413,6 +1413,38 @@ def test_cli_polishes_on_several_contexts_in_one_process(orc, tmp_path, n_ctx):
         assert stat(multi.stderr) == stat(single.stderr) and len(stat(multi.stderr)) > 12, ingest
 
 
+def test_one_process_driver_gathers_over_the_communicator_and_survives_a_rank_that_never_joins(orc, tmp_path):
+    """VERDICT r5 item 8 / ADVICE r4.  The one-process multi-GPU driver's RCCL route (PP_GATHER=rccl: pp_comm_init from one
+    thread per context, pp_polish_gather's AllGather of sizes + one group of Send / Recv, one D2H) has never run with more
+    than one rank -- RCCL refuses two ranks on one device.  With tests/fake_rccl.cpp as the communicator library (PP_RCCL_LIB:
+    the same nine entry points, ranks as threads of one process on one device) it runs here with 2 and 3 contexts and gives
+    the oracle's bytes.  And a rank that fails before it joins (FAKE_RCCL_FAIL_RANK: its ncclCommInitRank returns an error, the
+    others wait for it as RCCL's would, for good) no longer keeps the command: pp_comm_init gives up after PP_COMM_TIMEOUT
+    seconds, the driver falls back to the route where every device copies its share out, same bytes."""
+    import time
+    ds = synth.rich_dataset(str(tmp_path), seed=91, contig_lens=(120_000, 2_000, 40_000), coverage=12, repeat_len=300, repeat_copies=3)
+    sams = [ds["sam1"], ds["sam2"]]
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    fake = os.path.join(str(tmp_path), "librccl_fake.so")
+    b = subprocess.run(["hipcc", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-o", fake],
+                       capture_output=True, timeout=300)
+    assert b.returncode == 0, b.stderr.decode()[-2000:]
+    want = orc.polish_files(ds["fasta"], sams)["fasta"]
+    for n_ctx in (2, 3):
+        r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, timeout=300,
+                           env=dict(os.environ, PP_SHARE_GPU=str(n_ctx), PP_GATHER="rccl", PP_RCCL_LIB=fake, PP_TIMING="1"))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"ONE RCCL gather" in r.stderr, r.stderr.decode()[-2000:]
+        assert r.stdout == want, n_ctx
+    t0 = time.time()
+    r = subprocess.run([exe, "polish", ds["fasta"], *sams], capture_output=True, timeout=120,
+                       env=dict(os.environ, PP_SHARE_GPU="3", PP_GATHER="rccl", PP_RCCL_LIB=fake, PP_TIMING="1", FAKE_RCCL_FAIL_RANK="1",
+                                PP_COMM_TIMEOUT="3"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"every device copies its share out" in r.stderr and r.stdout == want
+    assert time.time() - t0 < 60
+
+
 @pytest.mark.parametrize("world", [3, 8])
 def test_device_split_equals_host_split(ctx, pp, orc, world):
     """pp_shard_split on a device batch (kernels: flag, scans, gather of the SoA / SEQ bytes / CIGAR runs) gives the part
