@@ -272,6 +272,24 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     const uint4 *wq = (const uint4 *)wo;
     const u64 trip = (u64)WU * blockDim.x;
     const u64 span = (hi - lo + trip - 1) / trip * trip;  // whole waves and whole trips: the ballots below need every lane
+#ifdef PP_EXP_PREPD_EXTRA_STREAM
+    // (experiment build: one more pass over the block's entries that only loads them -- what the streaming alone costs)
+    {
+        u32 acc = 0;
+        for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
+            uint4 xa[WU], xb[WU];
+#pragma unroll
+            for (int u = 0; u < WU; u++) {
+                const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);
+                xa[u] = wq[2 * a];
+                xb[u] = wq[2 * a + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < WU; u++) acc ^= xa[u].x ^ xa[u].y ^ xa[u].z ^ xa[u].w ^ xb[u].x ^ xb[u].y ^ xb[u].z ^ xb[u].w;
+        }
+        if (acc == 0x12345679u && n == 1) first[0] = acc;
+    }
+#endif
     for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
         uint4 qa[WU], qb[WU];
         u32 pc[WU], pr[WU];
@@ -325,12 +343,16 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
             }
             // a bulk read that reaches into the next window: one extra there
             const u32 w1 = bulk ? (u32)((g + seq_len - 1u) / (u64)TILE) : 0u;
+#ifndef PP_EXP_PREPD_NOEMIT
             if (bulk && w1 > h) X.emit(w1, wo_item(seq_off, seq_len, kclass_of(k), g, w1, file_idx));
+#endif
             if (bulk) fast_len = max(fast_len, seq_len);
+#ifndef PP_EXP_PREPD_NOLATER
             else if (in) {
                 const u32 slot = atomicAdd(&n_later, 1u);
                 if (slot < LATER_MAX) { later[2u * slot] = qa[u]; later[2u * slot + 1u] = qb[u]; }
             }
+#endif
         }
     }
     PP_STAMP(0, 2);

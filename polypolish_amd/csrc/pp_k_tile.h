@@ -1487,7 +1487,8 @@ constexpr u32 HEAVY_BLOCKS = HEAVY_SLOTS * HEAVY_PARTS;      // helper blocks at
 #define PP_TILE_LAZY_ARGS 1
 #endif
 // Profiling builds only (make variant NAME=stopK DEFS=-DPP_TILE_STOP=K, tools/exp_tile_phases.sh): an ordinary window's
-// workgroup ends behind phase K -- 1 prologue, 2 items, 3 prefix sums, 4 vote pass 1, 5 vote pass 2 -- so that the counters
+// workgroup ends behind phase K -- 9 at its start, 8 the first entries asked for, 1 prologue, 2 items, 3 prefix sums, 4 vote pass 1,
+// 5 vote pass 2 -- so that the counters
 // and the duration of the truncated kernels give every phase's instructions and its share of the time (the window then
 // emits nothing: the results are wrong by design).
 #ifndef PP_TILE_STOP
@@ -1568,6 +1569,10 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         }
         if (w >= A.nwin) return;
     }
+    if (PP_TILE_STOP == 9 && !heavy) {  // (profiling build: what a workgroup costs that does nothing)
+        if (threadIdx.x == 0) { A.win_len[w] = 0; A.win_nflag[w] = 0; }
+        return;
+    }
     constexpr bool BULK = DIRECT && P4 && GW == 5;
     // (BULK: where the window's entries lie in every run and how many extras it has -- asked for HERE, with the three words the
     // next lines wait for: behind them it was a round trip of its own at the start of every workgroup)
@@ -1638,6 +1643,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         D.begin(A, runs, v0, v1 - v0, A.xent + (u64)w * A.xcap, (u32)__builtin_amdgcn_readfirstlane((int)x0),
                 (u32)__builtin_amdgcn_readfirstlane((int)(x1 - x0)), (u32)__builtin_amdgcn_readfirstlane((int)wave), lane);
     }
+    PP_STOP_AFTER(8)  // (profiling build: the window's stretches known, the first pass's entries asked for)
     for (u32 i = tid; i < (u32)(N_ROWS * TILE / 4); i += TILE_THREADS) ((uint4 *)cnt)[i] = make_uint4(0, 0, 0, 0);  // (16 bytes a store)
     if (tid < (u32)(TILE / 32)) { s_fbits[tid] = 0; s_ndbits[tid] = 0; }
     {

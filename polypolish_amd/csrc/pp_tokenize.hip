@@ -468,15 +468,19 @@ __global__ __launch_bounds__(256) void k_tok_win_bytes_g(const u32 *__restrict__
     const u32 w = win_of[r];
     if (w != WIN_NONE) { atomicAdd(&wbytes[w], seq_room(g_seq_len[r])); atomicAdd(&wcount[w], 1u); }
 }
+// (one 64-bit counter per window, records in bits 40.. and bytes below, as in k_tok_win_place: a record's room and its entry of
+// the mirror get their places from ONE atomic, so the rooms of a window follow each other in the order of its entries -- with
+// reads of one length a whole file's rooms then lie at one pitch along the mirror, which k_tile's first loads count on)
 __global__ __launch_bounds__(256) void k_tok_win_place_g(const u32 *__restrict__ win_of, const u32 *__restrict__ g_seq_len, u32 n_aln,
-                                                         const u64 *__restrict__ wbase, const u32 *__restrict__ wcbase, u32 *__restrict__ wcur,
-                                                         u32 *__restrict__ wccur, u64 *__restrict__ seq_pos, u32 *__restrict__ slot) {
+                                                         const u64 *__restrict__ wbase, const u32 *__restrict__ wcbase, u64 *__restrict__ wcur,
+                                                         u64 *__restrict__ seq_pos, u32 *__restrict__ slot) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_aln) return;
     const u32 w = win_of[r];
     if (w == WIN_NONE) return;
-    seq_pos[r] = wbase[w] + (u64)atomicAdd(&wcur[w], seq_room(g_seq_len[r]));
-    slot[r] = wcbase[w] + atomicAdd(&wccur[w], 1u);
+    const u64 old = atomicAdd((unsigned long long *)&wcur[w], (1ull << 40) | (u64)seq_room(g_seq_len[r]));
+    seq_pos[r] = wbase[w] + (old & WIN_BYTES_MASK);
+    slot[r] = wcbase[w] + (u32)(old >> 40);
 }
 
 }  // namespace
@@ -934,7 +938,7 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
                                    per_block, n_win, (const u64 *)D->d_wcur.p, (const u64 *)D->d_wbase.p, (const u32 *)D->d_wcbase.p,
                                    (u64 *)D->d_seqpos.p, (u32 *)D->d_slot.p);
             } else {
-                ENS(d_wcur, (u64)n_win * 8);  // two u32 cursors per window
+                ENS(d_wcur, (u64)n_win * 8);  // one 64-bit cursor per window
                 PP_HIPCHK(ctx, hipMemsetAsync(D->d_wbytes.p, 0, ((size_t)n_win + 1) * 4, st));
                 PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcount.p, 0, ((size_t)n_win + 1) * 4, st));
                 PP_HIPCHK(ctx, hipMemsetAsync(D->d_wcur.p, 0, (size_t)n_win * 8, st));
@@ -943,8 +947,8 @@ static int ingest_text(pp_dev_ingest *D, const char *path, const char *text, u64
                 if ((rc = scan_u32<u64>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wbytes.p, (u64)n_win, (u64 *)D->d_wbase.p))) return rc;
                 if ((rc = scan_u32<u32>(ctx, D->d_sums, D->d_sumsoff, (const u32 *)D->d_wcount.p, (u64)n_win, (u32 *)D->d_wcbase.p))) return rc;
                 hipLaunchKernelGGL(k_tok_win_place_g, dim3((n_aln + 255) / 256), dim3(256), 0, st, (const u32 *)D->d_win.p,
-                                   (const u32 *)D->d_gseq.p, n_aln, (const u64 *)D->d_wbase.p, (const u32 *)D->d_wcbase.p, (u32 *)D->d_wcur.p,
-                                   (u32 *)D->d_wcur.p + n_win, (u64 *)D->d_seqpos.p, (u32 *)D->d_slot.p);
+                                   (const u32 *)D->d_gseq.p, n_aln, (const u64 *)D->d_wbase.p, (const u32 *)D->d_wcbase.p, (u64 *)D->d_wcur.p,
+                                   (u64 *)D->d_seqpos.p, (u32 *)D->d_slot.p);
             }
         }
         if (window_layout) {
