@@ -284,7 +284,8 @@ int pp_ctx_set_profiling(pp_ctx *ctx, int enable); /* 0 off, 1 every kernel grou
 int pp_polish_kernel_times(pp_ctx *ctx, pp_kernel_times *out);
 /* Which way the last pp_polish_finish of this context went: 1 = the direct path (the window-order mirror and its run table:
  * pp_aln_batch.wo_run_end -- a rank of a sharded job included: pp_shard_split restricts the table with the mirror), 0 = the
- * bucketing path (no mirror, no run table, more than PP_WO_MAX_RUNS runs, the one-process multi-GPU driver's slice views, a
+ * bucketing path (no mirror, no run table, more than PP_WO_MAX_RUNS runs -- one per SAM file, or per file and device in the
+ * one-process multi-GPU driver --, a
  * mirror that turned out not to be in run order or not to mirror its records, a window that needs more room for its extras
  * than the windows can be given).  The results are the same either way; for reports (bench.py names the kernel it timed). */
 int pp_polish_took_direct_path(const pp_ctx *ctx);

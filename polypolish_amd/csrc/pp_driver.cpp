@@ -615,7 +615,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
     } else {
         // ---- the plan, from the alignment counts per contig ----
         // source batches in file order: sharded -> (file, slice) pieces living on the contexts' GPUs; host ingest -> files
-        struct Src { pp_aln_batch view; int mem; int owner; uint64_t base; uint32_t wo_base; };
+        struct Src { pp_aln_batch view; int mem; int owner; uint64_t base; uint32_t wo_base; std::vector<uint64_t> runs; };
         std::vector<Src> srcs;
         uint64_t base = 0;
         if (sharded) {
@@ -628,9 +628,20 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
                     v.n_aln = hi - lo;
                     v.contig += lo; v.ref_start += lo; v.k += lo; v.seq_off += lo; v.seq_len += lo; v.cig_off += lo; v.n_cig += lo;
                     if (v.wo) v.wo += lo;  // (a slice's entries of the window-order mirror are its own stretch; they count from lo)
-                    v.wo_n_runs = 0;       // (the run table is the whole batch's)
+                    // the slice's runs: the whole batch's, cut to [lo, hi) and counted from lo (the tokenizer ends a run with every
+                    // file: one run, the slice itself) -- with them a part of the slice takes the direct path like any other
+                    std::vector<uint64_t> runs;
+                    const pp_aln_batch &wb = whole[(size_t)sidx];
+                    for (uint32_t r = 0; v.wo && wb.wo_run_end && r < wb.wo_n_runs; r++) {
+                        const uint64_t e = std::min(std::max(wb.wo_run_end[r], lo), hi) - lo;
+                        if (e > (runs.empty() ? 0 : runs.back())) runs.push_back(e);
+                    }
+                    if (runs.empty() || runs.back() != hi - lo) runs.clear();  // (not known: the bucketing path)
+                    v.wo_n_runs = 0;
                     v.wo_run_end = nullptr;
-                    srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base, (uint32_t)lo});
+                    srcs.push_back(Src{v, PP_MEM_DEVICE, sidx, base, (uint32_t)lo, std::move(runs)});
+                    srcs.back().view.wo_n_runs = (uint32_t)srcs.back().runs.size();
+                    srcs.back().view.wo_run_end = srcs.back().runs.empty() ? nullptr : srcs.back().runs.data();
                     base += hi - lo;
                 }
             // (one context after the other: a histogram kernel each, they add into the same host array)
@@ -642,7 +653,7 @@ static int polish_files_impl(pp_ctx *const *ctxs, int n_ctx, const char *assembl
             for (pp_ingest *gi : gs) {
                 pp_aln_batch v;
                 pp_ingest_batch(gi, &v);
-                srcs.push_back(Src{v, PP_MEM_HOST, -1, base, 0u});
+                srcs.push_back(Src{v, PP_MEM_HOST, -1, base, 0u, {}});
                 base += v.n_aln;
                 pp_shard_count(nullptr, &v, PP_MEM_HOST, nc, per_contig.data());
             }

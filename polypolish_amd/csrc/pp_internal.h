@@ -68,7 +68,11 @@ constexpr uint32_t ENT_PRETRIM = 2u;   // no indel, but too long / overhanging f
 constexpr uint32_t ENT_NOTRIM = 4u;
 constexpr uint32_t ENT_POINT = 8u;
 constexpr uint32_t NKW_INDEL1 = 3u;    // class bits (30-31) of the nkeep word: span | a << 9 | is_deletion << 17 below them
-constexpr uint32_t INDEL1_MIN_SEG = 8; // both flanks at least this long (PLAIN_MIN_LEN), else the general walk
+// both flanks at least this long, else the general walk.  1 since round 6 (8 = PLAIN_MIN_LEN before): a flank of fewer than
+// eight bases is a plain item on the direct path (DirectBulk::loadable) and a fast-class item of the one-at-a-time kind elsewhere;
+// as slow items -- a wave each, three dependent round trips -- the reads with their indel within eight bases of an end (a
+// tenth of the ~200 reads over every planted indel) were 17 us of k_tile_direct's 181 on configs[1] (profiles/r6y_*)
+constexpr uint32_t INDEL1_MIN_SEG = 1;
 constexpr uint32_t FAST_MAX_LEN = 252; // a read of <= 252 bases is one dword-per-lane wave load
 // depth-share class of a work item (8 bits; kclass_of / k_of_class in pp_k_common.h): 0: k = 1 | 1..20: k = 2^class |
 // 21..254: k = class - 18 (3..236, the other small k: all-hits reads in a handful of copies) | 255: any other k (looked up)

@@ -54,6 +54,42 @@ __device__ __forceinline__ uint4 wo_item(u64 so, u32 len, u32 kc, u64 g, u32 w, 
 // on; an extra for a window outside that range (a workgroup across the end of a run, a long read), or one more than the
 // stage holds, takes its slot from the global counter on the spot.
 constexpr u32 XLOCAL = 64, CTG_LDS = 1024;
+// A contig's offset out of the table in LDS (up to CTG_LDS contigs) or out of memory.  As `in_lds ? lds[i] : mem[i]` the compiler
+// made ONE flat load of a selected address, and a flat load is waited for with vmcnt(0): every lookup drained all the loads the
+// wave had in flight (k_prepd's next entries).  A branch per kind, each waiting for its own load (the empty asm uses the value
+// inside the branch): the usual case then waits for LDS alone.
+struct CtgTab {
+    const u64 *lds, *mem;
+    bool in_lds;  // (uniform)
+    __device__ __forceinline__ u64 operator()(u32 i) const {
+        u32 x, y;
+        if (in_lds) {
+            const u64 v = lds[i];
+            x = (u32)v; y = (u32)(v >> 32);
+            asm volatile("" : "+v"(x), "+v"(y));
+        } else {
+            const u64 v = mem[i];
+            x = (u32)v; y = (u32)(v >> 32);
+            asm volatile("" : "+v"(x), "+v"(y));
+        }
+        return (u64)x | ((u64)y << 32);
+    }
+    // offsets i and i + 1 (one wait)
+    __device__ __forceinline__ void pair(u32 i, u64 &a, u64 &b) const {
+        u32 x, y, z, w;
+        if (in_lds) {
+            const u64 v = lds[i], v1 = lds[i + 1u];
+            x = (u32)v; y = (u32)(v >> 32); z = (u32)v1; w = (u32)(v1 >> 32);
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+        } else {
+            const u64 v = mem[i], v1 = mem[i + 1u];
+            x = (u32)v; y = (u32)(v >> 32); z = (u32)v1; w = (u32)(v1 >> 32);
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+        }
+        a = (u64)x | ((u64)y << 32);
+        b = (u64)z | ((u64)w << 32);
+    }
+};
 struct XSink {
     uint4 *st_item;  // LDS: [xstage] staged items ...
     u32 *st_key;     //      ... their (local window << 16 | rank among the workgroup's extras of that window)
@@ -222,7 +258,11 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     const u64 n = P.n;
     const pp_wo_rec *const wo = P.wo;
     const u32 n_contigs = P.n_contigs, nwin = P.nwin, n_runs = P.n_runs;
-    const u32 *const run_end = P.run_end;
+    // (the ends of the runs out of LDS: read from memory inside the loop -- every trip of a wave that is not in the last run --
+    // each was a vector load waited for with vmcnt(0), which drains the entries asked for ahead)
+    __shared__ u32 s_run_end[PP_WO_MAX_RUNS];
+    if (threadIdx.x < P.n_runs) s_run_end[threadIdx.x] = P.run_end[threadIdx.x];  // (in front of the barrier below)
+    const u32 *const run_end = s_run_end;
     u64 *const status = P.status;
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     const bool ctg_lds = n_contigs <= CTG_LDS;
@@ -242,7 +282,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     __syncthreads();
     PP_STAMP(0, 1);
     X.wbase = s_wbase;
-    auto ctg = [&](u32 i) -> u64 { return ctg_lds ? s_ctg[i] : P.contig_off[i]; };
+    const CtgTab ctg{s_ctg, P.contig_off, ctg_lds};
     const u32 lane = threadIdx.x & 63u;
     const u32 stride = nwin + 1u;
     u32 *const first = P.first;
@@ -290,20 +330,36 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
         if (acc == 0x12345679u && n == 1) first[0] = acc;
     }
 #endif
-    for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
-        uint4 qa[WU], qb[WU];
-        u32 pc[WU], pr[WU];
+    // The loads run AHEAD of the work, in the registers the work has just left (PP_PREPD_ROLL, the default): a trip's WU sets of
+    // loads are asked for one by one, set u of the NEXT trip as soon as set u of this one has been worked off -- while a wave
+    // computes, one set is always on its way.  Asked for all at the top of a trip and waited for together, nothing of the wave's
+    // was in flight while it computed: 23 % of the issue slots used, 61 % of the wave-cycles waiting, 213 MB in 42 us where a
+    // loop that only loads them takes 27 (profiles/r6y_*).
+    uint4 qa[WU], qb[WU];
+    u32 pc[WU], pr[WU];
+    auto ask = [&](int u, u64 a0) __attribute__((always_inline)) {
+        const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);  // clamped: the loads are unconditional
+        qa[u] = wq[2 * a];
+        qb[u] = wq[2 * a + 1];
+        // (contig, ref_start) of the entry in front of the wave's first one
+        const u64 wf = a0 - lane + (u64)u * blockDim.x;  // (the same for the whole wave)
+        const u64 pf = min(wf ? wf - 1 : 0, n - 1);
+        pc[u] = wo[pf].contig;
+        pr[u] = wo[pf].ref_start;
+    };
+#ifndef PP_PREPD_ROLL
+#define PP_PREPD_ROLL 1
+#endif
+    if (PP_PREPD_ROLL && lo < hi) {
 #pragma unroll
-        for (int u = 0; u < WU; u++) {
-            const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);  // clamped: the loads are unconditional
-            qa[u] = wq[2 * a];
-            qb[u] = wq[2 * a + 1];
-            // (contig, ref_start) of the entry in front of the wave's first one
-            const u64 wf = a0 - lane + (u64)u * blockDim.x;  // (the same for the whole wave)
-            const u64 pf = min(wf ? wf - 1 : 0, n - 1);
-            pc[u] = wo[pf].contig;
-            pr[u] = wo[pf].ref_start;
+        for (int u = 0; u < WU; u++) ask(u, lo + threadIdx.x);
+    }
+    for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
+        if (!PP_PREPD_ROLL) {
+#pragma unroll
+            for (int u = 0; u < WU; u++) ask(u, a0);
         }
+        const bool more = a0 + trip < lo + span;  // (uniform)
 #pragma unroll
         for (int u = 0; u < WU; u++) {
             const u64 a = a0 + (u64)u * blockDim.x;
@@ -312,7 +368,8 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
             const u64 seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32);
             const bool c_ok = contig < n_contigs;
             const u32 cc = min(contig, n_contigs - 1u);
-            const u64 c_lo = ctg(cc), c_hi = ctg(cc + 1u);
+            u64 c_lo, c_hi;
+            ctg.pair(cc, c_lo, c_hi);
             const bool bulk = in && wo_bulk(c_ok, ref_start, seq_len, op0, c_hi - c_lo);
             const u64 g = c_lo + ref_start;
             const u32 h = in && c_ok ? (u32)min(g / (u64)TILE, (u64)(nwin - 1u)) : NOHOME;
@@ -353,6 +410,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
                 if (slot < LATER_MAX) { later[2u * slot] = qa[u]; later[2u * slot + 1u] = qb[u]; }
             }
 #endif
+            if (PP_PREPD_ROLL && more) ask(u, a0 + trip);
         }
     }
     PP_STAMP(0, 2);
@@ -390,7 +448,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
     constexpr u32 XSTAGE = 4 * THREADS;
     __shared__ uint4 st_item[XSTAGE];
-    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
+    __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st;
     __shared__ u64 s_ctg[CTG_LDS + 1];
     PP_STAMP(1, 0);
     if (*P.status != ~0ull) return;
@@ -399,22 +457,22 @@ __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
     const u64 i0 = min(total, (u64)blockIdx.x * per), i1 = min(total, i0 + per);
     if (i0 >= i1) return;
     const bool ctg_lds = P.n_contigs <= CTG_LDS;
+    // One round trip for everything that is known now: the contig table, the stretch's first entry (every thread asks for the
+    // same one: the window the local counters start at), this thread's own first entry.  (Thread 0 alone looking at the first
+    // entry and then at its contig's offset, and every thread asking for its entry behind the barrier, were three trips.)
     if (ctg_lds)
         for (u32 i = threadIdx.x; i <= P.n_contigs; i += blockDim.x) s_ctg[i] = P.contig_off[i];
-    if (threadIdx.x == 0) {  // the window of the stretch's first record: where the local counters start
-        u32 wb = 0;
-        const uint4 q0 = P.g_later[2ull * i0];
-        if (q0.x < P.n_contigs) wb = wo_home(P.contig_off[q0.x], q0.y, P.nwin);
-        s_wbase = wb;
-    }
+    const uint4 q0 = P.g_later[2ull * i0];
+    const u64 i_first = i0 + threadIdx.x, i_mine = min(i_first, i1 - 1);
+    uint4 qa = P.g_later[2ull * i_mine], qb = P.g_later[2ull * i_mine + 1];
     XSink X{st_item, st_key, l_cnt, l_base, l_nb, &n_st, XSTAGE, 0u, P.xcap, P.x_cnt, P.x_nb, P.xent, P.x_need, P.status};
     X.clear();
     __syncthreads();
     PP_STAMP(1, 1);
-    X.wbase = s_wbase;
-    auto ctg = [&](u32 i) -> u64 { return ctg_lds ? s_ctg[i] : P.contig_off[i]; };
-    for (u64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const uint4 qa = P.g_later[2ull * i], qb = P.g_later[2ull * i + 1];
+    const CtgTab ctg{s_ctg, P.contig_off, ctg_lds};
+    X.wbase = q0.x < P.n_contigs ? wo_home(ctg(q0.x), q0.y, P.nwin) : 0u;  // (the same in every thread)
+    for (u64 i = i_first; i < i1; i += blockDim.x) {
+        if (i != i_first) { qa = P.g_later[2ull * i]; qb = P.g_later[2ull * i + 1]; }
         pp_wo_rec r;
         r.contig = qa.x; r.ref_start = qa.y; r.k = qa.z; r.seq_len = qa.w;
         r.seq_off = (u64)qb.x | ((u64)qb.y << 32); r.op0 = qb.z; r.file_idx = qb.w;

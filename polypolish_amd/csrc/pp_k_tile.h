@@ -1258,10 +1258,13 @@ struct DirectBulk {
     };
     static constexpr u32 LN_REL0 = 256;  // (rel > -256: a fast-class read has at most FAST_MAX_LEN bases)
     static constexpr u32 LN_FAST = 1u << 20, LN_PLAIN = 1u << 21, LN_SHARED = 1u << 22, LN_NOTRIM = 1u << 23, LN_POINT = 1u << 24, LN_SLOW = 1u << 25;
-    // the read's chunks are loaded from its place in the mirror when all NCH chunk loads stay inside it: 8 .. 32 NCH bases, 32 NCH
-    // nibbles from its start on inside the array (seq4 has 32 bytes of slack behind it)
+    // the read's chunks are loaded from its place in the mirror when all NCH chunk loads stay inside it: 1 .. 32 NCH bases, 32 NCH
+    // nibbles from its start on inside the array (seq4 has 32 bytes of slack behind it), and the four bytes that end with its last
+    // base as well (so + L >= 8).  A piece of fewer than eight bases (the short flank of a read with its indel near an end) is
+    // fine: the trim looks at the last eight bases of the READ, which are the read's own on either side of the indel; where they
+    // are not (a whole read that short whose bases are all the same) trim4 comes out negative and the bytes decide.
     __device__ static __forceinline__ bool loadable(const TileArgs &A, u64 so, u32 L) {
-        return L - PLAIN_MIN_LEN <= 32u * NCH - PLAIN_MIN_LEN && so + 32u * NCH <= A.seq_bytes;
+        return L - 1u <= 32u * NCH - 1u && so + L >= 8u && so + 32u * NCH <= A.seq_bytes;
     }
     __device__ __forceinline__ Lean distill(const TileArgs &A, const RecMap &M, u32 p, const uint4 &qa, const uint4 &qb, bool listed) const {
         Lean n{0ull, 0u};
@@ -1364,13 +1367,19 @@ struct DirectBulk {
                 }
                 // a slow item (indels in several runs, a long read): listed for the slow round (tile_window), or -- no room --
                 // counted for a round over all of the window's extras
+#ifndef PP_EXP_NOSLOW
                 if (cur.pack & LN_SLOW) {
                     const u32 slot = atomicAdd(defer_n, 1u);
                     if (slot < defer_cap) defer[slot] = src;
                 }
+#endif
                 // the entry AT a read's single indel (ENT_POINT): one tally -- the two-byte key of an insertion is counted by
                 // string (pileup.rs:56-63), the empty slot of a deletion is the "-" key
+#ifdef PP_EXP_NOPOINT
+                if (false) {
+#else
                 if ((cur.pack & LN_POINT) && rel_r >= 0) {
+#endif
                     tile_add(cnt, (my.y >> 24) ? ROW_OTH : ROW_DEL, rel_r);
                     share_range(cnt, ndbits, S, rel_r, rel_r + 1, (my.y >> 8) & 0xFFu, my.w);
                     if ((my.y >> 24) == 2u) pt_insert(S.pt, S.pt_over, rel_r, A.seq, (u64)my.x | ((u64)(my.y & 0xFFu) << 32));
@@ -1378,6 +1387,9 @@ struct DirectBulk {
                 // a fast-class read the pass does not take (fewer than 8 bases; the last reads of the seq array; an odd-start flank
                 // that fills its last chunk): one item per pass, as the fast class that is not plain in tile_items
                 u64 rest = __ballot((cur.pack & (LN_FAST | LN_PLAIN | LN_POINT)) == LN_FAST);
+#ifdef PP_EXP_NOREST
+                rest = 0;
+#endif
                 while (rest) {
                     const u32 j = (u32)__ffsll((long long)rest) - 1u;
                     rest &= rest - 1;

@@ -264,9 +264,11 @@ void set_view(pp_shard_part *P, uint64_t n, uint64_t seq_bytes, uint64_t n_cig_t
     }
 }
 
-// the source's run table is usable: the whole batch's mirror (not a view's), ends ascending, the last one the record count
+// the source's run table is usable: ends ascending, the last one the record count (a view on records [lo, hi) of a larger batch
+// brings its own table, counted from lo -- the multi-GPU driver cuts the tokenizer's for its slices)
 bool src_runs_ok(const pp_aln_batch *b, u32 wo_base) {
-    if (!b->wo || wo_base || !b->wo_n_runs || b->wo_n_runs > PP_WO_MAX_RUNS || !b->wo_run_end) return false;
+    (void)wo_base;
+    if (!b->wo || !b->wo_n_runs || b->wo_n_runs > PP_WO_MAX_RUNS || !b->wo_run_end) return false;
     uint64_t prev = 0;
     for (u32 r = 0; r < b->wo_n_runs; r++) {
         if (b->wo_run_end[r] < prev) return false;
