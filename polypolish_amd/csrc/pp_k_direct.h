@@ -337,27 +337,30 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     // loop that only loads them takes 27 (profiles/r6y_*).
     uint4 qa[WU], qb[WU];
     u32 pc[WU], pr[WU];
-    auto ask = [&](int u, u64 a0) __attribute__((always_inline)) {
-        const u64 a = min(a0 + (u64)u * blockDim.x, n - 1);  // clamped: the loads are unconditional
+    // (`real` = false, behind the block's last trip: the block's first entry once more, one line for the whole wave.  The loads
+    // are UNCONDITIONAL: with a branch around them the compiler has to wait for the loads of the path that did not take it --
+    // the set asked for ahead included, vmcnt(0) where vmcnt(3) would do)
+    auto ask = [&](int u, u64 a0, bool real) __attribute__((always_inline)) {
+        const u64 a = real ? min(a0 + (u64)u * blockDim.x, n - 1) : lo;  // clamped
         qa[u] = wq[2 * a];
         qb[u] = wq[2 * a + 1];
         // (contig, ref_start) of the entry in front of the wave's first one
         const u64 wf = a0 - lane + (u64)u * blockDim.x;  // (the same for the whole wave)
-        const u64 pf = min(wf ? wf - 1 : 0, n - 1);
+        const u64 pf = real ? min(wf ? wf - 1 : 0, n - 1) : lo;
         pc[u] = wo[pf].contig;
         pr[u] = wo[pf].ref_start;
     };
 #ifndef PP_PREPD_ROLL
 #define PP_PREPD_ROLL 1
 #endif
-    if (PP_PREPD_ROLL && lo < hi) {
+    if (PP_PREPD_ROLL) {
 #pragma unroll
-        for (int u = 0; u < WU; u++) ask(u, lo + threadIdx.x);
+        for (int u = 0; u < WU; u++) ask(u, lo + threadIdx.x, true);  // (lo < n, or the grid would be smaller)
     }
     for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
         if (!PP_PREPD_ROLL) {
 #pragma unroll
-            for (int u = 0; u < WU; u++) ask(u, a0);
+            for (int u = 0; u < WU; u++) ask(u, a0, true);
         }
         const bool more = a0 + trip < lo + span;  // (uniform)
 #pragma unroll
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
                 if (slot < LATER_MAX) { later[2u * slot] = qa[u]; later[2u * slot + 1u] = qb[u]; }
             }
 #endif
-            if (PP_PREPD_ROLL && more) ask(u, a0 + trip);
+            if (PP_PREPD_ROLL) ask(u, a0 + trip, more);
         }
     }
     PP_STAMP(0, 2);

@@ -39,11 +39,17 @@ __device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32
     return 0;
 }
 
-// One workgroup of 256 threads per window, eight consecutive positions per thread (one 8-byte load of their codes, and,
-// where every position emits exactly one byte -- nearly always -- one 8-byte store).
-constexpr int COMPACT_THREADS = TILE / 8;
+// One workgroup per window, PP_EMIT_PPT consecutive positions per thread (one load of their codes, and, where every position
+// emits exactly one byte -- nearly always -- one store).  Sixteen positions a thread since round 6 (eight before): two waves
+// per window instead of four -- the 2442 windows of a 5 Mbp job are then 0.6 rounds of the chip's wave slots, not 1.2.
+#ifndef PP_EMIT_PPT
+#define PP_EMIT_PPT 16
+#endif
+constexpr int EMIT_PPT = PP_EMIT_PPT;
+static_assert(EMIT_PPT == 8 || EMIT_PPT == 16, "an 8- or 16-byte load of codes per thread");
+constexpr int COMPACT_THREADS = TILE / EMIT_PPT;
 // What a workgroup needs before it can do anything -- the job's status, the window's two output offsets, the number of
-// multi-byte winners, the thread's eight codes -- is asked for AT ONCE and looked at afterwards: written as a chain of early
+// multi-byte winners, the thread's codes -- is asked for AT ONCE and looked at afterwards: written as a chain of early
 // returns (status, then the offsets, then the codes) it was four memory round trips, one after the other, for a workgroup
 // that computes for a few hundred nanoseconds (k_emit 14.6 us for the 2442 windows of a 5 Mbp job, two rounds of the chip's
 // wave slots).  The empty asm keeps the compiler from moving the codes' load back down behind the returns.
@@ -54,25 +60,28 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
                                                u8 *__restrict__ out, const u64 *__restrict__ status) {
     __shared__ u32 wsum[COMPACT_THREADS / 64];
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const u64 p0 = (u64)w * TILE + 8ull * t;
-    const bool whole = p0 + 8 <= G;
-    uint2 v = make_uint2(0u, 0u);
-    if (whole) v = *(const uint2 *)(code + p0);  // p0 is a multiple of 8 and the code array is 256-byte aligned
+    const u64 p0 = (u64)w * TILE + (u64)EMIT_PPT * t;
+    const bool whole = p0 + EMIT_PPT <= G;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (whole) {  // p0 is a multiple of EMIT_PPT and the code array is 256-byte aligned
+        if constexpr (EMIT_PPT == 16) v = *(const uint4 *)(code + p0);
+        else { const uint2 h = *(const uint2 *)(code + p0); v.x = h.x; v.y = h.y; }
+    }
     const u64 st = *status, o0 = win_out[w], o1 = win_out[w + 1];
     const u32 n_multi = counters[1];
-    asm volatile("" : "+v"(v.x), "+v"(v.y));
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     if ((st != ~0ull) | (o1 == o0)) return;  // the job is off / nothing to emit (a window of another rank, or all deletions)
-    u8 c[8];
+    u8 c[EMIT_PPT];
     if (whole) {
-        __builtin_memcpy(c, &v, 8);
+        __builtin_memcpy(c, &v, EMIT_PPT);
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) c[i] = (p0 + i < G) ? code[p0 + i] : (u8)0;
+        for (int i = 0; i < EMIT_PPT; i++) c[i] = (p0 + i < G) ? code[p0 + i] : (u8)0;
     }
-    u32 len[8], s = 0;
+    u32 len[EMIT_PPT], s = 0;
     bool all_one = true;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < EMIT_PPT; i++) {
         len[i] = code_len(c[i], (u32)(p0 + i), multi, n_multi);
         s += len[i];
         all_one = all_one && c[i] != 0 && c[i] < 0x80u;
@@ -88,10 +97,10 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
     for (u32 i = 0; i < wave; i++) base += wsum[i];
     u64 off = o0 + base + (inc - s);
     if (all_one) {
-        __builtin_memcpy(out + off, c, 8);  // unaligned 8-byte store
+        __builtin_memcpy(out + off, c, EMIT_PPT);  // one unaligned store
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < EMIT_PPT; i++) {
             if (c[i] && c[i] < 0x80u) out[off] = c[i];
             off += len[i];
         }

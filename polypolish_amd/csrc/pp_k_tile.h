@@ -1619,9 +1619,13 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
     }
 #endif
 
-    if (A.own) {
+    if (A.own && !A.own_win) {
         // Sharded job: a window that lies inside ONE contig and outside the range of it this context emits is
         // somebody else's (k_prep gave it no work items): nothing to tally, nothing to vote.
+        // (Not with the list of the windows this context works on -- own_win, what the host always brings along with the
+        // ranges: every window of the grid then touches a range it emits, and the question -- the window's contig, its
+        // offset, its range: four dependent round trips at the top of every workgroup -- made a rank's share of configs[3]
+        // 0.175 ms of k_tile where its windows take 0.134 at the whole job's rate.)
         const u64 last = min(w0 + TILE, A.G) - 1;
         const u32 c0 = find_contig_wave(A.contig_off, A.n_contigs, w0, lane);
         const u64 cb = A.contig_off[c0];

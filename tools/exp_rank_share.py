@@ -15,6 +15,7 @@ lens, cov, repeat, label = bench.config_shape(config)
 job = bench.make_job(dev, contig_lens=lens, coverage=cov, repeat=repeat)
 job = bench.synthjob.with_wo(bench.synthjob.with_seq4(job))   # the two mirrors, as bench.py's default job carries them
 ctx = pp.Context(0)
+ctx.trust_mirrors(True)   # (as bench.py: the job's torch-made mirror is what an ingest would hand over)
 ctx.set_profiling(1)
 counts = np.bincount(job["recs"]["contig"].cpu().numpy().astype(np.int64), minlength=len(lens))
 plan = pp.Plan(job["contig_off"], counts, world, 0)

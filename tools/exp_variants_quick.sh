@@ -17,6 +17,7 @@ job = synthjob.make_job(dev, contig_lens=lens, coverage=coverage, seed=42 + conf
 job = synthjob.with_wo(synthjob.with_seq4(job))
 torch.cuda.synchronize()
 ctx = pp.Context(0)
+ctx.trust_mirrors(True)
 ctx.set_profiling(1)
 acc = {}
 for i in range(12):
