@@ -508,8 +508,9 @@ def test_fuzz_cigar_walk_against_the_oracle(ctx, pp, orc):
 
 def test_one_indel_reads_edge_cases(ctx, pp, orc):
     """Reads with ONE 1-base indel (aM1IbM / aM1DbM) are cut into flank / entry at the indel / flank work items instead of
-    being walked (alignment.rs:175-201) -- unless a flank is shorter than 8 bases or the homopolymer trim
-    (alignment.rs:364-378) would reach the indel, which take the general walk.  Every indel position of a 40-base read,
+    being walked (alignment.rs:175-201) -- unless the flank in front is empty or the homopolymer trim
+    (alignment.rs:364-378) would reach the indel, which take the general walk (until round 6 a flank of fewer than 8 bases
+    did too; such a flank is now a plain piece of 1..7 bases on the direct path).  Every indel position of a 40-base read,
     both kinds, read ends of homopolymers of 1..7 bases (so the trim ends before, at and beyond the indel), starts on both
     sides of a 2048-position window boundary, depth shares 1, 1/2 and 1/3: per-position depth / counts / thresholds /
     status and the bytes against the oracle, with and without the per-position records."""
