@@ -80,6 +80,11 @@ __device__ __forceinline__ u8 pass_qc(const FileDev &self, u32 a, u32 n_this, co
 // alignment that needs no thresholds for it -- its read has one alignment in this file, or none in the other: all of them
 // in a job without multi-mapped reads -- is "pass": the host fills both verdict arrays with it before the launch.  The reads whose verdicts need the thresholds (several alignments here, at least one
 // there) are only listed, for k_filter_listed.  `poisoned`: an end is needed that the reference could not have parsed.
+// Two reads a lane since round 6 (FILTER_RPT), each stage's loads of both asked for together: the kernel is its chain of three
+// dependent gathers (group offsets -> group index -> fields), and with one read a lane the 13,000 workgroups of a 3.3 M read job
+// were six rounds of that chain.  The loads are unconditional (a read that is not a one-and-one pair looks at alignment 0 of
+// either file: the host only launches the kernel when both files have alignments).
+constexpr u32 FILTER_RPT = 2, FILTER_RPB = 256u * FILTER_RPT;  // reads per lane / per workgroup (and the workgroup's stretch of the list)
 __global__ __launch_bounds__(256) void k_filter_reads(u32 n_reads, FileDev f1, FileDev f2, u8 *__restrict__ orient,
                                                       u32 *__restrict__ insert,
                                                       u32 *__restrict__ list, u32 *__restrict__ blk_cnt, u32 *__restrict__ any_listed,
@@ -87,41 +92,69 @@ __global__ __launch_bounds__(256) void k_filter_reads(u32 n_reads, FileDev f1, F
     __shared__ u32 s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool listed = false;
-    if (r < n_reads) {
-        const u32 g1 = f1.grp_off[r], g1e = f1.grp_off[r + 1], g2 = f2.grp_off[r], g2e = f2.grp_off[r + 1];
-        const u32 n1 = g1e - g1, n2 = g2e - g2;
+    u32 r[FILTER_RPT], g1[FILTER_RPT], g2[FILTER_RPT], n1[FILTER_RPT], n2[FILTER_RPT], a[FILTER_RPT], b[FILTER_RPT];
+    bool in[FILTER_RPT], one[FILTER_RPT], listed[FILTER_RPT];
+#pragma unroll
+    for (u32 u = 0; u < FILTER_RPT; u++) {
+        r[u] = blockIdx.x * FILTER_RPB + u * 256u + threadIdx.x;
+        in[u] = r[u] < n_reads;
+        const u32 rr = in[u] ? r[u] : 0u;
+        g1[u] = f1.grp_off[rr]; n1[u] = f1.grp_off[rr + 1];
+        g2[u] = f2.grp_off[rr]; n2[u] = f2.grp_off[rr + 1];
+    }
+#pragma unroll
+    for (u32 u = 0; u < FILTER_RPT; u++) {
+        n1[u] -= g1[u];
+        n2[u] -= g2[u];
+        one[u] = in[u] && n1[u] == 1u && n2[u] == 1u;
+        listed[u] = in[u] && ((n1[u] > 1u && n2[u] > 0u) || (n2[u] > 1u && n1[u] > 0u));
+        // (else: one alignment here and none there, several here and none there, none at all -- everything passes)
+        a[u] = f1.grp_idx[one[u] ? g1[u] : 0u];
+        b[u] = f2.grp_idx[one[u] ? g2[u] : 0u];
+    }
+    u32 ra[FILTER_RPT], rb[FILTER_RPT], fa[FILTER_RPT], fb[FILTER_RPT];
+    u64 s1[FILTER_RPT], s2[FILTER_RPT], e1[FILTER_RPT], e2[FILTER_RPT];
+#pragma unroll
+    for (u32 u = 0; u < FILTER_RPT; u++) {
+        const u32 ia = one[u] ? a[u] : 0u, ib = one[u] ? b[u] : 0u;
+        ra[u] = f1.ref_id[ia]; rb[u] = f2.ref_id[ib];
+        s1[u] = f1.ref_start[ia]; s2[u] = f2.ref_start[ib];
+        fa[u] = f1.flags[ia]; fb[u] = f2.flags[ib];
+        e1[u] = f1.ref_end ? f1.ref_end[ia] : 0ull;  // (precomputed ends: asked for with the other fields)
+        e2[u] = f2.ref_end ? f2.ref_end[ib] : 0ull;
+    }
+#pragma unroll
+    for (u32 u = 0; u < FILTER_RPT; u++) {
         u8 o = 255;
         u32 ins = 0;
-        if (n1 == 1u && n2 == 1u) {
-            const u32 a = f1.grp_idx[g1], b = f2.grp_idx[g2];
-            if (f1.ref_id[a] == f2.ref_id[b]) {
-                const u64 s1 = f1.ref_start[a], s2 = f2.ref_start[b];
-                const u64 e1 = ref_end_of(f1, a, s1), e2 = ref_end_of(f2, b, s2);
-                if (e1 == PP_REF_END_UNPARSEABLE || e2 == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
-                o = (u8)orientation_of(f1.flags[a], s1, e1, f2.flags[b], s2, e2);
-                ins = insert_of(s1, e1, s2, e2);
-            }
-        } else if ((n1 > 1u && n2 > 0u) || (n2 > 1u && n1 > 0u)) {
-            listed = true;
-        }  // (else: one alignment here and none there, several here and none there, none at all -- everything passes)
+        if (one[u] && ra[u] == rb[u]) {
+            if (!f1.ref_end) e1[u] = ref_end_of(f1, a[u], s1[u]);
+            if (!f2.ref_end) e2[u] = ref_end_of(f2, b[u], s2[u]);
+            if (e1[u] == PP_REF_END_UNPARSEABLE || e2[u] == PP_REF_END_UNPARSEABLE) atomicOr(poisoned, 1u);
+            o = (u8)orientation_of(fa[u], s1[u], e1[u], fb[u], s2[u], e2[u]);
+            ins = insert_of(s1[u], e1[u], s2[u], e2[u]);
+        }
         // A verdict that needs no thresholds is "pass", and the verdict arrays were filled with it before the launch: nothing
         // to store here (a byte per alignment at its place in FILE order -- the reads come in whatever order the loader
         // grouped them -- would be millions of scattered read-modify-writes).
-        orient[r] = o;
-        insert[r] = ins;
+        if (in[u]) {
+            orient[r[u]] = o;
+            insert[r[u]] = ins;
+        }
     }
-    // The list, in the workgroup's own stretch of it: [256 * block, + blk_cnt[block]).  (One counter for all of it -- a
+    // The list, in the workgroup's own stretch of it: [FILTER_RPB * block, + blk_cnt[block]).  (One counter for all of it -- a
     // returning atomic per wave on ONE address -- is served every ~5 ns however few lanes ask: 0.25 ms for the 52,000 waves
     // of a 3.3 M read job, five times the rest of the kernel.)
-    const u64 m = __ballot(listed);
-    if (m) {
-        const u32 lane = threadIdx.x & 63u, leader = (u32)__ffsll((long long)m) - 1u;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&s_cnt, (u32)__popcll(m));
-        base = (u32)__shfl((int)base, (int)leader, 64);
-        if (listed) list[blockIdx.x * blockDim.x + base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = r;
+#pragma unroll
+    for (u32 u = 0; u < FILTER_RPT; u++) {
+        const u64 m = __ballot(listed[u]);
+        if (m) {
+            const u32 lane = threadIdx.x & 63u, leader = (u32)__ffsll((long long)m) - 1u;
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&s_cnt, (u32)__popcll(m));
+            base = (u32)__shfl((int)base, (int)leader, 64);
+            if (listed[u]) list[blockIdx.x * FILTER_RPB + base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = r[u];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -131,7 +164,7 @@ __global__ __launch_bounds__(256) void k_filter_reads(u32 n_reads, FileDev f1, F
 }
 
 // the listed reads: alignment_pass_qc with the thresholds, one lane per read, every alignment of it in either file
-__global__ __launch_bounds__(256) void k_filter_listed(const u32 *__restrict__ list, const u32 *__restrict__ blk_cnt, FileDev f1, FileDev f2,
+__global__ __launch_bounds__(FILTER_RPB) void k_filter_listed(const u32 *__restrict__ list, const u32 *__restrict__ blk_cnt, FileDev f1, FileDev f2,
                                                        u32 low, u32 high, u32 correct, u8 *__restrict__ pass1, u8 *__restrict__ pass2,
                                                        u32 *__restrict__ poisoned) {
     if (threadIdx.x >= blk_cnt[blockIdx.x]) return;  // (the grid and the workgroups are k_filter_reads')
@@ -237,8 +270,8 @@ static int filter_reads(pp_ctx *ctx) {
     int rc;
     if ((rc = dev_ensure(ctx, ctx->f_orient, n))) return rc;
     if ((rc = dev_ensure(ctx, ctx->f_insert, (size_t)n * 4))) return rc;
-    const uint32_t n_blocks = (n + 255u) / 256u;
-    if ((rc = dev_ensure(ctx, ctx->f_list, (size_t)n_blocks * 256 * 4))) return rc;
+    const uint32_t n_blocks = (n + FILTER_RPB - 1u) / FILTER_RPB;
+    if ((rc = dev_ensure(ctx, ctx->f_list, (size_t)n_blocks * FILTER_RPB * 4))) return rc;
     if ((rc = dev_ensure(ctx, ctx->f_blkcnt, (size_t)n_blocks * 4))) return rc;
     for (int f = 0; f < 2; f++) {
         const uint64_t na = ctx->fdev.file[f].n_aln;
@@ -246,13 +279,19 @@ static int filter_reads(pp_ctx *ctx) {
         // (an alignment that is in no read's group -- the input's contract has none -- passes, as an alignment without mates does)
         if (na) PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_pass[f].p, 1, na, ctx->stream));
     }
-    if (n) {
+    if (n && ctx->fdev.file[0].n_aln && ctx->fdev.file[1].n_aln) {
         timer_begin(ctx, "samples");
         hipLaunchKernelGGL(k_filter_reads, dim3(n_blocks), dim3(256), 0, ctx->stream, n, file_dev(ctx, 0), file_dev(ctx, 1),
                            (u8 *)ctx->f_orient.p, (u32 *)ctx->f_insert.p, (u32 *)ctx->f_list.p, (u32 *)ctx->f_blkcnt.p,
                            (u32 *)ctx->f_poisoned.p + 1, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);
         PP_HIPCHK(ctx, hipGetLastError());
+    } else if (n) {
+        // a file without alignments: no read is a pair, none is listed (the kernel's unconditional loads want an alignment 0 in
+        // both files)
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_orient.p, 255, n, ctx->stream));
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_insert.p, 0, (size_t)n * 4, ctx->stream));
+        PP_HIPCHK(ctx, hipMemsetAsync(ctx->f_blkcnt.p, 0, (size_t)n_blocks * 4, ctx->stream));
     }
     ctx->filter_reads_done = true;
     return PP_OK;
@@ -283,7 +322,7 @@ extern "C" int pp_filter_pairs(pp_ctx *ctx, uint32_t low, uint32_t high, uint8_t
         if (int rc = filter_reads(ctx)) return rc;
     if (ctx->fdev.n_reads && ctx->filter_n_listed != 0) {  // (0: pp_filter_samples read the count back -- a job without multi-mapped reads)
         timer_begin(ctx, "pairs");
-        hipLaunchKernelGGL(k_filter_listed, dim3((ctx->fdev.n_reads + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32 *)ctx->f_list.p,
+        hipLaunchKernelGGL(k_filter_listed, dim3((ctx->fdev.n_reads + FILTER_RPB - 1u) / FILTER_RPB), dim3(FILTER_RPB), 0, ctx->stream, (const u32 *)ctx->f_list.p,
                            (const u32 *)ctx->f_blkcnt.p, file_dev(ctx, 0), file_dev(ctx, 1), low, high, (u32)orientation, (u8 *)ctx->f_pass[0].p,
                            (u8 *)ctx->f_pass[1].p, (u32 *)ctx->f_poisoned.p);
         timer_end(ctx);

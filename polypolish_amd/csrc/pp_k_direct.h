@@ -250,7 +250,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, PrepdArgs P) {
     constexpr u32 LATER_MAX = THREADS >= 1024 ? 768 : 320, XSTAGE = 2 * THREADS;  // (73 KB / 40 KB of LDS in all: two / four workgroups per CU)
     __shared__ uint4 later[2 * LATER_MAX];  // the noted entries themselves (k_prepg then starts from the entry, not from its index)
-    __shared__ u32 n_later, s_later_at;
+    __shared__ u32 n_later, s_later_at, s_unit;
     __shared__ uint4 st_item[XSTAGE];
     __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st, s_wbase;
     __shared__ u64 s_ctg[CTG_LDS + 1];  // the contig table when it has up to CTG_LDS contigs: a record's two offsets are then LDS reads, not a dependent trip to memory
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
         for (u32 i = threadIdx.x; i <= n_contigs; i += blockDim.x) s_ctg[i] = P.contig_off[i];
     if (threadIdx.x == 0) {
         n_later = 0;
+        s_unit = blockDim.x >> 6;  // (the next unit of the loop to be taken: every wave starts with the one of its own number)
         u32 wb = 0;
         if (lo < hi) {
             const pp_wo_rec r0 = wo[lo];
@@ -335,17 +336,21 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     // computes, one set is always on its way.  Asked for all at the top of a trip and waited for together, nothing of the wave's
     // was in flight while it computed: 23 % of the issue slots used, 61 % of the wave-cycles waiting, 213 MB in 42 us where a
     // loop that only loads them takes 27 (profiles/r6y_*).
+#ifndef PP_PREPD_DYN
+#define PP_PREPD_DYN 1
+#endif
+    const u32 ustride = PP_PREPD_DYN ? 64u : blockDim.x;  // between the WU sets of entries a wave works on in one trip
     uint4 qa[WU], qb[WU];
     u32 pc[WU], pr[WU];
     // (`real` = false, behind the block's last trip: the block's first entry once more, one line for the whole wave.  The loads
     // are UNCONDITIONAL: with a branch around them the compiler has to wait for the loads of the path that did not take it --
     // the set asked for ahead included, vmcnt(0) where vmcnt(3) would do)
     auto ask = [&](int u, u64 a0, bool real) __attribute__((always_inline)) {
-        const u64 a = real ? min(a0 + (u64)u * blockDim.x, n - 1) : lo;  // clamped
+        const u64 a = real ? min(a0 + (u64)u * ustride, n - 1) : lo;  // clamped
         qa[u] = wq[2 * a];
         qb[u] = wq[2 * a + 1];
         // (contig, ref_start) of the entry in front of the wave's first one
-        const u64 wf = a0 - lane + (u64)u * blockDim.x;  // (the same for the whole wave)
+        const u64 wf = a0 - lane + (u64)u * ustride;  // (the same for the whole wave)
         const u64 pf = real ? min(wf ? wf - 1 : 0, n - 1) : lo;
         pc[u] = wo[pf].contig;
         pr[u] = wo[pf].ref_start;
@@ -353,19 +358,34 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
 #ifndef PP_PREPD_ROLL
 #define PP_PREPD_ROLL 1
 #endif
+    // The waves of a workgroup take their trips from a counter in LDS (PP_PREPD_DYN, the default), not every wave the same
+    // number: with equal shares thread 0's wave was done 5 us before the workgroup's last one (of 27 us of loop: the waves'
+    // luck with the memory system), and the kernel ends with its slowest workgroup.  Unit j = the 64 WU entries from
+    // lo + 64 WU j on: a wave's entries come in ascending order, whatever units it gets (what the run tracking below counts on).
+    const u32 n_units = (u32)(span / (64u * WU));
+    auto unit_a0 = [&](u32 j) -> u64 { return lo + (u64)j * (64u * WU) + lane; };
+    u32 unit = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (the first one: the wave's own number)
     if (PP_PREPD_ROLL) {
 #pragma unroll
-        for (int u = 0; u < WU; u++) ask(u, lo + threadIdx.x, true);  // (lo < n, or the grid would be smaller)
+        for (int u = 0; u < WU; u++) ask(u, PP_PREPD_DYN ? unit_a0(unit) : lo + threadIdx.x, true);  // (lo < n, or the grid would be smaller)
     }
-    for (u64 a0 = lo + threadIdx.x; a0 < lo + span; a0 += trip) {
+    for (u64 a0 = lo + threadIdx.x; PP_PREPD_DYN ? unit < n_units : a0 < lo + span; a0 += trip) {
+        u32 unit_next = 0;
+        if (PP_PREPD_DYN) {
+            a0 = unit_a0(unit);
+            u32 t = 0;
+            if (lane == 0) t = atomicAdd(&s_unit, 1u);
+            unit_next = (u32)__builtin_amdgcn_readfirstlane((int)t);
+        }
         if (!PP_PREPD_ROLL) {
 #pragma unroll
             for (int u = 0; u < WU; u++) ask(u, a0, true);
         }
-        const bool more = a0 + trip < lo + span;  // (uniform)
+        const bool more = PP_PREPD_DYN ? unit_next < n_units : a0 + trip < lo + span;  // (uniform)
+        const u64 a0_next = PP_PREPD_DYN ? (more ? unit_a0(unit_next) : lo) : a0 + trip;
 #pragma unroll
         for (int u = 0; u < WU; u++) {
-            const u64 a = a0 + (u64)u * blockDim.x;
+            const u64 a = a0 + (u64)u * ustride;
             const bool in = a < hi;
             const u32 contig = qa[u].x, ref_start = qa[u].y, k = qa[u].z, seq_len = qa[u].w, op0 = qb[u].z, file_idx = qb[u].w;
             const u64 seq_off = (u64)qb[u].x | ((u64)qb[u].y << 32);
@@ -413,8 +433,9 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
                 if (slot < LATER_MAX) { later[2u * slot] = qa[u]; later[2u * slot + 1u] = qb[u]; }
             }
 #endif
-            if (PP_PREPD_ROLL) ask(u, a0 + trip, more);
+            if (PP_PREPD_ROLL) ask(u, a0_next, more);
         }
+        unit = unit_next;
     }
     PP_STAMP(0, 2);
     __syncthreads();
