@@ -768,7 +768,8 @@ PrepdArgs PA;
         if (nbd_threads == 1024) hipLaunchKernelGGL(k_prepd<1024>, dim3(NBD), dim3(1024), 0, st, (u64)chunk_d, PA);
         else hipLaunchKernelGGL(k_prepd<512>, dim3(NBD), dim3(512), 0, st, (u64)chunk_d, PA);
         // ... and the records it only noted (indels, long reads: a few per cent), a lane each
-        hipLaunchKernelGGL(k_prepg<256>, dim3((unsigned)std::max<uint64_t>(64, std::min<uint64_t>(16384, n / 8192 + 1))), dim3(256), 0, st, PA);
+        static const long prepg_div = getenv("PP_PREPG_DIV") && atol(getenv("PP_PREPG_DIV")) > 0 ? atol(getenv("PP_PREPG_DIV")) : 4096;  // records of the job per workgroup of k_prepg (tuning; 8192 until round 6: -1.5 us, tools/exp_prepg_sweep.sh)
+        hipLaunchKernelGGL(k_prepg<256>, dim3((unsigned)std::max<uint64_t>(64, std::min<uint64_t>(16384, n / (uint64_t)prepg_div + 1))), dim3(256), 0, st, PA);
         timer_end(ctx);
         timer_begin(ctx, "bucket");
         hipLaunchKernelGGL(k_winplan, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, n_runs, (const u32 *)ctx->b_first.p,
