@@ -48,17 +48,50 @@ __device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32
 constexpr int EMIT_PPT = PP_EMIT_PPT;
 static_assert(EMIT_PPT == 8 || EMIT_PPT == 16, "an 8- or 16-byte load of codes per thread");
 constexpr int COMPACT_THREADS = TILE / EMIT_PPT;
+// A job of up to EMIT_FUSE_MAX windows (8 Mbp) has NO scan kernel in front of the emission (round 6): a workgroup adds up the
+// output lengths of the windows in front of its own itself -- eight 16-byte loads a thread at most, asked for with everything
+// else it needs, summed through the barrier it has anyway --, the wave that writes the job's total checks it against the room.
+// k_scan over 2,442 windows was 5 us of kernel and 5 us of waiting for its launch in a 300 us job; a larger job keeps it (every
+// workgroup reading all lengths in front of it is 16 KB at 4,096 windows and grows with the square of the job).
+constexpr u32 EMIT_FUSE_MAX = 4096;
+// what this THREAD adds to sum(win_len[0 .. w)): the windows 4 t + 4 nthreads j + {0..3} below w
+template <u32 NTHREADS>
+__device__ __forceinline__ u64 prefix_part(const u32 *__restrict__ win_len, u32 w, u32 t) {
+    // (four loads in flight at a time -- 2,048 windows with 128 threads: one batch for most windows of a 5 Mbp job, a second
+    // trip for those behind; all eight at once made the kernel 112 registers a lane)
+    u64 p = 0;
+#pragma unroll 1
+    for (u32 i0 = 4u * t; i0 < w; i0 += 16u * NTHREADS) {
+        uint4 v[4];
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) {
+            const u32 i = i0 + 4u * NTHREADS * j;
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < w) v[j] = *(const uint4 *)(win_len + i);  // (the array has room for a multiple of four windows; what lies at or behind w is masked below)
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4u; j++) {
+            const u32 i = i0 + 4u * NTHREADS * j;
+            p += (u64)(i < w ? v[j].x : 0u) + (i + 1u < w ? v[j].y : 0u) + (i + 2u < w ? v[j].z : 0u) + (i + 3u < w ? v[j].w : 0u);
+        }
+    }
+    return p;
+}
+
 // What a workgroup needs before it can do anything -- the job's status, the window's two output offsets, the number of
 // multi-byte winners, the thread's codes -- is asked for AT ONCE and looked at afterwards: written as a chain of early
 // returns (status, then the offsets, then the codes) it was four memory round trips, one after the other, for a workgroup
 // that computes for a few hundred nanoseconds (k_emit 14.6 us for the 2442 windows of a 5 Mbp job, two rounds of the chip's
 // wave slots).  The empty asm keeps the compiler from moving the codes' load back down behind the returns.
+// FUSED: no scan in front -- win_len instead of win_out; cap_out: the room of `out`
+template <bool FUSED>
 __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ code, u64 G,
-                                               const u64 *__restrict__ win_out,
+                                               const u64 *__restrict__ win_out, const u32 *__restrict__ win_len, u64 cap_out,
                                                const MultiEnt *__restrict__ multi,
                                                const u32 *__restrict__ counters,
                                                u8 *__restrict__ out, const u64 *__restrict__ status) {
     __shared__ u32 wsum[COMPACT_THREADS / 64];
+    __shared__ u64 psum[COMPACT_THREADS / 64];
     const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const u64 p0 = (u64)w * TILE + (u64)EMIT_PPT * t;
     const bool whole = p0 + EMIT_PPT <= G;
@@ -67,7 +100,15 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
         if constexpr (EMIT_PPT == 16) v = *(const uint4 *)(code + p0);
         else { const uint2 h = *(const uint2 *)(code + p0); v.x = h.x; v.y = h.y; }
     }
-    const u64 st = *status, o0 = win_out[w], o1 = win_out[w + 1];
+    const u64 st = *status;
+    u64 o0 = 0, o1 = 0, part = 0;
+    if constexpr (FUSED) {
+        o1 = win_len[w];  // (its own length: all that the early return below asks about)
+        part = prefix_part<COMPACT_THREADS>(win_len, w, t);
+    } else {
+        o0 = win_out[w];
+        o1 = win_out[w + 1];
+    }
     const u32 n_multi = counters[1];
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     if ((st != ~0ull) | (o1 == o0)) return;  // the job is off / nothing to emit (a window of another rank, or all deletions)
@@ -92,9 +133,19 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
         if ((int)lane >= o) inc += v2;
     }
     if (lane == 63) wsum[wave] = inc;
+    if constexpr (FUSED) {
+        const u64 pw = wave_sum64(part);
+        if (lane == 0) psum[wave] = pw;
+    }
     __syncthreads();
     u32 base = 0;
     for (u32 i = 0; i < wave; i++) base += wsum[i];
+    if constexpr (FUSED) {
+        const u64 len_w = o1;
+        o0 = 0;
+        for (u32 i = 0; i < (u32)(COMPACT_THREADS / 64); i++) o0 += psum[i];
+        if (o0 + len_w > cap_out) return;  // (no room: the wave that writes the total raises DE_CAPACITY, the host grows the buffer and reruns)
+    }
     u64 off = o0 + base + (inc - s);
     if (all_one) {
         __builtin_memcpy(out + off, c, EMIT_PPT);  // one unaligned store
@@ -111,8 +162,10 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
 // waves [n_multi, n_multi + n_contigs]: output offset of each contig start (and the total).
 // The bytes emitted between the window's start and the position are added up by the lanes of the wave (a thread on
 // its own walked up to 2047 codes one dependent load after the other: 0.3 ms for the 100 contig starts of configs[3]).
+template <bool FUSED>
 __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, const u8 *__restrict__ code, u64 G,
                                                  const u64 *__restrict__ win_out, u32 nwin,
+                                                 const u32 *__restrict__ win_len, u64 cap_out, u64 *__restrict__ total_out, u64 *status,
                                                  const MultiEnt *__restrict__ multi,
                                                  const u32 *__restrict__ counters,
                                                  const u8 *__restrict__ seq,
@@ -121,21 +174,31 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
     const u32 n_multi = counters[1];
     const u32 lane = threadIdx.x & 63u;
     const u32 n_todo = n_multi + n_contigs + 1u;
+    // where window w's bytes begin: the scan's, or (fused form, win_len != nullptr) added up by the wave
+    auto begin_of = [&](u32 w) -> u64 {
+        if constexpr (FUSED) return wave_sum64(prefix_part<64>(win_len, w, lane)); else return win_out[w];
+    };
     for (u32 t = first_wave; t < n_todo; t += n_waves) {
         u64 gp;
         if (t < n_multi) gp = multi[t].pos; else gp = contig_off[t - n_multi];
         u64 off;
         if (gp >= G) {
-            off = win_out[nwin];
+            off = begin_of(nwin);
+            if (FUSED && t == n_todo - 1u && lane == 0) {  // the job's total (the scan's part in the fused form)
+                *total_out = off;
+                if (off > cap_out) report(status, off, DE_CAPACITY);
+            }
         } else {
             const u32 w = (u32)(gp / TILE);
             u32 part = 0;
-            if (win_out[w + 1] != win_out[w])  // (a window that emits nothing may be one nobody worked on: no codes there)
+            bool emits;
+            if constexpr (FUSED) emits = win_len[w] != 0u; else emits = win_out[w + 1] != win_out[w];
+            if (emits)  // (a window that emits nothing may be one nobody worked on: no codes there)
                 for (u64 q = (u64)w * TILE + lane; q < gp; q += 64) part += code_len(code[q], (u32)q, multi, n_multi);
-            off = win_out[w] + wave_sum(part);
+            off = begin_of(w) + wave_sum(part);
         }
         if (t < n_multi) {
-            if (lane == 0) {
+            if (lane == 0 && !(FUSED && off + multi[t].len > cap_out)) {
                 const u8 *s = seq + multi[t].off;
                 for (u32 b = 0; b < multi[t].len; b++)
                     if (s[b] != (u8)'-') out[off++] = s[b];
@@ -149,13 +212,18 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
 // One launch for both: blocks [0, nwin) compact their window, the blocks behind them finalize (the two touch different
 // bytes of the output and read the same inputs).
 // n_work = windows to compact: all of them, or (sharded job, own_win: see k_tile) the ones this context works on.
+// FUSED: the form for jobs of up to EMIT_FUSE_MAX windows -- no k_scan in front, win_len instead of win_out; cap_out / total_out /
+// status: what the scan checked and wrote.  (An instance of its own: the lengths in flight cost registers a large job's
+// hundred thousand workgroups do without.)
+template <bool FUSED>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__ code, u64 G, const u64 *__restrict__ win_out,
+                                                          const u32 *__restrict__ win_len, u64 cap_out, u64 *__restrict__ total_out,
                                                           u32 nwin, u32 n_work, const u32 *__restrict__ own_win,
                                                           const MultiEnt *__restrict__ multi,
                                                           const u32 *__restrict__ counters, const u8 *__restrict__ seq,
                                                           const u64 *__restrict__ contig_off, u32 n_contigs,
                                                           u8 *__restrict__ out, u64 *__restrict__ ctg_out,
-                                                          const u64 *__restrict__ status) {
+                                                          u64 *__restrict__ status) {
     if (blockIdx.x < n_work) {
         u32 w = blockIdx.x;
         if (own_win) {
@@ -168,12 +236,12 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__
             }
             w = first[lo] + (w - before[lo]);
         }
-        compact_window(w, code, G, win_out, multi, counters, out, status);
+        compact_window<FUSED>(w, code, G, win_out, win_len, cap_out, multi, counters, out, status);
     } else {
         if (*status != ~0ull) return;
         constexpr u32 WPB = COMPACT_THREADS / 64;
-        finalize_entries((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, multi,
-                         counters, seq, contig_off, n_contigs, out, ctg_out);
+        finalize_entries<FUSED>((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, win_len, cap_out,
+                         total_out, status, multi, counters, seq, contig_off, n_contigs, out, ctg_out);
     }
 }
 

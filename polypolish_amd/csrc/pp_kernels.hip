@@ -609,7 +609,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
         if (two_level) ENS(b_entB, ctx->cap_ent * 16);
     }
-    ENS(b_code, G); ENS(b_winlen, (uint64_t)nwin * 4); ENS(b_winout, ((uint64_t)nwin + 1) * 8);
+    ENS(b_code, G); ENS(b_winlen, ((uint64_t)nwin + 3) / 4 * 16 + 16);  /* (room for a multiple of four windows: k_emit's fused prefix reads 16 bytes at a time) */ ENS(b_winout, ((uint64_t)nwin + 1) * 8);
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
@@ -976,13 +976,18 @@ PrepdArgs PA;
     u64 *d_winout = (u64 *)ctx->b_winout.p;
     auto launch_emit = [&]() {
     timer_begin(ctx, "emit");
-    hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
-                       d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
+    // (a job of up to EMIT_FUSE_MAX windows: no scan kernel -- k_emit's workgroups add the lengths in front of their window up
+    // themselves; PP_EMIT_FUSE=0: tuning / tests)
+    static const bool env_no_fuse = getenv("PP_EMIT_FUSE") && atoi(getenv("PP_EMIT_FUSE")) == 0;
+    const bool fuse = nwin <= EMIT_FUSE_MAX && !env_no_fuse;
+    if (!fuse)
+        hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
+                           d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
     const uint64_t nfin = ctx->cap_multi + nc + 1;  // multi-byte winners + contig starts: one wave each, grid-stride
     const unsigned fin_blocks = (unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4);
-    hipLaunchKernelGGL(k_emit, dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G,
-                       (const u64 *)d_winout, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc,
-                       (u8 *)ctx->b_out.p, d_ctg_out, (const u64 *)d_status);
+    #define PP_EMIT_ARGS dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout, (const u32 *)T.win_len, (u64)ctx->cap_out, d_meta + 5, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, d_status
+    if (fuse) hipLaunchKernelGGL(k_emit<true>, PP_EMIT_ARGS); else hipLaunchKernelGGL(k_emit<false>, PP_EMIT_ARGS);
+#undef PP_EMIT_ARGS
     timer_end(ctx);
     };
     // The replays' five launches cost 23 us even when k_tile flagged nothing for them (4.5 us apiece: rocprofv3, round 5) --
