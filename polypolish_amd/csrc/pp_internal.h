@@ -182,9 +182,13 @@ struct pp_ctx {
     std::vector<uint32_t> emit;  // pp_polish_set_emit: (lo, hi) per contig, empty = everything
     std::vector<uint32_t> run_full_of;  // compact run (pp_kernels.hip, run_pipeline): the job's contig behind each contig of the run
     uint32_t run_nc = 0;                // contigs of the last run
+    uint32_t last_multi = ~0u;          // multi-byte winners of the last job (sizes k_emit's grid for the next one)
     uint32_t last_listed = ~0u;         // positions the last job listed for k_exact (sizes its grid for the next one)
     bool no_compact = false;            // this job is being rerun over the whole assembly (DE_HALO)
-    uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block
+    uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block (+ 2 words: k_emit's EmitTail)
+    pp::DevBuf b_emit_done;             // k_emit's counters of finished workgroups (EmitTail::done)
+    bool emit_done_clean = false;       // ... known to be zero
+    uint64_t emit_serial = 0;           // launches of k_emit so far (what its last workgroup writes behind the copy)
     // what k_meta_init has already set up, on the stream, for the next job (run_pipeline): valid while nothing else touched it
     struct MetaReady {
         const void *meta; uint32_t words; const void *za, *zb, *zc; uint32_t nwin; const void *tab; double fv, fi;

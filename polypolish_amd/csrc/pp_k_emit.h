@@ -185,7 +185,7 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
         if (gp >= G) {
             off = begin_of(nwin);
             if (FUSED && t == n_todo - 1u && lane == 0) {  // the job's total (the scan's part in the fused form)
-                *total_out = off;
+                __hip_atomic_store(total_out, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: emit_tail)
                 if (off > cap_out) report(status, off, DE_CAPACITY);
             }
         } else {
@@ -204,7 +204,89 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
                     if (s[b] != (u8)'-') out[off++] = s[b];
             }
         } else if (lane == 0) {
-            ctg_out[t - n_multi] = off;
+            __hip_atomic_store(&ctg_out[t - n_multi], off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: emit_tail)
+        }
+    }
+}
+
+// The job's results go to the HOST from here (round 6): the workgroup that finishes last -- a counter in the metadata block --
+// copies the block into pinned host memory, and, when the job is through, sets the block and the per-window counts up for the
+// next job of the same shape (k_meta_init's part).  Until then a step ended with a copy kernel of the runtime (8 us for 2 KB:
+// a launch and a PCIe round trip of its own) and k_meta_init (4.7 us and the host's turn-around in front of it) behind k_emit.
+// "Last" is counted in two levels -- groups of EMIT_DONE_GROUP workgroups, then the groups --, every counter in a 64-byte stretch of
+// its own: one counter for all of them made k_emit five times as long (0.017 -> 0.10 ms for 4,490 workgroups, 0.23 -> 1.6 ms
+// for 26,500: agent-scope atomics on ONE address go through at 30-55 ns apiece).  The counters reset themselves.
+constexpr u32 EMIT_DONE_GROUP = 64, EMIT_DONE_STRIDE = 8;  // (workgroups per first-level counter; u64 words between two counters)
+__host__ __device__ constexpr u64 emit_done_words(u64 blocks) { return (1ull + (blocks + EMIT_DONE_GROUP - 1) / EMIT_DONE_GROUP) * EMIT_DONE_STRIDE; }
+struct EmitTail {
+    u64 *meta;      // the job's metadata block ...
+    u32 words;
+    u32 reinit;     // 0: leave the block as it is; 1: set it up for the next job if this one is through AND flagged nothing (the host
+                    // would run the replays and the emission once more); 2: ... if this one is through
+    u64 *host;      // ... its copy in pinned host memory: words + 2 (nullptr: the host copies, nothing to do here) --
+                    // [words] = 1: the block is set up again; [words + 1] = serial, written last
+    u64 serial;
+    u64 *done;      // the counters: [0] groups that are through, [EMIT_DONE_STRIDE * (1 + g)] workgroups of group g (zero between launches)
+    u32 *zero_a, *zero_b, *zero_c, *zero_d;  // what k_meta_init zeroes per window (pairs; nullptr: nothing)
+    u32 n_zero;
+    u32 ordered;    // 1: the host polls [words + 1] instead of waiting for the kernel's end
+};
+__device__ __forceinline__ void emit_tail(const EmitTail &Z) {
+    __shared__ u32 s_last;
+    if (!Z.host) return;
+    // What k_emit writes into the block travels as agent-scope atomics (the status: atomicMin; the contig offsets and the total:
+    // write-through stores, finalize_entries), ordered against the counter by waiting for their acknowledgements -- as k_tile's
+    // heavy-window rendezvous, see there for the memory-model note.  (With a __threadfence() per workgroup -- a write-back of the
+    // XCD's L2 each -- k_emit took 0.11 ms instead of 0.02.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_emit's last-workgroup hand-over relies on gfx942/gfx950 agent-scope store/load semantics"
+#endif
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 *const mine = Z.done + (u64)EMIT_DONE_STRIDE * (1u + blockIdx.x / EMIT_DONE_GROUP);
+        const u32 in_group = min(EMIT_DONE_GROUP, gridDim.x - blockIdx.x / EMIT_DONE_GROUP * EMIT_DONE_GROUP);
+        bool last = false;
+        if (__hip_atomic_fetch_add(mine, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u64)in_group - 1ull) {
+            __hip_atomic_store(mine, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(Z.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u64)((gridDim.x + EMIT_DONE_GROUP - 1u) / EMIT_DONE_GROUP) - 1ull;
+            if (last) __hip_atomic_store(Z.done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // (one round trip: what every thread has to know, and its first word of the block)
+    const u32 i0 = threadIdx.x;
+    const u64 st = __hip_atomic_load(Z.meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 c01 = __hip_atomic_load(Z.meta + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 c23 = __hip_atomic_load(Z.meta + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v = __hip_atomic_load(Z.meta + min(i0, Z.words - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool flagged = (u32)c01 != 0u || (u32)c23 != 0u;  // (counters 0 and 2: listed for k_exact, flagged in all)
+    const bool again = st == ~0ull && (Z.reinit == 2u || (Z.reinit == 1u && !flagged));
+    __syncthreads();  // (every wave has looked at words 0-2 before their owner resets them)
+    for (u32 i = i0; i < Z.words; i += blockDim.x) {
+        if (i != i0) v = __hip_atomic_load(Z.meta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(Z.host + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (again) Z.meta[i] = i == 0 ? ~0ull : 0ull;
+    }
+    if (!Z.ordered && threadIdx.x == 0) {  // (a host that waits for the kernel's end: nothing to order)
+        __hip_atomic_store(Z.host + Z.words, again ? 1ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(Z.host + Z.words + 1, Z.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (again) {
+        if (Z.zero_a)
+            for (u32 i = threadIdx.x; i < Z.n_zero; i += blockDim.x) { Z.zero_a[i] = 0; Z.zero_b[i] = 0; }
+        if (Z.zero_c)
+            for (u32 i = threadIdx.x; i < Z.n_zero; i += blockDim.x) { Z.zero_c[i] = 0; Z.zero_d[i] = 0; }
+    }
+    if (Z.ordered) {  // a host that polls the serial: written when the copy's write-through stores are acknowledged
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(Z.host + Z.words, again ? 1ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_s_waitcnt(0);
+            __hip_atomic_store(Z.host + Z.words + 1, Z.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -223,7 +305,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__
                                                           const u32 *__restrict__ counters, const u8 *__restrict__ seq,
                                                           const u64 *__restrict__ contig_off, u32 n_contigs,
                                                           u8 *__restrict__ out, u64 *__restrict__ ctg_out,
-                                                          u64 *__restrict__ status) {
+                                                          u64 *__restrict__ status, EmitTail Z) {
     if (blockIdx.x < n_work) {
         u32 w = blockIdx.x;
         if (own_win) {
@@ -237,12 +319,12 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__
             w = first[lo] + (w - before[lo]);
         }
         compact_window<FUSED>(w, code, G, win_out, win_len, cap_out, multi, counters, out, status);
-    } else {
-        if (*status != ~0ull) return;
+    } else if (*status == ~0ull) {
         constexpr u32 WPB = COMPACT_THREADS / 64;
         finalize_entries<FUSED>((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, win_len, cap_out,
                          total_out, status, multi, counters, seq, contig_off, n_contigs, out, ctg_out);
     }
+    emit_tail(Z);
 }
 
 }  // namespace pp

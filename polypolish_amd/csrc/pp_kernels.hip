@@ -974,8 +974,47 @@ PrepdArgs PA;
     };
 
     u64 *d_winout = (u64 *)ctx->b_winout.p;
+    static const bool env_no_spec = getenv("PP_SPECULATE") && atoi(getenv("PP_SPECULATE")) == 0;  // tuning / tests (see below)
+    const bool speculate = ctx->nothing_flagged_last && !ctx->debug && !env_no_spec;
+    const bool speculate_now = speculate;
+    // The job's one read-back lands in pinned host memory -- written by k_emit's last workgroup (EmitTail, pp_k_emit.h), which also
+    // sets the metadata block up for the next job when this one is through; PP_RESULT_COPY=1 (tuning / tests): the copy on the
+    // stream and k_meta_init behind it, as until round 6.
+    if (ctx->h_meta_words < meta_words + 2) {
+        if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+        ctx->h_meta = nullptr;
+        ctx->h_meta_words = 0;
+        PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocDefault));
+        ctx->h_meta_words = meta_words + 64;
+    }
+    {   // k_emit's "who is last" counters: zero between launches (they reset themselves); zeroed here when they are new, or a launch may have been cut short
+        const size_t want = (size_t)emit_done_words((uint64_t)nwin + 2048) * 8;
+        const bool fresh = ctx->b_emit_done.cap < want;
+        if ((rc = dev_ensure(ctx, ctx->b_emit_done, want))) return rc;
+        if (fresh || !ctx->emit_done_clean) PP_HIPCHK(ctx, hipMemsetAsync(ctx->b_emit_done.p, 0, ctx->b_emit_done.cap, st));
+        ctx->emit_done_clean = false;  // (until this pass's read-back says the emission ended as it should)
+    }
+    static const bool env_result_copy = getenv("PP_RESULT_COPY") && atoi(getenv("PP_RESULT_COPY")) != 0;
+    u64 *d_hmeta = nullptr;
+    if (!env_result_copy) PP_HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_hmeta, ctx->h_meta, 0));
+    // (the last workgroup alone zeroes the per-window counts: a job of up to EMIT_FUSE_MAX windows -- a larger one keeps k_meta_init's blocks)
+    const bool tail_reinit = d_hmeta && !env_no_ahead && !ctx->debug && nwin <= EMIT_FUSE_MAX;
+    // The host watches the serial in the pinned block instead of waiting for the stream: it has the results when the last workgroup
+    // has written them, not when the kernel's end has been signalled and hipStreamSynchronize has noticed (-6 us a step;
+    // `profiles/r6zz_results_to_host_ab.txt`).  The stream is asked every few thousand looks: a launch that failed never writes the
+    // serial.  PP_SYNC=wait (tuning / tests): hipStreamSynchronize; PP_SYNC=query: hipStreamQuery in a loop.
+    static const bool env_sync_wait = getenv("PP_SYNC") && strcmp(getenv("PP_SYNC"), "poll") != 0;
+    const bool sync_by_poll = !env_sync_wait && d_hmeta;
+    uint32_t emit_round = 0;
     auto launch_emit = [&]() {
     timer_begin(ctx, "emit");
+    EmitTail Z{};
+    Z.meta = d_meta; Z.words = (u32)meta_words; Z.host = d_hmeta; Z.serial = ++ctx->emit_serial; Z.done = (u64 *)ctx->b_emit_done.p;
+    Z.reinit = !tail_reinit ? 0u : (speculate_now && emit_round == 0 ? 1u : 2u);
+    emit_round++;
+    Z.zero_a = sharded_job ? (u32 *)ctx->b_winlen.p : nullptr; Z.zero_b = sharded_job ? (u32 *)ctx->b_win_nflag.p : nullptr;
+    Z.zero_c = direct ? (u32 *)ctx->b_xcnt.p : nullptr; Z.zero_d = direct ? (u32 *)ctx->b_xcnt.p + nwin : nullptr; Z.n_zero = nwin;
+    Z.ordered = sync_by_poll ? 1u : 0u;
     // (a job of up to EMIT_FUSE_MAX windows: no scan kernel -- k_emit's workgroups add the lengths in front of their window up
     // themselves; PP_EMIT_FUSE=0: tuning / tests)
     static const bool env_no_fuse = getenv("PP_EMIT_FUSE") && atoi(getenv("PP_EMIT_FUSE")) == 0;
@@ -983,9 +1022,12 @@ PrepdArgs PA;
     if (!fuse)
         hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
                            d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
-    const uint64_t nfin = ctx->cap_multi + nc + 1;  // multi-byte winners + contig starts: one wave each, grid-stride
+    // multi-byte winners + contig starts: one wave each, grid-stride.  How many winners there are is known on the device only: as many
+    // waves as twice the job before had (a context's first job: as the room for them) -- 2,048 workgroups that found nothing to do
+    // were half of a 5 Mbp job's launch.
+    const uint64_t nfin = (ctx->last_multi == ~0u ? (uint64_t)ctx->cap_multi : std::min<uint64_t>(ctx->cap_multi, 2ull * ctx->last_multi + 64)) + nc + 1;
     const unsigned fin_blocks = (unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4);
-    #define PP_EMIT_ARGS dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout, (const u32 *)T.win_len, (u64)ctx->cap_out, d_meta + 5, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, d_status
+    #define PP_EMIT_ARGS dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout, (const u32 *)T.win_len, (u64)ctx->cap_out, d_meta + 5, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, d_status, Z
     if (fuse) hipLaunchKernelGGL(k_emit<true>, PP_EMIT_ARGS); else hipLaunchKernelGGL(k_emit<false>, PP_EMIT_ARGS);
 #undef PP_EMIT_ARGS
     timer_end(ctx);
@@ -995,43 +1037,48 @@ PrepdArgs PA;
     // job flagged when its metadata are back, and only then -- anything flagged -- runs them and the emission once more
     // (a second synchronisation: ~35 us; the polished bytes are the same either way -- a flagged position emits nothing
     // until its replay has decided it).  Not with per-position records (they are the replays' to write).
-    static const bool env_no_spec = getenv("PP_SPECULATE") && atoi(getenv("PP_SPECULATE")) == 0;  // tuning / tests
-    const bool speculate = ctx->nothing_flagged_last && !ctx->debug && !env_no_spec;
     if (!speculate) launch_exact();
     launch_emit();
     PP_HIPCHK(ctx, hipGetLastError());
 
-    // the job's one read-back, into pinned memory (a copy into pageable memory goes through the runtime's staging buffer
-    // and keeps the host waiting for longer than the GPU needs)
-    if (ctx->h_meta_words < meta_words) {
-        if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
-        ctx->h_meta = nullptr;
-        ctx->h_meta_words = 0;
-        PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocDefault));
-        ctx->h_meta_words = meta_words + 64;
-    }
-    PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
-    {
+    // the job's one read-back: k_emit's last workgroup wrote it (or, PP_RESULT_COPY=1, a copy on the stream into the pinned block:
+    // a copy into pageable memory goes through the runtime's staging buffer and keeps the host waiting for longer than the GPU needs)
+    auto read_back = [&]() -> int {
+        if (!d_hmeta) PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
         // PP_SYNC=query (tuning): poll the stream instead of waiting in hipStreamSynchronize
         static const bool sync_by_query = getenv("PP_SYNC") && !strcmp(getenv("PP_SYNC"), "query");
-        if (sync_by_query) {
+        if (sync_by_poll) {
+            for (uint32_t spins = 0;; spins++) {
+                if (__atomic_load_n(&ctx->h_meta[meta_words + 1], __ATOMIC_ACQUIRE) == ctx->emit_serial) break;
+                if ((spins & 0xFFFu) == 0xFFFu) {
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q != hipErrorNotReady) { PP_HIPCHK(ctx, q); break; }  // (done: the check below decides)
+                }
+            }
+        } else if (sync_by_query) {
             hipError_t q;
             while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
             PP_HIPCHK(ctx, q);
         } else PP_HIPCHK(ctx, hipStreamSynchronize(st));
-    }
+        if (d_hmeta && __atomic_load_n(&ctx->h_meta[meta_words + 1], __ATOMIC_ACQUIRE) != ctx->emit_serial)
+            return ctx->fail(PP_ERR_HIP, "the emission ended without its results in host memory");
+        return PP_OK;
+    };
+    if ((rc = read_back())) return rc;
+    ctx->emit_done_clean = true;
     if (speculate && ctx->h_meta[0] == ~0ull && (((const uint32_t *)&ctx->h_meta[1])[0] || ((const uint32_t *)&ctx->h_meta[1])[2])) {
         launch_exact();  // something was flagged after all
         launch_emit();
         PP_HIPCHK(ctx, hipGetLastError());
-        PP_HIPCHK(ctx, hipMemcpyAsync(ctx->h_meta, d_meta, meta_words * 8, hipMemcpyDeviceToHost, st));
-        PP_HIPCHK(ctx, hipStreamSynchronize(st));
+        if ((rc = read_back())) return rc;
     }
     meta.assign(ctx->h_meta, ctx->h_meta + meta_words);
     *n_entries_out = (uint32_t)meta[3];
     if (meta[0] == ~0ull && !env_no_ahead) {  // the job is through: the metadata block (and the per-window zeros) of the next one
-        launch_meta_init();
-        PP_HIPCHK(ctx, hipGetLastError());
+        if (!(d_hmeta && ctx->h_meta[meta_words] == 1ull)) {  // (not already done by k_emit's last workgroup)
+            launch_meta_init();
+            PP_HIPCHK(ctx, hipGetLastError());
+        }
         ctx->meta_ready = meta_key;
         ctx->meta_ready_valid = true;
     }
@@ -1151,6 +1198,7 @@ extern "C" int pp_polish_finish(pp_ctx *ctx) {
     ctx->nothing_flagged_last = cnt[0] == 0 && cnt[2] == 0;
     ctx->maxlen_hint = (uint32_t)meta[9];
     ctx->n_multi = cnt[1];
+    ctx->last_multi = cnt[1];
     ctx->n_keys = meta[8];
     // per-contig results: the run's contigs are the job's, or (compact run) the ones this context owns -- the others
     // have no bytes and no statistics here
@@ -1365,7 +1413,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_vote_tab, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_win_heavy, &ctx->b_hslab, &ctx->b_sub_bases,
                      &ctx->b_runs, &ctx->b_first, &ctx->b_xcnt, &ctx->b_xent, &ctx->b_need_win, &ctx->b_win_lo, &ctx->b_win_hi, &ctx->b_later,
-                     &ctx->b_out, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
+                     &ctx->b_out, &ctx->b_emit_done, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
                      &ctx->f_insert, &ctx->f_list, &ctx->f_blkcnt};
     for (DevBuf *b : all) dev_free(*b);

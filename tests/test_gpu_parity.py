@@ -1137,6 +1137,34 @@ def test_cli_is_a_drop_in(orc, tmp_path):
     assert r.returncode == 1 and b"file does not exist" in r.stderr
 
 
+def test_the_ways_a_job_ends_give_the_same_bytes(orc, tmp_path):
+    """How the results of a job reach the host is a tuning matter (round 6): k_emit's last workgroup writes the metadata block
+    into pinned host memory and sets it up for the next job, the host polls (default), waits for the stream (PP_SYNC=wait),
+    or the stream copies the block and k_meta_init runs behind it as before (PP_RESULT_COPY=1); the scan kernel in front of
+    the emission or not (PP_EMIT_FUSE=0); no steady-state shortcuts (PP_SPECULATE=0 PP_INIT_AHEAD=0).  The switches are read
+    once per process: through the CLI, on a job with flagged positions (a repeat: the replays and a second round of the
+    emission), stdout against the oracle's."""
+    ds = synth.rich_dataset(str(tmp_path), seed=43, contig_lens=(9000, 2500), coverage=40, repeat_len=350, repeat_copies=4)
+    exe = os.path.join(ROOT, "bin", "polypolish")
+    want = orc.polish_files(ds["fasta"], [ds["sam1"], ds["sam2"]])
+    for env in ({}, {"PP_SYNC": "wait"}, {"PP_SYNC": "query"}, {"PP_RESULT_COPY": "1"}, {"PP_EMIT_FUSE": "0"},
+                {"PP_SPECULATE": "0", "PP_INIT_AHEAD": "0"}, {"PP_RESULT_COPY": "1", "PP_EMIT_FUSE": "0", "PP_SYNC": "wait"}):
+        r = subprocess.run([exe, "polish", ds["fasta"], ds["sam1"], ds["sam2"]], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, (env, r.stderr[-300:])
+        assert r.stdout == want["fasta"], env
+
+
+def test_job_after_job_on_one_context_with_and_without_flagged_positions(ctx, orc):
+    """k_emit's last workgroup sets the metadata block up for the NEXT job only when this one is through and (first round of a
+    speculating context) flagged nothing: clean job, job with flagged positions, clean job again, twice -- every one of them
+    per position against the oracle."""
+    clean = synth.fast_records(seed=81, contig_lens=(40_000, 9_000), coverage=60, indel_read_frac=0.01)
+    shared = synth.fast_records(seed=82, contig_lens=(30_000,), coverage=80, k_choices=(1, 3), k_probs=(0.97, 0.03), indel_read_frac=0.01)
+    for _ in range(2):
+        for contig_off, bases, recs in (clean, clean, shared, clean, shared, shared, clean):
+            _compare_records(ctx, orc, contig_off, bases, recs)
+
+
 def test_configs0_shape_through_the_cli(tmp_path):
     """BASELINE.json configs[0]: one 50 kbp contig, 10,000 x 150 bp paired reads, text in / FASTA out through
     bin/polypolish -- polish (both ingests), filter and the fused command against the oracle's CLI, sha256 of every

@@ -25,6 +25,22 @@ for i in range(12):
     if i >= 4:
         for k, v in ctx.kernel_times()["ms"].items():
             acc[k] = acc.get(k, 0.0) + v / 8
-print("variant", name, "config", config, {k: round(v, 4) for k, v in acc.items()})
+wall = {}
+for prof in (2, 0):  # wall time per step as bench.py's timed steps run (events around the dominant kernel only) / without any events
+    ctx.set_profiling(prof)
+    for _ in range(3):
+        bench.run_job(ctx, pp, job)
+    best = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            bench.run_job(ctx, pp, job)
+            if prof:
+                ctx.kernel_times()
+        ctx.sync()
+        best = min(best, (time.perf_counter() - t0) / 20)
+    wall["step_ms_prof%d" % prof] = round(best * 1e3, 4)
+print("variant", name, "config", config, {k: round(v, 4) for k, v in acc.items()}, wall)
 PY
 done
