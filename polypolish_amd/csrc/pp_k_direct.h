@@ -192,6 +192,9 @@ __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdAr
         u32 nc = 1;
         u64 co = 0;
         if (multi) { nc = P.n_cig[fi]; co = P.cig_off[fi]; }
+#ifdef PP_PREP_STAMPS
+        if constexpr (RUNS_IN_REGS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(1, 5); }
+#endif
         if (nc == 0) report(P.status, fi, DE_BAD_RUN);
         else {
             const u32 *const cg = P.cigar + co;
@@ -203,6 +206,9 @@ __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdAr
                 r1 = cg[min(1u, nc - 1u)]; r2 = cg[min(2u, nc - 1u)]; r3 = cg[min(3u, nc - 1u)]; r4 = cg[min(4u, nc - 1u)];
                 r5 = cg[min(5u, nc - 1u)]; r6 = cg[min(6u, nc - 1u)]; r7 = cg[min(7u, nc - 1u)];
             }
+#ifdef PP_PREP_STAMPS
+            if constexpr (RUNS_IN_REGS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(1, 6); }
+#endif
             prep_general_t(fi, r.ref_start, sl, nc,
                            [&](u32 i) -> u32 {
                                if (!RUNS_IN_REGS) return multi ? cg[i] : r.op0;
@@ -216,6 +222,9 @@ __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdAr
         }
     }
     const u32 word = nk_out | ((u32)fl_out << 30);
+#ifdef PP_PREP_STAMPS
+    if constexpr (RUNS_IN_REGS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(1, 7); }
+#endif
     if (!word) return;
     const u32 kc = kclass_of(r.k);
     const u32 cls = word >> 30, ia = (word >> 9) & 0xFFu, idel = (word >> 17) & 1u;
@@ -468,19 +477,32 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
 }
 
 // k_prepg: the records k_prepd noted, one lane each (a few per cent of a short-read job: all of their round trips at once)
+// LDS: 13 KB a workgroup -- a stage of two extras a thread (a workgroup has a record for two of three threads and most records
+// are three pieces; what does not fit takes its slot on the spot), a contig table of PREPG_CTG_LDS entries.  With four a thread and
+// k_prepd's table of 1,024 contigs (29 KB) five workgroups fit a CU, 1,280 the chip, and the 1,628 of a 5 Mbp job started over
+// 16 us (block timeline, `profiles/r6zz_prepg_trips_and_rounds.txt`); with all of them resident at once the kernel takes the
+// same 27 us (A/B in the same file: the chains of round trips are slower the more of them run at a time) -- kept for the room it
+// leaves, not for a gain.
+#ifndef PP_PREPG_XSTAGE
+#define PP_PREPG_XSTAGE 2
+#endif
+#ifndef PP_PREPG_CTG
+#define PP_PREPG_CTG 256
+#endif
+constexpr u32 PREPG_CTG_LDS = PP_PREPG_CTG;
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_prepg(PrepdArgs P) {
-    constexpr u32 XSTAGE = 4 * THREADS;
+    constexpr u32 XSTAGE = PP_PREPG_XSTAGE * THREADS;
     __shared__ uint4 st_item[XSTAGE];
     __shared__ u32 st_key[XSTAGE], l_cnt[XLOCAL], l_base[XLOCAL], l_nb[XLOCAL], n_st;
-    __shared__ u64 s_ctg[CTG_LDS + 1];
+    __shared__ u64 s_ctg[PREPG_CTG_LDS + 1];
     PP_STAMP(1, 0);
     if (*P.status != ~0ull) return;
     const u64 total = min(*P.g_nlater, P.cap_later);
     const u64 per = (total + gridDim.x - 1) / gridDim.x;
     const u64 i0 = min(total, (u64)blockIdx.x * per), i1 = min(total, i0 + per);
     if (i0 >= i1) return;
-    const bool ctg_lds = P.n_contigs <= CTG_LDS;
+    const bool ctg_lds = P.n_contigs <= PREPG_CTG_LDS;
     // One round trip for everything that is known now: the contig table, the stretch's first entry (every thread asks for the
     // same one: the window the local counters start at), this thread's own first entry.  (Thread 0 alone looking at the first
     // entry and then at its contig's offset, and every thread asking for its entry behind the barrier, were three trips.)

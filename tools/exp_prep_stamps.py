@@ -14,9 +14,16 @@ if "--direct" in sys.argv:  # the direct path's one pass over the mirror (pp_k_d
                              "slots taken for the staged extras", "extras written (thread 0)"]),
              1: ("k_prepg", ["start", "stage cleared, first window known", "noted records done (thread 0)", "... whole block", "extras written (thread 0)"])}
 t0 = a[0][:, 0][a[0][:, 0] > 0].min()
+order = {}
+if "--direct" in sys.argv and "--prepg-trips" in sys.argv:  # k_prepg's record of thread 0, trip by trip (slots 5-7 sit between slots 1 and 2)
+    names[1] = ("k_prepg", ["start", "stage cleared, first window known", "run count / CIGAR offset / last 8 bases there", "the runs there", "runs walked, trim known",
+                            "pieces staged (thread 0's record done)", "... whole block", "extras written (thread 0)"])
+    order[1] = [0, 1, 5, 6, 7, 2, 3, 4]
 for k in sorted(names):
     nm, pts = names[k]
     b = a[k]
+    if k in order:
+        b = b[:, order[k]]
     ran = b[:, 0] > 0
     us = (b[ran][:, :len(pts)] - t0) / 100.0
     print(f"{nm}: {ran.sum()} blocks; first start {us[:, 0].min():.1f} us, last start {us[:, 0].max():.1f}, last end {us[:, len(pts) - 1].max():.1f}")
