@@ -188,6 +188,7 @@ struct pp_ctx {
     uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block (+ 2 words: k_emit's EmitTail)
     pp::DevBuf b_emit_done;             // k_emit's counters of finished workgroups (EmitTail::done)
     bool emit_done_clean = false;       // ... known to be zero
+    uint64_t *d_hmeta = nullptr;        // ... as the device sees it
     uint64_t emit_serial = 0;           // launches of k_emit so far (what its last workgroup writes behind the copy)
     // what k_meta_init has already set up, on the stream, for the next job (run_pipeline): valid while nothing else touched it
     struct MetaReady {

@@ -986,6 +986,7 @@ PrepdArgs PA;
         ctx->h_meta_words = 0;
         PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocDefault));
         ctx->h_meta_words = meta_words + 64;
+        PP_HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_hmeta, ctx->h_meta, 0));
     }
     {   // k_emit's "who is last" counters: zero between launches (they reset themselves); zeroed here when they are new, or a launch may have been cut short
         const size_t want = (size_t)emit_done_words((uint64_t)nwin + 2048) * 8;
@@ -995,8 +996,7 @@ PrepdArgs PA;
         ctx->emit_done_clean = false;  // (until this pass's read-back says the emission ended as it should)
     }
     static const bool env_result_copy = getenv("PP_RESULT_COPY") && atoi(getenv("PP_RESULT_COPY")) != 0;
-    u64 *d_hmeta = nullptr;
-    if (!env_result_copy) PP_HIPCHK(ctx, hipHostGetDevicePointer((void **)&d_hmeta, ctx->h_meta, 0));
+    u64 *const d_hmeta = env_result_copy ? nullptr : (u64 *)ctx->d_hmeta;
     // (the last workgroup alone zeroes the per-window counts: a job of up to EMIT_FUSE_MAX windows -- a larger one keeps k_meta_init's blocks)
     const bool tail_reinit = d_hmeta && !env_no_ahead && !ctx->debug && nwin <= EMIT_FUSE_MAX;
     // The host watches the serial in the pinned block instead of waiting for the stream: it has the results when the last workgroup
