@@ -234,7 +234,9 @@ int pp_polish_result_size(pp_ctx *ctx, uint64_t *total_bytes);
  * n_contigs) may be NULL. */
 int pp_polish_result(pp_ctx *ctx, uint8_t *out, int out_mem, uint64_t *contig_out_off,
                      pp_contig_stats *stats);
-/* Device pointer to the polished bytes (valid until the next pp_polish_begin). */
+/* Device pointer to the polished bytes (valid until the next pp_polish_begin); the context's stream is idle when this returns
+ * (pp_polish_finish itself may return a few microseconds before its last kernel's end has been signalled: it has the job's
+ * results from that kernel's last workgroup -- readers on other streams come through here). */
 const uint8_t *pp_polish_result_device(pp_ctx *ctx);
 
 /* Optional per-position record (what the --debug TSV is made of, src/pileup.rs:150-166):

@@ -189,6 +189,7 @@ struct pp_ctx {
     pp::DevBuf b_emit_done;             // k_emit's counters of finished workgroups (EmitTail::done)
     bool emit_done_clean = false;       // ... known to be zero
     uint64_t *d_hmeta = nullptr;        // ... as the device sees it
+    bool stream_may_be_busy = false;    // the last pp_polish_finish returned on the polled serial, not on the stream's end
     uint64_t emit_serial = 0;           // launches of k_emit so far (what its last workgroup writes behind the copy)
     // what k_meta_init has already set up, on the stream, for the next job (run_pipeline): valid while nothing else touched it
     struct MetaReady {

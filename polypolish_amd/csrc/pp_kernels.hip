@@ -1048,6 +1048,7 @@ PrepdArgs PA;
         // PP_SYNC=query (tuning): poll the stream instead of waiting in hipStreamSynchronize
         static const bool sync_by_query = getenv("PP_SYNC") && !strcmp(getenv("PP_SYNC"), "query");
         if (sync_by_poll) {
+            ctx->stream_may_be_busy = true;
             for (uint32_t spins = 0;; spins++) {
                 if (__atomic_load_n(&ctx->h_meta[meta_words + 1], __ATOMIC_ACQUIRE) == ctx->emit_serial) break;
                 if ((spins & 0xFFFu) == 0xFFFu) {
@@ -1055,7 +1056,7 @@ PrepdArgs PA;
                     if (q != hipErrorNotReady) { PP_HIPCHK(ctx, q); break; }  // (done: the check below decides)
                 }
             }
-        } else if (sync_by_query) {
+        } else if ((ctx->stream_may_be_busy = false), sync_by_query) {
             hipError_t q;
             while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
             PP_HIPCHK(ctx, q);
@@ -1253,7 +1254,14 @@ extern "C" int pp_polish_result(pp_ctx *ctx, uint8_t *out, int out_mem, uint64_t
 }
 
 extern "C" const uint8_t *pp_polish_result_device(pp_ctx *ctx) {
-    return (ctx && ctx->job_done) ? (const uint8_t *)ctx->b_out.p : nullptr;
+    if (!(ctx && ctx->job_done)) return nullptr;
+    // (pp_polish_finish returns when k_emit's last workgroup has handed the results over -- the kernel's end, with its write-back of
+    // the bytes for readers outside this stream, may be a few microseconds away: the caller reads through a stream of its own)
+    if (ctx->stream_may_be_busy) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->stream_may_be_busy = false;
+    }
+    return (const uint8_t *)ctx->b_out.p;
 }
 
 extern "C" int pp_polish_set_debug(pp_ctx *ctx, int enable) {
