@@ -186,6 +186,7 @@ struct pp_ctx {
     uint32_t last_listed = ~0u;         // positions the last job listed for k_exact (sizes its grid for the next one)
     bool no_compact = false;            // this job is being rerun over the whole assembly (DE_HALO)
     uint64_t *h_meta = nullptr;         // pinned host copy of the job's metadata block (+ 2 words: k_emit's EmitTail)
+    pp::DevBuf b_wincoarse;             // output bytes per WIN_COARSE consecutive windows (k_emit's offsets)
     pp::DevBuf b_emit_done;             // k_emit's counters of finished workgroups (EmitTail::done)
     bool emit_done_clean = false;       // ... known to be zero
     uint64_t *d_hmeta = nullptr;        // ... as the device sees it
@@ -193,9 +194,9 @@ struct pp_ctx {
     uint64_t emit_serial = 0;           // launches of k_emit so far (what its last workgroup writes behind the copy)
     // what k_meta_init has already set up, on the stream, for the next job (run_pipeline): valid while nothing else touched it
     struct MetaReady {
-        const void *meta; uint32_t words; const void *za, *zb, *zc; uint32_t nwin; const void *tab; double fv, fi;
+        const void *meta; uint32_t words; const void *za, *zb, *zc; uint32_t nwin; const void *tab; double fv, fi; const void *ze;
         bool operator==(const MetaReady &o) const {
-            return meta == o.meta && words == o.words && za == o.za && zb == o.zb && zc == o.zc && nwin == o.nwin && tab == o.tab && fv == o.fv && fi == o.fi;
+            return meta == o.meta && words == o.words && za == o.za && zb == o.zb && zc == o.zc && nwin == o.nwin && tab == o.tab && fv == o.fv && fi == o.fi && ze == o.ze;
         }
     };
     MetaReady meta_ready{};

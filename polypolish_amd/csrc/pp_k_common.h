@@ -38,11 +38,20 @@ struct MultiEnt {  // a position whose polished string has 2+ bytes (an insertio
 // computed with the very operations the vote uses on an f64 depth, so that a position whose depth is an integer -- every
 // position no shared read touches -- reads its thresholds instead of multiplying and rounding twice.
 constexpr u32 VOTE_TAB_N = 4096;
+// Output bytes are counted per window (win_len) and per WIN_COARSE consecutive windows (win_coarse, added to with atomics by whoever
+// adds to win_len): a workgroup of k_emit finds where its window's bytes begin from the coarse sums in front of its group and the
+// windows of the group in front of it -- no scan kernel, whatever the job's size (pp_k_emit.h).
+constexpr u32 WIN_COARSE = 64, WIN_COARSE2 = 64 * 64;  // (and per WIN_COARSE2 windows on top: a 250 Mbp job has 122 k windows)
+__device__ __forceinline__ void note_out_len(u32 *win_coarse, u32 *win_coarse2, u32 w, u32 len) {
+    atomicAdd(&win_coarse[w / WIN_COARSE], len);
+    atomicAdd(&win_coarse2[w / WIN_COARSE2], len);
+}
 __device__ __forceinline__ u32 d_bankers(double x);
-__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 *zero_c, u32 *zero_d, u32 n_zero, u32 *thr, double fv,
-                            double fi) {
+__global__ void k_meta_init(u64 *meta, u32 words, u32 *zero_a, u32 *zero_b, u32 *zero_c, u32 *zero_d, u32 n_zero, u32 *zero_e, u32 n_zero_e,
+                            u32 *thr, double fv, double fi) {
     if (blockIdx.x == 0) {
         for (u32 i = threadIdx.x; i < words; i += blockDim.x) meta[i] = i == 0 ? ~0ull : 0ull;
+        for (u32 i = threadIdx.x; i < n_zero_e; i += blockDim.x) zero_e[i] = 0;  // (the coarse sums of the output lengths)
         for (u32 n = threadIdx.x; n < VOTE_TAB_N; n += blockDim.x) {
             thr[2 * n] = d_bankers(__dmul_rn((double)n, fv));
             thr[2 * n + 1] = d_bankers(__dmul_rn((double)n, fi));

@@ -48,33 +48,52 @@ __device__ __forceinline__ u32 code_len(u8 c, u32 gp, const MultiEnt *multi, u32
 constexpr int EMIT_PPT = PP_EMIT_PPT;
 static_assert(EMIT_PPT == 8 || EMIT_PPT == 16, "an 8- or 16-byte load of codes per thread");
 constexpr int COMPACT_THREADS = TILE / EMIT_PPT;
-// A job of up to EMIT_FUSE_MAX windows (8 Mbp) has NO scan kernel in front of the emission (round 6): a workgroup adds up the
-// output lengths of the windows in front of its own itself -- eight 16-byte loads a thread at most, asked for with everything
-// else it needs, summed through the barrier it has anyway --, the wave that writes the job's total checks it against the room.
-// k_scan over 2,442 windows was 5 us of kernel and 5 us of waiting for its launch in a 300 us job; a larger job keeps it (every
-// workgroup reading all lengths in front of it is 16 KB at 4,096 windows and grows with the square of the job).
-constexpr u32 EMIT_FUSE_MAX = 4096;
-// what this THREAD adds to sum(win_len[0 .. w)): the windows 4 t + 4 nthreads j + {0..3} below w
+// NO scan kernel in front of the emission (round 6): a workgroup adds up the output lengths in front of its window itself, from
+// sums kept at two levels by whoever writes win_len (win_coarse: per WIN_COARSE = 64 windows, win_coarse2: per 4,096) -- a few
+// sixteen-byte loads, asked for with everything else it needs, summed through the barrier it has anyway; the wave that writes
+// the job's total checks it against the room.  k_scan over 2,442 windows was 5 us of kernel and 5 us of waiting for its launch in
+// a 300 us job, over the 122 k windows of a 250 Mbp job 80 us.  (First cut: every workgroup reading ALL lengths in front of it --
+// 16 KB at 4,096 windows, growing with the square of the job: jobs of up to EMIT_FUSE_MAX windows only.  Second: one level of
+// coarse sums -- 7.6 KB a workgroup at 122 k windows: k_emit there as slow as k_scan + k_emit had been.)
+constexpr u32 EMIT_FUSE_MAX = 4096;  // (what is left of it: up to here k_emit's last workgroup re-initialises the job's metadata alone)
+// what this THREAD adds to sum(a[0 .. n)): the elements 4 t + 4 nthreads j + {0..3} below n
 template <u32 NTHREADS>
-__device__ __forceinline__ u64 prefix_part(const u32 *__restrict__ win_len, u32 w, u32 t) {
-    // (four loads in flight at a time -- 2,048 windows with 128 threads: one batch for most windows of a 5 Mbp job, a second
-    // trip for those behind; all eight at once made the kernel 112 registers a lane)
+__device__ __forceinline__ u64 sum_part(const u32 *__restrict__ a, u32 n, u32 t) {
+    // (four loads in flight at a time; all eight at once made the kernel 112 registers a lane)
     u64 p = 0;
 #pragma unroll 1
-    for (u32 i0 = 4u * t; i0 < w; i0 += 16u * NTHREADS) {
+    for (u32 i0 = 4u * t; i0 < n; i0 += 16u * NTHREADS) {
         uint4 v[4];
 #pragma unroll
         for (u32 j = 0; j < 4u; j++) {
             const u32 i = i0 + 4u * NTHREADS * j;
             v[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < w) v[j] = *(const uint4 *)(win_len + i);  // (the array has room for a multiple of four windows; what lies at or behind w is masked below)
+            if (i < n) v[j] = *(const uint4 *)(a + i);  // (the arrays have room for a multiple of four elements; what lies at or behind n is masked below)
         }
 #pragma unroll
         for (u32 j = 0; j < 4u; j++) {
             const u32 i = i0 + 4u * NTHREADS * j;
-            p += (u64)(i < w ? v[j].x : 0u) + (i + 1u < w ? v[j].y : 0u) + (i + 2u < w ? v[j].z : 0u) + (i + 3u < w ? v[j].w : 0u);
+            p += (u64)(i < n ? v[j].x : 0u) + (i + 1u < n ? v[j].y : 0u) + (i + 2u < n ? v[j].z : 0u) + (i + 3u < n ? v[j].w : 0u);
         }
     }
+    return p;
+}
+// what this THREAD adds to sum(win_len[0 .. w)) = the second-level sums in front of the window's second-level group + the coarse
+// sums of that group in front of the window's coarse group + the windows of the coarse group in front of it: at most three
+// 16-byte loads a thread up to 262 k windows, in flight together
+template <u32 NTHREADS>
+__device__ __forceinline__ u64 prefix_part(const u32 *__restrict__ win_coarse, const u32 *__restrict__ win_coarse2,
+                                           const u32 *__restrict__ win_len, u32 w, u32 t) {
+    static_assert(WIN_COARSE == 64 && WIN_COARSE2 == 64 * WIN_COARSE && NTHREADS >= 32, "two stretches of up to 64 elements: sixteen threads each");
+    const u32 g = w / WIN_COARSE, g2 = w / WIN_COARSE2;
+    // threads 0-15: the windows [64 g, w); threads 16-31: the coarse sums [64 g2, g)
+    const bool second = t >= 16u;
+    const u32 *const a = second ? win_coarse + (u64)g2 * 64u : win_len + (u64)g * WIN_COARSE;
+    const u32 n = second ? g - g2 * 64u : w - g * WIN_COARSE, i = 4u * (t & 15u);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (t < 32u && i < n) v = *(const uint4 *)(a + i);  // (asked for in front of the loop below: in flight with its first batch)
+    u64 p = sum_part<NTHREADS>(win_coarse2, g2, t);
+    if (t < 32u) p += (u64)(i < n ? v.x : 0u) + (i + 1u < n ? v.y : 0u) + (i + 2u < n ? v.z : 0u) + (i + 3u < n ? v.w : 0u);
     return p;
 }
 
@@ -86,7 +105,7 @@ __device__ __forceinline__ u64 prefix_part(const u32 *__restrict__ win_len, u32 
 // FUSED: no scan in front -- win_len instead of win_out; cap_out: the room of `out`
 template <bool FUSED>
 __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ code, u64 G,
-                                               const u64 *__restrict__ win_out, const u32 *__restrict__ win_len, u64 cap_out,
+                                               const u64 *__restrict__ win_out, const u32 *__restrict__ win_len, const u32 *__restrict__ win_coarse, const u32 *__restrict__ win_coarse2, u64 cap_out,
                                                const MultiEnt *__restrict__ multi,
                                                const u32 *__restrict__ counters,
                                                u8 *__restrict__ out, const u64 *__restrict__ status) {
@@ -104,7 +123,7 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
     u64 o0 = 0, o1 = 0, part = 0;
     if constexpr (FUSED) {
         o1 = win_len[w];  // (its own length: all that the early return below asks about)
-        part = prefix_part<COMPACT_THREADS>(win_len, w, t);
+        part = prefix_part<COMPACT_THREADS>(win_coarse, win_coarse2, win_len, w, t);
     } else {
         o0 = win_out[w];
         o1 = win_out[w + 1];
@@ -165,7 +184,7 @@ __device__ __forceinline__ void compact_window(u32 w, const u8 *__restrict__ cod
 template <bool FUSED>
 __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, const u8 *__restrict__ code, u64 G,
                                                  const u64 *__restrict__ win_out, u32 nwin,
-                                                 const u32 *__restrict__ win_len, u64 cap_out, u64 *__restrict__ total_out, u64 *status,
+                                                 const u32 *__restrict__ win_len, const u32 *__restrict__ win_coarse, const u32 *__restrict__ win_coarse2, u64 cap_out, u64 *__restrict__ total_out, u64 *status,
                                                  const MultiEnt *__restrict__ multi,
                                                  const u32 *__restrict__ counters,
                                                  const u8 *__restrict__ seq,
@@ -176,7 +195,7 @@ __device__ __forceinline__ void finalize_entries(u32 first_wave, u32 n_waves, co
     const u32 n_todo = n_multi + n_contigs + 1u;
     // where window w's bytes begin: the scan's, or (fused form, win_len != nullptr) added up by the wave
     auto begin_of = [&](u32 w) -> u64 {
-        if constexpr (FUSED) return wave_sum64(prefix_part<64>(win_len, w, lane)); else return win_out[w];
+        if constexpr (FUSED) return wave_sum64(prefix_part<64>(win_coarse, win_coarse2, win_len, w, lane)); else return win_out[w];
     };
     for (u32 t = first_wave; t < n_todo; t += n_waves) {
         u64 gp;
@@ -229,6 +248,8 @@ struct EmitTail {
     u64 *done;      // the counters: [0] groups that are through, [EMIT_DONE_STRIDE * (1 + g)] workgroups of group g (zero between launches)
     u32 *zero_a, *zero_b, *zero_c, *zero_d;  // what k_meta_init zeroes per window (pairs; nullptr: nothing)
     u32 n_zero;
+    u32 *zero_e;    // ... and the coarse sums of the output lengths
+    u32 n_zero_e;
     u32 ordered;    // 1: the host polls [words + 1] instead of waiting for the kernel's end
 };
 __device__ __forceinline__ void emit_tail(const EmitTail &Z) {
@@ -275,6 +296,7 @@ __device__ __forceinline__ void emit_tail(const EmitTail &Z) {
         __hip_atomic_store(Z.host + Z.words + 1, Z.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (again) {
+        for (u32 i = threadIdx.x; i < Z.n_zero_e; i += blockDim.x) Z.zero_e[i] = 0;
         if (Z.zero_a)
             for (u32 i = threadIdx.x; i < Z.n_zero; i += blockDim.x) { Z.zero_a[i] = 0; Z.zero_b[i] = 0; }
         if (Z.zero_c)
@@ -299,7 +321,7 @@ __device__ __forceinline__ void emit_tail(const EmitTail &Z) {
 // hundred thousand workgroups do without.)
 template <bool FUSED>
 __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__ code, u64 G, const u64 *__restrict__ win_out,
-                                                          const u32 *__restrict__ win_len, u64 cap_out, u64 *__restrict__ total_out,
+                                                          const u32 *__restrict__ win_len, const u32 *__restrict__ win_coarse, const u32 *__restrict__ win_coarse2, u64 cap_out, u64 *__restrict__ total_out,
                                                           u32 nwin, u32 n_work, const u32 *__restrict__ own_win,
                                                           const MultiEnt *__restrict__ multi,
                                                           const u32 *__restrict__ counters, const u8 *__restrict__ seq,
@@ -318,10 +340,10 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_emit(const u8 *__restrict__
             }
             w = first[lo] + (w - before[lo]);
         }
-        compact_window<FUSED>(w, code, G, win_out, win_len, cap_out, multi, counters, out, status);
+        compact_window<FUSED>(w, code, G, win_out, win_len, win_coarse, win_coarse2, cap_out, multi, counters, out, status);
     } else if (*status == ~0ull) {
         constexpr u32 WPB = COMPACT_THREADS / 64;
-        finalize_entries<FUSED>((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, win_len, cap_out,
+        finalize_entries<FUSED>((blockIdx.x - n_work) * WPB + (threadIdx.x >> 6), (gridDim.x - n_work) * WPB, code, G, win_out, nwin, win_len, win_coarse, win_coarse2, cap_out,
                          total_out, status, multi, counters, seq, contig_off, n_contigs, out, ctg_out);
     }
     emit_tail(Z);

@@ -89,7 +89,7 @@ struct ExactArgs {
     double fv, fi;
     ulonglong2 *scratch;
     u8 *code;
-    u32 *win_len;
+    u32 *win_len, *win_coarse, *win_coarse2;
     u32 *counters;
     MultiEnt *multi;
     ContigStatsDev *stats;
@@ -370,7 +370,7 @@ __device__ void exact_block(const ExactArgs &A, u32 f, u32 cap, ulonglong2 *cov,
         A.code[gp] = v.out;
         emit = v.out ? 1u : 0u;
     }
-    if (emit) atomicAdd(&A.win_len[w], emit);
+    if (emit) { atomicAdd(&A.win_len[w], emit); note_out_len(A.win_coarse, A.win_coarse2, w, emit); }
     if (v.status == PP_ST_CHANGED) atomicAdd(&A.stats[c].changed, 1ull);
     if (n == 0) atomicAdd(&A.stats[c].zero_depth, 1ull);
     atomicAdd(&A.stats[c].depth_fx, (u64)llrint(depth * (double)(1u << DEPTH_FX_BITS)));
@@ -535,7 +535,7 @@ __device__ void exact_one(const ExactArgs &A, u32 f) {
         A.code[gp] = v.out;
         emit = v.out ? 1u : 0u;
     }
-    if (emit) atomicAdd(&A.win_len[w], emit);
+    if (emit) { atomicAdd(&A.win_len[w], emit); note_out_len(A.win_coarse, A.win_coarse2, w, emit); }
     const u32 c = find_contig(A.contig_off, A.n_contigs, gp);
     if (v.status == PP_ST_CHANGED) atomicAdd(&A.stats[c].changed, 1ull);
     if (n == 0) atomicAdd(&A.stats[c].zero_depth, 1ull);
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(1024, (SUB == 1 && SMAX <= SORT_SMALL) ? 8 : 4) voi
     }
     __syncthreads();
     if (tid == 0) {
-        if (pk[0]) atomicAdd(&A.win_len[w], (u32)pk[0]);
+        if (pk[0]) { atomicAdd(&A.win_len[w], (u32)pk[0]); note_out_len(A.win_coarse, A.win_coarse2, w, (u32)pk[0]); }
         if (pk[1]) atomicAdd(&A.stats[c_first].changed, pk[1]);
         if (pk[2]) atomicAdd(&A.stats[c_first].zero_depth, pk[2]);
         if (pk[3]) atomicAdd(&A.stats[c_first].depth_fx, pk[3]);

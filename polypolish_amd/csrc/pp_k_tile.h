@@ -26,6 +26,7 @@ struct TileArgs {
     double fv, fi;
     u8 *code;
     u32 *win_len;
+    u32 *win_coarse, *win_coarse2;  // output bytes per WIN_COARSE / WIN_COARSE2 consecutive windows (k_emit's offsets: pp_k_emit.h)
     u32 *counters;  // [0] positions on the global replay list, [1] n_multi, [2] all flagged positions
     u32 cap_flag;
     const u32 *vote_tab;  // (valid, invalid) thresholds per integer depth below VOTE_TAB_N (k_meta_init)
@@ -2153,6 +2154,7 @@ __device__ __forceinline__ void tile_window(const TileArgs &A) {
         A.win_nflag[w] = s_nflag;
         if (s_nflag) atomicAdd(&A.counters[2], s_nflag);
         A.win_len[w] = s_len;
+        if (s_len) note_out_len(A.win_coarse, A.win_coarse2, w, s_len);
         if (s_changed) atomicAdd(&A.stats[s_c0].changed, (u64)s_changed);
         if (s_zero) atomicAdd(&A.stats[s_c0].zero_depth, (u64)s_zero);
         if (s_depth) atomicAdd(&A.stats[s_c0].depth_fx, s_depth);

@@ -566,6 +566,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     } else {
         ctx->cap_ent = std::max<size_t>(ctx->cap_ent, (size_t)(n + n / 4 + 4096));
     }
+    const uint64_t coarse1_words = ((uint64_t)nwin / WIN_COARSE + 1 + 3) / 4 * 4 + 4, coarse2_words = ((uint64_t)nwin / WIN_COARSE2 + 1 + 3) / 4 * 4 + 4;
 #define ENS(buf, bytes) if ((rc = dev_ensure(ctx, ctx->buf, (size_t)(bytes)))) return rc
     // metadata block (u64 words): 0 status | 1-2 counters | 3 work items | 4 scratch elements (10: the same, counted
     // as the positions are listed) |
@@ -609,7 +610,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         ENS(b_ccnt, (uint64_t)ncoarse * 4); ENS(b_coff, ((uint64_t)ncoarse + 1) * 4);
         if (two_level) ENS(b_entB, ctx->cap_ent * 16);
     }
-    ENS(b_code, G); ENS(b_winlen, ((uint64_t)nwin + 3) / 4 * 16 + 16);  /* (room for a multiple of four windows: k_emit's fused prefix reads 16 bytes at a time) */ ENS(b_winout, ((uint64_t)nwin + 1) * 8);
+    ENS(b_code, G); ENS(b_winlen, ((uint64_t)nwin + 3) / 4 * 16 + 16);  /* (room for a multiple of four windows: k_emit's fused prefix reads 16 bytes at a time) */ ENS(b_winout, ((uint64_t)nwin + 1) * 8); ENS(b_wincoarse, (coarse1_words + coarse2_words) * 4);  /* sums of win_len per 64 and per 4,096 windows, each padded for 16-byte loads */
     ENS(b_entA, ctx->cap_ent * 16);
     ENS(b_flag_pos, ctx->cap_flag * 4); ENS(b_flag_cov, ctx->cap_flag * 4); ENS(b_flag_scr, (ctx->cap_flag + 1) * 8);
     ENS(b_flag_bits, (uint64_t)nwin * (TILE / 8)); ENS(b_win_nflag, (uint64_t)nwin * 4);
@@ -631,12 +632,13 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     // run while the host is busy with the results of the job before.
     const bool sharded_job = !ctx->emit.empty();
     const pp_ctx::MetaReady meta_key{d_meta, (u32)meta_words, sharded_job ? ctx->b_winlen.p : nullptr, sharded_job ? ctx->b_win_nflag.p : nullptr,
-                                     direct ? ctx->b_xcnt.p : nullptr, nwin, ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid};
+                                     direct ? ctx->b_xcnt.p : nullptr, nwin, ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid, ctx->b_wincoarse.p};
+    const u32 n_coarse = (u32)(coarse1_words + coarse2_words);  // the sums of the windows' output lengths (k_emit's offsets), both levels
     auto launch_meta_init = [&]() {
         hipLaunchKernelGGL(k_meta_init, dim3(sharded_job || direct ? 1u + (nwin + 4095u) / 4096u : 1u), dim3(256), 0, st, d_meta, (u32)meta_words,
                            sharded_job ? (u32 *)ctx->b_winlen.p : (u32 *)nullptr, sharded_job ? (u32 *)ctx->b_win_nflag.p : (u32 *)nullptr,
                            direct ? (u32 *)ctx->b_xcnt.p : (u32 *)nullptr, direct ? (u32 *)ctx->b_xcnt.p + nwin : (u32 *)nullptr, nwin,
-                           (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
+                           (u32 *)ctx->b_wincoarse.p, n_coarse, (u32 *)ctx->b_vote_tab.p, ctx->params.fraction_valid, ctx->params.fraction_invalid);
     };
     static const bool env_no_ahead = getenv("PP_INIT_AHEAD") && atoi(getenv("PP_INIT_AHEAD")) == 0;  // tuning / tests
     if (!(ctx->meta_ready_valid && ctx->meta_ready == meta_key)) launch_meta_init();
@@ -856,7 +858,7 @@ PrepdArgs PA;
     T.n_cig = B.n_cig; T.cigar = B.cigar; T.kk = B.k;
     T.bases = d_bases; T.G = G; T.contig_off = d_ctg; T.n_contigs = nc;
     T.min_depth = ctx->params.min_depth; T.fv = ctx->params.fraction_valid; T.fi = ctx->params.fraction_invalid;
-    T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p;
+    T.code = (u8 *)ctx->b_code.p; T.win_len = (u32 *)ctx->b_winlen.p; T.win_coarse = (u32 *)ctx->b_wincoarse.p; T.win_coarse2 = T.win_coarse + coarse1_words;
     T.counters = d_counters; T.cap_flag = (u32)ctx->cap_flag;
     T.vote_tab = (const u32 *)ctx->b_vote_tab.p;
     T.multi = (MultiEnt *)ctx->b_multi.p; T.cap_multi = (u32)ctx->cap_multi;
@@ -945,7 +947,7 @@ PrepdArgs PA;
     E.cig_off = (const u64 *)B.cig_off; E.n_cig = B.n_cig; E.cigar = B.cigar; E.kk = B.k;
     E.bases = d_bases; E.G = G; E.contig_off = d_ctg; E.n_contigs = nc; E.seq_bytes = B.seq_bytes;
     E.min_depth = T.min_depth; E.fv = T.fv; E.fi = T.fi;
-    E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len;
+    E.scratch = (ulonglong2 *)ctx->b_scratch.p; E.code = T.code; E.win_len = T.win_len; E.win_coarse = T.win_coarse; E.win_coarse2 = T.win_coarse2;
     E.counters = d_counters; E.multi = (MultiEnt *)ctx->b_multi.p; E.stats = d_stats;
     E.dbg_depth = T.dbg_depth; E.dbg_counts = T.dbg_counts; E.dbg_status = T.dbg_status;
     E.status = d_status; E.dbg = T.dbg;
@@ -1013,12 +1015,12 @@ PrepdArgs PA;
     Z.reinit = !tail_reinit ? 0u : (speculate_now && emit_round == 0 ? 1u : 2u);
     emit_round++;
     Z.zero_a = sharded_job ? (u32 *)ctx->b_winlen.p : nullptr; Z.zero_b = sharded_job ? (u32 *)ctx->b_win_nflag.p : nullptr;
-    Z.zero_c = direct ? (u32 *)ctx->b_xcnt.p : nullptr; Z.zero_d = direct ? (u32 *)ctx->b_xcnt.p + nwin : nullptr; Z.n_zero = nwin;
+    Z.zero_c = direct ? (u32 *)ctx->b_xcnt.p : nullptr; Z.zero_d = direct ? (u32 *)ctx->b_xcnt.p + nwin : nullptr; Z.n_zero = nwin; Z.zero_e = T.win_coarse; Z.n_zero_e = n_coarse;
     Z.ordered = sync_by_poll ? 1u : 0u;
-    // (a job of up to EMIT_FUSE_MAX windows: no scan kernel -- k_emit's workgroups add the lengths in front of their window up
-    // themselves; PP_EMIT_FUSE=0: tuning / tests)
+    // (no scan kernel -- k_emit's workgroups add the lengths in front of their window up themselves, from the coarse sums and their
+    // group's windows; PP_EMIT_FUSE=0: tuning / tests)
     static const bool env_no_fuse = getenv("PP_EMIT_FUSE") && atoi(getenv("PP_EMIT_FUSE")) == 0;
-    const bool fuse = nwin <= EMIT_FUSE_MAX && !env_no_fuse;
+    const bool fuse = !env_no_fuse;
     if (!fuse)
         hipLaunchKernelGGL(k_scan<u64>, dim3(1), dim3(1024), 0, st, (const u32 *)T.win_len, (u64)nwin, (const u32 *)nullptr,
                            d_winout, d_meta + 5, (u64)ctx->cap_out, d_status);
@@ -1027,7 +1029,7 @@ PrepdArgs PA;
     // were half of a 5 Mbp job's launch.
     const uint64_t nfin = (ctx->last_multi == ~0u ? (uint64_t)ctx->cap_multi : std::min<uint64_t>(ctx->cap_multi, 2ull * ctx->last_multi + 64)) + nc + 1;
     const unsigned fin_blocks = (unsigned)std::min<uint64_t>(2048, (nfin + 3) / 4);
-    #define PP_EMIT_ARGS dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout, (const u32 *)T.win_len, (u64)ctx->cap_out, d_meta + 5, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, d_status, Z
+    #define PP_EMIT_ARGS dim3(n_own_win + fin_blocks), dim3(COMPACT_THREADS), 0, st, (const u8 *)T.code, (u64)G, (const u64 *)d_winout, (const u32 *)T.win_len, (const u32 *)T.win_coarse, (const u32 *)T.win_coarse2, (u64)ctx->cap_out, d_meta + 5, nwin, n_own_win, d_own_win, (const MultiEnt *)ctx->b_multi.p, (const u32 *)d_counters, B.seq, d_ctg, nc, (u8 *)ctx->b_out.p, d_ctg_out, d_status, Z
     if (fuse) hipLaunchKernelGGL(k_emit<true>, PP_EMIT_ARGS); else hipLaunchKernelGGL(k_emit<false>, PP_EMIT_ARGS);
 #undef PP_EMIT_ARGS
     timer_end(ctx);
@@ -1421,7 +1423,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *ctx) {
                      &ctx->b_flag_scr, &ctx->b_scratch, &ctx->b_multi, &ctx->b_meta, &ctx->b_vote_tab, &ctx->b_flag_bits, &ctx->b_win_nflag, &ctx->b_win_slab, &ctx->b_slab_win, &ctx->b_slabs, &ctx->b_ents, &ctx->b_keys, &ctx->b_own,
                      &ctx->b_win_heavy, &ctx->b_hslab, &ctx->b_sub_bases,
                      &ctx->b_runs, &ctx->b_first, &ctx->b_xcnt, &ctx->b_xent, &ctx->b_need_win, &ctx->b_win_lo, &ctx->b_win_hi, &ctx->b_later,
-                     &ctx->b_out, &ctx->b_emit_done, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
+                     &ctx->b_out, &ctx->b_emit_done, &ctx->b_wincoarse, &ctx->b_dbg_depth, &ctx->b_dbg_counts, &ctx->b_dbg_status,
                      &ctx->f_refend[0], &ctx->f_refend[1], &ctx->f_pass[0], &ctx->f_pass[1], &ctx->f_orient, &ctx->f_poisoned,
                      &ctx->f_insert, &ctx->f_list, &ctx->f_blkcnt};
     for (DevBuf *b : all) dev_free(*b);
