@@ -986,7 +986,7 @@ PrepdArgs PA;
         if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
         ctx->h_meta = nullptr;
         ctx->h_meta_words = 0;
-        PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocDefault));
+        PP_HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_meta, (meta_words + 64) * 8, hipHostMallocCoherent));  // (fine-grained: what the kernel writes is seen while it runs -- the polling below -- whatever HIP_HOST_COHERENT says)
         ctx->h_meta_words = meta_words + 64;
         PP_HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_hmeta, ctx->h_meta, 0));
     }
