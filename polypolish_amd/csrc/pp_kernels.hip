@@ -2,9 +2,11 @@
 //
 // Two pipelines, the same results.  A batch that brings its window-order mirror AND the mirror's run table -- what the
 // library's own ingests hand over, and what pp_shard_split leaves a rank of a sharded job -- takes the DIRECT path (round 5,
-// pp_k_direct.h): k_meta_init (done ahead, at the end of the job before) -> k_prepd -> k_prepg -> k_winplan ->
-// k_tile_direct -> [k_xmat, k_exact2 x 3, k_exact: only when something was flagged for them] -> k_scan -> k_emit; no work
-// items for the bulk of the records.  Everything else takes the BUCKETING path of rounds 1-4:
+// pp_k_direct.h): [k_meta_init: only when the job before did not leave the metadata ready] -> k_prepd -> k_prepg -> k_winplan ->
+// k_tile_direct -> [k_xmat, k_exact2 x 3, k_exact: only when something was flagged for them] -> k_emit (no scan in front: output
+// offsets from coarse sums of the windows' lengths; its last workgroup hands the job's metadata to the host and sets them up for
+// the next job, pp_k_emit.h): five launches in the steady state, no work items for the bulk of the records.  Everything else takes
+// the BUCKETING path of rounds 1-4:
 // Pipeline (one pp_polish_finish, 13 stream operations):
 //   k_meta_init  the job's metadata block (status, counters, heavy-window list)
 //   k_prep     persistent blocks stream the alignment records: the bulk (one short M run inside its contig) on the
@@ -27,7 +29,7 @@
 //              shares) are replayed exactly: the window's items sorted by file order, one sequential f64 pass
 //   k_exact    the positions whose string-keyed counts (insertions, N...) could reach a threshold: one workgroup per
 //              position scans the window's items, its first wave sorts the covering alignments, tallies and groups keys
-//   k_scan / k_emit  drop '-' (polish.rs:188), prefix-sum emit lengths, write polished bytes, contig offsets
+//   k_emit     drop '-' (polish.rs:188), prefix sums of the emit lengths (in-kernel; PP_EMIT_FUSE=0: k_scan), polished bytes, contig offsets
 //
 // Integer counting, HBM/LDS bound: no MFMA anywhere by design.
 #include "pp_internal.h"
