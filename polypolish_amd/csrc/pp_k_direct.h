@@ -250,6 +250,17 @@ __device__ __forceinline__ void general_record(const pp_wo_rec &r, const PrepdAr
 }
 
 constexpr u32 NOIDX = 0xFFFFFFFFu;
+// PP_PREPD_TAIL (the default since the end of round 6): k_prepd works its noted records off ITSELF, one lane each out of the list in
+// LDS, behind its loop -- no list in memory, no k_prepg.  Round 5 had moved them out ("their chain of round trips kept the chip from
+// streaming"): then a workgroup in its chain held a slot that a waiting workgroup would have streamed in.  With 1.5 rounds of
+// workgroups or more (768 for the 5 Mbp job, 8,700 entries each) the chains of one round run under the streaming of the next, and
+// a latency-bound kernel of 27 us (k_prepg: 130 k records, a chain of five round trips each) is gone: prep 0.072 -> 0.069 on
+// configs[1], 0.30 -> 0.26 on configs[3], 0.74 -> 0.62-0.68 on configs[4] (`profiles/r6zz_prepd_tail_ab.txt`).  With ONE round
+// (512 workgroups) it loses (0.079), and the 512-thread instance is erratic (0.066-0.15 from one workgroup count to the next).
+// -DPP_PREPD_TAIL=0: the two kernels.
+#ifndef PP_PREPD_TAIL
+#define PP_PREPD_TAIL 1
+#endif
 
 // k_prepd: the streaming pass.  The records that are not bulk are only NOTED -- first in LDS, then, one stretch per
 // workgroup, in a list in memory that k_prepg works off with a lane per record: here, between the loop and the end of a
@@ -452,12 +463,26 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
     // the noted records: a stretch of the list in memory -- or, when there are more of them than either list holds, worked
     // off here, from the block's entries once more (then the stretch, as far as it lies inside the list, is marked empty)
     const u32 n_noted = n_later;
+#if PP_PREPD_TAIL
+    // the noted records worked off here, one lane each out of the list in LDS (see PP_PREPD_TAIL above)
+    const bool listed = n_noted <= LATER_MAX;
+    if (listed) {
+        for (u32 i = threadIdx.x; i < n_noted; i += blockDim.x) {
+            const uint4 qa = later[2u * i], qb = later[2u * i + 1u];
+            pp_wo_rec r;
+            r.contig = qa.x; r.ref_start = qa.y; r.k = qa.z; r.seq_len = qa.w;
+            r.seq_off = (u64)qb.x | ((u64)qb.y << 32); r.op0 = qb.z; r.file_idx = qb.w;
+            general_record(r, P, ctg, X);
+        }
+    }
+#else
     if (threadIdx.x == 0) s_later_at = n_noted ? (u32)min(atomicAdd(P.g_nlater, (u64)n_noted), (u64)NOIDX) : 0u;
     __syncthreads();
     const u64 at = s_later_at;
     const bool listed = n_noted <= LATER_MAX && at + n_noted <= P.cap_later;
     for (u32 i = threadIdx.x; i < 2u * n_noted; i += blockDim.x)
         if (at + (i >> 1) < P.cap_later) P.g_later[2ull * at + i] = listed ? later[i] : make_uint4(NOIDX, NOIDX, NOIDX, NOIDX);
+#endif
     if (!listed && n_noted) {
         for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
             const pp_wo_rec r = wo[a];

@@ -758,7 +758,10 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
         static const long nbd_threads = getenv("PP_PREPD_THREADS") ? atol(getenv("PP_PREPD_THREADS")) : 1024;
         // (one resident wave of workgroups for the 5 Mbp job -- 13,000 entries each: a workgroup's list of noted entries holds
         // 768 of them, 6 % -- and as many more of that size as a larger job needs)
-        const uint32_t NBD = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(forced_nbd > 0 ? (uint64_t)forced_nbd : std::max<uint64_t>(512, n / 13000), (n + 2047) / 2048));
+        // (PP_PREPD_TAIL, the noted records inside k_prepd: a round and a half of workgroups at least -- the chains of round trips of
+        // one round under the streaming of the next --, 8,700 entries each: `profiles/r6zz_prepd_tail_ab.txt`)
+        const uint64_t nbd_default = PP_PREPD_TAIL ? std::max<uint64_t>(768, n / 8700) : std::max<uint64_t>(512, n / 13000);
+        const uint32_t NBD = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(forced_nbd > 0 ? (uint64_t)forced_nbd : nbd_default, (n + 2047) / 2048));
         const uint64_t chunk_d = (n + NBD - 1) / NBD;
         timer_begin(ctx, "prep");
 PrepdArgs PA;
@@ -773,7 +776,7 @@ PrepdArgs PA;
         else hipLaunchKernelGGL(k_prepd<512>, dim3(NBD), dim3(512), 0, st, (u64)chunk_d, PA);
         // ... and the records it only noted (indels, long reads: a few per cent), a lane each
         static const long prepg_div = getenv("PP_PREPG_DIV") && atol(getenv("PP_PREPG_DIV")) > 0 ? atol(getenv("PP_PREPG_DIV")) : 4096;  // records of the job per workgroup of k_prepg (tuning; 8192 until round 6: -1.5 us, tools/exp_prepg_sweep.sh)
-        hipLaunchKernelGGL(k_prepg<256>, dim3((unsigned)std::max<uint64_t>(64, std::min<uint64_t>(16384, n / (uint64_t)prepg_div + 1))), dim3(256), 0, st, PA);
+        if (!PP_PREPD_TAIL) hipLaunchKernelGGL(k_prepg<256>, dim3((unsigned)std::max<uint64_t>(64, std::min<uint64_t>(16384, n / (uint64_t)prepg_div + 1))), dim3(256), 0, st, PA);
         timer_end(ctx);
         timer_begin(ctx, "bucket");
         hipLaunchKernelGGL(k_winplan, dim3((nwin + 255) / 256), dim3(256), 0, st, nwin, n_runs, (const u32 *)ctx->b_first.p,
