@@ -856,7 +856,7 @@ def main():
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "hbm_actual": moved(traffic, dom_avg_ms),
                      "kernel": dom_kernel or "?", "kernel_ms": round(dom_avg_ms, 4), "algorithmic_bytes": b_alg,
-                     "path": ("direct: k_prepd + k_prepg (one pass over the window-order mirror: validation, where the windows begin, extras) -> "
+                     "path": ("direct: k_prepd (one pass over the window-order mirror: validation, where the windows begin, extras; the records that are not bulk behind its loop) -> k_winplan -> "
                               "k_tile_direct (a window's bulk straight from the mirror) -- no bucketing pass, no work items for 93 % of the records"
                               if direct_path else "bucketing: k_prep -> k_scan_cols / k_scan / k_fill (16-byte work items) -> k_tile"),
                      "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / peak, 4) if world == 1 else None},

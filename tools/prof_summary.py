@@ -52,7 +52,8 @@ def traffic_json(out_path, bench_dirs, calib_dirs):
            "calibration": {"kernel": ck, "copied_bytes": n, "fetch_raw_bytes": round(f_raw), "write_raw_bytes": round(w_raw),
                            "fetch_measured_factor": round(n / f_raw, 3) if f_raw else None},
            "kernels": kernels,
-           "pipeline_hbm_bytes": sum(v["hbm_bytes"] for v in kernels.values())}
+           # (a step's kernels: k_check_wo belongs to the bench's foreign-mirror leg, one launch that reads 7 GB)
+           "pipeline_hbm_bytes": sum(v["hbm_bytes"] for k, v in kernels.items() if not k.startswith("k_check_wo"))}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
 
