@@ -585,7 +585,7 @@ static int run_pipeline(pp_ctx *ctx, std::vector<uint64_t> &meta, uint32_t *n_en
     if (direct) {
         ENS(b_first, (uint64_t)n_runs * (nwin + 1) * 4); ENS(b_xcnt, (uint64_t)nwin * 8);  /* extras per window | entries that are not bulk per window */ if (dev_ensure(ctx, ctx->b_xent, (size_t)((uint64_t)nwin * ctx->xcap * 16))) { (void)hipGetLastError(); ctx->no_direct = true; return run_pipeline(ctx, meta, n_entries_out); }  /* (no room for the windows' extras: the bucketing path) */
         ENS(b_need_win, (uint64_t)nwin * 4); ENS(b_win_lo, (uint64_t)nwin * 4); ENS(b_win_hi, (uint64_t)nwin * 4);
-        ENS(b_later, cap_later * 32);
+        ENS(b_later, PP_PREPD_TAIL ? 64 : cap_later * 32);  /* (the list of noted records in memory: the two-kernel build only) */
         std::vector<uint32_t> ends(ctx->wo_runs.begin(), ctx->wo_runs.end());
         if (!(ends == ctx->runs_on_dev && ctx->b_runs.p)) {  // (the same table as the job before: already there)
             const void *dummy;
