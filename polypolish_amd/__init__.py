@@ -819,6 +819,17 @@ class Context:
         lib().pp_polish_kernel_times(self._h, C.byref(kt))
         return kt.as_dict()
 
+    def first_kernel_ms(self):
+        """(name as bytes, milliseconds) of the first kernel group the last job timed, or None: what bench.py's timed steps read
+        after every job (profiling level 2: the dominant kernel alone) -- one C call into a structure that is kept, no dictionaries."""
+        kt = getattr(self, "_kt", None)
+        if kt is None:
+            kt = self._kt = KernelTimes()
+            self._kt_ref = C.byref(kt)
+            self._kt_fn = lib().pp_polish_kernel_times
+        self._kt_fn(self._h, self._kt_ref)
+        return (kt.name[0], kt.ms[0]) if kt.n else None
+
     def positions(self):
         G = self._G
         arrs = {"depth": np.zeros(G, np.float64), "status": np.zeros(G, np.uint8)}
