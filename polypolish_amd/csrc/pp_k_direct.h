@@ -487,7 +487,7 @@ __global__ __launch_bounds__(THREADS, PP_PREP_WAVES) void k_prepd(u64 chunk, Pre
         for (u64 a = lo + threadIdx.x; a < hi; a += blockDim.x) {
             const pp_wo_rec r = wo[a];
             const u32 cc = min(r.contig, n_contigs - 1u);
-            if (!wo_bulk(r.contig < n_contigs, r.ref_start, r.seq_len, r.op0, ctg(cc + 1u) - ctg(cc))) general_record<false>(r, P, ctg, X);
+            if (!wo_bulk(r.contig < n_contigs, r.ref_start, r.seq_len, r.op0, ctg(cc + 1u) - ctg(cc))) general_record<PP_PREPD_TAIL != 0>(r, P, ctg, X);  // (runs in registers where the tail above has them anyway: with every run read where it is needed a workgroup of a job with indels in 30 % of its reads took 0.8 ms here)
         }
     }
     PP_STAMP(0, 4);
